@@ -1,0 +1,393 @@
+"""
+``deepbinner classify`` — host side of the hot path, a drop-in for the reference's
+``deepbinner/classify.py`` (same function names, arguments, return values, stdout/stderr text and
+``sys.exit('Error: ...')`` behaviour; reference line numbers cited per function).
+
+What differs is where the arithmetic happens: the model object is a ``HipModel`` (weights resident
+in HBM behind the C ABI of ``include/deepbinner_hip.h``) and ``call_batch`` hands the whole
+per-batch job — window slicing, normalisation, the CNN, the min/max merge, renormalisation and the
+barcode call — to the GPU in one ``dbh_classify_i16`` call.  A model object that only offers
+``predict`` (seam b1) is still accepted and driven through the same windowing/merge logic on the
+host, which is how the host logic is tested without a GPU.
+"""
+
+import os
+import pathlib
+import sys
+
+import numpy as np
+
+from . import hdf5_lite
+from .load_fast5s import find_all_fast5s, get_read_id_and_signal, determine_single_or_multi_fast5s
+from .misc import print_summary_table
+from .model_format import ModelWeights
+from .trim_signal import normalise
+
+
+def build_model(weights):
+    """ModelWeights -> device-resident model.  The single place a backend is chosen; there is no
+    CPU implementation to fall back to."""
+    from .hip_backend import HipModel
+    return HipModel(weights)
+
+
+def classify(args):
+    """Reference classify.py:32-55."""
+    set_tensorflow_threads(args)
+
+    start_model, start_input_size, end_model, end_input_size, output_size, model_count = \
+        load_and_check_models(args.start_model, args.end_model, args.scan_size)
+
+    input_type = determine_input_type(args.input)
+    if input_type == 'training_data' and model_count == 2:
+        sys.exit('Error: training data can only be classified using a single model')
+    print('', file=sys.stderr)
+
+    if input_type == 'directory':
+        classify_fast5_files(find_all_fast5s(args.input, verbose=True),
+                             start_model, start_input_size, end_model, end_input_size,
+                             output_size, args)
+    elif input_type == 'single_fast5':
+        classify_fast5_files([args.input],
+                             start_model, start_input_size, end_model, end_input_size,
+                             output_size, args)
+    elif input_type == 'training_data':
+        classify_training_data(args.input, start_model, start_input_size, end_model,
+                               end_input_size, output_size, args)
+    else:
+        assert False
+
+
+def load_and_check_models(start_model_filename, end_model_filename, scan_size,
+                          out_dest=sys.stderr):
+    """Reference classify.py:58-83. Returns (start_model, start_input_size, end_model,
+    end_input_size, output_size, model_count)."""
+    start_model = start_input_size = start_output_size = None
+    end_model = end_input_size = end_output_size = None
+    if start_model_filename is not None:
+        start_model, start_input_size, start_output_size = \
+            load_trained_model(start_model_filename, out_dest=out_dest)
+        check_input_size(start_input_size, scan_size)
+    if end_model_filename is not None:
+        end_model, end_input_size, end_output_size = \
+            load_trained_model(end_model_filename, out_dest=out_dest)
+        check_input_size(end_input_size, scan_size)
+
+    model_count = (start_model is not None) + (end_model is not None)
+    if model_count == 2:
+        if start_output_size != end_output_size:
+            sys.exit('Error: two models have different number of barcode classes')
+        output_size = start_output_size
+    elif start_model is not None:
+        output_size = start_output_size
+    else:
+        output_size = end_output_size
+    return start_model, start_input_size, end_model, end_input_size, output_size, model_count
+
+
+def load_trained_model(model_file, out_dest=sys.stderr):
+    """Reference classify.py:86-103.  Accepts the reference's Keras-2.1.4 HDF5 model files and
+    this package's ``.dbw`` weight files."""
+    if not pathlib.Path(model_file).is_file():
+        sys.exit('Error: {} does not exist'.format(model_file))
+    print('Loading {}... '.format(model_file), file=out_dest, end='', flush=True)
+    bad_model = ('Error: model input has incorrect shape - are you sure that {} is a valid '
+                 'model file?'.format(model_file))
+    try:
+        weights, _ = ModelWeights.load(str(model_file))
+    except (OSError, ValueError, KeyError, IndexError):
+        sys.exit(bad_model)
+    model = build_model(weights)
+    print('done', file=out_dest)
+    try:
+        assert len(model.inputs) == 1
+        input_shape = model.inputs[0].shape
+        output_shape = model.outputs[0].shape
+        input_size = int(input_shape[1])
+        output_size = int(output_shape[1])
+        assert input_size > 10
+        assert input_shape[2] == 1
+    except (AssertionError, IndexError):
+        sys.exit(bad_model)
+    return model, input_size, output_size
+
+
+def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, end_input_size,
+                         output_size, args, full_output=True, summary_table=True,
+                         verified_single_read=False):
+    """Reference classify.py:106-180. -> (classifications, read_id_to_fast5_file)."""
+    if not fast5_files:
+        sys.exit('Error: no fast5 files found')
+    out_dest = sys.stderr if full_output else sys.stdout
+
+    if not verified_single_read:
+        if determine_single_or_multi_fast5s(fast5_files) == 'multi':
+            sys.exit('Error: deepbinner classify requires one-read-per-file fast5s - convert with '
+                     'multi_to_single_fast5 before running')
+
+    using_read_starts = start_model is not None
+    using_read_ends = end_model is not None
+
+    print_classification_progress(0, len(fast5_files), 'fast5s', out_dest=out_dest)
+    if full_output:
+        print_output_header(args.verbose, using_read_starts, using_read_ends, output_size)
+
+    classifications, read_id_to_fast5_file = {}, {}
+    for fast5_batch in chunker(fast5_files, args.batch_size):
+        read_ids, signals = [], []
+        for fast5_file in fast5_batch:
+            read_id, signal = get_read_id_and_signal(fast5_file)
+            if signal is None:
+                continue
+            read_id_to_fast5_file[read_id] = fast5_file
+            read_ids.append(read_id)
+            signals.append(signal)
+
+        lines = classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
+                                    end_input_size, output_size, args, classifications)
+        if full_output:
+            for line in lines:
+                print(line)
+
+        print_classification_progress(len(classifications), len(fast5_files), 'fast5s',
+                                      out_dest=out_dest)
+
+    if full_output:
+        print('', file=sys.stderr)
+        if summary_table:
+            print_summary_table(classifications)
+    return classifications, read_id_to_fast5_file
+
+
+def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
+                        end_input_size, output_size, args, classifications):
+    """The body of the reference's per-batch loop (classify.py:141-171) for reads already in
+    memory: run the model(s), combine, record calls, and return the TSV lines."""
+    using_read_starts = start_model is not None
+    using_read_ends = end_model is not None
+    start_calls = start_probs = end_calls = end_probs = None
+    if using_read_starts:
+        start_calls, start_probs = call_batch(start_input_size, output_size, read_ids, signals,
+                                              start_model, args, 'start')
+    if using_read_ends:
+        end_calls, end_probs = call_batch(end_input_size, output_size, read_ids, signals,
+                                          end_model, args, 'end')
+    lines = []
+    for i, read_id in enumerate(read_ids):
+        if using_read_starts and using_read_ends:
+            final_barcode_call = combine_calls(start_calls[i], end_calls[i], args)
+        elif using_read_starts:
+            final_barcode_call = start_calls[i]
+        else:
+            final_barcode_call = end_calls[i]
+        classifications[read_id] = final_barcode_call
+        output = [read_id, final_barcode_call]
+        if args.verbose:
+            if using_read_starts:
+                output += ['%.2f' % x for x in start_probs[i]]
+                if using_read_ends:
+                    output.append(start_calls[i])
+            if using_read_ends:
+                output += ['%.2f' % x for x in end_probs[i]]
+                if using_read_starts:
+                    output.append(end_calls[i])
+        lines.append('\t'.join(output))
+    return lines
+
+
+def classify_training_data(input_file, start_model, start_input_size, end_model, end_input_size,
+                           output_size, args):
+    """Reference classify.py:183-239: ``label<TAB>v1,v2,...`` lines, one model only."""
+    using_read_starts = start_model is not None
+    using_read_ends = end_model is not None
+
+    with open(input_file) as f:
+        num_lines = sum(1 for _ in f)
+    print_classification_progress(0, num_lines, 'training data')
+    print_output_header(args.verbose, using_read_starts, using_read_ends, output_size)
+
+    assert not (using_read_starts and using_read_ends)
+    model, input_size = ((start_model, start_input_size) if using_read_starts
+                         else (end_model, end_input_size))
+
+    classifications = {}
+    with open(input_file, 'rt') as training_data:
+        line_num = 0
+        finished = False
+        while not finished:
+            read_ids, signals = [], []
+            while len(read_ids) < args.batch_size:
+                line = training_data.readline()
+                if not line:
+                    finished = True
+                    break
+                line_num += 1
+                barcode, signal = line.rstrip().split('\t')
+                read_ids.append('line_{}_barcode_{}'.format(line_num, barcode))
+                signals.append(np.array([int(x) for x in signal.split(',')]))
+
+            # the reference always passes 'start' here (classify.py:223-224)
+            calls, probs = call_batch(input_size, output_size, read_ids, signals, model, args,
+                                      'start')
+            for i, read_id in enumerate(read_ids):
+                classifications[read_id] = calls[i]
+                output = [read_id, calls[i]]
+                if args.verbose:
+                    output += ['%.2f' % x for x in probs[i]]
+                print('\t'.join(output))
+            print_classification_progress(len(classifications), num_lines, 'training data')
+
+    print('', file=sys.stderr)
+    print_summary_table(classifications)
+
+
+def determine_input_type(input_file_or_dir):
+    """Reference classify.py:242-263."""
+    path = pathlib.Path(input_file_or_dir)
+    if path.is_dir():
+        return 'directory'
+    if not path.is_file():
+        sys.exit('Error: {} is neither a file nor a directory'.format(input_file_or_dir))
+    try:
+        hdf5_lite.File(str(input_file_or_dir), 'r').close()
+        return 'single_fast5'
+    except OSError:
+        pass
+    try:
+        with open(input_file_or_dir) as f:
+            parts = f.readline().split('\t')
+        _ = int(parts[0])
+        signals = [int(x) for x in parts[1].split(',')]
+        assert len(signals) > 10
+        return 'training_data'
+    except (AssertionError, ValueError, IndexError, UnicodeDecodeError):
+        sys.exit('Error: could not determine input type')
+
+
+def chunker(seq, size):
+    return (seq[pos:pos + size] for pos in range(0, len(seq), size))
+
+
+def print_output_header(verbose, using_read_starts, using_read_ends, output_size):
+    """Reference classify.py:270-282."""
+    header = ['read_ID', 'barcode_call']
+    if verbose and using_read_starts and using_read_ends:
+        for side in ('start', 'end'):
+            header.append(side + '_none')
+            header += ['{}_{}'.format(side, i) for i in range(1, output_size)]
+            header.append(side + '_barcode_call')
+    elif verbose:
+        header.append('none')
+        header += [str(i) for i in range(1, output_size)]
+    print('\t'.join(header))
+
+
+def get_barcode_call_from_probabilities(probabilities, score_diff_threshold):
+    """Reference classify.py:285-295: best class 0 -> 'none'; otherwise the best barcode must
+    beat the runner-up (which may be class 0) by score_diff.  Ties go to the lower index."""
+    ranked = sorted(enumerate(probabilities), key=lambda item: item[1], reverse=True)
+    (best, best_p), (_, second_p) = ranked[0], ranked[1]
+    if best == 0:
+        return 'none'
+    return str(best) if best_p - second_p >= score_diff_threshold else 'none'
+
+
+def combine_calls(start_call, end_call, args):
+    """Reference classify.py:298-322."""
+    if start_call == end_call:
+        return start_call
+    if args.require_both:
+        return 'none'
+    if args.require_start:
+        return start_call if end_call == 'none' else 'none'
+    assert args.require_either
+    if start_call == 'none':
+        return end_call
+    return start_call if end_call == 'none' else 'none'
+
+
+def call_batch(input_size, output_size, read_ids, signals, model, args, side):
+    """Reference classify.py:325-384 -> (barcode_calls, probabilities)."""
+    assert side in ('start', 'end')
+    step_size = input_size // 2
+    steps = int(args.scan_size / step_size)
+    assert steps * step_size == args.scan_size
+
+    if not read_ids:
+        return [], []
+
+    if hasattr(model, 'classify_signals'):
+        # Seam b2: the whole of this function runs on the GPU.
+        probs, calls = model.classify_signals(signals, side, int(args.scan_size), args.score_diff)
+        barcode_calls = ['none' if c == 0 else str(int(c)) for c in calls]
+        return barcode_calls, [row for row in probs]
+
+    # Seam b1: host windowing around model.predict.
+    merged = None
+    for s in range(steps):
+        sig_start = s * step_size
+        sig_end = sig_start + input_size
+        input_signals = np.zeros([len(read_ids), input_size], dtype=float)
+        for i, signal in enumerate(signals):
+            if side == 'start':
+                window = normalise(signal[sig_start:sig_end])
+                input_signals[i, :len(window)] = window          # zero-padded on the right
+            else:
+                a = max(len(signal) - sig_end, 0)
+                b = max(len(signal) - sig_start, 0)
+                window = normalise(signal[a:b])
+                input_signals[i, input_size - len(window):] = window   # ... on the left
+        labels = model.predict(np.expand_dims(input_signals, axis=2),
+                               batch_size=args.batch_size)
+        labels = np.asarray(labels)
+        if merged is None:
+            merged = np.array(labels, copy=True)
+        else:
+            # no-barcode: minimum over the ranges; each barcode: maximum over the ranges
+            merged[:, 0] = np.minimum(merged[:, 0], labels[:, 0])
+            merged[:, 1:] = np.maximum(merged[:, 1:], labels[:, 1:])
+
+    probabilities = [make_sum_to_one(row) for row in merged]
+    barcode_calls = [get_barcode_call_from_probabilities(p, args.score_diff)
+                     for p in probabilities]
+    return barcode_calls, probabilities
+
+
+def make_sum_to_one(probabilities):
+    """Reference classify.py:387-393, in float64 (what NumPy-1.x scalar promotion gave the
+    reference): keep the no-barcode probability, rescale the rest to fill 1 - p_none."""
+    values = [float(p) for p in probabilities]
+    no_barcode_prob = values[0]
+    factor = np.float64(1.0 - no_barcode_prob) / np.float64(sum(values[1:]))
+    scaled = [p * factor for p in values]
+    scaled[0] = no_barcode_prob
+    return scaled
+
+
+def check_input_size(input_size, scan_size):
+    """Reference classify.py:396-407."""
+    step_size = input_size // 2
+    if step_size * 2 != input_size:
+        sys.exit('Error: the model input size must be even (currently {})'.format(input_size))
+    steps = int(scan_size / step_size)
+    if steps * step_size != scan_size:
+        acceptable_scan_sizes = [str(step_size * i) for i in range(2, 8)] + ['etc']
+        sys.exit('Error: --scan_size must be a multiple of half the model input size\n'
+                 'acceptable values for --scan_size are '
+                 '{}'.format(', '.join(acceptable_scan_sizes)))
+
+
+def print_classification_progress(completed, total, label, out_dest=sys.stderr):
+    percent = 100.0 * completed / total
+    print('\rClassifying {}: {} / {} ({:.1f}%)'.format(label, completed, total, percent),
+          file=out_dest, end='', flush=True)
+
+
+def set_tensorflow_threads(args):
+    """Reference classify.py:416-423 configured a TensorFlow session.  Here the only runtime
+    choice is which GPU to use: ``DEEPBINNER_DEVICE`` or, under a one-process-per-GPU launcher,
+    ``LOCAL_RANK``.  The TensorFlow thread flags are accepted and ignored."""
+    ordinal = os.environ.get('DEEPBINNER_DEVICE', os.environ.get('LOCAL_RANK'))
+    if ordinal is not None:
+        from . import hip_backend
+        hip_backend.set_device(int(ordinal))

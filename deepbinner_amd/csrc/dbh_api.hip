@@ -1,0 +1,550 @@
+// dbh_api.hip — host side of libdeepbinner_hip.so: the C ABI declared in
+// include/deepbinner_hip.h.  Packs the canonical weight blob into the kernel's fragment order,
+// owns the device buffers, launches the kernels of dbh_forward.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/deepbinner_hip.h"
+#include "dbh_forward.hip"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? DBH_ERR_OUT_OF_MEMORY : DBH_ERR_HIP;
+}
+
+#define DBH_HIP(call)                                         \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);     \
+    } while (0)
+
+// canonical (Keras) shapes of the 20 convolutions for a given class count
+struct CanonConv { int k, cin, cout; };
+void canon_convs(int n_classes, CanonConv out[dbh::kNumConvs]) {
+    for (int i = 0; i < dbh::kNumConvs; ++i) {
+        out[i].k = dbh::kConv[i].taps;
+        out[i].cin = dbh::kConv[i].cin;
+        out[i].cout = (i == dbh::kNumConvs - 1) ? n_classes : dbh::kConv[i].cout_pad;
+    }
+}
+
+int64_t canon_param_count(int n_classes) {
+    CanonConv cc[dbh::kNumConvs];
+    canon_convs(n_classes, cc);
+    int64_t n = 0;
+    for (int i = 0; i < dbh::kNumConvs; ++i) n += (int64_t)cc[i].k * cc[i].cin * cc[i].cout + cc[i].cout;
+    for (int i = 0; i < dbh::kNumBn; ++i) n += 4 * dbh::kBnChannels[i];
+    return n;
+}
+
+// canonical blob -> packed buffer (layout: dbh_layout.h)
+void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
+    using namespace dbh;
+    packed.assign(kPackedFloats, 0.f);
+    CanonConv cc[kNumConvs];
+    canon_convs(n_classes, cc);
+    const float* p = w;
+    for (int i = 0; i < kNumConvs; ++i) {
+        const int k = cc[i].k, cin = cc[i].cin, cout = cc[i].cout;
+        const float* kernel = p;                 // [k][cin][cout]
+        const float* bias = p + (size_t)k * cin * cout;
+        p = bias + cout;
+        float* dst = packed.data() + weight_offset(i);
+        if (i == 0) {
+            // conv1d_1 stays [tap][cout] for the VALU path
+            for (int tap = 0; tap < 3; ++tap)
+                for (int c = 0; c < cout; ++c) dst[tap * 48 + c] = kernel[(tap * cin) * cout + c];
+        } else {
+            const int sp_n = cin / 8, nt = kConv[i].cout_pad / 16;
+            for (int tap = 0; tap < k; ++tap)
+                for (int sp = 0; sp < sp_n; ++sp)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 2; ++e) {
+                                const int ci = 8 * sp + 2 * (lane >> 4) + e;
+                                const int co = 16 * t + (lane & 15);
+                                const float v = co < cout ? kernel[((size_t)tap * cin + ci) * cout + co] : 0.f;
+                                dst[((((size_t)tap * sp_n + sp) * nt + t) * 64 + lane) * 2 + e] = v;
+                            }
+        }
+        float* bdst = packed.data() + bias_offset(i);
+        for (int c = 0; c < cout; ++c) bdst[c] = bias[c];
+    }
+    for (int i = 0; i < kNumBn; ++i) {
+        const int c_n = kBnChannels[i];
+        const float *gamma = p, *beta = p + c_n, *mean = p + 2 * c_n, *var = p + 3 * c_n;
+        p += 4 * c_n;
+        float* sc = packed.data() + bn_scale_offset(i);
+        float* sh = packed.data() + bn_shift_offset(i);
+        for (int c = 0; c < c_n; ++c) {
+            const double scale = (double)gamma[c] / std::sqrt((double)var[c] + 1e-3);
+            sc[c] = (float)scale;
+            sh[c] = (float)((double)beta[c] - (double)mean[c] * scale);
+        }
+    }
+}
+
+}  // namespace
+
+struct dbh_model {
+    int n_classes = 0;
+    int device = 0;
+    float* d_packed = nullptr;
+    // workspace for the host-pointer entry points, grown on demand
+    void* d_in = nullptr;      size_t in_bytes = 0;
+    void* d_work = nullptr;    size_t work_bytes = 0;
+    void* d_out = nullptr;     size_t out_bytes = 0;
+    // live timing of the forward kernel (dbh_forward_timing_*)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    int64_t timed_windows = 0;
+};
+
+namespace {
+
+int ensure(void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return DBH_OK;
+    if (*ptr) {
+        DBH_HIP(hipFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    DBH_HIP(hipMalloc(ptr, need));
+    *have = need;
+    return DBH_OK;
+}
+
+int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev,
+                   int debug_stage, float* debug_dev, hipStream_t stream) {
+    if (n == 0) return DBH_OK;
+    // grid.x limit is 2^31-1 blocks; chunk anyway to keep launches bounded
+    const int64_t kChunk = 1 << 20;
+    for (int64_t off = 0; off < n; off += kChunk) {
+        const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
+        hipEvent_t ev_stop = nullptr;
+        if (m->timing && debug_stage < 0) {
+            if (m->events_used == m->events.size()) {
+                hipEvent_t a, b;
+                DBH_HIP(hipEventCreate(&a));
+                DBH_HIP(hipEventCreate(&b));
+                m->events.emplace_back(a, b);
+            }
+            DBH_HIP(hipEventRecord(m->events[m->events_used].first, stream));
+            ev_stop = m->events[m->events_used].second;
+            ++m->events_used;
+            m->timed_windows += cnt;
+        }
+        hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)cnt), dim3(dbh::kThreads), 0,
+                           stream, m->d_packed, x_dev + off * dbh::kWindow,
+                           probs_dev ? probs_dev + off * m->n_classes : nullptr, m->n_classes,
+                           debug_stage,
+                           debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 ? 0 : debug_stage]
+                                     : nullptr);
+        DBH_HIP(hipGetLastError());
+        if (ev_stop) DBH_HIP(hipEventRecord(ev_stop, stream));
+    }
+    return DBH_OK;
+}
+
+inline int steps_for(int scan_size) { return scan_size / (dbh::kWindow / 2); }
+
+}  // namespace
+
+extern "C" {
+
+const char* dbh_version(void) { return "deepbinner_hip 0.1 (gfx950)"; }
+
+const char* dbh_status_string(int status) {
+    switch (status) {
+        case DBH_OK: return "ok";
+        case DBH_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case DBH_ERR_NO_DEVICE: return "no HIP device available";
+        case DBH_ERR_HIP: return "HIP runtime error";
+        case DBH_ERR_BAD_WEIGHTS: return "weight blob does not match the Deepbinner architecture";
+        case DBH_ERR_UNSUPPORTED: return "unsupported model geometry";
+        case DBH_ERR_OUT_OF_MEMORY: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char* dbh_last_error(void) { return g_last_error.c_str(); }
+
+int dbh_device_count(int* count) {
+    if (!count) return DBH_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        hip_fail(e, "hipGetDeviceCount");
+        return DBH_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return n > 0 ? DBH_OK : DBH_ERR_NO_DEVICE;
+}
+
+int dbh_set_device(int ordinal) {
+    DBH_HIP(hipSetDevice(ordinal));
+    return DBH_OK;
+}
+
+int dbh_get_device(int* ordinal) {
+    if (!ordinal) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipGetDevice(ordinal));
+    return DBH_OK;
+}
+
+int dbh_device_name(int ordinal, char* buf, int buf_len) {
+    if (!buf || buf_len <= 0) return DBH_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    DBH_HIP(hipGetDeviceProperties(&prop, ordinal));
+    std::snprintf(buf, (size_t)buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+                  prop.multiProcessorCount);
+    return DBH_OK;
+}
+
+int dbh_device_synchronize(void) {
+    DBH_HIP(hipDeviceSynchronize());
+    return DBH_OK;
+}
+
+int dbh_malloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return DBH_OK;
+}
+int dbh_free(void* dev_ptr) {
+    if (dev_ptr) DBH_HIP(hipFree(dev_ptr));
+    return DBH_OK;
+}
+int dbh_malloc_host(void** host_ptr, size_t bytes) {
+    if (!host_ptr) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return DBH_OK;
+}
+int dbh_free_host(void* host_ptr) {
+    if (host_ptr) DBH_HIP(hipHostFree(host_ptr));
+    return DBH_OK;
+}
+int dbh_memcpy_h2d(void* dst, const void* src, size_t bytes, dbh_stream stream) {
+    DBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_memcpy_d2h(void* dst, const void* src, size_t bytes, dbh_stream stream) {
+    DBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_memcpy_d2d(void* dst, const void* src, size_t bytes, dbh_stream stream) {
+    DBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_stream_create(dbh_stream* stream) {
+    if (!stream) return DBH_ERR_INVALID_ARGUMENT;
+    hipStream_t s;
+    DBH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (dbh_stream)s;
+    return DBH_OK;
+}
+int dbh_stream_destroy(dbh_stream stream) {
+    DBH_HIP(hipStreamDestroy((hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_stream_synchronize(dbh_stream stream) {
+    DBH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_event_create(dbh_event* event) {
+    if (!event) return DBH_ERR_INVALID_ARGUMENT;
+    hipEvent_t e;
+    DBH_HIP(hipEventCreate(&e));
+    *event = (dbh_event)e;
+    return DBH_OK;
+}
+int dbh_event_destroy(dbh_event event) {
+    DBH_HIP(hipEventDestroy((hipEvent_t)event));
+    return DBH_OK;
+}
+int dbh_event_record(dbh_event event, dbh_stream stream) {
+    DBH_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return DBH_OK;
+}
+int dbh_event_synchronize(dbh_event event) {
+    DBH_HIP(hipEventSynchronize((hipEvent_t)event));
+    return DBH_OK;
+}
+int dbh_event_elapsed_ms(dbh_event start, dbh_event stop, float* ms) {
+    if (!ms) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return DBH_OK;
+}
+
+int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int input_size,
+                     dbh_model** model) {
+    if (!weights || !model) return DBH_ERR_INVALID_ARGUMENT;
+    *model = nullptr;
+    if (input_size != dbh::kWindow || n_classes < 2 || n_classes > dbh::kMaxClasses)
+        return DBH_ERR_UNSUPPORTED;
+    if (n_floats != canon_param_count(n_classes)) return DBH_ERR_BAD_WEIGHTS;
+    int count = 0;
+    int st = dbh_device_count(&count);
+    if (st != DBH_OK) return st;
+    std::vector<float> packed;
+    pack_weights(weights, n_classes, packed);
+    dbh_model* m = new (std::nothrow) dbh_model();
+    if (!m) return DBH_ERR_OUT_OF_MEMORY;
+    m->n_classes = n_classes;
+    hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(m->d_packed, packed.data(), packed.size() * sizeof(float),
+                      hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->d_packed) (void)hipFree(m->d_packed);
+        delete m;
+        return hip_fail(e, "dbh_model_create");
+    }
+    *model = m;
+    return DBH_OK;
+}
+
+int dbh_model_destroy(dbh_model* m) {
+    if (!m) return DBH_OK;
+    if (m->d_packed) (void)hipFree(m->d_packed);
+    if (m->d_in) (void)hipFree(m->d_in);
+    if (m->d_work) (void)hipFree(m->d_work);
+    if (m->d_out) (void)hipFree(m->d_out);
+    for (auto& ev : m->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    delete m;
+    return DBH_OK;
+}
+
+int dbh_model_input_size(const dbh_model* m, int* input_size) {
+    if (!m || !input_size) return DBH_ERR_INVALID_ARGUMENT;
+    *input_size = dbh::kWindow;
+    return DBH_OK;
+}
+int dbh_model_output_size(const dbh_model* m, int* n_classes) {
+    if (!m || !n_classes) return DBH_ERR_INVALID_ARGUMENT;
+    *n_classes = m->n_classes;
+    return DBH_OK;
+}
+
+int dbh_predict_dev(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev,
+                    dbh_stream stream) {
+    if (!m || n < 0 || (n > 0 && (!x_dev || !probs_dev))) return DBH_ERR_INVALID_ARGUMENT;
+    return launch_forward(m, x_dev, n, probs_dev, -1, nullptr, (hipStream_t)stream);
+}
+
+int dbh_predict(dbh_model* m, const float* x_host, int64_t n, float* probs_host) {
+    if (!m || n < 0 || (n > 0 && (!x_host || !probs_host))) return DBH_ERR_INVALID_ARGUMENT;
+    if (n == 0) return DBH_OK;
+    // bounded staging: 65,536 windows (256 MiB of fp32 input) per round trip
+    const int64_t kChunk = 65536;
+    const int64_t cap = n < kChunk ? n : kChunk;
+    int st = ensure(&m->d_in, &m->in_bytes, (size_t)cap * dbh::kWindow * sizeof(float));
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_out, &m->out_bytes, (size_t)cap * m->n_classes * sizeof(float));
+    if (st != DBH_OK) return st;
+    for (int64_t off = 0; off < n; off += kChunk) {
+        const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
+        DBH_HIP(hipMemcpyAsync(m->d_in, x_host + off * dbh::kWindow,
+                               (size_t)cnt * dbh::kWindow * sizeof(float), hipMemcpyHostToDevice, 0));
+        st = launch_forward(m, (const float*)m->d_in, cnt, (float*)m->d_out, -1, nullptr, 0);
+        if (st != DBH_OK) return st;
+        DBH_HIP(hipMemcpyAsync(probs_host + off * m->n_classes, m->d_out,
+                               (size_t)cnt * m->n_classes * sizeof(float), hipMemcpyDeviceToHost, 0));
+        DBH_HIP(hipStreamSynchronize(0));
+    }
+    return DBH_OK;
+}
+
+int dbh_normalise_windows_dev(const int16_t* samples_dev, const int64_t* offsets_dev,
+                              int64_t n_reads, int side, int scan_size, float* windows_dev,
+                              dbh_stream stream) {
+    const int steps = steps_for(scan_size);
+    if (n_reads < 0 || steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
+        (side != DBH_SIDE_START && side != DBH_SIDE_END))
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!samples_dev || !offsets_dev || !windows_dev) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t kChunkReads = (1 << 24) / steps;
+    for (int64_t r0 = 0; r0 < n_reads; r0 += kChunkReads) {
+        const int64_t cnt = (n_reads - r0 < kChunkReads) ? (n_reads - r0) : kChunkReads;
+        hipLaunchKernelGGL(dbh::dbh_normalise_kernel, dim3((unsigned)(cnt * steps)), dim3(256), 0,
+                           (hipStream_t)stream, samples_dev,
+                           (const long long*)(offsets_dev + r0), steps, side,
+                           windows_dev + r0 * steps * dbh::kWindow);
+        DBH_HIP(hipGetLastError());
+    }
+    return DBH_OK;
+}
+
+int dbh_merge_calls_dev(const float* window_probs_dev, int64_t n_reads, int steps, int n_classes,
+                        double score_diff, float* probs_dev, int32_t* calls_dev,
+                        dbh_stream stream) {
+    if (n_reads < 0 || steps <= 0 || n_classes < 2 || n_classes > dbh::kMaxClasses)
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!window_probs_dev || !probs_dev || !calls_dev) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_reads + 7) / 8;
+    hipLaunchKernelGGL(dbh::dbh_merge_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, window_probs_dev, (long long)n_reads, steps,
+                       n_classes, score_diff, probs_dev, (int*)calls_dev);
+    DBH_HIP(hipGetLastError());
+    return DBH_OK;
+}
+
+int dbh_classify_workspace_bytes(const dbh_model* m, int64_t n_reads, int scan_size,
+                                 size_t* bytes) {
+    if (!m || !bytes || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
+    const int steps = steps_for(scan_size);
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size) return DBH_ERR_INVALID_ARGUMENT;
+    const size_t windows = (size_t)n_reads * steps;
+    *bytes = windows * dbh::kWindow * sizeof(float) + windows * m->n_classes * sizeof(float) + 256;
+    return DBH_OK;
+}
+
+int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* offsets_dev,
+                         int64_t n_reads, int side, int scan_size, double score_diff,
+                         float* probs_dev, int32_t* calls_dev, void* workspace_dev,
+                         dbh_stream stream) {
+    if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!workspace_dev) return DBH_ERR_INVALID_ARGUMENT;
+    const int steps = steps_for(scan_size);
+    const size_t windows = (size_t)n_reads * steps;
+    float* x = (float*)workspace_dev;
+    float* wprobs = x + windows * dbh::kWindow;
+    int st = dbh_normalise_windows_dev(samples_dev, offsets_dev, n_reads, side, scan_size, x, stream);
+    if (st != DBH_OK) return st;
+    st = launch_forward(m, x, (int64_t)windows, wprobs, -1, nullptr, (hipStream_t)stream);
+    if (st != DBH_OK) return st;
+    return dbh_merge_calls_dev(wprobs, n_reads, steps, m->n_classes, score_diff, probs_dev,
+                               calls_dev, stream);
+}
+
+int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* offsets_host,
+                     int64_t n_reads, int side, int scan_size, double score_diff,
+                     float* probs_host, int32_t* calls_host) {
+    if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!offsets_host || !probs_host || !calls_host) return DBH_ERR_INVALID_ARGUMENT;
+    const int steps = steps_for(scan_size);
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
+        (side != DBH_SIDE_START && side != DBH_SIDE_END))
+        return DBH_ERR_INVALID_ARGUMENT;
+    // bounded device footprint: process reads in groups whose windows fit ~512 MiB of fp32
+    const int64_t group = (int64_t)(131072 / steps) > 0 ? (131072 / steps) : 1;
+    for (int64_t r0 = 0; r0 < n_reads; r0 += group) {
+        const int64_t cnt = (n_reads - r0 < group) ? (n_reads - r0) : group;
+        const int64_t s0 = offsets_host[r0], s1 = offsets_host[r0 + cnt];
+        if (s1 < s0) return DBH_ERR_INVALID_ARGUMENT;
+        const size_t sample_bytes = (size_t)(s1 - s0) * sizeof(int16_t);
+        const size_t off_bytes = (size_t)(cnt + 1) * sizeof(int64_t);
+        const size_t in_need = ((sample_bytes + 255) & ~(size_t)255) + off_bytes;
+        int st = ensure(&m->d_in, &m->in_bytes, in_need ? in_need : 256);
+        if (st != DBH_OK) return st;
+        size_t work = 0;
+        st = dbh_classify_workspace_bytes(m, cnt, scan_size, &work);
+        if (st != DBH_OK) return st;
+        st = ensure(&m->d_work, &m->work_bytes, work);
+        if (st != DBH_OK) return st;
+        const size_t out_need = (size_t)cnt * m->n_classes * sizeof(float) + (size_t)cnt * sizeof(int32_t);
+        st = ensure(&m->d_out, &m->out_bytes, out_need);
+        if (st != DBH_OK) return st;
+
+        std::vector<int64_t> rel((size_t)cnt + 1);
+        for (int64_t i = 0; i <= cnt; ++i) rel[(size_t)i] = offsets_host[r0 + i] - s0;
+        int16_t* d_samples = (int16_t*)m->d_in;
+        int64_t* d_offsets = (int64_t*)((char*)m->d_in + ((sample_bytes + 255) & ~(size_t)255));
+        if (sample_bytes)
+            DBH_HIP(hipMemcpyAsync(d_samples, samples_host + s0, sample_bytes, hipMemcpyHostToDevice, 0));
+        DBH_HIP(hipMemcpyAsync(d_offsets, rel.data(), off_bytes, hipMemcpyHostToDevice, 0));
+        float* d_probs = (float*)m->d_out;
+        int32_t* d_calls = (int32_t*)((char*)m->d_out + (size_t)cnt * m->n_classes * sizeof(float));
+        st = dbh_classify_i16_dev(m, d_samples, d_offsets, cnt, side, scan_size, score_diff, d_probs,
+                                  d_calls, m->d_work, 0);
+        if (st != DBH_OK) return st;
+        DBH_HIP(hipMemcpyAsync(probs_host + r0 * m->n_classes, d_probs,
+                               (size_t)cnt * m->n_classes * sizeof(float), hipMemcpyDeviceToHost, 0));
+        DBH_HIP(hipMemcpyAsync(calls_host + r0, d_calls, (size_t)cnt * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, 0));
+        DBH_HIP(hipStreamSynchronize(0));
+    }
+    return DBH_OK;
+}
+
+int dbh_stage_floats(int stage, int64_t* floats_per_window) {
+    if (!floats_per_window || stage < 0 || stage > 7) return DBH_ERR_INVALID_ARGUMENT;
+    *floats_per_window = dbh::kStageFloats[stage];
+    return DBH_OK;
+}
+
+int dbh_debug_forward(dbh_model* m, const float* x_host, int64_t n, int stage, float* out_host) {
+    if (!m || n <= 0 || !x_host || !out_host || stage < 0 || stage > 7)
+        return DBH_ERR_INVALID_ARGUMENT;
+    const size_t per = (size_t)dbh::kStageFloats[stage];
+    int st = ensure(&m->d_in, &m->in_bytes, (size_t)n * dbh::kWindow * sizeof(float));
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_work, &m->work_bytes, (size_t)n * per * sizeof(float));
+    if (st != DBH_OK) return st;
+    DBH_HIP(hipMemcpyAsync(m->d_in, x_host, (size_t)n * dbh::kWindow * sizeof(float),
+                           hipMemcpyHostToDevice, 0));
+    DBH_HIP(hipMemsetAsync(m->d_work, 0, (size_t)n * per * sizeof(float), 0));
+    st = launch_forward(m, (const float*)m->d_in, n, nullptr, stage, (float*)m->d_work, 0);
+    if (st != DBH_OK) return st;
+    DBH_HIP(hipMemcpyAsync(out_host, m->d_work, (size_t)n * per * sizeof(float),
+                           hipMemcpyDeviceToHost, 0));
+    DBH_HIP(hipStreamSynchronize(0));
+    return DBH_OK;
+}
+
+int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs) {
+    hipFuncAttributes attr;
+    DBH_HIP(hipFuncGetAttributes(&attr, (const void*)dbh::dbh_forward_kernel));
+    if (threads_per_block) *threads_per_block = dbh::kThreads;
+    if (lds_bytes) *lds_bytes = (int)attr.sharedSizeBytes;
+    if (vgprs) *vgprs = attr.numRegs;
+    return DBH_OK;
+}
+
+int dbh_forward_timing_enable(dbh_model* m, int enable) {
+    if (!m) return DBH_ERR_INVALID_ARGUMENT;
+    m->timing = enable != 0;
+    m->events_used = 0;
+    m->timed_windows = 0;
+    return DBH_OK;
+}
+
+int dbh_forward_timing_read(dbh_model* m, double* total_ms, int64_t* launches, int64_t* windows) {
+    if (!m || !total_ms || !launches || !windows) return DBH_ERR_INVALID_ARGUMENT;
+    double sum = 0.0;
+    for (size_t i = 0; i < m->events_used; ++i) {
+        DBH_HIP(hipEventSynchronize(m->events[i].second));
+        float ms = 0.f;
+        DBH_HIP(hipEventElapsedTime(&ms, m->events[i].first, m->events[i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)m->events_used;
+    *windows = m->timed_windows;
+    m->events_used = 0;
+    m->timed_windows = 0;
+    return DBH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,646 @@
+// dbh_forward.hip — the Deepbinner forward pass as ONE gfx950 kernel: one 512-thread workgroup
+// (8 wave64s, 2 per SIMD) carries one 1024-sample window through all 20 convolutions with the
+// activations resident in LDS the whole way; HBM sees 4 KiB in and n_classes floats out per
+// window, the 429 KB of weights stream from L2.
+//
+// What it computes: reference deepbinner/network_architecture.py:18-95 as evaluated by
+// model.predict (deepbinner/classify.py:361) — see oracle/network_ref.py for the operator
+// semantics (TensorFlow SAME padding, valid-count average pooling, BN after ReLU/pool).
+//
+// How: every convolution except conv1d_1 (C_in = 1, VALU) is a sum over taps of
+// [positions x C_in] . [C_in x C_out] products issued on the fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the vector-ALU rate, which leaves the VALU
+// free for the fused bias+ReLU(+MaxPool2)(+BatchNorm) epilogues).  M = 16 positions,
+// N = 16 output channels, K = 4 input channels per instruction.
+//   A fragments (activations): ds_read_b64 from the [position][channel] LDS image, row stride
+//     C+4 floats so the 16 rows of a tile fall on distinct bank groups;
+//   B fragments (weights): ds_read_b64 from a fragment-ordered copy staged in LDS (layers with
+//     >= 4 position tiles, where each weight is reused by every tile) or global_load_dwordx2
+//     straight from L2 (the L = 16 / 8 tail, where each weight is used once per window);
+//   accumulators stay in registers until the whole layer has been read, so layers at L = 512
+//     update the single 104 KiB activation buffer in place (barrier, write, barrier);
+//   the next layer's weights are fetched into registers while the current layer's MFMAs run
+//     and dropped into the LDS weight buffer behind the same barrier.
+#include <hip/hip_runtime.h>
+
+#include "dbh_layout.h"
+
+namespace dbh {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// acc[m][t] += sum over (tap, sp, e) of A-tile(m) x B-tile(t).
+//   a_lane: this lane's A address for tile 0, tap 0, sp 0:
+//           region + (first_row + (lane&15)*row_step) * S + 2*(lane>>4)
+//   b_lane: this lane's B address for tap 0, sp 0, tile 0:  weights + t0*128 + lane*2
+//   MROWS : physical rows between consecutive M tiles (16 * conv stride)
+//   SPTOT : C_in/8 of the whole layer (stride of the tap index in the weight image);
+//           SP <= SPTOT is how many channel-pairs groups this call walks (split-K).
+// All offsets are compile-time so every access is base + immediate.
+// ---------------------------------------------------------------------------------------------
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
+__device__ __forceinline__ void conv_tiles(const float* a_lane, const float* b_lane,
+                                           f4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int sp = 0; sp < SP; ++sp) {
+            f2 a[MT], b[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                a[m] = *reinterpret_cast<const f2*>(a_lane + (m * MROWS + tap) * S + sp * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                b[t] = *reinterpret_cast<const f2*>(b_lane +
+                                                    ((tap * SPTOT + sp) * NTTOT + t) * 128);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(a[m].x, b[t].x, acc[m][t]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(a[m].y, b[t].y, acc[m][t]);
+        }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused epilogue.  An accumulator register r of lane l holds position 4*(l>>4)+r of the tile and
+// output channel (l&15) of the N tile, so MaxPool2 pairs (r0,r1),(r2,r3) are in-register.
+//   out_lane  : region + (first_out_row + ROWQ*(lane>>4)) * S_OUT + channel_base + (lane&15)
+//               with ROWQ = 2 when pooling, 4 otherwise
+//   bias_lane : packed + bias_offset + t0*16 + (lane&15); scale/shift likewise (BN channel!)
+// Order per element: +bias, ReLU, [max over the position pair], [x*scale + shift]  —
+// conv -> ReLU -> MaxPool -> BatchNorm exactly as network_architecture.py:34-40 orders them.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int S_OUT, bool POOL, bool BN>
+__device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lane,
+                                         const float* __restrict__ bias_lane,
+                                         const float* __restrict__ scale_lane,
+                                         const float* __restrict__ shift_lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float b = bias_lane[t * 16];
+        float sc = 1.f, sh = 0.f;
+        if (BN) {
+            sc = scale_lane[t * 16];
+            sh = shift_lane[t * 16];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float v0 = fmaxf(acc[m][t].x + b, 0.f);
+            float v1 = fmaxf(acc[m][t].y + b, 0.f);
+            float v2 = fmaxf(acc[m][t].z + b, 0.f);
+            float v3 = fmaxf(acc[m][t].w + b, 0.f);
+            if (POOL) {
+                float o0 = fmaxf(v0, v1);
+                float o1 = fmaxf(v2, v3);
+                if (BN) {
+                    o0 = fmaf(o0, sc, sh);
+                    o1 = fmaf(o1, sc, sh);
+                }
+                out_lane[(m * 8 + 0) * S_OUT + t * 16] = o0;
+                out_lane[(m * 8 + 1) * S_OUT + t * 16] = o1;
+            } else {
+                if (BN) {
+                    v0 = fmaf(v0, sc, sh);
+                    v1 = fmaf(v1, sc, sh);
+                    v2 = fmaf(v2, sc, sh);
+                    v3 = fmaf(v3, sc, sh);
+                }
+                out_lane[(m * 16 + 0) * S_OUT + t * 16] = v0;
+                out_lane[(m * 16 + 1) * S_OUT + t * 16] = v1;
+                out_lane[(m * 16 + 2) * S_OUT + t * 16] = v2;
+                out_lane[(m * 16 + 3) * S_OUT + t * 16] = v3;
+            }
+        }
+    }
+}
+
+// Weights of the NEXT layer are copied HBM/L2 -> LDS by the DMA path (global_load_lds_dwordx4:
+// 64 lanes x 16 B = one 1 KiB piece per wave-instruction, destination = wave-uniform base +
+// lane*16) while the current layer's MFMAs run; no VGPRs, no ds_write.  The __syncthreads()
+// that ends the layer carries the vmcnt(0) that retires them.
+template <int NFLOATS>
+__device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* lds_dst, int lane,
+                                            int wave) {
+    static_assert(NFLOATS % 256 == 0, "weight blocks are whole 1 KiB pieces");
+    constexpr int kPieces = NFLOATS / 256;
+#pragma unroll
+    for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
+        const int piece = wave + kWaves * i;   // wave-uniform
+        if (piece < kPieces)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + piece * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero_row(float* region, int row, int stride, int channels,
+                                         int tid) {
+    if (tid < channels) region[row * stride + tid] = 0.f;
+}
+
+__device__ __forceinline__ void dump_stage(const float* region, int stride, int rows,
+                                           int channels, float* __restrict__ out, int tid) {
+    for (int idx = tid; idx < rows * channels; idx += kThreads) {
+        const int r = idx / channels, c = idx - r * channels;
+        out[idx] = region[(r + 1) * stride + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One convolution of stages B-D, updating the activation buffer at lds+kActOff in place.
+//   CONV    : 0-based layer index; its weights are already in lds + W_CUR
+//   L       : input length;  POOL/BNI: fused MaxPool2 / batch-norm index (-1 = none)
+//   NEXT_N  : floats of the next block of weights, DMA'd from next_g into next_lds meanwhile
+// ---------------------------------------------------------------------------------------------
+template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N>
+__device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
+                                              const float* __restrict__ next_g, float* next_lds,
+                                              int tid, int lane, int wave) {
+    constexpr int TAPS = kConv[CONV].taps;
+    constexpr int SP = kConv[CONV].cin / 8;
+    constexpr int NT = kConv[CONV].cout_pad / 16;
+    constexpr int MTILES = L / 16;
+    constexpr int MT = MTILES / kWaves;
+    static_assert(MT >= 1 && MT * kWaves == MTILES, "layer does not tile over the waves");
+    constexpr int LOUT = POOL ? L / 2 : L;
+    constexpr bool BN = BNI >= 0;
+    const int n = lane & 15, q = lane >> 4;
+
+    dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
+
+    f4 acc[MT][NT];
+    zero_acc(acc);
+    const int m0 = wave * MT;
+    // 'same' k=3: logical row p+tap-1 = physical row p+tap; k=1: physical row p+1.
+    const float* a_lane = lds + kActOff + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
+    const float* b_lane = lds + W_CUR + lane * 2;
+    conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc);
+
+    __syncthreads();   // every wave has finished reading the old activations and weights
+
+    float* out_lane = lds + kActOff +
+                      (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
+    const float* bias_lane = packed + bias_offset(CONV) + n;
+    const float* scale_lane = packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n;
+    const float* shift_lane = packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n;
+    epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+    zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
+    zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
+
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A small-M layer (one 16-position tile: conv17/18/19): weights straight from global, the
+// contraction split over KS groups of 3 waves (one per N tile), partial tiles summed via LDS.
+// ---------------------------------------------------------------------------------------------
+template <int CONV, int S_IN, int STRIDE, int KS, bool POOL, int BNI>
+__device__ __forceinline__ void splitk_layer(float* lds, const float* in_region, float* out_region,
+                                             const float* __restrict__ packed, int tid, int lane,
+                                             int wave) {
+    constexpr int TAPS = kConv[CONV].taps;
+    constexpr int SPTOT = kConv[CONV].cin / 8;
+    constexpr int SP = SPTOT / KS;
+    static_assert(SP * KS == SPTOT, "split-K must divide C_in/8");
+    static_assert(3 * KS <= kWaves, "not enough waves for this split");
+    constexpr bool BN = BNI >= 0;
+    const int n = lane & 15, q = lane >> 4;
+
+    if (wave < 3 * KS) {
+        const int t = wave % 3, ks = wave / 3;
+        f4 acc[1][1];
+        zero_acc(acc);
+        // stride-2 'same' pads on the right only: logical row 2p+tap = physical row 2p+tap+1;
+        // stride-1 'same' k=3: physical row p+tap.
+        const int first = (STRIDE == 2) ? 1 : 0;
+        const float* a_lane = in_region + (first + n * STRIDE) * S_IN + 2 * q + ks * SP * 8;
+        const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t) * 128 + lane * 2;
+        conv_tiles<TAPS, SP, SPTOT, 1, 1, 3, S_IN, 16 * STRIDE>(a_lane, b_lane, acc);
+        *reinterpret_cast<f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4) = acc[0][0];
+    }
+    __syncthreads();
+    if (wave < 3) {
+        const int t = wave;
+        f4 acc[1][1];
+        acc[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks)
+            acc[0][0] += *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
+        float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
+        const float* bias_lane = packed + bias_offset(CONV) + t * 16 + n;
+        const float* scale_lane = packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + t * 16 + n;
+        const float* shift_lane = packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + t * 16 + n;
+        epilogue<1, 1, kS48, POOL, BN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+    }
+    __syncthreads();
+}
+
+// One wave's share of the 1x1 convolutions of the inception block (4 position tiles x 1 N tile).
+template <int NTTOT, int S_OUT, bool POOLBN>
+__device__ __forceinline__ void inception_1x1(const float* in_region, const float* w_lds,
+                                              float* out_region, int out_ch,
+                                              const float* __restrict__ bias_lane,
+                                              const float* __restrict__ scale_lane,
+                                              const float* __restrict__ shift_lane, int t,
+                                              int lane) {
+    const int n = lane & 15, q = lane >> 4;
+    f4 acc[4][1];
+    zero_acc(acc);
+    conv_tiles<1, 6, 6, 4, 1, NTTOT, kS48, 16>(in_region + (n + 1) * kS48 + 2 * q,
+                                               w_lds + t * 128 + lane * 2, acc);
+    float* out_lane = out_region + (1 + (POOLBN ? 2 * q : 4 * q)) * S_OUT + out_ch + n;
+    epilogue<4, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+}
+
+// k=3 convolution of the inception block over MT position tiles starting at tile m0.
+template <int SP, int MT, int S_IN, int S_OUT, bool POOLBN>
+__device__ __forceinline__ void inception_k3(const float* in_region, const float* w_lds,
+                                             float* out_region, int out_ch,
+                                             const float* __restrict__ bias_lane,
+                                             const float* __restrict__ scale_lane,
+                                             const float* __restrict__ shift_lane, int t, int m0,
+                                             int lane) {
+    const int n = lane & 15, q = lane >> 4;
+    f4 acc[MT][1];
+    zero_acc(acc);
+    conv_tiles<3, SP, SP, MT, 1, 3, S_IN, 16>(in_region + (m0 * 16 + n) * S_IN + 2 * q,
+                                              w_lds + t * 128 + lane * 2, acc);
+    float* out_lane = out_region +
+                      (1 + (POOLBN ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + out_ch + n;
+    epilogue<MT, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+}
+
+// =============================================================================================
+// The kernel.  grid = n_windows, block = 512.
+//   x      [n_windows][1024]   normalised windows (fp32)
+//   probs  [n_windows][n_classes]
+//   debug_stage >= 0: write the activations after stage 'A'+debug_stage to debug_out and stop.
+// =============================================================================================
+__global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
+    const float* __restrict__ packed, const float* __restrict__ x, float* __restrict__ probs,
+    int n_classes, int debug_stage, float* __restrict__ debug_out) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const long win = blockIdx.x;
+    const float* xw = x + win * kWindow;
+
+    // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
+    {
+        dma_weights<conv_weight_floats(1)>(packed + weight_offset(1), lds + kW0, lane, wave);
+        const int p = tid;   // 512 threads <-> 512 output positions
+        const float x0 = xw[2 * p], x1 = xw[2 * p + 1];
+        const float x2 = (2 * p + 2 < kWindow) ? xw[2 * p + 2] : 0.f;
+        const float* w = packed + weight_offset(0);
+        const float* bias = packed + bias_offset(0);
+        const float* sc = packed + bn_scale_offset(0);
+        const float* sh = packed + bn_shift_offset(0);
+        float* row = lds + kActOff + (p + 1) * kS48;
+#pragma unroll
+        for (int c4 = 0; c4 < 12; ++c4) {
+            f4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c4 * 4 + i;
+                float v = fmaf(w[c], x0, bias[c]);
+                v = fmaf(w[48 + c], x1, v);
+                v = fmaf(w[96 + c], x2, v);
+                v = fmaxf(v, 0.f);
+                o[i] = fmaf(v, sc[c], sh[c]);
+            }
+            *reinterpret_cast<f4*>(row + c4 * 4) = o;
+        }
+        zero_row(lds + kActOff, 0, kS48, 48, tid);
+        zero_row(lds + kActOff, 513, kS48, 48, tid);
+        __syncthreads();
+    }
+    if (debug_stage == 0) {
+        dump_stage(lds + kActOff, kS48, 512, 48, debug_out + win * kStageFloats[0], tid);
+        return;
+    }
+
+    // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
+    inplace_layer<1, kW0, 512, kS48, kS48, false, -1, conv_weight_floats(2)>(
+        lds, packed, packed + weight_offset(2), lds + kW1, tid, lane, wave);
+    inplace_layer<2, kW1, 512, kS48, kS48, false, -1, conv_weight_floats(3)>(
+        lds, packed, packed + weight_offset(3), lds + kW0, tid, lane, wave);
+    inplace_layer<3, kW0, 512, kS48, kS48, true, 1, conv_weight_floats(4)>(
+        lds, packed, packed + weight_offset(4), lds + kW1, tid, lane, wave);
+    if (debug_stage == 1) {
+        dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
+        return;
+    }
+
+    // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
+    inplace_layer<4, kW1, 256, kS48, kS16, false, -1, conv_weight_floats(5)>(
+        lds, packed, packed + weight_offset(5), lds + kW0, tid, lane, wave);
+    inplace_layer<5, kW0, 256, kS16, kS48, false, -1, conv_weight_floats(6)>(
+        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave);
+    inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
+        lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave);
+    if (debug_stage == 2) {
+        dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
+        return;
+    }
+
+    // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
+    inplace_layer<7, kW0, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
+        lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave);
+    // conv9 prefetches ALL inception weights (conv10..16) into their stage-E home.
+    inplace_layer<8, kW1, 128, kS48, kS48, true, 3, kEWFloats>(
+        lds, packed, packed + weight_offset(9), lds + kEW, tid, lane, wave);
+    if (debug_stage == 3) {
+        dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);
+        return;
+    }
+
+    // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
+    {
+        // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
+        const float* X = lds + kEX;
+        for (int idx = tid; idx < 64 * 48; idx += kThreads) {
+            const int p = idx / 48, c = idx - p * 48;
+            const float s = X[p * kS48 + c] + X[(p + 1) * kS48 + c] + X[(p + 2) * kS48 + c];
+            const float cnt = (p == 0 || p == 63) ? 2.f : 3.f;
+            lds[kEAP + (p + 1) * kS48 + c] = s / cnt;
+        }
+        zero_row(lds + kET3, 0, kS16, 16, tid);
+        zero_row(lds + kET3, 65, kS16, 16, tid);
+        zero_row(lds + kET4a, 0, kS16, 16, tid);
+        zero_row(lds + kET4a, 65, kS16, 16, tid);
+        zero_row(lds + kET4b, 0, kS48, 48, tid);
+        zero_row(lds + kET4b, 65, kS48, 48, tid);
+        zero_row(lds + kECat, 0, kS192, 192, tid);
+        zero_row(lds + kECat, 33, kS192, 192, tid);
+        __syncthreads();
+
+        constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
+        constexpr int w11 = kEW + weight_offset(10) - weight_offset(9);
+        constexpr int w12 = kEW + weight_offset(11) - weight_offset(9);
+        constexpr int w13 = kEW + weight_offset(12) - weight_offset(9);
+        constexpr int w14 = kEW + weight_offset(13) - weight_offset(9);
+        constexpr int w15 = kEW + weight_offset(14) - weight_offset(9);
+        constexpr int w16 = kEW + weight_offset(15) - weight_offset(9);
+        const float* sc5 = packed + bn_scale_offset(4) + n;
+        const float* sh5 = packed + bn_shift_offset(4) + n;
+
+        // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
+        if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
+            const int t = wave;
+            inception_1x1<3, kS192, true>(lds + kEAP, lds + w10, lds + kECat, t * 16,
+                                          packed + bias_offset(9) + t * 16 + n, sc5 + t * 16,
+                                          sh5 + t * 16, t, lane);
+        } else if (wave < 6) {     // conv11 -> concat channels 48..95
+            const int t = wave - 3;
+            inception_1x1<3, kS192, true>(lds + kEX, lds + w11, lds + kECat, 48 + t * 16,
+                                          packed + bias_offset(10) + t * 16 + n,
+                                          sc5 + 48 + t * 16, sh5 + 48 + t * 16, t, lane);
+        } else if (wave == 6) {    // conv12 -> 16-channel bottleneck of branch 3
+            inception_1x1<1, kS16, false>(lds + kEX, lds + w12, lds + kET3, 0,
+                                          packed + bias_offset(11) + n, nullptr, nullptr, 0, lane);
+        } else {                   // conv14 -> 16-channel bottleneck of branch 4
+            inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0,
+                                          packed + bias_offset(13) + n, nullptr, nullptr, 0, lane);
+        }
+        __syncthreads();
+
+        // E2: conv13 (16->48, k3) -> concat 96..143 ; conv15 (16->48, k3) -> T4b
+        if (wave < 3) {
+            const int t = wave;
+            inception_k3<2, 4, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96 + t * 16,
+                                                  packed + bias_offset(12) + t * 16 + n,
+                                                  sc5 + 96 + t * 16, sh5 + 96 + t * 16, t, 0, lane);
+        } else if (wave < 6) {
+            const int t = wave - 3;
+            inception_k3<2, 4, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, t * 16,
+                                                  packed + bias_offset(14) + t * 16 + n, nullptr,
+                                                  nullptr, t, 0, lane);
+        }
+        __syncthreads();
+
+        // E3: conv16 (48->48, k3) -> concat 144..191
+        if (wave < 6) {
+            const int t = wave % 3, m0 = (wave / 3) * 2;
+            inception_k3<6, 2, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
+                                                  144 + t * 16,
+                                                  packed + bias_offset(15) + t * 16 + n,
+                                                  sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
+                                                  lane);
+        }
+        __syncthreads();
+    }
+    if (debug_stage == 4) {
+        dump_stage(lds + kECat, kS192, 32, 192, debug_out + win * kStageFloats[4], tid);
+        return;
+    }
+
+    // ---------------- stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48 ---------
+    zero_row(lds + kFOut, 0, kS48, 48, tid);
+    zero_row(lds + kFOut, 17, kS48, 48, tid);
+    zero_row(lds + kG1, 0, kS48, 48, tid);
+    zero_row(lds + kG1, 17, kS48, 48, tid);
+    for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
+    splitk_layer<16, kS192, 2, 2, false, 5>(lds, lds + kECat, lds + kFOut, packed, tid, lane, wave);
+    if (debug_stage == 5) {
+        dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
+        return;
+    }
+
+    // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
+    splitk_layer<17, kS48, 1, 2, false, -1>(lds, lds + kFOut, lds + kG1, packed, tid, lane, wave);
+    splitk_layer<18, kS48, 1, 2, true, 6>(lds, lds + kG1, lds + kG2, packed, tid, lane, wave);
+    if (debug_stage == 6) {
+        dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
+        return;
+    }
+
+    // ---------------- stage H: conv20 (1x1 -> classes) + ReLU + GlobalAveragePool + Softmax ---
+    if (wave < 2) {
+        const int t = wave;
+        f4 acc[1][1];
+        zero_acc(acc);
+        conv_tiles<1, 6, 6, 1, 1, 2, kS48, 16>(lds + kG2 + (n + 1) * kS48 + 2 * q,
+                                               packed + weight_offset(19) + t * 128 + lane * 2, acc);
+        const float b = packed[bias_offset(19) + t * 16 + n];
+        float s = 0.f;
+        if (q < 2) {   // rows 4q..4q+3 of the tile; only positions 0..7 exist
+            s = fmaxf(acc[0][0].x + b, 0.f) + fmaxf(acc[0][0].y + b, 0.f) +
+                fmaxf(acc[0][0].z + b, 0.f) + fmaxf(acc[0][0].w + b, 0.f);
+        }
+        s += __shfl_xor(s, 16);
+        if (q == 0) lds[kLogits + t * 16 + n] = s * 0.125f;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool valid = lane < n_classes;
+        const float v = valid ? lds[kLogits + (lane & 31)] : -INFINITY;
+        float mx = v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float e = valid ? expf(v - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        if (debug_stage == 7) {
+            if (lane < 32) debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+            return;
+        }
+        if (valid) probs[win * n_classes + lane] = e / sum;
+    }
+}
+
+// =============================================================================================
+// Seam b2 helpers.
+// =============================================================================================
+
+// One block per (read, step): slice the window (classify.py:337-349), z-normalise it in fp64
+// (trim_signal.py:61-69; the sums are exact integers), zero-pad right ('start') or left ('end')
+// (classify.py:352-357) and emit fp32, which is what Keras casts the float64 input to.
+__global__ __launch_bounds__(256) void dbh_normalise_kernel(
+    const int16_t* __restrict__ samples, const long long* __restrict__ offsets, int steps,
+    int side, float* __restrict__ windows) {
+    __shared__ long long red[2][4];
+    const long long read = blockIdx.x / steps;
+    const int step = blockIdx.x - (int)(read * steps);
+    const long long base = offsets[read];
+    const long long len = offsets[read + 1] - base;
+    const long long sig_start = (long long)step * (kWindow / 2);
+    const long long sig_end = sig_start + kWindow;
+    long long a, b;
+    if (side == 0) {
+        a = sig_start < len ? sig_start : len;
+        b = sig_end < len ? sig_end : len;
+    } else {
+        a = len - sig_end > 0 ? len - sig_end : 0;
+        b = len - sig_start > 0 ? len - sig_start : 0;
+    }
+    const int cnt = (int)(b - a);
+    const int tid = threadIdx.x;
+    const int16_t* src = samples + base + a;
+
+    int v[4];
+    long long s1 = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + i * 256;
+        v[i] = (k < cnt) ? (int)src[k] : 0;
+        s1 += v[i];
+        s2 += (long long)v[i] * v[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = s1;
+        red[1][tid >> 6] = s2;
+    }
+    __syncthreads();
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+
+    float* out = windows + (long long)blockIdx.x * kWindow;
+    double mean = 0.0, inv = 1.0;
+    bool divide = false;
+    double stdev = 0.0;
+    if (cnt > 0) {
+        mean = (double)s1 / (double)cnt;
+        // population variance = (n*sum(x^2) - sum(x)^2) / n^2, numerator exact in int64
+        const long long num = (long long)cnt * s2 - s1 * s1;
+        stdev = sqrt((double)num) / (double)cnt;
+        divide = stdev > 0.0;
+    }
+    (void)inv;
+    const int pad_left = (side == 0) ? 0 : kWindow - cnt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + i * 256;          // position in the source slice
+        if (k < cnt) {
+            const double d = (double)v[i] - mean;
+            out[pad_left + k] = (float)(divide ? d / stdev : d);
+        }
+    }
+    // zero padding: [cnt, 1024) for 'start', [0, 1024-cnt) for 'end'
+    const int pad_begin = (side == 0) ? cnt : 0;
+    const int pad_count = kWindow - cnt;
+    for (int k = tid; k < pad_count; k += 256) out[pad_begin + k] = 0.f;
+}
+
+// 32 lanes per read: merge the per-step softmax vectors (classify.py:368-374: min for class 0,
+// max for the barcodes), rescale the barcodes so the vector sums to one (classify.py:387-393,
+// in fp64 like NumPy-1.x scalar promotion did) and make the call (classify.py:285-295).
+__global__ __launch_bounds__(256) void dbh_merge_kernel(const float* __restrict__ wprobs,
+                                                        long long n_reads, int steps,
+                                                        int n_classes, double score_diff,
+                                                        float* __restrict__ probs,
+                                                        int* __restrict__ calls) {
+    const long long read = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int c = threadIdx.x & 31;
+    if (read >= n_reads) return;   // whole 32-lane groups exit together
+    const bool valid = c < n_classes;
+    float merged = 0.f;
+    if (valid) {
+        const float* src = wprobs + read * steps * n_classes + c;
+        merged = src[0];
+        for (int s = 1; s < steps; ++s) {
+            const float v = src[(long long)s * n_classes];
+            merged = (c == 0) ? fminf(merged, v) : fmaxf(merged, v);
+        }
+    }
+    double p = (double)merged;
+    double rest = (valid && c > 0) ? p : 0.0;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) rest += __shfl_xor(rest, off, 32);
+    const double p0 = __shfl(p, 0, 32);
+    const double factor = (1.0 - p0) / rest;
+    if (c > 0) p = p * factor;
+    if (valid) probs[read * n_classes + c] = (float)p;
+
+    // top two by value, ties to the lower class index (Python's stable sort, reverse=True)
+    double best = valid ? p : -1.0;
+    int best_i = c;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 32);
+        const int oi = __shfl_xor(best_i, off, 32);
+        if (ov > best || (ov == best && oi < best_i)) {
+            best = ov;
+            best_i = oi;
+        }
+    }
+    double second = (valid && c != best_i) ? p : -1.0;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) second = fmax(second, __shfl_xor(second, off, 32));
+    if (c == 0) {
+        int call = 0;
+        if (best_i != 0 && (best - second) >= score_diff) call = best_i;
+        calls[read] = call;
+    }
+}
+
+}  // namespace dbh

@@ -1,0 +1,129 @@
+// dbh_layout.h — compile-time description of the Deepbinner network
+// (reference deepbinner/network_architecture.py:18-95) as the forward kernel sees it:
+// which convolutions run on the MFMA path, where their pre-swizzled "fragment order" weights
+// live in the packed HBM buffer, and how the LDS arena is carved per stage.
+//
+// Shared by the host-side packer (dbh_api.hip) and the device code (dbh_forward.hip).
+#pragma once
+
+namespace dbh {
+
+constexpr int kWindow = 1024;          // model input size (classify.py:96)
+constexpr int kMaxClasses = 32;        // conv1d_20 is padded to two 16-wide N tiles
+constexpr int kNumConvs = 20;
+constexpr int kNumBn = 7;
+
+// ---------------------------------------------------------------------------------------------
+// Convolution table (index = Keras layer number - 1).  cout_pad is C_out rounded up to 16.
+// ---------------------------------------------------------------------------------------------
+struct ConvSpec { int taps, cin, cout_pad, stride; };
+constexpr ConvSpec kConv[kNumConvs] = {
+    {3, 1, 48, 2},     // conv1d_1   (VALU path, C_in = 1)
+    {3, 48, 48, 1},    // conv1d_2
+    {3, 48, 48, 1},    // conv1d_3
+    {3, 48, 48, 1},    // conv1d_4
+    {1, 48, 16, 1},    // conv1d_5
+    {3, 16, 48, 1},    // conv1d_6
+    {3, 48, 48, 1},    // conv1d_7
+    {3, 48, 48, 1},    // conv1d_8
+    {3, 48, 48, 1},    // conv1d_9
+    {1, 48, 48, 1},    // conv1d_10
+    {1, 48, 48, 1},    // conv1d_11
+    {1, 48, 16, 1},    // conv1d_12
+    {3, 16, 48, 1},    // conv1d_13
+    {1, 48, 16, 1},    // conv1d_14
+    {3, 16, 48, 1},    // conv1d_15
+    {3, 48, 48, 1},    // conv1d_16
+    {3, 192, 48, 2},   // conv1d_17
+    {3, 48, 48, 1},    // conv1d_18
+    {3, 48, 48, 1},    // conv1d_19
+    {1, 48, 32, 1},    // conv1d_20  (n_classes <= 32, zero padded)
+};
+constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
+
+// Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
+constexpr int conv_weight_floats(int i) {
+    return kConv[i].taps * kConv[i].cin * kConv[i].cout_pad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed parameter buffer (floats).  [ weights of conv 1..20 | bias of conv 1..20 (cout_pad
+// each) | BN scale,shift of bn 1..7 ].  BN is pre-folded on the host in fp64:
+//   scale = gamma / sqrt(var + 1e-3),  shift = beta - mean * scale.
+// ---------------------------------------------------------------------------------------------
+constexpr int weight_offset(int i) {
+    int off = 0;
+    for (int j = 0; j < i; ++j) off += conv_weight_floats(j);
+    return off;
+}
+constexpr int kWeightFloats = weight_offset(kNumConvs);
+constexpr int bias_offset(int i) {
+    int off = kWeightFloats;
+    for (int j = 0; j < i; ++j) off += kConv[j].cout_pad;
+    return off;
+}
+constexpr int kBiasEnd = bias_offset(kNumConvs);
+constexpr int bn_scale_offset(int i) {
+    int off = kBiasEnd;
+    for (int j = 0; j < i; ++j) off += 2 * kBnChannels[j];
+    return off;
+}
+constexpr int bn_shift_offset(int i) { return bn_scale_offset(i) + kBnChannels[i]; }
+constexpr int kPackedFloats = bn_scale_offset(kNumBn);
+
+// Fragment order of an MFMA-path layer (v_mfma_f32_16x16x4_f32, B operand = weights):
+//   index = (((tap * SP + sp) * NT + t) * 64 + lane) * 2 + e
+//   value = W[tap][8*sp + 2*(lane>>4) + e][16*t + (lane&15)]
+// with SP = C_in/8 and NT = cout_pad/16.  One ds_read_b64 / global_load_dwordx2 per lane yields
+// the B fragments of two consecutive k-steps; the A side (activations) pairs channels the same
+// way, so the contraction order is a fixed permutation of (tap, c_in).
+
+// ---------------------------------------------------------------------------------------------
+// LDS arena (floats).  Activations are [position][channel] with row stride C+4 (stride/4 odd ->
+// conflict-free ds_read_b64 A-fragment loads) and one zero row before and after the data
+// ("physical row = logical position + 1") to serve 'same' padding.
+// ---------------------------------------------------------------------------------------------
+constexpr int kS48 = 52;
+constexpr int kS16 = 20;
+constexpr int kS192 = 196;
+
+// stages A-D: one in-place activation buffer + two weight buffers filled by LDS-DMA
+// (global_load_lds_dwordx4) one layer ahead of use.
+constexpr int kActOff = 0;
+constexpr int kActFloats = (512 + 2) * kS48;               // 26,728
+constexpr int kWFloats = 3 * 48 * 48;                      // 6,912
+constexpr int kW0 = kActOff + kActFloats;
+constexpr int kW1 = kW0 + kWFloats;
+constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 40,552 = 162,208 B
+
+// stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
+// their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
+constexpr int kEX = 0;                                     // BN4 output, 66 rows x 52
+constexpr int kEAP = kEX + 66 * kS48;                      // avg-pooled copy
+constexpr int kEW = kEAP + 66 * kS48;                      // weights of conv10..16
+constexpr int kEWFloats = weight_offset(16) - weight_offset(9);   // 17,664
+constexpr int kET3 = kEW + kEWFloats;                      // conv12 out, 66 x 20
+constexpr int kET4a = kET3 + 66 * kS16;                    // conv14 out, 66 x 20
+constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 52
+constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
+constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
+static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
+static_assert(kEW + kEWFloats <= kW1, "stage-E weights would land on conv9's weight buffer");
+
+// stages F-H (reuse the front of the arena; the concat buffer stays where it is)
+constexpr int kFOut = 0;                                   // conv17+BN6 out, 18 rows x 52
+constexpr int kG1 = kFOut + 18 * kS48;                     // conv18 out
+constexpr int kG2 = kG1 + 18 * kS48;                       // conv19+pool+BN7 out (8 rows + pads)
+constexpr int kRed = kG2 + 18 * kS48;                      // split-K partial tiles, 12 x 256
+constexpr int kLogits = kRed + 12 * 256;                   // 32 floats
+constexpr int kTailEnd = kLogits + 32;
+static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
+
+constexpr int kLdsFloats = kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD;
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
+
+// floats per window of the debug dump after each stage (dense [L][C])
+constexpr int kStageFloats[8] = {512 * 48, 256 * 48, 128 * 48, 64 * 48, 32 * 192, 16 * 48,
+                                 8 * 48, 32};
+
+}  // namespace dbh

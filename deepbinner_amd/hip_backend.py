@@ -1,0 +1,380 @@
+"""
+ctypes binding of ``libdeepbinner_hip.so`` (C ABI: ``include/deepbinner_hip.h``) and the
+``HipModel`` object that stands where the reference has a Keras ``Model``:
+
+* ``model.inputs[0].shape`` / ``model.outputs[0].shape`` / ``len(model.inputs)`` — what
+  ``load_trained_model`` inspects (reference ``deepbinner/classify.py:92-99``);
+* ``model.predict(x, batch_size=...)`` — seam b1 (``classify.py:361``);
+* ``model.classify_signals(...)`` — seam b2, all of ``call_batch`` (``classify.py:325-384``) on
+  the device.
+
+The binding idiom follows the reference's own native binding
+(``deepbinner/dtw_semi_global.py:30-41``): ``LoadLibrary`` + ``ndpointer(..., C_CONTIGUOUS)`` +
+explicit ``restype``/``argtypes`` + caller-allocated outputs.
+
+There is deliberately NO CPU fallback: if the library or a GPU is missing the error is loud.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+from numpy.ctypeslib import ndpointer
+
+from .model_format import ModelWeights
+
+_LIB_NAME = 'libdeepbinner_hip.so'
+_lib = None
+
+SIDE_START, SIDE_END = 0, 1
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def _f32(flags='C_CONTIGUOUS'):
+    return ndpointer(dtype=np.float32, flags=flags)
+
+
+def load_library():
+    """Load (once) and type the shared library.  Raises HipBackendError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.isfile(path):
+        raise HipBackendError(
+            '{} has not been built - run `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C deepbinner_amd/csrc`). There is no CPU fallback.'.format(path))
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise HipBackendError('could not load {}: {}'.format(path, e)) from e
+
+    c_int, c_i64, c_void_p, c_size_t = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    P = ctypes.POINTER
+    sigs = {
+        'dbh_version': (ctypes.c_char_p, []),
+        'dbh_status_string': (ctypes.c_char_p, [c_int]),
+        'dbh_last_error': (ctypes.c_char_p, []),
+        'dbh_device_count': (c_int, [P(c_int)]),
+        'dbh_set_device': (c_int, [c_int]),
+        'dbh_get_device': (c_int, [P(c_int)]),
+        'dbh_device_name': (c_int, [c_int, ctypes.c_char_p, c_int]),
+        'dbh_device_synchronize': (c_int, []),
+        'dbh_malloc': (c_int, [P(c_void_p), c_size_t]),
+        'dbh_free': (c_int, [c_void_p]),
+        'dbh_malloc_host': (c_int, [P(c_void_p), c_size_t]),
+        'dbh_free_host': (c_int, [c_void_p]),
+        'dbh_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+        'dbh_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+        'dbh_memcpy_d2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+        'dbh_stream_create': (c_int, [P(c_void_p)]),
+        'dbh_stream_destroy': (c_int, [c_void_p]),
+        'dbh_stream_synchronize': (c_int, [c_void_p]),
+        'dbh_event_create': (c_int, [P(c_void_p)]),
+        'dbh_event_destroy': (c_int, [c_void_p]),
+        'dbh_event_record': (c_int, [c_void_p, c_void_p]),
+        'dbh_event_synchronize': (c_int, [c_void_p]),
+        'dbh_event_elapsed_ms': (c_int, [c_void_p, c_void_p, P(ctypes.c_float)]),
+        'dbh_model_create': (c_int, [_f32(), c_i64, c_int, c_int, P(c_void_p)]),
+        'dbh_model_destroy': (c_int, [c_void_p]),
+        'dbh_model_input_size': (c_int, [c_void_p, P(c_int)]),
+        'dbh_model_output_size': (c_int, [c_void_p, P(c_int)]),
+        'dbh_predict': (c_int, [c_void_p, _f32(), c_i64, _f32()]),
+        'dbh_predict_dev': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+        'dbh_classify_i16': (c_int, [c_void_p, ndpointer(np.int16, flags='C_CONTIGUOUS'),
+                                     ndpointer(np.int64, flags='C_CONTIGUOUS'), c_i64, c_int,
+                                     c_int, ctypes.c_double, _f32(),
+                                     ndpointer(np.int32, flags='C_CONTIGUOUS')]),
+        'dbh_classify_workspace_bytes': (c_int, [c_void_p, c_i64, c_int, P(c_size_t)]),
+        'dbh_classify_i16_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
+                                         ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+        'dbh_normalise_windows_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p,
+                                              c_void_p]),
+        'dbh_merge_calls_dev': (c_int, [c_void_p, c_i64, c_int, c_int, ctypes.c_double, c_void_p,
+                                        c_void_p, c_void_p]),
+        'dbh_stage_floats': (c_int, [c_int, P(c_i64)]),
+        'dbh_debug_forward': (c_int, [c_void_p, _f32(), c_i64, c_int, _f32()]),
+        'dbh_forward_kernel_info': (c_int, [P(c_int), P(c_int), P(c_int)]),
+        'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
+        'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
+    }
+    for name, (restype, argtypes) in sigs.items():
+        fn = getattr(lib, name)     # AttributeError here = header and library out of step
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    'dbh_version', 'dbh_status_string', 'dbh_last_error', 'dbh_device_count', 'dbh_set_device',
+    'dbh_get_device', 'dbh_device_name', 'dbh_device_synchronize', 'dbh_malloc', 'dbh_free',
+    'dbh_malloc_host', 'dbh_free_host', 'dbh_memcpy_h2d', 'dbh_memcpy_d2h', 'dbh_memcpy_d2d',
+    'dbh_stream_create', 'dbh_stream_destroy', 'dbh_stream_synchronize', 'dbh_event_create',
+    'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
+    'dbh_model_create', 'dbh_model_destroy', 'dbh_model_input_size', 'dbh_model_output_size',
+    'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
+    'dbh_classify_i16_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
+    'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
+    'dbh_forward_timing_enable', 'dbh_forward_timing_read',
+]
+
+
+def check(status, what='libdeepbinner_hip call'):
+    if status != 0:
+        lib = load_library()
+        msg = lib.dbh_status_string(status).decode()
+        detail = lib.dbh_last_error().decode()
+        raise HipBackendError('{} failed: {}{}'.format(what, msg,
+                                                       ' ({})'.format(detail) if detail else ''))
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    status = lib.dbh_device_count(ctypes.byref(n))
+    if status != 0:
+        return 0
+    return n.value
+
+
+def device_name(ordinal=0):
+    lib = load_library()
+    buf = ctypes.create_string_buffer(256)
+    check(lib.dbh_device_name(ordinal, buf, 256), 'dbh_device_name')
+    return buf.value.decode()
+
+
+def set_device(ordinal):
+    check(load_library().dbh_set_device(int(ordinal)), 'dbh_set_device')
+
+
+def synchronize():
+    check(load_library().dbh_device_synchronize(), 'dbh_device_synchronize')
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through the C ABI (no torch / no other GPU library)."""
+
+    def __init__(self, nbytes):
+        self._lib = load_library()
+        self.nbytes = int(nbytes)
+        ptr = ctypes.c_void_p()
+        check(self._lib.dbh_malloc(ctypes.byref(ptr), self.nbytes), 'dbh_malloc')
+        self.ptr = ptr.value
+
+    @classmethod
+    def from_array(cls, array, stream=None):
+        array = np.ascontiguousarray(array)
+        buf = cls(max(array.nbytes, 1))
+        buf.upload(array, stream)
+        return buf
+
+    def upload(self, array, stream=None):
+        array = np.ascontiguousarray(array)
+        assert array.nbytes <= self.nbytes
+        check(self._lib.dbh_memcpy_h2d(self.ptr, array.ctypes.data, array.nbytes, stream),
+              'dbh_memcpy_h2d')
+        check(self._lib.dbh_stream_synchronize(stream), 'dbh_stream_synchronize')
+
+    def download(self, shape, dtype, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self._lib.dbh_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, stream),
+              'dbh_memcpy_d2h')
+        check(self._lib.dbh_stream_synchronize(stream), 'dbh_stream_synchronize')
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._lib.dbh_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self._lib = load_library()
+        e = ctypes.c_void_p()
+        check(self._lib.dbh_event_create(ctypes.byref(e)), 'dbh_event_create')
+        self.handle = e.value
+
+    def record(self, stream=None):
+        check(self._lib.dbh_event_record(self.handle, stream), 'dbh_event_record')
+
+    def synchronize(self):
+        check(self._lib.dbh_event_synchronize(self.handle), 'dbh_event_synchronize')
+
+    def elapsed_ms(self, later):
+        ms = ctypes.c_float(0)
+        check(self._lib.dbh_event_elapsed_ms(self.handle, later.handle, ctypes.byref(ms)),
+              'dbh_event_elapsed_ms')
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.dbh_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _TensorSpec:
+    """Minimal stand-in for the Keras tensors load_trained_model looks at (classify.py:93-97)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class HipModel:
+    """A trained Deepbinner model resident on one MI355X."""
+
+    def __init__(self, weights, device=None):
+        if not isinstance(weights, ModelWeights):
+            raise TypeError('weights must be a ModelWeights')
+        self._lib = load_library()
+        if device_count() < 1:
+            raise HipBackendError('no HIP device is visible - Deepbinner-AMD needs an MI355X '
+                                  '(gfx950) GPU; there is no CPU fallback')
+        if device is not None:
+            set_device(device)
+        self.weights = weights
+        flat = weights.flat()
+        handle = ctypes.c_void_p()
+        check(self._lib.dbh_model_create(flat, flat.size, weights.n_classes, weights.input_size,
+                                         ctypes.byref(handle)), 'dbh_model_create')
+        self._handle = handle
+        self.n_classes = weights.n_classes
+        self.input_size = weights.input_size
+        self.inputs = [_TensorSpec((None, self.input_size, 1))]
+        self.outputs = [_TensorSpec((None, self.n_classes))]
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def close(self):
+        if self._handle:
+            self._lib.dbh_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- seam b1 ------------------------------------------------------------------------------
+    def predict(self, x, batch_size=None, verbose=0):
+        """x: [N, 1024, 1] (or [N, 1024]) float -> float32 [N, n_classes], a fresh writable array.
+        ``batch_size`` is accepted for signature compatibility; results do not depend on it."""
+        x = np.asarray(x)
+        if x.ndim == 3:
+            if x.shape[2] != 1:
+                raise ValueError('expected input of shape (N, {}, 1)'.format(self.input_size))
+            x = x[:, :, 0]
+        if x.ndim != 2 or x.shape[1] != self.input_size:
+            raise ValueError('expected input of shape (N, {}, 1)'.format(self.input_size))
+        x = np.ascontiguousarray(x, dtype=np.float32)      # Keras casts float64 -> float32 too
+        probs = np.empty((x.shape[0], self.n_classes), dtype=np.float32)
+        if x.shape[0]:
+            check(self._lib.dbh_predict(self._handle, x, x.shape[0], probs), 'dbh_predict')
+        return probs
+
+    # -- seam b2 ------------------------------------------------------------------------------
+    def classify_signals(self, signals, side, scan_size, score_diff):
+        """signals: list of 1-D integer arrays -> (probs float32 [N, C], calls int32 [N])."""
+        n = len(signals)
+        scan_size = int(scan_size)
+        keep = scan_size + self.input_size // 2      # samples any window can touch
+        parts = []
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        for i, s in enumerate(signals):
+            s = np.asarray(s)
+            if s.ndim != 1:
+                raise ValueError('signals must be one-dimensional')
+            if len(s) and (s.min() < -32768 or s.max() > 32767):
+                raise ValueError('signal values do not fit int16')
+            # only the scanned end of the read is shipped to the GPU; window contents and
+            # positions are unchanged by dropping samples no window reaches
+            part = s[:keep] if side == 'start' else s[max(len(s) - keep, 0):]
+            parts.append(np.asarray(part, dtype=np.int16))
+            offsets[i + 1] = offsets[i] + len(part)
+        samples = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int16)
+        samples = np.ascontiguousarray(samples, dtype=np.int16)
+        if samples.size == 0:
+            samples = np.zeros(1, dtype=np.int16)
+        probs = np.empty((n, self.n_classes), dtype=np.float32)
+        calls = np.empty(n, dtype=np.int32)
+        if n:
+            side_code = SIDE_START if side == 'start' else SIDE_END
+            check(self._lib.dbh_classify_i16(self._handle, samples, offsets, n, side_code,
+                                             scan_size, float(score_diff), probs, calls),
+                  'dbh_classify_i16')
+        return probs, calls
+
+    # -- device-resident entry points (inputs/outputs are raw device pointers) -----------------
+    def workspace_bytes(self, n_reads, scan_size):
+        n = ctypes.c_size_t(0)
+        check(self._lib.dbh_classify_workspace_bytes(self._handle, n_reads, int(scan_size),
+                                                     ctypes.byref(n)),
+              'dbh_classify_workspace_bytes')
+        return n.value
+
+    def classify_dev(self, samples_ptr, offsets_ptr, n_reads, side, scan_size, score_diff,
+                     probs_ptr, calls_ptr, workspace_ptr, stream=None):
+        check(self._lib.dbh_classify_i16_dev(self._handle, samples_ptr, offsets_ptr, n_reads,
+                                             SIDE_START if side == 'start' else SIDE_END,
+                                             int(scan_size), float(score_diff), probs_ptr,
+                                             calls_ptr, workspace_ptr, stream),
+              'dbh_classify_i16_dev')
+
+    def predict_dev(self, x_ptr, n_windows, probs_ptr, stream=None):
+        check(self._lib.dbh_predict_dev(self._handle, x_ptr, n_windows, probs_ptr, stream),
+              'dbh_predict_dev')
+
+    def timing_enable(self, enable=True):
+        check(self._lib.dbh_forward_timing_enable(self._handle, 1 if enable else 0),
+              'dbh_forward_timing_enable')
+
+    def timing_read(self):
+        ms, launches, windows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dbh_forward_timing_read(self._handle, ctypes.byref(ms),
+                                                ctypes.byref(launches), ctypes.byref(windows)),
+              'dbh_forward_timing_read')
+        return ms.value, launches.value, windows.value
+
+    # -- introspection ------------------------------------------------------------------------
+    def debug_stage(self, x, stage):
+        """Activations after stage 'A'..'G' (or 'logits') for windows x [N, 1024]."""
+        idx = {'A': 0, 'B': 1, 'C': 2, 'D': 3, 'E': 4, 'F': 5, 'G': 6, 'logits': 7}[stage]
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1, self.input_size))
+        per = ctypes.c_int64(0)
+        check(self._lib.dbh_stage_floats(idx, ctypes.byref(per)), 'dbh_stage_floats')
+        out = np.empty((x.shape[0], per.value), dtype=np.float32)
+        check(self._lib.dbh_debug_forward(self._handle, x, x.shape[0], idx, out),
+              'dbh_debug_forward')
+        shapes = {0: (512, 48), 1: (256, 48), 2: (128, 48), 3: (64, 48), 4: (32, 192),
+                  5: (16, 48), 6: (8, 48), 7: (32,)}
+        return out.reshape((x.shape[0],) + shapes[idx])
+
+
+def forward_kernel_info():
+    lib = load_library()
+    t, l, v = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.dbh_forward_kernel_info(ctypes.byref(t), ctypes.byref(l), ctypes.byref(v)),
+          'dbh_forward_kernel_info')
+    return {'threads_per_block': t.value, 'lds_bytes': l.value, 'vgprs': v.value}

@@ -1,0 +1,100 @@
+"""
+fast5 discovery and signal loading — mirror of the reference's ``deepbinner/load_fast5s.py``
+with h5py replaced by this package's own reader (``hdf5_lite``).
+
+Beyond the reference: ``iter_reads`` walks every read of a multi-read fast5 directly, which is
+what lets ``realtime`` skip the reference's ``multi_to_single_fast5`` subprocess
+(reference ``realtime.py:183-190``).
+"""
+
+import os
+import random
+import sys
+
+from . import hdf5_lite
+
+
+def _read_group(hdf5_file):
+    """The group holding ``read_id`` and ``Signal`` for a one-read file, or None
+    (reference load_fast5s.py:29-43)."""
+    keys = list(hdf5_file.keys())
+    if 'Raw' in keys:   # older format: exactly one read under /Raw/Reads
+        return list(hdf5_file['Raw/Reads/'].values())[0]
+    reads = [k for k in keys if k.startswith('read_')]
+    if len(reads) > 1:
+        sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
+    if not reads:
+        return None
+    return hdf5_file[reads[0] + '/Raw/']
+
+
+def get_read_id_and_signal(fast5_file):
+    """-> (read_id str, int16 ndarray); (None, None) for unreadable files
+    (reference load_fast5s.py:25-49)."""
+    try:
+        with hdf5_lite.File(str(fast5_file), 'r') as hdf5_file:
+            group = _read_group(hdf5_file)
+            if group is None:
+                return None, None
+            read_id = group.attrs['read_id'].decode()
+            signal = group['Signal'][:]
+        return read_id, signal
+    except (OSError, KeyError):
+        return None, None
+
+
+def iter_reads(fast5_file):
+    """Yield (read_id, signal) for every read of a single- or multi-read fast5."""
+    try:
+        with hdf5_lite.File(str(fast5_file), 'r') as hdf5_file:
+            keys = list(hdf5_file.keys())
+            if 'Raw' in keys:
+                groups = [list(hdf5_file['Raw/Reads/'].values())[0]]
+            else:
+                groups = [hdf5_file[k + '/Raw/'] for k in keys if k.startswith('read_')]
+            for group in groups:
+                yield group.attrs['read_id'].decode(), group['Signal'][:]
+    except (OSError, KeyError):
+        return
+
+
+def find_all_fast5s(directory, verbose=False):
+    if verbose:
+        print('Looking for fast5 files in {}... '.format(directory), file=sys.stderr, end='',
+              flush=True)
+    fast5s = [os.path.join(root, name)
+              for root, _, names in os.walk(str(directory))
+              for name in names if name.endswith('.fast5')]
+    if verbose:
+        print('{} {} found'.format(len(fast5s), 'fast5' if len(fast5s) == 1 else 'fast5s'),
+              file=sys.stderr)
+    return fast5s
+
+
+def determine_single_or_multi_fast5s(fast5s):
+    """Inspect up to five randomly chosen files (reference load_fast5s.py:67-90)."""
+    sample = list(fast5s)
+    random.shuffle(sample)
+    kinds = set()
+    for fast5_file in sample[:5]:
+        keys = get_root_level_keys(fast5_file)
+        if 'Raw' in keys:
+            kinds.add('single-old')
+            continue
+        read_count = sum(1 for k in keys if k.startswith('read_'))
+        if read_count == 1:
+            kinds.add('single-new')
+        elif read_count > 1:
+            kinds.add('multi')
+    if 'multi' in kinds and 'single-old' in kinds:
+        sys.exit('Error: your reads appear to be a mixture of old and new formats. Deepbinner '
+                 'can handle one or the other, but not both at once.')
+    return 'multi' if 'multi' in kinds else 'single'
+
+
+def get_root_level_keys(fast5_file):
+    try:
+        with hdf5_lite.File(str(fast5_file), 'r') as hdf5_file:
+            return list(hdf5_file.keys())
+    except OSError:
+        return []

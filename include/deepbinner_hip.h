@@ -1,0 +1,137 @@
+/*
+ * deepbinner_hip.h — C ABI of libdeepbinner_hip.so, the MI355X (gfx950) implementation of
+ * Deepbinner's classify hot path.
+ *
+ * The reference has no C ABI on this path: its only device boundary is the Keras call
+ *     labels = model.predict(input_signals, batch_size=args.batch_size)   deepbinner/classify.py:361
+ * on a model obtained from keras.models.load_model (classify.py:90), wrapped by call_batch
+ * (classify.py:325-384).  This header is what a binding for that boundary binds instead; it is
+ * modelled on the reference's own ctypes idiom for its one native library
+ * (deepbinner/dtw_semi_global.py:30-41: cdll.LoadLibrary, C-contiguous ndpointers, explicit
+ * restype/argtypes, caller-allocated outputs, plain-int sizes, scalar return code).
+ *
+ * Conventions
+ *   - every function returns a dbh_status (0 = DBH_OK); nothing throws or exits across the ABI;
+ *   - buffers are plain pointers + element counts, C-contiguous, little-endian;
+ *   - "_dev" variants take DEVICE pointers and a stream and do not synchronise; the others take
+ *     HOST pointers, copy, run and return when the result is in the caller's buffer;
+ *   - a model handle belongs to the device that was current when it was created; calls on one
+ *     handle must not overlap (the reference host code is single-threaded, classify.py:416-423).
+ */
+#ifndef DEEPBINNER_HIP_H
+#define DEEPBINNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DBH_OK = 0,
+    DBH_ERR_INVALID_ARGUMENT = 1,
+    DBH_ERR_NO_DEVICE = 2,        /* no gfx950-capable HIP device visible */
+    DBH_ERR_HIP = 3,              /* a HIP runtime call failed; see dbh_last_error() */
+    DBH_ERR_BAD_WEIGHTS = 4,      /* blob size does not match the Deepbinner architecture */
+    DBH_ERR_UNSUPPORTED = 5,      /* e.g. input_size != 1024 or n_classes > 32 */
+    DBH_ERR_OUT_OF_MEMORY = 6
+} dbh_status;
+
+typedef struct dbh_model dbh_model;      /* opaque: packed weights resident in HBM */
+typedef void* dbh_stream;                /* a hipStream_t */
+typedef void* dbh_event;                 /* a hipEvent_t */
+
+#define DBH_SIDE_START 0                 /* classify.py:343-344, windows right-padded  (:355) */
+#define DBH_SIDE_END 1                   /* classify.py:345-349, windows left-padded   (:357) */
+#define DBH_CALL_NONE 0                  /* barcode call 'none' (classify.py:289-290,295)   */
+#define DBH_WINDOW 1024                  /* model input size, classify.py:96                */
+
+/* ---- library / device ------------------------------------------------------------------ */
+const char* dbh_version(void);
+const char* dbh_status_string(int status);
+const char* dbh_last_error(void);                       /* text of the last DBH_ERR_HIP      */
+int dbh_device_count(int* count);
+int dbh_set_device(int ordinal);                        /* replaces set_tensorflow_threads' device_count, classify.py:416-423 */
+int dbh_get_device(int* ordinal);
+int dbh_device_name(int ordinal, char* buf, int buf_len);
+int dbh_device_synchronize(void);
+
+/* ---- raw device memory (so a host language needs no other GPU library) ----------------- */
+int dbh_malloc(void** dev_ptr, size_t bytes);
+int dbh_free(void* dev_ptr);
+int dbh_malloc_host(void** host_ptr, size_t bytes);     /* pinned, for overlapped H2D        */
+int dbh_free_host(void* host_ptr);
+int dbh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, dbh_stream stream);
+int dbh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, dbh_stream stream);
+int dbh_memcpy_d2d(void* dev_dst, const void* dev_src, size_t bytes, dbh_stream stream);
+int dbh_stream_create(dbh_stream* stream);
+int dbh_stream_destroy(dbh_stream stream);
+int dbh_stream_synchronize(dbh_stream stream);
+int dbh_event_create(dbh_event* event);
+int dbh_event_destroy(dbh_event event);
+int dbh_event_record(dbh_event event, dbh_stream stream);
+int dbh_event_synchronize(dbh_event event);
+int dbh_event_elapsed_ms(dbh_event start, dbh_event stop, float* ms);
+
+/* ---- model (replaces keras.models.load_model, classify.py:90) -------------------------- */
+/* weights: the canonical flat fp32 blob (deepbinner_amd/model_format.py): for conv 1..20
+ * kernel[k][C_in][C_out] then bias[C_out]; for batch-norm 1..7 gamma, beta, mean, variance.
+ * n_floats must equal the architecture's parameter count for n_classes (107,197 for 13). */
+int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int input_size,
+                     dbh_model** model);
+int dbh_model_destroy(dbh_model* model);
+int dbh_model_input_size(const dbh_model* model, int* input_size);   /* model.inputs[0].shape[1], classify.py:93-96  */
+int dbh_model_output_size(const dbh_model* model, int* n_classes);   /* model.outputs[0].shape[1], classify.py:94-97 */
+
+/* ---- seam b1: model.predict (classify.py:361) ------------------------------------------ */
+/* x: n_windows x 1024 fp32 (already normalised);  probs: n_windows x n_classes fp32 softmax. */
+int dbh_predict(dbh_model* model, const float* x_host, int64_t n_windows, float* probs_host);
+int dbh_predict_dev(dbh_model* model, const float* x_dev, int64_t n_windows, float* probs_dev,
+                    dbh_stream stream);
+
+/* ---- seam b2: call_batch (classify.py:325-384) ------------------------------------------ */
+/* samples: concatenated int16 raw signals; offsets[n_reads+1] delimit each read (any length
+ * >= 0).  For each read: scan_size/512 windows (classify.py:330-349), normalise
+ * (trim_signal.py:61-69, fp64), zero-pad (classify.py:352-357), forward pass, min/max merge
+ * (classify.py:368-374), make_sum_to_one (classify.py:387-393) and the top-2 threshold call
+ * (classify.py:285-295).  probs: n_reads x n_classes fp32; calls: n_reads int32, 0 = 'none'. */
+int dbh_classify_i16(dbh_model* model, const int16_t* samples_host, const int64_t* offsets_host,
+                     int64_t n_reads, int side, int scan_size, double score_diff,
+                     float* probs_host, int32_t* calls_host);
+/* device-resident variant; workspace_dev must hold dbh_classify_workspace_bytes() bytes. */
+int dbh_classify_workspace_bytes(const dbh_model* model, int64_t n_reads, int scan_size,
+                                 size_t* bytes);
+int dbh_classify_i16_dev(dbh_model* model, const int16_t* samples_dev, const int64_t* offsets_dev,
+                         int64_t n_reads, int side, int scan_size, double score_diff,
+                         float* probs_dev, int32_t* calls_dev, void* workspace_dev,
+                         dbh_stream stream);
+
+/* ---- pieces of seam b2, exposed for parity tests ---------------------------------------- */
+/* windows_dev: (n_reads * steps) x 1024 fp32, read-major (window index = read*steps + step). */
+int dbh_normalise_windows_dev(const int16_t* samples_dev, const int64_t* offsets_dev,
+                              int64_t n_reads, int side, int scan_size, float* windows_dev,
+                              dbh_stream stream);
+int dbh_merge_calls_dev(const float* window_probs_dev, int64_t n_reads, int steps, int n_classes,
+                        double score_diff, float* probs_dev, int32_t* calls_dev,
+                        dbh_stream stream);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+/* Activations after stage 'A'..'G'  for n_windows windows, row-major
+ * [window][position][channel]; out_host must hold n_windows * dbh_stage_floats(stage) floats. */
+int dbh_stage_floats(int stage, int64_t* floats_per_window);
+int dbh_debug_forward(dbh_model* model, const float* x_host, int64_t n_windows, int stage,
+                      float* out_host);
+/* name and static resource use of the forward kernel, for bench/roofline bookkeeping */
+int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs);
+/* Live kernel timing: while enabled, every launch of the forward kernel is bracketed by HIP events
+ * on the stream it is launched on; dbh_forward_timing_read synchronises those events, returns the
+ * summed kernel time, the number of launches and of windows they covered, and resets the tally. */
+int dbh_forward_timing_enable(dbh_model* model, int enable);
+int dbh_forward_timing_read(dbh_model* model, double* total_ms, int64_t* launches,
+                            int64_t* windows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPBINNER_HIP_H */

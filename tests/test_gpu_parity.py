@@ -1,0 +1,235 @@
+"""
+Parity of the HIP path with the oracle — the tests proper (need an MI355X; `-m gpu`).
+Everything goes through the C ABI (deepbinner_amd.hip_backend -> libdeepbinner_hip.so).
+
+Tolerances: softmax probabilities within 1e-4 absolute of the fp64 oracle (BASELINE.json
+north_star); the fp32-vs-fp64 spread of the oracle itself is < 2e-6, so the checks below use
+tighter bounds where the arithmetic allows.  Integer work (calls) must be identical.
+"""
+import argparse
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, PLAN, MODEL_DIR
+from oracle import classify_ref, network_ref
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-4
+
+
+def pack(signals):
+    offsets = np.zeros(len(signals) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(s) for s in signals])
+    samples = (np.concatenate(signals) if len(signals) and offsets[-1] else
+               np.zeros(0)).astype(np.int16)
+    return samples, offsets
+
+
+def call_names(calls):
+    return ['none' if c == 0 else str(int(c)) for c in calls]
+
+
+def test_native_library_is_loaded(hip):
+    maps = open('/proc/self/maps').read()
+    assert 'libdeepbinner_hip.so' in maps
+    info = hip.forward_kernel_info()
+    assert info['threads_per_block'] == 512 and info['lds_bytes'] > 100000
+
+
+# ---- per-stage activations -----------------------------------------------------------------
+@pytest.mark.parametrize('stage', ['A', 'B', 'C', 'D', 'E', 'F', 'G', 'logits'])
+def test_stage_activations(hip_models, stage):
+    g = np.load(os.path.join(GOLD, 'stages_EXP-NBD103_read_starts.npz'))
+    got = hip_models['EXP-NBD103_read_starts'].debug_stage(g['x'], stage)
+    want = g[stage]
+    if stage == 'logits':
+        got = got[:, :want.shape[1]]
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err < 2e-5 * scale, 'stage %s: max err %.3e (scale %.2f)' % (stage, err, scale)
+
+
+# ---- seam b1: predict ------------------------------------------------------------------------
+@pytest.mark.parametrize('model_name,side', PLAN)
+def test_predict_matches_oracle(hip_models, model_name, side):
+    x = np.load(os.path.join(GOLD, 'windows_%s.npy' % side)).reshape(-1, 1024)
+    want = np.load(os.path.join(GOLD, 'window_probs_%s_%s.npy' % (model_name, side)))
+    got = hip_models[model_name].predict(x[:, :, None], batch_size=256)
+    assert got.dtype == np.float32 and got.shape == want.shape and got.flags.writeable
+    assert np.abs(got - want).max() < PROB_TOL
+    assert np.array_equal(got.argmax(axis=1), want.argmax(axis=1))
+    assert np.abs(got.sum(axis=1) - 1).max() < 1e-5
+
+
+def test_predict_edge_inputs(hip_models, weights):
+    model = hip_models['EXP-NBD103_read_starts']
+    assert model.predict(np.zeros((0, 1024, 1))).shape == (0, 13)
+    rng = np.random.default_rng(1)
+    x = np.zeros((5, 1024), dtype=np.float32)
+    x[1] = 1.0
+    x[2] = rng.standard_normal(1024) * 50          # large amplitude
+    x[3, :7] = rng.standard_normal(7)              # nearly empty (short read, right padded)
+    x[4, -300:] = rng.standard_normal(300)         # left padded (end side)
+    got = model.predict(x)
+    want = network_ref.forward(weights['EXP-NBD103_read_starts'], x, dtype=np.float64)
+    assert np.abs(got - want).max() < PROB_TOL
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((3, 1000, 1)))
+
+
+def test_predict_is_order_and_batch_independent(hip_models):
+    """Size-independent properties at BASELINE config-2 size (10k windows)."""
+    model = hip_models['EXP-NBD103_read_starts']
+    base = np.load(os.path.join(GOLD, 'windows_start.npy')).reshape(-1, 1024)
+    rng = np.random.default_rng(20260927)
+    idx = rng.integers(0, len(base), size=10000)
+    x = base[idx] + (rng.standard_normal((10000, 1024)) * 0.01).astype(np.float32)
+    full = model.predict(x)
+    assert np.abs(full.sum(axis=1) - 1).max() < 1e-5 and np.isfinite(full).all()
+    perm = rng.permutation(10000)
+    assert np.array_equal(model.predict(x[perm]), full[perm])          # bit-exact
+    parts = np.concatenate([model.predict(x[i:i + 256]) for i in range(0, 10000, 256)])
+    assert np.array_equal(parts, full)
+    dup = model.predict(np.repeat(x[:3], 4, axis=0))
+    assert np.array_equal(dup[0], dup[3]) and np.array_equal(dup[4], dup[7])
+    # spot check against the oracle
+    from deepbinner_amd.model_format import ModelWeights
+    w, _ = ModelWeights.load(os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'))
+    want = network_ref.forward(w, x[:64], dtype=np.float64)
+    assert np.abs(full[:64] - want).max() < PROB_TOL
+
+
+# ---- seam b2: classify_i16 -------------------------------------------------------------------
+@pytest.mark.parametrize('model_name,side', PLAN)
+def test_classify_matches_reference_call_batch(hip_models, gold, all_signals, model_name, side):
+    probs, calls = hip_models[model_name].classify_signals(all_signals, side, 6144, 0.5)
+    assert call_names(calls) == gold['calls']['%s/%s' % (model_name, side)]
+    ref = np.load(os.path.join(GOLD, 'merged_%s_%s.npy' % (model_name, side)))
+    assert np.abs(probs - ref).max() < PROB_TOL
+
+
+@pytest.mark.parametrize('side', ['start', 'end'])
+def test_normalise_kernel(hip, gold, all_signals, side):
+    """int16 -> windows on the device == the reference's normalise + padding (float32 of fp64)."""
+    lib = hip.load_library()
+    samples, offsets = pack(all_signals)
+    d_s = hip.DeviceBuffer.from_array(samples)
+    d_o = hip.DeviceBuffer.from_array(offsets)
+    n = len(all_signals)
+    d_w = hip.DeviceBuffer(n * 12 * 1024 * 4)
+    hip.check(lib.dbh_normalise_windows_dev(d_s.ptr, d_o.ptr, n, 0 if side == 'start' else 1,
+                                            6144, d_w.ptr, None))
+    got = d_w.download((n, 12, 1024), np.float32)
+    ref = np.load(os.path.join(GOLD, 'windows_%s.npy' % side)).transpose(1, 0, 2)
+    # exact integer sums on the device vs NumPy's float64 reductions: <= 1 ulp of float32
+    assert np.abs(got - ref).max() <= 2.4e-7 * max(1.0, float(np.abs(ref).max()))
+    assert np.array_equal(got == 0, ref == 0)      # padding lands in exactly the same places
+
+
+def test_classify_ragged_and_degenerate_reads(hip_models, weights):
+    """Empty, tiny, flat, exactly-window-sized and long reads (classify.py:337-358 edge cases)."""
+    rng = np.random.default_rng(7)
+    signals = [np.zeros(0, dtype=np.int16),
+               np.array([500], dtype=np.int16),
+               np.full(300, 480, dtype=np.int16),                       # std == 0
+               rng.integers(300, 700, 511).astype(np.int16),
+               rng.integers(300, 700, 1024).astype(np.int16),
+               rng.integers(300, 700, 1025).astype(np.int16),
+               rng.integers(300, 700, 6144).astype(np.int16),
+               rng.integers(0, 2047, 20000).astype(np.int16),
+               rng.integers(-32768, 32767, 7000).astype(np.int16)]      # full int16 range
+    w = weights['EXP-NBD103_read_starts']
+    for side in ('start', 'end'):
+        for scan in (6144, 512, 1024):
+            probs, calls = hip_models['EXP-NBD103_read_starts'].classify_signals(
+                signals, side, scan, 0.5)
+            o_calls, o_probs = classify_ref.call_batch(
+                lambda x: network_ref.forward(w, x.astype(np.float32), dtype=np.float64),
+                signals, 1024, scan, 0.5, side)
+            assert call_names(calls) == o_calls
+            assert np.abs(probs - o_probs).max() < PROB_TOL
+    p, c = hip_models['EXP-NBD103_read_starts'].classify_signals([], 'start', 6144, 0.5)
+    assert p.shape == (0, 13) and c.shape == (0,)
+
+
+def test_merge_kernel_rules(hip):
+    """min for class 0 / max for barcodes / renormalise / top-2 threshold, incl. ties."""
+    lib = hip.load_library()
+    rng = np.random.default_rng(3)
+    n, steps, C = 1000, 12, 13
+    raw = rng.random((n, steps, C)).astype(np.float32) ** 4
+    raw /= raw.sum(axis=2, keepdims=True)
+    raw[0] = 1.0 / C                              # all-equal: best is class 0 by tie rule
+    raw[1, :, :] = 0
+    raw[1, :, 5] = 0.75
+    raw[1, :, 0] = 0.25                           # diff exactly 0.5 -> called
+    d_in = hip.DeviceBuffer.from_array(raw)
+    d_p = hip.DeviceBuffer(n * C * 4)
+    d_c = hip.DeviceBuffer(n * 4)
+    hip.check(lib.dbh_merge_calls_dev(d_in.ptr, n, steps, C, 0.5, d_p.ptr, d_c.ptr, None))
+    probs = d_p.download((n, C), np.float32)
+    calls = d_c.download((n,), np.int32)
+    merged = classify_ref.merge_steps(list(raw.transpose(1, 0, 2)))
+    want = np.stack([classify_ref.make_sum_to_one(r) for r in merged])
+    assert np.abs(probs - want).max() < 1e-6
+    assert call_names(calls) == [classify_ref.barcode_call(r, 0.5) for r in want]
+    assert calls[0] == 0 and calls[1] == 5
+
+
+def test_classify_many_reads_properties(hip_models, all_signals):
+    """100k-read scale (config 3 size) via invariants: tiling the 37 real reads must reproduce
+    their calls everywhere, in any order."""
+    reps = 2703                                    # 37 * 2703 = 100,011 reads
+    signals = [s[:7000] for s in all_signals] * reps
+    model = hip_models['EXP-NBD103_read_starts']
+    probs, calls = model.classify_signals(signals, 'start', 6144, 0.5)
+    base_p, base_c = probs[:37], calls[:37]
+    assert np.array_equal(calls.reshape(reps, 37), np.tile(base_c, (reps, 1)))
+    assert np.array_equal(probs.reshape(reps, 37, 13), np.broadcast_to(base_p, (reps, 37, 13)))
+    assert np.abs(probs.sum(axis=1) - 1).max() < 1e-5
+
+
+# ---- the drop-in surface on the real backend ---------------------------------------------------
+def test_end_to_end_fast5_classification(hip, capsys):
+    """reference tests/test_classify.py:143-160 + :272-296 through the real HipModel."""
+    import deepbinner_amd.classify as classify
+    import deepbinner_amd.load_fast5s as load_fast5s
+    from test_oracle_golden import EXPECTED_START, EXPECTED_END
+    args = argparse.Namespace(verbose=True, batch_size=128, scan_size=6144, score_diff=0.5,
+                              require_either=True, require_start=False, require_both=False)
+    fast5s = load_fast5s.find_all_fast5s(os.path.join(GOLD, 'fast5', 'single'))
+    sm, si, em, ei, osz, cnt = classify.load_and_check_models(
+        os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+        os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
+    assert type(sm).__name__ == 'HipModel' and (si, ei, osz, cnt) == (1024, 1024, 13, 2)
+    classifications, _ = classify.classify_fast5_files(fast5s, sm, si, em, ei, osz, args,
+                                                       full_output=True, summary_table=False)
+    assert classifications == EXPECTED_START
+    lines = capsys.readouterr().out.splitlines()
+    row = ['0.00', '0.00', '0.00', '1.00'] + ['0.00'] * 9
+    assert ('177c3867-6812-4476-a6da-9e4d5c43b760\t3\t' + '\t'.join(row + ['3'] + row + ['3'])) \
+        in lines
+    args.require_either, args.require_both = False, True
+    classifications, _ = classify.classify_fast5_files(fast5s, sm, si, em, ei, osz, args,
+                                                       full_output=False)
+    assert classifications == EXPECTED_END
+
+
+def test_b1_and_b2_seams_agree(hip_models, gold, all_signals):
+    """call_batch via model.predict (host windowing) == call_batch fully on the device."""
+    import deepbinner_amd.classify as classify
+    model = hip_models['EXP-NBD103_read_ends']
+    args = argparse.Namespace(scan_size=6144, batch_size=256, score_diff=0.5)
+
+    class PredictOnly:
+        def predict(self, x, batch_size=None):
+            return model.predict(x, batch_size)
+
+    ids = ['r%d' % i for i in range(len(all_signals))]
+    c1, p1 = classify.call_batch(1024, 13, ids, all_signals, PredictOnly(), args, 'end')
+    c2, p2 = classify.call_batch(1024, 13, ids, all_signals, model, args, 'end')
+    assert c1 == c2
+    assert np.abs(np.array(p1) - np.array(p2)).max() < 2e-6

@@ -1,0 +1,311 @@
+"""
+Host-side drop-in surface (CPU only): the reference's own tests restated against
+deepbinner_amd — tests/test_classify.py, test_combine_calls.py, test_load_fast5s.py — with the
+model object replaced by an oracle-backed double at seam b1 (conftest.oracle_backend), so the
+windowing / merge / call / TSV logic of deepbinner_amd.classify is what is under test.
+"""
+import argparse
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, MODEL_DIR
+from test_oracle_golden import EXPECTED_START, EXPECTED_END
+import deepbinner_amd.classify as classify
+import deepbinner_amd.load_fast5s as load_fast5s
+import deepbinner_amd.trim_signal as trim_signal
+from deepbinner_amd import hdf5_lite
+
+FAST5_DIR = os.path.join(GOLD, 'fast5', 'single')
+MULTI_DIR = os.path.join(GOLD, 'fast5', 'multi')
+START_MODEL = os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw')
+END_MODEL = os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw')
+SINGLE = os.path.join(FAST5_DIR, '5210_N128870_20180511_FAH70336_MN20200_sequencing_run_057_'
+                                 'Deepbinner_amplicon_43629_read_11206_ch_157_strand.fast5')
+ROW = ['0.00', '0.00', '0.00', '1.00'] + ['0.00'] * 9
+
+
+def make_args(**kw):
+    base = dict(verbose=False, batch_size=128, scan_size=6144, score_diff=0.5,
+                require_either=False, require_start=False, require_both=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+# ---- model loading (reference tests/test_classify.py:24-68) -------------------------------
+def test_load_2_models(oracle_backend):
+    out = io.StringIO()
+    sm, si, em, ei, osz, cnt = classify.load_and_check_models(START_MODEL, END_MODEL, 6144,
+                                                              out_dest=out)
+    assert (si, ei, osz, cnt) == (1024, 1024, 13, 2)
+    assert 'Loading' in out.getvalue() and 'done' in out.getvalue()
+
+
+def test_load_start_only(oracle_backend):
+    sm, si, em, ei, osz, cnt = classify.load_and_check_models(START_MODEL, None, 6144,
+                                                              out_dest=io.StringIO())
+    assert si == 1024 and em is None and ei is None and osz == 13 and cnt == 1
+
+
+def test_load_end_only(oracle_backend):
+    sm, si, em, ei, osz, cnt = classify.load_and_check_models(None, END_MODEL, 6144,
+                                                              out_dest=io.StringIO())
+    assert ei == 1024 and sm is None and si is None and osz == 13 and cnt == 1
+
+
+def test_bad_scan_size(oracle_backend):
+    with pytest.raises(SystemExit) as e:
+        classify.load_and_check_models(START_MODEL, END_MODEL, 6143, out_dest=io.StringIO())
+    assert '--scan_size must be a multiple' in str(e.value)
+
+
+def test_missing_and_invalid_model(oracle_backend, tmp_path):
+    with pytest.raises(SystemExit) as e:
+        classify.load_trained_model(str(tmp_path / 'nope'), out_dest=io.StringIO())
+    assert 'does not exist' in str(e.value)
+    bad = tmp_path / 'bad'
+    bad.write_bytes(b'not a model file at all' * 10)
+    with pytest.raises(SystemExit) as e:
+        classify.load_trained_model(str(bad), out_dest=io.StringIO())
+    assert 'model input has incorrect shape' in str(e.value)
+
+
+def test_build_model_has_no_cpu_fallback(monkeypatch, weights):
+    """Without a GPU the product path must fail loudly, never compute on the CPU."""
+    from deepbinner_amd import hip_backend
+    if hip_backend.device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    with pytest.raises(hip_backend.HipBackendError):
+        classify.build_model(weights['EXP-NBD103_read_starts'])
+
+
+# ---- end-to-end calls (reference tests/test_classify.py:104-180) ---------------------------
+@pytest.mark.parametrize('start,end,mode,expected', [
+    (True, False, None, EXPECTED_START),
+    (False, True, None, EXPECTED_END),
+    (True, True, 'require_either', EXPECTED_START),
+    (True, True, 'require_both', EXPECTED_END),
+])
+def test_fast5_classification(oracle_backend, capsys, start, end, mode, expected):
+    args = make_args(**({mode: True} if mode else {}))
+    fast5s = load_fast5s.find_all_fast5s(FAST5_DIR, verbose=True)
+    sm, si, em, ei, osz, _ = classify.load_and_check_models(
+        START_MODEL if start else None, END_MODEL if end else None, 6144,
+        out_dest=io.StringIO())
+    classifications, id_to_file = classify.classify_fast5_files(fast5s, sm, si, em, ei, osz, args,
+                                                                full_output=False)
+    assert classifications == expected
+    assert set(id_to_file) == set(expected)
+    out = capsys.readouterr().out
+    assert 'Classifying fast5s: 7 / 7 (100.0%)' in out     # full_output=False -> stdout
+
+
+# ---- exact TSV (reference tests/test_classify.py:182-296) ----------------------------------
+@pytest.mark.parametrize('start,end,verbose,header,row', [
+    (True, False, False, 'read_ID\tbarcode_call', '177c3867-6812-4476-a6da-9e4d5c43b760\t3'),
+    (True, False, True,
+     'read_ID\tbarcode_call\tnone\t1\t2\t3\t4\t5\t6\t7\t8\t9\t10\t11\t12',
+     '177c3867-6812-4476-a6da-9e4d5c43b760\t3\t' + '\t'.join(ROW)),
+    (False, True, True,
+     'read_ID\tbarcode_call\tnone\t1\t2\t3\t4\t5\t6\t7\t8\t9\t10\t11\t12',
+     '177c3867-6812-4476-a6da-9e4d5c43b760\t3\t' + '\t'.join(ROW)),
+    (True, True, False, 'read_ID\tbarcode_call', '177c3867-6812-4476-a6da-9e4d5c43b760\t3'),
+    (True, True, True,
+     'read_ID\tbarcode_call\t' + '\t'.join(['start_none'] + ['start_%d' % i for i in range(1, 13)]
+                                           + ['start_barcode_call', 'end_none']
+                                           + ['end_%d' % i for i in range(1, 13)]
+                                           + ['end_barcode_call']),
+     '177c3867-6812-4476-a6da-9e4d5c43b760\t3\t' + '\t'.join(ROW + ['3'] + ROW + ['3'])),
+])
+def test_tsv_output(oracle_backend, capsys, start, end, verbose, header, row):
+    args = make_args(verbose=verbose, require_either=start and end)
+    sm, si, em, ei, osz, _ = classify.load_and_check_models(
+        START_MODEL if start else None, END_MODEL if end else None, 6144,
+        out_dest=io.StringIO())
+    classifications, _ = classify.classify_fast5_files([SINGLE], sm, si, em, ei, osz, args,
+                                                       full_output=True, summary_table=False)
+    assert classifications['177c3867-6812-4476-a6da-9e4d5c43b760'] == '3'
+    lines = capsys.readouterr().out.splitlines()
+    assert lines == [header, row]
+
+
+def test_headers_match_reference(gold, capsys):
+    for key, want in gold['calls']['headers'].items():
+        verbose, st, en = (c == '1' for c in key)
+        classify.print_output_header(verbose, st, en, 13)
+        assert capsys.readouterr().out == want
+
+
+def test_summary_table(capsys):
+    from deepbinner_amd.misc import print_summary_table
+    import sys
+    print_summary_table({'a': '3', 'b': 'none', 'c': '12', 'd': '3'}, output=sys.stderr)
+    err = capsys.readouterr().err
+    assert err == '\nBarcode     Count\n      3         2\n     12         1\n   none         1\n\n'
+
+
+# ---- combine_calls (reference tests/test_combine_calls.py:27-51) ---------------------------
+def test_combine_calls_truth_table(gold):
+    for key, want in gold['calls']['combine_table'].items():
+        mode, s, e = key.split('|')
+        args = make_args(**{mode: True})
+        assert classify.combine_calls(s, e, args) == want
+    assert len(gold['calls']['combine_table']) == 15
+
+
+# ---- small functions ----------------------------------------------------------------------
+def test_barcode_call_rule():
+    f = classify.get_barcode_call_from_probabilities
+    assert f([0.6, 0.4, 0.0], 0.5) == 'none'            # best is class 0
+    assert f([0.1, 0.8, 0.1], 0.5) == '1'
+    assert f([0.3, 0.7, 0.0], 0.5) == 'none'            # runner-up may be class 0
+    assert f([0.2, 0.4, 0.4], 0.1) == 'none'            # tie -> lower index best, diff 0
+    assert f([0.25, 0.75, 0.0], 0.5) == '1'             # >= threshold
+
+
+def test_make_sum_to_one():
+    p = classify.make_sum_to_one(np.array([0.2, 0.9, 0.3, 0.4], dtype=np.float32))
+    assert p[0] == pytest.approx(0.2, abs=1e-7)
+    assert sum(p) == pytest.approx(1.0, abs=1e-7)
+    assert p[1] / p[2] == pytest.approx(3.0, rel=1e-6)
+
+
+def test_check_input_size():
+    classify.check_input_size(1024, 512)          # accepted by the reference too
+    with pytest.raises(SystemExit) as e:
+        classify.check_input_size(1023, 6144)
+    assert 'must be even' in str(e.value)
+    with pytest.raises(SystemExit) as e:
+        classify.check_input_size(1024, 1000)
+    assert 'acceptable values for --scan_size are 1024, 1536, 2048, 2560, 3072, 3584, etc' \
+        in str(e.value)
+
+
+def test_normalise_matches_reference_edges(gold):
+    edge = gold['calls']['normalise_edge']
+    assert list(trim_signal.normalise(np.array([], dtype=np.int16))) == edge['empty']
+    assert trim_signal.normalise(np.array([7, 7, 7], dtype=np.int16)).tolist() == edge['flat']
+    assert trim_signal.normalise(np.array([1, 2, 3, 4], dtype=np.int16)).tolist() == edge['ramp']
+
+
+def test_find_signal_start_pos(gold):
+    got = [trim_signal.find_signal_start_pos(s) for s in gold['signals']]
+    assert got == gold['calls']['trim_start']
+    for s, want in zip(gold['multi_signals'], gold['calls']['multi_trim_start']):
+        if want < 0:
+            with pytest.raises(trim_signal.CannotTrim):
+                trim_signal.find_signal_start_pos(s)
+        else:
+            assert trim_signal.find_signal_start_pos(s) == want
+    with pytest.raises(trim_signal.CannotTrim):
+        trim_signal.find_signal_start_pos(np.zeros(100, dtype=np.int16))
+
+
+def test_call_batch_b1_matches_reference(gold, all_signals, weights):
+    """Seam-b1 host path of call_batch == the reference's call_batch on the same predict."""
+    from conftest import OracleModel
+    ids = gold['read_ids'] + gold['multi_read_ids']
+    for model_name, side in (('EXP-NBD103_read_starts', 'start'), ('EXP-NBD103_read_ends', 'end')):
+        calls, probs = classify.call_batch(1024, 13, ids, all_signals,
+                                           OracleModel(weights[model_name]), make_args(), side)
+        assert calls == gold['calls']['%s/%s' % (model_name, side)]
+        ref = np.load(os.path.join(GOLD, 'merged_%s_%s.npy' % (model_name, side)))
+        assert np.abs(np.array(probs) - ref).max() < 1e-6
+    assert classify.call_batch(1024, 13, [], [], None, make_args(), 'start') == ([], [])
+
+
+def test_training_data_path(oracle_backend, gold, tmp_path, capsys):
+    path = tmp_path / 'train.txt'
+    with open(path, 'w') as f:
+        for label, sig in (('3', gold['signals'][0]), ('2', gold['signals'][1])):
+            f.write('%s\t%s\n' % (label, ','.join(str(int(v)) for v in sig[:2000])))
+    assert classify.determine_input_type(str(path)) == 'training_data'
+    sm, si, em, ei, osz, _ = classify.load_and_check_models(START_MODEL, None, 6144,
+                                                            out_dest=io.StringIO())
+    classify.classify_training_data(str(path), sm, si, em, ei, osz, make_args())
+    lines = capsys.readouterr().out.splitlines()
+    assert lines[0] == 'read_ID\tbarcode_call'
+    assert lines[1].startswith('line_1_barcode_3\t') and lines[2].startswith('line_2_barcode_2\t')
+
+
+# ---- fast5 loading (reference tests/test_load_fast5s.py:32-85) ------------------------------
+def test_find_all_fast5s(capsys):
+    assert len(load_fast5s.find_all_fast5s(FAST5_DIR)) == 7
+    assert len(load_fast5s.find_all_fast5s(FAST5_DIR, verbose=True)) == 7
+    err = capsys.readouterr().err
+    assert 'Looking for fast5 files' in err and '7 fast5s found' in err
+
+
+@pytest.mark.parametrize('name,read_id,length,first,idx,val', [
+    ('5210_N128870_20180511_FAH70336_MN20200_sequencing_run_057_Deepbinner_amplicon_43629_'
+     'read_11206_ch_157_strand.fast5', '177c3867-6812-4476-a6da-9e4d5c43b760', 4971, 714, 4950, 396),
+    ('5210_N128870_20180511_FAH70336_MN20200_sequencing_run_057_Deepbinner_amplicon_43629_'
+     'read_13863_ch_212_strand.fast5', '9bfcf22c-5654-4b4c-b8f7-d3cebd416338', 4983, 493, 4862, 618),
+    ('FAK33493_1336eeb8050cb1ca93d41712cf8e817516306473_1000000.fast5',
+     '2fbd86a4-029a-45cf-8f18-411d542572ba', 5395, 505, 5388, 436),
+])
+def test_get_read_id_and_signal(name, read_id, length, first, idx, val):
+    rid, signal = load_fast5s.get_read_id_and_signal(os.path.join(FAST5_DIR, name))
+    assert rid == read_id and len(signal) == length
+    assert signal[0] == first and signal[idx] == val and signal.dtype == np.int16
+
+
+def test_missing_fast5():
+    assert load_fast5s.get_read_id_and_signal(os.path.join(FAST5_DIR, 'not_a_real_file.fast5')) \
+        == (None, None)
+
+
+def test_single_or_multi():
+    single = load_fast5s.find_all_fast5s(FAST5_DIR)
+    multi = load_fast5s.find_all_fast5s(MULTI_DIR)
+    assert load_fast5s.determine_single_or_multi_fast5s(single) == 'single'
+    assert load_fast5s.determine_single_or_multi_fast5s(multi) == 'multi'
+
+
+def test_loader_matches_packed_golden(gold):
+    by_file = dict(zip(gold['files'], zip(gold['read_ids'], gold['signals'])))
+    for name, (rid, sig) in by_file.items():
+        got_id, got = load_fast5s.get_read_id_and_signal(os.path.join(FAST5_DIR, name))
+        assert got_id == rid and np.array_equal(got, sig)
+    multi = {}
+    for path in sorted(load_fast5s.find_all_fast5s(MULTI_DIR)):
+        for rid, sig in load_fast5s.iter_reads(path):
+            multi[rid] = sig
+    assert len(multi) == 30
+    for rid, sig in zip(gold['multi_read_ids'], gold['multi_signals']):
+        assert np.array_equal(multi[rid], sig)
+
+
+def test_multi_read_refused_by_classify(oracle_backend):
+    sm, si, em, ei, osz, _ = classify.load_and_check_models(START_MODEL, None, 6144,
+                                                            out_dest=io.StringIO())
+    with pytest.raises(SystemExit) as e:
+        classify.classify_fast5_files(load_fast5s.find_all_fast5s(MULTI_DIR), sm, si, em, ei, osz,
+                                      make_args())
+    assert 'requires one-read-per-file fast5s' in str(e.value)
+    with pytest.raises(SystemExit) as e:
+        classify.classify_fast5_files([], sm, si, em, ei, osz, make_args())
+    assert 'no fast5 files found' in str(e.value)
+
+
+def test_hdf5_reader_rejects_garbage(tmp_path):
+    p = tmp_path / 'x.fast5'
+    p.write_bytes(b'\x00' * 4096)
+    with pytest.raises(OSError):
+        hdf5_lite.File(str(p))
+    assert load_fast5s.get_root_level_keys(str(p)) == []
+    assert classify.determine_input_type(SINGLE) == 'single_fast5'
+    assert classify.determine_input_type(FAST5_DIR) == 'directory'
+
+
+def test_keras_model_file_import():
+    """The reference's own model files load through hdf5_lite (only where they are mounted)."""
+    ref = '/root/reference/models/EXP-NBD103_read_starts'
+    if not os.path.isfile(ref):
+        pytest.skip('reference checkout not present')
+    from deepbinner_amd.model_format import ModelWeights
+    w, shape = ModelWeights.load(ref)
+    assert shape == [None, 1024, 1] and w.n_classes == 13
+    assert np.array_equal(w.flat(), ModelWeights.load(START_MODEL)[0].flat())
