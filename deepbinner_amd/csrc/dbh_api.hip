@@ -134,7 +134,7 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
     for (int64_t off = 0; off < n; off += kChunk) {
         const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
         hipEvent_t ev_stop = nullptr;
-        if (m->timing && debug_stage < 0) {
+        if (m->timing && (debug_stage < 0 || debug_stage >= 100)) {
             if (m->events_used == m->events.size()) {
                 hipEvent_t a, b;
                 DBH_HIP(hipEventCreate(&a));
@@ -150,7 +150,7 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
                            stream, m->d_packed, x_dev + off * dbh::kWindow,
                            probs_dev ? probs_dev + off * m->n_classes : nullptr, m->n_classes,
                            debug_stage,
-                           debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 ? 0 : debug_stage]
+                           debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 || debug_stage > 7 ? 0 : debug_stage]
                                      : nullptr);
         DBH_HIP(hipGetLastError());
         if (ev_stop) DBH_HIP(hipEventRecord(ev_stop, stream));
@@ -520,6 +520,12 @@ int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs) 
     if (lds_bytes) *lds_bytes = (int)attr.sharedSizeBytes;
     if (vgprs) *vgprs = attr.numRegs;
     return DBH_OK;
+}
+
+int dbh_forward_truncated_dev(dbh_model* m, const float* x_dev, int64_t n, int last_stage,
+                              dbh_stream stream) {
+    if (!m || n <= 0 || !x_dev || last_stage < 0 || last_stage > 6) return DBH_ERR_INVALID_ARGUMENT;
+    return launch_forward(m, x_dev, n, nullptr, 100 + last_stage, nullptr, (hipStream_t)stream);
 }
 
 int dbh_forward_timing_enable(dbh_model* m, int enable) {

@@ -295,7 +295,8 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
 // The kernel.  grid = n_windows, block = 512.
 //   x      [n_windows][1024]   normalised windows (fp32)
 //   probs  [n_windows][n_classes]
-//   debug_stage >= 0: write the activations after stage 'A'+debug_stage to debug_out and stop.
+//   debug_stage in [0,7]: write the activations after stage 'A'+debug_stage to debug_out and
+//   stop; 100+k: stop after stage k without writing (per-stage timing); -1: full forward.
 // =============================================================================================
 __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, float* __restrict__ probs,
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const int n = lane & 15, q = lane >> 4;
     const long win = blockIdx.x;
     const float* xw = x + win * kWindow;
+    // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
+    const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
     {
@@ -338,8 +341,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         zero_row(lds + kActOff, 513, kS48, 48, tid);
         __syncthreads();
     }
-    if (debug_stage == 0) {
-        dump_stage(lds + kActOff, kS48, 512, 48, debug_out + win * kStageFloats[0], tid);
+    if (stop_stage == 0) {
+        if (debug_stage < 100)
+            dump_stage(lds + kActOff, kS48, 512, 48, debug_out + win * kStageFloats[0], tid);
         return;
     }
 
@@ -350,8 +354,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         lds, packed, packed + weight_offset(3), lds + kW0, tid, lane, wave);
     inplace_layer<3, kW0, 512, kS48, kS48, true, 1, conv_weight_floats(4)>(
         lds, packed, packed + weight_offset(4), lds + kW1, tid, lane, wave);
-    if (debug_stage == 1) {
-        dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
+    if (stop_stage == 1) {
+        if (debug_stage < 100)
+            dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
         return;
     }
 
@@ -362,8 +367,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave);
     inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
         lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave);
-    if (debug_stage == 2) {
-        dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
+    if (stop_stage == 2) {
+        if (debug_stage < 100)
+            dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
         return;
     }
 
@@ -373,8 +379,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // conv9 prefetches ALL inception weights (conv10..16) into their stage-E home.
     inplace_layer<8, kW1, 128, kS48, kS48, true, 3, kEWFloats>(
         lds, packed, packed + weight_offset(9), lds + kEW, tid, lane, wave);
-    if (debug_stage == 3) {
-        dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);
+    if (stop_stage == 3) {
+        if (debug_stage < 100)
+            dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);
         return;
     }
 
@@ -453,8 +460,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         }
         __syncthreads();
     }
-    if (debug_stage == 4) {
-        dump_stage(lds + kECat, kS192, 32, 192, debug_out + win * kStageFloats[4], tid);
+    if (stop_stage == 4) {
+        if (debug_stage < 100)
+            dump_stage(lds + kECat, kS192, 32, 192, debug_out + win * kStageFloats[4], tid);
         return;
     }
 
@@ -465,16 +473,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     zero_row(lds + kG1, 17, kS48, 48, tid);
     for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
     splitk_layer<16, kS192, 2, 2, false, 5>(lds, lds + kECat, lds + kFOut, packed, tid, lane, wave);
-    if (debug_stage == 5) {
-        dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
+    if (stop_stage == 5) {
+        if (debug_stage < 100)
+            dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
         return;
     }
 
     // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
     splitk_layer<17, kS48, 1, 2, false, -1>(lds, lds + kFOut, lds + kG1, packed, tid, lane, wave);
     splitk_layer<18, kS48, 1, 2, true, 6>(lds, lds + kG1, lds + kG2, packed, tid, lane, wave);
-    if (debug_stage == 6) {
-        dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
+    if (stop_stage == 6) {
+        if (debug_stage < 100)
+            dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
         return;
     }
 

@@ -124,6 +124,10 @@ int dbh_debug_forward(dbh_model* model, const float* x_host, int64_t n_windows, 
                       float* out_host);
 /* name and static resource use of the forward kernel, for bench/roofline bookkeeping */
 int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs);
+/* Run the forward kernel only up to and including stage last_stage (0 = 'A' .. 6 = 'G'), writing
+ * nothing: lets a profiler attribute kernel time to stages by differencing. */
+int dbh_forward_truncated_dev(dbh_model* model, const float* x_dev, int64_t n_windows,
+                              int last_stage, dbh_stream stream);
 /* Live kernel timing: while enabled, every launch of the forward kernel is bracketed by HIP events
  * on the stream it is launched on; dbh_forward_timing_read synchronises those events, returns the
  * summed kernel time, the number of launches and of windows they covered, and resets the tally. */
