@@ -4,7 +4,7 @@ bench.py — reads classified/sec on the Deepbinner classify hot path (BASELINE.
 
 Workload (BASELINE.json configs[1]): EXP-NBD103_read_starts, 10,000 synthetic 1024-sample int16
 signals, batch 256, per GPU.  One STEP = one pass of the whole hot path over those 10,000 reads in
-batches of 256 through seam b2 (`dbh_classify_i16_dev`: window slice + fp64 z-normalise + the
+batches of 256 through seam b2 (`dbh_classify_i16_batched_dev`: window slice + fp64 z-normalise + the
 20-conv CNN + merge + renormalise + barcode call), with `--scan_size 512` so each 1024-sample read
 is exactly one full window (classify.py:401-402 accepts it) — i.e. 1 read = 1 window = one
 classification.  Inputs are resident in HBM before the timed region; per-read calls are gathered
@@ -114,8 +114,7 @@ def main():
     # ---- inputs resident in HBM (rank-specific seed: every GPU has its own 10,000 reads) ------
     reads = synthetic_reads(N_READS, 20260927 + rank)
     d_samples = hip_backend.DeviceBuffer.from_array(reads)
-    # per-batch offsets are identical (fixed 1024-sample reads): one offsets array, reused
-    d_offsets = hip_backend.DeviceBuffer.from_array(np.arange(BATCH + 1, dtype=np.int64) * 1024)
+    d_offsets = hip_backend.DeviceBuffer.from_array(np.arange(N_READS + 1, dtype=np.int64) * 1024)
     d_probs = hip_backend.DeviceBuffer(N_READS * model.n_classes * 4)
     if world > 1:
         calls_t = torch.empty(N_READS, dtype=torch.int32, device='cuda')
@@ -124,14 +123,12 @@ def main():
     else:
         d_calls = hip_backend.DeviceBuffer(N_READS * 4)
         calls_ptr = d_calls.ptr
-    d_work = hip_backend.DeviceBuffer(model.workspace_bytes(BATCH, SCAN_SIZE))
-    batches = [(s, min(BATCH, N_READS - s)) for s in range(0, N_READS, BATCH)]
-
+    # One C-ABI call per step: the library walks the 10,000 reads in batches of 256 as a
+    # three-stage pipeline on its own HIP streams (normalise(i+1) | CNN(i) | merge(i-1)); the CNN
+    # launches run back to back on one stream, which is also where their HIP events are recorded.
     def step():
-        for start, count in batches:
-            model.classify_dev(d_samples.ptr + start * 1024 * 2, d_offsets.ptr, count, 'start',
-                               SCAN_SIZE, SCORE_DIFF, d_probs.ptr + start * model.n_classes * 4,
-                               calls_ptr + start * 4, d_work.ptr, None)
+        model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, N_READS, BATCH, 'start',
+                                   SCAN_SIZE, SCORE_DIFF, d_probs.ptr, calls_ptr, None)
         if world > 1:
             dist.all_gather_into_tensor(gathered, calls_t)
 
@@ -178,6 +175,7 @@ def main():
                                'merge + call), scan_size {} => 1 window per read, inputs resident '
                                'in HBM'.format(MODEL, N_READS, BATCH, SCAN_SIZE),
                    'reads_per_step_per_gpu': N_READS, 'batch': BATCH, 'windows_per_read': 1,
+                   'pipeline': 'normalise | CNN | merge on 3 HIP streams, depth 4',
                    'parallelism': 'reads sharded, {} rank(s), RCCL all_gather of calls'.format(world)
                    if world > 1 else 'single GPU'},
     }

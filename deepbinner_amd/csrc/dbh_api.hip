@@ -105,6 +105,13 @@ struct dbh_model {
     void* d_in = nullptr;      size_t in_bytes = 0;
     void* d_work = nullptr;    size_t work_bytes = 0;
     void* d_out = nullptr;     size_t out_bytes = 0;
+    // three-stage pipeline of dbh_classify_i16_batched_dev
+    static constexpr int kDepth = 4;
+    bool pipe_ready = false;
+    hipStream_t s_norm = nullptr, s_fwd = nullptr, s_merge = nullptr;
+    hipEvent_t ev_norm[kDepth] = {}, ev_fwd[kDepth] = {}, ev_merge[kDepth] = {};
+    hipEvent_t ev_begin = nullptr, ev_end[3] = {};
+    void* d_pipe = nullptr;    size_t pipe_bytes = 0;
     // live timing of the forward kernel (dbh_forward_timing_*)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -328,6 +335,19 @@ int dbh_model_destroy(dbh_model* m) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    if (m->pipe_ready) {
+        for (int i = 0; i < dbh_model::kDepth; ++i) {
+            (void)hipEventDestroy(m->ev_norm[i]);
+            (void)hipEventDestroy(m->ev_fwd[i]);
+            (void)hipEventDestroy(m->ev_merge[i]);
+        }
+        (void)hipEventDestroy(m->ev_begin);
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(m->ev_end[i]);
+        (void)hipStreamDestroy(m->s_norm);
+        (void)hipStreamDestroy(m->s_fwd);
+        (void)hipStreamDestroy(m->s_merge);
+    }
+    if (m->d_pipe) (void)hipFree(m->d_pipe);
     delete m;
     return DBH_OK;
 }
@@ -435,6 +455,80 @@ int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t
     if (st != DBH_OK) return st;
     return dbh_merge_calls_dev(wprobs, n_reads, steps, m->n_classes, score_diff, probs_dev,
                                calls_dev, stream);
+}
+
+int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
+                                 const int64_t* offsets_dev, int64_t n_reads, int batch_size,
+                                 int side, int scan_size, double score_diff, float* probs_dev,
+                                 int32_t* calls_dev, dbh_stream stream) {
+    if (!m || n_reads < 0 || batch_size <= 0) return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    const int steps = steps_for(scan_size);
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
+        (side != DBH_SIDE_START && side != DBH_SIDE_END) || !samples_dev || !offsets_dev ||
+        !probs_dev || !calls_dev)
+        return DBH_ERR_INVALID_ARGUMENT;
+    constexpr int D = dbh_model::kDepth;
+    if (!m->pipe_ready) {
+        DBH_HIP(hipStreamCreateWithFlags(&m->s_norm, hipStreamNonBlocking));
+        DBH_HIP(hipStreamCreateWithFlags(&m->s_fwd, hipStreamNonBlocking));
+        DBH_HIP(hipStreamCreateWithFlags(&m->s_merge, hipStreamNonBlocking));
+        for (int i = 0; i < D; ++i) {
+            DBH_HIP(hipEventCreateWithFlags(&m->ev_norm[i], hipEventDisableTiming));
+            DBH_HIP(hipEventCreateWithFlags(&m->ev_fwd[i], hipEventDisableTiming));
+            DBH_HIP(hipEventCreateWithFlags(&m->ev_merge[i], hipEventDisableTiming));
+        }
+        DBH_HIP(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i)
+            DBH_HIP(hipEventCreateWithFlags(&m->ev_end[i], hipEventDisableTiming));
+        m->pipe_ready = true;
+    }
+    // one workspace slot per in-flight batch: windows (fp32) + per-window probabilities
+    const size_t slot_windows = (size_t)batch_size * steps;
+    const size_t slot_bytes =
+        ((slot_windows * (dbh::kWindow + m->n_classes) * sizeof(float)) + 255) & ~(size_t)255;
+    int st = ensure(&m->d_pipe, &m->pipe_bytes, slot_bytes * D);
+    if (st != DBH_OK) return st;
+
+    hipStream_t caller = (hipStream_t)stream;
+    DBH_HIP(hipEventRecord(m->ev_begin, caller));
+    DBH_HIP(hipStreamWaitEvent(m->s_norm, m->ev_begin, 0));
+    DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_begin, 0));
+    DBH_HIP(hipStreamWaitEvent(m->s_merge, m->ev_begin, 0));
+
+    int64_t i = 0;
+    for (int64_t r0 = 0; r0 < n_reads; r0 += batch_size, ++i) {
+        const int64_t cnt = (n_reads - r0 < batch_size) ? (n_reads - r0) : batch_size;
+        const int k = (int)(i % D);
+        float* x = (float*)((char*)m->d_pipe + slot_bytes * k);
+        float* wprobs = x + slot_windows * dbh::kWindow;
+        if (i >= D) {
+            // slot reuse: the windows must have been consumed by the forward pass of batch i-D,
+            // its per-window probabilities by that batch's merge
+            DBH_HIP(hipStreamWaitEvent(m->s_norm, m->ev_fwd[k], 0));
+            DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_merge[k], 0));
+        }
+        st = dbh_normalise_windows_dev(samples_dev, offsets_dev + r0, cnt, side, scan_size, x,
+                                       (dbh_stream)m->s_norm);
+        if (st != DBH_OK) return st;
+        DBH_HIP(hipEventRecord(m->ev_norm[k], m->s_norm));
+        DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_norm[k], 0));
+        st = launch_forward(m, x, cnt * steps, wprobs, -1, nullptr, m->s_fwd);
+        if (st != DBH_OK) return st;
+        DBH_HIP(hipEventRecord(m->ev_fwd[k], m->s_fwd));
+        DBH_HIP(hipStreamWaitEvent(m->s_merge, m->ev_fwd[k], 0));
+        st = dbh_merge_calls_dev(wprobs, cnt, steps, m->n_classes, score_diff,
+                                 probs_dev + r0 * m->n_classes, calls_dev + r0,
+                                 (dbh_stream)m->s_merge);
+        if (st != DBH_OK) return st;
+        DBH_HIP(hipEventRecord(m->ev_merge[k], m->s_merge));
+    }
+    hipStream_t all[3] = {m->s_norm, m->s_fwd, m->s_merge};
+    for (int j = 0; j < 3; ++j) {
+        DBH_HIP(hipEventRecord(m->ev_end[j], all[j]));
+        DBH_HIP(hipStreamWaitEvent(caller, m->ev_end[j], 0));
+    }
+    return DBH_OK;
 }
 
 int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* offsets_host,

@@ -19,8 +19,8 @@
 //     straight from L2 (the L = 16 / 8 tail, where each weight is used once per window);
 //   accumulators stay in registers until the whole layer has been read, so layers at L = 512
 //     update the single 104 KiB activation buffer in place (barrier, write, barrier);
-//   the next layer's weights are fetched into registers while the current layer's MFMAs run
-//     and dropped into the LDS weight buffer behind the same barrier.
+//   the next layer's weights are copied L2 -> LDS by the DMA path (global_load_lds_dwordx4)
+//     into the other of two weight buffers while the current layer's MFMAs run.
 #include <hip/hip_runtime.h>
 
 #include "dbh_layout.h"
@@ -47,30 +47,56 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 //           SP <= SPTOT is how many channel-pairs groups this call walks (split-K).
 // All offsets are compile-time so every access is base + immediate.
 // ---------------------------------------------------------------------------------------------
+template <int MT, int NT>
+struct Frags {
+    f2 a[MT];
+    f2 b[NT];
+};
+
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
+__device__ __forceinline__ void load_frags(Frags<MT, NT>& f, const float* a_lane,
+                                           const float* b_lane, int it) {
+    const int tap = it / SP, sp = it % SP;   // 'it' is a compile-time constant after unrolling
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        f.a[m] = *reinterpret_cast<const f2*>(a_lane + (m * MROWS + tap) * S + sp * 8);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        f.b[t] = *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * NTTOT + t) * 128);
+}
+
+// Software-pipelined: the fragments of step it+1 are requested before the MFMAs of step it are
+// issued.  MFMA intrinsics are pure, so neither instruction selection nor sched_barrier alone
+// keeps them where the source puts them (hipcc sank two thirds of them to the end of the layer
+// and spilled the fragments they pinned); the empty asm statements tie every accumulator chain
+// to its step and fence the LDS loads, which pins the schedule without emitting an instruction.
 template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
 __device__ __forceinline__ void conv_tiles(const float* a_lane, const float* b_lane,
                                            f4 (&acc)[MT][NT]) {
+    constexpr int NIT = TAPS * SP;
+    Frags<MT, NT> buf[2];
+    load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS>(buf[0], a_lane, b_lane, 0);
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int it = 0; it < NIT; ++it) {
+        if (it + 1 < NIT)
+            load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS>(buf[(it + 1) & 1], a_lane,
+                                                                 b_lane, it + 1);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const Frags<MT, NT>& f = buf[it & 1];
 #pragma unroll
-        for (int sp = 0; sp < SP; ++sp) {
-            f2 a[MT], b[NT];
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                a[m] = *reinterpret_cast<const f2*>(a_lane + (m * MROWS + tap) * S + sp * 8);
+            for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].x, f.b[t].x, acc[m][t]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                b[t] = *reinterpret_cast<const f2*>(b_lane +
-                                                    ((tap * SPTOT + sp) * NTTOT + t) * 128);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].y, f.b[t].y, acc[m][t]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(a[m].x, b[t].x, acc[m][t]);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(a[m].y, b[t].y, acc[m][t]);
-        }
+            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[m][t]));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -91,19 +117,30 @@ __device__ __forceinline__ void zero_acc(f4 (&acc)[MT][NT]) {
 // Order per element: +bias, ReLU, [max over the position pair], [x*scale + shift]  —
 // conv -> ReLU -> MaxPool -> BatchNorm exactly as network_architecture.py:34-40 orders them.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int S_OUT, bool POOL, bool BN>
-__device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lane,
-                                         const float* __restrict__ bias_lane,
+// Per-lane epilogue constants, fetched from L2 BEFORE the layer's MFMA loop so their latency
+// hides under it (a load issued after the barrier would stall every layer by an L2 round trip).
+template <int NT, bool BN>
+struct EpiParams {
+    float b[NT], sc[NT], sh[NT];
+    __device__ __forceinline__ void load(const float* __restrict__ bias_lane,
                                          const float* __restrict__ scale_lane,
                                          const float* __restrict__ shift_lane) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float b = bias_lane[t * 16];
-        float sc = 1.f, sh = 0.f;
-        if (BN) {
-            sc = scale_lane[t * 16];
-            sh = shift_lane[t * 16];
+        for (int t = 0; t < NT; ++t) {
+            b[t] = bias_lane[t * 16];
+            sc[t] = BN ? scale_lane[t * 16] : 1.f;
+            sh[t] = BN ? shift_lane[t * 16] : 0.f;
         }
+    }
+};
+
+template <int MT, int NT, int S_OUT, bool POOL, bool BN>
+__device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lane,
+                                         const EpiParams<NT, BN>& ep) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float b = ep.b[t];
+        const float sc = ep.sc[t], sh = ep.sh[t];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float v0 = fmaxf(acc[m][t].x + b, 0.f);
@@ -188,6 +225,9 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     const int n = lane & 15, q = lane >> 4;
 
     dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
+    EpiParams<NT, BN> ep;
+    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
+            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
 
     f4 acc[MT][NT];
     zero_acc(acc);
@@ -201,10 +241,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
 
     float* out_lane = lds + kActOff +
                       (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
-    const float* bias_lane = packed + bias_offset(CONV) + n;
-    const float* scale_lane = packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n;
-    const float* shift_lane = packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n;
-    epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+    epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, ep);
     zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
     zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
 
@@ -212,32 +249,70 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// A small-M layer (one 16-position tile: conv17/18/19): weights straight from global, the
-// contraction split over KS groups of 3 waves (one per N tile), partial tiles summed via LDS.
+// A small-M layer (one 16-position tile: conv17/18/19).  Each weight is used once per window,
+// so B fragments skip LDS: every wave fetches its share from L2 into registers one stage AHEAD
+// (SplitKRegs::prefetch) and the contraction is split over KS groups of 3 waves (one per N
+// tile) whose partial tiles are summed through LDS.
 // ---------------------------------------------------------------------------------------------
-template <int CONV, int S_IN, int STRIDE, int KS, bool POOL, int BNI>
-__device__ __forceinline__ void splitk_layer(float* lds, const float* in_region, float* out_region,
-                                             const float* __restrict__ packed, int tid, int lane,
-                                             int wave) {
-    constexpr int TAPS = kConv[CONV].taps;
-    constexpr int SPTOT = kConv[CONV].cin / 8;
-    constexpr int SP = SPTOT / KS;
+template <int CONV, int KS, bool BN>
+struct SplitKRegs {
+    static constexpr int TAPS = kConv[CONV].taps;
+    static constexpr int SPTOT = kConv[CONV].cin / 8;
+    static constexpr int SP = SPTOT / KS;
     static_assert(SP * KS == SPTOT, "split-K must divide C_in/8");
     static_assert(3 * KS <= kWaves, "not enough waves for this split");
-    constexpr bool BN = BNI >= 0;
+    f2 b[TAPS * SP];
+    EpiParams<1, BN> ep;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int bn_index,
+                                             int lane, int wave) {
+        if (wave < 3 * KS) {
+            const int t = wave % 3, ks = wave / 3;
+            const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t) * 128 + lane * 2;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp)
+                    b[tap * SP + sp] =
+                        *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * 3) * 128);
+        }
+        if (wave < 3) {
+            const int ch = wave * 16 + (lane & 15);
+            ep.load(packed + bias_offset(CONV) + ch,
+                    packed + (BN ? bn_scale_offset(bn_index) : 0) + ch,
+                    packed + (BN ? bn_shift_offset(bn_index) : 0) + ch);
+        }
+    }
+};
+
+template <int CONV, int S_IN, int STRIDE, int KS, bool POOL, bool BN>
+__device__ __forceinline__ void splitk_layer(float* lds, const float* in_region, float* out_region,
+                                             const SplitKRegs<CONV, KS, BN>& regs, int lane,
+                                             int wave) {
+    constexpr int TAPS = SplitKRegs<CONV, KS, BN>::TAPS;
+    constexpr int SP = SplitKRegs<CONV, KS, BN>::SP;
     const int n = lane & 15, q = lane >> 4;
 
     if (wave < 3 * KS) {
         const int t = wave % 3, ks = wave / 3;
-        f4 acc[1][1];
-        zero_acc(acc);
         // stride-2 'same' pads on the right only: logical row 2p+tap = physical row 2p+tap+1;
         // stride-1 'same' k=3: physical row p+tap.
         const int first = (STRIDE == 2) ? 1 : 0;
         const float* a_lane = in_region + (first + n * STRIDE) * S_IN + 2 * q + ks * SP * 8;
-        const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t) * 128 + lane * 2;
-        conv_tiles<TAPS, SP, SPTOT, 1, 1, 3, S_IN, 16 * STRIDE>(a_lane, b_lane, acc);
-        *reinterpret_cast<f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4) = acc[0][0];
+        // two accumulator chains so consecutive MFMAs never wait on each other
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            f2 a[SP];
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp)
+                a[sp] = *reinterpret_cast<const f2*>(a_lane + tap * S_IN + sp * 8);
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp) {
+                acc0 = mfma4(a[sp].x, regs.b[tap * SP + sp].x, acc0);
+                acc1 = mfma4(a[sp].y, regs.b[tap * SP + sp].y, acc1);
+            }
+        }
+        *reinterpret_cast<f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4) = acc0 + acc1;
     }
     __syncthreads();
     if (wave < 3) {
@@ -248,10 +323,7 @@ __device__ __forceinline__ void splitk_layer(float* lds, const float* in_region,
         for (int ks = 1; ks < KS; ++ks)
             acc[0][0] += *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
         float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
-        const float* bias_lane = packed + bias_offset(CONV) + t * 16 + n;
-        const float* scale_lane = packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + t * 16 + n;
-        const float* shift_lane = packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + t * 16 + n;
-        epilogue<1, 1, kS48, POOL, BN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+        epilogue<1, 1, kS48, POOL, BN>(acc, out_lane, regs.ep);
     }
     __syncthreads();
 }
@@ -265,16 +337,19 @@ __device__ __forceinline__ void inception_1x1(const float* in_region, const floa
                                               const float* __restrict__ shift_lane, int t,
                                               int lane) {
     const int n = lane & 15, q = lane >> 4;
+    EpiParams<1, POOLBN> ep;
+    ep.load(bias_lane, scale_lane, shift_lane);
     f4 acc[4][1];
     zero_acc(acc);
     conv_tiles<1, 6, 6, 4, 1, NTTOT, kS48, 16>(in_region + (n + 1) * kS48 + 2 * q,
                                                w_lds + t * 128 + lane * 2, acc);
     float* out_lane = out_region + (1 + (POOLBN ? 2 * q : 4 * q)) * S_OUT + out_ch + n;
-    epilogue<4, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+    epilogue<4, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, ep);
 }
 
-// k=3 convolution of the inception block over MT position tiles starting at tile m0.
-template <int SP, int MT, int S_IN, int S_OUT, bool POOLBN>
+// k=3 convolution of the inception block: MT position tiles from tile m0 x NT channel tiles
+// from tile t (pointers are for channel tile t; NT > 1 walks on in steps of 16 channels).
+template <int SP, int MT, int NT, int S_IN, int S_OUT, bool POOLBN>
 __device__ __forceinline__ void inception_k3(const float* in_region, const float* w_lds,
                                              float* out_region, int out_ch,
                                              const float* __restrict__ bias_lane,
@@ -282,13 +357,15 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
                                              const float* __restrict__ shift_lane, int t, int m0,
                                              int lane) {
     const int n = lane & 15, q = lane >> 4;
-    f4 acc[MT][1];
+    EpiParams<NT, POOLBN> ep;
+    ep.load(bias_lane, scale_lane, shift_lane);
+    f4 acc[MT][NT];
     zero_acc(acc);
-    conv_tiles<3, SP, SP, MT, 1, 3, S_IN, 16>(in_region + (m0 * 16 + n) * S_IN + 2 * q,
-                                              w_lds + t * 128 + lane * 2, acc);
+    conv_tiles<3, SP, SP, MT, NT, 3, S_IN, 16>(in_region + (m0 * 16 + n) * S_IN + 2 * q,
+                                               w_lds + t * 128 + lane * 2, acc);
     float* out_lane = out_region +
                       (1 + (POOLBN ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + out_ch + n;
-    epilogue<MT, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, bias_lane, scale_lane, shift_lane);
+    epilogue<MT, NT, S_OUT, POOLBN, POOLBN>(acc, out_lane, ep);
 }
 
 // =============================================================================================
@@ -313,30 +390,33 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
+    // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
+    // straight from global (k = lane>>4 picks the tap), B[k][n] = w[k][n].  One MFMA per
+    // (position tile, N tile); the standard epilogue applies bias, ReLU and BN1.
     {
         dma_weights<conv_weight_floats(1)>(packed + weight_offset(1), lds + kW0, lane, wave);
-        const int p = tid;   // 512 threads <-> 512 output positions
-        const float x0 = xw[2 * p], x1 = xw[2 * p + 1];
-        const float x2 = (2 * p + 2 < kWindow) ? xw[2 * p + 2] : 0.f;
-        const float* w = packed + weight_offset(0);
-        const float* bias = packed + bias_offset(0);
-        const float* sc = packed + bn_scale_offset(0);
-        const float* sh = packed + bn_shift_offset(0);
-        float* row = lds + kActOff + (p + 1) * kS48;
+        constexpr int MT = 512 / 16 / kWaves;
+        const int m0 = wave * MT;
+        float a[MT], bw[3];
 #pragma unroll
-        for (int c4 = 0; c4 < 12; ++c4) {
-            f4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = c4 * 4 + i;
-                float v = fmaf(w[c], x0, bias[c]);
-                v = fmaf(w[48 + c], x1, v);
-                v = fmaf(w[96 + c], x2, v);
-                v = fmaxf(v, 0.f);
-                o[i] = fmaf(v, sc[c], sh[c]);
-            }
-            *reinterpret_cast<f4*>(row + c4 * 4) = o;
+        for (int m = 0; m < MT; ++m) {
+            const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
+            a[m] = (q < 3 && idx < kWindow) ? xw[idx] : 0.f;      // idx == 1024: right padding
         }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
+        f4 acc[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc[m][t] = mfma4(a[m], bw[t], f4{0.f, 0.f, 0.f, 0.f});
+        EpiParams<3, true> ep;
+        ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
+                packed + bn_shift_offset(0) + n);
+        float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
+        epilogue<MT, 3, kS48, false, true>(acc, out_lane, ep);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
         __syncthreads();
@@ -386,6 +466,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
+    SplitKRegs<16, 2, true> r17;
     {
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
@@ -435,28 +516,31 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         }
         __syncthreads();
 
-        // E2: conv13 (16->48, k3) -> concat 96..143 ; conv15 (16->48, k3) -> T4b
-        if (wave < 3) {
-            const int t = wave;
-            inception_k3<2, 4, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96 + t * 16,
-                                                  packed + bias_offset(12) + t * 16 + n,
-                                                  sc5 + 96 + t * 16, sh5 + 96 + t * 16, t, 0, lane);
-        } else if (wave < 6) {
-            const int t = wave - 3;
-            inception_k3<2, 4, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, t * 16,
-                                                  packed + bias_offset(14) + t * 16 + n, nullptr,
-                                                  nullptr, t, 0, lane);
+        // E2: conv15 (16->48, k3) -> T4b, the only input of E3 not ready yet
+        if (wave < 6) {
+            const int t = wave % 3, m0 = (wave / 3) * 2;
+            inception_k3<2, 2, 1, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, t * 16,
+                                                     packed + bias_offset(14) + t * 16 + n,
+                                                     nullptr, nullptr, t, m0, lane);
         }
         __syncthreads();
 
-        // E3: conv16 (48->48, k3) -> concat 144..191
+        // E3: conv16 (48->48, k3) -> concat 144..191 on waves 0-5 and conv13 (16->48, k3) ->
+        // concat 96..143 on waves 6-7: 72 MFMAs per wave on every wave.  conv17's weights start
+        // their trip from L2 to registers now, one stage ahead.
+        r17.prefetch(packed, 5, lane, wave);
         if (wave < 6) {
             const int t = wave % 3, m0 = (wave / 3) * 2;
-            inception_k3<6, 2, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
-                                                  144 + t * 16,
-                                                  packed + bias_offset(15) + t * 16 + n,
-                                                  sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
-                                                  lane);
+            inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
+                                                     144 + t * 16,
+                                                     packed + bias_offset(15) + t * 16 + n,
+                                                     sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
+                                                     lane);
+        } else {
+            const int m0 = (wave - 6) * 2;
+            inception_k3<2, 2, 3, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
+                                                     packed + bias_offset(12) + n, sc5 + 96,
+                                                     sh5 + 96, 0, m0, lane);
         }
         __syncthreads();
     }
@@ -472,7 +556,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     zero_row(lds + kG1, 0, kS48, 48, tid);
     zero_row(lds + kG1, 17, kS48, 48, tid);
     for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
-    splitk_layer<16, kS192, 2, 2, false, 5>(lds, lds + kECat, lds + kFOut, packed, tid, lane, wave);
+    SplitKRegs<17, 2, false> r18;
+    r18.prefetch(packed, 0, lane, wave);
+    splitk_layer<16, kS192, 2, 2, false, true>(lds, lds + kECat, lds + kFOut, r17, lane, wave);
     if (stop_stage == 5) {
         if (debug_stage < 100)
             dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
@@ -480,8 +566,20 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
-    splitk_layer<17, kS48, 1, 2, false, -1>(lds, lds + kFOut, lds + kG1, packed, tid, lane, wave);
-    splitk_layer<18, kS48, 1, 2, true, 6>(lds, lds + kG1, lds + kG2, packed, tid, lane, wave);
+    SplitKRegs<18, 2, true> r19;
+    r19.prefetch(packed, 6, lane, wave);
+    splitk_layer<17, kS48, 1, 2, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave);
+    // conv20's fragments and bias: fetched before conv19 runs
+    f2 b20[6];
+    float bias20 = 0.f;
+    if (wave < 2) {
+#pragma unroll
+        for (int sp = 0; sp < 6; ++sp)
+            b20[sp] = *reinterpret_cast<const f2*>(packed + weight_offset(19) +
+                                                   (sp * 2 + wave) * 128 + lane * 2);
+        bias20 = packed[bias_offset(19) + wave * 16 + n];
+    }
+    splitk_layer<18, kS48, 1, 2, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave);
     if (stop_stage == 6) {
         if (debug_stage < 100)
             dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
@@ -491,15 +589,20 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // ---------------- stage H: conv20 (1x1 -> classes) + ReLU + GlobalAveragePool + Softmax ---
     if (wave < 2) {
         const int t = wave;
-        f4 acc[1][1];
-        zero_acc(acc);
-        conv_tiles<1, 6, 6, 1, 1, 2, kS48, 16>(lds + kG2 + (n + 1) * kS48 + 2 * q,
-                                               packed + weight_offset(19) + t * 128 + lane * 2, acc);
-        const float b = packed[bias_offset(19) + t * 16 + n];
+        const float* a_lane = lds + kG2 + (n + 1) * kS48 + 2 * q;
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 6; ++sp) {
+            const f2 a = *reinterpret_cast<const f2*>(a_lane + sp * 8);
+            acc0 = mfma4(a.x, b20[sp].x, acc0);
+            acc1 = mfma4(a.y, b20[sp].y, acc1);
+        }
+        const f4 acc = acc0 + acc1;
+        const float b = bias20;
         float s = 0.f;
         if (q < 2) {   // rows 4q..4q+3 of the tile; only positions 0..7 exist
-            s = fmaxf(acc[0][0].x + b, 0.f) + fmaxf(acc[0][0].y + b, 0.f) +
-                fmaxf(acc[0][0].z + b, 0.f) + fmaxf(acc[0][0].w + b, 0.f);
+            s = fmaxf(acc.x + b, 0.f) + fmaxf(acc.y + b, 0.f) + fmaxf(acc.z + b, 0.f) +
+                fmaxf(acc.w + b, 0.f);
         }
         s += __shfl_xor(s, 16);
         if (q == 0) lds[kLogits + t * 16 + n] = s * 0.125f;

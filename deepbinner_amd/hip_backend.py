@@ -95,6 +95,9 @@ def load_library():
         'dbh_classify_workspace_bytes': (c_int, [c_void_p, c_i64, c_int, P(c_size_t)]),
         'dbh_classify_i16_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+        'dbh_classify_i16_batched_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
+                                                 c_int, ctypes.c_double, c_void_p, c_void_p,
+                                                 c_void_p]),
         'dbh_normalise_windows_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p,
                                               c_void_p]),
         'dbh_merge_calls_dev': (c_int, [c_void_p, c_i64, c_int, c_int, ctypes.c_double, c_void_p,
@@ -122,7 +125,7 @@ EXPORTED_SYMBOLS = [
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
-    'dbh_classify_i16_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
+    'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_timing_enable', 'dbh_forward_timing_read',
 ]
@@ -342,6 +345,13 @@ class HipModel:
                                              int(scan_size), float(score_diff), probs_ptr,
                                              calls_ptr, workspace_ptr, stream),
               'dbh_classify_i16_dev')
+
+    def classify_batched_dev(self, samples_ptr, offsets_ptr, n_reads, batch_size, side, scan_size,
+                             score_diff, probs_ptr, calls_ptr, stream=None):
+        check(self._lib.dbh_classify_i16_batched_dev(
+            self._handle, samples_ptr, offsets_ptr, n_reads, int(batch_size),
+            SIDE_START if side == 'start' else SIDE_END, int(scan_size), float(score_diff),
+            probs_ptr, calls_ptr, stream), 'dbh_classify_i16_batched_dev')
 
     def predict_dev(self, x_ptr, n_windows, probs_ptr, stream=None):
         check(self._lib.dbh_predict_dev(self._handle, x_ptr, n_windows, probs_ptr, stream),

@@ -107,6 +107,16 @@ int dbh_classify_i16_dev(dbh_model* model, const int16_t* samples_dev, const int
                          float* probs_dev, int32_t* calls_dev, void* workspace_dev,
                          dbh_stream stream);
 
+/* The same job for many reads in batches of batch_size (the reference's --batch_size loop,
+ * classify.py:130) as a three-stage pipeline on internal HIP streams: normalise(i+1), CNN(i) and
+ * merge(i-1) overlap, the CNN launches run back to back.  offsets_dev holds n_reads+1 ABSOLUTE
+ * offsets into samples_dev.  Work is ordered after what `stream` has queued so far, and `stream`
+ * is made to wait for the results; the call itself does not block the host. */
+int dbh_classify_i16_batched_dev(dbh_model* model, const int16_t* samples_dev,
+                                 const int64_t* offsets_dev, int64_t n_reads, int batch_size,
+                                 int side, int scan_size, double score_diff, float* probs_dev,
+                                 int32_t* calls_dev, dbh_stream stream);
+
 /* ---- pieces of seam b2, exposed for parity tests ---------------------------------------- */
 /* windows_dev: (n_reads * steps) x 1024 fp32, read-major (window index = read*steps + step). */
 int dbh_normalise_windows_dev(const int16_t* samples_dev, const int64_t* offsets_dev,

@@ -233,3 +233,25 @@ def test_b1_and_b2_seams_agree(hip_models, gold, all_signals):
     c2, p2 = classify.call_batch(1024, 13, ids, all_signals, model, args, 'end')
     assert c1 == c2
     assert np.abs(np.array(p1) - np.array(p2)).max() < 2e-6
+
+
+@pytest.mark.parametrize('side,scan,batch', [('start', 6144, 8), ('end', 6144, 5), ('start', 512, 3),
+                                             ('end', 1024, 64)])
+def test_batched_pipeline_matches_single_call(hip, hip_models, all_signals, side, scan, batch):
+    """dbh_classify_i16_batched_dev (3-stream pipeline, slot reuse) == one big classify call."""
+    model = hip_models['EXP-NBD103_read_ends']
+    signals = [s[:7000] if side == 'start' else s[-7000:] for s in all_signals] * 3
+    signals.insert(5, np.zeros(0, dtype=np.int16))
+    signals.insert(11, np.full(100, 512, dtype=np.int16))
+    want_p, want_c = model.classify_signals(signals, side, scan, 0.5)
+    samples, offsets = pack(signals)
+    d_s = hip.DeviceBuffer.from_array(samples)
+    d_o = hip.DeviceBuffer.from_array(offsets)
+    n = len(signals)
+    d_p = hip.DeviceBuffer(n * 13 * 4)
+    d_c = hip.DeviceBuffer(n * 4)
+    for _ in range(2):      # second round re-uses the pipeline's streams, events and slots
+        model.classify_batched_dev(d_s.ptr, d_o.ptr, n, batch, side, scan, 0.5, d_p.ptr, d_c.ptr)
+        hip.synchronize()
+        assert np.array_equal(d_c.download((n,), np.int32), want_c)
+        assert np.array_equal(d_p.download((n, 13), np.float32), want_p)
