@@ -105,13 +105,6 @@ struct dbh_model {
     void* d_in = nullptr;      size_t in_bytes = 0;
     void* d_work = nullptr;    size_t work_bytes = 0;
     void* d_out = nullptr;     size_t out_bytes = 0;
-    // three-stage pipeline of dbh_classify_i16_batched_dev
-    static constexpr int kDepth = 4;
-    bool pipe_ready = false;
-    hipStream_t s_norm = nullptr, s_fwd = nullptr, s_merge = nullptr;
-    hipEvent_t ev_norm[kDepth] = {}, ev_fwd[kDepth] = {}, ev_merge[kDepth] = {};
-    hipEvent_t ev_begin = nullptr, ev_end[3] = {};
-    void* d_pipe = nullptr;    size_t pipe_bytes = 0;
     // live timing of the forward kernel (dbh_forward_timing_*)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -133,11 +126,21 @@ int ensure(void** ptr, size_t* have, size_t need) {
     return DBH_OK;
 }
 
+struct FusedInput {          // seam-b2 mode of the forward kernel (all null/zero = seam b1)
+    const int16_t* samples = nullptr;
+    const int64_t* offsets = nullptr;
+    int steps = 1;
+    int side = 0;
+    double score_diff = 0.0;
+    int32_t* calls = nullptr;
+};
+
 int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev,
-                   int debug_stage, float* debug_dev, hipStream_t stream) {
+                   int debug_stage, float* debug_dev, hipStream_t stream,
+                   const FusedInput& in = FusedInput()) {
     if (n == 0) return DBH_OK;
     // grid.x limit is 2^31-1 blocks; chunk anyway to keep launches bounded
-    const int64_t kChunk = 1 << 20;
+    const int64_t kChunk = (int64_t)(1 << 20) * in.steps;   // whole reads per launch
     for (int64_t off = 0; off < n; off += kChunk) {
         const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
         hipEvent_t ev_stop = nullptr;
@@ -154,11 +157,15 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
             m->timed_windows += cnt;
         }
         hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)cnt), dim3(dbh::kThreads), 0,
-                           stream, m->d_packed, x_dev + off * dbh::kWindow,
+                           stream, m->d_packed, x_dev ? x_dev + off * dbh::kWindow : nullptr,
                            probs_dev ? probs_dev + off * m->n_classes : nullptr, m->n_classes,
                            debug_stage,
                            debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 || debug_stage > 7 ? 0 : debug_stage]
-                                     : nullptr);
+                                     : nullptr,
+                           in.samples,
+                           in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr,
+                           in.steps, in.side, in.score_diff,
+                           in.calls ? (int*)(in.calls + off / in.steps) : nullptr);
         DBH_HIP(hipGetLastError());
         if (ev_stop) DBH_HIP(hipEventRecord(ev_stop, stream));
     }
@@ -335,19 +342,6 @@ int dbh_model_destroy(dbh_model* m) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    if (m->pipe_ready) {
-        for (int i = 0; i < dbh_model::kDepth; ++i) {
-            (void)hipEventDestroy(m->ev_norm[i]);
-            (void)hipEventDestroy(m->ev_fwd[i]);
-            (void)hipEventDestroy(m->ev_merge[i]);
-        }
-        (void)hipEventDestroy(m->ev_begin);
-        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(m->ev_end[i]);
-        (void)hipStreamDestroy(m->s_norm);
-        (void)hipStreamDestroy(m->s_fwd);
-        (void)hipStreamDestroy(m->s_merge);
-    }
-    if (m->d_pipe) (void)hipFree(m->d_pipe);
     delete m;
     return DBH_OK;
 }
@@ -444,14 +438,28 @@ int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t
                          dbh_stream stream) {
     if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
-    if (!workspace_dev) return DBH_ERR_INVALID_ARGUMENT;
     const int steps = steps_for(scan_size);
-    const size_t windows = (size_t)n_reads * steps;
-    float* x = (float*)workspace_dev;
-    float* wprobs = x + windows * dbh::kWindow;
-    int st = dbh_normalise_windows_dev(samples_dev, offsets_dev, n_reads, side, scan_size, x, stream);
-    if (st != DBH_OK) return st;
-    st = launch_forward(m, x, (int64_t)windows, wprobs, -1, nullptr, (hipStream_t)stream);
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
+        (side != DBH_SIDE_START && side != DBH_SIDE_END) || !samples_dev || !offsets_dev ||
+        !probs_dev || !calls_dev)
+        return DBH_ERR_INVALID_ARGUMENT;
+    FusedInput in;
+    in.samples = samples_dev;
+    in.offsets = offsets_dev;
+    in.steps = steps;
+    in.side = side;
+    in.score_diff = score_diff;
+    if (steps == 1) {
+        // one window per read: slice + normalise + CNN + renormalise + call in ONE launch
+        in.calls = calls_dev;
+        return launch_forward(m, nullptr, n_reads, probs_dev, -1, nullptr, (hipStream_t)stream, in);
+    }
+    // several scan steps per read: the CNN kernel slices and normalises its own windows and
+    // leaves per-window probabilities in the workspace; the merge kernel finishes each read
+    if (!workspace_dev) return DBH_ERR_INVALID_ARGUMENT;
+    float* wprobs = (float*)workspace_dev;
+    int st = launch_forward(m, nullptr, n_reads * steps, wprobs, -1, nullptr, (hipStream_t)stream,
+                            in);
     if (st != DBH_OK) return st;
     return dbh_merge_calls_dev(wprobs, n_reads, steps, m->n_classes, score_diff, probs_dev,
                                calls_dev, stream);
@@ -463,70 +471,18 @@ int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
                                  int32_t* calls_dev, dbh_stream stream) {
     if (!m || n_reads < 0 || batch_size <= 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
-    const int steps = steps_for(scan_size);
-    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
-        (side != DBH_SIDE_START && side != DBH_SIDE_END) || !samples_dev || !offsets_dev ||
-        !probs_dev || !calls_dev)
-        return DBH_ERR_INVALID_ARGUMENT;
-    constexpr int D = dbh_model::kDepth;
-    if (!m->pipe_ready) {
-        DBH_HIP(hipStreamCreateWithFlags(&m->s_norm, hipStreamNonBlocking));
-        DBH_HIP(hipStreamCreateWithFlags(&m->s_fwd, hipStreamNonBlocking));
-        DBH_HIP(hipStreamCreateWithFlags(&m->s_merge, hipStreamNonBlocking));
-        for (int i = 0; i < D; ++i) {
-            DBH_HIP(hipEventCreateWithFlags(&m->ev_norm[i], hipEventDisableTiming));
-            DBH_HIP(hipEventCreateWithFlags(&m->ev_fwd[i], hipEventDisableTiming));
-            DBH_HIP(hipEventCreateWithFlags(&m->ev_merge[i], hipEventDisableTiming));
-        }
-        DBH_HIP(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i)
-            DBH_HIP(hipEventCreateWithFlags(&m->ev_end[i], hipEventDisableTiming));
-        m->pipe_ready = true;
-    }
-    // one workspace slot per in-flight batch: windows (fp32) + per-window probabilities
-    const size_t slot_windows = (size_t)batch_size * steps;
-    const size_t slot_bytes =
-        ((slot_windows * (dbh::kWindow + m->n_classes) * sizeof(float)) + 255) & ~(size_t)255;
-    int st = ensure(&m->d_pipe, &m->pipe_bytes, slot_bytes * D);
+    size_t work = 0;
+    int st = dbh_classify_workspace_bytes(m, batch_size, scan_size, &work);
     if (st != DBH_OK) return st;
-
-    hipStream_t caller = (hipStream_t)stream;
-    DBH_HIP(hipEventRecord(m->ev_begin, caller));
-    DBH_HIP(hipStreamWaitEvent(m->s_norm, m->ev_begin, 0));
-    DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_begin, 0));
-    DBH_HIP(hipStreamWaitEvent(m->s_merge, m->ev_begin, 0));
-
-    int64_t i = 0;
-    for (int64_t r0 = 0; r0 < n_reads; r0 += batch_size, ++i) {
+    st = ensure(&m->d_work, &m->work_bytes, work);
+    if (st != DBH_OK) return st;
+    // in-order on the caller's stream: each batch is one launch (scan_size 512) or two, so the
+    // CNN launches run back to back and the workspace can be reused batch after batch
+    for (int64_t r0 = 0; r0 < n_reads; r0 += batch_size) {
         const int64_t cnt = (n_reads - r0 < batch_size) ? (n_reads - r0) : batch_size;
-        const int k = (int)(i % D);
-        float* x = (float*)((char*)m->d_pipe + slot_bytes * k);
-        float* wprobs = x + slot_windows * dbh::kWindow;
-        if (i >= D) {
-            // slot reuse: the windows must have been consumed by the forward pass of batch i-D,
-            // its per-window probabilities by that batch's merge
-            DBH_HIP(hipStreamWaitEvent(m->s_norm, m->ev_fwd[k], 0));
-            DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_merge[k], 0));
-        }
-        st = dbh_normalise_windows_dev(samples_dev, offsets_dev + r0, cnt, side, scan_size, x,
-                                       (dbh_stream)m->s_norm);
+        st = dbh_classify_i16_dev(m, samples_dev, offsets_dev + r0, cnt, side, scan_size, score_diff,
+                                  probs_dev + r0 * m->n_classes, calls_dev + r0, m->d_work, stream);
         if (st != DBH_OK) return st;
-        DBH_HIP(hipEventRecord(m->ev_norm[k], m->s_norm));
-        DBH_HIP(hipStreamWaitEvent(m->s_fwd, m->ev_norm[k], 0));
-        st = launch_forward(m, x, cnt * steps, wprobs, -1, nullptr, m->s_fwd);
-        if (st != DBH_OK) return st;
-        DBH_HIP(hipEventRecord(m->ev_fwd[k], m->s_fwd));
-        DBH_HIP(hipStreamWaitEvent(m->s_merge, m->ev_fwd[k], 0));
-        st = dbh_merge_calls_dev(wprobs, cnt, steps, m->n_classes, score_diff,
-                                 probs_dev + r0 * m->n_classes, calls_dev + r0,
-                                 (dbh_stream)m->s_merge);
-        if (st != DBH_OK) return st;
-        DBH_HIP(hipEventRecord(m->ev_merge[k], m->s_merge));
-    }
-    hipStream_t all[3] = {m->s_norm, m->s_fwd, m->s_merge};
-    for (int j = 0; j < 3; ++j) {
-        DBH_HIP(hipEventRecord(m->ev_end[j], all[j]));
-        DBH_HIP(hipStreamWaitEvent(caller, m->ev_end[j], 0));
     }
     return DBH_OK;
 }
@@ -620,6 +576,27 @@ int dbh_forward_truncated_dev(dbh_model* m, const float* x_dev, int64_t n, int l
                               dbh_stream stream) {
     if (!m || n <= 0 || !x_dev || last_stage < 0 || last_stage > 6) return DBH_ERR_INVALID_ARGUMENT;
     return launch_forward(m, x_dev, n, nullptr, 100 + last_stage, nullptr, (hipStream_t)stream);
+}
+
+int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* stamps_host) {
+    if (!m || n <= 0 || !x_host || !stamps_host) return DBH_ERR_INVALID_ARGUMENT;
+    const size_t stamp_bytes = (size_t)n * dbh::kWaves * 64 * sizeof(int64_t);
+    int st = ensure(&m->d_in, &m->in_bytes, (size_t)n * dbh::kWindow * sizeof(float));
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_work, &m->work_bytes, stamp_bytes);
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_out, &m->out_bytes, (size_t)n * m->n_classes * sizeof(float));
+    if (st != DBH_OK) return st;
+    DBH_HIP(hipMemcpyAsync(m->d_in, x_host, (size_t)n * dbh::kWindow * sizeof(float),
+                           hipMemcpyHostToDevice, 0));
+    DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
+    hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0, 0,
+                       m->d_packed, (const float*)m->d_in, (float*)m->d_out, m->n_classes, 300,
+                       (float*)m->d_work, nullptr, nullptr, 1, 0, 0.0, nullptr);
+    DBH_HIP(hipGetLastError());
+    DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
+    DBH_HIP(hipStreamSynchronize(0));
+    return DBH_OK;
 }
 
 int dbh_forward_timing_enable(dbh_model* m, int enable) {

@@ -47,57 +47,129 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 //           SP <= SPTOT is how many channel-pairs groups this call walks (split-K).
 // All offsets are compile-time so every access is base + immediate.
 // ---------------------------------------------------------------------------------------------
+// Cycle-stamp for the timeline mode (debug_stage 300): ts is non-null only in lane 0 of each
+// wave and points at that wave's 64 slots.
+__device__ __forceinline__ void mark(long long* ts, int id) {
+    if (ts) ts[id] = (long long)__builtin_readcyclecounter();
+}
+
+// All-lanes reduction over a 16-lane row with DPP moves (no LDS round trips, unlike
+// __shfl_xor -> ds_bpermute): xor 1, xor 2, half-row mirror, row mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
+    return fmaxf(v, dpp_move<0x140>(v));  // row_mirror
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v + dpp_move<0x140>(v);
+}
+__device__ __forceinline__ float lane_value(float v, int src_lane) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
 template <int MT, int NT>
 struct Frags {
     f2 a[MT];
     f2 b[NT];
 };
 
-template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
-__device__ __forceinline__ void load_frags(Frags<MT, NT>& f, const float* a_lane,
-                                           const float* b_lane, int it) {
-    const int tap = it / SP, sp = it % SP;   // 'it' is a compile-time constant after unrolling
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-        f.a[m] = *reinterpret_cast<const f2*>(a_lane + (m * MROWS + tap) * S + sp * 8);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        f.b[t] = *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * NTTOT + t) * 128);
+// LDS byte address of a pointer into the __shared__ arena (generic -> local address space).
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
 }
 
-// Software-pipelined: the fragments of step it+1 are requested before the MFMAs of step it are
-// issued.  MFMA intrinsics are pure, so neither instruction selection nor sched_barrier alone
-// keeps them where the source puts them (hipcc sank two thirds of them to the end of the layer
-// and spilled the fragments they pinned); the empty asm statements tie every accumulator chain
-// to its step and fence the LDS loads, which pins the schedule without emitting an instruction.
+// One ds_read_b64 the compiler cannot see.  hipcc's own wait-count pass drains ALL outstanding LDS
+// reads (lgkmcnt(0)) in front of every second MFMA group of this loop, exposing a full LDS
+// round trip each time; issuing the reads from inline asm and counting them by hand
+// (frag_wait) keeps the next step's fragments in flight under the current step's MFMAs.
+template <int OFFSET_BYTES>
+__device__ __forceinline__ f2 ds_read_f2(unsigned addr) {
+    f2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2"
+                 : "=v"(v)
+                 : "v"(addr), "i"(OFFSET_BYTES)
+                 : "memory");
+    return v;
+}
+
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS, int IT>
+__device__ __forceinline__ void load_frags(Frags<MT, NT>& f, unsigned a_addr, unsigned b_addr) {
+    constexpr int tap = IT / SP, sp = IT % SP;
+    static_assert(((MT - 1) * MROWS + TAPS - 1) * S * 4 + SP * 32 < 65536, "ds offset range");
+    static_assert(((TAPS * SPTOT) * NTTOT + NT) * 512 < 65536, "ds offset range");
+    if constexpr (MT > 0) f.a[0] = ds_read_f2<((0 * MROWS + tap) * S + sp * 8) * 4>(a_addr);
+    if constexpr (MT > 1) f.a[1] = ds_read_f2<((1 * MROWS + tap) * S + sp * 8) * 4>(a_addr);
+    if constexpr (MT > 2) f.a[2] = ds_read_f2<((2 * MROWS + tap) * S + sp * 8) * 4>(a_addr);
+    if constexpr (MT > 3) f.a[3] = ds_read_f2<((3 * MROWS + tap) * S + sp * 8) * 4>(a_addr);
+    static_assert(MT <= 4 && NT <= 3, "extend load_frags");
+    if constexpr (NT > 0) f.b[0] = ds_read_f2<(((tap * SPTOT + sp) * NTTOT + 0) * 128) * 4>(b_addr);
+    if constexpr (NT > 1) f.b[1] = ds_read_f2<(((tap * SPTOT + sp) * NTTOT + 1) * 128) * 4>(b_addr);
+    if constexpr (NT > 2) f.b[2] = ds_read_f2<(((tap * SPTOT + sp) * NTTOT + 2) * 128) * 4>(b_addr);
+}
+
+// Wait until at most PENDING of this wave's LDS reads are outstanding, and make the fragment
+// registers depend on the wait so no consumer can be scheduled above it.
+template <int PENDING, int MT, int NT>
+__device__ __forceinline__ void frag_wait(Frags<MT, NT>& f) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(f.a[m]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(f.b[t]));
+}
+
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS, int IT>
+__device__ __forceinline__ void conv_step(unsigned a_addr, unsigned b_addr, Frags<MT, NT> (&buf)[2],
+                                          f4 (&acc)[MT][NT]) {
+    constexpr int NIT = TAPS * SP;
+    if constexpr (IT + 1 < NIT) {
+        load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, IT + 1>(buf[(IT + 1) & 1], a_addr,
+                                                                     b_addr);
+        frag_wait<MT + NT>(buf[IT & 1]);     // the MT+NT reads just issued may stay in flight
+    } else {
+        frag_wait<0>(buf[IT & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const Frags<MT, NT>& f = buf[IT & 1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].x, f.b[t].x, acc[m][t]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].y, f.b[t].y, acc[m][t]);
+    // MFMA intrinsics are pure: without these pins hipcc sinks most of them to the end of the
+    // layer and spills the fragments they keep alive
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[m][t]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT + 1 < NIT)
+        conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, IT + 1>(a_addr, b_addr, buf, acc);
+}
+
+// acc[m][t] += sum over (tap, sp, e) of A-tile(m) x B-tile(t), software-pipelined: the fragments
+// of step it+1 are requested before the MFMAs of step it are issued.  a_lane / b_lane must
+// point into LDS.
 template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
 __device__ __forceinline__ void conv_tiles(const float* a_lane, const float* b_lane,
                                            f4 (&acc)[MT][NT]) {
-    constexpr int NIT = TAPS * SP;
+    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(b_lane);
     Frags<MT, NT> buf[2];
-    load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS>(buf[0], a_lane, b_lane, 0);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        if (it + 1 < NIT)
-            load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS>(buf[(it + 1) & 1], a_lane,
-                                                                 b_lane, it + 1);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const Frags<MT, NT>& f = buf[it & 1];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].x, f.b[t].x, acc[m][t]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = mfma4(f.a[m].y, f.b[t].y, acc[m][t]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[m][t]));
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, 0>(buf[0], a_addr, b_addr);
+    conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, 0>(a_addr, b_addr, buf, acc);
 }
 
 template <int MT, int NT>
@@ -213,7 +285,8 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
 template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N>
 __device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
                                               const float* __restrict__ next_g, float* next_lds,
-                                              int tid, int lane, int wave) {
+                                              int tid, int lane, int wave, long long* ts,
+                                              int ts_base) {
     constexpr int TAPS = kConv[CONV].taps;
     constexpr int SP = kConv[CONV].cin / 8;
     constexpr int NT = kConv[CONV].cout_pad / 16;
@@ -236,46 +309,54 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     const float* a_lane = lds + kActOff + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
     const float* b_lane = lds + W_CUR + lane * 2;
     conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc);
+    mark(ts, ts_base);
 
     __syncthreads();   // every wave has finished reading the old activations and weights
+    mark(ts, ts_base + 1);
 
     float* out_lane = lds + kActOff +
                       (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
     epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, ep);
     zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
     zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
+    mark(ts, ts_base + 2);
 
     __syncthreads();
+    mark(ts, ts_base + 3);
 }
 
 // ---------------------------------------------------------------------------------------------
 // A small-M layer (one 16-position tile: conv17/18/19).  Each weight is used once per window,
-// so B fragments skip LDS: every wave fetches its share from L2 into registers one stage AHEAD
-// (SplitKRegs::prefetch) and the contraction is split over KS groups of 3 waves (one per N
-// tile) whose partial tiles are summed through LDS.
+// so B fragments skip LDS: every wave fetches its share from L2 into registers well AHEAD of
+// use (SmallMRegs::prefetch).  A wave owns NTW of the 3 N tiles and 1/KS of the contraction:
+//   conv17 (K = 576): KS = 8, NTW = 3 -> all 8 waves, 54 MFMAs each, partial tiles summed via LDS;
+//   conv18/19 (K = 144): KS = 1, NTW = 1 -> 3 waves, 36 MFMAs each, no reduction phase at all.
 // ---------------------------------------------------------------------------------------------
-template <int CONV, int KS, bool BN>
-struct SplitKRegs {
+template <int CONV, int KS, int NTW, bool BN>
+struct SmallMRegs {
     static constexpr int TAPS = kConv[CONV].taps;
     static constexpr int SPTOT = kConv[CONV].cin / 8;
     static constexpr int SP = SPTOT / KS;
-    static_assert(SP * KS == SPTOT, "split-K must divide C_in/8");
-    static_assert(3 * KS <= kWaves, "not enough waves for this split");
-    f2 b[TAPS * SP];
+    static constexpr int NGROUPS = 3 / NTW;             // wave groups along N
+    static constexpr int ACTIVE = KS * NGROUPS;
+    static_assert(SP * KS == SPTOT && NGROUPS * NTW == 3 && ACTIVE <= kWaves, "bad split");
+    f2 b[TAPS * SP * NTW];
     EpiParams<1, BN> ep;
     __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int bn_index,
                                              int lane, int wave) {
-        if (wave < 3 * KS) {
-            const int t = wave % 3, ks = wave / 3;
-            const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t) * 128 + lane * 2;
+        if (wave < ACTIVE) {
+            const int t0 = (wave % NGROUPS) * NTW, ks = wave / NGROUPS;
+            const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t0) * 128 + lane * 2;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
                 for (int sp = 0; sp < SP; ++sp)
-                    b[tap * SP + sp] =
-                        *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * 3) * 128);
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        b[(tap * SP + sp) * NTW + t] = *reinterpret_cast<const f2*>(
+                            b_lane + ((tap * SPTOT + sp) * 3 + t) * 128);
         }
-        if (wave < 3) {
+        if (wave < 3) {     // the waves that run the epilogue (one N tile each)
             const int ch = wave * 16 + (lane & 15);
             ep.load(packed + bias_offset(CONV) + ch,
                     packed + (BN ? bn_scale_offset(bn_index) : 0) + ch,
@@ -284,22 +365,25 @@ struct SplitKRegs {
     }
 };
 
-template <int CONV, int S_IN, int STRIDE, int KS, bool POOL, bool BN>
-__device__ __forceinline__ void splitk_layer(float* lds, const float* in_region, float* out_region,
-                                             const SplitKRegs<CONV, KS, BN>& regs, int lane,
-                                             int wave) {
-    constexpr int TAPS = SplitKRegs<CONV, KS, BN>::TAPS;
-    constexpr int SP = SplitKRegs<CONV, KS, BN>::SP;
+template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN>
+__device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
+                                              const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
+                                              int wave, long long* ts, int ts_base) {
+    using R = SmallMRegs<CONV, KS, NTW, BN>;
+    constexpr int TAPS = R::TAPS, SP = R::SP;
     const int n = lane & 15, q = lane >> 4;
-
-    if (wave < 3 * KS) {
-        const int t = wave % 3, ks = wave / 3;
+    f4 acc[1][NTW];
+    zero_acc(acc);
+    if (wave < R::ACTIVE) {
+        const int ks = wave / R::NGROUPS;
         // stride-2 'same' pads on the right only: logical row 2p+tap = physical row 2p+tap+1;
         // stride-1 'same' k=3: physical row p+tap.
         const int first = (STRIDE == 2) ? 1 : 0;
         const float* a_lane = in_region + (first + n * STRIDE) * S_IN + 2 * q + ks * SP * 8;
-        // two accumulator chains so consecutive MFMAs never wait on each other
-        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+        // even/odd k-steps accumulate separately so consecutive MFMAs never wait on each other
+        f4 odd[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) odd[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             f2 a[SP];
@@ -307,25 +391,50 @@ __device__ __forceinline__ void splitk_layer(float* lds, const float* in_region,
             for (int sp = 0; sp < SP; ++sp)
                 a[sp] = *reinterpret_cast<const f2*>(a_lane + tap * S_IN + sp * 8);
 #pragma unroll
-            for (int sp = 0; sp < SP; ++sp) {
-                acc0 = mfma4(a[sp].x, regs.b[tap * SP + sp].x, acc0);
-                acc1 = mfma4(a[sp].y, regs.b[tap * SP + sp].y, acc1);
-            }
-        }
-        *reinterpret_cast<f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4) = acc0 + acc1;
-    }
-    __syncthreads();
-    if (wave < 3) {
-        const int t = wave;
-        f4 acc[1][1];
-        acc[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
+            for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
-        for (int ks = 1; ks < KS; ++ks)
-            acc[0][0] += *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
-        float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
-        epilogue<1, 1, kS48, POOL, BN>(acc, out_lane, regs.ep);
+                for (int t = 0; t < NTW; ++t) {
+                    const f2 bw = regs.b[(tap * SP + sp) * NTW + t];
+                    acc[0][t] = mfma4(a[sp].x, bw.x, acc[0][t]);
+                    odd[t] = mfma4(a[sp].y, bw.y, odd[t]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[0][t] += odd[t];
     }
+    if constexpr (KS > 1) {
+        static_assert(NTW == 3, "split-K path assumes every wave holds all three N tiles");
+        if (wave < R::ACTIVE) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                *reinterpret_cast<f4*>(lds + kRed + (wave * 3 + t) * 256 + lane * 4) = acc[0][t];
+        }
+        mark(ts, ts_base);
+        __syncthreads();
+        mark(ts, ts_base + 1);
+        if (wave < 3) {
+            const int t = wave;
+            f4 sum[1][1];
+            sum[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks)
+                sum[0][0] +=
+                    *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
+            float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
+            epilogue<1, 1, kS48, POOL, BN>(sum, out_lane, regs.ep);
+        }
+    } else {
+        static_assert(NTW == 1, "direct path: one N tile per wave");
+        mark(ts, ts_base);
+        mark(ts, ts_base + 1);
+        if (wave < 3) {
+            float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + wave * 16 + n;
+            epilogue<1, 1, kS48, POOL, BN>(acc, out_lane, regs.ep);
+        }
+    }
+    mark(ts, ts_base + 2);
     __syncthreads();
+    mark(ts, ts_base + 3);
 }
 
 // One wave's share of the 1x1 convolutions of the inception block (4 position tiles x 1 N tile).
@@ -368,6 +477,69 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
     epilogue<MT, NT, S_OUT, POOLBN, POOLBN>(acc, out_lane, ep);
 }
 
+// ---------------------------------------------------------------------------------------------
+// make_sum_to_one + barcode call for one read held by a 32-lane group (lane c = class c):
+// classify.py:387-393 in fp64 (what NumPy-1.x scalar promotion gave the reference) and
+// classify.py:285-295 (ties to the lower class index: Python's stable sort with reverse=True).
+// Shared by the stand-alone merge kernel and the forward kernel's fused single-step finish.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void renormalise_and_call(float merged, int c, int n_classes,
+                                                     double score_diff, float* probs_row,
+                                                     int* call_out) {
+    const bool valid = c < n_classes;
+    double p = (double)merged;
+    double rest = (valid && c > 0) ? p : 0.0;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) rest += __shfl_xor(rest, off, 32);
+    const double p0 = __shfl(p, 0, 32);
+    const double factor = (1.0 - p0) / rest;
+    if (c > 0) p = p * factor;
+    if (valid) probs_row[c] = (float)p;
+
+    double best = valid ? p : -1.0;
+    int best_i = c;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 32);
+        const int oi = __shfl_xor(best_i, off, 32);
+        if (ov > best || (ov == best && oi < best_i)) {
+            best = ov;
+            best_i = oi;
+        }
+    }
+    double second = (valid && c != best_i) ? p : -1.0;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) second = fmax(second, __shfl_xor(second, off, 32));
+    if (c == 0) *call_out = (best_i != 0 && (best - second) >= score_diff) ? best_i : 0;
+}
+
+// Window bounds of scan step `step` inside a read of `len` samples (classify.py:337-349).
+__device__ __forceinline__ void window_bounds(long long len, int step, int side, long long* a,
+                                              long long* b) {
+    const long long sig_start = (long long)step * (kWindow / 2);
+    const long long sig_end = sig_start + kWindow;
+    if (side == 0) {
+        *a = sig_start < len ? sig_start : len;
+        *b = sig_end < len ? sig_end : len;
+    } else {
+        *a = len - sig_end > 0 ? len - sig_end : 0;
+        *b = len - sig_start > 0 ? len - sig_start : 0;
+    }
+}
+
+// mean and population standard deviation from exact integer sums (trim_signal.py:61-69)
+__device__ __forceinline__ void mean_std(long long s1, long long s2, int cnt, double* mean,
+                                         double* stdev) {
+    *mean = 0.0;
+    *stdev = 0.0;
+    if (cnt > 0) {
+        *mean = (double)s1 / (double)cnt;
+        // population variance = (n*sum(x^2) - sum(x)^2) / n^2, numerator exact in int64
+        const long long num = (long long)cnt * s2 - s1 * s1;
+        *stdev = sqrt((double)num) / (double)cnt;
+    }
+}
+
 // =============================================================================================
 // The kernel.  grid = n_windows, block = 512.
 //   x      [n_windows][1024]   normalised windows (fp32)
@@ -375,9 +547,14 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
 //   debug_stage in [0,7]: write the activations after stage 'A'+debug_stage to debug_out and
 //   stop; 100+k: stop after stage k without writing (per-stage timing); -1: full forward.
 // =============================================================================================
+//   Fused seam-b2 mode (samples != nullptr): window w = (read w / steps, scan step w % steps) is
+//   sliced and z-normalised from the int16 signal inside stage A, and when calls != nullptr
+//   (steps == 1) the read is finished here too: renormalise + barcode call, no merge kernel.
 __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, float* __restrict__ probs,
-    int n_classes, int debug_stage, float* __restrict__ debug_out) {
+    int n_classes, int debug_stage, float* __restrict__ debug_out,
+    const int16_t* __restrict__ samples, const long long* __restrict__ offsets, int steps,
+    int side, double score_diff, int* __restrict__ calls) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
     const int tid = threadIdx.x;
@@ -385,9 +562,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const long win = blockIdx.x;
-    const float* xw = x + win * kWindow;
     // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
     const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
+    // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
+    long long* ts = nullptr;
+    if (debug_stage == 300 && lane == 0)
+        ts = reinterpret_cast<long long*>(debug_out) + (win * kWaves + wave) * 64;
+    mark(ts, 0);
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
     // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
@@ -398,10 +579,59 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
         float a[MT], bw[3];
+        if (samples == nullptr) {
+            const float* xw = x + win * kWindow;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
-            a[m] = (q < 3 && idx < kWindow) ? xw[idx] : 0.f;      // idx == 1024: right padding
+            for (int m = 0; m < MT; ++m) {
+                const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
+                a[m] = (q < 3 && idx < kWindow) ? xw[idx] : 0.f;      // idx == 1024: right padding
+            }
+        } else {
+            // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
+            const long long read = win / steps;
+            const int step = (int)(win - read * steps);
+            const long long base = offsets[read];
+            long long wa, wb;
+            window_bounds(offsets[read + 1] - base, step, side, &wa, &wb);
+            const int cnt = (int)(wb - wa);
+            const int16_t* src = samples + base + wa;
+            const int v0 = tid < cnt ? (int)src[tid] : 0;
+            const int v1 = tid + kThreads < cnt ? (int)src[tid + kThreads] : 0;
+            long long s1 = v0 + v1;
+            long long s2 = (long long)v0 * v0 + (long long)v1 * v1;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s1 += __shfl_xor(s1, off);
+                s2 += __shfl_xor(s2, off);
+            }
+            long long* red = reinterpret_cast<long long*>(lds + kW1);   // kW1 is idle in stage A
+            if (lane == 0) {
+                red[wave] = s1;
+                red[kWaves + wave] = s2;
+            }
+            __syncthreads();
+            s1 = 0;
+            s2 = 0;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) {
+                s1 += red[i];
+                s2 += red[kWaves + i];
+            }
+            double mean, stdev;
+            mean_std(s1, s2, cnt, &mean, &stdev);
+            const bool divide = stdev > 0.0;
+            const int pad_left = (side == 0) ? 0 : kWindow - cnt;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int idx = 2 * ((m0 + m) * 16 + n) + q;
+                const int k = idx - pad_left;
+                float v = 0.f;
+                if (q < 3 && k >= 0 && k < cnt) {
+                    const double d = (double)src[k] - mean;
+                    v = (float)(divide ? d / stdev : d);
+                }
+                a[m] = v;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -420,6 +650,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
         __syncthreads();
+        mark(ts, 1);
     }
     if (stop_stage == 0) {
         if (debug_stage < 100)
@@ -429,11 +660,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
     inplace_layer<1, kW0, 512, kS48, kS48, false, -1, conv_weight_floats(2)>(
-        lds, packed, packed + weight_offset(2), lds + kW1, tid, lane, wave);
+        lds, packed, packed + weight_offset(2), lds + kW1, tid, lane, wave, ts, 2);
     inplace_layer<2, kW1, 512, kS48, kS48, false, -1, conv_weight_floats(3)>(
-        lds, packed, packed + weight_offset(3), lds + kW0, tid, lane, wave);
+        lds, packed, packed + weight_offset(3), lds + kW0, tid, lane, wave, ts, 6);
     inplace_layer<3, kW0, 512, kS48, kS48, true, 1, conv_weight_floats(4)>(
-        lds, packed, packed + weight_offset(4), lds + kW1, tid, lane, wave);
+        lds, packed, packed + weight_offset(4), lds + kW1, tid, lane, wave, ts, 10);
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
@@ -442,11 +673,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
 
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
     inplace_layer<4, kW1, 256, kS48, kS16, false, -1, conv_weight_floats(5)>(
-        lds, packed, packed + weight_offset(5), lds + kW0, tid, lane, wave);
+        lds, packed, packed + weight_offset(5), lds + kW0, tid, lane, wave, ts, 14);
     inplace_layer<5, kW0, 256, kS16, kS48, false, -1, conv_weight_floats(6)>(
-        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave);
+        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave, ts, 18);
     inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
-        lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave);
+        lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave, ts, 22);
     if (stop_stage == 2) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
@@ -455,10 +686,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
 
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     inplace_layer<7, kW0, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
-        lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave);
-    // conv9 prefetches ALL inception weights (conv10..16) into their stage-E home.
+        lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave, ts, 26);
+    // conv9 prefetches ALL inception weights (conv10..16) into their stage-E home, and conv17's
+    // 110 KB of weights start their trip from L2 to registers here too: the whole burst (every
+    // CU of a 256-window launch asks at once) drains under conv9's ~4 us of MFMAs.
+    SmallMRegs<16, 8, 3, true> r17;
+    r17.prefetch(packed, 5, lane, wave);
     inplace_layer<8, kW1, 128, kS48, kS48, true, 3, kEWFloats>(
-        lds, packed, packed + weight_offset(9), lds + kEW, tid, lane, wave);
+        lds, packed, packed + weight_offset(9), lds + kEW, tid, lane, wave, ts, 30);
     if (stop_stage == 3) {
         if (debug_stage < 100)
             dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);
@@ -466,7 +701,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
-    SplitKRegs<16, 2, true> r17;
     {
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
@@ -485,6 +719,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         zero_row(lds + kECat, 0, kS192, 192, tid);
         zero_row(lds + kECat, 33, kS192, 192, tid);
         __syncthreads();
+        mark(ts, 34);
 
         constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
         constexpr int w11 = kEW + weight_offset(10) - weight_offset(9);
@@ -514,7 +749,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0,
                                           packed + bias_offset(13) + n, nullptr, nullptr, 0, lane);
         }
+        mark(ts, 35);
         __syncthreads();
+        mark(ts, 36);
 
         // E2: conv15 (16->48, k3) -> T4b, the only input of E3 not ready yet
         if (wave < 6) {
@@ -523,12 +760,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                      packed + bias_offset(14) + t * 16 + n,
                                                      nullptr, nullptr, t, m0, lane);
         }
+        mark(ts, 37);
         __syncthreads();
+        mark(ts, 38);
 
         // E3: conv16 (48->48, k3) -> concat 144..191 on waves 0-5 and conv13 (16->48, k3) ->
-        // concat 96..143 on waves 6-7: 72 MFMAs per wave on every wave.  conv17's weights start
-        // their trip from L2 to registers now, one stage ahead.
-        r17.prefetch(packed, 5, lane, wave);
+        // concat 96..143 on waves 6-7: 72 MFMAs per wave on every wave.
         if (wave < 6) {
             const int t = wave % 3, m0 = (wave / 3) * 2;
             inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
@@ -542,7 +779,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                      packed + bias_offset(12) + n, sc5 + 96,
                                                      sh5 + 96, 0, m0, lane);
         }
+        mark(ts, 39);
         __syncthreads();
+        mark(ts, 40);
     }
     if (stop_stage == 4) {
         if (debug_stage < 100)
@@ -556,9 +795,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     zero_row(lds + kG1, 0, kS48, 48, tid);
     zero_row(lds + kG1, 17, kS48, 48, tid);
     for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
-    SplitKRegs<17, 2, false> r18;
+    SmallMRegs<17, 1, 1, false> r18;
     r18.prefetch(packed, 0, lane, wave);
-    splitk_layer<16, kS192, 2, 2, false, true>(lds, lds + kECat, lds + kFOut, r17, lane, wave);
+    small_m_layer<16, kS192, 2, 8, 3, false, true>(lds, lds + kECat, lds + kFOut, r17, lane, wave,
+                                                   ts, 41);
     if (stop_stage == 5) {
         if (debug_stage < 100)
             dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
@@ -566,9 +806,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
-    SplitKRegs<18, 2, true> r19;
+    SmallMRegs<18, 1, 1, true> r19;
     r19.prefetch(packed, 6, lane, wave);
-    splitk_layer<17, kS48, 1, 2, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave);
+    small_m_layer<17, kS48, 1, 1, 1, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave, ts,
+                                                   45);
     // conv20's fragments and bias: fetched before conv19 runs
     f2 b20[6];
     float bias20 = 0.f;
@@ -579,7 +820,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                    (sp * 2 + wave) * 128 + lane * 2);
         bias20 = packed[bias_offset(19) + wave * 16 + n];
     }
-    splitk_layer<18, kS48, 1, 2, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave);
+    small_m_layer<18, kS48, 1, 1, 1, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave, ts, 49);
     if (stop_stage == 6) {
         if (debug_stage < 100)
             dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
@@ -607,23 +848,33 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         s += __shfl_xor(s, 16);
         if (q == 0) lds[kLogits + t * 16 + n] = s * 0.125f;
     }
+    mark(ts, 53);
     __syncthreads();
+    mark(ts, 54);
     if (wave == 0) {
         const bool valid = lane < n_classes;
         const float v = valid ? lds[kLogits + (lane & 31)] : -INFINITY;
-        float mx = v;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        // classes live in lanes 0..31 = two 16-lane rows
+        const float rmx = row16_max(v);
+        const float mx = fmaxf(lane_value(rmx, 0), lane_value(rmx, 16));
         const float e = valid ? expf(v - mx) : 0.f;
-        float sum = e;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        const float rsum = row16_sum(e);
+        const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
         if (debug_stage == 7) {
             if (lane < 32) debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
             return;
         }
-        if (valid) probs[win * n_classes + lane] = e / sum;
+        const float p = e / sum;
+        if (calls != nullptr) {
+            // single scan step: this window IS the read (classify.py:368-382 with one range)
+            if (lane < 32)
+                renormalise_and_call(valid ? p : 0.f, lane, n_classes, score_diff,
+                                     probs + win * n_classes, calls + win);
+        } else if (valid) {
+            probs[win * n_classes + lane] = p;
+        }
     }
+    mark(ts, 55);
 }
 
 // =============================================================================================
@@ -641,16 +892,8 @@ __global__ __launch_bounds__(256) void dbh_normalise_kernel(
     const int step = blockIdx.x - (int)(read * steps);
     const long long base = offsets[read];
     const long long len = offsets[read + 1] - base;
-    const long long sig_start = (long long)step * (kWindow / 2);
-    const long long sig_end = sig_start + kWindow;
     long long a, b;
-    if (side == 0) {
-        a = sig_start < len ? sig_start : len;
-        b = sig_end < len ? sig_end : len;
-    } else {
-        a = len - sig_end > 0 ? len - sig_end : 0;
-        b = len - sig_start > 0 ? len - sig_start : 0;
-    }
+    window_bounds(len, step, side, &a, &b);
     const int cnt = (int)(b - a);
     const int tid = threadIdx.x;
     const int16_t* src = samples + base + a;
@@ -678,17 +921,9 @@ __global__ __launch_bounds__(256) void dbh_normalise_kernel(
     s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 
     float* out = windows + (long long)blockIdx.x * kWindow;
-    double mean = 0.0, inv = 1.0;
-    bool divide = false;
-    double stdev = 0.0;
-    if (cnt > 0) {
-        mean = (double)s1 / (double)cnt;
-        // population variance = (n*sum(x^2) - sum(x)^2) / n^2, numerator exact in int64
-        const long long num = (long long)cnt * s2 - s1 * s1;
-        stdev = sqrt((double)num) / (double)cnt;
-        divide = stdev > 0.0;
-    }
-    (void)inv;
+    double mean, stdev;
+    mean_std(s1, s2, cnt, &mean, &stdev);
+    const bool divide = stdev > 0.0;
     const int pad_left = (side == 0) ? 0 : kWindow - cnt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -725,35 +960,8 @@ __global__ __launch_bounds__(256) void dbh_merge_kernel(const float* __restrict_
             merged = (c == 0) ? fminf(merged, v) : fmaxf(merged, v);
         }
     }
-    double p = (double)merged;
-    double rest = (valid && c > 0) ? p : 0.0;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) rest += __shfl_xor(rest, off, 32);
-    const double p0 = __shfl(p, 0, 32);
-    const double factor = (1.0 - p0) / rest;
-    if (c > 0) p = p * factor;
-    if (valid) probs[read * n_classes + c] = (float)p;
-
-    // top two by value, ties to the lower class index (Python's stable sort, reverse=True)
-    double best = valid ? p : -1.0;
-    int best_i = c;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(best, off, 32);
-        const int oi = __shfl_xor(best_i, off, 32);
-        if (ov > best || (ov == best && oi < best_i)) {
-            best = ov;
-            best_i = oi;
-        }
-    }
-    double second = (valid && c != best_i) ? p : -1.0;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) second = fmax(second, __shfl_xor(second, off, 32));
-    if (c == 0) {
-        int call = 0;
-        if (best_i != 0 && (best - second) >= score_diff) call = best_i;
-        calls[read] = call;
-    }
+    renormalise_and_call(merged, c, n_classes, score_diff, probs + read * n_classes,
+                         calls + read);
 }
 
 }  // namespace dbh

@@ -114,8 +114,8 @@ static_assert(kEW + kEWFloats <= kW1, "stage-E weights would land on conv9's wei
 constexpr int kFOut = 0;                                   // conv17+BN6 out, 18 rows x 52
 constexpr int kG1 = kFOut + 18 * kS48;                     // conv18 out
 constexpr int kG2 = kG1 + 18 * kS48;                       // conv19+pool+BN7 out (8 rows + pads)
-constexpr int kRed = kG2 + 18 * kS48;                      // split-K partial tiles, 12 x 256
-constexpr int kLogits = kRed + 12 * 256;                   // 32 floats
+constexpr int kRed = kG2 + 18 * kS48;                      // split-K partial tiles, 24 x 256
+constexpr int kLogits = kRed + 24 * 256;                   // 32 floats
 constexpr int kTailEnd = kLogits + 32;
 static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
 

@@ -106,6 +106,8 @@ def load_library():
         'dbh_debug_forward': (c_int, [c_void_p, _f32(), c_i64, c_int, _f32()]),
         'dbh_forward_kernel_info': (c_int, [P(c_int), P(c_int), P(c_int)]),
         'dbh_forward_truncated_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+        'dbh_forward_timeline': (c_int, [c_void_p, _f32(), c_i64,
+                                         ndpointer(np.int64, flags='C_CONTIGUOUS')]),
         'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
     }
@@ -127,7 +129,7 @@ EXPORTED_SYMBOLS = [
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
-    'dbh_forward_truncated_dev', 'dbh_forward_timing_enable', 'dbh_forward_timing_read',
+    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timing_enable', 'dbh_forward_timing_read',
 ]
 
 
@@ -360,6 +362,13 @@ class HipModel:
     def forward_truncated_dev(self, x_ptr, n_windows, last_stage, stream=None):
         check(self._lib.dbh_forward_truncated_dev(self._handle, x_ptr, n_windows, last_stage,
                                                   stream), 'dbh_forward_truncated_dev')
+
+    def timeline(self, x):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1, self.input_size))
+        out = np.zeros((x.shape[0], 8, 64), dtype=np.int64)
+        check(self._lib.dbh_forward_timeline(self._handle, x, x.shape[0], out),
+              'dbh_forward_timeline')
+        return out
 
     def timing_enable(self, enable=True):
         check(self._lib.dbh_forward_timing_enable(self._handle, 1 if enable else 0),

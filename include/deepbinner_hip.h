@@ -99,7 +99,8 @@ int dbh_predict_dev(dbh_model* model, const float* x_dev, int64_t n_windows, flo
 int dbh_classify_i16(dbh_model* model, const int16_t* samples_host, const int64_t* offsets_host,
                      int64_t n_reads, int side, int scan_size, double score_diff,
                      float* probs_host, int32_t* calls_host);
-/* device-resident variant; workspace_dev must hold dbh_classify_workspace_bytes() bytes. */
+/* device-resident variant; workspace_dev must hold dbh_classify_workspace_bytes() bytes (unused,
+ * and may be NULL, when scan_size is 512: the whole read then finishes inside one launch). */
 int dbh_classify_workspace_bytes(const dbh_model* model, int64_t n_reads, int scan_size,
                                  size_t* bytes);
 int dbh_classify_i16_dev(dbh_model* model, const int16_t* samples_dev, const int64_t* offsets_dev,
@@ -107,11 +108,10 @@ int dbh_classify_i16_dev(dbh_model* model, const int16_t* samples_dev, const int
                          float* probs_dev, int32_t* calls_dev, void* workspace_dev,
                          dbh_stream stream);
 
-/* The same job for many reads in batches of batch_size (the reference's --batch_size loop,
- * classify.py:130) as a three-stage pipeline on internal HIP streams: normalise(i+1), CNN(i) and
- * merge(i-1) overlap, the CNN launches run back to back.  offsets_dev holds n_reads+1 ABSOLUTE
- * offsets into samples_dev.  Work is ordered after what `stream` has queued so far, and `stream`
- * is made to wait for the results; the call itself does not block the host. */
+/* The same job for many reads in batches of batch_size reads (the reference's --batch_size loop,
+ * classify.py:130), queued in order on `stream`.  offsets_dev holds n_reads+1 ABSOLUTE offsets
+ * into samples_dev.  With scan_size 512 every batch is a single kernel launch (slice + normalise
+ * + CNN + renormalise + call); otherwise two (CNN, merge).  Does not block the host. */
 int dbh_classify_i16_batched_dev(dbh_model* model, const int16_t* samples_dev,
                                  const int64_t* offsets_dev, int64_t n_reads, int batch_size,
                                  int side, int scan_size, double score_diff, float* probs_dev,
@@ -138,6 +138,10 @@ int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs);
  * nothing: lets a profiler attribute kernel time to stages by differencing. */
 int dbh_forward_truncated_dev(dbh_model* model, const float* x_dev, int64_t n_windows,
                               int last_stage, dbh_stream stream);
+/* Timeline of one forward launch: every wave of every workgroup stamps the shader cycle counter at
+ * each phase boundary (slot meanings: tools/timeline.py).  stamps_host: n_windows x 8 x 64 int64. */
+int dbh_forward_timeline(dbh_model* model, const float* x_host, int64_t n_windows,
+                         int64_t* stamps_host);
 /* Live kernel timing: while enabled, every launch of the forward kernel is bracketed by HIP events
  * on the stream it is launched on; dbh_forward_timing_read synchronises those events, returns the
  * summed kernel time, the number of launches and of windows they covered, and resets the tally. */

@@ -255,3 +255,27 @@ def test_batched_pipeline_matches_single_call(hip, hip_models, all_signals, side
         hip.synchronize()
         assert np.array_equal(d_c.download((n,), np.int32), want_c)
         assert np.array_equal(d_p.download((n, 13), np.float32), want_p)
+
+
+@pytest.mark.parametrize('side,scan', [('start', 6144), ('end', 6144), ('start', 512), ('end', 512)])
+def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, side, scan):
+    """slice+normalise (and, at one scan step, renormalise+call) fused into the CNN kernel must
+    reproduce normalise kernel -> CNN kernel -> merge kernel bit for bit."""
+    lib = hip.load_library()
+    model = hip_models['EXP-NBD103_read_starts']
+    signals = list(all_signals) + [np.zeros(0, dtype=np.int16), np.full(9, 3, dtype=np.int16)]
+    n, steps = len(signals), scan // 512
+    samples, offsets = pack(signals)
+    d_s, d_o = hip.DeviceBuffer.from_array(samples), hip.DeviceBuffer.from_array(offsets)
+    d_w = hip.DeviceBuffer(n * steps * 1024 * 4)
+    d_wp = hip.DeviceBuffer(n * steps * 13 * 4)
+    d_p, d_c = hip.DeviceBuffer(n * 13 * 4), hip.DeviceBuffer(n * 4)
+    code = 0 if side == 'start' else 1
+    hip.check(lib.dbh_normalise_windows_dev(d_s.ptr, d_o.ptr, n, code, scan, d_w.ptr, None))
+    model.predict_dev(d_w.ptr, n * steps, d_wp.ptr)
+    hip.check(lib.dbh_merge_calls_dev(d_wp.ptr, n, steps, 13, 0.5, d_p.ptr, d_c.ptr, None))
+    hip.synchronize()
+    want_p, want_c = d_p.download((n, 13), np.float32), d_c.download((n,), np.int32)
+    got_p, got_c = model.classify_signals(signals, side, scan, 0.5)
+    assert np.array_equal(got_c, want_c)
+    assert np.array_equal(got_p, want_p)

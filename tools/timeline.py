@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Cycle-accurate phase timeline of the forward kernel (dbh_forward_timeline): average, over all
+workgroups of one 256-window launch, of the per-phase durations seen by the slowest wave.
+Usage: python tools/timeline.py [n_windows]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from deepbinner_amd import hip_backend                      # noqa: E402
+from deepbinner_amd.model_format import ModelWeights        # noqa: E402
+
+LAYERS = ['conv2', 'conv3', 'conv4', 'conv5', 'conv6', 'conv7', 'conv8', 'conv9']
+NAMES = {0: 'start', 1: 'A done'}
+for i, l in enumerate(LAYERS):
+    for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
+        NAMES[2 + 4 * i + j] = '%s %s' % (l, what)
+NAMES.update({34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
+              38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
+for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
+    for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
+        NAMES[base + j] = '%s %s' % (l, what)
+NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    w, _ = ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models',
+                                          'EXP-NBD103_read_starts.dbw'))
+    model = hip_backend.HipModel(w, device=0)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, 1024)).astype(np.float32)
+    model.timeline(x)                       # warm-up
+    st = model.timeline(x)                  # [n, 8 waves, 64]
+    ids = sorted(NAMES)
+    t0 = st[:, :, 0].min(axis=1, keepdims=True)          # block start
+    rel = st[:, :, ids] - t0[:, :, None]                 # cycles since block start
+    last = rel.max(axis=1)                               # slowest wave reaches each mark
+    first = rel.min(axis=1)
+    mean_last = last.mean(axis=0)
+    mean_first = first.mean(axis=0)
+    prev = 0.0
+    rows = []
+    for k, i in enumerate(ids):
+        rows.append((NAMES[i], mean_last[k], mean_last[k] - prev, mean_last[k] - mean_first[k]))
+        prev = mean_last[k]
+    total = mean_last[-1]
+    print('%-26s %10s %9s %7s %10s' % ('mark', 'cum_cycles', 'delta', 'pct', 'wave_skew'))
+    for name, cum, d, skew in rows:
+        print('%-26s %10.0f %9.0f %6.1f%% %10.0f' % (name, cum, d, 100 * d / total, skew))
+    print(json.dumps({'total_cycles': float(total), 'n_windows': n}))
+
+
+if __name__ == '__main__':
+    main()
