@@ -65,6 +65,28 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
             // conv1d_1 stays [tap][cout] for the VALU path
             for (int tap = 0; tap < 3; ++tap)
                 for (int c = 0; c < cout; ++c) dst[tap * 48 + c] = kernel[(tap * cin) * cout + c];
+        } else if (kConv[i].wino) {
+            // Winograd F(2,3): four transformed matrices, computed in fp64, in fragment order
+            const int sp_n = cin / 8, nt = kConv[i].cout_pad / 16;
+            for (int xi = 0; xi < 4; ++xi)
+                for (int sp = 0; sp < sp_n; ++sp)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 2; ++e) {
+                                const int ci = 8 * sp + 2 * (lane >> 4) + e;
+                                const int co = 16 * t + (lane & 15);
+                                double v = 0.0;
+                                if (co < cout) {
+                                    const double g0 = kernel[((size_t)0 * cin + ci) * cout + co];
+                                    const double g1 = kernel[((size_t)1 * cin + ci) * cout + co];
+                                    const double g2 = kernel[((size_t)2 * cin + ci) * cout + co];
+                                    v = xi == 0 ? g0
+                                      : xi == 1 ? 0.5 * (g0 + g1 + g2)
+                                      : xi == 2 ? 0.5 * (g0 - g1 + g2)
+                                                : g2;
+                                }
+                                dst[((((size_t)xi * sp_n + sp) * nt + t) * 64 + lane) * 2 + e] = (float)v;
+                            }
         } else {
             const int sp_n = cin / 8, nt = kConv[i].cout_pad / 16;
             for (int tap = 0; tap < k; ++tap)

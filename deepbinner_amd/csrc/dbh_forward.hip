@@ -77,6 +77,18 @@ __device__ __forceinline__ float lane_value(float v, int src_lane) {
                               __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
+// Compile-time step index handed to a layer's "side job": extra memory requests (next stage's
+// weights) that are trickled out a few per MFMA step instead of as one burst - a burst fills the
+// vector-memory queue and stalls the issuing wave in front of its own MFMAs.
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+struct NoSide {
+    template <int I>
+    __device__ __forceinline__ void operator()(IntC<I>) const {}
+};
+
 template <int MT, int NT>
 struct Frags {
     f2 a[MT];
@@ -128,15 +140,18 @@ __device__ __forceinline__ void frag_wait(Frags<MT, NT>& f) {
     for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(f.b[t]));
 }
 
-template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS, int IT>
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS, int IT,
+          class Side>
 __device__ __forceinline__ void conv_step(unsigned a_addr, unsigned b_addr, Frags<MT, NT> (&buf)[2],
-                                          f4 (&acc)[MT][NT]) {
+                                          f4 (&acc)[MT][NT], const Side& side) {
     constexpr int NIT = TAPS * SP;
     if constexpr (IT + 1 < NIT) {
         load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, IT + 1>(buf[(IT + 1) & 1], a_addr,
                                                                      b_addr);
+        side(IntC<IT>{});
         frag_wait<MT + NT>(buf[IT & 1]);     // the MT+NT reads just issued may stay in flight
     } else {
+        side(IntC<IT>{});
         frag_wait<0>(buf[IT & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -157,19 +172,20 @@ __device__ __forceinline__ void conv_step(unsigned a_addr, unsigned b_addr, Frag
         for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[m][t]));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT + 1 < NIT)
-        conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, IT + 1>(a_addr, b_addr, buf, acc);
+        conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, IT + 1>(a_addr, b_addr, buf, acc, side);
 }
 
 // acc[m][t] += sum over (tap, sp, e) of A-tile(m) x B-tile(t), software-pipelined: the fragments
 // of step it+1 are requested before the MFMAs of step it are issued.  a_lane / b_lane must
 // point into LDS.
-template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS>
+template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS,
+          class Side = NoSide>
 __device__ __forceinline__ void conv_tiles(const float* a_lane, const float* b_lane,
-                                           f4 (&acc)[MT][NT]) {
+                                           f4 (&acc)[MT][NT], const Side& side = Side()) {
     const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(b_lane);
     Frags<MT, NT> buf[2];
     load_frags<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, 0>(buf[0], a_addr, b_addr);
-    conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, 0>(a_addr, b_addr, buf, acc);
+    conv_step<TAPS, SP, SPTOT, MT, NT, NTTOT, S, MROWS, 0>(a_addr, b_addr, buf, acc, side);
 }
 
 template <int MT, int NT>
@@ -263,6 +279,22 @@ __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* 
     }
 }
 
+// The same copy, spread over the NIT steps of the running layer (step IT issues its share).
+template <int NFLOATS, int IT, int NIT>
+__device__ __forceinline__ void dma_weights_slice(const float* __restrict__ g, float* lds_dst,
+                                                  int lane, int wave) {
+    constexpr int kPieces = NFLOATS / 256;
+    constexpr int kPerWave = (kPieces + kWaves - 1) / kWaves;
+#pragma unroll
+    for (int i = IT * kPerWave / NIT; i < (IT + 1) * kPerWave / NIT; ++i) {
+        const int piece = wave + kWaves * i;
+        if (piece < kPieces)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + piece * 256 + lane * 4),
+                (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+    }
+}
+
 __device__ __forceinline__ void zero_row(float* region, int row, int stride, int channels,
                                          int tid) {
     if (tid < channels) region[row * stride + tid] = 0.f;
@@ -282,11 +314,12 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
 //   L       : input length;  POOL/BNI: fused MaxPool2 / batch-norm index (-1 = none)
 //   NEXT_N  : floats of the next block of weights, DMA'd from next_g into next_lds meanwhile
 // ---------------------------------------------------------------------------------------------
-template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N>
+template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N,
+          class Side = NoSide>
 __device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
                                               const float* __restrict__ next_g, float* next_lds,
                                               int tid, int lane, int wave, long long* ts,
-                                              int ts_base) {
+                                              int ts_base, const Side& side = Side()) {
     constexpr int TAPS = kConv[CONV].taps;
     constexpr int SP = kConv[CONV].cin / 8;
     constexpr int NT = kConv[CONV].cout_pad / 16;
@@ -297,7 +330,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     constexpr bool BN = BNI >= 0;
     const int n = lane & 15, q = lane >> 4;
 
-    dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
+    if constexpr (NEXT_N > 0) dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
     EpiParams<NT, BN> ep;
     ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
             packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
@@ -308,7 +341,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     // 'same' k=3: logical row p+tap-1 = physical row p+tap; k=1: physical row p+1.
     const float* a_lane = lds + kActOff + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
     const float* b_lane = lds + W_CUR + lane * 2;
-    conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc);
+    conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc, side);
     mark(ts, ts_base);
 
     __syncthreads();   // every wave has finished reading the old activations and weights
@@ -319,6 +352,188 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, ep);
     zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
     zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
+    mark(ts, ts_base + 2);
+
+    __syncthreads();
+    mark(ts, ts_base + 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1), in place.
+//   For the output pair (2j, 2j+1) and d = x[2j-1 .. 2j+2]:
+//     U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3            (input transform, VALU)
+//     M_xi = U_xi . V_xi  over the 48 input channels             (four GEMMs, MFMA)
+//     y[2j] = M0+M1+M2,  y[2j+1] = M1-M2-M3                      (output transform, epilogue)
+//   with V0 = g0, V1 = (g0+g1+g2)/2, V2 = (g0-g1+g2)/2, V3 = g2 pre-computed on the host:
+//   4 products per output pair instead of 6, i.e. 1.5x fewer MFMAs for the same result
+//   (fp32 round-off differs by a few ulp per layer; the parity tests bound the end effect).
+// A wave owns MT tiles of 16 pairs (= 32 positions each).  The four V matrices arrive as two
+// halves (V0,V1 | V2,V3) in rotating LDS slots: phase 1 multiplies by the first half while the
+// second half of the NEXT layer... see the DMA calls at the call sites.
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+struct WinoFrags {
+    f2 d[MT][3];
+    f2 b[2][3];
+};
+
+template <int MT, int PHASE, int SP_IDX>
+__device__ __forceinline__ void wino_load(WinoFrags<MT>& f, unsigned a_addr, unsigned b_addr) {
+    // phase 0 needs d0,d1,d2 (rows +0..+2 from the tile's first physical row), phase 1 d1,d2,d3
+    static_assert(MT <= 2, "extend wino_load");
+    constexpr int R = PHASE;
+    if constexpr (MT > 0) {
+        f.d[0][0] = ds_read_f2<((0 * 32 + R + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
+        f.d[0][1] = ds_read_f2<((0 * 32 + R + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
+        f.d[0][2] = ds_read_f2<((0 * 32 + R + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    }
+    if constexpr (MT > 1) {
+        f.d[1][0] = ds_read_f2<((1 * 32 + R + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
+        f.d[1][1] = ds_read_f2<((1 * 32 + R + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
+        f.d[1][2] = ds_read_f2<((1 * 32 + R + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    }
+    // the slot holds [xi' 0..1][sp 0..5][t 0..2] fragments of 128 floats
+    f.b[0][0] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
+    f.b[0][1] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
+    f.b[0][2] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
+    f.b[1][0] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
+    f.b[1][1] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
+    f.b[1][2] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
+}
+
+template <int PENDING, int MT>
+__device__ __forceinline__ void wino_wait(WinoFrags<MT>& f) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(f.d[m][k]));
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
+}
+
+template <int MT, int PHASE, int SP_IDX>
+__device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
+                                          f4 (&acc)[4][MT][3]) {
+    constexpr int kLoads = 3 * MT + 6;
+    if constexpr (SP_IDX + 1 < 6) {
+        wino_load<MT, PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
+        wino_wait<kLoads>(buf[SP_IDX & 1]);
+    } else {
+        wino_wait<0>(buf[SP_IDX & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const WinoFrags<MT>& f = buf[SP_IDX & 1];
+    f2 u[2][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if constexpr (PHASE == 0) {
+            u[0][m] = f.d[m][0] - f.d[m][2];     // U0 = d0 - d2
+            u[1][m] = f.d[m][1] + f.d[m][2];     // U1 = d1 + d2
+        } else {                                  // loaded rows are d1, d2, d3
+            u[0][m] = f.d[m][1] - f.d[m][0];     // U2 = d2 - d1
+            u[1][m] = f.d[m][0] - f.d[m][2];     // U3 = d1 - d3
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, acc[2 * PHASE + x][m][t]);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc[2 * PHASE + x][m][t] = mfma4(u[x][m].y, f.b[x][t].y, acc[2 * PHASE + x][m][t]);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][m][t]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP_IDX + 1 < 6) wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
+}
+
+template <int MT, int PHASE>
+__device__ __forceinline__ void wino_phase(const float* a_lane, const float* slot_lane,
+                                           f4 (&acc)[4][MT][3]) {
+    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
+    WinoFrags<MT> buf[2];
+    wino_load<MT, PHASE, 0>(buf[0], a_addr, b_addr);
+    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc);
+}
+
+// One Winograd layer of stage B.  SLOT_A / SLOT_B: LDS homes of this layer's (V0,V1) / (V2,V3).
+// next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
+// at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
+template <int CONV, int L, bool POOL, int BNI, int SLOT_A, int SLOT_B, class Dma1, class Dma2>
+__device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__ packed, int tid,
+                                           int lane, int wave, long long* ts, int ts_base,
+                                           const Dma1& next1, const Dma2& next2) {
+    static_assert(kConv[CONV].wino && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    constexpr int MT = (L / 32) / kWaves;
+    static_assert(MT >= 1 && MT * kWaves * 32 == L, "layer does not tile over the waves");
+    constexpr int LOUT = POOL ? L / 2 : L;
+    constexpr bool BN = BNI >= 0;
+    const int n = lane & 15, q = lane >> 4;
+    const int m0 = wave * MT;
+
+    next1();
+    EpiParams<3, BN> ep;
+    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
+            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    f4 acc[4][MT][3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) zero_acc(acc[x]);
+    // pair j = m0*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
+    const float* a_lane = lds + kActOff + (m0 * 32 + 2 * n) * kS48 + 2 * q;
+    wino_phase<MT, 0>(a_lane, lds + SLOT_A + lane * 2, acc);
+    __syncthreads();      // (V2,V3) have landed for everyone; SLOT_A may be overwritten
+    next2();
+    wino_phase<MT, 1>(a_lane, lds + SLOT_B + lane * 2, acc);
+    mark(ts, ts_base);
+
+    __syncthreads();      // every wave has finished reading the old activations
+    mark(ts, ts_base + 1);
+
+    // output transform + bias + ReLU (+ MaxPool over the pair) (+ BN); lane holds pairs 4q+r
+    float* out = lds + kActOff + n;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f4 even = acc[0][m][t] + acc[1][m][t] + acc[2][m][t];
+            const f4 odd = acc[1][m][t] - acc[2][m][t] - acc[3][m][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ye = fmaxf(even[r] + b, 0.f);
+                float yo = fmaxf(odd[r] + b, 0.f);
+                const int j = (m0 + m) * 16 + 4 * q + r;
+                if (POOL) {
+                    float o = fmaxf(ye, yo);
+                    if (BN) o = fmaf(o, sc, sh);
+                    out[(1 + j) * kS48 + t * 16] = o;
+                } else {
+                    if (BN) {
+                        ye = fmaf(ye, sc, sh);
+                        yo = fmaf(yo, sc, sh);
+                    }
+                    out[(1 + 2 * j) * kS48 + t * 16] = ye;
+                    out[(2 + 2 * j) * kS48 + t * 16] = yo;
+                }
+            }
+        }
+    }
+    zero_row(lds + kActOff, 0, kS48, 48, tid);
+    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
     mark(ts, ts_base + 2);
 
     __syncthreads();
@@ -356,11 +571,29 @@ struct SmallMRegs {
                         b[(tap * SP + sp) * NTW + t] = *reinterpret_cast<const f2*>(
                             b_lane + ((tap * SPTOT + sp) * 3 + t) * 128);
         }
+        prefetch_epilogue(packed, bn_index, lane, wave);
+    }
+    __device__ __forceinline__ void prefetch_epilogue(const float* __restrict__ packed,
+                                                      int bn_index, int lane, int wave) {
         if (wave < 3) {     // the waves that run the epilogue (one N tile each)
             const int ch = wave * 16 + (lane & 15);
             ep.load(packed + bias_offset(CONV) + ch,
                     packed + (BN ? bn_scale_offset(bn_index) : 0) + ch,
                     packed + (BN ? bn_shift_offset(bn_index) : 0) + ch);
+        }
+    }
+    // fragments [K0, K1) only - for trickling the fetch across the steps of an earlier layer
+    template <int K0, int K1>
+    __device__ __forceinline__ void prefetch_slice(const float* __restrict__ packed, int lane,
+                                                   int wave) {
+        if (wave < ACTIVE) {
+            const int t0 = (wave % NGROUPS) * NTW, ks = wave / NGROUPS;
+            const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t0) * 128 + lane * 2;
+#pragma unroll
+            for (int k = K0; k < K1; ++k) {
+                const int t = k % NTW, sp = (k / NTW) % SP, tap = k / (NTW * SP);
+                b[k] = *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * 3 + t) * 128);
+            }
         }
     }
 };
@@ -575,7 +808,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // straight from global (k = lane>>4 picks the tap), B[k][n] = w[k][n].  One MFMA per
     // (position tile, N tile); the standard epilogue applies bias, ReLU and BN1.
     {
-        dma_weights<conv_weight_floats(1)>(packed + weight_offset(1), lds + kW0, lane, wave);
+        // conv2's transformed weights: (V0,V1) -> slot 0, (V2,V3) -> slot 1
+        dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
+        dma_weights<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
         float a[MT], bw[3];
@@ -604,7 +839,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                 s1 += __shfl_xor(s1, off);
                 s2 += __shfl_xor(s2, off);
             }
-            long long* red = reinterpret_cast<long long*>(lds + kW1);   // kW1 is idle in stage A
+            // slot 2 of the weight area is idle until conv2 starts its first DMA
+            long long* red = reinterpret_cast<long long*>(lds + kSlot2);
             if (lane == 0) {
                 red[wave] = s1;
                 red[kWaves + wave] = s2;
@@ -659,12 +895,21 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    inplace_layer<1, kW0, 512, kS48, kS48, false, -1, conv_weight_floats(2)>(
-        lds, packed, packed + weight_offset(2), lds + kW1, tid, lane, wave, ts, 2);
-    inplace_layer<2, kW1, 512, kS48, kS48, false, -1, conv_weight_floats(3)>(
-        lds, packed, packed + weight_offset(3), lds + kW0, tid, lane, wave, ts, 6);
-    inplace_layer<3, kW0, 512, kS48, kS48, true, 1, conv_weight_floats(4)>(
-        lds, packed, packed + weight_offset(4), lds + kW1, tid, lane, wave, ts, 10);
+    // Winograd layers; weight halves rotate through the three slots:
+    //   conv2: (V0,V1)@0 (V2,V3)@1 | conv3: @2 @0 | conv4: @1 @2 | conv5,6 -> slot 0 region
+    wino_layer<1, 512, false, -1, kSlot0, kSlot1>(
+        lds, packed, tid, lane, wave, ts, 2,
+        [&] { dma_weights<kWinoHalf>(packed + weight_offset(2), lds + kSlot2, lane, wave); },
+        [&] { dma_weights<kWinoHalf>(packed + weight_offset(2) + kWinoHalf, lds + kSlot0, lane, wave); });
+    wino_layer<2, 512, false, -1, kSlot2, kSlot0>(
+        lds, packed, tid, lane, wave, ts, 6,
+        [&] { dma_weights<kWinoHalf>(packed + weight_offset(3), lds + kSlot1, lane, wave); },
+        [&] { dma_weights<kWinoHalf>(packed + weight_offset(3) + kWinoHalf, lds + kSlot2, lane, wave); });
+    wino_layer<3, 512, true, 1, kSlot1, kSlot2>(
+        lds, packed, tid, lane, wave, ts, 10,
+        [&] { dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW0, lane, wave); },
+        [&] { dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                 lds + kW0 + conv_weight_floats(4), lane, wave); });
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
@@ -672,12 +917,27 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
-    inplace_layer<4, kW1, 256, kS48, kS16, false, -1, conv_weight_floats(5)>(
-        lds, packed, packed + weight_offset(5), lds + kW0, tid, lane, wave, ts, 14);
-    inplace_layer<5, kW0, 256, kS16, kS48, false, -1, conv_weight_floats(6)>(
-        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave, ts, 18);
-    inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
-        lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave, ts, 22);
+    // conv5's and conv6's weights sit side by side in the first half of the weight area (DMA'd
+    // during conv4); conv7's go to the second half while conv5 runs.
+    inplace_layer<4, kW0, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
+        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave, ts, 14);
+    inplace_layer<5, kW0 + conv_weight_floats(4), 256, kS16, kS48, false, -1, 0>(
+        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
+    // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
+    // here, a couple per MFMA step of conv7, long before stage F needs them.
+    SmallMRegs<16, 8, 3, true> r17;
+    r17.prefetch_epilogue(packed, 5, lane, wave);
+    {
+        constexpr int kSteps7 = kConv[6].taps * (kConv[6].cin / 8);       // 18 MFMA steps
+        constexpr int kFrags17 = decltype(r17)::TAPS * decltype(r17)::SP * 3;   // 27 per wave
+        auto side7 = [&](auto tag) {
+            constexpr int IT = decltype(tag)::value;
+            r17.template prefetch_slice<IT * kFrags17 / kSteps7, (IT + 1) * kFrags17 / kSteps7>(
+                packed, lane, wave);
+        };
+        inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
+            lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave, ts, 22, side7);
+    }
     if (stop_stage == 2) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
@@ -687,13 +947,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     inplace_layer<7, kW0, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
         lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave, ts, 26);
-    // conv9 prefetches ALL inception weights (conv10..16) into their stage-E home, and conv17's
-    // 110 KB of weights start their trip from L2 to registers here too: the whole burst (every
-    // CU of a 256-window launch asks at once) drains under conv9's ~4 us of MFMAs.
-    SmallMRegs<16, 8, 3, true> r17;
-    r17.prefetch(packed, 5, lane, wave);
-    inplace_layer<8, kW1, 128, kS48, kS48, true, 3, kEWFloats>(
-        lds, packed, packed + weight_offset(9), lds + kEW, tid, lane, wave, ts, 30);
+    // conv9 brings ALL inception weights (conv10..16) into their stage-E home by LDS-DMA, a few
+    // 1 KiB pieces per MFMA step.
+    {
+        constexpr int kSteps9 = kConv[8].taps * (kConv[8].cin / 8);       // 18 MFMA steps
+        auto side9 = [&](auto tag) {
+            constexpr int IT = decltype(tag)::value;
+            dma_weights_slice<kEWFloats, IT, kSteps9>(packed + weight_offset(9), lds + kEW, lane,
+                                                      wave);
+        };
+        inplace_layer<8, kW1, 128, kS48, kS48, true, 3, 0>(lds, packed, nullptr, nullptr, tid, lane,
+                                                           wave, ts, 30, side9);
+    }
     if (stop_stage == 3) {
         if (debug_stage < 100)
             dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);

@@ -16,34 +16,37 @@ constexpr int kNumBn = 7;
 // ---------------------------------------------------------------------------------------------
 // Convolution table (index = Keras layer number - 1).  cout_pad is C_out rounded up to 16.
 // ---------------------------------------------------------------------------------------------
-struct ConvSpec { int taps, cin, cout_pad, stride; };
+// wino: the layer runs as Winograd F(2,3) — two outputs per position pair from FOUR
+// element-wise-transformed products instead of six (1.5x fewer MFMAs); its weights are stored
+// as the four transformed matrices  V0 = g0, V1 = (g0+g1+g2)/2, V2 = (g0-g1+g2)/2, V3 = g2.
+struct ConvSpec { int taps, cin, cout_pad, stride; bool wino; };
 constexpr ConvSpec kConv[kNumConvs] = {
-    {3, 1, 48, 2},     // conv1d_1   (VALU path, C_in = 1)
-    {3, 48, 48, 1},    // conv1d_2
-    {3, 48, 48, 1},    // conv1d_3
-    {3, 48, 48, 1},    // conv1d_4
-    {1, 48, 16, 1},    // conv1d_5
-    {3, 16, 48, 1},    // conv1d_6
-    {3, 48, 48, 1},    // conv1d_7
-    {3, 48, 48, 1},    // conv1d_8
-    {3, 48, 48, 1},    // conv1d_9
-    {1, 48, 48, 1},    // conv1d_10
-    {1, 48, 48, 1},    // conv1d_11
-    {1, 48, 16, 1},    // conv1d_12
-    {3, 16, 48, 1},    // conv1d_13
-    {1, 48, 16, 1},    // conv1d_14
-    {3, 16, 48, 1},    // conv1d_15
-    {3, 48, 48, 1},    // conv1d_16
-    {3, 192, 48, 2},   // conv1d_17
-    {3, 48, 48, 1},    // conv1d_18
-    {3, 48, 48, 1},    // conv1d_19
-    {1, 48, 32, 1},    // conv1d_20  (n_classes <= 32, zero padded)
+    {3, 1, 48, 2, false},     // conv1d_1   (K = 3 padded to one MFMA k-step)
+    {3, 48, 48, 1, true},     // conv1d_2
+    {3, 48, 48, 1, true},     // conv1d_3
+    {3, 48, 48, 1, true},     // conv1d_4
+    {1, 48, 16, 1, false},    // conv1d_5
+    {3, 16, 48, 1, false},    // conv1d_6
+    {3, 48, 48, 1, false},    // conv1d_7
+    {3, 48, 48, 1, false},    // conv1d_8
+    {3, 48, 48, 1, false},    // conv1d_9
+    {1, 48, 48, 1, false},    // conv1d_10
+    {1, 48, 48, 1, false},    // conv1d_11
+    {1, 48, 16, 1, false},    // conv1d_12
+    {3, 16, 48, 1, false},    // conv1d_13
+    {1, 48, 16, 1, false},    // conv1d_14
+    {3, 16, 48, 1, false},    // conv1d_15
+    {3, 48, 48, 1, false},    // conv1d_16
+    {3, 192, 48, 2, false},   // conv1d_17
+    {3, 48, 48, 1, false},    // conv1d_18
+    {3, 48, 48, 1, false},    // conv1d_19
+    {1, 48, 32, 1, false},    // conv1d_20  (n_classes <= 32, zero padded)
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
-    return kConv[i].taps * kConv[i].cin * kConv[i].cout_pad;
+    return (kConv[i].wino ? 4 : kConv[i].taps) * kConv[i].cin * kConv[i].cout_pad;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -74,7 +77,8 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // Fragment order of an MFMA-path layer (v_mfma_f32_16x16x4_f32, B operand = weights):
 //   index = (((tap * SP + sp) * NT + t) * 64 + lane) * 2 + e
 //   value = W[tap][8*sp + 2*(lane>>4) + e][16*t + (lane&15)]
-// with SP = C_in/8 and NT = cout_pad/16.  One ds_read_b64 / global_load_dwordx2 per lane yields
+// with SP = C_in/8 and NT = cout_pad/16 (for a Winograd layer "tap" runs over the four
+// transformed matrices V0..V3).  One ds_read_b64 / global_load_dwordx2 per lane yields
 // the B fragments of two consecutive k-steps; the A side (activations) pairs channels the same
 // way, so the contraction order is a fixed permutation of (tap, c_in).
 
@@ -87,14 +91,21 @@ constexpr int kS48 = 52;
 constexpr int kS16 = 20;
 constexpr int kS192 = 196;
 
-// stages A-D: one in-place activation buffer + two weight buffers filled by LDS-DMA
-// (global_load_lds_dwordx4) one layer ahead of use.
+// stages A-D: one in-place activation buffer + a 54 KiB weight area filled by LDS-DMA
+// (global_load_lds_dwordx4) ahead of use.  Direct layers see it as two 6,912-float buffers
+// (kW0, kW1); the Winograd layers of stage B as three 4,608-float slots (two transformed
+// matrices each) rotated so that the half a layer needs next is always already in flight.
 constexpr int kActOff = 0;
 constexpr int kActFloats = (512 + 2) * kS48;               // 26,728
 constexpr int kWFloats = 3 * 48 * 48;                      // 6,912
 constexpr int kW0 = kActOff + kActFloats;
 constexpr int kW1 = kW0 + kWFloats;
 constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 40,552 = 162,208 B
+constexpr int kWinoHalf = 2 * 48 * 48;                     // 4,608: two transformed matrices
+constexpr int kSlot0 = kW0;
+constexpr int kSlot1 = kW0 + kWinoHalf;
+constexpr int kSlot2 = kW0 + 2 * kWinoHalf;
+static_assert(kSlot2 + kWinoHalf == kLdsFloatsAD, "three Winograd slots fill the weight area");
 
 // stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
 // their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
