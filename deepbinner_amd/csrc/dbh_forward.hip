@@ -907,9 +907,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         [&] { dma_weights<kWinoHalf>(packed + weight_offset(3) + kWinoHalf, lds + kSlot2, lane, wave); });
     wino_layer<3, 512, true, 1, kSlot1, kSlot2>(
         lds, packed, tid, lane, wave, ts, 10,
-        [&] { dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW0, lane, wave); },
-        [&] { dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                 lds + kW0 + conv_weight_floats(4), lane, wave); });
+        [&] { dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW5, lane, wave); },
+        [&] { dma_weights<conv_weight_floats(5)>(packed + weight_offset(5), lds + kW6, lane, wave); });
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
@@ -917,27 +916,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
-    // conv5's and conv6's weights sit side by side in the first half of the weight area (DMA'd
-    // during conv4); conv7's go to the second half while conv5 runs.
-    inplace_layer<4, kW0, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
-        lds, packed, packed + weight_offset(6), lds + kW1, tid, lane, wave, ts, 14);
-    inplace_layer<5, kW0 + conv_weight_floats(4), 256, kS16, kS48, false, -1, 0>(
+    // conv5's and conv6's weights sit side by side at the bottom of the weight area (DMA'd
+    // during conv4); conv7's four Winograd matrices follow them, fetched while conv5 runs.
+    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
+        lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
+    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0>(
         lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
-    // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
-    // here, a couple per MFMA step of conv7, long before stage F needs them.
-    SmallMRegs<16, 8, 3, true> r17;
-    r17.prefetch_epilogue(packed, 5, lane, wave);
-    {
-        constexpr int kSteps7 = kConv[6].taps * (kConv[6].cin / 8);       // 18 MFMA steps
-        constexpr int kFrags17 = decltype(r17)::TAPS * decltype(r17)::SP * 3;   // 27 per wave
-        auto side7 = [&](auto tag) {
-            constexpr int IT = decltype(tag)::value;
-            r17.template prefetch_slice<IT * kFrags17 / kSteps7, (IT + 1) * kFrags17 / kSteps7>(
-                packed, lane, wave);
-        };
-        inplace_layer<6, kW1, 256, kS48, kS48, true, 2, conv_weight_floats(7)>(
-            lds, packed, packed + weight_offset(7), lds + kW0, tid, lane, wave, ts, 22, side7);
-    }
+    // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
+    // activation buffer meanwhile
+    wino_layer<6, 256, true, 2, kW7a, kW7b>(
+        lds, packed, tid, lane, wave, ts, 22,
+        [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); },
+        [] {});
     if (stop_stage == 2) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
@@ -945,8 +935,21 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
-    inplace_layer<7, kW0, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
-        lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave, ts, 26);
+    // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
+    // here, a couple per MFMA step of conv8, long before stage F needs them.
+    SmallMRegs<16, 8, 3, true> r17;
+    r17.prefetch_epilogue(packed, 5, lane, wave);
+    {
+        constexpr int kSteps8 = kConv[7].taps * (kConv[7].cin / 8);       // 18 MFMA steps
+        constexpr int kFrags17 = decltype(r17)::TAPS * decltype(r17)::SP * 3;   // 27 per wave
+        auto side8 = [&](auto tag) {
+            constexpr int IT = decltype(tag)::value;
+            r17.template prefetch_slice<IT * kFrags17 / kSteps8, (IT + 1) * kFrags17 / kSteps8>(
+                packed, lane, wave);
+        };
+        inplace_layer<7, kUpper, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
+            lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave, ts, 26, side8);
+    }
     // conv9 brings ALL inception weights (conv10..16) into their stage-E home by LDS-DMA, a few
     // 1 KiB pieces per MFMA step.
     {

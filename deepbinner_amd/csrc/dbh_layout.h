@@ -27,7 +27,7 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {3, 48, 48, 1, true},     // conv1d_4
     {1, 48, 16, 1, false},    // conv1d_5
     {3, 16, 48, 1, false},    // conv1d_6
-    {3, 48, 48, 1, false},    // conv1d_7
+    {3, 48, 48, 1, true},     // conv1d_7
     {3, 48, 48, 1, false},    // conv1d_8
     {3, 48, 48, 1, false},    // conv1d_9
     {1, 48, 48, 1, false},    // conv1d_10
@@ -106,6 +106,16 @@ constexpr int kSlot0 = kW0;
 constexpr int kSlot1 = kW0 + kWinoHalf;
 constexpr int kSlot2 = kW0 + 2 * kWinoHalf;
 static_assert(kSlot2 + kWinoHalf == kLdsFloatsAD, "three Winograd slots fill the weight area");
+// stage C onwards the activations need at most 258 rows, so the upper half of the activation
+// buffer doubles as one more weight buffer
+constexpr int kUpper = 258 * kS48;                          // 13,416
+static_assert(kUpper + 4 * 48 * 48 <= kW0, "upper weight buffer must stay below the weight area");
+// conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
+constexpr int kW5 = kW0;
+constexpr int kW6 = kW5 + 1 * 48 * 16;
+constexpr int kW7a = kW6 + 3 * 16 * 48;
+constexpr int kW7b = kW7a + kWinoHalf;
+static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the weight area");
 
 // stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
 // their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
