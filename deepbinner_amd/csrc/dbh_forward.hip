@@ -414,14 +414,16 @@ __device__ __forceinline__ void wino_wait(WinoFrags<MT>& f) {
         for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
 }
 
-template <int MT, int PHASE, int SP_IDX>
+template <int MT, int PHASE, int SP_IDX, class Side>
 __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
-                                          f4 (&acc)[4][MT][3]) {
+                                          f4 (&acc)[4][MT][3], const Side& side) {
     constexpr int kLoads = 3 * MT + 6;
     if constexpr (SP_IDX + 1 < 6) {
         wino_load<MT, PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
+        side(IntC<SP_IDX>{});
         wino_wait<kLoads>(buf[SP_IDX & 1]);
     } else {
+        side(IntC<SP_IDX>{});
         wino_wait<0>(buf[SP_IDX & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -458,16 +460,16 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
             for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][m][t]));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP_IDX + 1 < 6) wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
+    if constexpr (SP_IDX + 1 < 6) wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, side);
 }
 
-template <int MT, int PHASE>
+template <int MT, int PHASE, class Side = NoSide>
 __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slot_lane,
-                                           f4 (&acc)[4][MT][3]) {
+                                           f4 (&acc)[4][MT][3], const Side& side = Side()) {
     const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
     WinoFrags<MT> buf[2];
     wino_load<MT, PHASE, 0>(buf[0], a_addr, b_addr);
-    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc);
+    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc, side);
 }
 
 // One Winograd layer of stage B.  SLOT_A / SLOT_B: LDS homes of this layer's (V0,V1) / (V2,V3).
@@ -529,6 +531,105 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
                     out[(1 + 2 * j) * kS48 + t * 16] = ye;
                     out[(2 + 2 * j) * kS48 + t * 16] = yo;
                 }
+            }
+        }
+    }
+    zero_row(lds + kActOff, 0, kS48, 48, tid);
+    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
+    mark(ts, ts_base + 2);
+
+    __syncthreads();
+    mark(ts, ts_base + 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same Winograd layer at L = 128, where there are only four 16-pair tiles for eight waves:
+// wave w takes tile w&3 and ONE half of the transform pair (w < 4: M0,M1 from V0,V1; w >= 4:
+// M2,M3 from V2,V3), 72 MFMAs each, and partner waves (w, w+4) swap what the other needs
+// through XCHG before the fused epilogue:
+//   no pooling: the low wave finishes the even positions (M0+M1+M2), the high wave the odd
+//               ones (M1-M2-M3);
+//   pooling   : max(even, odd) needs both in one lane, so the high wave ships M2 and M2+M3 and
+//               the low wave finishes the tile alone.
+// The exchange write precedes the barrier that also ends the activation reads, so the layer
+// still costs two barriers.
+// ---------------------------------------------------------------------------------------------
+template <int CONV, bool POOL, int BNI, int SLOT_A, int SLOT_B, int XCHG, class Side,
+          class StepSide = NoSide>
+__device__ __forceinline__ void wino_split_layer(float* lds, const float* __restrict__ packed,
+                                                 int tid, int lane, int wave, long long* ts,
+                                                 int ts_base, const Side& side,
+                                                 const StepSide& step_side = StepSide()) {
+    static_assert(kConv[CONV].wino && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    constexpr int L = 128;
+    constexpr int LOUT = POOL ? L / 2 : L;
+    constexpr bool BN = BNI >= 0;
+    const int n = lane & 15, q = lane >> 4;
+    const int m = wave & 3;
+    const bool high = wave >= 4;
+
+    side();
+    EpiParams<3, BN> ep;
+    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
+            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    f4 acc[4][1][3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) zero_acc(acc[x]);
+    const float* a_lane = lds + kActOff + (m * 32 + 2 * n) * kS48 + 2 * q;
+    float* mine = lds + XCHG + (wave & 3) * 6 * 256 + lane * 4;     // slot shared by the pair
+    if (!high) {
+        wino_phase<1, 0>(a_lane, lds + SLOT_A + lane * 2, acc, step_side);
+        if (!POOL) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(mine + t * 256) = acc[1][0][t];
+        }
+    } else {
+        wino_phase<1, 1>(a_lane, lds + SLOT_B + lane * 2, acc, step_side);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<f4*>(mine + (3 + t) * 256) = acc[2][0][t];
+            if (POOL) *reinterpret_cast<f4*>(mine + t * 256) = acc[2][0][t] + acc[3][0][t];
+        }
+    }
+    mark(ts, ts_base);
+
+    __syncthreads();      // activations fully read; exchange tiles visible
+    mark(ts, ts_base + 1);
+
+    float* out = lds + kActOff + n;
+    if (!POOL) {
+        // low wave: even positions from M0+M1 (+M2 from the partner); high wave: odd positions
+        // from -(M2+M3) (+M1 from the partner)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+            f4 y;
+            if (!high)
+                y = acc[0][0][t] + acc[1][0][t] + *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
+            else
+                y = *reinterpret_cast<const f4*>(mine + t * 256) - acc[2][0][t] - acc[3][0][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(y[r] + b, 0.f);
+                if (BN) v = fmaf(v, sc, sh);
+                const int j = m * 16 + 4 * q + r;
+                out[(1 + 2 * j + (high ? 1 : 0)) * kS48 + t * 16] = v;
+            }
+        }
+    } else if (!high) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+            const f4 m2 = *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
+            const f4 m23 = *reinterpret_cast<const f4*>(mine + t * 256);
+            const f4 even = acc[0][0][t] + acc[1][0][t] + m2;
+            const f4 odd = acc[1][0][t] - m23;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = fmaxf(fmaxf(even[r] + b, 0.f), fmaxf(odd[r] + b, 0.f));
+                if (BN) o = fmaf(o, sc, sh);
+                const int j = m * 16 + 4 * q + r;
+                out[(1 + j) * kS48 + t * 16] = o;
             }
         }
     }
@@ -936,32 +1037,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
 
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
-    // here, a couple per MFMA step of conv8, long before stage F needs them.
+    // while conv8 runs, long before stage F needs them; conv9's Winograd matrices go to the top
+    // of the arena by DMA.
     SmallMRegs<16, 8, 3, true> r17;
     r17.prefetch_epilogue(packed, 5, lane, wave);
-    {
-        constexpr int kSteps8 = kConv[7].taps * (kConv[7].cin / 8);       // 18 MFMA steps
-        constexpr int kFrags17 = decltype(r17)::TAPS * decltype(r17)::SP * 3;   // 27 per wave
-        auto side8 = [&](auto tag) {
+    wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
+        lds, packed, tid, lane, wave, ts, 26,
+        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
+        [&](auto tag) {      // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
             constexpr int IT = decltype(tag)::value;
-            r17.template prefetch_slice<IT * kFrags17 / kSteps8, (IT + 1) * kFrags17 / kSteps8>(
-                packed, lane, wave);
-        };
-        inplace_layer<7, kUpper, 128, kS48, kS48, false, -1, conv_weight_floats(8)>(
-            lds, packed, packed + weight_offset(8), lds + kW1, tid, lane, wave, ts, 26, side8);
-    }
-    // conv9 brings ALL inception weights (conv10..16) into their stage-E home by LDS-DMA, a few
-    // 1 KiB pieces per MFMA step.
-    {
-        constexpr int kSteps9 = kConv[8].taps * (kConv[8].cin / 8);       // 18 MFMA steps
-        auto side9 = [&](auto tag) {
-            constexpr int IT = decltype(tag)::value;
-            dma_weights_slice<kEWFloats, IT, kSteps9>(packed + weight_offset(9), lds + kEW, lane,
-                                                      wave);
-        };
-        inplace_layer<8, kW1, 128, kS48, kS48, true, 3, 0>(lds, packed, nullptr, nullptr, tid, lane,
-                                                           wave, ts, 30, side9);
-    }
+            r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
+        });
+    // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
+    wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
+        lds, packed, tid, lane, wave, ts, 30, [&] {
+            dma_weights<kEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave);
+        });
     if (stop_stage == 3) {
         if (debug_stage < 100)
             dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);

@@ -28,8 +28,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {1, 48, 16, 1, false},    // conv1d_5
     {3, 16, 48, 1, false},    // conv1d_6
     {3, 48, 48, 1, true},     // conv1d_7
-    {3, 48, 48, 1, false},    // conv1d_8
-    {3, 48, 48, 1, false},    // conv1d_9
+    {3, 48, 48, 1, true},     // conv1d_8
+    {3, 48, 48, 1, true},     // conv1d_9
     {1, 48, 48, 1, false},    // conv1d_10
     {1, 48, 48, 1, false},    // conv1d_11
     {1, 48, 16, 1, false},    // conv1d_12
@@ -116,6 +116,14 @@ constexpr int kW6 = kW5 + 1 * 48 * 16;
 constexpr int kW7a = kW6 + 3 * 16 * 48;
 constexpr int kW7b = kW7a + kWinoHalf;
 static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the weight area");
+// stage D (L = 128, Winograd split over wave pairs): conv8's weights in the upper buffer, its
+// pair-exchange scratch right above the activations; conv9's weights at the top of the arena
+// and its exchange scratch below them, both clear of the stage-E weights arriving meanwhile.
+constexpr int kXchgFloats = 4 * 6 * 256;                   // 4 sender waves x 6 tiles x 256
+constexpr int kX8 = 130 * kS48 + 8;                        // 6,768
+constexpr int kW9 = kLdsFloatsAD - 4 * 48 * 48;            // 31,336
+constexpr int kX9 = kW9 - kXchgFloats;                     // 25,192
+static_assert(kX8 + kXchgFloats <= kUpper, "conv8 exchange scratch hits its weights");
 
 // stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
 // their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
@@ -129,7 +137,7 @@ constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 5
 constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
 constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
 static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
-static_assert(kEW + kEWFloats <= kW1, "stage-E weights would land on conv9's weight buffer");
+static_assert(kEW + kEWFloats <= kX9, "stage-E weights would land on conv9's scratch/weights");
 
 // stages F-H (reuse the front of the arena; the concat buffer stays where it is)
 constexpr int kFOut = 0;                                   // conv17+BN6 out, 18 rows x 52
