@@ -7,20 +7,22 @@
 // model.predict (deepbinner/classify.py:361) — see oracle/network_ref.py for the operator
 // semantics (TensorFlow SAME padding, valid-count average pooling, BN after ReLU/pool).
 //
-// How: every convolution except conv1d_1 (C_in = 1, VALU) is a sum over taps of
-// [positions x C_in] . [C_in x C_out] products issued on the fp32 matrix pipe
-// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains at the vector-ALU rate, which leaves the VALU
-// free for the fused bias+ReLU(+MaxPool2)(+BatchNorm) epilogues).  M = 16 positions,
-// N = 16 output channels, K = 4 input channels per instruction.
-//   A fragments (activations): ds_read_b64 from the [position][channel] LDS image, row stride
-//     C+4 floats so the 16 rows of a tile fall on distinct bank groups;
-//   B fragments (weights): ds_read_b64 from a fragment-ordered copy staged in LDS (layers with
-//     >= 4 position tiles, where each weight is reused by every tile) or global_load_dwordx2
-//     straight from L2 (the L = 16 / 8 tail, where each weight is used once per window);
-//   accumulators stay in registers until the whole layer has been read, so layers at L = 512
-//     update the single 104 KiB activation buffer in place (barrier, write, barrier);
-//   the next layer's weights are copied L2 -> LDS by the DMA path (global_load_lds_dwordx4)
-//     into the other of two weight buffers while the current layer's MFMAs run.
+// How (DESIGN.md section 4 has the full account):
+//   - every convolution is a sum of [positions x C_in] . [C_in x C_out] products on the fp32
+//     matrix pipe (v_mfma_f32_16x16x4_f32: M = 16 positions, N = 16 output channels, K = 4 input
+//     channels; exact fp32 FMA chains at the vector-ALU rate, VALU free for the epilogues);
+//   - the six 48->48 k=3 layers at L >= 128 (84 % of the FLOPs) run as Winograd F(2,3): four
+//     transformed products per output pair instead of six, 1.5x fewer MFMAs;
+//   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row stride
+//     C+4 floats, conflict-free), issued from inline asm one step ahead with hand-counted waits;
+//   - B fragments (weights): ds_read_b64 from a fragment-ordered copy that LDS-DMA
+//     (global_load_lds_dwordx4) brought in one layer ahead, or - for the single-tile tail layers,
+//     where a weight is used once per window - global loads straight into registers, trickled
+//     out several stages ahead;
+//   - accumulators hold a whole layer, so the 104 KiB activation buffer is updated in place
+//     (barrier, fused bias/ReLU/MaxPool/BatchNorm epilogue, barrier);
+//   - in seam-b2 mode the kernel also slices and z-normalises its int16 window (fp64, exact
+//     integer sums) and, for one-window reads, renormalises and makes the barcode call.
 #include <hip/hip_runtime.h>
 
 #include "dbh_layout.h"
@@ -222,12 +224,22 @@ struct EpiParams {
     }
 };
 
-template <int MT, int NT, int S_OUT, bool POOL, bool BN>
+// Start the accumulators at the bias instead of zero: the MFMA chain then delivers conv + bias
+// and the epilogue saves one VALU add per output (ADD_BIAS = false below).
+template <int MT, int NT, bool BN>
+__device__ __forceinline__ void bias_acc(f4 (&acc)[MT][NT], const EpiParams<NT, BN>& ep) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]};
+}
+
+template <int MT, int NT, int S_OUT, bool POOL, bool BN, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lane,
                                          const EpiParams<NT, BN>& ep) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float b = ep.b[t];
+        const float b = ADD_BIAS ? ep.b[t] : 0.f;
         const float sc = ep.sc[t], sh = ep.sh[t];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -336,7 +348,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
             packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
 
     f4 acc[MT][NT];
-    zero_acc(acc);
+    bias_acc(acc, ep);
     const int m0 = wave * MT;
     // 'same' k=3: logical row p+tap-1 = physical row p+tap; k=1: physical row p+1.
     const float* a_lane = lds + kActOff + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
@@ -349,7 +361,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
 
     float* out_lane = lds + kActOff +
                       (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
-    epilogue<MT, NT, S_OUT, POOL, BN>(acc, out_lane, ep);
+    epilogue<MT, NT, S_OUT, POOL, BN, false>(acc, out_lane, ep);
     zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
     zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
     mark(ts, ts_base + 2);
@@ -491,9 +503,18 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
     EpiParams<3, BN> ep;
     ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
             packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    // M0 starts at +bias and M3 at -bias, so even = M0+M1+M2 and odd = M1-M2-M3 both arrive
+    // with the bias already added
     f4 acc[4][MT][3];
+    zero_acc(acc[1]);
+    zero_acc(acc[2]);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) zero_acc(acc[x]);
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            acc[0][m][t] = f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]};
+            acc[3][m][t] = f4{-ep.b[t], -ep.b[t], -ep.b[t], -ep.b[t]};
+        }
     // pair j = m0*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
     const float* a_lane = lds + kActOff + (m0 * 32 + 2 * n) * kS48 + 2 * q;
     wino_phase<MT, 0>(a_lane, lds + SLOT_A + lane * 2, acc);
@@ -509,15 +530,15 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
     float* out = lds + kActOff + n;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+        const float sc = ep.sc[t], sh = ep.sh[t];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const f4 even = acc[0][m][t] + acc[1][m][t] + acc[2][m][t];
             const f4 odd = acc[1][m][t] - acc[2][m][t] - acc[3][m][t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float ye = fmaxf(even[r] + b, 0.f);
-                float yo = fmaxf(odd[r] + b, 0.f);
+                float ye = fmaxf(even[r], 0.f);
+                float yo = fmaxf(odd[r], 0.f);
                 const int j = (m0 + m) * 16 + 4 * q + r;
                 if (POOL) {
                     float o = fmaxf(ye, yo);
@@ -573,8 +594,13 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
             packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
     f4 acc[4][1][3];
+    zero_acc(acc[1]);
+    zero_acc(acc[2]);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) zero_acc(acc[x]);
+    for (int t = 0; t < 3; ++t) {     // +bias rides in M0 (even outputs), -bias in M3 (odd)
+        acc[0][0][t] = f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]};
+        acc[3][0][t] = f4{-ep.b[t], -ep.b[t], -ep.b[t], -ep.b[t]};
+    }
     const float* a_lane = lds + kActOff + (m * 32 + 2 * n) * kS48 + 2 * q;
     float* mine = lds + XCHG + (wave & 3) * 6 * 256 + lane * 4;     // slot shared by the pair
     if (!high) {
@@ -602,7 +628,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
         // from -(M2+M3) (+M1 from the partner)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+            const float sc = ep.sc[t], sh = ep.sh[t];
             f4 y;
             if (!high)
                 y = acc[0][0][t] + acc[1][0][t] + *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
@@ -610,7 +636,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
                 y = *reinterpret_cast<const f4*>(mine + t * 256) - acc[2][0][t] - acc[3][0][t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(y[r] + b, 0.f);
+                float v = fmaxf(y[r], 0.f);
                 if (BN) v = fmaf(v, sc, sh);
                 const int j = m * 16 + 4 * q + r;
                 out[(1 + 2 * j + (high ? 1 : 0)) * kS48 + t * 16] = v;
@@ -619,14 +645,14 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     } else if (!high) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const float b = ep.b[t], sc = ep.sc[t], sh = ep.sh[t];
+            const float sc = ep.sc[t], sh = ep.sh[t];
             const f4 m2 = *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
             const f4 m23 = *reinterpret_cast<const f4*>(mine + t * 256);
             const f4 even = acc[0][0][t] + acc[1][0][t] + m2;
             const f4 odd = acc[1][0][t] - m23;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float o = fmaxf(fmaxf(even[r] + b, 0.f), fmaxf(odd[r] + b, 0.f));
+                float o = fmaxf(fmaxf(even[r], odd[r]), 0.f);
                 if (BN) o = fmaf(o, sc, sh);
                 const int j = m * 16 + 4 * q + r;
                 out[(1 + j) * kS48 + t * 16] = o;
@@ -783,11 +809,11 @@ __device__ __forceinline__ void inception_1x1(const float* in_region, const floa
     EpiParams<1, POOLBN> ep;
     ep.load(bias_lane, scale_lane, shift_lane);
     f4 acc[4][1];
-    zero_acc(acc);
+    bias_acc(acc, ep);
     conv_tiles<1, 6, 6, 4, 1, NTTOT, kS48, 16>(in_region + (n + 1) * kS48 + 2 * q,
                                                w_lds + t * 128 + lane * 2, acc);
     float* out_lane = out_region + (1 + (POOLBN ? 2 * q : 4 * q)) * S_OUT + out_ch + n;
-    epilogue<4, 1, S_OUT, POOLBN, POOLBN>(acc, out_lane, ep);
+    epilogue<4, 1, S_OUT, POOLBN, POOLBN, false>(acc, out_lane, ep);
 }
 
 // k=3 convolution of the inception block: MT position tiles from tile m0 x NT channel tiles
@@ -803,12 +829,12 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
     EpiParams<NT, POOLBN> ep;
     ep.load(bias_lane, scale_lane, shift_lane);
     f4 acc[MT][NT];
-    zero_acc(acc);
+    bias_acc(acc, ep);
     conv_tiles<3, SP, SP, MT, NT, 3, S_IN, 16>(in_region + (m0 * 16 + n) * S_IN + 2 * q,
                                                w_lds + t * 128 + lane * 2, acc);
     float* out_lane = out_region +
                       (1 + (POOLBN ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + out_ch + n;
-    epilogue<MT, NT, S_OUT, POOLBN, POOLBN>(acc, out_lane, ep);
+    epilogue<MT, NT, S_OUT, POOLBN, POOLBN, false>(acc, out_lane, ep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1050,8 +1076,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         });
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
-        lds, packed, tid, lane, wave, ts, 30, [&] {
-            dma_weights<kEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave);
+        lds, packed, tid, lane, wave, ts, 30, [] {},
+        [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
+            dma_weights_slice<kEWFloats, decltype(tag)::value, 6>(packed + weight_offset(9),
+                                                                  lds + kEW, lane, wave);
         });
     if (stop_stage == 3) {
         if (debug_stage < 100)

@@ -279,3 +279,27 @@ def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, sid
     got_p, got_c = model.classify_signals(signals, side, scan, 0.5)
     assert np.array_equal(got_c, want_c)
     assert np.array_equal(got_p, want_p)
+
+
+def test_bench_two_ranks_share_one_gpu(hip):
+    """bench.py's N > 1 path (torchrun env, sharded reads, gather, MAX-over-ranks timing, one JSON
+    line from rank 0) on a one-GPU box: both ranks use device 0, gather over gloo."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DEEPBINNER_BENCH_SHARE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    result = json.loads(lines[0])
+    assert result['n_gpus'] == 2 and result['steps'] == 3 and result['value'] > 0
+    assert result['scaling'] == 'weak' and 'roofline' in result
