@@ -127,6 +127,15 @@ struct dbh_model {
     void* d_in = nullptr;      size_t in_bytes = 0;
     void* d_work = nullptr;    size_t work_bytes = 0;
     void* d_out = nullptr;     size_t out_bytes = 0;
+    // double-buffered host <-> device staging of dbh_classify_i16 (overlapped H2D / D2H)
+    struct Slot {
+        hipStream_t stream = nullptr;
+        void* h_in = nullptr;   size_t h_in_bytes = 0;     // pinned
+        void* h_out = nullptr;  size_t h_out_bytes = 0;    // pinned
+        void* d_in = nullptr;   size_t d_in_bytes = 0;
+        void* d_out = nullptr;  size_t d_out_bytes = 0;
+        void* d_work = nullptr; size_t d_work_bytes = 0;
+    } slot[2];
     // live timing of the forward kernel (dbh_forward_timing_*)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -156,6 +165,18 @@ struct FusedInput {          // seam-b2 mode of the forward kernel (all null/zer
     double score_diff = 0.0;
     int32_t* calls = nullptr;
 };
+
+int ensure_host(void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return DBH_OK;
+    if (*ptr) {
+        DBH_HIP(hipHostFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    DBH_HIP(hipHostMalloc(ptr, need, hipHostMallocDefault));
+    *have = need;
+    return DBH_OK;
+}
 
 int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev,
                    int debug_stage, float* debug_dev, hipStream_t stream,
@@ -364,6 +385,14 @@ int dbh_model_destroy(dbh_model* m) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    for (auto& sl : m->slot) {
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.d_work) (void)hipFree(sl.d_work);
+    }
     delete m;
     return DBH_OK;
 }
@@ -519,45 +548,68 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
     if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
         (side != DBH_SIDE_START && side != DBH_SIDE_END))
         return DBH_ERR_INVALID_ARGUMENT;
-    // bounded device footprint: process reads in groups whose windows fit ~512 MiB of fp32
+    // Reads travel in groups through two staging slots, each with its own stream: while the GPU
+    // works on group g, the host packs and uploads group g+1 and the results of group g-1 come
+    // back - H2D, kernels and D2H of neighbouring groups overlap.
+    const int C = m->n_classes;
     const int64_t group = (int64_t)(131072 / steps) > 0 ? (131072 / steps) : 1;
-    for (int64_t r0 = 0; r0 < n_reads; r0 += group) {
+    struct Pending { int64_t r0 = 0, cnt = 0; bool live = false; } pending[2];
+    auto drain = [&](int k) -> int {
+        dbh_model::Slot& sl = m->slot[k];
+        if (!pending[k].live) return DBH_OK;
+        DBH_HIP(hipStreamSynchronize(sl.stream));
+        const int64_t cnt = pending[k].cnt, r0 = pending[k].r0;
+        std::memcpy(probs_host + r0 * C, sl.h_out, (size_t)cnt * C * sizeof(float));
+        std::memcpy(calls_host + r0, (char*)sl.h_out + (size_t)cnt * C * sizeof(float),
+                    (size_t)cnt * sizeof(int32_t));
+        pending[k].live = false;
+        return DBH_OK;
+    };
+    int64_t g = 0;
+    for (int64_t r0 = 0; r0 < n_reads; r0 += group, ++g) {
+        const int k = (int)(g & 1);
+        dbh_model::Slot& sl = m->slot[k];
+        int st = drain(k);
+        if (st != DBH_OK) return st;
+        if (!sl.stream) DBH_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         const int64_t cnt = (n_reads - r0 < group) ? (n_reads - r0) : group;
         const int64_t s0 = offsets_host[r0], s1 = offsets_host[r0 + cnt];
         if (s1 < s0) return DBH_ERR_INVALID_ARGUMENT;
-        const size_t sample_bytes = (size_t)(s1 - s0) * sizeof(int16_t);
+        const size_t sample_bytes = ((size_t)(s1 - s0) * sizeof(int16_t) + 255) & ~(size_t)255;
         const size_t off_bytes = (size_t)(cnt + 1) * sizeof(int64_t);
-        const size_t in_need = ((sample_bytes + 255) & ~(size_t)255) + off_bytes;
-        int st = ensure(&m->d_in, &m->in_bytes, in_need ? in_need : 256);
-        if (st != DBH_OK) return st;
+        const size_t in_bytes = sample_bytes + off_bytes;
+        const size_t out_bytes = (size_t)cnt * C * sizeof(float) + (size_t)cnt * sizeof(int32_t);
         size_t work = 0;
         st = dbh_classify_workspace_bytes(m, cnt, scan_size, &work);
-        if (st != DBH_OK) return st;
-        st = ensure(&m->d_work, &m->work_bytes, work);
-        if (st != DBH_OK) return st;
-        const size_t out_need = (size_t)cnt * m->n_classes * sizeof(float) + (size_t)cnt * sizeof(int32_t);
-        st = ensure(&m->d_out, &m->out_bytes, out_need);
+        if (st == DBH_OK) st = ensure_host(&sl.h_in, &sl.h_in_bytes, in_bytes);
+        if (st == DBH_OK) st = ensure_host(&sl.h_out, &sl.h_out_bytes, out_bytes);
+        if (st == DBH_OK) st = ensure(&sl.d_in, &sl.d_in_bytes, in_bytes);
+        if (st == DBH_OK) st = ensure(&sl.d_out, &sl.d_out_bytes, out_bytes);
+        if (st == DBH_OK) st = ensure(&sl.d_work, &sl.d_work_bytes, work);
         if (st != DBH_OK) return st;
 
-        std::vector<int64_t> rel((size_t)cnt + 1);
-        for (int64_t i = 0; i <= cnt; ++i) rel[(size_t)i] = offsets_host[r0 + i] - s0;
-        int16_t* d_samples = (int16_t*)m->d_in;
-        int64_t* d_offsets = (int64_t*)((char*)m->d_in + ((sample_bytes + 255) & ~(size_t)255));
-        if (sample_bytes)
-            DBH_HIP(hipMemcpyAsync(d_samples, samples_host + s0, sample_bytes, hipMemcpyHostToDevice, 0));
-        DBH_HIP(hipMemcpyAsync(d_offsets, rel.data(), off_bytes, hipMemcpyHostToDevice, 0));
-        float* d_probs = (float*)m->d_out;
-        int32_t* d_calls = (int32_t*)((char*)m->d_out + (size_t)cnt * m->n_classes * sizeof(float));
-        st = dbh_classify_i16_dev(m, d_samples, d_offsets, cnt, side, scan_size, score_diff, d_probs,
-                                  d_calls, m->d_work, 0);
+        if (s1 > s0) {
+            if (!samples_host) return DBH_ERR_INVALID_ARGUMENT;
+            std::memcpy(sl.h_in, samples_host + s0, (size_t)(s1 - s0) * sizeof(int16_t));
+        }
+        int64_t* rel = (int64_t*)((char*)sl.h_in + sample_bytes);
+        for (int64_t i = 0; i <= cnt; ++i) rel[i] = offsets_host[r0 + i] - s0;
+        DBH_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, sl.stream));
+        float* d_probs = (float*)sl.d_out;
+        int32_t* d_calls = (int32_t*)((char*)sl.d_out + (size_t)cnt * C * sizeof(float));
+        st = dbh_classify_i16_dev(m, (const int16_t*)sl.d_in,
+                                  (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side,
+                                  scan_size, score_diff, d_probs, d_calls, sl.d_work,
+                                  (dbh_stream)sl.stream);
         if (st != DBH_OK) return st;
-        DBH_HIP(hipMemcpyAsync(probs_host + r0 * m->n_classes, d_probs,
-                               (size_t)cnt * m->n_classes * sizeof(float), hipMemcpyDeviceToHost, 0));
-        DBH_HIP(hipMemcpyAsync(calls_host + r0, d_calls, (size_t)cnt * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, 0));
-        DBH_HIP(hipStreamSynchronize(0));
+        DBH_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream));
+        pending[k].r0 = r0;
+        pending[k].cnt = cnt;
+        pending[k].live = true;
     }
-    return DBH_OK;
+    int st = drain(0);
+    if (st != DBH_OK) return st;
+    return drain(1);
 }
 
 int dbh_stage_floats(int stage, int64_t* floats_per_window) {
