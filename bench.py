@@ -42,6 +42,7 @@ N_READS = 10000
 BATCH = 256
 SCAN_SIZE = 512
 SCORE_DIFF = 0.5
+TIMING_STRIDE = 8
 
 
 def synthetic_reads(n, seed):
@@ -95,6 +96,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true',
+                    help='experiment: skip the per-launch HIP events (roofline object omitted)')
     args = ap.parse_args()
 
     rank, local_rank, world = env_world()
@@ -163,7 +166,9 @@ def main():
     sync()
     barrier()
     sync()
-    model.timing_enable(True)
+    # HIP events around every 8th forward launch (5 of the 40 launches of a step): recording them
+    # around EVERY launch costs ~7 us of queue time per batch and slows what is being measured
+    model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -196,7 +201,9 @@ def main():
                    'parallelism': 'reads sharded, {} rank(s), RCCL all_gather of calls'.format(world)
                    if world > 1 else 'single GPU'},
     }
-    if rank == 0:
+    if rank == 0 and args.no_kernel_timing:
+        print(json.dumps(result))
+    elif rank == 0:
         avg_ms = kernel_ms / max(launches, 1)
         windows_per_launch = windows / max(launches, 1)
         achieved = FLOP_PER_WINDOW * windows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
@@ -209,6 +216,7 @@ def main():
             'bound': 'mfma', 'kernel': 'dbh_forward_kernel', 'achieved': achieved,
             'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
             'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
+            'timed_every_nth_launch': TIMING_STRIDE,
             'windows_per_launch': windows_per_launch,
             'algorithmic_flop_per_window': FLOP_PER_WINDOW,
             # fused seam b2: int16 samples in, fp32 probabilities + int32 call out

@@ -137,7 +137,8 @@ struct dbh_model {
         void* d_work = nullptr; size_t d_work_bytes = 0;
     } slot[2];
     // live timing of the forward kernel (dbh_forward_timing_*)
-    bool timing = false;
+    int timing = 0;              // 0 = off, n = bracket every n-th forward launch with events
+    int64_t launch_counter = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     int64_t timed_windows = 0;
@@ -187,7 +188,8 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
     for (int64_t off = 0; off < n; off += kChunk) {
         const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
         hipEvent_t ev_stop = nullptr;
-        if (m->timing && (debug_stage < 0 || debug_stage >= 100)) {
+        if (m->timing > 0 && (debug_stage < 0 || debug_stage >= 100) &&
+            (m->launch_counter++ % m->timing) == 0) {
             if (m->events_used == m->events.size()) {
                 hipEvent_t a, b;
                 DBH_HIP(hipEventCreate(&a));
@@ -675,7 +677,8 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
 
 int dbh_forward_timing_enable(dbh_model* m, int enable) {
     if (!m) return DBH_ERR_INVALID_ARGUMENT;
-    m->timing = enable != 0;
+    m->timing = enable > 0 ? enable : 0;
+    m->launch_counter = 0;
     m->events_used = 0;
     m->timed_windows = 0;
     return DBH_OK;

@@ -370,8 +370,9 @@ class HipModel:
               'dbh_forward_timeline')
         return out
 
-    def timing_enable(self, enable=True):
-        check(self._lib.dbh_forward_timing_enable(self._handle, 1 if enable else 0),
+    def timing_enable(self, every_nth=1):
+        """Bracket every n-th forward launch with HIP events (0/False = off, True = every)."""
+        check(self._lib.dbh_forward_timing_enable(self._handle, int(every_nth)),
               'dbh_forward_timing_enable')
 
     def timing_read(self):

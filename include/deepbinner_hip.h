@@ -142,9 +142,11 @@ int dbh_forward_truncated_dev(dbh_model* model, const float* x_dev, int64_t n_wi
  * each phase boundary (slot meanings: tools/timeline.py).  stamps_host: n_windows x 8 x 64 int64. */
 int dbh_forward_timeline(dbh_model* model, const float* x_host, int64_t n_windows,
                          int64_t* stamps_host);
-/* Live kernel timing: while enabled, every launch of the forward kernel is bracketed by HIP events
- * on the stream it is launched on; dbh_forward_timing_read synchronises those events, returns the
- * summed kernel time, the number of launches and of windows they covered, and resets the tally. */
+/* Live kernel timing: with enable = n > 0, every n-th launch of the forward kernel is bracketed by
+ * HIP events on the stream it is launched on (n = 1: every launch; the event pair itself costs a
+ * few microseconds of queue time, so sampling keeps the measurement from slowing what it
+ * measures); dbh_forward_timing_read synchronises those events, returns the summed kernel time,
+ * the number of timed launches and of windows they covered, and resets the tally. 0 = off. */
 int dbh_forward_timing_enable(dbh_model* model, int enable);
 int dbh_forward_timing_read(dbh_model* model, double* total_ms, int64_t* launches,
                             int64_t* windows);
