@@ -43,7 +43,13 @@ def classify(args):
         sys.exit('Error: training data can only be classified using a single model')
     print('', file=sys.stderr)
 
-    if input_type == 'directory':
+    from . import sharding
+    if input_type == 'directory' and sharding.env_world()[2] > 1:
+        # launched one process per GPU (torch.distributed.run): shard the reads, gather the calls
+        sharding.classify_fast5_files_sharded(find_all_fast5s(args.input, verbose=True),
+                                              start_model, start_input_size, end_model,
+                                              end_input_size, output_size, args)
+    elif input_type == 'directory':
         classify_fast5_files(find_all_fast5s(args.input, verbose=True),
                              start_model, start_input_size, end_model, end_input_size,
                              output_size, args)

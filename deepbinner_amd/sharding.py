@@ -50,3 +50,83 @@ def gather_calls(local_calls, n_total, world_size, rank):
         a, b = shard_bounds(n_total, world_size, r)
         pieces.append(out[r * longest:r * longest + (b - a)])
     return torch.cat(pieces)
+
+
+def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end_model,
+                                 end_input_size, output_size, args):
+    """``deepbinner classify DIR`` across the GPUs of one node: every rank (one process per GPU,
+    its model(s) already loaded on its own device) classifies a contiguous shard of the sorted
+    file list with the ordinary per-batch loop; per-read calls come back with one all-gather
+    (RCCL on GPUs), TSV lines and read ids with one object gather; rank 0 prints exactly what the
+    single-process path prints (reference classify.py:106-180).  Returns the same
+    ``(classifications, read_id_to_fast5_file)`` on rank 0 and ``({}, {})`` elsewhere."""
+    import sys
+    import numpy as np
+    import torch
+    from . import classify as c
+    from .load_fast5s import get_read_id_and_signal, determine_single_or_multi_fast5s
+    from .misc import print_summary_table
+
+    rank, local_rank, world = env_world()
+    backend = os.environ.get('DEEPBINNER_DIST_BACKEND', 'nccl')
+    dist = init_process_group(backend)
+    if not fast5_files:
+        sys.exit('Error: no fast5 files found')
+    fast5_files = sorted(fast5_files)           # os.walk order may differ between processes
+    if determine_single_or_multi_fast5s(fast5_files) == 'multi':
+        sys.exit('Error: deepbinner classify requires one-read-per-file fast5s - convert with '
+                 'multi_to_single_fast5 before running')
+    a, b = shard_bounds(len(fast5_files), world, rank)
+    mine = fast5_files[a:b]
+
+    if rank == 0:
+        c.print_classification_progress(0, len(fast5_files), 'fast5s')
+        c.print_output_header(args.verbose, start_model is not None, end_model is not None,
+                              output_size)
+    classifications, id_to_file, lines = {}, {}, []
+    for batch in c.chunker(mine, args.batch_size):
+        read_ids, signals = [], []
+        for fast5_file in batch:
+            read_id, signal = get_read_id_and_signal(fast5_file)
+            if signal is None:
+                continue
+            id_to_file[read_id] = fast5_file
+            read_ids.append(read_id)
+            signals.append(signal)
+        lines += c.classify_read_batch(read_ids, signals, start_model, start_input_size,
+                                       end_model, end_input_size, output_size, args,
+                                       classifications)
+        if rank == 0:   # rank 0's shard is as large as any: its progress stands for the job
+            c.print_classification_progress(min(len(classifications) * world, len(fast5_files)),
+                                            len(fast5_files), 'fast5s')
+
+    # per-read calls: int32, 0 = 'none' (the collective of SURVEY.md section 8e)
+    device = torch.device('cuda', local_rank) if backend == 'nccl' else torch.device('cpu')
+    order = list(classifications)
+    local = torch.tensor([0 if classifications[r] == 'none' else int(classifications[r])
+                          for r in order], dtype=torch.int32, device=device)
+    counts = [None] * world
+    dist.all_gather_object(counts, len(order))
+    longest = max(max(counts), 1)
+    padded = torch.zeros(longest, dtype=torch.int32, device=device)
+    padded[:local.numel()] = local
+    gathered = torch.empty(world * longest, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(gathered, padded)
+    payload = [None] * world if rank == 0 else None
+    dist.gather_object((order, lines, id_to_file), payload, dst=0)
+    result = ({}, {})
+    if rank == 0:
+        all_calls = gathered.cpu().numpy().reshape(world, longest)
+        merged, merged_files = {}, {}
+        for r, (ids, tsv, files) in enumerate(payload):
+            for line in tsv:
+                print(line)
+            for i, read_id in enumerate(ids):
+                merged[read_id] = 'none' if all_calls[r, i] == 0 else str(int(all_calls[r, i]))
+            merged_files.update(files)
+        c.print_classification_progress(len(merged), len(fast5_files), 'fast5s')
+        print('', file=sys.stderr)
+        print_summary_table(merged)
+        result = (merged, merged_files)
+    dist.barrier()
+    return result

@@ -303,3 +303,26 @@ def test_bench_two_ranks_share_one_gpu(hip):
     result = json.loads(lines[0])
     assert result['n_gpus'] == 2 and result['steps'] == 3 and result['value'] > 0
     assert result['scaling'] == 'weak' and 'roofline' in result
+
+
+def test_cli_classify_two_ranks_share_one_gpu(hip):
+    """The real CLI under torchrun with 2 ranks on this box's single GPU (gather over gloo):
+    rank 0 prints every read once with the reference's expected calls."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    from test_oracle_golden import EXPECTED_END
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=REPO, DEEPBINNER_DIST_BACKEND='gloo', DEEPBINNER_DEVICE='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'deepbinner_amd',
+           'classify', '--native', '--require_both', '--batch_size', '2',
+           os.path.join(GOLD, 'fast5', 'single')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rows = dict(l.split('\t') for l in out.stdout.splitlines() if '\t' in l)
+    assert rows.pop('read_ID') == 'barcode_call'
+    assert rows == EXPECTED_END          # require_both column of the reference's tests

@@ -70,3 +70,43 @@ def test_two_rank_gloo_gather(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'GATHER_OK' in out.stdout
+
+
+CLI_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import deepbinner_amd.classify as classify
+from deepbinner_amd import deepbinner as cli
+from conftest import OracleModel
+classify.build_model = lambda w: OracleModel(w)      # CPU box: oracle-backed model double
+classify.set_tensorflow_threads = lambda args: None  # ... and no GPU to select
+cli.main(['classify', '--native', '--verbose', '--batch_size', '3',
+          os.path.join(sys.argv[1], 'tests', 'golden', 'fast5', 'single')])
+'''
+
+
+def test_cli_classify_sharded_over_two_ranks(tmp_path):
+    """`deepbinner classify DIR` under torchrun with 2 ranks (gloo): rank 0 prints the same TSV
+    the single-process run prints, each read exactly once, with the reference's expected calls."""
+    from test_oracle_golden import EXPECTED_START
+    script = tmp_path / 'cli_worker.py'
+    script.write_text(CLI_WORKER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', DEEPBINNER_DIST_BACKEND='gloo')
+    env.pop('LOCAL_RANK', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), REPO]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if '\t' in l]
+    assert lines[0].startswith('read_ID\tbarcode_call\tstart_none')
+    rows = {l.split('\t')[0]: l.split('\t') for l in lines[1:]}
+    assert len(lines) == 8 and set(rows) == set(EXPECTED_START)
+    # default two-model mode is require_either -> the start column of the reference's tests
+    assert {k: v[1] for k, v in rows.items()} == EXPECTED_START
+    assert all(len(v) == 30 for v in rows.values())
+    assert 'Barcode     Count' in out.stderr
