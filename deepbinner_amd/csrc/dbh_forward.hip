@@ -91,6 +91,17 @@ struct NoSide {
     __device__ __forceinline__ void operator()(IntC<I>) const {}
 };
 
+// Wave-wide sum of a non-negative 32-bit integer per lane (result < 2^31) with DPP row
+// reductions + three readlanes instead of six rounds of ds_bpermute.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 template <int MT, int NT>
 struct Frags {
     f2 a[MT];
@@ -941,6 +952,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
         float a[MT], bw[3];
+        // everything this stage needs from memory is requested up front, in one round trip
+        EpiParams<3, true> ep;
+        ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
+                packed + bn_shift_offset(0) + n);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
         if (samples == nullptr) {
             const float* xw = x + win * kWindow;
 #pragma unroll
@@ -957,24 +975,36 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             window_bounds(offsets[read + 1] - base, step, side, &wa, &wb);
             const int cnt = (int)(wb - wa);
             const int16_t* src = samples + base + wa;
+            const int pad_left = (side == 0) ? 0 : kWindow - cnt;
+            // this lane's two samples for the statistics and its A-fragment samples, together
             const int v0 = tid < cnt ? (int)src[tid] : 0;
             const int v1 = tid + kThreads < cnt ? (int)src[tid + kThreads] : 0;
-            long long s1 = v0 + v1;
-            long long s2 = (long long)v0 * v0 + (long long)v1 * v1;
+            int raw[MT];
+            bool inside[MT];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                s1 += __shfl_xor(s1, off);
-                s2 += __shfl_xor(s2, off);
+            for (int m = 0; m < MT; ++m) {
+                const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
+                inside[m] = q < 3 && k >= 0 && k < cnt;
+                raw[m] = inside[m] ? (int)src[k] : 0;
             }
+            // exact integer sums: sum(x) and sum(x^2) split in 16-bit halves so that every
+            // wave-wide partial stays below 2^31
+            const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
+            const unsigned sq0 = (unsigned)(v0 * v0), sq1 = (unsigned)(v1 * v1);   // <= 2^30
+            const int present = (tid < cnt ? 1 : 0) + (tid + kThreads < cnt ? 1 : 0);
+            const int w_sum = wave_sum_i32((tid < cnt ? biased0 : 0) +
+                                           (tid + kThreads < cnt ? biased1 : 0));
+            const int w_cnt = wave_sum_i32(present);
+            const int w_lo = wave_sum_i32((int)(sq0 & 0xFFFF) + (int)(sq1 & 0xFFFF));
+            const int w_hi = wave_sum_i32((int)(sq0 >> 16) + (int)(sq1 >> 16));
             // slot 2 of the weight area is idle until conv2 starts its first DMA
             long long* red = reinterpret_cast<long long*>(lds + kSlot2);
             if (lane == 0) {
-                red[wave] = s1;
-                red[kWaves + wave] = s2;
+                red[wave] = (long long)w_sum - 32768LL * w_cnt;
+                red[kWaves + wave] = ((long long)w_hi << 16) + (long long)w_lo;
             }
             __syncthreads();
-            s1 = 0;
-            s2 = 0;
+            long long s1 = 0, s2 = 0;
 #pragma unroll
             for (int i = 0; i < kWaves; ++i) {
                 s1 += red[i];
@@ -983,31 +1013,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             double mean, stdev;
             mean_std(s1, s2, cnt, &mean, &stdev);
             const bool divide = stdev > 0.0;
-            const int pad_left = (side == 0) ? 0 : kWindow - cnt;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int idx = 2 * ((m0 + m) * 16 + n) + q;
-                const int k = idx - pad_left;
                 float v = 0.f;
-                if (q < 3 && k >= 0 && k < cnt) {
-                    const double d = (double)src[k] - mean;
+                if (inside[m]) {
+                    const double d = (double)raw[m] - mean;
                     v = (float)(divide ? d / stdev : d);
                 }
                 a[m] = v;
             }
         }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
         f4 acc[MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc[m][t] = mfma4(a[m], bw[t], f4{0.f, 0.f, 0.f, 0.f});
-        EpiParams<3, true> ep;
-        ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
-                packed + bn_shift_offset(0) + n);
         float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
         epilogue<MT, 3, kS48, false, true>(acc, out_lane, ep);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
