@@ -66,9 +66,19 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
             for (int tap = 0; tap < 3; ++tap)
                 for (int c = 0; c < cout; ++c) dst[tap * 48 + c] = kernel[(tap * cin) * cout + c];
         } else if (kConv[i].wino) {
-            // Winograd F(2,3): four transformed matrices, computed in fp64, in fragment order
+            // Winograd F(2,3) / F(4,3): the transformed matrices V = G g, computed in fp64, each
+            // in fragment order
             const int sp_n = cin / 8, nt = kConv[i].cout_pad / 16;
-            for (int xi = 0; xi < 4; ++xi)
+            const int n_xi = kConv[i].wino == 4 ? 6 : 4;
+            static const double G23[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+            static const double G43[6][3] = {{1. / 4, 0, 0},
+                                             {-1. / 6, -1. / 6, -1. / 6},
+                                             {-1. / 6, 1. / 6, -1. / 6},
+                                             {1. / 24, 1. / 12, 1. / 6},
+                                             {1. / 24, -1. / 12, 1. / 6},
+                                             {0, 0, 1}};
+            for (int xi = 0; xi < n_xi; ++xi) {
+                const double* G = kConv[i].wino == 4 ? G43[xi] : G23[xi];
                 for (int sp = 0; sp < sp_n; ++sp)
                     for (int t = 0; t < nt; ++t)
                         for (int lane = 0; lane < 64; ++lane)
@@ -76,17 +86,12 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                                 const int ci = 8 * sp + 2 * (lane >> 4) + e;
                                 const int co = 16 * t + (lane & 15);
                                 double v = 0.0;
-                                if (co < cout) {
-                                    const double g0 = kernel[((size_t)0 * cin + ci) * cout + co];
-                                    const double g1 = kernel[((size_t)1 * cin + ci) * cout + co];
-                                    const double g2 = kernel[((size_t)2 * cin + ci) * cout + co];
-                                    v = xi == 0 ? g0
-                                      : xi == 1 ? 0.5 * (g0 + g1 + g2)
-                                      : xi == 2 ? 0.5 * (g0 - g1 + g2)
-                                                : g2;
-                                }
+                                if (co < cout)
+                                    for (int tap = 0; tap < 3; ++tap)
+                                        v += G[tap] * (double)kernel[((size_t)tap * cin + ci) * cout + co];
                                 dst[((((size_t)xi * sp_n + sp) * nt + t) * 64 + lane) * 2 + e] = (float)v;
                             }
+            }
         } else {
             const int sp_n = cin / 8, nt = kConv[i].cout_pad / 16;
             for (int tap = 0; tap < k; ++tap)

@@ -502,7 +502,7 @@ template <int CONV, int L, bool POOL, int BNI, int SLOT_A, int SLOT_B, class Dma
 __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__ packed, int tid,
                                            int lane, int wave, long long* ts, int ts_base,
                                            const Dma1& next1, const Dma2& next2) {
-    static_assert(kConv[CONV].wino && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    static_assert(kConv[CONV].wino == 2 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     constexpr int MT = (L / 32) / kWaves;
     static_assert(MT >= 1 && MT * kWaves * 32 == L, "layer does not tile over the waves");
     constexpr int LOUT = POOL ? L / 2 : L;
@@ -575,6 +575,191 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Winograd F(4,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1) at L = 512, in place.
+//   For the output quad (4j .. 4j+3) and d = x[4j-1 .. 4j+4]:
+//     U0 = 4d0-5d2+d4        U1 = (d3+d4)-4(d1+d2)    U2 = (d4-d3)+4(d1-d2)
+//     U3 = (d4-d2)+2(d3-d1)  U4 = (d4-d2)-2(d3-d1)    U5 = 4d1-5d3+d5        (VALU, registers)
+//     M_xi = U_xi . V_xi over the 48 input channels                           (six GEMMs, MFMA)
+//     y0 = M0+M1+M2+M3+M4   y1 = M1-M2+2(M3-M4)   y2 = M1+M2+4(M3+M4)   y3 = M1-M2+8(M3-M4)+M5
+//   6 products per output quad instead of 12: HALF the MFMAs of the direct convolution.  The
+//   extra fp32 round-off is ~2x the direct form's (end-to-end |dp| 1.7e-6 vs 0.8e-6 against the
+//   fp64 oracle, tolerance 1e-4).
+// One wave owns one tile of 16 quads (64 positions) and all 3 channel tiles: 18 accumulators.
+// The six V matrices come as three thirds (V0,V1 | V2,V3 | V4,V5), each with a fixed LDS slot;
+// phase p multiplies by third p.  While phase 1 runs, the NEXT layer's first third replaces the
+// one phase 0 has finished with, and so on, so weights are always a phase or more ahead.
+// ---------------------------------------------------------------------------------------------
+template <int PHASE>
+struct W43Frags {
+    static constexpr int kRows = PHASE == 1 ? 4 : 5;     // d0..d4 | d1..d4 | d1..d5
+    static constexpr int kFirst = PHASE == 0 ? 0 : 1;
+    f2 d[kRows];
+    f2 b[2][3];
+};
+
+template <int PHASE, int SP_IDX>
+__device__ __forceinline__ void w43_load(W43Frags<PHASE>& f, unsigned a_addr, unsigned b_addr) {
+    using F = W43Frags<PHASE>;
+    f.d[0] = ds_read_f2<((F::kFirst + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    f.d[1] = ds_read_f2<((F::kFirst + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    f.d[2] = ds_read_f2<((F::kFirst + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    f.d[3] = ds_read_f2<((F::kFirst + 3) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    if constexpr (F::kRows == 5)
+        f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    f.b[0][0] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
+    f.b[0][1] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
+    f.b[0][2] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
+    f.b[1][0] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
+    f.b[1][1] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
+    f.b[1][2] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
+}
+
+template <int PENDING, int PHASE>
+__device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
+#pragma unroll
+    for (int k = 0; k < W43Frags<PHASE>::kRows; ++k) asm volatile("" : "+v"(f.d[k]));
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
+}
+
+template <int PHASE, int SP_IDX>
+__device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
+                                         W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3]) {
+    constexpr int kLoads = W43Frags<PHASE>::kRows + 6;
+    if constexpr (SP_IDX + 1 < 6) {
+        w43_load<PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
+        w43_wait<kLoads>(buf[SP_IDX & 1]);
+    } else {
+        w43_wait<0>(buf[SP_IDX & 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const W43Frags<PHASE>& f = buf[SP_IDX & 1];
+    f2 u[2];
+    if constexpr (PHASE == 0) {            // rows d0..d4
+        u[0] = 4.f * f.d[0] - 5.f * f.d[2] + f.d[4];
+        u[1] = (f.d[3] + f.d[4]) - 4.f * (f.d[1] + f.d[2]);
+    } else if constexpr (PHASE == 1) {     // rows d1..d4 at index 0..3
+        u[0] = (f.d[3] - f.d[2]) + 4.f * (f.d[0] - f.d[1]);
+        u[1] = (f.d[3] - f.d[1]) + 2.f * (f.d[2] - f.d[0]);
+    } else {                               // rows d1..d5 at index 0..4
+        u[0] = (f.d[3] - f.d[1]) - 2.f * (f.d[2] - f.d[0]);
+        u[1] = 4.f * f.d[0] - 5.f * f.d[2] + f.d[4];
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            acc[2 * PHASE + x][t] = mfma4(u[x].x, f.b[x][t].x, acc[2 * PHASE + x][t]);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            acc[2 * PHASE + x][t] = mfma4(u[x].y, f.b[x][t].y, acc[2 * PHASE + x][t]);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][t]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
+}
+
+template <int PHASE>
+__device__ __forceinline__ void w43_phase(const float* a_lane, const float* slot_lane,
+                                          f4 (&acc)[6][3]) {
+    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
+    W43Frags<PHASE> buf[2];
+    w43_load<PHASE, 0>(buf[0], a_addr, b_addr);
+    w43_step<PHASE, 0>(a_addr, b_addr, buf, acc);
+}
+
+// dma0/1/2: the DMA requests issued at the top of phase 0/1/2 (see the call sites).
+template <int CONV, bool POOL, int BNI, class Dma0, class Dma1, class Dma2>
+__device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
+                                          int lane, int wave, long long* ts, int ts_base,
+                                          const Dma0& dma0, const Dma1& dma1, const Dma2& dma2) {
+    static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    constexpr int L = 512;
+    static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
+    constexpr int LOUT = POOL ? L / 2 : L;
+    constexpr bool BN = BNI >= 0;
+    const int n = lane & 15, q = lane >> 4;
+
+    dma0();
+    EpiParams<3, BN> ep;
+    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
+            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    // M1 enters all four outputs with weight +1, so it is the accumulator that starts at the bias
+    f4 acc[6][3];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float v = x == 1 ? ep.b[t] : 0.f;
+            acc[x][t] = f4{v, v, v, v};
+        }
+    // quad j = wave*16 + n needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
+    const float* a_lane = lds + kActOff + (wave * 64 + 4 * n) * kS48 + 2 * q;
+    w43_phase<0>(a_lane, lds + kSlot0 + lane * 2, acc);
+    __syncthreads();      // second third landed; slot 0 free
+    dma1();
+    w43_phase<1>(a_lane, lds + kSlot1 + lane * 2, acc);
+    __syncthreads();      // last third landed; slot 1 free
+    dma2();
+    w43_phase<2>(a_lane, lds + kSlot2 + lane * 2, acc);
+    mark(ts, ts_base);
+
+    __syncthreads();      // every wave has finished reading the old activations
+    mark(ts, ts_base + 1);
+
+    float* out = lds + kActOff + n;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float sc = ep.sc[t], sh = ep.sh[t];
+        const f4 s12 = acc[1][t] + acc[2][t], d12 = acc[1][t] - acc[2][t];
+        const f4 s34 = acc[3][t] + acc[4][t], d34 = acc[3][t] - acc[4][t];
+        const f4 y0 = acc[0][t] + s12 + s34;
+        const f4 y1 = d12 + 2.f * d34;
+        const f4 y2 = s12 + 4.f * s34;
+        const f4 y3 = d12 + 8.f * d34 + acc[5][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = wave * 16 + 4 * q + r;
+            float v0 = fmaxf(y0[r], 0.f), v1 = fmaxf(y1[r], 0.f);
+            float v2 = fmaxf(y2[r], 0.f), v3 = fmaxf(y3[r], 0.f);
+            if (POOL) {
+                float o0 = fmaxf(v0, v1), o1 = fmaxf(v2, v3);
+                if (BN) {
+                    o0 = fmaf(o0, sc, sh);
+                    o1 = fmaf(o1, sc, sh);
+                }
+                out[(1 + 2 * j) * kS48 + t * 16] = o0;
+                out[(2 + 2 * j) * kS48 + t * 16] = o1;
+            } else {
+                if (BN) {
+                    v0 = fmaf(v0, sc, sh);
+                    v1 = fmaf(v1, sc, sh);
+                    v2 = fmaf(v2, sc, sh);
+                    v3 = fmaf(v3, sc, sh);
+                }
+                out[(1 + 4 * j) * kS48 + t * 16] = v0;
+                out[(2 + 4 * j) * kS48 + t * 16] = v1;
+                out[(3 + 4 * j) * kS48 + t * 16] = v2;
+                out[(4 + 4 * j) * kS48 + t * 16] = v3;
+            }
+        }
+    }
+    zero_row(lds + kActOff, 0, kS48, 48, tid);
+    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
+    mark(ts, ts_base + 2);
+
+    __syncthreads();
+    mark(ts, ts_base + 3);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same Winograd layer at L = 128, where there are only four 16-pair tiles for eight waves:
 // wave w takes tile w&3 and ONE half of the transform pair (w < 4: M0,M1 from V0,V1; w >= 4:
 // M2,M3 from V2,V3), 72 MFMAs each, and partner waves (w, w+4) swap what the other needs
@@ -592,7 +777,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
                                                  int tid, int lane, int wave, long long* ts,
                                                  int ts_base, const Side& side,
                                                  const StepSide& step_side = StepSide()) {
-    static_assert(kConv[CONV].wino && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    static_assert(kConv[CONV].wino == 2 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     constexpr int L = 128;
     constexpr int LOUT = POOL ? L / 2 : L;
     constexpr bool BN = BNI >= 0;
@@ -946,7 +1131,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // straight from global (k = lane>>4 picks the tap), B[k][n] = w[k][n].  One MFMA per
     // (position tile, N tile); the standard epilogue applies bias, ReLU and BN1.
     {
-        // conv2's transformed weights: (V0,V1) -> slot 0, (V2,V3) -> slot 1
+        // conv2's transformed weights: (V0,V1) -> slot 0, (V2,V3) -> slot 1; (V4,V5) follow
+        // during conv2's own first phase
         dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         dma_weights<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
         constexpr int MT = 512 / 16 / kWaves;
@@ -1043,20 +1229,32 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd layers; weight halves rotate through the three slots:
-    //   conv2: (V0,V1)@0 (V2,V3)@1 | conv3: @2 @0 | conv4: @1 @2 | conv5,6 -> slot 0 region
-    wino_layer<1, 512, false, -1, kSlot0, kSlot1>(
-        lds, packed, tid, lane, wave, ts, 2,
-        [&] { dma_weights<kWinoHalf>(packed + weight_offset(2), lds + kSlot2, lane, wave); },
-        [&] { dma_weights<kWinoHalf>(packed + weight_offset(2) + kWinoHalf, lds + kSlot0, lane, wave); });
-    wino_layer<2, 512, false, -1, kSlot2, kSlot0>(
-        lds, packed, tid, lane, wave, ts, 6,
-        [&] { dma_weights<kWinoHalf>(packed + weight_offset(3), lds + kSlot1, lane, wave); },
-        [&] { dma_weights<kWinoHalf>(packed + weight_offset(3) + kWinoHalf, lds + kSlot2, lane, wave); });
-    wino_layer<3, 512, true, 1, kSlot1, kSlot2>(
-        lds, packed, tid, lane, wave, ts, 10,
-        [&] { dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW5, lane, wave); },
-        [&] { dma_weights<conv_weight_floats(5)>(packed + weight_offset(5), lds + kW6, lane, wave); });
+    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p; it is fetched while the
+    // previous layer (or this one) is busy with another slot:
+    //   during phase 0: this layer's last third -> slot 2
+    //   during phase 1: next layer's first third -> slot 0
+    //   during phase 2: next layer's second third -> slot 1
+    auto third = [&](int conv, int p, float* dst) {
+        dma_weights<kWinoHalf>(packed + weight_offset(conv) + p * kWinoHalf, dst, lane, wave);
+    };
+    w43_layer<1, false, -1>(lds, packed, tid, lane, wave, ts, 2,
+                            [&] { third(1, 2, lds + kSlot2); },
+                            [&] { third(2, 0, lds + kSlot0); },
+                            [&] { third(2, 1, lds + kSlot1); });
+    w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6,
+                            [&] { third(2, 2, lds + kSlot2); },
+                            [&] { third(3, 0, lds + kSlot0); },
+                            [&] { third(3, 1, lds + kSlot1); });
+    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 once phase 0 is done
+    w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10,
+                          [&] { third(3, 2, lds + kSlot2); },
+                          [&] {
+                              dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
+                                                                 lds + kW5, lane, wave);
+                              dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                 lds + kW6, lane, wave);
+                          },
+                          [] {});
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);

@@ -16,37 +16,42 @@ constexpr int kNumBn = 7;
 // ---------------------------------------------------------------------------------------------
 // Convolution table (index = Keras layer number - 1).  cout_pad is C_out rounded up to 16.
 // ---------------------------------------------------------------------------------------------
-// wino: the layer runs as Winograd F(2,3) — two outputs per position pair from FOUR
-// element-wise-transformed products instead of six (1.5x fewer MFMAs); its weights are stored
-// as the four transformed matrices  V0 = g0, V1 = (g0+g1+g2)/2, V2 = (g0-g1+g2)/2, V3 = g2.
-struct ConvSpec { int taps, cin, cout_pad, stride; bool wino; };
+// wino = 2: the layer runs as Winograd F(2,3) — two outputs per position pair from FOUR
+//   element-wise-transformed products instead of six (1.5x fewer MFMAs); weights are stored as
+//   V0 = g0, V1 = (g0+g1+g2)/2, V2 = (g0-g1+g2)/2, V3 = g2.
+// wino = 4: Winograd F(4,3) — four outputs per position quad from SIX products instead of
+//   twelve (2x fewer MFMAs); weights are stored as V0 = g0/4, V1 = -(g0+g1+g2)/6,
+//   V2 = -(g0-g1+g2)/6, V3 = g0/24+g1/12+g2/6, V4 = g0/24-g1/12+g2/6, V5 = g2.
+// wino = 0: direct convolution.
+struct ConvSpec { int taps, cin, cout_pad, stride; int wino; };
 constexpr ConvSpec kConv[kNumConvs] = {
-    {3, 1, 48, 2, false},     // conv1d_1   (K = 3 padded to one MFMA k-step)
-    {3, 48, 48, 1, true},     // conv1d_2
-    {3, 48, 48, 1, true},     // conv1d_3
-    {3, 48, 48, 1, true},     // conv1d_4
-    {1, 48, 16, 1, false},    // conv1d_5
-    {3, 16, 48, 1, false},    // conv1d_6
-    {3, 48, 48, 1, true},     // conv1d_7
-    {3, 48, 48, 1, true},     // conv1d_8
-    {3, 48, 48, 1, true},     // conv1d_9
-    {1, 48, 48, 1, false},    // conv1d_10
-    {1, 48, 48, 1, false},    // conv1d_11
-    {1, 48, 16, 1, false},    // conv1d_12
-    {3, 16, 48, 1, false},    // conv1d_13
-    {1, 48, 16, 1, false},    // conv1d_14
-    {3, 16, 48, 1, false},    // conv1d_15
-    {3, 48, 48, 1, false},    // conv1d_16
-    {3, 192, 48, 2, false},   // conv1d_17
-    {3, 48, 48, 1, false},    // conv1d_18
-    {3, 48, 48, 1, false},    // conv1d_19
-    {1, 48, 32, 1, false},    // conv1d_20  (n_classes <= 32, zero padded)
+    {3, 1, 48, 2, 0},     // conv1d_1   (K = 3 padded to one MFMA k-step)
+    {3, 48, 48, 1, 4},        // conv1d_2
+    {3, 48, 48, 1, 4},        // conv1d_3
+    {3, 48, 48, 1, 4},        // conv1d_4
+    {1, 48, 16, 1, 0},    // conv1d_5
+    {3, 16, 48, 1, 0},    // conv1d_6
+    {3, 48, 48, 1, 2},        // conv1d_7
+    {3, 48, 48, 1, 2},        // conv1d_8
+    {3, 48, 48, 1, 2},        // conv1d_9
+    {1, 48, 48, 1, 0},    // conv1d_10
+    {1, 48, 48, 1, 0},    // conv1d_11
+    {1, 48, 16, 1, 0},    // conv1d_12
+    {3, 16, 48, 1, 0},    // conv1d_13
+    {1, 48, 16, 1, 0},    // conv1d_14
+    {3, 16, 48, 1, 0},    // conv1d_15
+    {3, 48, 48, 1, 0},    // conv1d_16
+    {3, 192, 48, 2, 0},   // conv1d_17
+    {3, 48, 48, 1, 0},    // conv1d_18
+    {3, 48, 48, 1, 0},    // conv1d_19
+    {1, 48, 32, 1, 0},    // conv1d_20  (n_classes <= 32, zero padded)
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
-    return (kConv[i].wino ? 4 : kConv[i].taps) * kConv[i].cin * kConv[i].cout_pad;
+    return (kConv[i].wino == 4 ? 6 : kConv[i].wino == 2 ? 4 : kConv[i].taps) * kConv[i].cin *
+           kConv[i].cout_pad;
 }
 
 // ---------------------------------------------------------------------------------------------
