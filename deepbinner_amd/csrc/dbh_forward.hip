@@ -127,6 +127,16 @@ __device__ __forceinline__ f2 ds_read_f2(unsigned addr) {
     return v;
 }
 
+template <int OFFSET_BYTES>
+__device__ __forceinline__ f4 ds_read_f4(unsigned addr) {
+    f4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                 : "=v"(v)
+                 : "v"(addr), "i"(OFFSET_BYTES)
+                 : "memory");
+    return v;
+}
+
 template <int TAPS, int SP, int SPTOT, int MT, int NT, int NTTOT, int S, int MROWS, int IT>
 __device__ __forceinline__ void load_frags(Frags<MT, NT>& f, unsigned a_addr, unsigned b_addr) {
     constexpr int tap = IT / SP, sp = IT % SP;
@@ -451,17 +461,19 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
     }
     __builtin_amdgcn_sched_barrier(0);
     const WinoFrags<MT>& f = buf[SP_IDX & 1];
-    f2 u[2][MT];
+    f2 u[2][MT];     // scalar component-wise on purpose: no packed VALU between MFMAs
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if constexpr (PHASE == 0) {
-            u[0][m] = f.d[m][0] - f.d[m][2];     // U0 = d0 - d2
-            u[1][m] = f.d[m][1] + f.d[m][2];     // U1 = d1 + d2
-        } else {                                  // loaded rows are d1, d2, d3
-            u[0][m] = f.d[m][1] - f.d[m][0];     // U2 = d2 - d1
-            u[1][m] = f.d[m][0] - f.d[m][2];     // U3 = d1 - d3
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if constexpr (PHASE == 0) {
+                u[0][m][e] = f.d[m][0][e] - f.d[m][2][e];     // U0 = d0 - d2
+                u[1][m][e] = f.d[m][1][e] + f.d[m][2][e];     // U1 = d1 + d2
+            } else {                                          // loaded rows are d1, d2, d3
+                u[0][m][e] = f.d[m][1][e] - f.d[m][0][e];     // U2 = d2 - d1
+                u[1][m][e] = f.d[m][0][e] - f.d[m][2][e];     // U3 = d1 - d3
+            }
         }
-    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -586,15 +598,18 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 //   fp64 oracle, tolerance 1e-4).
 // One wave owns one tile of 16 quads (64 positions) and all 3 channel tiles: 18 accumulators.
 // The six V matrices come as three thirds (V0,V1 | V2,V3 | V4,V5), each with a fixed LDS slot;
-// phase p multiplies by third p.  While phase 1 runs, the NEXT layer's first third replaces the
-// one phase 0 has finished with, and so on, so weights are always a phase or more ahead.
+// phase 0 multiplies by the first two thirds, phase 1 by the last, and every third is fetched
+// at least a phase ahead of its use (see the DMA requests at the call sites).
 // ---------------------------------------------------------------------------------------------
+// Phase 0 covers xi = 0..3 (slots 0 and 1, which are adjacent, so the four matrices are one
+// contiguous image) from rows d0..d4; phase 1 covers xi = 4,5 (slot 2) from rows d1..d5.
 template <int PHASE>
 struct W43Frags {
-    static constexpr int kRows = PHASE == 1 ? 4 : 5;     // d0..d4 | d1..d4 | d1..d5
-    static constexpr int kFirst = PHASE == 0 ? 0 : 1;
-    f2 d[kRows];
-    f2 b[2][3];
+    static constexpr int kThirds = PHASE == 0 ? 2 : 1;   // thirds (pairs of matrices) covered
+    static constexpr int kXi = 2 * kThirds;
+    static constexpr int kFirst = PHASE;                 // first of the 5 rows read
+    f2 d[5];
+    f4 b[kThirds][3];     // {xi even .x/.y, xi odd .x/.y} per channel tile
 };
 
 template <int PHASE, int SP_IDX>
@@ -604,31 +619,35 @@ __device__ __forceinline__ void w43_load(W43Frags<PHASE>& f, unsigned a_addr, un
     f.d[1] = ds_read_f2<((F::kFirst + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
     f.d[2] = ds_read_f2<((F::kFirst + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
     f.d[3] = ds_read_f2<((F::kFirst + 3) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    if constexpr (F::kRows == 5)
-        f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    f.b[0][0] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
-    f.b[0][1] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
-    f.b[0][2] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
-    f.b[1][0] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
-    f.b[1][1] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
-    f.b[1][2] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
+    f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    // a third is [sp][t][lane][xi&1][e]: 256 floats per (sp, t)
+    f.b[0][0] = ds_read_f4<((SP_IDX * 3 + 0) * 256) * 4>(b_addr);
+    f.b[0][1] = ds_read_f4<((SP_IDX * 3 + 1) * 256) * 4>(b_addr);
+    f.b[0][2] = ds_read_f4<((SP_IDX * 3 + 2) * 256) * 4>(b_addr);
+    if constexpr (F::kThirds == 2) {
+        f.b[1][0] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 0) * 256) * 4>(b_addr);
+        f.b[1][1] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 1) * 256) * 4>(b_addr);
+        f.b[1][2] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 2) * 256) * 4>(b_addr);
+    }
 }
 
 template <int PENDING, int PHASE>
 __device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
     asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
 #pragma unroll
-    for (int k = 0; k < W43Frags<PHASE>::kRows; ++k) asm volatile("" : "+v"(f.d[k]));
+    for (int k = 0; k < 5; ++k) asm volatile("" : "+v"(f.d[k]));
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int h = 0; h < W43Frags<PHASE>::kThirds; ++h)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[h][t]));
 }
 
 template <int PHASE, int SP_IDX>
 __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
                                          W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3]) {
-    constexpr int kLoads = W43Frags<PHASE>::kRows + 6;
+    constexpr int kXi = W43Frags<PHASE>::kXi;
+    constexpr int kX0 = PHASE == 0 ? 0 : 4;              // first xi of this phase
+    constexpr int kLoads = 5 + 3 * W43Frags<PHASE>::kThirds;
     if constexpr (SP_IDX + 1 < 6) {
         w43_load<PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
         w43_wait<kLoads>(buf[SP_IDX & 1]);
@@ -637,31 +656,38 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
     }
     __builtin_amdgcn_sched_barrier(0);
     const W43Frags<PHASE>& f = buf[SP_IDX & 1];
-    f2 u[2];
-    if constexpr (PHASE == 0) {            // rows d0..d4
-        u[0] = 4.f * f.d[0] - 5.f * f.d[2] + f.d[4];
-        u[1] = (f.d[3] + f.d[4]) - 4.f * (f.d[1] + f.d[2]);
-    } else if constexpr (PHASE == 1) {     // rows d1..d4 at index 0..3
-        u[0] = (f.d[3] - f.d[2]) + 4.f * (f.d[0] - f.d[1]);
-        u[1] = (f.d[3] - f.d[1]) + 2.f * (f.d[2] - f.d[0]);
-    } else {                               // rows d1..d5 at index 0..4
-        u[0] = (f.d[3] - f.d[1]) - 2.f * (f.d[2] - f.d[0]);
-        u[1] = 4.f * f.d[0] - 5.f * f.d[2] + f.d[4];
+    // Input transform, deliberately component by component with scalar FMAs: packed fp32 VALU
+    // (v_pk_add/mul_f32, what vector-typed code compiles to) costs ~10 extra cycles per
+    // instruction when it sits between MFMAs.
+    f2 u[kXi];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float d0 = f.d[0][e], d1 = f.d[1][e], d2 = f.d[2][e], d3 = f.d[3][e], d4 = f.d[4][e];
+        if constexpr (PHASE == 0) {        // rows d0..d4
+            u[0][e] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+            u[1][e] = fmaf(-4.f, d1 + d2, d3 + d4);
+            u[2][e] = fmaf(4.f, d1 - d2, d4 - d3);
+            u[3][e] = fmaf(2.f, d3 - d1, d4 - d2);
+        } else {                           // rows d1..d5 at index 0..4
+            u[0][e] = fmaf(-2.f, d2 - d0, d3 - d1);
+            u[1][e] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        }
     }
+    // f.b[h][t] = {V(2h).e0, V(2h).e1, V(2h+1).e0, V(2h+1).e1} for this lane's (k, n)
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            acc[2 * PHASE + x][t] = mfma4(u[x].x, f.b[x][t].x, acc[2 * PHASE + x][t]);
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < kXi; ++x)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            acc[2 * PHASE + x][t] = mfma4(u[x].y, f.b[x][t].y, acc[2 * PHASE + x][t]);
+            acc[kX0 + x][t] = mfma4(u[x].x, f.b[x >> 1][t][2 * (x & 1)], acc[kX0 + x][t]);
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < kXi; ++x)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][t]));
+        for (int t = 0; t < 3; ++t)
+            acc[kX0 + x][t] = mfma4(u[x].y, f.b[x >> 1][t][2 * (x & 1) + 1], acc[kX0 + x][t]);
+#pragma unroll
+    for (int x = 0; x < kXi; ++x)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[kX0 + x][t]));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
 }
@@ -675,11 +701,11 @@ __device__ __forceinline__ void w43_phase(const float* a_lane, const float* slot
     w43_step<PHASE, 0>(a_addr, b_addr, buf, acc);
 }
 
-// dma0/1/2: the DMA requests issued at the top of phase 0/1/2 (see the call sites).
-template <int CONV, bool POOL, int BNI, class Dma0, class Dma1, class Dma2>
+// dma0/1: the DMA requests issued at the top of phase 0/1 (see the call sites).
+template <int CONV, bool POOL, int BNI, class Dma0, class Dma1>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
-                                          const Dma0& dma0, const Dma1& dma1, const Dma2& dma2) {
+                                          const Dma0& dma0, const Dma1& dma1) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     constexpr int L = 512;
     static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
@@ -702,13 +728,12 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
         }
     // quad j = wave*16 + n needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
     const float* a_lane = lds + kActOff + (wave * 64 + 4 * n) * kS48 + 2 * q;
-    w43_phase<0>(a_lane, lds + kSlot0 + lane * 2, acc);
-    __syncthreads();      // second third landed; slot 0 free
+    w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc);
+    if (ts_base == 2) mark(ts, 56);
+    __syncthreads();      // last third landed in slot 2; slots 0 and 1 free
+    if (ts_base == 2) mark(ts, 57);
     dma1();
-    w43_phase<1>(a_lane, lds + kSlot1 + lane * 2, acc);
-    __syncthreads();      // last third landed; slot 1 free
-    dma2();
-    w43_phase<2>(a_lane, lds + kSlot2 + lane * 2, acc);
+    w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc);
     mark(ts, ts_base);
 
     __syncthreads();      // every wave has finished reading the old activations
@@ -1229,23 +1254,19 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p; it is fetched while the
-    // previous layer (or this one) is busy with another slot:
-    //   during phase 0: this layer's last third -> slot 2
-    //   during phase 1: next layer's first third -> slot 0
-    //   during phase 2: next layer's second third -> slot 1
+    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p.  Phase 0 (xi 0..3)
+    // reads slots 0+1 while this layer's last third streams into slot 2; phase 1 (xi 4,5)
+    // reads slot 2 while the NEXT layer's first two thirds stream into slots 0+1.
     auto third = [&](int conv, int p, float* dst) {
         dma_weights<kWinoHalf>(packed + weight_offset(conv) + p * kWinoHalf, dst, lane, wave);
     };
     w43_layer<1, false, -1>(lds, packed, tid, lane, wave, ts, 2,
                             [&] { third(1, 2, lds + kSlot2); },
-                            [&] { third(2, 0, lds + kSlot0); },
-                            [&] { third(2, 1, lds + kSlot1); });
+                            [&] { third(2, 0, lds + kSlot0); third(2, 1, lds + kSlot1); });
     w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6,
                             [&] { third(2, 2, lds + kSlot2); },
-                            [&] { third(3, 0, lds + kSlot0); },
-                            [&] { third(3, 1, lds + kSlot1); });
-    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 once phase 0 is done
+                            [&] { third(3, 0, lds + kSlot0); third(3, 1, lds + kSlot1); });
+    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 during phase 1
     w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10,
                           [&] { third(3, 2, lds + kSlot2); },
                           [&] {
@@ -1253,8 +1274,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                                  lds + kW5, lane, wave);
                               dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
                                                                  lds + kW6, lane, wave);
-                          },
-                          [] {});
+                          });
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);

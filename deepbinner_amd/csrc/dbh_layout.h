@@ -88,11 +88,14 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // way, so the contraction order is a fixed permutation of (tap, c_in).
 
 // ---------------------------------------------------------------------------------------------
-// LDS arena (floats).  Activations are [position][channel] with row stride C+4 (stride/4 odd ->
-// conflict-free ds_read_b64 A-fragment loads) and one zero row before and after the data
-// ("physical row = logical position + 1") to serve 'same' padding.
+// LDS arena (floats).  Activations are [position][channel] with a padded row stride and one zero
+// row before and after the data ("physical row = logical position + 1") to serve 'same' padding.
+// The stride decides the bank pattern of the 16 rows an A-fragment ds_read_b64 touches, which
+// are 1, 2 or 4 rows apart (direct / Winograd F(2,3) / F(4,3)): for the 48-channel buffers 50
+// floats gives distinct bank groups at row steps 1 and 2 and a 2-way conflict at step 4 (52 is
+// clean at step 1 but 4-way at step 4, which made LDS the limiter of the F(4,3) layers).
 // ---------------------------------------------------------------------------------------------
-constexpr int kS48 = 52;
+constexpr int kS48 = 50;
 constexpr int kS16 = 20;
 constexpr int kS192 = 196;
 
@@ -101,11 +104,11 @@ constexpr int kS192 = 196;
 // (kW0, kW1); the Winograd layers of stage B as three 4,608-float slots (two transformed
 // matrices each) rotated so that the half a layer needs next is always already in flight.
 constexpr int kActOff = 0;
-constexpr int kActFloats = (512 + 2) * kS48;               // 26,728
+constexpr int kActFloats = (512 + 2) * kS48;               // 25,700
 constexpr int kWFloats = 3 * 48 * 48;                      // 6,912
 constexpr int kW0 = kActOff + kActFloats;
 constexpr int kW1 = kW0 + kWFloats;
-constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 40,552 = 162,208 B
+constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 39,524
 constexpr int kWinoHalf = 2 * 48 * 48;                     // 4,608: two transformed matrices
 constexpr int kSlot0 = kW0;
 constexpr int kSlot1 = kW0 + kWinoHalf;
@@ -113,7 +116,7 @@ constexpr int kSlot2 = kW0 + 2 * kWinoHalf;
 static_assert(kSlot2 + kWinoHalf == kLdsFloatsAD, "three Winograd slots fill the weight area");
 // stage C onwards the activations need at most 258 rows, so the upper half of the activation
 // buffer doubles as one more weight buffer
-constexpr int kUpper = 258 * kS48;                          // 13,416
+constexpr int kUpper = 258 * kS48;                          // 12,900
 static_assert(kUpper + 4 * 48 * 48 <= kW0, "upper weight buffer must stay below the weight area");
 // conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
 constexpr int kW5 = kW0;
@@ -126,9 +129,7 @@ static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the w
 // and its exchange scratch below them, both clear of the stage-E weights arriving meanwhile.
 constexpr int kXchgFloats = 4 * 6 * 256;                   // 4 sender waves x 6 tiles x 256
 constexpr int kX8 = 130 * kS48 + 8;                        // 6,768
-constexpr int kW9 = kLdsFloatsAD - 4 * 48 * 48;            // 31,336
-constexpr int kX9 = kW9 - kXchgFloats;                     // 25,192
-static_assert(kX8 + kXchgFloats <= kUpper, "conv8 exchange scratch hits its weights");
+static_assert(kX8 % 4 == 0 && kX8 + kXchgFloats <= kUpper, "conv8 exchange scratch hits its weights");
 
 // stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
 // their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
@@ -142,7 +143,9 @@ constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 5
 constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
 constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
 static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
-static_assert(kEW + kEWFloats <= kX9, "stage-E weights would land on conv9's scratch/weights");
+constexpr int kX9 = (kEW + kEWFloats + 3) / 4 * 4;         // conv9's exchange scratch
+constexpr int kW9 = kX9 + kXchgFloats;                     // conv9's four Winograd matrices
+constexpr int kLdsFloatsD = kW9 + 4 * 48 * 48;
 
 // stages F-H (reuse the front of the arena; the concat buffer stays where it is)
 constexpr int kFOut = 0;                                   // conv17+BN6 out, 18 rows x 52
@@ -153,7 +156,10 @@ constexpr int kLogits = kRed + 24 * 256;                   // 32 floats
 constexpr int kTailEnd = kLogits + 32;
 static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
 
-constexpr int kLdsFloats = kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD;
+constexpr int kLdsFloats =
+    (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
+        ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
+        : kLdsFloatsD;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])

@@ -24,6 +24,7 @@ for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
     for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
         NAMES[base + j] = '%s %s' % (l, what)
 NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
+EXTRA = {56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
 
 
 def main():
@@ -51,6 +52,9 @@ def main():
     print('%-26s %10s %9s %7s %10s' % ('mark', 'cum_cycles', 'delta', 'pct', 'wave_skew'))
     for name, cum, d, skew in rows:
         print('%-26s %10.0f %9.0f %6.1f%% %10.0f' % (name, cum, d, 100 * d / total, skew))
+    for i, name in EXTRA.items():
+        r = st[:, :, i] - t0
+        print('%-26s first wave %8.0f  last wave %8.0f' % (name, r.min(axis=1).mean(), r.max(axis=1).mean()))
     print(json.dumps({'total_cycles': float(total), 'n_windows': n}))
 
 
