@@ -24,6 +24,7 @@
 //   - in seam-b2 mode the kernel also slices and z-normalises its int16 window (fp64, exact
 //     integer sums) and, for one-window reads, renormalises and makes the barcode call.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "dbh_layout.h"
 
@@ -90,6 +91,22 @@ struct NoSide {
     template <int I>
     __device__ __forceinline__ void operator()(IntC<I>) const {}
 };
+// Marks side work made of plain global loads to registers: a Winograd step issues those BETWEEN
+// its MFMAs, one after every second MFMA, because a bunch of vector-memory instructions holds
+// the wave (and its in-order MFMAs) ~35 cycles each, a lone one ~9 (tools/microbench/
+// mfma_issue.hip).  LDS-DMA requests do not gain from this (M0 set-up) and stay up front.
+template <class F>
+struct Interleaved {
+    F f;
+    template <int I>
+    __device__ __forceinline__ void operator()(IntC<I> t) const { f(t); }
+};
+template <class F>
+__device__ __forceinline__ Interleaved<F> interleaved(F f) { return Interleaved<F>{f}; }
+template <class T>
+struct is_interleaved : std::false_type {};
+template <class F>
+struct is_interleaved<Interleaved<F>> : std::true_type {};
 
 // Wave-wide sum of a non-negative 32-bit integer per lane (result < 2^31) with DPP row
 // reductions + three readlanes instead of six rounds of ds_bpermute.
@@ -453,10 +470,10 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
     constexpr int kLoads = 3 * MT + 6;
     if constexpr (SP_IDX + 1 < 6) {
         wino_load<MT, PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
-        side(IntC<SP_IDX>{});
+        if constexpr (!is_interleaved<Side>::value) side(IntC<SP_IDX>{});
         wino_wait<kLoads>(buf[SP_IDX & 1]);
     } else {
-        side(IntC<SP_IDX>{});
+        if constexpr (!is_interleaved<Side>::value) side(IntC<SP_IDX>{});
         wino_wait<0>(buf[SP_IDX & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -477,6 +494,12 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
+        for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(u[x][m]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (is_interleaved<Side>::value) side(IntC<SP_IDX>{});
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -488,6 +511,13 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc[2 * PHASE + x][m][t] = mfma4(u[x][m].y, f.b[x][t].y, acc[2 * PHASE + x][m][t]);
+    if constexpr (is_interleaved<Side>::value) {
+#pragma unroll
+        for (int k = 0; k < 6 * MT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM
+        }
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -597,19 +627,30 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 //   extra fp32 round-off is ~2x the direct form's (end-to-end |dp| 1.7e-6 vs 0.8e-6 against the
 //   fp64 oracle, tolerance 1e-4).
 // One wave owns one tile of 16 quads (64 positions) and all 3 channel tiles: 18 accumulators.
-// The six V matrices come as three thirds (V0,V1 | V2,V3 | V4,V5), each with a fixed LDS slot;
-// phase 0 multiplies by the first two thirds, phase 1 by the last, and every third is fetched
-// at least a phase ahead of its use (see the DMA requests at the call sites).
+// The six V matrices come as three thirds in the order V1,V2 | V3,V4 | V0,V5 (kW43Slot), each
+// with a fixed LDS slot; phase 0 multiplies by the first two thirds, phase 1 by the last, and
+// every third is fetched at least a phase ahead of its use (see the DMA requests at the call
+// sites).
 // ---------------------------------------------------------------------------------------------
-// Phase 0 covers xi = 0..3 (slots 0 and 1, which are adjacent, so the four matrices are one
-// contiguous image) from rows d0..d4; phase 1 covers xi = 4,5 (slot 2) from rows d1..d5.
+// Phase 0 covers xi = 1..4 (slots 0 and 1, which are adjacent, so the four matrices are one
+// contiguous image): these need only rows d1..d4 and share their sub-expressions,
+//     a = d4-4d2, b = d3-4d1: U1 = a+b, U2 = a-b;   c = d4-d2, e = d3-d1: U3 = c+2e, U4 = c-2e
+// - 8 VALU per component.  Phase 1 covers xi = 0, 5 (slot 2) from all six rows, 4 VALU per
+// component.  VALU issued between MFMAs is not free on this chip (tools/microbench/
+// mfma_issue.hip: ~2.6 cycles of matrix-pipe time each when bunched, ~6 for a lone one, packed
+// fp32 ~12), so the transform is kept as short as the algebra allows, scalar, and in ONE block
+// ahead of the step's MFMAs.
 template <int PHASE>
 struct W43Frags {
     static constexpr int kThirds = PHASE == 0 ? 2 : 1;   // thirds (pairs of matrices) covered
     static constexpr int kXi = 2 * kThirds;
-    static constexpr int kFirst = PHASE;                 // first of the 5 rows read
-    f2 d[5];
-    f4 b[kThirds][3];     // {xi even .x/.y, xi odd .x/.y} per channel tile
+    static constexpr int kFirst = PHASE == 0 ? 1 : 0;    // first row read
+    static constexpr int kRows = PHASE == 0 ? 4 : 6;
+    static constexpr int kLoads = kRows + 3 * kThirds;
+    // accumulator (= xi) of the x-th matrix of this phase
+    static constexpr int xi(int x) { return PHASE == 0 ? 1 + x : (x == 0 ? 0 : 5); }
+    f2 d[kRows];
+    f4 b[kThirds][3];     // {first of the pair .x/.y, second .x/.y} per channel tile
 };
 
 template <int PHASE, int SP_IDX>
@@ -619,8 +660,11 @@ __device__ __forceinline__ void w43_load(W43Frags<PHASE>& f, unsigned a_addr, un
     f.d[1] = ds_read_f2<((F::kFirst + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
     f.d[2] = ds_read_f2<((F::kFirst + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
     f.d[3] = ds_read_f2<((F::kFirst + 3) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    // a third is [sp][t][lane][xi&1][e]: 256 floats per (sp, t)
+    if constexpr (F::kRows == 6) {
+        f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
+        f.d[5] = ds_read_f2<((F::kFirst + 5) * kS48 + SP_IDX * 8) * 4>(a_addr);
+    }
+    // a third is [sp][t][lane][which of the pair][e]: 256 floats per (sp, t)
     f.b[0][0] = ds_read_f4<((SP_IDX * 3 + 0) * 256) * 4>(b_addr);
     f.b[0][1] = ds_read_f4<((SP_IDX * 3 + 1) * 256) * 4>(b_addr);
     f.b[0][2] = ds_read_f4<((SP_IDX * 3 + 2) * 256) * 4>(b_addr);
@@ -635,7 +679,7 @@ template <int PENDING, int PHASE>
 __device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
     asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
 #pragma unroll
-    for (int k = 0; k < 5; ++k) asm volatile("" : "+v"(f.d[k]));
+    for (int k = 0; k < W43Frags<PHASE>::kRows; ++k) asm volatile("" : "+v"(f.d[k]));
 #pragma unroll
     for (int h = 0; h < W43Frags<PHASE>::kThirds; ++h)
 #pragma unroll
@@ -645,49 +689,50 @@ __device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
 template <int PHASE, int SP_IDX>
 __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
                                          W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3]) {
-    constexpr int kXi = W43Frags<PHASE>::kXi;
-    constexpr int kX0 = PHASE == 0 ? 0 : 4;              // first xi of this phase
-    constexpr int kLoads = 5 + 3 * W43Frags<PHASE>::kThirds;
+    using F = W43Frags<PHASE>;
+    constexpr int kXi = F::kXi;
     if constexpr (SP_IDX + 1 < 6) {
         w43_load<PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
-        w43_wait<kLoads>(buf[SP_IDX & 1]);
+        w43_wait<F::kLoads>(buf[SP_IDX & 1]);
     } else {
         w43_wait<0>(buf[SP_IDX & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const W43Frags<PHASE>& f = buf[SP_IDX & 1];
-    // Input transform, deliberately component by component with scalar FMAs: packed fp32 VALU
-    // (v_pk_add/mul_f32, what vector-typed code compiles to) costs ~10 extra cycles per
-    // instruction when it sits between MFMAs.
+    const F& f = buf[SP_IDX & 1];
     f2 u[kXi];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float d0 = f.d[0][e], d1 = f.d[1][e], d2 = f.d[2][e], d3 = f.d[3][e], d4 = f.d[4][e];
-        if constexpr (PHASE == 0) {        // rows d0..d4
-            u[0][e] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-            u[1][e] = fmaf(-4.f, d1 + d2, d3 + d4);
-            u[2][e] = fmaf(4.f, d1 - d2, d4 - d3);
-            u[3][e] = fmaf(2.f, d3 - d1, d4 - d2);
-        } else {                           // rows d1..d5 at index 0..4
-            u[0][e] = fmaf(-2.f, d2 - d0, d3 - d1);
-            u[1][e] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
+            const float d1 = f.d[0][e], d2 = f.d[1][e], d3 = f.d[2][e], d4 = f.d[3][e];
+            const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+            const float c = d4 - d2, g = d3 - d1;
+            u[0][e] = a + b;
+            u[1][e] = a - b;
+            u[2][e] = fmaf(2.f, g, c);
+            u[3][e] = fmaf(-2.f, g, c);
+        } else {                           // rows d0..d5
+            u[0][e] = fmaf(4.f, f.d[0][e], fmaf(-5.f, f.d[2][e], f.d[4][e]));
+            u[1][e] = fmaf(4.f, f.d[1][e], fmaf(-5.f, f.d[3][e], f.d[5][e]));
         }
     }
-    // f.b[h][t] = {V(2h).e0, V(2h).e1, V(2h+1).e0, V(2h+1).e1} for this lane's (k, n)
+#pragma unroll
+    for (int x = 0; x < kXi; ++x) asm volatile("" : "+v"(u[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    // f.b[h][t] = {V(pair h, first).e0, .e1, V(pair h, second).e0, .e1} for this lane's (k, n)
 #pragma unroll
     for (int x = 0; x < kXi; ++x)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            acc[kX0 + x][t] = mfma4(u[x].x, f.b[x >> 1][t][2 * (x & 1)], acc[kX0 + x][t]);
+            acc[F::xi(x)][t] = mfma4(u[x].x, f.b[x >> 1][t][2 * (x & 1)], acc[F::xi(x)][t]);
 #pragma unroll
     for (int x = 0; x < kXi; ++x)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            acc[kX0 + x][t] = mfma4(u[x].y, f.b[x >> 1][t][2 * (x & 1) + 1], acc[kX0 + x][t]);
+            acc[F::xi(x)][t] = mfma4(u[x].y, f.b[x >> 1][t][2 * (x & 1) + 1], acc[F::xi(x)][t]);
 #pragma unroll
     for (int x = 0; x < kXi; ++x)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[kX0 + x][t]));
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[F::xi(x)][t]));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
 }
@@ -907,7 +952,7 @@ struct SmallMRegs {
     EpiParams<1, BN> ep;
     __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int bn_index,
                                              int lane, int wave) {
-        if (wave < ACTIVE) {
+        if (ACTIVE == kWaves || wave < ACTIVE) {
             const int t0 = (wave % NGROUPS) * NTW, ks = wave / NGROUPS;
             const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t0) * 128 + lane * 2;
 #pragma unroll
@@ -934,7 +979,7 @@ struct SmallMRegs {
     template <int K0, int K1>
     __device__ __forceinline__ void prefetch_slice(const float* __restrict__ packed, int lane,
                                                    int wave) {
-        if (wave < ACTIVE) {
+        if (ACTIVE == kWaves || wave < ACTIVE) {
             const int t0 = (wave % NGROUPS) * NTW, ks = wave / NGROUPS;
             const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t0) * 128 + lane * 2;
 #pragma unroll
@@ -1309,10 +1354,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
         lds, packed, tid, lane, wave, ts, 26,
         [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
-        [&](auto tag) {      // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
+        interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
             constexpr int IT = decltype(tag)::value;
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
-        });
+        }));
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
         lds, packed, tid, lane, wave, ts, 30, [] {},

@@ -110,6 +110,9 @@ constexpr int kW0 = kActOff + kActFloats;
 constexpr int kW1 = kW0 + kWFloats;
 constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 39,524
 constexpr int kWinoHalf = 2 * 48 * 48;                     // 4,608: two transformed matrices
+// F(4,3) matrices are stored V1,V2 | V3,V4 | V0,V5: the first two thirds need only rows d1..d4
+// of the six-row input tile and share their sub-expressions; kW43Slot[xi] = position of V_xi.
+constexpr int kW43Slot[6] = {4, 0, 1, 2, 3, 5};
 constexpr int kSlot0 = kW0;
 constexpr int kSlot1 = kW0 + kWinoHalf;
 constexpr int kSlot2 = kW0 + 2 * kWinoHalf;
