@@ -771,56 +771,92 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
             const float v = x == 1 ? ep.b[t] : 0.f;
             acc[x][t] = f4{v, v, v, v};
         }
-    // quad j = wave*16 + n needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
-    const float* a_lane = lds + kActOff + (wave * 64 + 4 * n) * kS48 + 2 * q;
+    // MFMA row m = 4q'+r' of the wave's tile works on quad pm(m) = 2q' + (r'&1) + 8(r'>>1), so
+    // that in the epilogue the four lane groups of one store (m = 4q+r, q = 0..3) write quads
+    // 2 apart = 16-bank-aligned quarters of the 64 LDS banks instead of colliding two by two.
+    // quad j = wave*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
+    const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
+    const float* a_lane = lds + kActOff + (wave * 64 + 4 * pm_n) * kS48 + 2 * q;
+    if (ts_base == 2) mark(ts, 58);
     w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc);
     if (ts_base == 2) mark(ts, 56);
     __syncthreads();      // last third landed in slot 2; slots 0 and 1 free
     if (ts_base == 2) mark(ts, 57);
     dma1();
     w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc);
+
+    // Output transform + ReLU (+ pooling, BN) in registers, then the stores.  Register PAIRS
+    // (v_pk_add_f32 / v_pk_fma_f32: two rows of the tile per instruction - no MFMA is in flight,
+    // so packed fp32 runs at full rate) halve the VALU count of this VALU-bound phase; ReLU and
+    // pooling stay scalar (no packed fp32 max).
+    constexpr int NV = POOL ? 2 : 4;
+    float o[3][2][2][NV];
+    auto transform = [&] {
+        const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+    #pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float sc = ep.sc[t], sh = ep.sh[t];
+    #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 a0 = f2{acc[0][t][2 * h], acc[0][t][2 * h + 1]};
+                const f2 a1 = f2{acc[1][t][2 * h], acc[1][t][2 * h + 1]};
+                const f2 a2 = f2{acc[2][t][2 * h], acc[2][t][2 * h + 1]};
+                const f2 a3 = f2{acc[3][t][2 * h], acc[3][t][2 * h + 1]};
+                const f2 a4 = f2{acc[4][t][2 * h], acc[4][t][2 * h + 1]};
+                const f2 a5 = f2{acc[5][t][2 * h], acc[5][t][2 * h + 1]};
+                const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+                const f2 y0 = a0 + s12 + s34;
+                const f2 y1 = __builtin_elementwise_fma(k2, d34, d12);
+                const f2 y2 = __builtin_elementwise_fma(k4, s34, s12);
+                const f2 y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
+                    float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
+                    if constexpr (POOL) {
+                        float o0 = fmaxf(v0, v1), o1 = fmaxf(v2, v3);
+                        if (BN) {
+                            o0 = fmaf(o0, sc, sh);
+                            o1 = fmaf(o1, sc, sh);
+                        }
+                        o[t][h][e][0] = o0;
+                        o[t][h][e][1] = o1;
+                    } else {
+                        if (BN) {
+                            v0 = fmaf(v0, sc, sh);
+                            v1 = fmaf(v1, sc, sh);
+                            v2 = fmaf(v2, sc, sh);
+                            v3 = fmaf(v3, sc, sh);
+                        }
+                        o[t][h][e][0] = v0;
+                        o[t][h][e][1] = v1;
+                        o[t][h][e][2] = v2;
+                        o[t][h][e][3] = v3;
+                    }
+                }
+            }
+        }
+    };
     mark(ts, ts_base);
 
     __syncthreads();      // every wave has finished reading the old activations
     mark(ts, ts_base + 1);
+    // (Doing this arithmetic ahead of the barrier - all waves, or only the older wave of each
+    // SIMD - was measured and does not pay: it slows the partner's last MFMAs by as much as it
+    // saves here.)
+    transform();
 
     float* out = lds + kActOff + n;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const float sc = ep.sc[t], sh = ep.sh[t];
-        const f4 s12 = acc[1][t] + acc[2][t], d12 = acc[1][t] - acc[2][t];
-        const f4 s34 = acc[3][t] + acc[4][t], d34 = acc[3][t] - acc[4][t];
-        const f4 y0 = acc[0][t] + s12 + s34;
-        const f4 y1 = d12 + 2.f * d34;
-        const f4 y2 = s12 + 4.f * s34;
-        const f4 y3 = d12 + 8.f * d34 + acc[5][t];
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = wave * 16 + 4 * q + r;
-            float v0 = fmaxf(y0[r], 0.f), v1 = fmaxf(y1[r], 0.f);
-            float v2 = fmaxf(y2[r], 0.f), v3 = fmaxf(y3[r], 0.f);
-            if (POOL) {
-                float o0 = fmaxf(v0, v1), o1 = fmaxf(v2, v3);
-                if (BN) {
-                    o0 = fmaf(o0, sc, sh);
-                    o1 = fmaf(o1, sc, sh);
-                }
-                out[(1 + 2 * j) * kS48 + t * 16] = o0;
-                out[(2 + 2 * j) * kS48 + t * 16] = o1;
-            } else {
-                if (BN) {
-                    v0 = fmaf(v0, sc, sh);
-                    v1 = fmaf(v1, sc, sh);
-                    v2 = fmaf(v2, sc, sh);
-                    v3 = fmaf(v3, sc, sh);
-                }
-                out[(1 + 4 * j) * kS48 + t * 16] = v0;
-                out[(2 + 4 * j) * kS48 + t * 16] = v1;
-                out[(3 + 4 * j) * kS48 + t * 16] = v2;
-                out[(4 + 4 * j) * kS48 + t * 16] = v3;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = wave * 16 + 2 * q + e + 8 * h;      // pm(4q + 2h + e)
+#pragma unroll
+                for (int i = 0; i < NV; ++i) out[(1 + NV * j + i) * kS48 + t * 16] = o[t][h][e][i];
             }
-        }
-    }
     zero_row(lds + kActOff, 0, kS48, 48, tid);
     zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
     mark(ts, ts_base + 2);

@@ -79,6 +79,23 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     M(0) M(1) M(2) M(3) M(4) M(5) G4(28,2048) M(6) M(7) M(8) M(9) M(10) M(11)
 #define PAT_G2_BUNCHED \
     G2(18,0) G2(19,512) G2(20,1024) G2(21,1536) G2(18,2048) PAT_PURE
+// the F(4,3) phase-0 step as the kernel has it: 4 b64 + 6 b128, 14 v_fma in one bunch, 24 MFMAs
+#define V14 V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) V(14) V(15)
+#define PAT_STEP_FRONT \
+    L64(18,0) L64(19,1024) L64(20,2048) L64(21,3072) L128(26,4096) L128(27,5120) L128(28,6144) \
+    L128(29,7168) L128(26,8192) L128(27,9216) V14 PAT_PURE
+// the same work software-pipelined inside the wave: the VALU bunch in the middle of the MFMA
+// block, the LDS reads one after every second MFMA
+#define PAT_STEP_MID \
+    M(0) M(1) L64(18,0) M(2) M(3) L64(19,1024) M(4) M(5) L64(20,2048) M(6) M(7) L64(21,3072) \
+    M(8) M(9) L128(26,4096) M(10) M(11) V14 M(0) M(1) L128(27,5120) M(2) M(3) L128(28,6144) \
+    M(4) M(5) L128(29,7168) M(6) M(7) L128(26,8192) M(8) M(9) L128(27,9216) M(10) M(11)
+// two bunches of 7
+#define V7 V(14) V(15) V(16) V(17) V(14) V(15) V(16)
+#define PAT_STEP_MID2 \
+    M(0) M(1) L64(18,0) M(2) M(3) L64(19,1024) M(4) M(5) L64(20,2048) M(6) M(7) V7 L64(21,3072) \
+    M(8) M(9) L128(26,4096) M(10) M(11) M(0) M(1) L128(27,5120) M(2) M(3) L128(28,6144) \
+    M(4) M(5) L128(29,7168) M(6) M(7) V7 L128(26,8192) M(8) M(9) L128(27,9216) M(10) M(11)
 // s_nop between MFMAs (pure issue-slot cost)
 #define XS(i) M(i) SN
 #define PAT_SNOP \
@@ -136,6 +153,9 @@ KERNEL(k_l128_bunched, PAT_L128_BUNCHED)
 KERNEL(k_mix, PAT_MIX)
 KERNEL(k_mix_pk, PAT_MIX_PK)
 KERNEL(k_snop, PAT_SNOP)
+KERNEL(k_step_front, PAT_STEP_FRONT)
+KERNEL(k_step_mid, PAT_STEP_MID)
+KERNEL(k_step_mid2, PAT_STEP_MID2)
 KERNEL(k_g2, PAT_G2)
 KERNEL(k_g4, PAT_G4)
 KERNEL(k_g2b, PAT_G2_BUNCHED)
@@ -186,5 +206,8 @@ int main() {
     run("24 MFMA, 5 global_load_dwordx2 spread", k_g2);
     run("24 MFMA, 3 global_load_dwordx4 spread", k_g4);
     run("5 global_load_dwordx2 bunched, then 24 MFMA", k_g2b);
+    run("step: 10 LDS, 14 v_fma, then 24 MFMA", k_step_front);
+    run("step: 12 MFMA, 14 v_fma, 12 MFMA, LDS spread", k_step_mid);
+    run("step: 2 bunches of 7 v_fma inside 24 MFMA, LDS spread", k_step_mid2);
     return 0;
 }

@@ -24,7 +24,7 @@ for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
     for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
         NAMES[base + j] = '%s %s' % (l, what)
 NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
-EXTRA = {56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
+EXTRA = {58: 'conv2 prologue done', 56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
 
 
 def main():
