@@ -264,6 +264,25 @@ struct EpiParams {
 
 // Start the accumulators at the bias instead of zero: the MFMA chain then delivers conv + bias
 // and the epilogue saves one VALU add per output (ADD_BIAS = false below).
+// Where epilogue parameter OFF of the packed image lives: in the LDS copy (kParams) if it is
+// part of it, else in global memory.
+template <int OFF>
+__device__ __forceinline__ const float* param_ptr(const float* lds, const float* packed) {
+    if constexpr (OFF >= kWeightFloats && OFF - kWeightFloats < kParamFloats)
+        return lds + kParams + (OFF - kWeightFloats);
+    else
+        return packed + OFF;
+}
+// bias / BN scale / BN shift of layer CONV (BN index BNI, -1 = none) for channel n of tile 0
+template <int CONV, int BNI, int NT>
+__device__ __forceinline__ void load_epi(EpiParams<NT, (BNI >= 0)>& ep, const float* lds,
+                                         const float* packed, int n) {
+    constexpr int B = BNI >= 0 ? BNI : 0;
+    ep.load(param_ptr<bias_offset(CONV)>(lds, packed) + n,
+            param_ptr<bn_scale_offset(B)>(lds, packed) + n,
+            param_ptr<bn_shift_offset(B)>(lds, packed) + n);
+}
+
 template <int MT, int NT, bool BN>
 __device__ __forceinline__ void bias_acc(f4 (&acc)[MT][NT], const EpiParams<NT, BN>& ep) {
 #pragma unroll
@@ -382,8 +401,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
 
     if constexpr (NEXT_N > 0) dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
     EpiParams<NT, BN> ep;
-    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
-            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    load_epi<CONV, BNI>(ep, lds, packed, n);
 
     f4 acc[MT][NT];
     bias_acc(acc, ep);
@@ -554,8 +572,7 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 
     next1();
     EpiParams<3, BN> ep;
-    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
-            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    load_epi<CONV, BNI>(ep, lds, packed, n);
     // M0 starts at +bias and M3 at -bias, so even = M0+M1+M2 and odd = M1-M2-M3 both arrive
     // with the bias already added
     f4 acc[4][MT][3];
@@ -760,8 +777,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
 
     dma0();
     EpiParams<3, BN> ep;
-    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
-            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    load_epi<CONV, BNI>(ep, lds, packed, n);
     // M1 enters all four outputs with weight +1, so it is the accumulator that starts at the bias
     f4 acc[6][3];
 #pragma unroll
@@ -893,8 +909,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
 
     side();
     EpiParams<3, BN> ep;
-    ep.load(packed + bias_offset(CONV) + n, packed + (BN ? bn_scale_offset(BN ? BNI : 0) : 0) + n,
-            packed + (BN ? bn_shift_offset(BN ? BNI : 0) : 0) + n);
+    load_epi<CONV, BNI>(ep, lds, packed, n);
     f4 acc[4][1][3];
     zero_acc(acc[1]);
     zero_acc(acc[2]);
@@ -1248,6 +1263,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         EpiParams<3, true> ep;
         ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
                 packed + bn_shift_offset(0) + n);
+        // the LDS copy of the later layers' epilogue parameters (published by this stage's barrier)
+        constexpr int kParamRounds = (kParamFloats + kThreads - 1) / kThreads;
+        float pv[kParamRounds];
+#pragma unroll
+        for (int i = 0; i < kParamRounds; ++i)
+            pv[i] = (tid + i * kThreads < kParamFloats) ? packed[kWeightFloats + tid + i * kThreads]
+                                                        : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
             bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
@@ -1325,6 +1347,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         epilogue<MT, 3, kS48, false, true>(acc, out_lane, ep);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
+#pragma unroll
+        for (int i = 0; i < kParamRounds; ++i)
+            if (tid + i * kThreads < kParamFloats) lds[kParams + tid + i * kThreads] = pv[i];
         __syncthreads();
         mark(ts, 1);
     }
@@ -1394,6 +1419,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             constexpr int IT = decltype(tag)::value;
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
         }));
+    // BN5's scale/shift (384 floats, too many for the parameter table): one per thread, fetched
+    // here, parked in LDS at the top of stage E
+    const float bn5v = tid < 2 * 192 ? packed[bn_scale_offset(4) + tid] : 0.f;
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
         lds, packed, tid, lane, wave, ts, 30, [] {},
@@ -1425,6 +1453,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         zero_row(lds + kET4b, 65, kS48, 48, tid);
         zero_row(lds + kECat, 0, kS192, 192, tid);
         zero_row(lds + kECat, 33, kS192, 192, tid);
+        if (tid < 2 * 192) lds[kEBn5 + tid] = bn5v;
         __syncthreads();
         mark(ts, 34);
 
@@ -1435,26 +1464,27 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         constexpr int w14 = kEW + weight_offset(13) - weight_offset(9);
         constexpr int w15 = kEW + weight_offset(14) - weight_offset(9);
         constexpr int w16 = kEW + weight_offset(15) - weight_offset(9);
-        const float* sc5 = packed + bn_scale_offset(4) + n;
-        const float* sh5 = packed + bn_shift_offset(4) + n;
+        const float* sc5 = lds + kEBn5 + n;
+        const float* sh5 = lds + kEBn5 + 192 + n;
+        const float* bias_tab = lds + kParams - kWeightFloats + n;     // + bias_offset(conv)
 
         // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
         if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
             const int t = wave;
             inception_1x1<3, kS192, true>(lds + kEAP, lds + w10, lds + kECat, t * 16,
-                                          packed + bias_offset(9) + t * 16 + n, sc5 + t * 16,
+                                          bias_tab + bias_offset(9) + t * 16, sc5 + t * 16,
                                           sh5 + t * 16, t, lane);
         } else if (wave < 6) {     // conv11 -> concat channels 48..95
             const int t = wave - 3;
             inception_1x1<3, kS192, true>(lds + kEX, lds + w11, lds + kECat, 48 + t * 16,
-                                          packed + bias_offset(10) + t * 16 + n,
+                                          bias_tab + bias_offset(10) + t * 16,
                                           sc5 + 48 + t * 16, sh5 + 48 + t * 16, t, lane);
         } else if (wave == 6) {    // conv12 -> 16-channel bottleneck of branch 3
             inception_1x1<1, kS16, false>(lds + kEX, lds + w12, lds + kET3, 0,
-                                          packed + bias_offset(11) + n, nullptr, nullptr, 0, lane);
+                                          bias_tab + bias_offset(11), nullptr, nullptr, 0, lane);
         } else {                   // conv14 -> 16-channel bottleneck of branch 4
             inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0,
-                                          packed + bias_offset(13) + n, nullptr, nullptr, 0, lane);
+                                          bias_tab + bias_offset(13), nullptr, nullptr, 0, lane);
         }
         mark(ts, 35);
         __syncthreads();
@@ -1464,7 +1494,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         if (wave < 6) {
             const int t = wave % 3, m0 = (wave / 3) * 2;
             inception_k3<2, 2, 1, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, t * 16,
-                                                     packed + bias_offset(14) + t * 16 + n,
+                                                     bias_tab + bias_offset(14) + t * 16,
                                                      nullptr, nullptr, t, m0, lane);
         }
         mark(ts, 37);
@@ -1477,13 +1507,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             const int t = wave % 3, m0 = (wave / 3) * 2;
             inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
                                                      144 + t * 16,
-                                                     packed + bias_offset(15) + t * 16 + n,
+                                                     bias_tab + bias_offset(15) + t * 16,
                                                      sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
                                                      lane);
         } else {
             const int m0 = (wave - 6) * 2;
             inception_k3<2, 2, 3, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
-                                                     packed + bias_offset(12) + n, sc5 + 96,
+                                                     bias_tab + bias_offset(12), sc5 + 96,
                                                      sh5 + 96, 0, m0, lane);
         }
         mark(ts, 39);

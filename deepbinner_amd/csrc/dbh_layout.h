@@ -159,10 +159,20 @@ constexpr int kLogits = kRed + 24 * 256;                   // 32 floats
 constexpr int kTailEnd = kLogits + 32;
 static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
 
-constexpr int kLdsFloats =
+// BN5's scale and shift (2 x 192 floats), parked above stage E's buffers for the inception block
+constexpr int kEBn5 = kLdsFloatsE;
+static_assert(kEBn5 + 2 * 192 <= (kLdsFloatsAD > kLdsFloatsD ? kLdsFloatsAD : kLdsFloatsD), "");
+constexpr int kArenaFloats =
     (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
         ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
         : kLdsFloatsD;
+// Above the arena, for the whole kernel: a copy of every bias and of BN1..BN4's scale/shift
+// (packed[kWeightFloats ..), so that a layer's epilogue parameters come from LDS (~100 cycles)
+// instead of L2 (~700 cycles, exposed at the top of every layer).  BN5..BN7 do not fit; their
+// users fetch them from global memory well ahead of use.
+constexpr int kParams = kArenaFloats;
+constexpr int kParamFloats = (kBiasEnd - kWeightFloats) + 2 * (48 + 48 + 48 + 48);
+constexpr int kLdsFloats = kParams + kParamFloats;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])

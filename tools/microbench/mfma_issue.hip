@@ -96,15 +96,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     M(0) M(1) L64(18,0) M(2) M(3) L64(19,1024) M(4) M(5) L64(20,2048) M(6) M(7) V7 L64(21,3072) \
     M(8) M(9) L128(26,4096) M(10) M(11) M(0) M(1) L128(27,5120) M(2) M(3) L128(28,6144) \
     M(4) M(5) L128(29,7168) M(6) M(7) V7 L128(26,8192) M(8) M(9) L128(27,9216) M(10) M(11)
+// dependent chains: 24 MFMAs over 1, 2, 3, 4, 6 accumulators (reuse distance = that many issues)
+#define PAT_DEP1 M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0)
+#define PAT_DEP2 M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1) M(0) M(1)
+#define PAT_DEP3 M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2) M(0) M(1) M(2)
+#define PAT_DEP4 M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3)
+#define PAT_DEP6 M(0) M(1) M(2) M(3) M(4) M(5) M(0) M(1) M(2) M(3) M(4) M(5) M(0) M(1) M(2) M(3) M(4) M(5) M(0) M(1) M(2) M(3) M(4) M(5)
 // s_nop between MFMAs (pure issue-slot cost)
 #define XS(i) M(i) SN
 #define PAT_SNOP \
     XS(0) XS(1) XS(2) XS(3) XS(4) XS(5) XS(6) XS(7) XS(8) XS(9) XS(10) XS(11) \
     XS(0) XS(1) XS(2) XS(3) XS(4) XS(5) XS(6) XS(7) XS(8) XS(9) XS(10) XS(11)
 
-#define KERNEL(NAME, PATTERN)                                                                     \
-    __global__ __launch_bounds__(512) void NAME(float* out, long long* cyc, int steps) {          \
-        __shared__ f4 sh[1024];                                                                   \
+#define KERNEL(NAME, PATTERN) KERNEL_T(NAME, PATTERN, 512)
+#define KERNEL_T(NAME, PATTERN, THREADS)                                                           \
+    __global__ __launch_bounds__(THREADS) void NAME(float* out, long long* cyc, int steps) {      \
+        __shared__ f4 sh[6144];   /* 96 KiB: one block per CU */                                  \
         for (int i = threadIdx.x; i < 1024; i += blockDim.x) sh[i] = f4{1, 2, 3, 4};              \
         f4 acc[12], ld[4];                                                                        \
         for (int i = 0; i < 12; ++i) acc[i] = f4{0, 0, 0, 0};                                     \
@@ -136,8 +143,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         for (int i = 0; i < 4; ++i) sv += v[i] + pv[i].x + pv[i].y;                               \
         out[blockIdx.x * blockDim.x + threadIdx.x] = s4.x + s4.y + s4.z + s4.w + sv;              \
         if ((threadIdx.x & 63) == 0) {                                                            \
-            cyc[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 2] = t0;                                  \
-            cyc[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 2 + 1] = t1;                              \
+            cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0;                                  \
+            cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1;                              \
         }                                                                                         \
     }
 
@@ -153,6 +160,18 @@ KERNEL(k_l128_bunched, PAT_L128_BUNCHED)
 KERNEL(k_mix, PAT_MIX)
 KERNEL(k_mix_pk, PAT_MIX_PK)
 KERNEL(k_snop, PAT_SNOP)
+KERNEL_T(k_dep1, PAT_DEP1, 256)
+KERNEL_T(k_dep2, PAT_DEP2, 256)
+KERNEL_T(k_dep3, PAT_DEP3, 256)
+KERNEL_T(k_dep4, PAT_DEP4, 256)
+KERNEL_T(k_dep6, PAT_DEP6, 256)
+KERNEL(k_dep2_2w, PAT_DEP2)
+KERNEL(k_dep3_2w, PAT_DEP3)
+KERNEL_T(k_pure_1wave, PAT_PURE, 256)
+KERNEL_T(k_pure_3wave, PAT_PURE, 768)
+KERNEL_T(k_pure_4wave, PAT_PURE, 1024)
+KERNEL_T(k_front_1wave, PAT_STEP_FRONT, 256)
+KERNEL_T(k_front_4wave, PAT_STEP_FRONT, 1024)
 KERNEL(k_step_front, PAT_STEP_FRONT)
 KERNEL(k_step_mid, PAT_STEP_MID)
 KERNEL(k_step_mid2, PAT_STEP_MID2)
@@ -162,30 +181,30 @@ KERNEL(k_g2b, PAT_G2_BUNCHED)
 
 typedef void (*kern_t)(float*, long long*, int);
 
-static void run(const char* name, kern_t k) {
+static void run(const char* name, kern_t k, int threads = 512) {
     float* out;
     long long* cyc;
-    (void)hipMalloc(&out, 256 * 512 * 4);
-    (void)hipMalloc(&cyc, 256 * 8 * 16);
+    (void)hipMalloc(&out, 256 * 1024 * 4);
+    (void)hipMalloc(&cyc, 256 * 16 * 16);
     const int steps = 200;
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, out, cyc, steps);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, out, cyc, steps);
     (void)hipDeviceSynchronize();
-    static long long h[256 * 16];
+    static long long h[256 * 32];
     (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double span = 0, w0 = 0;
     for (int b = 0; b < 256; ++b) {
-        long long lo = h[b * 16], hi = h[b * 16 + 1];
-        for (int w = 1; w < 8; ++w) {
-            lo = std::min(lo, h[(b * 8 + w) * 2]);
-            hi = std::max(hi, h[(b * 8 + w) * 2 + 1]);
+        long long lo = h[b * 32], hi = h[b * 32 + 1];
+        for (int w = 1; w < threads / 64; ++w) {
+            lo = std::min(lo, h[(b * 16 + w) * 2]);
+            hi = std::max(hi, h[(b * 16 + w) * 2 + 1]);
         }
         span += double(hi - lo);
-        w0 += double(h[b * 16 + 1] - h[b * 16]);
+        w0 += double(h[b * 32 + 1] - h[b * 32]);
     }
     span /= 256;
     w0 /= 256;
     printf("%-60s %6.2f cycles/MFMA/SIMD   (wave 0: %6.2f per own MFMA)\n", name,
-           span / (steps * 24.0 * 2), w0 / (steps * 24.0));
+           span / (steps * 24.0 * (threads / 256.0)), w0 / (steps * 24.0));
     (void)hipFree(out);
     (void)hipFree(cyc);
 }
@@ -206,6 +225,18 @@ int main() {
     run("24 MFMA, 5 global_load_dwordx2 spread", k_g2);
     run("24 MFMA, 3 global_load_dwordx4 spread", k_g4);
     run("5 global_load_dwordx2 bunched, then 24 MFMA", k_g2b);
+    run("24 MFMA, 1 wave per SIMD", k_pure_1wave, 256);
+    run("24 MFMA, 3 waves per SIMD", k_pure_3wave, 768);
+    run("24 MFMA, 4 waves per SIMD", k_pure_4wave, 1024);
+    run("1 wave/SIMD, accumulator reused every MFMA", k_dep1, 256);
+    run("1 wave/SIMD, accumulator reused every 2nd MFMA", k_dep2, 256);
+    run("1 wave/SIMD, accumulator reused every 3rd MFMA", k_dep3, 256);
+    run("1 wave/SIMD, accumulator reused every 4th MFMA", k_dep4, 256);
+    run("1 wave/SIMD, accumulator reused every 6th MFMA", k_dep6, 256);
+    run("2 waves/SIMD, accumulator reused every 2nd MFMA", k_dep2_2w);
+    run("2 waves/SIMD, accumulator reused every 3rd MFMA", k_dep3_2w);
+    run("step (front), 1 wave per SIMD", k_front_1wave, 256);
+    run("step (front), 4 waves per SIMD", k_front_4wave, 1024);
     run("step: 10 LDS, 14 v_fma, then 24 MFMA", k_step_front);
     run("step: 12 MFMA, 14 v_fma, 12 MFMA, LDS spread", k_step_mid);
     run("step: 2 bunches of 7 v_fma inside 24 MFMA, LDS spread", k_step_mid2);
