@@ -172,6 +172,10 @@ KERNEL_T(k_pure_3wave, PAT_PURE, 768)
 KERNEL_T(k_pure_4wave, PAT_PURE, 1024)
 KERNEL_T(k_front_1wave, PAT_STEP_FRONT, 256)
 KERNEL_T(k_front_4wave, PAT_STEP_FRONT, 1024)
+KERNEL_T(k_mid_1wave, PAT_STEP_MID, 256)
+KERNEL_T(k_mid2_1wave, PAT_STEP_MID2, 256)
+KERNEL_T(k_v1_1wave, PAT_V1, 256)
+KERNEL_T(k_l128_1wave, PAT_L128, 256)
 KERNEL(k_step_front, PAT_STEP_FRONT)
 KERNEL(k_step_mid, PAT_STEP_MID)
 KERNEL(k_step_mid2, PAT_STEP_MID2)
@@ -237,6 +241,10 @@ int main() {
     run("2 waves/SIMD, accumulator reused every 3rd MFMA", k_dep3_2w);
     run("step (front), 1 wave per SIMD", k_front_1wave, 256);
     run("step (front), 4 waves per SIMD", k_front_4wave, 1024);
+    run("step (mid), 1 wave per SIMD", k_mid_1wave, 256);
+    run("step (2 bunches), 1 wave per SIMD", k_mid2_1wave, 256);
+    run("24 MFMA + 1 v_fma after each, 1 wave per SIMD", k_v1_1wave, 256);
+    run("24 MFMA + ds_read_b128 after every 2nd, 1 wave per SIMD", k_l128_1wave, 256);
     run("step: 10 LDS, 14 v_fma, then 24 MFMA", k_step_front);
     run("step: 12 MFMA, 14 v_fma, 12 MFMA, LDS spread", k_step_mid);
     run("step: 2 bunches of 7 v_fma inside 24 MFMA, LDS spread", k_step_mid2);
