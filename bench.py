@@ -42,7 +42,8 @@ N_READS = 10000
 BATCH = 256
 SCAN_SIZE = 512
 SCORE_DIFF = 0.5
-TIMING_STRIDE = 8
+TIMING_STRIDE = 8           # an event bracket opens at every 8th forward launch ...
+TIMING_SPAN = 4             # ... and covers 4 consecutive (full, 256-window) launches
 
 
 def synthetic_reads(n, seed):
@@ -166,9 +167,12 @@ def main():
     sync()
     barrier()
     sync()
-    # HIP events around every 8th forward launch (5 of the 40 launches of a step): recording them
-    # around EVERY launch costs ~7 us of queue time per batch and slows what is being measured
-    model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE)
+    # One HIP event pair around launches 8k .. 8k+3 of the 40 launches of a step (all full,
+    # 256-window launches; the 16-window tail launch is never inside a bracket).  A pair around
+    # EVERY launch costs ~7 us of queue time per batch and slows what is being measured, and a
+    # pair around a single launch includes ~2.5 us of dispatch latency that back-to-back launches
+    # do not pay (rocprofv3's per-kernel duration is that much shorter).
+    model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -216,7 +220,7 @@ def main():
             'bound': 'mfma', 'kernel': 'dbh_forward_kernel', 'achieved': achieved,
             'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
             'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
-            'timed_every_nth_launch': TIMING_STRIDE,
+            'timed_every_nth_launch': TIMING_STRIDE, 'launches_per_event_bracket': TIMING_SPAN,
             'windows_per_launch': windows_per_launch,
             'algorithmic_flop_per_window': FLOP_PER_WINDOW,
             # fused seam b2: int16 samples in, fp32 probabilities + int32 call out

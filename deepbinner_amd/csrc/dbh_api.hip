@@ -152,7 +152,11 @@ struct dbh_model {
         void* d_work = nullptr; size_t d_work_bytes = 0;
     } slot[2];
     // live timing of the forward kernel (dbh_forward_timing_*)
-    int timing = 0;              // 0 = off, n = bracket every n-th forward launch with events
+    int timing = 0;              // 0 = off, n = open an event bracket at every n-th forward launch
+    int timing_span = 1;         // consecutive launches one bracket covers (<= timing)
+    hipEvent_t open_stop = nullptr;   // stop event of the bracket being filled
+    int64_t open_windows = 0;
+    int64_t timed_launches = 0;
     int64_t launch_counter = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -203,18 +207,26 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
     for (int64_t off = 0; off < n; off += kChunk) {
         const int64_t cnt = (n - off < kChunk) ? (n - off) : kChunk;
         hipEvent_t ev_stop = nullptr;
-        if (m->timing > 0 && (debug_stage < 0 || debug_stage >= 100) &&
-            (m->launch_counter++ % m->timing) == 0) {
-            if (m->events_used == m->events.size()) {
-                hipEvent_t a, b;
-                DBH_HIP(hipEventCreate(&a));
-                DBH_HIP(hipEventCreate(&b));
-                m->events.emplace_back(a, b);
+        if (m->timing > 0 && (debug_stage < 0 || debug_stage >= 100)) {
+            const int64_t pos = m->launch_counter++ % m->timing;
+            if (pos == 0) {
+                if (m->events_used == m->events.size()) {
+                    hipEvent_t a, b;
+                    DBH_HIP(hipEventCreate(&a));
+                    DBH_HIP(hipEventCreate(&b));
+                    m->events.emplace_back(a, b);
+                }
+                DBH_HIP(hipEventRecord(m->events[m->events_used].first, stream));
+                m->open_stop = m->events[m->events_used].second;
+                m->open_windows = 0;
             }
-            DBH_HIP(hipEventRecord(m->events[m->events_used].first, stream));
-            ev_stop = m->events[m->events_used].second;
-            ++m->events_used;
-            m->timed_windows += cnt;
+            if (m->open_stop && pos < m->timing_span) {
+                m->open_windows += cnt;
+                if (pos == m->timing_span - 1) {      // last launch of the bracket
+                    ev_stop = m->open_stop;
+                    m->open_stop = nullptr;
+                }
+            }
         }
         hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)cnt), dim3(dbh::kThreads), 0,
                            stream, m->d_packed, x_dev ? x_dev + off * dbh::kWindow : nullptr,
@@ -227,7 +239,12 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
                            in.steps, in.side, in.score_diff,
                            in.calls ? (int*)(in.calls + off / in.steps) : nullptr);
         DBH_HIP(hipGetLastError());
-        if (ev_stop) DBH_HIP(hipEventRecord(ev_stop, stream));
+        if (ev_stop) {
+            DBH_HIP(hipEventRecord(ev_stop, stream));
+            ++m->events_used;                          // only closed brackets count
+            m->timed_windows += m->open_windows;
+            m->timed_launches += m->timing_span;
+        }
     }
     return DBH_OK;
 }
@@ -690,13 +707,21 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
     return DBH_OK;
 }
 
-int dbh_forward_timing_enable(dbh_model* m, int enable) {
-    if (!m) return DBH_ERR_INVALID_ARGUMENT;
-    m->timing = enable > 0 ? enable : 0;
+int dbh_forward_timing_enable_span(dbh_model* m, int every_nth, int span) {
+    if (!m || span < 1 || (every_nth > 0 && span > every_nth)) return DBH_ERR_INVALID_ARGUMENT;
+    m->timing = every_nth > 0 ? every_nth : 0;
+    m->timing_span = span;
+    m->open_stop = nullptr;
+    m->open_windows = 0;
     m->launch_counter = 0;
     m->events_used = 0;
     m->timed_windows = 0;
+    m->timed_launches = 0;
     return DBH_OK;
+}
+
+int dbh_forward_timing_enable(dbh_model* m, int enable) {
+    return dbh_forward_timing_enable_span(m, enable, 1);
 }
 
 int dbh_forward_timing_read(dbh_model* m, double* total_ms, int64_t* launches, int64_t* windows) {
@@ -709,10 +734,12 @@ int dbh_forward_timing_read(dbh_model* m, double* total_ms, int64_t* launches, i
         sum += ms;
     }
     *total_ms = sum;
-    *launches = (int64_t)m->events_used;
+    *launches = m->timed_launches;
     *windows = m->timed_windows;
     m->events_used = 0;
     m->timed_windows = 0;
+    m->timed_launches = 0;
+    m->open_stop = nullptr;
     return DBH_OK;
 }
 

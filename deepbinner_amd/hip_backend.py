@@ -109,6 +109,7 @@ def load_library():
         'dbh_forward_timeline': (c_int, [c_void_p, _f32(), c_i64,
                                          ndpointer(np.int64, flags='C_CONTIGUOUS')]),
         'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
+        'dbh_forward_timing_enable_span': (c_int, [c_void_p, c_int, c_int]),
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
     }
     for name, (restype, argtypes) in sigs.items():
@@ -129,7 +130,8 @@ EXPORTED_SYMBOLS = [
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
-    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timing_enable', 'dbh_forward_timing_read',
+    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
+    'dbh_forward_timing_read',
 ]
 
 
@@ -370,10 +372,11 @@ class HipModel:
               'dbh_forward_timeline')
         return out
 
-    def timing_enable(self, every_nth=1):
-        """Bracket every n-th forward launch with HIP events (0/False = off, True = every)."""
-        check(self._lib.dbh_forward_timing_enable(self._handle, int(every_nth)),
-              'dbh_forward_timing_enable')
+    def timing_enable(self, every_nth=1, span=1):
+        """Bracket a run of ``span`` consecutive forward launches with one HIP event pair at
+        every n-th launch (0/False = off, True = every launch on its own)."""
+        check(self._lib.dbh_forward_timing_enable_span(self._handle, int(every_nth), int(span)),
+              'dbh_forward_timing_enable_span')
 
     def timing_read(self):
         ms, launches, windows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)

@@ -148,6 +148,12 @@ int dbh_forward_timeline(dbh_model* model, const float* x_host, int64_t n_window
  * measures); dbh_forward_timing_read synchronises those events, returns the summed kernel time,
  * the number of timed launches and of windows they covered, and resets the tally. 0 = off. */
 int dbh_forward_timing_enable(dbh_model* model, int enable);
+/* The same with ONE event pair around a run of `span` consecutive launches (span <= every_nth)
+ * starting at every every_nth-th launch: the pair's own cost (~2.5 us of dispatch latency lands
+ * inside the bracket) is shared by the run, so total_ms / launches is the launch-to-launch period
+ * of back-to-back launches, which is what rocprofv3's per-kernel duration plus the dispatch gap
+ * adds up to.  Brackets still open at dbh_forward_timing_read are dropped. */
+int dbh_forward_timing_enable_span(dbh_model* model, int every_nth, int span);
 int dbh_forward_timing_read(dbh_model* model, double* total_ms, int64_t* launches,
                             int64_t* windows);
 

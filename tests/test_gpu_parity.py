@@ -102,6 +102,28 @@ def test_predict_is_order_and_batch_independent(hip_models):
     assert np.abs(full[:64] - want).max() < PROB_TOL
 
 
+def test_live_kernel_timing_brackets(hip_models):
+    """dbh_forward_timing_*: one event pair per run of `span` launches at every n-th launch; only
+    closed brackets are reported, and timing does not change results."""
+    model = hip_models['EXP-NBD103_read_starts']
+    base = np.load(os.path.join(GOLD, 'windows_start.npy')).reshape(-1, 1024)[:32]
+    want = model.predict(base)
+    model.timing_enable(4, 2)
+    for _ in range(10):                      # launches 0..9: brackets {0,1}, {4,5}, {8,9}
+        assert np.array_equal(model.predict(base), want)
+    ms, launches, windows = model.timing_read()
+    assert launches == 6 and windows == 6 * 32 and ms > 0
+    assert 0.005 < ms / launches < 5.0       # tens of microseconds per launch
+    model.timing_enable(3, 3)
+    for _ in range(5):                       # bracket {0,1,2} closed, {3,4,..} still open
+        model.predict(base)
+    ms, launches, windows = model.timing_read()
+    assert launches == 3 and windows == 3 * 32
+    model.timing_enable(False)
+    model.predict(base)
+    assert model.timing_read()[1] == 0
+
+
 # ---- seam b2: classify_i16 -------------------------------------------------------------------
 @pytest.mark.parametrize('model_name,side', PLAN)
 def test_classify_matches_reference_call_batch(hip_models, gold, all_signals, model_name, side):
