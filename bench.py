@@ -112,16 +112,20 @@ def main():
     # DEEPBINNER_BENCH_SHARE_GPU=1 is a TEST mode for boxes with one GPU: every rank uses
     # device 0 and the gather runs over gloo on host copies (RCCL refuses two ranks per device).
     share_gpu = os.environ.get('DEEPBINNER_BENCH_SHARE_GPU') == '1'
+    # DEEPBINNER_BENCH_FORCE_DIST=1 is a TEST mode too: take the multi-rank code path (process
+    # group, RCCL all-gather, MAX-over-ranks) even with a single rank, so that a one-GPU box
+    # exercises exactly what the N > 1 runs execute.
+    use_dist = world > 1 or os.environ.get('DEEPBINNER_BENCH_FORCE_DIST') == '1'
     device = 0 if share_gpu else local_rank
     dist = torch = None
-    if world > 1:
+    if use_dist:
         import torch
         from deepbinner_amd.sharding import init_process_group
         if share_gpu:
             dist = init_process_group('gloo')
         else:
             torch.cuda.set_device(local_rank)
-            dist = init_process_group('nccl')
+            dist = init_process_group('nccl', local_rank)
     hip_backend.set_device(device)
 
     weights, _ = ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models', MODEL + '.dbw'))
@@ -133,7 +137,7 @@ def main():
     d_samples = hip_backend.DeviceBuffer.from_array(reads)
     d_offsets = hip_backend.DeviceBuffer.from_array(np.arange(N_READS + 1, dtype=np.int64) * 1024)
     d_probs = hip_backend.DeviceBuffer(N_READS * model.n_classes * 4)
-    if world > 1 and not share_gpu:
+    if use_dist and not share_gpu:
         calls_t = torch.empty(N_READS, dtype=torch.int32, device='cuda')
         calls_ptr = calls_t.data_ptr()
         gathered = torch.empty(world * N_READS, dtype=torch.int32, device='cuda')
@@ -146,20 +150,20 @@ def main():
     def step():
         model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, N_READS, BATCH, 'start',
                                    SCAN_SIZE, SCORE_DIFF, d_probs.ptr, calls_ptr, None)
-        if world > 1 and share_gpu:
+        if use_dist and share_gpu:
             host = torch.from_numpy(d_calls.download((N_READS,), np.int32))
             out = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(out, host)
-        elif world > 1:
+        elif use_dist:
             dist.all_gather_into_tensor(gathered, calls_t)
 
     def sync():
         hip_backend.synchronize()
-        if world > 1 and not share_gpu:
+        if use_dist and not share_gpu:
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -183,7 +187,7 @@ def main():
     kernel_ms, launches, windows = model.timing_read()
     model.timing_enable(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -229,13 +233,16 @@ def main():
                                              / 8.0e12,
         }
         if world == 1 and not args.no_cpu_baseline:
-            gpu_calls = hip_backend.DeviceBuffer.download(d_calls, (N_READS,), np.int32)
+            if use_dist and not share_gpu:       # (forced single-rank RCCL test mode)
+                gpu_calls = calls_t.cpu().numpy()
+            else:
+                gpu_calls = d_calls.download((N_READS,), np.int32)
             gpu_probs = d_probs.download((N_READS, model.n_classes), np.float32)
             result['cpu_baseline'] = cpu_baseline(weights, reads, gpu_calls, gpu_probs)
         result['device'] = hip_backend.device_name(device)
         print(json.dumps(result))
     barrier()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

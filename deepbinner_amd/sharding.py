@@ -25,12 +25,19 @@ def env_world():
             int(os.environ.get('WORLD_SIZE', 1)))
 
 
-def init_process_group(backend):
+def init_process_group(backend, local_rank=None):
+    """Rendezvous from the torchrun environment.  For RCCL (backend 'nccl') pass this process's
+    ``local_rank``: the communicator is then bound to that GPU up front instead of being guessed
+    at the first collective."""
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(backend=backend)
+        kwargs = {}
+        if backend == 'nccl' and local_rank is not None:
+            import torch
+            kwargs['device_id'] = torch.device('cuda', int(local_rank))
+        dist.init_process_group(backend=backend, **kwargs)
     return dist
 
 
@@ -69,7 +76,9 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
 
     rank, local_rank, world = env_world()
     backend = os.environ.get('DEEPBINNER_DIST_BACKEND', 'nccl')
-    dist = init_process_group(backend)
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)       # object collectives stage through this device
+    dist = init_process_group(backend, local_rank)
     if not fast5_files:
         sys.exit('Error: no fast5 files found')
     fast5_files = sorted(fast5_files)           # os.walk order may differ between processes

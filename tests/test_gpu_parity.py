@@ -327,6 +327,31 @@ def test_bench_two_ranks_share_one_gpu(hip):
     assert result['scaling'] == 'weak' and 'roofline' in result
 
 
+def test_bench_rccl_path_single_rank(hip):
+    """The RCCL code path of bench.py (device-bound process group, all_gather_into_tensor of the
+    calls on the GPU, MAX-over-ranks, destroy) forced on with ONE rank under torchrun - what the
+    N = 2/4/8 runs execute, minus the peers."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DEEPBINNER_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    result = json.loads(lines[0])
+    assert result['n_gpus'] == 1 and result['value'] > 0 and 'roofline' in result
+    assert result['cpu_baseline']['calls_match_gpu'] is True
+
+
 def test_cli_classify_two_ranks_share_one_gpu(hip):
     """The real CLI under torchrun with 2 ranks on this box's single GPU (gather over gloo):
     rank 0 prints every read once with the reference's expected calls."""
