@@ -18,7 +18,8 @@ import sys
 import numpy as np
 
 from . import hdf5_lite
-from .load_fast5s import find_all_fast5s, get_read_id_and_signal, determine_single_or_multi_fast5s
+from .load_fast5s import (find_all_fast5s, get_read_id_and_signal,
+                          determine_single_or_multi_fast5s, LoaderPool, choose_loader_procs)
 from .misc import print_summary_table
 from .model_format import ModelWeights
 from .trim_signal import normalise
@@ -139,10 +140,9 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
         print_output_header(args.verbose, using_read_starts, using_read_ends, output_size)
 
     classifications, read_id_to_fast5_file = {}, {}
-    for fast5_batch in chunker(fast5_files, args.batch_size):
+    for loaded in load_in_batches(fast5_files, args):
         read_ids, signals = [], []
-        for fast5_file in fast5_batch:
-            read_id, signal = get_read_id_and_signal(fast5_file)
+        for fast5_file, read_id, signal in loaded:
             if signal is None:
                 continue
             read_id_to_fast5_file[read_id] = fast5_file
@@ -163,6 +163,29 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
         if summary_table:
             print_summary_table(classifications)
     return classifications, read_id_to_fast5_file
+
+
+def load_in_batches(fast5_files, args):
+    """The reference's ``for fast5_batch in chunker(...)`` + per-file load (classify.py:141-150):
+    yields, per batch of ``args.batch_size`` files, the list of (fast5_file, read_id, signal).
+    With more than one loader process (``--loader_procs``, or automatically for big jobs) the
+    files of later batches are loaded while the caller classifies the current one."""
+    procs = choose_loader_procs(getattr(args, 'loader_procs', None), len(fast5_files))
+    if procs <= 1:
+        for fast5_batch in chunker(fast5_files, args.batch_size):
+            yield [(f,) + tuple(get_read_id_and_signal(f)) for f in fast5_batch]
+        return
+    # only the scanned ends of a read matter to call_batch: spare the result pipe the middle
+    keep = int(args.scan_size) + 512
+    with LoaderPool(procs) as pool:
+        batch = []
+        for item in pool.load(list(fast5_files), keep):
+            batch.append(item)
+            if len(batch) == args.batch_size:
+                yield batch
+                batch = []
+        if batch:
+            yield batch
 
 
 def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,

@@ -58,6 +58,82 @@ def iter_reads(fast5_file):
         return
 
 
+def keep_ends(signal, keep):
+    """``signal`` if it is at most 2*keep samples long, else its first and last ``keep`` samples
+    joined.  Windows are cut from the first (start model) or last (end model) scan_size + half a
+    window samples only (reference classify.py:337-349), so with keep >= that the joined array
+    classifies exactly like the whole read."""
+    if keep is None or signal is None or len(signal) <= 2 * keep:
+        return signal
+    import numpy as np
+    return np.concatenate((signal[:keep], signal[-keep:]))
+
+
+def _load_files(paths, keep=None):
+    """Worker of LoaderPool: [(read_id, signal)] for a run of one-read files."""
+    out = []
+    for path in paths:
+        read_id, signal = get_read_id_and_signal(path)
+        out.append((read_id, keep_ends(signal, keep)))
+    return out
+
+
+class LoaderPool:
+    """Ordered, prefetching pool of loader processes for one-read fast5 files.
+
+    The reference loads its files one by one on the thread that also drives the model
+    (classify.py:141-150); with the network on the GPU that loop is the bottleneck (~1 ms per
+    file here against ~3 us per read on the device), so the files of the coming batches are
+    parsed and inflated by ``procs`` worker processes while the current batch is classified.
+    Results come back in file order; at most ``ahead`` runs of ``run`` files are in flight, so
+    memory stays bounded however far the loaders could get ahead.  Workers are spawned, not
+    forked: the parent may already hold a HIP context."""
+
+    def __init__(self, procs, run=8, ahead=None):
+        import multiprocessing
+        self.procs = int(procs)
+        self.run = int(run)
+        self.ahead = int(ahead) if ahead else 4 * self.procs
+        self._pool = multiprocessing.get_context('spawn').Pool(self.procs)
+
+    def load(self, fast5_files, keep=None):
+        """Yield (fast5_file, read_id, signal) for every file, in order.  ``keep``: ship only the
+        first and last ``keep`` samples of longer reads (see keep_ends) - the pipe back from the
+        workers is what limits this pool."""
+        from collections import deque
+        runs = [fast5_files[i:i + self.run] for i in range(0, len(fast5_files), self.run)]
+        pending, submitted = deque(), 0
+        while pending or submitted < len(runs):
+            while submitted < len(runs) and len(pending) < self.ahead:
+                pending.append((runs[submitted],
+                                self._pool.apply_async(_load_files, (runs[submitted], keep))))
+                submitted += 1
+            paths, job = pending.popleft()
+            for path, (read_id, signal) in zip(paths, job.get()):
+                yield path, read_id, signal
+
+    def close(self):
+        self._pool.terminate()
+        self._pool.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def choose_loader_procs(requested, n_files):
+    """Number of loader processes: the ``--loader_procs`` request, or by default up to 8 (more
+    only queue behind the parent's end of the result pipe: tools/loader_rate.py) once a job is
+    big enough to repay starting them (>= 512 files)."""
+    if requested is not None and int(requested) > 0:
+        return int(requested)
+    if n_files < 512:
+        return 1
+    return max(1, min(8, (os.cpu_count() or 2) // 2))
+
+
 def find_all_fast5s(directory, verbose=False):
     if verbose:
         print('Looking for fast5 files in {}... '.format(directory), file=sys.stderr, end='',

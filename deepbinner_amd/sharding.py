@@ -71,7 +71,7 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
     import numpy as np
     import torch
     from . import classify as c
-    from .load_fast5s import get_read_id_and_signal, determine_single_or_multi_fast5s
+    from .load_fast5s import determine_single_or_multi_fast5s
     from .misc import print_summary_table
 
     rank, local_rank, world = env_world()
@@ -93,10 +93,9 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
         c.print_output_header(args.verbose, start_model is not None, end_model is not None,
                               output_size)
     classifications, id_to_file, lines = {}, {}, []
-    for batch in c.chunker(mine, args.batch_size):
+    for loaded in c.load_in_batches(mine, args):
         read_ids, signals = [], []
-        for fast5_file in batch:
-            read_id, signal = get_read_id_and_signal(fast5_file)
+        for fast5_file, read_id, signal in loaded:
             if signal is None:
                 continue
             id_to_file[read_id] = fast5_file

@@ -257,6 +257,37 @@ def test_missing_fast5():
         == (None, None)
 
 
+def test_loader_pool_matches_serial_loader():
+    """LoaderPool: same (read_id, signal) as the serial loader, in file order, unreadable files
+    reported as (None, None), with more runs than the in-flight window allows at once."""
+    files = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
+    files = (files + [os.path.join(FAST5_DIR, 'not_a_real_file.fast5')]) * 4
+    want = [load_fast5s.get_read_id_and_signal(f) for f in files]
+    with load_fast5s.LoaderPool(2, run=3, ahead=2) as pool:
+        got = list(pool.load(files))
+    assert [g[0] for g in got] == files
+    for (path, read_id, signal), (want_id, want_signal) in zip(got, want):
+        assert read_id == want_id
+        assert (signal is None and want_signal is None) or np.array_equal(signal, want_signal)
+    assert load_fast5s.choose_loader_procs(None, 7) == 1
+    assert load_fast5s.choose_loader_procs(0, 100000) >= 1
+    assert load_fast5s.choose_loader_procs(5, 7) == 5
+
+
+def test_classification_with_loader_processes(oracle_backend, capsys):
+    """classify_fast5_files gives the same calls, ids and output with --loader_procs 2."""
+    fast5s = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
+    sm, si, em, ei, osz, _ = classify.load_and_check_models(START_MODEL, None, 6144,
+                                                            out_dest=io.StringIO())
+    outs = []
+    for procs in (1, 2):
+        args = make_args(loader_procs=procs, batch_size=3)
+        result = classify.classify_fast5_files(fast5s, sm, si, em, ei, osz, args)
+        outs.append((result, capsys.readouterr().out))
+    assert outs[0] == outs[1]
+    assert outs[0][0][0] == EXPECTED_START
+
+
 def test_single_or_multi():
     single = load_fast5s.find_all_fast5s(FAST5_DIR)
     multi = load_fast5s.find_all_fast5s(MULTI_DIR)

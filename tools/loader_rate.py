@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""The real-file path end to end: `deepbinner classify` over a directory of one-read fast5 files
+(the seven reads the reference's tests ship, replicated as symlinks), start + end models, default
+geometry (scan_size 6144, batch 256) - how fast the host loader feeds the GPU.
+  1. loader alone: serial (the reference's loop) and LoaderPool at several process counts;
+  2. classify_fast5_files on the HIP backend with the same loader settings.
+Usage: python tools/loader_rate.py [n_files]"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from deepbinner_amd import classify, load_fast5s             # noqa: E402
+
+FAST5_DIR = os.path.join(REPO, 'tests', 'golden', 'fast5', 'single')
+MODELS = os.path.join(REPO, 'deepbinner_amd', 'models')
+
+
+def main():
+    n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    sources = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
+    out = {'files': n_files, 'host_threads': os.cpu_count()}
+    with tempfile.TemporaryDirectory() as tmp:
+        files = []
+        for i in range(n_files):
+            dst = os.path.join(tmp, 'read_%06d.fast5' % i)
+            os.symlink(sources[i % len(sources)], dst)
+            files.append(dst)
+
+        t0 = time.perf_counter()
+        samples = 0
+        for f in files[:1024]:
+            samples += len(load_fast5s.get_read_id_and_signal(f)[1])
+        dt = time.perf_counter() - t0
+        out['loader serial (1,024 files)'] = {'reads_per_s': round(1024 / dt),
+                                              'mean_samples_per_read': samples // 1024}
+        for procs in (4, 8, 16, 32):
+            if procs > (os.cpu_count() or 1):
+                continue
+            with load_fast5s.LoaderPool(procs) as pool:
+                list(pool.load(files[:256]))            # workers started and warm
+                rates = {}
+                for label, keep in (('whole reads', None), ('scanned ends only', 6656)):
+                    t0 = time.perf_counter()
+                    n = sum(1 for _ in pool.load(files, keep))
+                    rates[label] = round(n / (time.perf_counter() - t0))
+            out['loader pool, %d processes' % procs] = {'reads_per_s': rates}
+
+        sm, si, em, ei, osz, _ = classify.load_and_check_models(
+            os.path.join(MODELS, 'EXP-NBD103_read_starts.dbw'),
+            os.path.join(MODELS, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
+        for procs in (1, 8):
+            if procs > (os.cpu_count() or 1):
+                continue
+            args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144,
+                                      score_diff=0.5, require_either=True, require_start=False,
+                                      require_both=False, loader_procs=procs)
+            subset = files if procs > 1 else files[:1024]
+            sink = io.StringIO()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(io.StringIO()):
+                calls, _ = classify.classify_fast5_files(subset, sm, si, em, ei, osz, args,
+                                                         verified_single_read=True)
+            dt = time.perf_counter() - t0
+            out['classify_fast5_files start+end models, loader_procs %d' % procs] = {
+                'files': len(subset), 'seconds': round(dt, 3),
+                'reads_per_s': round(len(subset) / dt), 'distinct_reads': len(calls)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
