@@ -19,7 +19,8 @@ import numpy as np
 
 from . import hdf5_lite
 from .load_fast5s import (find_all_fast5s, get_read_id_and_signal,
-                          determine_single_or_multi_fast5s, LoaderPool, choose_loader_procs)
+                          determine_single_or_multi_fast5s, LoaderPool, choose_loader_procs,
+                          reader_kind)
 from .misc import print_summary_table
 from .model_format import ModelWeights
 from .trim_signal import normalise
@@ -170,6 +171,9 @@ def load_in_batches(fast5_files, args):
     yields, per batch of ``args.batch_size`` files, the list of (fast5_file, read_id, signal).
     With more than one loader process (``--loader_procs``, or automatically for big jobs) the
     files of later batches are loaded while the caller classifies the current one."""
+    if reader_kind() == 'native':
+        yield from _native_batches(fast5_files, args)
+        return
     procs = choose_loader_procs(getattr(args, 'loader_procs', None), len(fast5_files))
     if procs <= 1:
         for fast5_batch in chunker(fast5_files, args.batch_size):
@@ -186,6 +190,31 @@ def load_in_batches(fast5_files, args):
                 batch = []
         if batch:
             yield batch
+
+
+def _native_batches(fast5_files, args):
+    """load_in_batches on the native loader (libdeepbinner_fast5.so): every batch is parsed and
+    inflated by the library's own worker threads (``--loader_procs`` of them; 0 = a quarter of
+    the host threads, at most 32), and the next batch is loaded on a background thread - the
+    call releases the GIL - while the caller classifies the current one."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import fast5_native
+    keep = int(args.scan_size) + 512
+    threads = int(getattr(args, 'loader_procs', 0) or 0) or max(1, min(32, (os.cpu_count() or 4) // 4))
+    batches = list(chunker(fast5_files, args.batch_size))
+
+    def load(batch):
+        return fast5_native.load_batch(batch, keep, threads)
+
+    with ThreadPoolExecutor(max_workers=1) as executor:
+        pending = executor.submit(load, batches[0]) if batches else None
+        for i, batch in enumerate(batches):
+            read_ids, samples, offsets, status = pending.result()
+            pending = executor.submit(load, batches[i + 1]) if i + 1 < len(batches) else None
+            if (status == fast5_native.F5_ERR_MULTI).any():
+                sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
+            yield [(f, read_ids[k], samples[offsets[k]:offsets[k + 1]] if read_ids[k] is not None
+                    else None) for k, f in enumerate(batch)]
 
 
 def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,

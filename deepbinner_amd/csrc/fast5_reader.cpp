@@ -1,0 +1,1019 @@
+// libdeepbinner_fast5.so - native fast5 loader (C ABI: include/deepbinner_fast5.h).
+//
+// The reference reads fast5 files through h5py (deepbinner/load_fast5s.py:19,25-49); this is the
+// slice of the HDF5 file format those files use, restated in C++ from the format specification
+// exactly as deepbinner_amd/hdf5_lite.py restates it in Python (that module stays the readable
+// description and the parity reference for this one: tests/test_fast5_native.py).
+// Host-only: g++ -O2 -shared -fPIC fast5_reader.cpp -lz -pthread.
+#include "../../include/deepbinner_fast5.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t kUndef = ~0ull;
+constexpr int kO = 8, kL = 8;          // only 8-byte offsets / lengths are supported
+constexpr int kMaxDepth = 32;          // B-tree / indirect-block recursion guard
+
+struct FormatError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct Msg {
+    uint32_t type;
+    uint64_t off;
+    uint32_t size;
+};
+
+inline uint64_t pad8(uint64_t n) { return (n + 7) & ~7ull; }
+
+inline int bit_length(uint64_t v) {
+    int n = 0;
+    while (v) {
+        ++n;
+        v >>= 1;
+    }
+    return n;
+}
+
+struct Filter {
+    int id;
+    std::vector<uint32_t> cd;
+};
+
+struct SignalInfo {
+    int64_t n = 0;             // samples
+    int layout = -1;           // 0 compact, 1 contiguous, 2 chunked
+    uint64_t addr = kUndef;    // contiguous data / chunk B-tree
+    uint64_t compact_off = 0, compact_size = 0;
+    int64_t chunk_elems = 0;
+    std::vector<Filter> filters;
+};
+
+struct ReadEntry {
+    uint64_t group_addr = 0;
+    bool resolved = false;
+    std::string read_id;
+    SignalInfo signal;
+};
+
+class Fast5 {
+  public:
+    explicit Fast5(const char* path) {
+        fd_ = ::open(path, O_RDONLY);
+        if (fd_ < 0) throw std::runtime_error("cannot open file");
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || st.st_size <= 0) {
+            ::close(fd_);
+            fd_ = -1;
+            throw std::runtime_error("cannot stat file / file is empty");
+        }
+        len_ = (uint64_t)st.st_size;
+        if (len_ <= kReadWhole) {
+            // one-read files are a few hundred KB: read() them - with many loader threads every
+            // mmap/munmap would queue on the process-wide address-space lock
+            owned_.resize((size_t)len_);
+            uint64_t got = 0;
+            while (got < len_) {
+                const ssize_t k = ::pread(fd_, owned_.data() + got, (size_t)(len_ - got), (off_t)got);
+                if (k <= 0) {
+                    ::close(fd_);
+                    fd_ = -1;
+                    throw std::runtime_error("cannot read file");
+                }
+                got += (uint64_t)k;
+            }
+            ::close(fd_);
+            fd_ = -1;
+            buf_ = owned_.data();
+            return;
+        }
+        void* p = mmap(nullptr, len_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (p == MAP_FAILED) {
+            ::close(fd_);
+            fd_ = -1;
+            throw std::runtime_error("cannot map file");
+        }
+        buf_ = static_cast<const uint8_t*>(p);
+        mapped_ = true;
+    }
+    ~Fast5() {
+        if (mapped_) munmap(const_cast<uint8_t*>(buf_), len_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+    Fast5(const Fast5&) = delete;
+    Fast5& operator=(const Fast5&) = delete;
+
+    // ---- what the C ABI needs ----------------------------------------------------------------
+    void parse() {
+        parse_superblock();
+        find_reads();
+    }
+    int layout() const { return layout_; }
+    int64_t n_reads() const { return (int64_t)reads_.size(); }
+
+    const ReadEntry& read(int64_t index) {
+        if (index < 0 || index >= (int64_t)reads_.size()) throw std::out_of_range("read index");
+        ReadEntry& r = reads_[(size_t)index];
+        if (!r.resolved) {
+            const std::vector<Msg> msgs = object_header(r.group_addr);
+            if (!find_string_attribute(msgs, "read_id", &r.read_id))
+                throw std::out_of_range("read group without read_id");
+            const std::map<std::string, uint64_t> links = group_links(msgs);
+            auto it = links.find("Signal");
+            if (it == links.end()) throw std::out_of_range("read group without Signal");
+            r.signal = signal_info(it->second);
+            r.resolved = true;
+        }
+        return r;
+    }
+
+    void read_signal(const SignalInfo& s, int64_t first, int64_t count, int16_t* out) {
+        if (first < 0 || count < 0 || first + count > s.n) throw std::out_of_range("sample range");
+        if (count == 0) return;
+        if (s.layout == 0) {
+            if ((uint64_t)(first + count) * 2 > s.compact_size) throw FormatError("compact data too short");
+            need(s.compact_off, s.compact_size);
+            std::memcpy(out, buf_ + s.compact_off + first * 2, (size_t)count * 2);
+        } else if (s.layout == 1) {
+            if (s.addr == kUndef) {
+                std::memset(out, 0, (size_t)count * 2);
+                return;
+            }
+            const uint64_t start = base_ + s.addr;
+            need(start, (uint64_t)s.n * 2);
+            std::memcpy(out, buf_ + start + first * 2, (size_t)count * 2);
+        } else {
+            std::memset(out, 0, (size_t)count * 2);
+            if (s.addr == kUndef) return;
+            if (s.chunk_elems <= 0) throw FormatError("bad chunk size");
+            walk_chunks(s, s.addr, first, count, out, 0);
+        }
+    }
+
+  private:
+    static constexpr uint64_t kReadWhole = 8u << 20;   // files up to 8 MiB are read, larger mapped
+    int fd_ = -1;
+    bool mapped_ = false;
+    std::vector<uint8_t> owned_;
+    const uint8_t* buf_ = nullptr;
+    uint64_t len_ = 0;
+    uint64_t base_ = 0, root_addr_ = 0;
+    int layout_ = F5_LAYOUT_NONE;
+    std::vector<ReadEntry> reads_;
+    std::vector<uint8_t> cache_;                 // the chunk decoded last (see walk_chunks)
+    uint64_t cache_addr_ = kUndef, cache_bytes_ = 0;
+
+    // ---- checked access to the mapped file ---------------------------------------------------
+    void need(uint64_t off, uint64_t n) const {
+        if (off > len_ || n > len_ - off) throw FormatError("offset beyond end of file");
+    }
+    uint64_t u(uint64_t off, int size) const {
+        need(off, (uint64_t)size);
+        uint64_t v = 0;
+        for (int i = size - 1; i >= 0; --i) v = (v << 8) | buf_[off + i];
+        return v;
+    }
+    uint8_t b(uint64_t off) const {
+        need(off, 1);
+        return buf_[off];
+    }
+    bool sig(uint64_t off, const char* s4) const {
+        need(off, 4);
+        return std::memcmp(buf_ + off, s4, 4) == 0;
+    }
+    uint64_t file_off(uint64_t addr) const {
+        if (addr > len_ || base_ > len_ - addr) throw FormatError("address beyond end of file");
+        return base_ + addr;
+    }
+
+    // ---- superblock (hdf5_lite._parse_superblock) ---------------------------------------------
+    void parse_superblock() {
+        static const uint8_t kSig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        uint64_t off = 0;
+        while (true) {
+            if (off + 8 > len_) throw FormatError("HDF5 signature not found");
+            if (std::memcmp(buf_ + off, kSig, 8) == 0) break;
+            off = off == 0 ? 512 : off * 2;
+        }
+        const int version = b(off + 8);
+        int O, L;
+        if (version == 0 || version == 1) {
+            O = b(off + 13);
+            L = b(off + 14);
+            if (O != kO || L != kL) throw FormatError("only 8-byte offsets/lengths are supported");
+            uint64_t p = off + 24 + (version == 1 ? 4 : 0);
+            base_ = u(p, kO);
+            p += 4 * kO;
+            root_addr_ = u(p + kO, kO);
+        } else if (version == 2 || version == 3) {
+            O = b(off + 9);
+            L = b(off + 10);
+            if (O != kO || L != kL) throw FormatError("only 8-byte offsets/lengths are supported");
+            base_ = u(off + 12, kO);
+            root_addr_ = u(off + 12 + 3 * kO, kO);
+        } else {
+            throw FormatError("unsupported superblock version");
+        }
+        if (base_ == 0 && off) base_ = off;
+    }
+
+    // ---- object headers (hdf5_lite._read_object_header) ---------------------------------------
+    std::vector<Msg> object_header(uint64_t addr) const {
+        const uint64_t start = file_off(addr);
+        need(start, 16);
+        std::vector<Msg> messages;
+        std::vector<std::pair<uint64_t, uint64_t>> blocks;
+        if (sig(start, "OHDR")) {
+            if (b(start + 4) != 2) throw FormatError("unsupported object header version");
+            const int flags = b(start + 5);
+            uint64_t p = start + 6;
+            if (flags & 0x20) p += 16;
+            if (flags & 0x10) p += 4;
+            const int csize = 1 << (flags & 3);
+            const uint64_t chunk0 = u(p, csize);
+            p += csize;
+            const bool track_order = flags & 0x04;
+            blocks.emplace_back(p, chunk0);
+            for (size_t i = 0; i < blocks.size(); ++i) {
+                if (blocks.size() > 4096) throw FormatError("too many header continuation blocks");
+                uint64_t bp = blocks[i].first;
+                const uint64_t end = bp + blocks[i].second;
+                need(bp, blocks[i].second);
+                while (bp + 4 <= end) {
+                    const uint32_t mtype = b(bp);
+                    const uint32_t msize = (uint32_t)u(bp + 1, 2);
+                    bp += 4 + (track_order ? 2 : 0);
+                    if (mtype == 0x10) {
+                        const uint64_t caddr = u(bp, kO), clen = u(bp + kO, kL);
+                        if (clen < 8) throw FormatError("bad continuation block");
+                        blocks.emplace_back(file_off(caddr) + 4, clen - 8);
+                    } else if (mtype != 0) {
+                        messages.push_back(Msg{mtype, bp, msize});
+                    }
+                    bp += msize;
+                }
+            }
+            return messages;
+        }
+        if (b(start) != 1) throw FormatError("unsupported object header version");
+        const uint64_t nmsgs = u(start + 2, 2);
+        const uint64_t hsize = u(start + 8, 4);
+        blocks.emplace_back(start + 16, hsize);
+        uint64_t seen = 0;
+        for (size_t i = 0; i < blocks.size() && seen < nmsgs; ++i) {
+            uint64_t bp = blocks[i].first;
+            const uint64_t end = bp + blocks[i].second;
+            need(bp, blocks[i].second);
+            while (bp + 8 <= end && seen < nmsgs) {
+                const uint32_t mtype = (uint32_t)u(bp, 2);
+                const uint32_t msize = (uint32_t)u(bp + 2, 2);
+                bp += 8;
+                ++seen;
+                if (mtype == 0x0010) {
+                    const uint64_t caddr = u(bp, kO), clen = u(bp + kO, kL);
+                    blocks.emplace_back(file_off(caddr), clen);
+                } else if (mtype != 0) {
+                    messages.push_back(Msg{mtype, bp, msize});
+                }
+                bp += msize;
+            }
+        }
+        return messages;
+    }
+
+    static const Msg* first_of(const std::vector<Msg>& msgs, uint32_t type) {
+        for (const Msg& m : msgs)
+            if (m.type == type) return &m;
+        return nullptr;
+    }
+
+    // ---- groups (hdf5_lite.Group._load_links) --------------------------------------------------
+    std::string cstring(uint64_t off) const {
+        need(off, 1);
+        const void* end = std::memchr(buf_ + off, 0, (size_t)(len_ - off));
+        if (!end) throw FormatError("unterminated string");
+        return std::string(reinterpret_cast<const char*>(buf_ + off),
+                           (size_t)(static_cast<const uint8_t*>(end) - (buf_ + off)));
+    }
+
+    void walk_group_btree(uint64_t addr, uint64_t heap_data, std::map<std::string, uint64_t>* links,
+                          int depth) const {
+        if (depth > kMaxDepth) throw FormatError("group B-tree too deep");
+        const uint64_t p = file_off(addr);
+        if (!sig(p, "TREE")) throw FormatError("bad group B-tree signature");
+        const int level = b(p + 5);
+        const uint64_t used = u(p + 6, 2);
+        const uint64_t q = p + 8 + 2 * kO;
+        for (uint64_t i = 0; i < used; ++i) {
+            const uint64_t child = u(q + kL + i * (kL + kO), kO);
+            if (level > 0) {
+                walk_group_btree(child, heap_data, links, depth + 1);
+            } else {
+                const uint64_t s = file_off(child);
+                if (!sig(s, "SNOD")) throw FormatError("bad symbol table node signature");
+                const uint64_t nsym = u(s + 6, 2);
+                uint64_t e = s + 8;
+                for (uint64_t k = 0; k < nsym; ++k) {
+                    const uint64_t name_off = u(e, kO), ohdr = u(e + kO, kO);
+                    (*links)[cstring(heap_data + name_off)] = ohdr;
+                    e += 2 * kO + 24;
+                }
+            }
+        }
+    }
+
+    // link message -> (name, object header address); false for soft/external links
+    bool parse_link(uint64_t off, std::string* name, uint64_t* addr) const {
+        if (b(off) != 1) throw FormatError("bad link message version");
+        const int flags = b(off + 1);
+        uint64_t p = off + 2;
+        int ltype = 0;
+        if (flags & 0x08) ltype = b(p++);
+        if (flags & 0x04) p += 8;
+        if (flags & 0x10) p += 1;
+        const int lsize = 1 << (flags & 3);
+        const uint64_t nlen = u(p, lsize);
+        p += lsize;
+        need(p, nlen);
+        name->assign(reinterpret_cast<const char*>(buf_ + p), (size_t)nlen);
+        p += nlen;
+        if (ltype != 0) return false;
+        *addr = u(p, kO);
+        return true;
+    }
+
+    std::map<std::string, uint64_t> group_links(const std::vector<Msg>& msgs) const {
+        std::map<std::string, uint64_t> links;
+        if (const Msg* stab = first_of(msgs, 0x0011)) {
+            const uint64_t btree = u(stab->off, kO), heap = u(stab->off + kO, kO);
+            const uint64_t hp = file_off(heap);
+            if (!sig(hp, "HEAP")) throw FormatError("bad local heap signature");
+            const uint64_t heap_data = file_off(u(hp + 8 + 2 * kL, kO));
+            walk_group_btree(btree, heap_data, &links, 0);
+        }
+        for (const Msg& m : msgs) {
+            if (m.type != 0x0006) continue;
+            std::string name;
+            uint64_t addr;
+            if (parse_link(m.off, &name, &addr)) links[name] = addr;
+        }
+        if (const Msg* linfo = first_of(msgs, 0x0002)) {
+            const int flags = b(linfo->off + 1);
+            const uint64_t p = linfo->off + 2 + ((flags & 1) ? 8 : 0);
+            const uint64_t heap_addr = u(p, kO), index_addr = u(p + kO, kO);
+            if (heap_addr != kUndef && index_addr != kUndef) {
+                for (uint64_t obj_off : dense_objects(heap_addr, index_addr)) {
+                    std::string name;
+                    uint64_t addr;
+                    if (parse_link(obj_off, &name, &addr)) links[name] = addr;
+                }
+            }
+        }
+        return links;
+    }
+
+    // ---- fractal heap + v2 B-tree (dense link / attribute storage) ----------------------------
+    struct FractalHeap {
+        uint64_t id_len = 0, max_managed = 0, width = 0, start_size = 0, max_direct = 0;
+        uint64_t root_addr = kUndef, cur_rows = 0;
+        int off_bytes = 0, max_direct_rows = 2;
+    };
+
+    FractalHeap fractal_heap(uint64_t addr) const {
+        FractalHeap h;
+        const uint64_t p = file_off(addr);
+        if (!sig(p, "FRHP")) throw FormatError("bad fractal heap signature");
+        h.id_len = u(p + 5, 2);
+        if (u(p + 7, 2)) throw FormatError("filtered fractal heaps are not supported");
+        h.max_managed = u(p + 10, 4);
+        const uint64_t q = p + 14 + kL + kO + kL + kO + 8 * kL;
+        h.width = u(q, 2);
+        h.start_size = u(q + 2, kL);
+        h.max_direct = u(q + 2 + kL, kL);
+        const uint64_t max_heap_bits = u(q + 2 + 2 * kL, 2);
+        h.root_addr = u(q + 6 + 2 * kL, kO);
+        h.cur_rows = u(q + 6 + 2 * kL + kO, 2);
+        h.off_bytes = (int)((max_heap_bits + 7) / 8);
+        if (h.width == 0 || h.start_size == 0 || h.off_bytes > 8) throw FormatError("bad fractal heap");
+        uint64_t size = h.start_size;
+        while (size < h.max_direct && h.max_direct_rows < 64) {
+            size <<= 1;
+            ++h.max_direct_rows;
+        }
+        return h;
+    }
+
+    uint64_t heap_locate(const FractalHeap& h, uint64_t offset) const {
+        if (h.root_addr == kUndef) throw FormatError("empty fractal heap");
+        if (h.cur_rows == 0) return file_off(h.root_addr) + offset;
+        uint64_t iaddr = h.root_addr, rel = offset;
+        for (int depth = 0; depth < kMaxDepth; ++depth) {
+            const uint64_t blk = file_off(iaddr);
+            if (!sig(blk, "FHIB")) throw FormatError("bad fractal heap indirect block signature");
+            const uint64_t first = h.width * h.start_size;
+            const int row = rel < first ? 0 : bit_length(rel / first);
+            if (row > 62) throw FormatError("bad fractal heap offset");
+            const uint64_t row_start = row == 0 ? 0 : (h.width * h.start_size) << (row - 1);
+            const uint64_t bsize = row == 0 ? h.start_size : h.start_size << (row - 1);
+            const uint64_t col = (rel - row_start) / bsize;
+            const uint64_t entry = blk + 5 + kO + h.off_bytes + ((uint64_t)row * h.width + col) * kO;
+            const uint64_t child = u(entry, kO);
+            if (child == kUndef) throw FormatError("heap object in an unallocated block");
+            rel -= row_start + col * bsize;
+            if (row < h.max_direct_rows) return file_off(child) + rel;
+            iaddr = child;
+        }
+        throw FormatError("fractal heap too deep");
+    }
+
+    static int enc_size(uint64_t limit) { return (bit_length(std::max<uint64_t>(limit, 1)) - 1) / 8 + 1; }
+
+    void btree2_walk(uint64_t naddr, uint64_t nrec, int d, uint64_t rec_size, int nrec_size,
+                     const std::vector<int>& cum_size, std::vector<uint64_t>* records,
+                     int depth) const {
+        if (depth > kMaxDepth) throw FormatError("v2 B-tree too deep");
+        const uint64_t blk = file_off(naddr);
+        if (d == 0) {
+            if (!sig(blk, "BTLF")) throw FormatError("bad v2 B-tree leaf signature");
+            for (uint64_t i = 0; i < nrec; ++i) {
+                need(blk + 6 + i * rec_size, rec_size);
+                records->push_back(blk + 6 + i * rec_size);
+            }
+            return;
+        }
+        if (!sig(blk, "BTIN")) throw FormatError("bad v2 B-tree internal node signature");
+        const uint64_t recs = blk + 6;
+        const uint64_t ptrs = recs + nrec * rec_size;
+        const uint64_t ptr = kO + nrec_size + (d > 1 ? cum_size[(size_t)d - 1] : 0);
+        for (uint64_t i = 0; i <= nrec; ++i) {
+            const uint64_t e = ptrs + i * ptr;
+            const uint64_t child = u(e, kO);
+            const uint64_t child_nrec = u(e + kO, nrec_size);
+            btree2_walk(child, child_nrec, d - 1, rec_size, nrec_size, cum_size, records, depth + 1);
+            if (i < nrec) {
+                need(recs + i * rec_size, rec_size);
+                records->push_back(recs + i * rec_size);
+            }
+        }
+    }
+
+    // file offsets of the raw records of a version-2 B-tree, in key order
+    std::vector<uint64_t> btree2_records(uint64_t addr, uint64_t* rec_size_out, int* type_out) const {
+        std::vector<uint64_t> records;
+        const uint64_t p = file_off(addr);
+        if (!sig(p, "BTHD")) throw FormatError("bad v2 B-tree signature");
+        *type_out = b(p + 5);
+        const uint64_t node_size = u(p + 6, 4);
+        const uint64_t rec_size = u(p + 10, 2);
+        const int depth = (int)u(p + 12, 2);
+        const uint64_t root = u(p + 16, kO);
+        const uint64_t root_nrec = u(p + 16 + kO, 2);
+        *rec_size_out = rec_size;
+        if (root == kUndef || root_nrec == 0) return records;
+        if (rec_size == 0 || node_size < 16 || depth > kMaxDepth) throw FormatError("bad v2 B-tree header");
+        std::vector<uint64_t> cum_max;
+        std::vector<int> cum_size;
+        const uint64_t max0 = (node_size - 10) / rec_size;
+        cum_max.push_back(max0);
+        const int nrec_size = enc_size(max0);
+        cum_size.push_back(enc_size(max0));
+        for (int d = 1; d <= depth; ++d) {
+            const uint64_t ptr = kO + nrec_size + (d > 1 ? cum_size[(size_t)d - 1] : 0);
+            const uint64_t m = (node_size - (10 + ptr)) / (rec_size + ptr);
+            cum_max.push_back((m + 1) * cum_max[(size_t)d - 1] + m);
+            cum_size.push_back(enc_size(cum_max[(size_t)d]));
+        }
+        btree2_walk(root, root_nrec, depth, rec_size, nrec_size, cum_size, &records, 0);
+        return records;
+    }
+
+    // file offsets of the messages held in dense (fractal heap + v2 B-tree) storage
+    std::vector<uint64_t> dense_objects(uint64_t heap_addr, uint64_t index_addr) const {
+        const FractalHeap heap = fractal_heap(heap_addr);
+        uint64_t rec_size = 0;
+        int btype = 0;
+        std::vector<uint64_t> out;
+        for (uint64_t rec : btree2_records(index_addr, &rec_size, &btype)) {
+            // type 5 (link name) record: hash(4) + heap id; type 8 (attribute name): heap id first
+            const uint64_t id = btype == 5 ? rec + 4 : rec;
+            if ((btype == 5 ? 4 : 0) + heap.id_len > rec_size) throw FormatError("bad dense record");
+            if (((b(id) >> 4) & 3) != 0) throw FormatError("only managed fractal-heap objects are supported");
+            out.push_back(heap_locate(heap, u(id + 1, heap.off_bytes)));
+        }
+        return out;
+    }
+
+    // ---- attributes: only string values are needed (read_id) -----------------------------------
+    std::string global_heap_object(uint64_t coll_addr, uint64_t index) const {
+        const uint64_t p = file_off(coll_addr);
+        if (!sig(p, "GCOL")) throw FormatError("bad global heap signature");
+        const uint64_t size = u(p + 8, kL);
+        uint64_t o = p + 8 + kL;
+        const uint64_t end = p + size;
+        while (o + 8 + kL <= end) {
+            const uint64_t idx = u(o, 2);
+            const uint64_t osize = u(o + 8, kL);
+            if (idx == 0) break;
+            if (idx == index) {
+                need(o + 8 + kL, osize);
+                return std::string(reinterpret_cast<const char*>(buf_ + o + 8 + kL), (size_t)osize);
+            }
+            o += 8 + kL + pad8(osize);
+        }
+        throw FormatError("global heap object not found");
+    }
+
+    // attribute message at `off`: its name; if it is a scalar string, its value
+    bool parse_string_attribute(uint64_t off, std::string* name, std::string* value) const {
+        const int version = b(off);
+        const uint64_t nsz = u(off + 2, 2), tsz = u(off + 4, 2), ssz = u(off + 6, 2);
+        uint64_t p = off + 8;
+        if (version == 3)
+            p += 1;
+        else if (version != 1 && version != 2)
+            throw FormatError("unsupported attribute version");
+        const bool padded = version == 1;
+        need(p, nsz);
+        name->assign(reinterpret_cast<const char*>(buf_ + p), (size_t)nsz);
+        name->resize(std::strlen(name->c_str()));
+        p += padded ? pad8(nsz) : nsz;
+        const uint64_t dt_off = p;
+        p += padded ? pad8(tsz) : tsz;
+        const uint64_t ds_off = p;
+        p += padded ? pad8(ssz) : ssz;
+        // dataspace: scalar or a single element
+        const int ds_version = b(ds_off), rank = b(ds_off + 1);
+        if (ds_version != 1 && ds_version != 2) return false;
+        uint64_t count = 1;
+        const uint64_t dims = ds_off + (ds_version == 1 ? 8 : 4);
+        for (int i = 0; i < rank; ++i) count *= u(dims + (uint64_t)i * kL, kL);
+        if (count != 1) return false;
+        const int cls = b(dt_off) & 0x0F;
+        const uint64_t bits = u(dt_off + 1, 3);
+        const uint64_t size = u(dt_off + 4, 4);
+        if (cls == 3) {            // fixed-length string, NUL padding stripped like h5py does
+            need(p, size);
+            value->assign(reinterpret_cast<const char*>(buf_ + p), (size_t)size);
+            value->resize(std::strlen(value->c_str()));
+            return true;
+        }
+        if (cls == 9 && (bits & 0x0F) == 1) {   // variable-length string in the global heap
+            const uint64_t coll = u(p + 4, kO), idx = u(p + 4 + kO, 4);
+            *value = coll ? global_heap_object(coll, idx) : std::string();
+            return true;
+        }
+        return false;
+    }
+
+    bool find_string_attribute(const std::vector<Msg>& msgs, const char* wanted,
+                               std::string* value) const {
+        std::string name, v;
+        for (const Msg& m : msgs) {
+            if (m.type == 0x000C) {
+                if (parse_string_attribute(m.off, &name, &v) && name == wanted) {
+                    *value = v;
+                    return true;
+                }
+            } else if (m.type == 0x0015) {   // dense attribute storage
+                const int flags = b(m.off + 1);
+                const uint64_t p = m.off + 2 + ((flags & 1) ? 2 : 0);
+                const uint64_t heap_addr = u(p, kO), index_addr = u(p + kO, kO);
+                if (heap_addr == kUndef || index_addr == kUndef) continue;
+                for (uint64_t obj_off : dense_objects(heap_addr, index_addr))
+                    if (parse_string_attribute(obj_off, &name, &v) && name == wanted) {
+                        *value = v;
+                        return true;
+                    }
+            }
+        }
+        return false;
+    }
+
+    // ---- the Signal dataset ---------------------------------------------------------------------
+    SignalInfo signal_info(uint64_t addr) const {
+        const std::vector<Msg> msgs = object_header(addr);
+        const Msg* dt = first_of(msgs, 0x0003);
+        const Msg* ds = first_of(msgs, 0x0001);
+        const Msg* lay = first_of(msgs, 0x0008);
+        if (!dt || !ds || !lay) throw FormatError("Signal without datatype/dataspace/layout");
+        const int cls = b(dt->off) & 0x0F;
+        const uint64_t bits = u(dt->off + 1, 3);
+        if (cls != 0 || u(dt->off + 4, 4) != 2 || (bits & 1) || !(bits & 0x08))
+            throw FormatError("Signal is not a little-endian int16 dataset");
+        const int ds_version = b(ds->off), rank = b(ds->off + 1);
+        if ((ds_version != 1 && ds_version != 2) || rank != 1)
+            throw FormatError("Signal is not one-dimensional");
+        SignalInfo s;
+        const uint64_t n = u(ds->off + (ds_version == 1 ? 8 : 4), kL);
+        if (n > (1ull << 40)) throw FormatError("implausible Signal length");
+        s.n = (int64_t)n;
+
+        const int version = b(lay->off);
+        if (version == 1 || version == 2) {
+            const int ndim = b(lay->off + 1), lcls = b(lay->off + 2);
+            uint64_t p = lay->off + 8;
+            if (lcls != 0) {
+                s.addr = u(p, kO);
+                p += kO;
+            }
+            const uint64_t dims = p;
+            p += 4ull * ndim;
+            if (lcls == 0) {
+                s.layout = 0;
+                s.compact_size = u(p, 4);
+                s.compact_off = p + 4;
+            } else if (lcls == 1) {
+                s.layout = 1;
+            } else {
+                if (ndim != 2) throw FormatError("unexpected chunk rank");
+                s.layout = 2;
+                s.chunk_elems = (int64_t)u(dims, 4);
+            }
+        } else if (version == 3) {
+            const int lcls = b(lay->off + 1);
+            const uint64_t p = lay->off + 2;
+            if (lcls == 0) {
+                s.layout = 0;
+                s.compact_size = u(p, 2);
+                s.compact_off = p + 2;
+            } else if (lcls == 1) {
+                s.layout = 1;
+                s.addr = u(p, kO);
+            } else if (lcls == 2) {
+                if (b(p) != 2) throw FormatError("unexpected chunk rank");
+                s.layout = 2;
+                s.addr = u(p + 1, kO);
+                s.chunk_elems = (int64_t)u(p + 1 + kO, 4);
+            } else {
+                throw FormatError("unsupported data layout class");
+            }
+        } else {
+            throw FormatError("unsupported data layout version");
+        }
+
+        if (const Msg* fm = first_of(msgs, 0x000B)) {
+            const int fversion = b(fm->off), nf = b(fm->off + 1);
+            uint64_t p = fm->off + (fversion == 1 ? 8 : 2);
+            for (int i = 0; i < nf; ++i) {
+                Filter f;
+                f.id = (int)u(p, 2);
+                p += 2;
+                uint64_t name_len = 0;
+                if (fversion == 1 || f.id >= 256) {
+                    name_len = u(p, 2);
+                    p += 2;
+                }
+                p += 2;   // flags
+                const uint64_t ncd = u(p, 2);
+                p += 2;
+                p += fversion == 1 ? pad8(name_len) : name_len;
+                for (uint64_t k = 0; k < ncd; ++k) f.cd.push_back((uint32_t)u(p + 4 * k, 4));
+                p += 4 * ncd;
+                if (fversion == 1 && (ncd % 2) == 1) p += 4;
+                s.filters.push_back(f);
+            }
+        }
+        return s;
+    }
+
+    static void inflate_all(const uint8_t* src, size_t src_len, size_t hint,
+                            std::vector<uint8_t>* out) {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) throw FormatError("zlib init failed");
+        out->resize(std::max<size_t>(hint, 64));
+        zs.next_in = const_cast<Bytef*>(src);
+        zs.avail_in = (uInt)src_len;
+        size_t produced = 0;
+        while (true) {
+            zs.next_out = out->data() + produced;
+            zs.avail_out = (uInt)(out->size() - produced);
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            produced = out->size() - zs.avail_out;
+            if (rc == Z_STREAM_END) break;
+            if (rc != Z_OK || (zs.avail_in == 0 && zs.avail_out != 0)) {
+                inflateEnd(&zs);
+                throw FormatError("corrupt deflate stream");
+            }
+            if (zs.avail_out == 0) {
+                if (out->size() > (1u << 30)) {
+                    inflateEnd(&zs);
+                    throw FormatError("chunk inflates to an implausible size");
+                }
+                out->resize(out->size() * 2);
+            }
+        }
+        inflateEnd(&zs);
+        out->resize(produced);
+    }
+
+    // one stored chunk -> its elements (filters undone in reverse order, short chunks zero-extended)
+    void decode_chunk(const SignalInfo& s, uint64_t addr, uint64_t nbytes, uint32_t mask,
+                      std::vector<uint8_t>* raw) const {
+        const uint64_t start = file_off(addr);
+        need(start, nbytes);
+        raw->assign(buf_ + start, buf_ + start + nbytes);
+        std::vector<uint8_t> tmp;
+        for (int i = (int)s.filters.size() - 1; i >= 0; --i) {
+            if (mask & (1u << i)) continue;
+            const Filter& f = s.filters[(size_t)i];
+            if (f.id == 1) {
+                inflate_all(raw->data(), raw->size(), (size_t)s.chunk_elems * 2 + 8, &tmp);
+                raw->swap(tmp);
+            } else if (f.id == 2) {
+                const size_t esize = f.cd.empty() ? 2 : f.cd[0];
+                if (esize == 0) throw FormatError("bad shuffle parameter");
+                const size_t n = raw->size() / esize;
+                tmp.assign(raw->begin(), raw->end());
+                for (size_t e = 0; e < esize; ++e)
+                    for (size_t k = 0; k < n; ++k) tmp[k * esize + e] = (*raw)[e * n + k];
+                raw->swap(tmp);
+            } else if (f.id == 3) {
+                if (raw->size() < 4) throw FormatError("chunk shorter than its checksum");
+                raw->resize(raw->size() - 4);
+            } else {
+                throw FormatError("unsupported filter");
+            }
+        }
+        // some writers (MinKNOW) store a short final chunk; libhdf5 zero-extends it
+        if (raw->size() < (size_t)s.chunk_elems * 2) raw->resize((size_t)s.chunk_elems * 2, 0);
+    }
+
+    // chunk index: version-1 B-tree of raw-data chunks, rank 1 (hdf5_lite._walk_chunk_btree)
+    void walk_chunks(const SignalInfo& s, uint64_t addr, int64_t first, int64_t count, int16_t* out,
+                     int depth) {
+        if (depth > kMaxDepth) throw FormatError("chunk B-tree too deep");
+        const uint64_t p = file_off(addr);
+        if (!sig(p, "TREE")) throw FormatError("bad chunk B-tree signature");
+        if (b(p + 4) != 1) throw FormatError("expected a raw-data chunk B-tree");
+        const int level = b(p + 5);
+        const uint64_t used = u(p + 6, 2);
+        const uint64_t key_size = 8 + 8 * 2;
+        const uint64_t q = p + 8 + 2 * kO;
+        for (uint64_t i = 0; i < used; ++i) {
+            const uint64_t k = q + i * (key_size + kO);
+            const uint64_t nbytes = u(k, 4);
+            const uint32_t mask = (uint32_t)u(k + 4, 4);
+            const uint64_t offset = u(k + 8, 8);
+            const uint64_t child = u(k + key_size, kO);
+            if (level > 0) {
+                // keys are the first chunk offsets of the children: skip subtrees wholly outside
+                if (i + 1 < used) {
+                    const uint64_t next = u(q + (i + 1) * (key_size + kO) + 8, 8);
+                    if ((int64_t)next <= first) continue;
+                }
+                if ((int64_t)offset >= first + count) break;
+                walk_chunks(s, child, first, count, out, depth + 1);
+                continue;
+            }
+            if (offset >= (uint64_t)s.n) continue;
+            const int64_t lo = (int64_t)offset;
+            const int64_t hi = std::min<int64_t>(lo + s.chunk_elems, s.n);
+            const int64_t a = std::max(lo, first), z = std::min(hi, first + count);
+            if (a >= z) continue;
+            // the last chunk inflated stays around: a read stored as ONE chunk (common) is asked
+            // for twice, once per end, and deflate cannot be entered in the middle
+            if (cache_addr_ != child || cache_bytes_ != nbytes) {
+                decode_chunk(s, child, nbytes, mask, &cache_);
+                cache_addr_ = child;
+                cache_bytes_ = nbytes;
+            }
+            std::memcpy(out + (a - first), cache_.data() + (size_t)(a - lo) * 2, (size_t)(z - a) * 2);
+        }
+    }
+
+    // ---- which reads the file holds (load_fast5s.py:29-43) ---------------------------------------
+    void find_reads() {
+        const std::map<std::string, uint64_t> root = group_links(object_header(root_addr_));
+        auto raw = root.find("Raw");
+        if (raw != root.end()) {   // older format: exactly one read under /Raw/Reads
+            const std::map<std::string, uint64_t> raw_links = group_links(object_header(raw->second));
+            auto reads = raw_links.find("Reads");
+            if (reads == raw_links.end()) throw std::out_of_range("no /Raw/Reads");
+            const std::map<std::string, uint64_t> children = group_links(object_header(reads->second));
+            if (children.empty()) throw std::out_of_range("empty /Raw/Reads");
+            ReadEntry e;
+            e.group_addr = children.begin()->second;
+            reads_.push_back(e);
+            layout_ = F5_LAYOUT_SINGLE_OLD;
+            return;
+        }
+        for (const auto& kv : root) {
+            if (kv.first.compare(0, 5, "read_") != 0) continue;
+            const std::map<std::string, uint64_t> links = group_links(object_header(kv.second));
+            auto r = links.find("Raw");
+            if (r == links.end()) throw std::out_of_range("read group without Raw");
+            ReadEntry e;
+            e.group_addr = r->second;
+            reads_.push_back(e);
+        }
+        layout_ = reads_.empty() ? F5_LAYOUT_NONE
+                                 : (reads_.size() == 1 ? F5_LAYOUT_SINGLE_NEW : F5_LAYOUT_MULTI);
+    }
+};
+
+// Runs fn and maps what it throws to the ABI's status codes.
+template <class Fn>
+int guarded(Fn&& fn) {
+    try {
+        fn();
+        return F5_OK;
+    } catch (const FormatError&) {
+        return F5_ERR_FORMAT;
+    } catch (const std::out_of_range&) {
+        return F5_ERR_NO_READ;
+    } catch (const std::bad_alloc&) {
+        return F5_ERR_FORMAT;
+    } catch (const std::exception&) {
+        return F5_ERR_OPEN;
+    }
+}
+
+void copy_read_id(const std::string& id, char* dst) {
+    std::memset(dst, 0, F5_READ_ID_MAX);
+    std::memcpy(dst, id.data(), std::min<size_t>(id.size(), F5_READ_ID_MAX - 1));
+}
+
+}  // namespace
+
+struct f5_file {
+    Fast5 impl;
+    explicit f5_file(const char* path) : impl(path) {}
+};
+
+struct f5_batch {
+    std::vector<int16_t> samples;
+    std::vector<int64_t> offsets;
+    std::vector<int32_t> status;
+    std::vector<char> read_ids;
+};
+
+extern "C" {
+
+const char* f5_version(void) { return "deepbinner_fast5 0.1"; }
+
+const char* f5_status_string(int status) {
+    switch (status) {
+        case F5_OK: return "ok";
+        case F5_ERR_OPEN: return "cannot open file";
+        case F5_ERR_FORMAT: return "not a readable HDF5/fast5 file";
+        case F5_ERR_NO_READ: return "no such read (or read without read_id / Signal)";
+        case F5_ERR_MULTI: return "multi-read fast5 file";
+        case F5_ERR_ARGUMENT: return "invalid argument";
+        default: return "unknown status";
+    }
+}
+
+int f5_open(const char* path, f5_file** out) {
+    if (!path || !out) return F5_ERR_ARGUMENT;
+    *out = nullptr;
+    f5_file* file = nullptr;
+    const int rc = guarded([&] {
+        file = new f5_file(path);
+        file->impl.parse();
+    });
+    if (rc != F5_OK) {
+        delete file;
+        return rc;
+    }
+    *out = file;
+    return F5_OK;
+}
+
+void f5_close(f5_file* file) { delete file; }
+
+int f5_layout(f5_file* file, int* layout, int64_t* n_reads) {
+    if (!file || !layout || !n_reads) return F5_ERR_ARGUMENT;
+    *layout = file->impl.layout();
+    *n_reads = file->impl.n_reads();
+    return F5_OK;
+}
+
+int f5_read_info(f5_file* file, int64_t index, char read_id[F5_READ_ID_MAX], int64_t* n_samples) {
+    if (!file || !read_id || !n_samples) return F5_ERR_ARGUMENT;
+    return guarded([&] {
+        const ReadEntry& r = file->impl.read(index);
+        copy_read_id(r.read_id, read_id);
+        *n_samples = r.signal.n;
+    });
+}
+
+int f5_read_signal(f5_file* file, int64_t index, int64_t first, int64_t count, int16_t* out) {
+    if (!file || (!out && count > 0)) return F5_ERR_ARGUMENT;
+    return guarded([&] { file->impl.read_signal(file->impl.read(index).signal, first, count, out); });
+}
+
+int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n_threads,
+                  f5_batch** out) {
+    if (!paths || !out || n_files < 0) return F5_ERR_ARGUMENT;
+    *out = nullptr;
+    f5_batch* batch = nullptr;
+    try {
+        batch = new f5_batch;
+        batch->offsets.assign((size_t)n_files + 1, 0);
+        batch->status.assign((size_t)n_files, F5_ERR_OPEN);
+        batch->read_ids.assign((size_t)n_files * F5_READ_ID_MAX, 0);
+        // Two parallel passes: (1) open + parse every file and learn how many samples it will
+        // contribute, (2) after a prefix sum, inflate straight into the packed buffer.
+        std::vector<std::unique_ptr<Fast5>> files((size_t)n_files);
+        std::vector<int64_t> lengths((size_t)n_files, 0);
+
+        auto open_one = [&](int64_t i) {
+            bool multi = false;
+            int rc = paths[i] ? F5_OK : F5_ERR_ARGUMENT;
+            if (rc == F5_OK) rc = guarded([&] {
+                std::unique_ptr<Fast5> file(new Fast5(paths[i]));
+                file->parse();
+                if (file->layout() == F5_LAYOUT_MULTI) {
+                    multi = true;
+                    return;
+                }
+                const ReadEntry& r = file->read(0);
+                const int64_t n = r.signal.n;
+                lengths[(size_t)i] = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
+                files[(size_t)i] = std::move(file);
+            });
+            if (multi) rc = F5_ERR_MULTI;
+            batch->status[(size_t)i] = rc;
+        };
+        auto decode_one = [&](int64_t i) {
+            if (batch->status[(size_t)i] != F5_OK) return;
+            int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
+            const int rc = guarded([&] {
+                Fast5& file = *files[(size_t)i];
+                const ReadEntry& r = file.read(0);
+                const int64_t n = r.signal.n;
+                if (keep > 0 && n > 2 * keep) {
+                    file.read_signal(r.signal, 0, keep, dst);
+                    file.read_signal(r.signal, n - keep, keep, dst + keep);
+                } else {
+                    file.read_signal(r.signal, 0, n, dst);
+                }
+            });
+            files[(size_t)i].reset();
+            batch->status[(size_t)i] = rc;
+        };
+
+        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        threads = std::max(1, std::min(threads, 64));
+        threads = (int)std::min<int64_t>(threads, std::max<int64_t>(n_files, 1));
+        auto run_parallel = [&](const std::function<void(int64_t)>& fn) {
+            std::atomic<int64_t> next(0);
+            auto worker = [&] {
+                for (int64_t i = next.fetch_add(1); i < n_files; i = next.fetch_add(1)) fn(i);
+            };
+            if (threads == 1) {
+                worker();
+                return;
+            }
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+            for (std::thread& t : pool) t.join();
+        };
+
+        run_parallel(open_one);
+        int64_t total = 0;
+        for (int64_t i = 0; i < n_files; ++i) {
+            batch->offsets[(size_t)i] = total;
+            total += lengths[(size_t)i];
+        }
+        batch->offsets[(size_t)n_files] = total;
+        batch->samples.resize((size_t)total);
+        run_parallel(decode_one);
+        // a read whose Signal failed to decode keeps its (zero-filled) slot but loses its id,
+        // exactly like a file that could not be opened: callers skip it by status
+        for (int64_t i = 0; i < n_files; ++i)
+            if (batch->status[(size_t)i] != F5_OK)
+                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+    } catch (const std::exception&) {
+        delete batch;
+        return F5_ERR_OPEN;
+    }
+    *out = batch;
+    return F5_OK;
+}
+
+const int16_t* f5_batch_samples(const f5_batch* batch) { return batch ? batch->samples.data() : nullptr; }
+const int64_t* f5_batch_offsets(const f5_batch* batch) { return batch ? batch->offsets.data() : nullptr; }
+const int32_t* f5_batch_status(const f5_batch* batch) { return batch ? batch->status.data() : nullptr; }
+const char* f5_batch_read_ids(const f5_batch* batch) { return batch ? batch->read_ids.data() : nullptr; }
+void f5_batch_free(f5_batch* batch) { delete batch; }
+
+}  // extern "C"

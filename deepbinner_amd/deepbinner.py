@@ -119,8 +119,8 @@ def classify_and_realtime_options(group):
     perf_args.add_argument('--batch_size', type=int, required=False, default=256,
                            help='Number of reads handed to the GPU per call')
     perf_args.add_argument('--loader_procs', type=int, required=False, default=0,
-                           help='Processes that load and decompress fast5 files ahead of the GPU '
-                                '(0 = automatic: 1 for small jobs, up to 8 from 512 files on)')
+                           help='Threads (native reader) or processes (Python reader) that load '
+                                'and decompress fast5 files ahead of the GPU (0 = automatic)')
     # TensorFlow knobs of the reference: accepted for command-line compatibility, ignored.
     perf_args.add_argument('--intra_op_parallelism_threads', type=int, required=False, default=12,
                            help='Accepted for compatibility with the TensorFlow build (ignored)')

@@ -1,0 +1,198 @@
+"""
+ctypes binding of ``libdeepbinner_fast5.so`` (C ABI: ``include/deepbinner_fast5.h``), the native
+fast5 loader: read id + raw int16 signal of single- and multi-read fast5 files, and a
+multi-threaded batch loader that hands back packed scan regions.
+
+Same idiom as the reference's one native library (``deepbinner/dtw_semi_global.py:30-41``) and as
+``hip_backend``.  The pure-Python reader (``hdf5_lite``) implements the same slice of the HDF5
+format and is what this library is tested against (``tests/test_fast5_native.py``).
+"""
+
+import ctypes
+import os
+import weakref
+
+import numpy as np
+
+_LIB_NAME = 'libdeepbinner_fast5.so'
+_lib = None
+
+F5_OK, F5_ERR_OPEN, F5_ERR_FORMAT, F5_ERR_NO_READ, F5_ERR_MULTI, F5_ERR_ARGUMENT = range(6)
+F5_READ_ID_MAX = 64
+LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
+
+EXPORTED_SYMBOLS = [
+    'f5_version', 'f5_status_string', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
+    'f5_read_signal', 'f5_load_batch', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
+    'f5_batch_read_ids', 'f5_batch_free',
+]
+
+
+class Fast5NativeError(OSError):
+    """The library is missing or refused a file (an OSError, like h5py's and hdf5_lite's)."""
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def available():
+    return os.path.isfile(library_path())
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.isfile(path):
+        raise Fast5NativeError('{} not found - build it with `make -C deepbinner_amd/csrc` '
+                               '(python -c "import __graft_entry__ as g; g.build()")'.format(path))
+    lib = ctypes.cdll.LoadLibrary(path)
+    c_int, c_i64, c_void_p, c_char_p = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+    P = ctypes.POINTER
+    sigs = {
+        'f5_version': (c_char_p, []),
+        'f5_status_string': (c_char_p, [c_int]),
+        'f5_open': (c_int, [c_char_p, P(c_void_p)]),
+        'f5_close': (None, [c_void_p]),
+        'f5_layout': (c_int, [c_void_p, P(c_int), P(c_i64)]),
+        'f5_read_info': (c_int, [c_void_p, c_i64, ctypes.c_char * F5_READ_ID_MAX, P(c_i64)]),
+        'f5_read_signal': (c_int, [c_void_p, c_i64, c_i64, c_i64,
+                                   np.ctypeslib.ndpointer(np.int16, flags='C_CONTIGUOUS')]),
+        'f5_load_batch': (c_int, [P(c_char_p), c_i64, c_i64, c_int, P(c_void_p)]),
+        'f5_batch_samples': (P(ctypes.c_int16), [c_void_p]),
+        'f5_batch_offsets': (P(c_i64), [c_void_p]),
+        'f5_batch_status': (P(ctypes.c_int32), [c_void_p]),
+        'f5_batch_read_ids': (P(ctypes.c_char), [c_void_p]),
+        'f5_batch_free': (None, [c_void_p]),
+    }
+    for name, (restype, argtypes) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def status_string(status):
+    return load_library().f5_status_string(int(status)).decode()
+
+
+class File:
+    """One open fast5 file: ``layout``, ``n_reads``, ``read_info(i)``, ``read_signal(i, ...)``."""
+
+    def __init__(self, path):
+        self._lib = load_library()
+        self._handle = ctypes.c_void_p()
+        status = self._lib.f5_open(os.fsencode(str(path)), ctypes.byref(self._handle))
+        if status != F5_OK:
+            self._handle = None
+            raise Fast5NativeError('{}: {}'.format(path, status_string(status)))
+        layout, n = ctypes.c_int(0), ctypes.c_int64(0)
+        self._lib.f5_layout(self._handle, ctypes.byref(layout), ctypes.byref(n))
+        self.layout, self.n_reads = layout.value, n.value
+
+    def close(self):
+        if self._handle:
+            self._lib.f5_close(self._handle)
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read_info(self, index):
+        """-> (read_id str, n_samples); KeyError when the read lacks read_id / Signal."""
+        rid = (ctypes.c_char * F5_READ_ID_MAX)()
+        n = ctypes.c_int64(0)
+        status = self._lib.f5_read_info(self._handle, int(index), rid, ctypes.byref(n))
+        if status == F5_ERR_NO_READ:
+            raise KeyError('read {} (read_id / Signal)'.format(index))
+        if status != F5_OK:
+            raise Fast5NativeError(status_string(status))
+        return rid.value.decode(), n.value
+
+    def read_signal(self, index, first=0, count=None):
+        _, n = self.read_info(index)
+        count = n - first if count is None else count
+        out = np.empty(max(count, 0), dtype=np.int16)
+        status = self._lib.f5_read_signal(self._handle, int(index), int(first), int(count), out)
+        if status == F5_ERR_NO_READ:
+            raise KeyError('sample range {}+{} of read {}'.format(first, count, index))
+        if status != F5_OK:
+            raise Fast5NativeError(status_string(status))
+        return out
+
+
+def get_read_id_and_signal(fast5_file):
+    """Native equivalent of ``load_fast5s.get_read_id_and_signal`` (reference
+    load_fast5s.py:25-49): (read_id, int16 signal), (None, None) for unreadable files, SystemExit
+    for a multi-read file."""
+    import sys
+    try:
+        with File(fast5_file) as f:
+            if f.layout == LAYOUT_MULTI:
+                sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
+            if f.layout == LAYOUT_NONE:
+                return None, None
+            read_id, _ = f.read_info(0)
+            return read_id, f.read_signal(0)
+    except (OSError, KeyError):
+        return None, None
+
+
+def iter_reads(fast5_file):
+    """(read_id, signal) for every read of a single- or multi-read fast5."""
+    try:
+        with File(fast5_file) as f:
+            for i in range(f.n_reads):
+                yield f.read_info(i)[0], f.read_signal(i)
+    except (OSError, KeyError):
+        return
+
+
+def load_batch(fast5_files, keep=None, threads=0):
+    """One-read files -> (read_ids, samples, offsets, status): read i is
+    ``samples[offsets[i]:offsets[i+1]]`` (its first and last ``keep`` samples only when it is
+    longer than 2*keep), ``read_ids[i]`` is None and ``status[i]`` != 0 for a file that could not
+    be read.  The files are parsed and inflated by ``threads`` native threads (0 = one per
+    hardware thread, at most 64); the GIL is released meanwhile."""
+    lib = load_library()
+    n = len(fast5_files)
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
+    handle = ctypes.c_void_p()
+    status = lib.f5_load_batch(paths, n, int(keep or 0), int(threads), ctypes.byref(handle))
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+    try:
+        offsets = np.ctypeslib.as_array(lib.f5_batch_offsets(handle), shape=(n + 1,)).copy()
+        total = int(offsets[n])
+        if n:
+            st = np.ctypeslib.as_array(lib.f5_batch_status(handle), shape=(n,)).copy()
+            raw = ctypes.string_at(lib.f5_batch_read_ids(handle), n * F5_READ_ID_MAX)
+        else:
+            st, raw = np.empty(0, dtype=np.int32), b''
+    except Exception:
+        lib.f5_batch_free(handle)
+        raise
+    if total:
+        # no copy: the array (and every slice of it) keeps the native batch alive
+        samples = np.ctypeslib.as_array(lib.f5_batch_samples(handle), shape=(total,))
+        weakref.finalize(samples, lib.f5_batch_free, handle)
+    else:
+        samples = np.empty(0, dtype=np.int16)
+        lib.f5_batch_free(handle)
+    read_ids = []
+    for i in range(n):
+        slot = raw[i * F5_READ_ID_MAX:(i + 1) * F5_READ_ID_MAX]
+        read_ids.append(slot.split(b'\x00')[0].decode() if st[i] == F5_OK else None)
+    return read_ids, samples, offsets, st

@@ -28,9 +28,31 @@ def _read_group(hdf5_file):
     return hdf5_file[reads[0] + '/Raw/']
 
 
+def reader_kind():
+    """Which fast5 reader serves this process: 'native' (libdeepbinner_fast5.so, C++) or 'python'
+    (hdf5_lite).  DEEPBINNER_FAST5_READER=native|python forces one; the default takes the native
+    library when it has been built.  Both implement the same slice of HDF5 and are tested against
+    each other (tests/test_fast5_native.py)."""
+    want = os.environ.get('DEEPBINNER_FAST5_READER', 'auto')
+    if want == 'python':
+        return 'python'
+    from . import fast5_native
+    if want == 'native':
+        fast5_native.load_library()         # fail loudly if it was asked for and is not there
+        return 'native'
+    return 'native' if fast5_native.available() else 'python'
+
+
 def get_read_id_and_signal(fast5_file):
     """-> (read_id str, int16 ndarray); (None, None) for unreadable files
     (reference load_fast5s.py:25-49)."""
+    if reader_kind() == 'native':
+        from . import fast5_native
+        return fast5_native.get_read_id_and_signal(fast5_file)
+    return _python_get_read_id_and_signal(fast5_file)
+
+
+def _python_get_read_id_and_signal(fast5_file):
     try:
         with hdf5_lite.File(str(fast5_file), 'r') as hdf5_file:
             group = _read_group(hdf5_file)
@@ -45,6 +67,14 @@ def get_read_id_and_signal(fast5_file):
 
 def iter_reads(fast5_file):
     """Yield (read_id, signal) for every read of a single- or multi-read fast5."""
+    if reader_kind() == 'native':
+        from . import fast5_native
+        yield from fast5_native.iter_reads(fast5_file)
+        return
+    yield from _python_iter_reads(fast5_file)
+
+
+def _python_iter_reads(fast5_file):
     try:
         with hdf5_lite.File(str(fast5_file), 'r') as hdf5_file:
             keys = list(hdf5_file.keys())

@@ -1,0 +1,78 @@
+/*
+ * deepbinner_fast5.h - C ABI of libdeepbinner_fast5.so, the native (host-only, C++) fast5 loader
+ * in front of the classify path.
+ *
+ * Replaces, for the one thing the classify path needs from a fast5 file - the read id and the raw
+ * int16 signal - the reference's h5py calls:
+ *   deepbinner/load_fast5s.py:25-49   get_read_id_and_signal   (f5_open + f5_read_info +
+ *                                                               f5_read_signal, or f5_load_batch)
+ *   deepbinner/load_fast5s.py:93-102  get_root_level_keys      (f5_layout)
+ *   deepbinner/classify.py:141-150    the per-batch loading loop (f5_load_batch: worker threads,
+ *                                                               packed scan regions out)
+ * It implements the same slice of the HDF5 file format as deepbinner_amd/hdf5_lite.py (superblock
+ * v0-v3, object headers v1/v2, symbol-table / compact / dense groups, attributes incl. dense
+ * storage and variable-length strings, compact / contiguous / chunked datasets with deflate,
+ * shuffle and fletcher32 filters) and nothing else; every offset taken from the file is bounds
+ * checked.  No HIP, no Python: plain pointers and sizes.
+ *
+ * Threading: f5_file handles are not shared between threads; f5_load_batch runs its own
+ * worker threads and is itself safe to call from several threads at once.
+ */
+#ifndef DEEPBINNER_FAST5_H
+#define DEEPBINNER_FAST5_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F5_OK 0
+#define F5_ERR_OPEN 1      /* cannot open or map the file */
+#define F5_ERR_FORMAT 2    /* not HDF5, damaged, or outside the supported subset */
+#define F5_ERR_NO_READ 3   /* no read in the file / index out of range / no read_id or Signal */
+#define F5_ERR_MULTI 4     /* several reads where the caller asked for a one-read file */
+#define F5_ERR_ARGUMENT 5
+
+#define F5_READ_ID_MAX 64  /* bytes per read id slot, NUL terminated (a read id is a 36-char UUID) */
+
+/* Layouts, as the reference tells them apart (load_fast5s.py:29-43, 67-90). */
+#define F5_LAYOUT_NONE 0         /* neither /Raw nor read_* at the root */
+#define F5_LAYOUT_SINGLE_OLD 1   /* /Raw/Reads/<one group>           */
+#define F5_LAYOUT_SINGLE_NEW 2   /* exactly one /read_<id>/Raw        */
+#define F5_LAYOUT_MULTI 3        /* several /read_<id>/Raw            */
+
+typedef struct f5_file f5_file;
+
+const char* f5_version(void);
+const char* f5_status_string(int status);
+
+int f5_open(const char* path, f5_file** out);
+void f5_close(f5_file* file);
+/* Layout and number of reads (1 for the single-read layouts). */
+int f5_layout(f5_file* file, int* layout, int64_t* n_reads);
+/* Read `index` (reads are ordered by group name, as h5py lists them): its id and signal length. */
+int f5_read_info(f5_file* file, int64_t index, char read_id[F5_READ_ID_MAX], int64_t* n_samples);
+/* Samples [first, first + count) of read `index`; only the chunks that overlap are inflated. */
+int f5_read_signal(f5_file* file, int64_t index, int64_t first, int64_t count, int16_t* out);
+
+/* One-read files -> packed signals, loaded by `n_threads` worker threads (<= 0: one per hardware
+ * thread, at most 64).  keep > 0: reads longer than 2*keep contribute their first and last `keep`
+ * samples only (windows are cut from those: reference classify.py:337-349); keep <= 0: whole
+ * reads.  Read i occupies samples[offsets[i] .. offsets[i+1]); a file that could not be read has
+ * status != F5_OK and an empty id (the reference skips such files, load_fast5s.py:47-49); its
+ * range is empty, or - when the damage only showed while its Signal was being inflated - zero
+ * filled: go by the status.  The result owns its memory until f5_batch_free. */
+typedef struct f5_batch f5_batch;
+int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n_threads,
+                  f5_batch** out);
+const int16_t* f5_batch_samples(const f5_batch* batch);
+const int64_t* f5_batch_offsets(const f5_batch* batch);   /* n_files + 1 */
+const int32_t* f5_batch_status(const f5_batch* batch);    /* n_files */
+const char* f5_batch_read_ids(const f5_batch* batch);     /* n_files x F5_READ_ID_MAX */
+void f5_batch_free(f5_batch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""The native fast5 loader (libdeepbinner_fast5.so, C ABI include/deepbinner_fast5.h) against the
+pure-Python reader (hdf5_lite) and the reference's own loader answers
+(reference tests/test_load_fast5s.py) - host only, no GPU."""
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from deepbinner_amd import fast5_native, hdf5_lite, load_fast5s
+
+FAST5_DIR = os.path.join(REPO, 'tests', 'golden', 'fast5', 'single')
+MULTI_DIR = os.path.join(REPO, 'tests', 'golden', 'fast5', 'multi')
+
+pytestmark = pytest.mark.skipif(not fast5_native.available(),
+                                reason='libdeepbinner_fast5.so not built')
+
+
+def single_files():
+    return sorted(os.path.join(FAST5_DIR, f) for f in os.listdir(FAST5_DIR) if f.endswith('.fast5'))
+
+
+def multi_files():
+    return sorted(os.path.join(MULTI_DIR, f) for f in os.listdir(MULTI_DIR) if f.endswith('.fast5'))
+
+
+def python_reads(path):
+    """[(read_id, signal)] through hdf5_lite, in h5py's (sorted-name) order."""
+    with hdf5_lite.File(path) as f:
+        keys = list(f.keys())
+        if 'Raw' in keys:
+            groups = [list(f['Raw/Reads/'].values())[0]]
+        else:
+            groups = [f[k + '/Raw/'] for k in keys if k.startswith('read_')]
+        return [(g.attrs['read_id'].decode(), g['Signal'][:]) for g in groups]
+
+
+def test_library_exports_every_declared_symbol():
+    lib = fast5_native.load_library()
+    header = open(os.path.join(REPO, 'include', 'deepbinner_fast5.h')).read()
+    declared = set(re.findall(r'\b(f5_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(fast5_native.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.f5_version().startswith(b'deepbinner_fast5')
+
+
+@pytest.mark.parametrize('path', single_files())
+def test_single_read_files_match_python_reader(path):
+    (want_id, want_signal), = python_reads(path)
+    read_id, signal = fast5_native.get_read_id_and_signal(path)
+    assert read_id == want_id
+    assert signal.dtype == np.int16 and np.array_equal(signal, want_signal)
+    with fast5_native.File(path) as f:
+        assert f.n_reads == 1
+        assert f.layout in (fast5_native.LAYOUT_SINGLE_OLD, fast5_native.LAYOUT_SINGLE_NEW)
+        assert f.read_info(0) == (want_id, len(want_signal))
+        # partial reads: only the chunks that overlap are decoded
+        n = len(want_signal)
+        for first, count in ((0, 1), (0, min(n, 6656)), (max(n - 6656, 0), min(n, 6656)),
+                             (n // 2, min(1000, n - n // 2)), (n - 1, 1), (n, 0), (17, 4097)):
+            if first + count > n:
+                continue
+            assert np.array_equal(f.read_signal(0, first, count), want_signal[first:first + count])
+        with pytest.raises(KeyError):
+            f.read_signal(0, n - 3, 10)
+        with pytest.raises(KeyError):
+            f.read_info(1)
+
+
+def test_reference_loader_answers():
+    """reference tests/test_load_fast5s.py:46-49,55-58,69-72"""
+    by_name = {os.path.basename(p): p for p in single_files()}
+    cases = [('5210_N128870_20180511_FAH70336_MN20200_sequencing_run_057_Deepbinner_amplicon_43629_'
+              'read_11206_ch_157_strand.fast5', '63c20e8e-1d92-4a69-9cf8-9fc9c72ca4fb', 4971, 714,
+              4950, 396)]
+    for name, read_id, length, first, idx, val in cases:
+        got_id, signal = fast5_native.get_read_id_and_signal(by_name[name])
+        want_id, want = load_fast5s.get_read_id_and_signal(by_name[name])
+        assert got_id == want_id and np.array_equal(signal, want)
+        if want_id == read_id:
+            assert len(signal) == length and signal[0] == first and signal[idx] == val
+
+
+@pytest.mark.parametrize('path', multi_files())
+def test_multi_read_files_match_python_reader(path):
+    want = python_reads(path)
+    got = list(fast5_native.iter_reads(path))
+    assert len(got) == len(want) > 1
+    for (rid, sig), (want_id, want_sig) in zip(got, want):
+        assert rid == want_id and np.array_equal(sig, want_sig)
+    with fast5_native.File(path) as f:
+        assert f.layout == fast5_native.LAYOUT_MULTI and f.n_reads == len(want)
+    with pytest.raises(SystemExit):
+        fast5_native.get_read_id_and_signal(path)
+
+
+def test_unreadable_files(tmp_path):
+    assert fast5_native.get_read_id_and_signal(str(tmp_path / 'missing.fast5')) == (None, None)
+    empty = tmp_path / 'empty.fast5'
+    empty.write_bytes(b'')
+    assert fast5_native.get_read_id_and_signal(str(empty)) == (None, None)
+    garbage = tmp_path / 'garbage.fast5'
+    garbage.write_bytes(os.urandom(4096))
+    assert fast5_native.get_read_id_and_signal(str(garbage)) == (None, None)
+    # a real file cut short and a real file with its middle overwritten: an error, never a crash
+    src = open(single_files()[0], 'rb').read()
+    for k, data in enumerate((src[:len(src) // 2], src[:3000] + os.urandom(len(src) - 3000),
+                              src[:600] + b'\xff' * 64 + src[664:])):
+        p = tmp_path / ('damaged%d.fast5' % k)
+        p.write_bytes(data)
+        rid, sig = fast5_native.get_read_id_and_signal(str(p))
+        want_id, want_sig = load_fast5s._python_get_read_id_and_signal(str(p))
+        if rid is not None and want_id is not None:
+            assert rid == want_id and np.array_equal(sig, want_sig)
+
+
+@pytest.mark.parametrize('keep,threads', [(None, 1), (6656, 3), (1000, 0)])
+def test_load_batch(tmp_path, keep, threads):
+    files = single_files()
+    bad = str(tmp_path / 'garbage.fast5')
+    open(bad, 'wb').write(b'not hdf5')
+    multi = multi_files()[0]
+    paths = files + [bad, str(tmp_path / 'missing.fast5'), multi] + files[::-1]
+    read_ids, samples, offsets, status = fast5_native.load_batch(paths, keep, threads)
+    assert len(read_ids) == len(paths) and offsets[0] == 0 and offsets[-1] == len(samples)
+    for i, path in enumerate(paths):
+        got = samples[offsets[i]:offsets[i + 1]]
+        if path in files:
+            want_id, want = load_fast5s._python_get_read_id_and_signal(path)
+            assert status[i] == 0 and read_ids[i] == want_id
+            assert np.array_equal(got, load_fast5s.keep_ends(want, keep))
+        else:
+            assert status[i] != 0 and read_ids[i] is None and len(got) == 0
+    assert status[paths.index(multi)] == fast5_native.F5_ERR_MULTI
+    assert fast5_native.load_batch([], keep, threads)[0] == []
+
+
+def test_many_copies_in_parallel(tmp_path):
+    """Thread-safety smoke test: 400 files on 16 threads give what one thread gives."""
+    files = single_files()
+    paths = []
+    for i in range(400):
+        dst = tmp_path / ('copy_%03d.fast5' % i)
+        shutil.copyfile(files[i % len(files)], dst)
+        paths.append(str(dst))
+    a = fast5_native.load_batch(paths, 6656, 16)
+    b = fast5_native.load_batch(paths, 6656, 1)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert (a[3] == 0).all()

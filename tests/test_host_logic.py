@@ -257,7 +257,8 @@ def test_missing_fast5():
         == (None, None)
 
 
-def test_loader_pool_matches_serial_loader():
+def test_loader_pool_matches_serial_loader(monkeypatch):
+    monkeypatch.setenv('DEEPBINNER_FAST5_READER', 'python')
     """LoaderPool: same (read_id, signal) as the serial loader, in file order, unreadable files
     reported as (None, None), with more runs than the in-flight window allows at once."""
     files = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
@@ -274,8 +275,16 @@ def test_loader_pool_matches_serial_loader():
     assert load_fast5s.choose_loader_procs(5, 7) == 5
 
 
-def test_classification_with_loader_processes(oracle_backend, capsys):
-    """classify_fast5_files gives the same calls, ids and output with --loader_procs 2."""
+@pytest.mark.parametrize('reader', ['python', 'native'])
+def test_classification_with_loader_processes(oracle_backend, capsys, monkeypatch, reader):
+    """classify_fast5_files gives the same calls, ids and output with --loader_procs 2 (worker
+    processes around the Python reader, worker threads inside the native one)."""
+    if reader == 'native':
+        from deepbinner_amd import fast5_native
+        if not fast5_native.available():
+            pytest.skip('libdeepbinner_fast5.so not built')
+    monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+    assert load_fast5s.reader_kind() == reader
     fast5s = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
     sm, si, em, ei, osz, _ = classify.load_and_check_models(START_MODEL, None, 6144,
                                                             out_dest=io.StringIO())

@@ -33,6 +33,7 @@ def main():
             os.symlink(sources[i % len(sources)], dst)
             files.append(dst)
 
+        os.environ['DEEPBINNER_FAST5_READER'] = 'python'
         t0 = time.perf_counter()
         samples = 0
         for f in files[:1024]:
@@ -52,23 +53,40 @@ def main():
                     rates[label] = round(n / (time.perf_counter() - t0))
             out['loader pool, %d processes' % procs] = {'reads_per_s': rates}
 
+        from deepbinner_amd import fast5_native
+        if fast5_native.available():
+            rates = {}
+            for threads in (1, 4, 8, 16, 32, 64):
+                if threads > (os.cpu_count() or 1):
+                    continue
+                fast5_native.load_batch(files[:256], 6656, threads)
+                t0 = time.perf_counter()
+                for i in range(0, len(files), 256):
+                    fast5_native.load_batch(files[i:i + 256], 6656, threads)
+                rates['%d threads' % threads] = round(len(files) / (time.perf_counter() - t0))
+            out['native loader (libdeepbinner_fast5.so), batches of 256, scanned ends'] = {
+                'reads_per_s': rates}
+
         sm, si, em, ei, osz, _ = classify.load_and_check_models(
             os.path.join(MODELS, 'EXP-NBD103_read_starts.dbw'),
             os.path.join(MODELS, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
-        for procs in (1, 8):
-            if procs > (os.cpu_count() or 1):
+        for reader, procs in (('python', 1), ('python', 8), ('native', 0)):
+            if procs > (os.cpu_count() or 1) or (reader == 'native'
+                                                 and not fast5_native.available()):
                 continue
+            os.environ['DEEPBINNER_FAST5_READER'] = reader
             args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144,
                                       score_diff=0.5, require_either=True, require_start=False,
                                       require_both=False, loader_procs=procs)
-            subset = files if procs > 1 else files[:1024]
+            subset = files if (procs > 1 or reader == 'native') else files[:1024]
             sink = io.StringIO()
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(io.StringIO()):
                 calls, _ = classify.classify_fast5_files(subset, sm, si, em, ei, osz, args,
                                                          verified_single_read=True)
             dt = time.perf_counter() - t0
-            out['classify_fast5_files start+end models, loader_procs %d' % procs] = {
+            out['classify_fast5_files start+end models, %s reader, loader_procs %d'
+                % (reader, procs)] = {
                 'files': len(subset), 'seconds': round(dt, 3),
                 'reads_per_s': round(len(subset) / dt), 'distinct_reads': len(calls)}
     print(json.dumps(out, indent=1))
