@@ -496,19 +496,17 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
     }
     __builtin_amdgcn_sched_barrier(0);
     const WinoFrags<MT>& f = buf[SP_IDX & 1];
-    f2 u[2][MT];     // scalar component-wise on purpose: no packed VALU between MFMAs
+    f2 u[2][MT];     // both components at once (v_pk_add_f32), in one block ahead of the MFMAs
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if constexpr (PHASE == 0) {
-                u[0][m][e] = f.d[m][0][e] - f.d[m][2][e];     // U0 = d0 - d2
-                u[1][m][e] = f.d[m][1][e] + f.d[m][2][e];     // U1 = d1 + d2
-            } else {                                          // loaded rows are d1, d2, d3
-                u[0][m][e] = f.d[m][1][e] - f.d[m][0][e];     // U2 = d2 - d1
-                u[1][m][e] = f.d[m][0][e] - f.d[m][2][e];     // U3 = d1 - d3
-            }
+    for (int m = 0; m < MT; ++m) {
+        if constexpr (PHASE == 0) {
+            u[0][m] = f.d[m][0] - f.d[m][2];     // U0 = d0 - d2
+            u[1][m] = f.d[m][1] + f.d[m][2];     // U1 = d1 + d2
+        } else {                                 // loaded rows are d1, d2, d3
+            u[0][m] = f.d[m][1] - f.d[m][0];     // U2 = d2 - d1
+            u[1][m] = f.d[m][0] - f.d[m][2];     // U3 = d1 - d3
         }
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -717,6 +715,7 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
     __builtin_amdgcn_sched_barrier(0);
     const F& f = buf[SP_IDX & 1];
     f2 u[kXi];
+#ifdef DBH_W43_SCALAR_TRANSFORM
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
@@ -732,6 +731,25 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
             u[1][e] = fmaf(4.f, f.d[1][e], fmaf(-5.f, f.d[3][e], f.d[5][e]));
         }
     }
+#else
+    // both components of a fragment at once (v_pk_fma_f32 / v_pk_add_f32): in ONE block ahead of
+    // the MFMAs a packed instruction costs the matrix pipe 4.3 cycles against 3.4 for a scalar
+    // one (tools/microbench/mfma_issue.hip) and does twice the work
+    const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
+    const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
+    if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
+        const f2 d1 = f.d[0], d2 = f.d[1], d3 = f.d[2], d4 = f.d[3];
+        const f2 a = __builtin_elementwise_fma(m4, d2, d4), b = __builtin_elementwise_fma(m4, d1, d3);
+        const f2 c = d4 - d2, g = d3 - d1;
+        u[0] = a + b;
+        u[1] = a - b;
+        u[2] = __builtin_elementwise_fma(p2, g, c);
+        u[3] = __builtin_elementwise_fma(m2, g, c);
+    } else {                           // rows d0..d5
+        u[0] = __builtin_elementwise_fma(p4, f.d[0], __builtin_elementwise_fma(m5, f.d[2], f.d[4]));
+        u[1] = __builtin_elementwise_fma(p4, f.d[1], __builtin_elementwise_fma(m5, f.d[3], f.d[5]));
+    }
+#endif
 #pragma unroll
     for (int x = 0; x < kXi; ++x) asm volatile("" : "+v"(u[x]));
     __builtin_amdgcn_sched_barrier(0);

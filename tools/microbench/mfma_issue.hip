@@ -45,6 +45,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PAT_V1_BUNCHED \
     V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) \
     V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) V(14) V(15) V(16) V(17) PAT_PURE
+// 12 packed VALU first (the same 24 flops per lane as PAT_V1_BUNCHED), then the 24 MFMAs
+#define PAT_P_BUNCHED \
+    P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) PAT_PURE
+#define PAT_P24_BUNCHED \
+    P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) \
+    P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) P(18) P(19) P(20) P(21) PAT_PURE
 // 12 LDS reads, one after every second MFMA
 #define PAT_L128 \
     M(0) M(1) L128(26,0) M(2) M(3) L128(27,1024) M(4) M(5) L128(28,2048) M(6) M(7) L128(29,3072) \
@@ -154,6 +160,8 @@ KERNEL(k_v2, PAT_V2)
 KERNEL(k_v4, PAT_V4)
 KERNEL(k_p1, PAT_P1)
 KERNEL(k_v1_bunched, PAT_V1_BUNCHED)
+KERNEL(k_p_bunched, PAT_P_BUNCHED)
+KERNEL(k_p24_bunched, PAT_P24_BUNCHED)
 KERNEL(k_l128, PAT_L128)
 KERNEL(k_l64, PAT_L64)
 KERNEL(k_l128_bunched, PAT_L128_BUNCHED)
@@ -221,6 +229,8 @@ int main() {
     run("24 MFMA, 4 v_fma after each", k_v4);
     run("24 MFMA, 1 v_pk_fma after each", k_p1);
     run("24 v_fma bunched, then 24 MFMA", k_v1_bunched);
+    run("12 v_pk_fma bunched, then 24 MFMA", k_p_bunched);
+    run("24 v_pk_fma bunched, then 24 MFMA", k_p24_bunched);
     run("24 MFMA, ds_read_b128 after every 2nd", k_l128);
     run("24 MFMA, ds_read_b64 after every 2nd", k_l64);
     run("12 ds_read_b128 bunched, then 24 MFMA", k_l128_bunched);
