@@ -482,6 +482,19 @@ __device__ __forceinline__ void wino_wait(WinoFrags<MT>& f) {
         for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
 }
 
+// a + b / a - b on both halves of a register pair.  (Written as asm because hipcc splits a plain
+// f2 add into two scalar ones whenever it likes the register allocation better.)
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int MT, int PHASE, int SP_IDX, class Side>
 __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
                                           f4 (&acc)[4][MT][3], const Side& side) {
@@ -500,11 +513,11 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if constexpr (PHASE == 0) {
-            u[0][m] = f.d[m][0] - f.d[m][2];     // U0 = d0 - d2
-            u[1][m] = f.d[m][1] + f.d[m][2];     // U1 = d1 + d2
-        } else {                                 // loaded rows are d1, d2, d3
-            u[0][m] = f.d[m][1] - f.d[m][0];     // U2 = d2 - d1
-            u[1][m] = f.d[m][0] - f.d[m][2];     // U3 = d1 - d3
+            u[0][m] = pk_sub(f.d[m][0], f.d[m][2]);     // U0 = d0 - d2
+            u[1][m] = pk_add(f.d[m][1], f.d[m][2]);     // U1 = d1 + d2
+        } else {                                        // loaded rows are d1, d2, d3
+            u[0][m] = pk_sub(f.d[m][1], f.d[m][0]);     // U2 = d2 - d1
+            u[1][m] = pk_sub(f.d[m][0], f.d[m][2]);     // U3 = d1 - d3
         }
     }
 #pragma unroll
@@ -848,13 +861,10 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
                     float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
                     float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
                     if constexpr (POOL) {
-                        float o0 = fmaxf(v0, v1), o1 = fmaxf(v2, v3);
-                        if (BN) {
-                            o0 = fmaf(o0, sc, sh);
-                            o1 = fmaf(o1, sc, sh);
-                        }
-                        o[t][h][e][0] = o0;
-                        o[t][h][e][1] = o1;
+                        f2 p = f2{fmaxf(v0, v1), fmaxf(v2, v3)};
+                        if (BN) p = __builtin_elementwise_fma(p, f2{sc, sc}, f2{sh, sh});
+                        o[t][h][e][0] = p.x;
+                        o[t][h][e][1] = p.y;
                     } else {
                         if (BN) {
                             v0 = fmaf(v0, sc, sh);
