@@ -12,7 +12,16 @@
 #include <vector>
 
 #include "../../include/deepbinner_hip.h"
+#define DBH_FORWARD_NS dbh
+#define DBH_TIMELINE 0
 #include "dbh_forward.hip"
+#undef DBH_FORWARD_NS
+#undef DBH_TIMELINE
+#define DBH_FORWARD_NS dbh_timeline      // the same kernels with the cycle stamps compiled in
+#define DBH_TIMELINE 1
+#include "dbh_forward.hip"
+#undef DBH_FORWARD_NS
+#undef DBH_TIMELINE
 
 namespace {
 
@@ -228,8 +237,9 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
                 }
             }
         }
-        hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)cnt), dim3(dbh::kThreads), 0,
-                           stream, m->d_packed, x_dev ? x_dev + off * dbh::kWindow : nullptr,
+        hipLaunchKernelGGL(debug_stage == 300 ? dbh_timeline::dbh_forward_kernel
+                                              : dbh::dbh_forward_kernel,
+                           dim3((unsigned)cnt), dim3(dbh::kThreads), 0, stream, m->d_packed, x_dev ? x_dev + off * dbh::kWindow : nullptr,
                            probs_dev ? probs_dev + off * m->n_classes : nullptr, m->n_classes,
                            debug_stage,
                            debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 || debug_stage > 7 ? 0 : debug_stage]
@@ -698,8 +708,8 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
     DBH_HIP(hipMemcpyAsync(m->d_in, x_host, (size_t)n * dbh::kWindow * sizeof(float),
                            hipMemcpyHostToDevice, 0));
     DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
-    hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0, 0,
-                       m->d_packed, (const float*)m->d_in, (float*)m->d_out, m->n_classes, 300,
+    hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0,
+                       0, m->d_packed, (const float*)m->d_in, (float*)m->d_out, m->n_classes, 300,
                        (float*)m->d_work, nullptr, nullptr, 1, 0, 0.0, nullptr);
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));

@@ -28,7 +28,20 @@
 
 #include "dbh_layout.h"
 
-namespace dbh {
+// This file is compiled twice by dbh_api.hip: as namespace dbh with DBH_TIMELINE 0 (the product)
+// and as namespace dbh_timeline with DBH_TIMELINE 1 (cycle stamps for tools/timeline.py).  The
+// stamps are global stores, and on gfx9 a store shares the vmcnt counter with the loads: one
+// conditional store anywhere makes hipcc wait for vmcnt(0) at every later use of a prefetched
+// register, so they must not even be compiled into the production kernel.
+#ifndef DBH_FORWARD_NS
+#define DBH_FORWARD_NS dbh
+#endif
+#ifndef DBH_TIMELINE
+#define DBH_TIMELINE 0
+#endif
+
+namespace DBH_FORWARD_NS {
+using namespace dbh;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -53,7 +66,12 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 // Cycle-stamp for the timeline mode (debug_stage 300): ts is non-null only in lane 0 of each
 // wave and points at that wave's 64 slots.
 __device__ __forceinline__ void mark(long long* ts, int id) {
+#if DBH_TIMELINE
     if (ts) ts[id] = (long long)__builtin_readcyclecounter();
+#else
+    (void)ts;
+    (void)id;
+#endif
 }
 
 // All-lanes reduction over a 16-lane row with DPP moves (no LDS round trips, unlike
@@ -1142,6 +1160,100 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
     mark(ts, ts_base + 3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv18 / conv19 (48 -> 48, k = 3, one 16-position tile): 108 MFMAs.  Three waves with a whole
+// N tile each (36 MFMAs, no reduction) leave one SIMD idle and the others with a lone wave; here
+// the 54 (tap, channel-step, N tile) units - fragment u of the packed layer IS unit u - are dealt
+// out round robin to all eight waves (unit u -> wave u % 8: 7 units on waves 0-5, 6 on 6-7), so
+// every SIMD multiplies for 27 MFMAs, every wave fetches 7 B fragments instead of 18, and the
+// per-wave partial tiles are summed through LDS as conv17's are.  A wave's j-th unit works on N
+// tile (wave + 2j) % 3: one of three compile-time patterns, picked by wave % 3.
+// ---------------------------------------------------------------------------------------------
+template <int CONV, bool BN>
+struct StripedRegs {
+    static_assert(kConv[CONV].taps == 3 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    static constexpr int kUnits = 3 * 6 * 3, kPer = (kUnits + kWaves - 1) / kWaves;
+    f2 b[kPer];
+    EpiParams<1, BN> ep;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int bn_index,
+                                             int lane, int wave) {
+        const float* b_lane = packed + weight_offset(CONV) + lane * 2;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            // unconditional (a wave without a 7th unit re-reads the last fragment and never uses
+            // it): a select on a freshly loaded value would make hipcc wait for the load at once
+            const int u = wave + kWaves * j < kUnits ? wave + kWaves * j : kUnits - 1;
+            b[j] = *reinterpret_cast<const f2*>(b_lane + u * 128);
+        }
+        // epilogue parameters: used by waves 0-2 (one N tile each), fetched by all - a branch
+        // here would cost hipcc its exact vmcnt bookkeeping, and every later use of an EARLIER
+        // prefetch would wait for this one too
+        const int ch = (wave % 3) * 16 + (lane & 15);
+        ep.load(packed + bias_offset(CONV) + ch,
+                packed + (BN ? bn_scale_offset(bn_index) : 0) + ch,
+                packed + (BN ? bn_shift_offset(bn_index) : 0) + ch);
+    }
+};
+
+template <int CONV, bool BN, int V>
+__device__ __forceinline__ void striped_units(const float* in_region,
+                                              const StripedRegs<CONV, BN>& regs, int lane, int wave,
+                                              f4 (&acc)[3]) {
+    using R = StripedRegs<CONV, BN>;
+    const int n = lane & 15, q = lane >> 4;
+    const float* a_lane = in_region + n * kS48 + 2 * q;    // 'same' k=3: physical row p + tap
+    f2 a[R::kPer];
+#pragma unroll
+    for (int j = 0; j < R::kPer; ++j) {
+        const int u = wave + kWaves * j;
+        const int k = (u < R::kUnits ? u : 0) / 3;             // tap * 6 + channel step
+        a[j] = *reinterpret_cast<const f2*>(a_lane + (k / 6) * kS48 + (k % 6) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < R::kPer; ++j) {
+        const int t = (V + 2 * j) % 3;
+        if (j == R::kPer - 1 && wave + kWaves * j >= R::kUnits) break;   // waves 6, 7: 6 units
+        acc[t] = mfma4(a[j].x, regs.b[j].x, acc[t]);
+        acc[t] = mfma4(a[j].y, regs.b[j].y, acc[t]);
+    }
+}
+
+template <int CONV, bool POOL, bool BN>
+__device__ __forceinline__ void striped_layer(float* lds, const float* in_region, float* out_region,
+                                              const StripedRegs<CONV, BN>& regs, int lane, int wave,
+                                              long long* ts, int ts_base) {
+    const int n = lane & 15, q = lane >> 4;
+    f4 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    const int v = wave % 3;
+    if (v == 0)
+        striped_units<CONV, BN, 0>(in_region, regs, lane, wave, acc);
+    else if (v == 1)
+        striped_units<CONV, BN, 1>(in_region, regs, lane, wave, acc);
+    else
+        striped_units<CONV, BN, 2>(in_region, regs, lane, wave, acc);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        *reinterpret_cast<f4*>(lds + kRed + (wave * 3 + t) * 256 + lane * 4) = acc[t];
+    mark(ts, ts_base);
+    __syncthreads();
+    mark(ts, ts_base + 1);
+    if (wave < 3) {
+        const int t = wave;
+        f4 sum[1][1];
+        sum[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w)
+            sum[0][0] += *reinterpret_cast<const f4*>(lds + kRed + (w * 3 + t) * 256 + lane * 4);
+        float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
+        epilogue<1, 1, kS48, POOL, BN>(sum, out_lane, regs.ep);
+    }
+    mark(ts, ts_base + 2);
+    __syncthreads();
+    mark(ts, ts_base + 3);
+}
+
 // One wave's share of the 1x1 convolutions of the inception block (4 position tiles x 1 N tile).
 template <int NTTOT, int S_OUT, bool POOLBN>
 __device__ __forceinline__ void inception_1x1(const float* in_region, const float* w_lds,
@@ -1560,7 +1672,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     zero_row(lds + kG1, 0, kS48, 48, tid);
     zero_row(lds + kG1, 17, kS48, 48, tid);
     for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
-    SmallMRegs<17, 1, 1, false> r18;
+    StripedRegs<17, false> r18;
     r18.prefetch(packed, 0, lane, wave);
     small_m_layer<16, kS192, 2, 8, 3, false, true>(lds, lds + kECat, lds + kFOut, r17, lane, wave,
                                                    ts, 41);
@@ -1571,10 +1683,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
-    SmallMRegs<18, 1, 1, true> r19;
+    StripedRegs<18, true> r19;
     r19.prefetch(packed, 6, lane, wave);
-    small_m_layer<17, kS48, 1, 1, 1, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave, ts,
-                                                   45);
+    striped_layer<17, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave, ts, 45);
     // conv20's fragments and bias: fetched before conv19 runs
     f2 b20[6];
     float bias20 = 0.f;
@@ -1585,7 +1696,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                    (sp * 2 + wave) * 128 + lane * 2);
         bias20 = packed[bias_offset(19) + wave * 16 + n];
     }
-    small_m_layer<18, kS48, 1, 1, 1, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave, ts, 49);
+    striped_layer<18, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave, ts, 49);
     if (stop_stage == 6) {
         if (debug_stage < 100)
             dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
@@ -1729,4 +1840,4 @@ __global__ __launch_bounds__(256) void dbh_merge_kernel(const float* __restrict_
                          calls + read);
 }
 
-}  // namespace dbh
+}  // namespace DBH_FORWARD_NS

@@ -34,7 +34,9 @@ class HipBackendError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    # DEEPBINNER_HIP_LIB: developer knob for A/B runs of two builds on the same GPU box
+    return os.environ.get('DEEPBINNER_HIP_LIB') or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def _f32(flags='C_CONTIGUOUS'):
