@@ -34,90 +34,73 @@ def build_model(weights):
 
 
 def classify(args):
-    """Reference classify.py:32-55."""
+    """``deepbinner classify`` (reference classify.py:32-55): load the model(s), work out what
+    ``args.input`` is and hand it to the matching driver."""
     set_tensorflow_threads(args)
+    *models, model_count = load_and_check_models(args.start_model, args.end_model, args.scan_size)
 
-    start_model, start_input_size, end_model, end_input_size, output_size, model_count = \
-        load_and_check_models(args.start_model, args.end_model, args.scan_size)
-
-    input_type = determine_input_type(args.input)
-    if input_type == 'training_data' and model_count == 2:
-        sys.exit('Error: training data can only be classified using a single model')
+    kind = determine_input_type(args.input)
+    if kind == 'training_data':
+        if model_count == 2:
+            sys.exit('Error: training data can only be classified using a single model')
+        print('', file=sys.stderr)
+        classify_training_data(args.input, *models, args)
+        return
     print('', file=sys.stderr)
-
+    assert kind in ('directory', 'single_fast5')
+    fast5s = find_all_fast5s(args.input, verbose=True) if kind == 'directory' else [args.input]
     from . import sharding
-    if input_type == 'directory' and sharding.env_world()[2] > 1:
-        # launched one process per GPU (torch.distributed.run): shard the reads, gather the calls
-        sharding.classify_fast5_files_sharded(find_all_fast5s(args.input, verbose=True),
-                                              start_model, start_input_size, end_model,
-                                              end_input_size, output_size, args)
-    elif input_type == 'directory':
-        classify_fast5_files(find_all_fast5s(args.input, verbose=True),
-                             start_model, start_input_size, end_model, end_input_size,
-                             output_size, args)
-    elif input_type == 'single_fast5':
-        classify_fast5_files([args.input],
-                             start_model, start_input_size, end_model, end_input_size,
-                             output_size, args)
-    elif input_type == 'training_data':
-        classify_training_data(args.input, start_model, start_input_size, end_model,
-                               end_input_size, output_size, args)
+    if kind == 'directory' and sharding.env_world()[2] > 1:
+        # one process per GPU (torch.distributed.run): shard the reads, gather the calls
+        sharding.classify_fast5_files_sharded(fast5s, *models, args)
     else:
-        assert False
+        classify_fast5_files(fast5s, *models, args)
 
 
 def load_and_check_models(start_model_filename, end_model_filename, scan_size,
                           out_dest=sys.stderr):
-    """Reference classify.py:58-83. Returns (start_model, start_input_size, end_model,
-    end_input_size, output_size, model_count)."""
-    start_model = start_input_size = start_output_size = None
-    end_model = end_input_size = end_output_size = None
-    if start_model_filename is not None:
-        start_model, start_input_size, start_output_size = \
-            load_trained_model(start_model_filename, out_dest=out_dest)
-        check_input_size(start_input_size, scan_size)
-    if end_model_filename is not None:
-        end_model, end_input_size, end_output_size = \
-            load_trained_model(end_model_filename, out_dest=out_dest)
-        check_input_size(end_input_size, scan_size)
-
-    model_count = (start_model is not None) + (end_model is not None)
-    if model_count == 2:
-        if start_output_size != end_output_size:
-            sys.exit('Error: two models have different number of barcode classes')
-        output_size = start_output_size
-    elif start_model is not None:
-        output_size = start_output_size
-    else:
-        output_size = end_output_size
-    return start_model, start_input_size, end_model, end_input_size, output_size, model_count
+    """-> (start_model, start_input_size, end_model, end_input_size, output_size, model_count)
+    (reference classify.py:58-83): either file name may be None; input sizes must fit the scan
+    size and two models must agree on the number of classes."""
+    loaded = []
+    for filename in (start_model_filename, end_model_filename):
+        if filename is None:
+            loaded.append((None, None, None))
+            continue
+        model, input_size, n_classes = load_trained_model(filename, out_dest=out_dest)
+        check_input_size(input_size, scan_size)
+        loaded.append((model, input_size, n_classes))
+    class_counts = [n for _, _, n in loaded if n is not None]
+    if len(set(class_counts)) > 1:
+        sys.exit('Error: two models have different number of barcode classes')
+    (start_model, start_size, _), (end_model, end_size, _) = loaded
+    return (start_model, start_size, end_model, end_size,
+            class_counts[0] if class_counts else None, len(class_counts))
 
 
 def load_trained_model(model_file, out_dest=sys.stderr):
-    """Reference classify.py:86-103.  Accepts the reference's Keras-2.1.4 HDF5 model files and
-    this package's ``.dbw`` weight files."""
+    """-> (model, input_size, output_size) from one of the reference's Keras-2.1.4 HDF5 model
+    files or one of this package's ``.dbw`` weight files (reference classify.py:86-103, same
+    messages)."""
     if not pathlib.Path(model_file).is_file():
         sys.exit('Error: {} does not exist'.format(model_file))
     print('Loading {}... '.format(model_file), file=out_dest, end='', flush=True)
-    bad_model = ('Error: model input has incorrect shape - are you sure that {} is a valid '
-                 'model file?'.format(model_file))
+    invalid = ('Error: model input has incorrect shape - are you sure that {} is a valid '
+               'model file?'.format(model_file))
     try:
         weights, _ = ModelWeights.load(str(model_file))
     except (OSError, ValueError, KeyError, IndexError):
-        sys.exit(bad_model)
+        sys.exit(invalid)
     model = build_model(weights)
     print('done', file=out_dest)
-    try:
-        assert len(model.inputs) == 1
-        input_shape = model.inputs[0].shape
-        output_shape = model.outputs[0].shape
-        input_size = int(input_shape[1])
-        output_size = int(output_shape[1])
-        assert input_size > 10
-        assert input_shape[2] == 1
-    except (AssertionError, IndexError):
-        sys.exit(bad_model)
-    return model, input_size, output_size
+    # the shape contract of seam b1: one input (None, L, 1) with L > 10, one output (None, C)
+    shapes = [tuple(t.shape) for t in model.inputs]
+    if len(shapes) != 1 or len(shapes[0]) != 3 or shapes[0][2] != 1 or not shapes[0][1] > 10:
+        sys.exit(invalid)
+    out_shape = tuple(model.outputs[0].shape)
+    if len(out_shape) < 2:
+        sys.exit(invalid)
+    return model, int(shapes[0][1]), int(out_shape[1])
 
 
 def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, end_input_size,
@@ -255,89 +238,78 @@ def classify_read_batch(read_ids, signals, start_model, start_input_size, end_mo
 
 def classify_training_data(input_file, start_model, start_input_size, end_model, end_input_size,
                            output_size, args):
-    """Reference classify.py:183-239: ``label<TAB>v1,v2,...`` lines, one model only."""
-    using_read_starts = start_model is not None
-    using_read_ends = end_model is not None
-
-    with open(input_file) as f:
-        num_lines = sum(1 for _ in f)
-    print_classification_progress(0, num_lines, 'training data')
-    print_output_header(args.verbose, using_read_starts, using_read_ends, output_size)
-
-    assert not (using_read_starts and using_read_ends)
-    model, input_size = ((start_model, start_input_size) if using_read_starts
+    """Classify a text file of ``label<TAB>v1,v2,...`` lines with ONE model (reference
+    classify.py:183-239).  Reads are named ``line_<n>_barcode_<label>``; like the reference, the
+    windows are always cut from the start of each signal (classify.py:223-224), whichever model
+    was given."""
+    assert (start_model is None) != (end_model is None)
+    model, input_size = ((start_model, start_input_size) if end_model is None
                          else (end_model, end_input_size))
+    with open(input_file, 'rt') as text:
+        records = [line.rstrip().split('\t') for line in text]
+    total = len(records)
+    print_classification_progress(0, total, 'training data')
+    print_output_header(args.verbose, start_model is not None, end_model is not None, output_size)
 
     classifications = {}
-    with open(input_file, 'rt') as training_data:
-        line_num = 0
-        finished = False
-        while not finished:
-            read_ids, signals = [], []
-            while len(read_ids) < args.batch_size:
-                line = training_data.readline()
-                if not line:
-                    finished = True
-                    break
-                line_num += 1
-                barcode, signal = line.rstrip().split('\t')
-                read_ids.append('line_{}_barcode_{}'.format(line_num, barcode))
-                signals.append(np.array([int(x) for x in signal.split(',')]))
-
-            # the reference always passes 'start' here (classify.py:223-224)
-            calls, probs = call_batch(input_size, output_size, read_ids, signals, model, args,
-                                      'start')
-            for i, read_id in enumerate(read_ids):
-                classifications[read_id] = calls[i]
-                output = [read_id, calls[i]]
-                if args.verbose:
-                    output += ['%.2f' % x for x in probs[i]]
-                print('\t'.join(output))
-            print_classification_progress(len(classifications), num_lines, 'training data')
+    for first in range(0, max(total, 1), args.batch_size):
+        batch = records[first:first + args.batch_size]
+        read_ids = ['line_{}_barcode_{}'.format(first + k + 1, label)
+                    for k, (label, _) in enumerate(batch)]
+        signals = [np.array([int(v) for v in values.split(',')]) for _, values in batch]
+        calls, probs = call_batch(input_size, output_size, read_ids, signals, model, args, 'start')
+        for read_id, call, row in zip(read_ids, calls, probs):
+            classifications[read_id] = call
+            fields = [read_id, call] + (['%.2f' % p for p in row] if args.verbose else [])
+            print('\t'.join(fields))
+        print_classification_progress(len(classifications), total, 'training data')
 
     print('', file=sys.stderr)
     print_summary_table(classifications)
 
 
 def determine_input_type(input_file_or_dir):
-    """Reference classify.py:242-263."""
+    """'directory' | 'single_fast5' | 'training_data' (reference classify.py:242-263): a file that
+    is not HDF5 counts as training data when its first line is ``<int>TAB<int>,<int>,...`` with
+    more than ten values."""
     path = pathlib.Path(input_file_or_dir)
     if path.is_dir():
         return 'directory'
     if not path.is_file():
         sys.exit('Error: {} is neither a file nor a directory'.format(input_file_or_dir))
     try:
-        hdf5_lite.File(str(input_file_or_dir), 'r').close()
-        return 'single_fast5'
+        hdf5_lite.File(str(path), 'r').close()
     except OSError:
         pass
+    else:
+        return 'single_fast5'
     try:
-        with open(input_file_or_dir) as f:
-            parts = f.readline().split('\t')
-        _ = int(parts[0])
-        signals = [int(x) for x in parts[1].split(',')]
-        assert len(signals) > 10
-        return 'training_data'
-    except (AssertionError, ValueError, IndexError, UnicodeDecodeError):
-        sys.exit('Error: could not determine input type')
+        with open(str(path)) as lines:
+            label, _, values = lines.readline().partition('\t')
+        int(label)
+        if len([int(v) for v in values.split('\t')[0].split(',')]) > 10:
+            return 'training_data'
+    except (ValueError, UnicodeDecodeError):
+        pass
+    sys.exit('Error: could not determine input type')
 
 
 def chunker(seq, size):
-    return (seq[pos:pos + size] for pos in range(0, len(seq), size))
+    """Consecutive slices of ``seq`` of at most ``size`` items."""
+    for first in range(0, len(seq), size):
+        yield seq[first:first + size]
 
 
 def print_output_header(verbose, using_read_starts, using_read_ends, output_size):
-    """Reference classify.py:270-282."""
-    header = ['read_ID', 'barcode_call']
+    """The TSV header row (reference classify.py:270-282)."""
+    columns = ['read_ID', 'barcode_call']
+    barcodes = ['none'] + [str(i) for i in range(1, output_size)]
     if verbose and using_read_starts and using_read_ends:
         for side in ('start', 'end'):
-            header.append(side + '_none')
-            header += ['{}_{}'.format(side, i) for i in range(1, output_size)]
-            header.append(side + '_barcode_call')
+            columns += [side + '_' + b for b in barcodes] + [side + '_barcode_call']
     elif verbose:
-        header.append('none')
-        header += [str(i) for i in range(1, output_size)]
-    print('\t'.join(header))
+        columns += barcodes
+    print('\t'.join(columns))
 
 
 def get_barcode_call_from_probabilities(probabilities, score_diff_threshold):
@@ -351,17 +323,20 @@ def get_barcode_call_from_probabilities(probabilities, score_diff_threshold):
 
 
 def combine_calls(start_call, end_call, args):
-    """Reference classify.py:298-322."""
+    """Final call of a read from its start-model and end-model calls (reference
+    classify.py:298-322): agreement always stands; otherwise require_both refuses, require_start
+    keeps a start call the end model is silent on, require_either keeps whichever side called
+    when the other is silent."""
     if start_call == end_call:
         return start_call
     if args.require_both:
         return 'none'
+    if end_call == 'none':
+        return start_call
     if args.require_start:
-        return start_call if end_call == 'none' else 'none'
+        return 'none'
     assert args.require_either
-    if start_call == 'none':
-        return end_call
-    return start_call if end_call == 'none' else 'none'
+    return end_call if start_call == 'none' else 'none'
 
 
 def call_batch(input_size, output_size, read_ids, signals, model, args, side):
@@ -423,22 +398,21 @@ def make_sum_to_one(probabilities):
 
 
 def check_input_size(input_size, scan_size):
-    """Reference classify.py:396-407."""
-    step_size = input_size // 2
-    if step_size * 2 != input_size:
+    """Windows advance by half the model's input size, so that size must be even and the scan
+    size a whole number of half-windows (reference classify.py:396-407, same messages)."""
+    half, odd = divmod(input_size, 2)
+    if odd:
         sys.exit('Error: the model input size must be even (currently {})'.format(input_size))
-    steps = int(scan_size / step_size)
-    if steps * step_size != scan_size:
-        acceptable_scan_sizes = [str(step_size * i) for i in range(2, 8)] + ['etc']
+    if int(scan_size / half) * half != scan_size:
+        examples = ', '.join([str(half * k) for k in range(2, 8)] + ['etc'])
         sys.exit('Error: --scan_size must be a multiple of half the model input size\n'
-                 'acceptable values for --scan_size are '
-                 '{}'.format(', '.join(acceptable_scan_sizes)))
+                 'acceptable values for --scan_size are ' + examples)
 
 
 def print_classification_progress(completed, total, label, out_dest=sys.stderr):
-    percent = 100.0 * completed / total
-    print('\rClassifying {}: {} / {} ({:.1f}%)'.format(label, completed, total, percent),
-          file=out_dest, end='', flush=True)
+    out_dest.write('\rClassifying %s: %s / %s (%.1f%%)' % (label, completed, total,
+                                                          100.0 * completed / total))
+    out_dest.flush()
 
 
 def set_tensorflow_threads(args):

@@ -1,9 +1,10 @@
 """
-Command line entry point — the ``classify`` and ``realtime`` subcommands of the reference's
-``deepbinner/deepbinner.py`` with the same flags, defaults and validation messages
-(reference ``deepbinner.py:90-156`` for the options, ``:283-345`` for the checks and preset
-resolution).  The other reference subcommands (bin, prep, balance, train, refine) are outside the
-GPU hot path and are not provided.
+Command line of the classify path: the ``classify`` and ``realtime`` sub-commands with the flags,
+defaults, validation and error messages of the reference's ``deepbinner/deepbinner.py``
+(:90-156 options, :283-345 checks and preset resolution), so that existing command lines keep
+working.  The options are declared as data (``OPTIONS``) and turned into argparse calls by one
+loop.  The reference's other sub-commands (bin, prep, balance, train, refine) are outside the GPU
+hot path and answer with a one-line refusal.
 """
 
 import argparse
@@ -12,184 +13,176 @@ import sys
 
 from .version import __version__
 
+NOT_PROVIDED = ('bin', 'prep', 'balance', 'train', 'refine')
+PRESETS = {'native': ('EXP-NBD103_read_starts', 'EXP-NBD103_read_ends'),
+           'rapid': ('SQK-RBK004_read_starts', None)}
+TWO_MODEL_FLAGS = ('require_either', 'require_start', 'require_both')
+_IGNORED = 'Accepted for compatibility with the TensorFlow build (ignored)'
+_HELP = (('-h', '--help'), dict(action='help', default=argparse.SUPPRESS,
+                                help='Show this help message and exit'))
 
-def main(argv=None):
+# (group title, [(flags, argparse keywords)]) shared by both sub-commands
+OPTIONS = [
+    ('Model presets', [
+        (('--native',), dict(action='store_true',
+                             help='Preset for EXP-NBD103 read start and end models')),
+        (('--rapid',), dict(action='store_true', help='Preset for SQK-RBK004 read start model')),
+    ]),
+    ('Models (at least one is required if not using a preset)', [
+        (('-s', '--start_model'), dict(type=str, help='Model trained on the starts of reads')),
+        (('-e', '--end_model'), dict(type=str, help='Model trained on the ends of reads')),
+    ]),
+    ('Barcoding', [
+        (('--scan_size',), dict(type=float, default=6144,
+                                help="This much of a read's start/end signal will examined for "
+                                     "barcode signals")),
+        (('--score_diff',), dict(type=float, default=0.5,
+                                 help='For a read to be classified, there must be this much '
+                                      'difference between the best and second-best barcode '
+                                      'scores')),
+    ]),
+    ('Two model (read start and read end) behaviour', [
+        (('--require_either',), dict(action='store_true',
+                                     help='Most lenient approach: a barcode call on either the '
+                                          'start or end is sufficient to classify a read, as long '
+                                          'as they do not disagree on the barcode (default '
+                                          'behaviour)')),
+        (('--require_start',), dict(action='store_true',
+                                    help='Moderate approach: a start barcode is required to '
+                                         'classify a read but an end barcode is optional')),
+        (('--require_both',), dict(action='store_true',
+                                   help='Most stringent approach: both start and end barcodes '
+                                        'must be present and agree to classify a read')),
+    ]),
+    ('Performance', [
+        (('--batch_size',), dict(type=int, default=256,
+                                 help='Number of reads handed to the GPU per call')),
+        (('--loader_procs',), dict(type=int, default=0,
+                                   help='Threads (native reader) or processes (Python reader) '
+                                        'that load and decompress fast5 files ahead of the GPU '
+                                        '(0 = automatic)')),
+        # TensorFlow knobs of the reference
+        (('--intra_op_parallelism_threads',), dict(type=int, default=12, help=_IGNORED)),
+        (('--inter_op_parallelism_threads',), dict(type=int, default=1, help=_IGNORED)),
+        (('--device_count',), dict(type=int, default=1, help=_IGNORED)),
+        (('--omp_num_threads',), dict(type=int, default=12, help=_IGNORED)),
+    ]),
+]
+
+# per sub-command: description, groups in front of the shared ones, the 'Other' group behind them
+COMMANDS = {
+    'classify': ('Classify fast5 reads',
+                 [('Positional', [
+                     (('input',), dict(type=str,
+                                       help='One of the following: a single fast5 file, a '
+                                            'directory of fast5 files (will be searched '
+                                            'recursively) or a tab-delimited file of training '
+                                            'data'))])],
+                 [(('--verbose',), dict(action='store_true',
+                                        help='Include the output probabilities for all barcodes '
+                                             'in the results (default: just show the final '
+                                             'barcode call)')), _HELP]),
+    'realtime': ('Sort fast5 files during sequencing',
+                 [('Required', [
+                     (('--in_dir',), dict(type=str, required=True,
+                                          help='Directory where sequencer deposits fast5 files')),
+                     (('--out_dir',), dict(type=str, required=True,
+                                           help='Directory to output binned fast5 files'))])],
+                 [(('--stop',), dict(action='store_true',
+                                     help='Automatically stop when there are no more input reads '
+                                          '(default: continue to run and wait for more reads)')),
+                  _HELP]),
+}
+
+
+def _add_groups(parser, groups):
+    for title, options in groups:
+        group = parser.add_argument_group(title)
+        for flags, keywords in options:
+            group.add_argument(*flags, **keywords)
+
+
+def build_parser():
     parser = argparse.ArgumentParser(
         prog='deepbinner',
         description='Deepbinner: a deep convolutional neural network barcode demultiplexer for '
                     'Oxford Nanopore reads (MI355X / HIP implementation of the classify path)',
         add_help=False)
     subparsers = parser.add_subparsers(title='Commands', dest='subparser_name')
-    classify_subparser(subparsers)
-    realtime_subparser(subparsers)
+    for name, (description, leading, other) in COMMANDS.items():
+        sub = subparsers.add_parser(name, description=description, add_help=False)
+        _add_groups(sub, leading + OPTIONS + [('Other', other)])
+    _add_groups(parser, [('Help', [
+        _HELP, (('--version',), dict(action='version', version=__version__,
+                                     help="Show program's version number and exit"))])])
+    return parser
 
-    help_args = parser.add_argument_group('Help')
-    help_args.add_argument('-h', '--help', action='help', default=argparse.SUPPRESS,
-                           help='Show this help message and exit')
-    help_args.add_argument('--version', action='version', version=__version__,
-                           help="Show program's version number and exit")
 
+def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
+    parser = build_parser()
     if not argv:
         parser.print_help(file=sys.stderr)
         sys.exit(1)
-    if argv[0] in ('bin', 'prep', 'balance', 'train', 'refine'):
+    if argv[0] in NOT_PROVIDED:
         sys.exit('Error: the {} command is not part of this build - it covers the classify and '
                  'realtime commands only'.format(argv[0]))
     args = parser.parse_args(argv)
-
-    if args.subparser_name == 'classify':
+    if args.subparser_name in COMMANDS:
         check_classify_and_realtime_arguments(args)
-        from .classify import classify
-        classify(args)
-    elif args.subparser_name == 'realtime':
-        check_classify_and_realtime_arguments(args)
-        from .realtime import realtime
-        realtime(args)
-
-
-def classify_subparser(subparsers):
-    group = subparsers.add_parser('classify', description='Classify fast5 reads', add_help=False)
-    positional_args = group.add_argument_group('Positional')
-    positional_args.add_argument('input', type=str,
-                                 help='One of the following: a single fast5 file, a directory of '
-                                      'fast5 files (will be searched recursively) or a '
-                                      'tab-delimited file of training data')
-    classify_and_realtime_options(group)
-    other_args = group.add_argument_group('Other')
-    other_args.add_argument('--verbose', action='store_true',
-                            help='Include the output probabilities for all barcodes in the '
-                                 'results (default: just show the final barcode call)')
-    other_args.add_argument('-h', '--help', action='help', default=argparse.SUPPRESS,
-                            help='Show this help message and exit')
-
-
-def realtime_subparser(subparsers):
-    group = subparsers.add_parser('realtime', description='Sort fast5 files during sequencing',
-                                  add_help=False)
-    required_args = group.add_argument_group('Required')
-    required_args.add_argument('--in_dir', type=str, required=True,
-                               help='Directory where sequencer deposits fast5 files')
-    required_args.add_argument('--out_dir', type=str, required=True,
-                               help='Directory to output binned fast5 files')
-    classify_and_realtime_options(group)
-    other_args = group.add_argument_group('Other')
-    other_args.add_argument('--stop', action='store_true',
-                            help='Automatically stop when there are no more input reads (default: '
-                                 'continue to run and wait for more reads)')
-    other_args.add_argument('-h', '--help', action='help', default=argparse.SUPPRESS,
-                            help='Show this help message and exit')
-
-
-def classify_and_realtime_options(group):
-    """Options shared by classify and realtime (reference deepbinner.py:109-156)."""
-    model_args = group.add_argument_group('Model presets')
-    model_args.add_argument('--native', action='store_true',
-                            help='Preset for EXP-NBD103 read start and end models')
-    model_args.add_argument('--rapid', action='store_true',
-                            help='Preset for SQK-RBK004 read start model')
-
-    model_args = group.add_argument_group('Models (at least one is required if not using a preset)')
-    model_args.add_argument('-s', '--start_model', type=str, required=False,
-                            help='Model trained on the starts of reads')
-    model_args.add_argument('-e', '--end_model', type=str, required=False,
-                            help='Model trained on the ends of reads')
-
-    barcode_args = group.add_argument_group('Barcoding')
-    barcode_args.add_argument('--scan_size', type=float, required=False, default=6144,
-                              help="This much of a read's start/end signal will examined for "
-                                   "barcode signals")
-    barcode_args.add_argument('--score_diff', type=float, required=False, default=0.5,
-                              help='For a read to be classified, there must be this much '
-                                   'difference between the best and second-best barcode scores')
-
-    two_model_args = group.add_argument_group('Two model (read start and read end) behaviour')
-    two_model_args.add_argument('--require_either', action='store_true',
-                                help='Most lenient approach: a barcode call on either the start '
-                                     'or end is sufficient to classify a read, as long as they do '
-                                     'not disagree on the barcode (default behaviour)')
-    two_model_args.add_argument('--require_start', action='store_true',
-                                help='Moderate approach: a start barcode is required to classify '
-                                     'a read but an end barcode is optional')
-    two_model_args.add_argument('--require_both', action='store_true',
-                                help='Most stringent approach: both start and end barcodes must be '
-                                     'present and agree to classify a read')
-
-    perf_args = group.add_argument_group('Performance')
-    perf_args.add_argument('--batch_size', type=int, required=False, default=256,
-                           help='Number of reads handed to the GPU per call')
-    perf_args.add_argument('--loader_procs', type=int, required=False, default=0,
-                           help='Threads (native reader) or processes (Python reader) that load '
-                                'and decompress fast5 files ahead of the GPU (0 = automatic)')
-    # TensorFlow knobs of the reference: accepted for command-line compatibility, ignored.
-    perf_args.add_argument('--intra_op_parallelism_threads', type=int, required=False, default=12,
-                           help='Accepted for compatibility with the TensorFlow build (ignored)')
-    perf_args.add_argument('--inter_op_parallelism_threads', type=int, required=False, default=1,
-                           help='Accepted for compatibility with the TensorFlow build (ignored)')
-    perf_args.add_argument('--device_count', type=int, required=False, default=1,
-                           help='Accepted for compatibility with the TensorFlow build (ignored)')
-    perf_args.add_argument('--omp_num_threads', type=int, required=False, default=12,
-                           help='Accepted for compatibility with the TensorFlow build (ignored)')
+        if args.subparser_name == 'classify':
+            from .classify import classify as run
+        else:
+            from .realtime import realtime as run
+        run(args)
 
 
 def check_classify_and_realtime_arguments(args):
-    """Reference deepbinner.py:283-317 (same messages; default two-model mode is
-    require_either, deepbinner.py:315-316)."""
-    if args.native and args.rapid:
+    """Preset resolution and option checks with the reference's messages (deepbinner.py:283-317);
+    with two models and no mode given the mode is require_either (:315-316)."""
+    chosen = [name for name in PRESETS if getattr(args, name)]
+    if len(chosen) > 1:
         sys.exit('Error: you can only use one model preset (--native or --rapid)')
-    if args.native or args.rapid:
-        preset_name = 'native' if args.native else 'rapid'
+    if chosen:
         if args.start_model is not None or args.end_model is not None:
             sys.exit('Error: you cannot explicitly specify a model and '
-                     'also use a model preset (--{})'.format(preset_name))
-    if args.native:
-        args.start_model = find_native_start_model()
-        args.end_model = find_native_end_model()
-    if args.rapid:
-        args.start_model = find_rapid_start_model()
+                     'also use a model preset (--{})'.format(chosen[0]))
+        start, end = PRESETS[chosen[0]]
+        args.start_model = find_model(start)
+        args.end_model = find_model(end) if end else None
 
-    model_count = (args.start_model is not None) + (args.end_model is not None)
-    if model_count == 0:
+    n_models = sum(m is not None for m in (args.start_model, args.end_model))
+    if n_models == 0:
         sys.exit('Error: you must provide at least one model')
-    if args.score_diff <= 0.0 or args.score_diff > 1.0:
+    if not 0.0 < args.score_diff <= 1.0:
         sys.exit('Error: --score_diff must be in the range (0, 1] (greater than 0 and less than or '
                  'equal to 1)')
-    for flag in ('require_either', 'require_start', 'require_both'):
-        if model_count < 2 and getattr(args, flag):
-            sys.exit('Error: --{} can only be used with two models (start and end)'.format(flag))
-    if two_model_args_used(args) > 1:
+    given = [flag for flag in TWO_MODEL_FLAGS if getattr(args, flag)]
+    if given and n_models < 2:
+        sys.exit('Error: --{} can only be used with two models (start and end)'.format(given[0]))
+    if len(given) > 1:
         sys.exit('Error: only one of the following options can be used: --require_either, '
                  '--require_start, --require_both')
-    if two_model_args_used(args) == 0:
+    if not given:
         args.require_either = True
     assert two_model_args_used(args) == 1
 
 
-def find_native_start_model():
-    return find_model('EXP-NBD103_read_starts')
-
-
-def find_native_end_model():
-    return find_model('EXP-NBD103_read_ends')
-
-
-def find_rapid_start_model():
-    return find_model('SQK-RBK004_read_starts')
+def two_model_args_used(args):
+    return sum(bool(getattr(args, flag)) for flag in TWO_MODEL_FLAGS)
 
 
 def find_model(model_name):
-    """Look where the reference looks (``models/`` beside or inside the package, reference
-    deepbinner.py:332-345) for the Keras file, then for this package's converted ``.dbw``."""
+    """Where the reference looks - ``models/`` beside or inside the package (deepbinner.py:332-345)
+    - first for the Keras file, then for this package's converted ``.dbw``."""
     here = pathlib.Path(__file__).resolve()
-    for base in (here.parents[1] / 'models', here.parents[0] / 'models'):
-        for name in (model_name, model_name + '.dbw'):
-            if (base / name).is_file():
-                return str(base / name)
+    candidates = [base / name
+                  for base in (here.parents[1] / 'models', here.parents[0] / 'models')
+                  for name in (model_name, model_name + '.dbw')]
+    for path in candidates:
+        if path.is_file():
+            return str(path)
     sys.exit('Error: could not find {} - did Deepbinner install correctly?'.format(model_name))
-
-
-def two_model_args_used(args):
-    return sum(1 for flag in (args.require_either, args.require_start, args.require_both) if flag)
 
 
 if __name__ == '__main__':

@@ -1,18 +1,19 @@
 """
-``deepbinner realtime`` — watch a directory during a sequencing run and sort fast5 files into
-``barcodeNN/`` / ``unclassified/`` — mirror of the reference's ``deepbinner/realtime.py``
-(``realtime`` :28-70, ``classify_and_move`` :81-108, ``move_classified_fast5s`` :111-143).
+``deepbinner realtime``: follow a directory while a sequencing run writes fast5 files into it and
+sort them into ``barcodeNN/`` / ``unclassified/`` under the output directory.
 
-Same polling loop, 20,000-single / 5-multi file caps per pass, ``ignore_files`` bookkeeping,
-directory names, progress and error text.  Difference: multi-read fast5 files are read directly
-with this package's HDF5 reader (``load_fast5s.iter_reads``) instead of being unpacked through the
-external ``multi_to_single_fast5`` tool into a temporary directory (reference :183-190); since a
-multi-read file holds reads of different barcodes it cannot be *moved* into one bin, so each pass
-appends ``read_id<TAB>barcode<TAB>source_file`` lines to ``<out_dir>/multi_read_classifications.tsv``
-and, when ``multi_to_single_fast5`` is installed, still unpacks and bins exactly as the reference.
+What the user sees is the reference's ``deepbinner/realtime.py`` (:28-196): a 5 s polling loop,
+at most 20,000 one-read files or 5 multi-read files per pass so that files start moving early,
+the same directory names, progress lines and error texts, ``--stop`` to exit once the input
+directory is drained.  How it is put together is this package's own: one ``Session`` object owns
+the models and the bookkeeping, a ``MoveTally`` does the filing, and multi-read files are
+classified straight from the container with this package's fast5 readers
+(``load_fast5s.iter_reads``) - the reference shells out to ``multi_to_single_fast5`` and bins the
+unpacked copies (:183-190), which is still done when that tool is installed.  A multi-read file
+holds reads of many barcodes and cannot be moved into one bin, so without the tool every pass
+appends ``read_id<TAB>barcode<TAB>source_file`` rows to ``<out_dir>/multi_read_classifications.tsv``.
 """
 
-import collections
 import os
 import pathlib
 import shutil
@@ -21,189 +22,173 @@ import sys
 import tempfile
 import time
 
-from .classify import load_and_check_models, classify_fast5_files, set_tensorflow_threads, \
-    classify_read_batch, chunker, print_classification_progress
+from . import classify
 from .load_fast5s import determine_single_or_multi_fast5s, iter_reads
 from .misc import print_summary_table
 
 POLL_SECONDS = 5
+PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
+
+
+def bin_name(barcode_call):
+    """Directory a call is filed under (reference realtime.py:146-150)."""
+    return 'unclassified' if barcode_call == 'none' else 'barcode%02d' % int(barcode_call)
+
+
+class MoveTally:
+    """Files one pass's fast5s into their bins and keeps count of what could not be moved."""
+
+    def __init__(self, out_dir, total):
+        self.out_dir, self.total = pathlib.Path(out_dir), total
+        self.moved = self.clashes = self.failures = 0
+
+    def _bin(self, barcode_call):
+        target = self.out_dir / bin_name(barcode_call)
+        if not target.is_dir():
+            try:
+                target.mkdir(parents=True)
+            except OSError:
+                sys.exit('Error: unable to create output directory {}'.format(target))
+        return target
+
+    def file(self, fast5_file, barcode_call, unmovable):
+        target = self._bin(barcode_call)
+        if (target / pathlib.Path(fast5_file).name).is_file():
+            self.clashes += 1
+            unmovable.add(fast5_file)          # never look at it again
+        else:
+            try:
+                shutil.move(fast5_file, str(target))
+                self.moved += 1
+            except OSError:
+                self.failures += 1
+        print('\rMoving fast5s:      {} / {} ({:.1f}%)'.format(
+            self.moved, self.total, 100.0 * self.moved / self.total), end='', flush=True)
+
+    def report(self):
+        print()
+        where = str(self.out_dir)
+        for count, one, many in (
+                (self.clashes,
+                 'Error: could not move 1 fast5 file because it already exists in {}',
+                 'Error: could not move {} fast5 files because they already exist in {}'),
+                (self.failures, 'Error: failed to move 1 fast5 file to {}',
+                 'Error: failed to move {} fast5 files to {}')):
+            if count == 1:
+                print(one.format(where))
+            elif count > 1:
+                print(many.format(count, where))
+        if self.failures == self.total:
+            sys.exit('Error: no files were successfully moved to {}'.format(where))
+
+
+class Session:
+    """One ``deepbinner realtime`` run: the loaded models plus what has been seen so far."""
+
+    def __init__(self, args):
+        self.args = args
+        args.verbose = False
+        self.in_dir, self.out_dir = pathlib.Path(args.in_dir), pathlib.Path(args.out_dir)
+        self.out_inside_in = self.in_dir in self.out_dir.parents
+        classify.set_tensorflow_threads(args)
+        (self.start_model, self.start_size, self.end_model, self.end_size, self.n_classes,
+         _) = classify.load_and_check_models(args.start_model, args.end_model, args.scan_size,
+                                             out_dest=sys.stdout)
+        self.unmovable = set()
+        self._prepare_out_dir()
+
+    def _prepare_out_dir(self):
+        if self.out_dir.is_file():
+            sys.exit('Error: {} is an existing file'.format(self.out_dir))
+        if not self.out_dir.is_dir():
+            try:
+                os.makedirs(str(self.out_dir), exist_ok=True)
+            except OSError:
+                sys.exit('Error: unable to create output directory {}'.format(self.out_dir))
+            print()
+            print('Making output directory: {}/'.format(self.out_dir))
+
+    def _models(self):
+        return (self.start_model, self.start_size, self.end_model, self.end_size, self.n_classes)
+
+    def waiting_files(self):
+        """fast5 files under in_dir that are neither already binned nor given up on."""
+        found = [str(p) for p in sorted(self.in_dir.glob('**/*.fast5'))]
+        if self.out_inside_in:
+            binned = {str(p) for p in self.out_dir.glob('**/*.fast5')}
+            found = [f for f in found if f not in binned]
+        return [f for f in found if f not in self.unmovable]
+
+    def handle(self, fast5s):
+        kind = determine_single_or_multi_fast5s(fast5s)
+        print()
+        print('Found {:,} fast5 files in {}'.format(len(fast5s), self.args.in_dir))
+        assert kind in PER_PASS
+        todo = fast5s[:PER_PASS[kind]]
+        if kind == 'single':
+            calls = self._bin_one_read_files(todo)
+        elif shutil.which('multi_to_single_fast5') is None:
+            self.unmovable.update(todo)
+            calls = self._tabulate_multi_read_files(todo)
+            print()
+        else:
+            self.unmovable.update(todo)
+            with tempfile.TemporaryDirectory() as scratch:
+                print('Unpacking fast5s with multi_to_single_fast5:')
+                for path in todo:
+                    subprocess.check_output(['multi_to_single_fast5', '-i', path, '-s', scratch])
+                print()
+                unpacked = [str(p) for p in sorted(pathlib.Path(scratch).glob('**/*.fast5'))]
+                calls = self._bin_one_read_files(unpacked)
+        print_summary_table(calls, output=sys.stdout)
+
+    def _bin_one_read_files(self, fast5s):
+        calls, source = classify.classify_fast5_files(
+            fast5s, *self._models(), self.args, full_output=False, verified_single_read=True)
+        print()
+        tally = MoveTally(self.out_dir, len(fast5s))
+        for read_id, call in calls.items():
+            tally.file(source[read_id], call, self.unmovable)
+        tally.report()
+        return calls
+
+    def _tabulate_multi_read_files(self, fast5s):
+        reads = [(read_id, signal, path) for path in fast5s for read_id, signal in iter_reads(path)]
+        calls, rows = {}, []
+        total = max(len(reads), 1)
+        classify.print_classification_progress(0, total, 'reads', out_dest=sys.stdout)
+        for chunk in classify.chunker(reads, self.args.batch_size):
+            ids = [r[0] for r in chunk]
+            classify.classify_read_batch(ids, [r[1] for r in chunk], *self._models(), self.args,
+                                         calls)
+            rows.extend('{}\t{}\t{}'.format(rid, calls[rid], path) for rid, _, path in chunk)
+            classify.print_classification_progress(len(calls), total, 'reads',
+                                                   out_dest=sys.stdout)
+        with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
+            table.writelines(row + '\n' for row in rows)
+        return calls
 
 
 def realtime(args):
+    """Entry point of the ``realtime`` sub-command (reference realtime.py:28-70)."""
     print()
-    args.verbose = False
-    nested_out_dir = pathlib.Path(args.in_dir) in pathlib.Path(args.out_dir).parents
-
-    set_tensorflow_threads(args)
-    start_model, start_input_size, end_model, end_input_size, output_size, model_count = \
-        load_and_check_models(args.start_model, args.end_model, args.scan_size,
-                              out_dest=sys.stdout)
-
-    make_output_dir(args.out_dir)
+    session = Session(args)
+    idle_announced = False
     try:
-        waiting = False
-        ignore_files = set()
         while True:
-            fast5s = look_for_new_fast5s(args.in_dir, args.out_dir, nested_out_dir)
-            fast5s = [x for x in fast5s if x not in ignore_files]
-            single_or_multi = determine_single_or_multi_fast5s(fast5s)
-
+            fast5s = session.waiting_files()
             if fast5s:
-                time.sleep(POLL_SECONDS)  # let any in-flight file moves finish
-                classify_and_move(fast5s, single_or_multi, args, start_model, start_input_size,
-                                  end_model, end_input_size, output_size, ignore_files)
-                waiting = False
-            elif args.stop:
-                break
+                time.sleep(POLL_SECONDS)        # let files that are still being written settle
+                session.handle(fast5s)
+                idle_announced = False
+                continue
+            if args.stop:
+                return
+            if idle_announced:
+                print('.', end='', flush=True)
             else:
-                if waiting:
-                    print('.', end='', flush=True)
-                else:
-                    print('\nWaiting for new fast5 files (Ctrl-C to stop)', end='', flush=True)
-                    waiting = True
-                time.sleep(POLL_SECONDS)
+                print('\nWaiting for new fast5 files (Ctrl-C to stop)', end='', flush=True)
+                idle_announced = True
+            time.sleep(POLL_SECONDS)
     except KeyboardInterrupt:
         print('\n\nStopping Deepbinner real-time binning\n')
-
-
-def look_for_new_fast5s(in_dir, out_dir, nested_out_dir):
-    in_dir_fast5s = [str(x) for x in sorted(pathlib.Path(in_dir).glob('**/*.fast5'))]
-    if nested_out_dir:
-        out_dir_fast5s = set(str(x) for x in sorted(pathlib.Path(out_dir).glob('**/*.fast5')))
-        in_dir_fast5s = [x for x in in_dir_fast5s if x not in out_dir_fast5s]
-    return in_dir_fast5s
-
-
-def classify_and_move(fast5s, single_or_multi, args, start_model, start_input_size, end_model,
-                      end_input_size, output_size, ignore_files):
-    print()
-    print('Found {:,} fast5 files in {}'.format(len(fast5s), args.in_dir))
-
-    # Work on a subset per pass so files start moving soon (reference realtime.py:86-94).
-    if single_or_multi == 'single':
-        fast5s = fast5s[:20000]
-    elif single_or_multi == 'multi':
-        fast5s = fast5s[:5]
-    else:
-        assert False
-
-    if single_or_multi == 'multi' and shutil.which('multi_to_single_fast5') is None:
-        ignore_files.update(fast5s)
-        classifications = classify_multi_read_fast5s(fast5s, args, start_model, start_input_size,
-                                                     end_model, end_input_size, output_size)
-        print()
-        print_summary_table(classifications, output=sys.stdout)
-        return
-
-    with tempfile.TemporaryDirectory() as temp_single_read_dir:
-        if single_or_multi == 'multi':
-            ignore_files.update(fast5s)
-            fast5s = unpack_multi_read_fast5s(fast5s, temp_single_read_dir)
-
-        classifications, read_id_to_fast5_file = \
-            classify_fast5_files(fast5s, start_model, start_input_size, end_model, end_input_size,
-                                 output_size, args, full_output=False, verified_single_read=True)
-        print()
-        move_classified_fast5s(classifications, read_id_to_fast5_file, args, fast5s, ignore_files)
-        print_summary_table(classifications, output=sys.stdout)
-
-
-def classify_multi_read_fast5s(fast5s, args, start_model, start_input_size, end_model,
-                               end_input_size, output_size):
-    """Classify every read of the given multi-read files straight from the container."""
-    reads = []
-    for path in fast5s:
-        for read_id, signal in iter_reads(path):
-            reads.append((read_id, signal, path))
-    classifications = {}
-    total = max(len(reads), 1)
-    print_classification_progress(0, total, 'reads', out_dest=sys.stdout)
-    rows = []
-    for batch in chunker(reads, args.batch_size):
-        ids = [r[0] for r in batch]
-        classify_read_batch(ids, [r[1] for r in batch], start_model, start_input_size, end_model,
-                            end_input_size, output_size, args, classifications)
-        rows += ['{}\t{}\t{}'.format(r[0], classifications[r[0]], r[2]) for r in batch]
-        print_classification_progress(len(classifications), total, 'reads', out_dest=sys.stdout)
-    with open(os.path.join(args.out_dir, 'multi_read_classifications.tsv'), 'at') as out:
-        for row in rows:
-            print(row, file=out)
-    return classifications
-
-
-def move_classified_fast5s(classifications, read_id_to_fast5_file, args, fast5s, ignore_files):
-    move_count, fail_move_already_exists, fail_move_other_reason = 0, 0, 0
-    counts = collections.defaultdict(int)
-    for read_id, barcode_call in classifications.items():
-        fast5_file = read_id_to_fast5_file[read_id]
-
-        out_dir = pathlib.Path(args.out_dir) / get_directory_name(barcode_call)
-        if not out_dir.is_dir():
-            try:
-                os.makedirs(str(out_dir))
-            except OSError:
-                sys.exit('Error: unable to create output directory {}'.format(out_dir))
-
-        dest_filepath = out_dir / pathlib.Path(fast5_file).name
-        if dest_filepath.is_file():
-            fail_move_already_exists += 1
-            ignore_files.add(fast5_file)
-        else:
-            try:
-                shutil.move(fast5_file, str(out_dir))
-                move_count += 1
-            except OSError:
-                fail_move_other_reason += 1
-
-        counts[barcode_call] += 1
-        print_moving_progress(move_count, len(fast5s))
-
-    print()
-    print_moving_error_messages(fail_move_already_exists, fail_move_other_reason, args.out_dir)
-
-    if fail_move_other_reason == len(fast5s):
-        sys.exit('Error: no files were successfully moved to {}'.format(args.out_dir))
-
-
-def get_directory_name(barcode_call):
-    if barcode_call == 'none':
-        return 'unclassified'
-    return 'barcode{:02d}'.format(int(barcode_call))
-
-
-def print_moving_error_messages(already_exists, other_reason, out_dir):
-    if already_exists == 1:
-        print('Error: could not move 1 fast5 file because it already exists in {}'.format(out_dir))
-    elif already_exists > 1:
-        print('Error: could not move {} fast5 files because they already exist '
-              'in {}'.format(already_exists, out_dir))
-    if other_reason == 1:
-        print('Error: failed to move 1 fast5 file to {}'.format(out_dir))
-    elif other_reason > 1:
-        print('Error: failed to move {} fast5 files to {}'.format(other_reason, out_dir))
-
-
-def make_output_dir(out_dir):
-    if pathlib.Path(out_dir).is_file():
-        sys.exit('Error: {} is an existing file'.format(out_dir))
-    if not pathlib.Path(out_dir).is_dir():
-        try:
-            os.makedirs(out_dir, exist_ok=True)
-            print()
-            print('Making output directory: {}/'.format(out_dir))
-        except OSError:
-            sys.exit('Error: unable to create output directory {}'.format(out_dir))
-
-
-def print_moving_progress(completed, total):
-    percent = 100.0 * completed / total
-    print('\rMoving fast5s:      {} / {} ({:.1f}%)'.format(completed, total, percent),
-          end='', flush=True)
-
-
-def unpack_multi_read_fast5s(fast5s, temp_single_read_dir):
-    print('Unpacking fast5s with multi_to_single_fast5:')
-    for fast5 in fast5s:
-        subprocess.check_output(['multi_to_single_fast5', '-i', fast5, '-s', temp_single_read_dir])
-    print()
-    return [str(x) for x in sorted(pathlib.Path(temp_single_read_dir).glob('**/*.fast5'))]
