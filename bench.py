@@ -144,6 +144,9 @@ def main():
     else:
         d_calls = hip_backend.DeviceBuffer(N_READS * 4)
         calls_ptr = d_calls.ptr
+    # the synthetic reads are all 1,024 samples long: say so (checked on the device per read)
+    if os.environ.get('DEEPBINNER_BENCH_NO_HINT') != '1':      # (A/B knob)
+        model.set_read_length_hint(1024, N_READS * 1024)
     # One C-ABI call per step: the library walks the 10,000 reads in batches of 256, one fused
     # kernel launch per batch, back to back on one stream - which is also where the HIP events
     # that time every launch are recorded.

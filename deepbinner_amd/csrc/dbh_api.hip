@@ -161,6 +161,7 @@ struct dbh_model {
         void* d_work = nullptr; size_t d_work_bytes = 0;
     } slot[2];
     // live timing of the forward kernel (dbh_forward_timing_*)
+    int64_t hint_len = 0, hint_cap = 0;   // dbh_model_set_read_length_hint
     int timing = 0;              // 0 = off, n = open an event bracket at every n-th forward launch
     int timing_span = 1;         // consecutive launches one bracket covers (<= timing)
     hipEvent_t open_stop = nullptr;   // stop event of the bracket being filled
@@ -193,6 +194,9 @@ struct FusedInput {          // seam-b2 mode of the forward kernel (all null/zer
     int side = 0;
     double score_diff = 0.0;
     int32_t* calls = nullptr;
+    // "every read is len_hint samples long": offsets[0] belongs to read number read0 of the
+    // sample buffer, which holds at least hint_cap samples (see dbh_model_set_read_length_hint)
+    int64_t read0 = 0, len_hint = 0, hint_cap = 0;
 };
 
 int ensure_host(void** ptr, size_t* have, size_t need) {
@@ -247,7 +251,9 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
                            in.samples,
                            in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr,
                            in.steps, in.side, in.score_diff,
-                           in.calls ? (int*)(in.calls + off / in.steps) : nullptr);
+                           in.calls ? (int*)(in.calls + off / in.steps) : nullptr,
+                           (long long)(in.read0 + off / in.steps), (long long)in.len_hint,
+                           (long long)in.hint_cap);
         DBH_HIP(hipGetLastError());
         if (ev_stop) {
             DBH_HIP(hipEventRecord(ev_stop, stream));
@@ -527,10 +533,13 @@ int dbh_classify_workspace_bytes(const dbh_model* m, int64_t n_reads, int scan_s
     return DBH_OK;
 }
 
-int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* offsets_dev,
-                         int64_t n_reads, int side, int scan_size, double score_diff,
-                         float* probs_dev, int32_t* calls_dev, void* workspace_dev,
-                         dbh_stream stream) {
+}  // extern "C"
+
+namespace {
+int classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* offsets_dev,
+                     int64_t n_reads, int side, int scan_size, double score_diff,
+                     float* probs_dev, int32_t* calls_dev, void* workspace_dev, dbh_stream stream,
+                     int64_t read0, int64_t len_hint, int64_t hint_cap) {
     if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
     const int steps = steps_for(scan_size);
@@ -544,6 +553,9 @@ int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t
     in.steps = steps;
     in.side = side;
     in.score_diff = score_diff;
+    in.read0 = read0;
+    in.len_hint = len_hint;
+    in.hint_cap = hint_cap;
     if (steps == 1) {
         // one window per read: slice + normalise + CNN + renormalise + call in ONE launch
         in.calls = calls_dev;
@@ -558,6 +570,26 @@ int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t
     if (st != DBH_OK) return st;
     return dbh_merge_calls_dev(wprobs, n_reads, steps, m->n_classes, score_diff, probs_dev,
                                calls_dev, stream);
+}
+}  // namespace
+
+extern "C" {
+
+int dbh_model_set_read_length_hint(dbh_model* m, int64_t read_length, int64_t capacity_samples) {
+    if (!m || read_length < 0 || capacity_samples < 0) return DBH_ERR_INVALID_ARGUMENT;
+    m->hint_len = read_length;
+    m->hint_cap = read_length > 0 ? capacity_samples : 0;
+    return DBH_OK;
+}
+
+int dbh_classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* offsets_dev,
+                         int64_t n_reads, int side, int scan_size, double score_diff,
+                         float* probs_dev, int32_t* calls_dev, void* workspace_dev,
+                         dbh_stream stream) {
+    if (!m) return DBH_ERR_INVALID_ARGUMENT;
+    return classify_i16_dev(m, samples_dev, offsets_dev, n_reads, side, scan_size, score_diff,
+                            probs_dev, calls_dev, workspace_dev, stream, 0, m->hint_len,
+                            m->hint_cap);
 }
 
 int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
@@ -575,8 +607,9 @@ int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
     // CNN launches run back to back and the workspace can be reused batch after batch
     for (int64_t r0 = 0; r0 < n_reads; r0 += batch_size) {
         const int64_t cnt = (n_reads - r0 < batch_size) ? (n_reads - r0) : batch_size;
-        st = dbh_classify_i16_dev(m, samples_dev, offsets_dev + r0, cnt, side, scan_size, score_diff,
-                                  probs_dev + r0 * m->n_classes, calls_dev + r0, m->d_work, stream);
+        st = classify_i16_dev(m, samples_dev, offsets_dev + r0, cnt, side, scan_size, score_diff,
+                              probs_dev + r0 * m->n_classes, calls_dev + r0, m->d_work, stream, r0,
+                              m->hint_len, m->hint_cap);
         if (st != DBH_OK) return st;
     }
     return DBH_OK;
@@ -638,13 +671,17 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         }
         int64_t* rel = (int64_t*)((char*)sl.h_in + sample_bytes);
         for (int64_t i = 0; i <= cnt; ++i) rel[i] = offsets_host[r0 + i] - s0;
+        // all reads of the group equally long?  then the kernel need not wait for the offsets
+        int64_t uniform = rel[1];
+        for (int64_t i = 1; i <= cnt && uniform > 0; ++i)
+            if (rel[i] != i * uniform) uniform = 0;
         DBH_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, sl.stream));
         float* d_probs = (float*)sl.d_out;
         int32_t* d_calls = (int32_t*)((char*)sl.d_out + (size_t)cnt * C * sizeof(float));
-        st = dbh_classify_i16_dev(m, (const int16_t*)sl.d_in,
-                                  (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side,
-                                  scan_size, score_diff, d_probs, d_calls, sl.d_work,
-                                  (dbh_stream)sl.stream);
+        st = classify_i16_dev(m, (const int16_t*)sl.d_in,
+                              (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side, scan_size,
+                              score_diff, d_probs, d_calls, sl.d_work, (dbh_stream)sl.stream, 0,
+                              uniform, s1 - s0);
         if (st != DBH_OK) return st;
         DBH_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream));
         pending[k].r0 = r0;
@@ -710,7 +747,37 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
     DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
     hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0,
                        0, m->d_packed, (const float*)m->d_in, (float*)m->d_out, m->n_classes, 300,
-                       (float*)m->d_work, nullptr, nullptr, 1, 0, 0.0, nullptr);
+                       (float*)m->d_work, nullptr, nullptr, 1, 0, 0.0, nullptr, 0LL, 0LL, 0LL);
+    DBH_HIP(hipGetLastError());
+    DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
+    DBH_HIP(hipStreamSynchronize(0));
+    return DBH_OK;
+}
+
+int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t n,
+                             int64_t* stamps_host) {
+    if (!m || n <= 0 || !samples_host || !stamps_host) return DBH_ERR_INVALID_ARGUMENT;
+    const size_t stamp_bytes = (size_t)n * dbh::kWaves * 64 * sizeof(int64_t);
+    const size_t sample_bytes = (size_t)n * dbh::kWindow * sizeof(int16_t);
+    const size_t offset_bytes = (size_t)(n + 1) * sizeof(int64_t);
+    int st = ensure(&m->d_in, &m->in_bytes, sample_bytes + offset_bytes + 16);
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_work, &m->work_bytes, stamp_bytes);
+    if (st != DBH_OK) return st;
+    st = ensure(&m->d_out, &m->out_bytes, (size_t)n * (m->n_classes + 1) * sizeof(float));
+    if (st != DBH_OK) return st;
+    std::vector<int64_t> offsets((size_t)n + 1);
+    for (int64_t i = 0; i <= n; ++i) offsets[(size_t)i] = i * dbh::kWindow;
+    char* d_offsets = (char*)m->d_in + ((sample_bytes + 7) & ~(size_t)7);
+    DBH_HIP(hipMemcpyAsync(m->d_in, samples_host, sample_bytes, hipMemcpyHostToDevice, 0));
+    DBH_HIP(hipMemcpyAsync(d_offsets, offsets.data(), offset_bytes, hipMemcpyHostToDevice, 0));
+    DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
+    DBH_HIP(hipStreamSynchronize(0));
+    hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0,
+                       0, m->d_packed, nullptr, (float*)m->d_out, m->n_classes, 300,
+                       (float*)m->d_work, (const int16_t*)m->d_in, (const long long*)d_offsets, 1,
+                       0, 0.5, (int*)((float*)m->d_out + n * m->n_classes), 0LL,
+                       (long long)m->hint_len, (long long)m->hint_cap);
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
     DBH_HIP(hipStreamSynchronize(0));

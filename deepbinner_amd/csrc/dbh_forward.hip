@@ -1344,16 +1344,22 @@ __device__ __forceinline__ void window_bounds(long long len, int step, int side,
     }
 }
 
-// mean and population standard deviation from exact integer sums (trim_signal.py:61-69)
+// z-normalisation constants from exact integer sums (trim_signal.py:61-69): x -> (x - mean) * inv
+// with mean = sum(x)/n and inv = 1/std = n / sqrt(n*sum(x^2) - sum(x)^2), the radicand exact in
+// int64; inv = 1 when std is 0 (the reference then only subtracts the mean).  Two fp64 divisions
+// and one square root per window instead of a division per sample: fp64 division is ~20
+// instructions at half rate, and stage A has nothing to hide them behind.  The product differs
+// from the reference's quotient by at most one fp64 ulp before the cast to fp32 (the parity
+// tests allow one fp32 ulp; both normalising kernels share this function, so they agree to the
+// bit with each other).
 __device__ __forceinline__ void mean_std(long long s1, long long s2, int cnt, double* mean,
-                                         double* stdev) {
+                                         double* inv) {
     *mean = 0.0;
-    *stdev = 0.0;
+    *inv = 1.0;
     if (cnt > 0) {
         *mean = (double)s1 / (double)cnt;
-        // population variance = (n*sum(x^2) - sum(x)^2) / n^2, numerator exact in int64
         const long long num = (long long)cnt * s2 - s1 * s1;
-        *stdev = sqrt((double)num) / (double)cnt;
+        if (num > 0) *inv = (double)cnt / sqrt((double)num);
     }
 }
 
@@ -1371,7 +1377,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, float* __restrict__ probs,
     int n_classes, int debug_stage, float* __restrict__ debug_out,
     const int16_t* __restrict__ samples, const long long* __restrict__ offsets, int steps,
-    int side, double score_diff, int* __restrict__ calls) {
+    int side, double score_diff, int* __restrict__ calls, long long read0, long long len_hint,
+    long long hint_cap) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
     const int tid = threadIdx.x;
@@ -1394,8 +1401,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     {
         // conv2's transformed weights: (V0,V1) -> slot 0, (V2,V3) -> slot 1; (V4,V5) follow
         // during conv2's own first phase
-        dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
-        dma_weights<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
+        auto fetch_conv2_weights = [&] {
+            dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
+            dma_weights<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
+        };
+        // seam b1: at once.  Seam b2: only after the barrier of the window statistics - a barrier
+        // retires every outstanding request of the wave, and waiting there for 36 KB of weights
+        // (~3.5k cycles at the cold start of a launch) would hold up the normalisation for
+        // nothing; issued behind it, they arrive under the normalisation, conv1 and its epilogue.
+        if (samples == nullptr) fetch_conv2_weights();
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
         float a[MT], bw[3];
@@ -1424,23 +1438,34 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
             const long long read = win / steps;
             const int step = (int)(win - read * steps);
-            const long long base = offsets[read];
-            long long wa, wb;
-            window_bounds(offsets[read + 1] - base, step, side, &wa, &wb);
-            const int cnt = (int)(wb - wa);
-            const int16_t* src = samples + base + wa;
-            const int pad_left = (side == 0) ? 0 : kWindow - cnt;
-            // this lane's two samples for the statistics and its A-fragment samples, together
-            const int v0 = tid < cnt ? (int)src[tid] : 0;
-            const int v1 = tid + kThreads < cnt ? (int)src[tid + kThreads] : 0;
-            int raw[MT];
+            int cnt, v0, v1, raw[MT];
             bool inside[MT];
+            // this lane's two samples for the statistics and its A-fragment samples, together
+            auto fetch = [&](long long base, long long len) {
+                long long wa, wb;
+                window_bounds(len, step, side, &wa, &wb);
+                cnt = (int)(wb - wa);
+                const int16_t* src = samples + base + wa;
+                const int pad_left = (side == 0) ? 0 : kWindow - cnt;
+                v0 = tid < cnt ? (int)src[tid] : 0;
+                v1 = tid + kThreads < cnt ? (int)src[tid + kThreads] : 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
-                inside[m] = q < 3 && k >= 0 && k < cnt;
-                raw[m] = inside[m] ? (int)src[k] : 0;
-            }
+                for (int m = 0; m < MT; ++m) {
+                    const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
+                    inside[m] = q < 3 && k >= 0 && k < cnt;
+                    raw[m] = inside[m] ? (int)src[k] : 0;
+                }
+            };
+            // Where a read starts is itself in memory (offsets[read]), and at the top of a kernel
+            // a dependent load costs ~3k cycles.  If the caller says that all reads are len_hint
+            // samples long, the samples are requested from where that puts them TOGETHER with the
+            // offsets, and fetched again only if the offsets disagree.
+            const long long guess = (read0 + read) * len_hint;
+            const bool speculate = len_hint > 0 && guess + len_hint <= hint_cap;
+            if (speculate) fetch(guess, len_hint);
+            const long long base = offsets[read];
+            const long long len = offsets[read + 1] - base;
+            if (!speculate || base != guess || len != len_hint) fetch(base, len);
             // exact integer sums: sum(x) and sum(x^2) split in 16-bit halves so that every
             // wave-wide partial stays below 2^31
             const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
@@ -1458,24 +1483,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                 red[kWaves + wave] = ((long long)w_hi << 16) + (long long)w_lo;
             }
             __syncthreads();
+            fetch_conv2_weights();
             long long s1 = 0, s2 = 0;
 #pragma unroll
             for (int i = 0; i < kWaves; ++i) {
                 s1 += red[i];
                 s2 += red[kWaves + i];
             }
-            double mean, stdev;
-            mean_std(s1, s2, cnt, &mean, &stdev);
-            const bool divide = stdev > 0.0;
+            double mean, inv;
+            mean_std(s1, s2, cnt, &mean, &inv);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float v = 0.f;
-                if (inside[m]) {
-                    const double d = (double)raw[m] - mean;
-                    v = (float)(divide ? d / stdev : d);
-                }
-                a[m] = v;
-            }
+            for (int m = 0; m < MT; ++m)
+                a[m] = inside[m] ? (float)(((double)raw[m] - mean) * inv) : 0.f;
         }
         f4 acc[MT][3];
 #pragma unroll
@@ -1483,8 +1502,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc[m][t] = mfma4(a[m], bw[t], f4{0.f, 0.f, 0.f, 0.f});
+        mark(ts, 59);
         float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
         epilogue<MT, 3, kS48, false, true>(acc, out_lane, ep);
+        mark(ts, 60);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
 #pragma unroll
@@ -1797,17 +1818,13 @@ __global__ __launch_bounds__(256) void dbh_normalise_kernel(
     s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 
     float* out = windows + (long long)blockIdx.x * kWindow;
-    double mean, stdev;
-    mean_std(s1, s2, cnt, &mean, &stdev);
-    const bool divide = stdev > 0.0;
+    double mean, inv;
+    mean_std(s1, s2, cnt, &mean, &inv);
     const int pad_left = (side == 0) ? 0 : kWindow - cnt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = tid + i * 256;          // position in the source slice
-        if (k < cnt) {
-            const double d = (double)v[i] - mean;
-            out[pad_left + k] = (float)(divide ? d / stdev : d);
-        }
+        if (k < cnt) out[pad_left + k] = (float)(((double)v[i] - mean) * inv);
     }
     // zero padding: [cnt, 1024) for 'start', [0, 1024-cnt) for 'end'
     const int pad_begin = (side == 0) ? cnt : 0;

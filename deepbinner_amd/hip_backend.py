@@ -110,6 +110,9 @@ def load_library():
         'dbh_forward_truncated_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
         'dbh_forward_timeline': (c_int, [c_void_p, _f32(), c_i64,
                                          ndpointer(np.int64, flags='C_CONTIGUOUS')]),
+        'dbh_model_set_read_length_hint': (c_int, [c_void_p, c_i64, c_i64]),
+        'dbh_forward_timeline_i16': (c_int, [c_void_p, np.ctypeslib.ndpointer(np.int16, flags='C_CONTIGUOUS'),
+                                     c_i64, np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')]),
         'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_timing_enable_span': (c_int, [c_void_p, c_int, c_int]),
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
@@ -128,11 +131,11 @@ EXPORTED_SYMBOLS = [
     'dbh_malloc_host', 'dbh_free_host', 'dbh_memcpy_h2d', 'dbh_memcpy_d2h', 'dbh_memcpy_d2d',
     'dbh_stream_create', 'dbh_stream_destroy', 'dbh_stream_synchronize', 'dbh_event_create',
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
-    'dbh_model_create', 'dbh_model_destroy', 'dbh_model_input_size', 'dbh_model_output_size',
+    'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
-    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
+    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
     'dbh_forward_timing_read',
 ]
 
@@ -372,6 +375,20 @@ class HipModel:
         out = np.zeros((x.shape[0], 8, 64), dtype=np.int64)
         check(self._lib.dbh_forward_timeline(self._handle, x, x.shape[0], out),
               'dbh_forward_timeline')
+        return out
+
+    def set_read_length_hint(self, read_length, capacity_samples=0):
+        """Tell the ``*_dev`` entry points that every read is ``read_length`` samples long (0
+        clears it); the hint is checked on the device, a wrong one only costs time."""
+        check(self._lib.dbh_model_set_read_length_hint(self._handle, int(read_length),
+                                                       int(capacity_samples)),
+              'dbh_model_set_read_length_hint')
+
+    def timeline_i16(self, reads):
+        reads = np.ascontiguousarray(np.asarray(reads, dtype=np.int16).reshape(-1, self.input_size))
+        out = np.zeros((reads.shape[0], 8, 64), dtype=np.int64)
+        check(self._lib.dbh_forward_timeline_i16(self._handle, reads, reads.shape[0], out),
+              'dbh_forward_timeline_i16')
         return out
 
     def timing_enable(self, every_nth=1, span=1):

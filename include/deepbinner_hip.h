@@ -99,6 +99,15 @@ int dbh_predict_dev(dbh_model* model, const float* x_dev, int64_t n_windows, flo
 int dbh_classify_i16(dbh_model* model, const int16_t* samples_host, const int64_t* offsets_host,
                      int64_t n_reads, int side, int scan_size, double score_diff,
                      float* probs_host, int32_t* calls_host);
+/* Optional hint for the *_dev entry points: "every read in the sample buffer is read_length
+ * samples long and the buffer holds at least capacity_samples samples".  The forward kernel then
+ * requests a read's samples from read_index * read_length TOGETHER with offsets[read_index]
+ * instead of after it (a dependent load costs ~3k cycles at the top of a kernel) and fetches
+ * again from the true place wherever the offsets disagree, so a wrong hint costs time, never
+ * correctness; speculative addresses beyond capacity_samples are not touched.  read_length 0
+ * clears the hint.  dbh_classify_i16 (host buffers) works this out per group by itself. */
+int dbh_model_set_read_length_hint(dbh_model* model, int64_t read_length,
+                                   int64_t capacity_samples);
 /* device-resident variant; workspace_dev must hold dbh_classify_workspace_bytes() bytes (unused,
  * and may be NULL, when scan_size is 512: the whole read then finishes inside one launch). */
 int dbh_classify_workspace_bytes(const dbh_model* model, int64_t n_reads, int scan_size,
@@ -142,6 +151,10 @@ int dbh_forward_truncated_dev(dbh_model* model, const float* x_dev, int64_t n_wi
  * each phase boundary (slot meanings: tools/timeline.py).  stamps_host: n_windows x 8 x 64 int64. */
 int dbh_forward_timeline(dbh_model* model, const float* x_host, int64_t n_windows,
                          int64_t* stamps_host);
+/* The same for the fused seam-b2 mode: n_reads reads of exactly 1,024 int16 samples each (side
+ * start, one scan step), so that the slice + normalise front of stage A is on the timeline. */
+int dbh_forward_timeline_i16(dbh_model* model, const int16_t* samples_host, int64_t n_reads,
+                             int64_t* stamps_host);
 /* Live kernel timing: with enable = n > 0, every n-th launch of the forward kernel is bracketed by
  * HIP events on the stream it is launched on (n = 1: every launch; the event pair itself costs a
  * few microseconds of queue time, so sampling keeps the measurement from slowing what it

@@ -102,6 +102,44 @@ def test_predict_is_order_and_batch_independent(hip_models):
     assert np.abs(full[:64] - want).max() < PROB_TOL
 
 
+def test_read_length_hint_never_changes_results(hip, weights):
+    """dbh_model_set_read_length_hint: right, wrong, too-small-capacity and ragged cases all give
+    bit-identical probabilities and calls (the device re-fetches wherever the offsets disagree)."""
+    model = hip.HipModel(weights['EXP-NBD103_read_starts'], device=0)
+    rng = np.random.default_rng(5)
+    uniform = rng.integers(200, 900, size=(300, 1024)).astype(np.int16)
+    ragged = [rng.integers(200, 900, size=int(n)).astype(np.int16)
+              for n in rng.integers(0, 3000, size=200)]
+
+    def run(reads, scan, side):
+        samples = np.concatenate([np.asarray(r).reshape(-1) for r in reads]) if len(reads) else \
+            np.empty(0, np.int16)
+        lengths = np.array([len(r) for r in reads], dtype=np.int64)
+        offsets = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+        d_s = hip.DeviceBuffer.from_array(samples if samples.size else np.zeros(1, np.int16))
+        d_o = hip.DeviceBuffer.from_array(offsets)
+        n = len(reads)
+        d_p = hip.DeviceBuffer(n * model.n_classes * 4)
+        d_c = hip.DeviceBuffer(n * 4)
+        model.classify_batched_dev(d_s.ptr, d_o.ptr, n, 64, side, scan, 0.5, d_p.ptr, d_c.ptr,
+                                   None)
+        hip.synchronize()
+        return d_p.download((n, model.n_classes), np.float32), d_c.download((n,), np.int32)
+
+    for reads, scan, side in ((uniform, 512, 'start'), (uniform, 1024, 'end'),
+                              (ragged, 512, 'start'), (ragged, 1024, 'end')):
+        model.set_read_length_hint(0)
+        want = run(reads, scan, side)
+        total = sum(len(r) for r in reads)
+        for hint, cap in ((1024, total), (1024, total // 2), (1000, total), (1024, 10 * total),
+                          (4096, total)):
+            model.set_read_length_hint(hint, min(cap, total))      # never beyond the buffer
+            got = run(reads, scan, side)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), \
+                (hint, cap, scan, side)
+    model.set_read_length_hint(0)
+
+
 def test_live_kernel_timing_brackets(hip_models):
     """dbh_forward_timing_*: one event pair per run of `span` launches at every n-th launch; only
     closed brackets are reported, and timing does not change results."""

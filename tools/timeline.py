@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Cycle-accurate phase timeline of the forward kernel (dbh_forward_timeline): average, over all
 workgroups of one 256-window launch, of the per-phase durations seen by the slowest wave.
-Usage: python tools/timeline.py [n_windows]"""
+Usage: python tools/timeline.py [n_windows]      (DEEPBINNER_TIMELINE_FUSED=1: the fused seam-b2
+mode - int16 reads in - instead of normalised fp32 windows)"""
 import json
 import os
 import sys
@@ -24,7 +25,7 @@ for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
     for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
         NAMES[base + j] = '%s %s' % (l, what)
 NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
-EXTRA = {58: 'conv2 prologue done', 56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
+EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 58: 'conv2 prologue done', 56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
 
 
 def main():
@@ -34,8 +35,14 @@ def main():
     model = hip_backend.HipModel(w, device=0)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((n, 1024)).astype(np.float32)
-    model.timeline(x)                       # warm-up
-    st = model.timeline(x)                  # [n, 8 waves, 64]
+    fused = os.environ.get('DEEPBINNER_TIMELINE_FUSED') == '1'
+    if fused:   # seam-b2 mode: int16 reads of 1,024 samples in, slice + normalise fused in stage A
+        x = np.clip(np.rint(x * 60 + 450), 0, 2047).astype(np.int16)
+        if os.environ.get('DEEPBINNER_TIMELINE_HINT') == '1':
+            model.set_read_length_hint(1024, x.size)
+    run = model.timeline_i16 if fused else model.timeline
+    run(x)                                  # warm-up
+    st = run(x)                             # [n, 8 waves, 64]
     ids = sorted(NAMES)
     t0 = st[:, :, 0].min(axis=1, keepdims=True)          # block start
     rel = st[:, :, ids] - t0[:, :, None]                 # cycles since block start
