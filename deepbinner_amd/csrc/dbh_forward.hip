@@ -1600,11 +1600,21 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     {
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
-        for (int idx = tid; idx < 64 * 48; idx += kThreads) {
-            const int p = idx / 48, c = idx - p * 48;
-            const float s = X[p * kS48 + c] + X[(p + 1) * kS48 + c] + X[(p + 2) * kS48 + c];
-            const float cnt = (p == 0 || p == 63) ? 2.f : 3.f;
-            lds[kEAP + (p + 1) * kS48 + c] = s / cnt;
+        // 384 threads, each one channel and eight consecutive positions: ten row reads for eight
+        // outputs (three per output the naive way)
+        if (tid < 8 * 48) {
+            const int g = tid / 48, c = tid - g * 48;
+            float x[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) x[i] = X[(8 * g + i) * kS48 + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = 8 * g + j;
+                // x (1/count), not / count: an fp32 division is ten instructions, and one ulp of
+                // the quotient is far inside the tolerance
+                const float inv = (p == 0 || p == 63) ? 0.5f : (1.f / 3.f);
+                lds[kEAP + (p + 1) * kS48 + c] = (x[j] + x[j + 1] + x[j + 2]) * inv;
+            }
         }
         zero_row(lds + kET3, 0, kS16, 16, tid);
         zero_row(lds + kET3, 65, kS16, 16, tid);
