@@ -206,7 +206,8 @@ def main():
         'config': {'workload': 'BASELINE.json configs[1]: {} model, {} synthetic 1024-sample int16 '
                                'signals per GPU per step, batch {}, seam b2 (slice + normalise + '
                                'CNN + renormalise + call fused in one launch per batch), '
-                               'scan_size {} => 1 window per read, inputs resident in HBM'.format(MODEL, N_READS, BATCH, SCAN_SIZE),
+                               'scan_size {} => 1 window per read, inputs resident in HBM, uniform read '
+                               'length declared (dbh_model_set_read_length_hint)'.format(MODEL, N_READS, BATCH, SCAN_SIZE),
                    'reads_per_step_per_gpu': N_READS, 'batch': BATCH, 'windows_per_read': 1,
                    'launches_per_batch': 1,
                    'parallelism': 'reads sharded, {} rank(s), RCCL all_gather of calls'.format(world)
