@@ -119,7 +119,10 @@ class File:
             raise KeyError('read {} (read_id / Signal)'.format(index))
         if status != F5_OK:
             raise Fast5NativeError(status_string(status))
-        return rid.value.decode(), n.value
+        try:
+            return rid.value.decode(), n.value
+        except UnicodeDecodeError:
+            raise KeyError('read {}: read_id is not text'.format(index)) from None
 
     def read_signal(self, index, first=0, count=None):
         _, n = self.read_info(index)
@@ -194,5 +197,9 @@ def load_batch(fast5_files, keep=None, threads=0):
     read_ids = []
     for i in range(n):
         slot = raw[i * F5_READ_ID_MAX:(i + 1) * F5_READ_ID_MAX]
-        read_ids.append(slot.split(b'\x00')[0].decode() if st[i] == F5_OK else None)
+        try:
+            read_ids.append(slot.split(b'\x00')[0].decode() if st[i] == F5_OK else None)
+        except UnicodeDecodeError:          # a damaged id: treat the file as unreadable
+            read_ids.append(None)
+            st[i] = F5_ERR_FORMAT
     return read_ids, samples, offsets, st

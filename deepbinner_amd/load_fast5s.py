@@ -61,7 +61,7 @@ def _python_get_read_id_and_signal(fast5_file):
             read_id = group.attrs['read_id'].decode()
             signal = group['Signal'][:]
         return read_id, signal
-    except (OSError, KeyError):
+    except Exception:      # h5py: OSError / KeyError; a damaged file can trip anything else
         return None, None
 
 
@@ -84,7 +84,7 @@ def _python_iter_reads(fast5_file):
                 groups = [hdf5_file[k + '/Raw/'] for k in keys if k.startswith('read_')]
             for group in groups:
                 yield group.attrs['read_id'].decode(), group['Signal'][:]
-    except (OSError, KeyError):
+    except Exception:      # h5py: OSError / KeyError; a damaged file can trip anything else
         return
 
 
