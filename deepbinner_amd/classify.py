@@ -89,7 +89,7 @@ def load_trained_model(model_file, out_dest=sys.stderr):
                'model file?'.format(model_file))
     try:
         weights, _ = ModelWeights.load(str(model_file))
-    except (OSError, ValueError, KeyError, IndexError):
+    except Exception:       # whatever a damaged or foreign file trips inside the readers
         sys.exit(invalid)
     model = build_model(weights)
     print('done', file=out_dest)
