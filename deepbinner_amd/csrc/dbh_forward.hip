@@ -1300,34 +1300,92 @@ __device__ __forceinline__ void inception_k3(const float* in_region, const float
 // classify.py:285-295 (ties to the lower class index: Python's stable sort with reverse=True).
 // Shared by the stand-alone merge kernel and the forward kernel's fused single-step finish.
 // ---------------------------------------------------------------------------------------------
+// 64-bit / index moves inside a 16-lane row (DPP, no LDS round trip) for the reductions below.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_move_i32<CTRL>((int)b);
+    const unsigned hi = (unsigned)dpp_move_i32<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The 32 lanes c = 0..31 of one read (two 16-lane rows) finish it: make_sum_to_one in fp64
+// (classify.py:387-393), then the top-two call rule (classify.py:285-295; ties to the lower
+// index).  Each all-reduce is four DPP steps inside the rows plus one v_permlane16_swap across
+// them - five ds_bpermute rounds of 64-bit values apiece made this the slowest 3k cycles of a
+// window.
+template <class T, class Combine>
+__device__ __forceinline__ T reduce32(T v, const Combine& combine) {
+    v = combine(v, T::template moved<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = combine(v, T::template moved<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = combine(v, T::template moved<0x141>(v));    // row_half_mirror
+    v = combine(v, T::template moved<0x140>(v));    // row_mirror
+    T row0, row1;                                   // both rows' results, seen from both rows
+    T::rows(v, &row0, &row1);
+    return combine(row0, row1);
+}
+// v_permlane16_swap_b32 (gfx950): (x, x) -> {the even row's x in both rows of a pair, the odd
+// row's x in both rows} - the cross-row step of a 32-lane reduction without an LDS round trip.
+__device__ __forceinline__ void rows_i32(int x, int* even, int* odd) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    *even = (int)r[0];
+    *odd = (int)r[1];
+}
+__device__ __forceinline__ void rows_f64(double x, double* even, double* odd) {
+    const long long b = __builtin_bit_cast(long long, x);
+    int lo0, lo1, hi0, hi1;
+    rows_i32((int)b, &lo0, &lo1);
+    rows_i32((int)(b >> 32), &hi0, &hi1);
+    *even = __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi0 << 32) | (unsigned)lo0));
+    *odd = __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi1 << 32) | (unsigned)lo1));
+}
+struct RedF64 {
+    double v;
+    template <int CTRL>
+    static __device__ __forceinline__ RedF64 moved(const RedF64& a) {
+        return RedF64{dpp_move_f64<CTRL>(a.v)};
+    }
+    static __device__ __forceinline__ void rows(const RedF64& a, RedF64* even, RedF64* odd) {
+        rows_f64(a.v, &even->v, &odd->v);
+    }
+};
+struct RedBest {
+    double v;
+    int i;
+    template <int CTRL>
+    static __device__ __forceinline__ RedBest moved(const RedBest& a) {
+        return RedBest{dpp_move_f64<CTRL>(a.v), dpp_move_i32<CTRL>(a.i)};
+    }
+    static __device__ __forceinline__ void rows(const RedBest& a, RedBest* even, RedBest* odd) {
+        rows_f64(a.v, &even->v, &odd->v);
+        rows_i32(a.i, &even->i, &odd->i);
+    }
+};
+
 __device__ __forceinline__ void renormalise_and_call(float merged, int c, int n_classes,
                                                      double score_diff, float* probs_row,
                                                      int* call_out) {
     const bool valid = c < n_classes;
     double p = (double)merged;
-    double rest = (valid && c > 0) ? p : 0.0;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) rest += __shfl_xor(rest, off, 32);
+    const double rest =
+        reduce32(RedF64{(valid && c > 0) ? p : 0.0},
+                 [](const RedF64& a, const RedF64& b) { return RedF64{a.v + b.v}; }).v;
     const double p0 = __shfl(p, 0, 32);
     const double factor = (1.0 - p0) / rest;
     if (c > 0) p = p * factor;
     if (valid) probs_row[c] = (float)p;
 
-    double best = valid ? p : -1.0;
-    int best_i = c;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(best, off, 32);
-        const int oi = __shfl_xor(best_i, off, 32);
-        if (ov > best || (ov == best && oi < best_i)) {
-            best = ov;
-            best_i = oi;
-        }
-    }
-    double second = (valid && c != best_i) ? p : -1.0;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) second = fmax(second, __shfl_xor(second, off, 32));
-    if (c == 0) *call_out = (best_i != 0 && (best - second) >= score_diff) ? best_i : 0;
+    const RedBest best = reduce32(RedBest{valid ? p : -1.0, c}, [](const RedBest& a, const RedBest& b) {
+        return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+    });
+    const double second =
+        reduce32(RedF64{(valid && c != best.i) ? p : -1.0},
+                 [](const RedF64& a, const RedF64& b) { return RedF64{fmax(a.v, b.v)}; }).v;
+    if (c == 0) *call_out = (best.i != 0 && (best.v - second) >= score_diff) ? best.i : 0;
 }
 
 // Window bounds of scan step `step` inside a read of `len` samples (classify.py:337-349).
