@@ -63,6 +63,9 @@ class CModel:
         steps = scan_size // 512
         out = np.empty((n * steps, 1024), dtype=np.float32)
         samples = np.ascontiguousarray(samples, dtype=np.int16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if n and (offsets[0] < 0 or offsets[-1] > samples.size or (np.diff(offsets) < 0).any()):
+            raise ValueError('offsets do not describe reads inside the sample buffer')
         if samples.size == 0:
             samples = np.zeros(1, dtype=np.int16)
         self.lib.dbref_windows(samples, np.ascontiguousarray(offsets, dtype=np.int64), n,

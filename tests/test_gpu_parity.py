@@ -140,6 +140,39 @@ def test_read_length_hint_never_changes_results(hip, weights):
     model.set_read_length_hint(0)
 
 
+@pytest.mark.parametrize('model_name,side,batch,scan,length', [
+    ('EXP-NBD103_read_starts', 'start', 512, 512, 1024),      # BASELINE configs[2], start model
+    ('EXP-NBD103_read_ends', 'end', 512, 512, 1024),          # BASELINE configs[2], end model
+    ('SQK-RBK004_read_starts', 'start', 256, 512, 1024),      # BASELINE configs[3]
+    ('EXP-NBD103_read_starts', 'start', 256, 6144, 6656),     # the CLI's default geometry
+])
+def test_baseline_configurations_match_oracle(hip, hip_models, weights, model_name, side, batch,
+                                              scan, length):
+    """The device-resident batched entry point on the other BASELINE.json configurations
+    (tools/config_rates.py times them at full size): calls identical to the oracle's C port and
+    probabilities within tolerance on 768 synthetic reads, with and without the length hint."""
+    from bench import synthetic_reads
+    from oracle import dbref
+    n = 768
+    reads = np.ascontiguousarray(
+        np.tile(synthetic_reads(n, 20260927), (1, -(-length // 1024)))[:, :length])
+    assert reads.shape == (n, length)
+    offsets = np.arange(n + 1, dtype=np.int64) * length
+    want_probs, want_calls = dbref.CModel(weights[model_name]).classify(
+        reads.reshape(-1), offsets, side, scan, 0.5)
+    model = hip_models[model_name]
+    d_s, d_o = hip.DeviceBuffer.from_array(reads), hip.DeviceBuffer.from_array(offsets)
+    d_p, d_c = hip.DeviceBuffer(n * model.n_classes * 4), hip.DeviceBuffer(n * 4)
+    for hint in (0, length):
+        model.set_read_length_hint(hint, reads.size)
+        model.classify_batched_dev(d_s.ptr, d_o.ptr, n, batch, side, scan, 0.5, d_p.ptr, d_c.ptr,
+                                   None)
+        hip.synchronize()
+        assert np.array_equal(d_c.download((n,), np.int32), want_calls)
+        assert np.abs(d_p.download((n, model.n_classes), np.float32) - want_probs).max() < PROB_TOL
+    model.set_read_length_hint(0)
+
+
 def test_live_kernel_timing_brackets(hip_models):
     """dbh_forward_timing_*: one event pair per run of `span` launches at every n-th launch; only
     closed brackets are reported, and timing does not change results."""
