@@ -1793,8 +1793,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage H: conv20 (1x1 -> classes) + ReLU + GlobalAveragePool + Softmax ---
-    if (wave < 2) {
-        const int t = wave;
+    // Wave t computes N tile t of conv20 (classes 16t .. 16t+15) and leaves their global-average
+    // logits in the q = 0 lanes.
+    auto conv20_logit = [&]() -> float {
         const float* a_lane = lds + kG2 + (n + 1) * kS48 + 2 * q;
         f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1810,8 +1811,42 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             s = fmaxf(acc.x + b, 0.f) + fmaxf(acc.y + b, 0.f) + fmaxf(acc.z + b, 0.f) +
                 fmaxf(acc.w + b, 0.f);
         }
-        s += __shfl_xor(s, 16);
-        if (q == 0) lds[kLogits + t * 16 + n] = s * 0.125f;
+        // rows q = 0 and q = 1 hold the two halves of the position sum
+        int even, odd;
+        rows_i32(__builtin_bit_cast(int, s), &even, &odd);
+        return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) * 0.125f;
+    };
+    if (n_classes <= 16) {
+        // every class is in N tile 0: wave 0 goes from the MFMAs to the call without leaving its
+        // registers - no logits in LDS, no barrier, classes in lanes 0..15
+        if (wave == 0) {
+            const float logit = conv20_logit();
+            const bool valid = lane < n_classes;
+            const float v = valid ? logit : -INFINITY;
+            const float mx = lane_value(row16_max(v), 0);
+            const float e = valid ? expf(v - mx) : 0.f;
+            const float sum = lane_value(row16_sum(e), 0);
+            if (debug_stage == 7) {
+                if (lane < 32) debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+                return;
+            }
+            const float p = e / sum;
+            if (calls != nullptr) {
+                if (lane < 32)
+                    renormalise_and_call(valid ? p : 0.f, lane, n_classes, score_diff,
+                                         probs + win * n_classes, calls + win);
+            } else if (valid) {
+                probs[win * n_classes + lane] = p;
+            }
+        }
+        mark(ts, 53);
+        mark(ts, 54);
+        mark(ts, 55);
+        return;
+    }
+    if (wave < 2) {
+        const float logit = conv20_logit();
+        if (q == 0) lds[kLogits + wave * 16 + n] = logit;
     }
     mark(ts, 53);
     __syncthreads();

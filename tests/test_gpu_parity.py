@@ -173,6 +173,37 @@ def test_baseline_configurations_match_oracle(hip, hip_models, weights, model_na
     model.set_read_length_hint(0)
 
 
+@pytest.mark.parametrize('n_classes', [2, 13, 16, 17, 25, 32])
+def test_other_class_counts(hip, weights, all_signals, n_classes):
+    """Both endings of the kernel - every class in one N tile (<= 16, no LDS round) and two N
+    tiles (17..32) - on models whose last convolution is redrawn for n_classes outputs."""
+    from deepbinner_amd.model_format import ModelWeights
+    from oracle import dbref
+    base = weights['EXP-NBD103_read_starts']
+    rng = np.random.default_rng(n_classes)
+    convs = list(base.convs[:-1]) + [
+        ((rng.standard_normal((1, 48, n_classes)) * 0.2).astype(np.float32),
+         (rng.standard_normal(n_classes) * 0.1).astype(np.float32))]
+    w = ModelWeights(n_classes, convs, base.bns)
+    model = hip.HipModel(w, device=0)
+    x = np.load(os.path.join(GOLD, 'windows_start.npy')).reshape(-1, 1024)[:40]
+    got = model.predict(x)
+    want = network_ref.forward(w, x, dtype=np.float64)
+    assert got.shape == (40, n_classes) and np.abs(got - want).max() < PROB_TOL
+    # seam b2 with one and with several scan steps against the C port
+    samples = np.concatenate(all_signals)
+    offsets = np.concatenate(([0], np.cumsum([len(s) for s in all_signals]))).astype(np.int64)
+    cm = dbref.CModel(w)
+    for side, scan in (('start', 512), ('end', 512), ('start', 6144)):
+        probs, calls = model.classify_signals(all_signals, side, scan, 0.05)
+        want_probs, want_calls = cm.classify(samples, offsets, side, scan, 0.05)
+        assert np.abs(probs - want_probs).max() < PROB_TOL
+        # a call may legitimately differ only where best - second sits on the threshold
+        for i in np.flatnonzero(calls != want_calls):
+            top = np.sort(want_probs[i])[::-1]
+            assert abs((top[0] - top[1]) - 0.05) < 1e-5, (side, scan, i)
+
+
 def test_live_kernel_timing_brackets(hip_models):
     """dbh_forward_timing_*: one event pair per run of `span` launches at every n-th launch; only
     closed brackets are reported, and timing does not change results."""
