@@ -584,7 +584,8 @@ __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slo
     wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc, side);
 }
 
-// One Winograd layer of stage B.  SLOT_A / SLOT_B: LDS homes of this layer's (V0,V1) / (V2,V3).
+// One F(2,3) Winograd layer with whole tiles per wave (conv7).  SLOT_A / SLOT_B: LDS homes of
+// this layer's (V0,V1) / (V2,V3).
 // next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
 // at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
 template <int CONV, int L, bool POOL, int BNI, int SLOT_A, int SLOT_B, class Dma1, class Dma2>
@@ -1457,7 +1458,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     // straight from global (k = lane>>4 picks the tap), B[k][n] = w[k][n].  One MFMA per
     // (position tile, N tile); the standard epilogue applies bias, ReLU and BN1.
     {
-        // conv2's transformed weights: (V0,V1) -> slot 0, (V2,V3) -> slot 1; (V4,V5) follow
+        // conv2's transformed weights: (V1,V2) -> slot 0, (V3,V4) -> slot 1; (V0,V5) follow
         // during conv2's own first phase
         auto fetch_conv2_weights = [&] {
             dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
@@ -1579,8 +1580,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p.  Phase 0 (xi 0..3)
-    // reads slots 0+1 while this layer's last third streams into slot 2; phase 1 (xi 4,5)
+    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p.  Phase 0 (xi 1..4)
+    // reads slots 0+1 while this layer's last third streams into slot 2; phase 1 (xi 0,5)
     // reads slot 2 while the NEXT layer's first two thirds stream into slots 0+1.
     auto third = [&](int conv, int p, float* dst) {
         dma_weights<kWinoHalf>(packed + weight_offset(conv) + p * kWinoHalf, dst, lane, wave);
