@@ -1560,10 +1560,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                acc[m][t] = mfma4(a[m], bw[t], f4{0.f, 0.f, 0.f, 0.f});
+                acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
         mark(ts, 59);
         float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
-        epilogue<MT, 3, kS48, false, true>(acc, out_lane, ep);
+        epilogue<MT, 3, kS48, false, true, false>(acc, out_lane, ep);
         mark(ts, 60);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
