@@ -1010,6 +1010,88 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
     return F5_OK;
 }
 
+int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
+                  f5_batch** out) {
+    if (!path || !out || first < 0 || count < 0) return F5_ERR_ARGUMENT;
+    *out = nullptr;
+    f5_batch* batch = nullptr;
+    try {
+        // every worker thread parses the file for itself (the reader object is not shared: it
+        // caches the chunk it inflated last); the reads are then dealt out one by one, in two
+        // passes like f5_load_batch: lengths, prefix sum, inflate into place
+        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        threads = std::max(1, std::min(threads, 64));
+        threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
+        std::vector<std::unique_ptr<Fast5>> readers((size_t)threads);
+        int open_status = F5_OK;
+        for (int t = 0; t < threads && open_status == F5_OK; ++t)
+            open_status = guarded([&] {
+                readers[(size_t)t].reset(new Fast5(path));
+                readers[(size_t)t]->parse();
+            });
+        if (open_status != F5_OK) return open_status;
+        if (first + count > readers[0]->n_reads()) return F5_ERR_NO_READ;
+
+        batch = new f5_batch;
+        batch->offsets.assign((size_t)count + 1, 0);
+        batch->status.assign((size_t)count, F5_ERR_OPEN);
+        batch->read_ids.assign((size_t)count * F5_READ_ID_MAX, 0);
+        std::vector<int64_t> lengths((size_t)count, 0);
+
+        auto run_parallel = [&](const std::function<void(Fast5&, int64_t)>& fn) {
+            std::atomic<int64_t> next(0);
+            auto worker = [&](int t) {
+                for (int64_t i = next.fetch_add(1); i < count; i = next.fetch_add(1))
+                    fn(*readers[(size_t)t], i);
+            };
+            if (threads == 1) {
+                worker(0);
+                return;
+            }
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t);
+            for (std::thread& t : pool) t.join();
+        };
+        run_parallel([&](Fast5& file, int64_t i) {
+            batch->status[(size_t)i] = guarded([&] {
+                const ReadEntry& r = file.read(first + i);
+                const int64_t n = r.signal.n;
+                lengths[(size_t)i] = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
+            });
+        });
+        int64_t total = 0;
+        for (int64_t i = 0; i < count; ++i) {
+            batch->offsets[(size_t)i] = total;
+            total += batch->status[(size_t)i] == F5_OK ? lengths[(size_t)i] : 0;
+        }
+        batch->offsets[(size_t)count] = total;
+        batch->samples.resize((size_t)total);
+        run_parallel([&](Fast5& file, int64_t i) {
+            if (batch->status[(size_t)i] != F5_OK) return;
+            int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
+            batch->status[(size_t)i] = guarded([&] {
+                const ReadEntry& r = file.read(first + i);
+                const int64_t n = r.signal.n;
+                if (keep > 0 && n > 2 * keep) {
+                    file.read_signal(r.signal, 0, keep, dst);
+                    file.read_signal(r.signal, n - keep, keep, dst + keep);
+                } else {
+                    file.read_signal(r.signal, 0, n, dst);
+                }
+            });
+        });
+        for (int64_t i = 0; i < count; ++i)
+            if (batch->status[(size_t)i] != F5_OK)
+                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+    } catch (const std::exception&) {
+        delete batch;
+        return F5_ERR_OPEN;
+    }
+    *out = batch;
+    return F5_OK;
+}
+
 const int16_t* f5_batch_samples(const f5_batch* batch) { return batch ? batch->samples.data() : nullptr; }
 const int64_t* f5_batch_offsets(const f5_batch* batch) { return batch ? batch->offsets.data() : nullptr; }
 const int32_t* f5_batch_status(const f5_batch* batch) { return batch ? batch->status.data() : nullptr; }

@@ -23,7 +23,7 @@ LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 
 EXPORTED_SYMBOLS = [
     'f5_version', 'f5_status_string', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
-    'f5_read_signal', 'f5_load_batch', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
+    'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
     'f5_batch_read_ids', 'f5_batch_free',
 ]
 
@@ -61,6 +61,7 @@ def load_library():
         'f5_read_signal': (c_int, [c_void_p, c_i64, c_i64, c_i64,
                                    np.ctypeslib.ndpointer(np.int16, flags='C_CONTIGUOUS')]),
         'f5_load_batch': (c_int, [P(c_char_p), c_i64, c_i64, c_int, P(c_void_p)]),
+        'f5_load_reads': (c_int, [c_char_p, c_i64, c_i64, c_i64, c_int, P(c_void_p)]),
         'f5_batch_samples': (P(ctypes.c_int16), [c_void_p]),
         'f5_batch_offsets': (P(c_i64), [c_void_p]),
         'f5_batch_status': (P(ctypes.c_int32), [c_void_p]),
@@ -163,19 +164,9 @@ def iter_reads(fast5_file):
         return
 
 
-def load_batch(fast5_files, keep=None, threads=0):
-    """One-read files -> (read_ids, samples, offsets, status): read i is
-    ``samples[offsets[i]:offsets[i+1]]`` (its first and last ``keep`` samples only when it is
-    longer than 2*keep), ``read_ids[i]`` is None and ``status[i]`` != 0 for a file that could not
-    be read.  The files are parsed and inflated by ``threads`` native threads (0 = one per
-    hardware thread, at most 64); the GIL is released meanwhile."""
-    lib = load_library()
-    n = len(fast5_files)
-    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
-    handle = ctypes.c_void_p()
-    status = lib.f5_load_batch(paths, n, int(keep or 0), int(threads), ctypes.byref(handle))
-    if status != F5_OK:
-        raise Fast5NativeError(status_string(status))
+def _unpack_batch(lib, handle, n):
+    """(read_ids, samples, offsets, status) from a native batch handle (which it frees, at once or
+    when the zero-copy sample array dies)."""
     try:
         offsets = np.ctypeslib.as_array(lib.f5_batch_offsets(handle), shape=(n + 1,)).copy()
         total = int(offsets[n])
@@ -199,7 +190,38 @@ def load_batch(fast5_files, keep=None, threads=0):
         slot = raw[i * F5_READ_ID_MAX:(i + 1) * F5_READ_ID_MAX]
         try:
             read_ids.append(slot.split(b'\x00')[0].decode() if st[i] == F5_OK else None)
-        except UnicodeDecodeError:          # a damaged id: treat the file as unreadable
+        except UnicodeDecodeError:          # a damaged id: treat the read as unreadable
             read_ids.append(None)
             st[i] = F5_ERR_FORMAT
     return read_ids, samples, offsets, st
+
+
+def load_batch(fast5_files, keep=None, threads=0):
+    """One-read files -> (read_ids, samples, offsets, status): read i is
+    ``samples[offsets[i]:offsets[i+1]]`` (its first and last ``keep`` samples only when it is
+    longer than 2*keep), ``read_ids[i]`` is None and ``status[i]`` != 0 for a file that could not
+    be read.  The files are parsed and inflated by ``threads`` native threads (0 = one per
+    hardware thread, at most 64); the GIL is released meanwhile."""
+    lib = load_library()
+    n = len(fast5_files)
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
+    handle = ctypes.c_void_p()
+    status = lib.f5_load_batch(paths, n, int(keep or 0), int(threads), ctypes.byref(handle))
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+    return _unpack_batch(lib, handle, n)
+
+
+def load_reads(fast5_file, first=0, count=None, keep=None, threads=0):
+    """Reads [first, first + count) of one (multi-read) fast5 file, loaded by native threads:
+    (read_ids, samples, offsets, status) as from load_batch.  count None = to the end."""
+    lib = load_library()
+    if count is None:
+        with File(fast5_file) as f:
+            count = max(f.n_reads - first, 0)
+    handle = ctypes.c_void_p()
+    status = lib.f5_load_reads(os.fsencode(str(fast5_file)), int(first), int(count),
+                               int(keep or 0), int(threads), ctypes.byref(handle))
+    if status != F5_OK:
+        raise Fast5NativeError('{}: {}'.format(fast5_file, status_string(status)))
+    return _unpack_batch(lib, handle, int(count))

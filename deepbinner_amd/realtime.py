@@ -23,7 +23,7 @@ import tempfile
 import time
 
 from . import classify
-from .load_fast5s import determine_single_or_multi_fast5s, iter_reads
+from .load_fast5s import determine_single_or_multi_fast5s, iter_reads, reader_kind
 from .misc import print_summary_table
 
 POLL_SECONDS = 5
@@ -152,8 +152,25 @@ class Session:
         tally.report()
         return calls
 
+    def _reads_of(self, path):
+        """(read_id, signal) of every read in a multi-read file.  With the native reader the
+        whole file is inflated by its worker threads in one call, and only the scanned ends of
+        long reads come back (all that call_batch looks at)."""
+        if reader_kind() != 'native':
+            return iter_reads(path)
+        from . import fast5_native
+        try:
+            ids, samples, offsets, _ = fast5_native.load_reads(
+                path, keep=int(self.args.scan_size) + 512,
+                threads=int(getattr(self.args, 'loader_procs', 0) or 0))
+        except OSError:
+            return []
+        return [(rid, samples[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(ids)
+                if rid is not None]
+
     def _tabulate_multi_read_files(self, fast5s):
-        reads = [(read_id, signal, path) for path in fast5s for read_id, signal in iter_reads(path)]
+        reads = [(read_id, signal, path) for path in fast5s
+                 for read_id, signal in self._reads_of(path)]
         calls, rows = {}, []
         total = max(len(reads), 1)
         classify.print_classification_progress(0, total, 'reads', out_dest=sys.stdout)

@@ -138,6 +138,28 @@ def test_load_batch(tmp_path, keep, threads):
     assert fast5_native.load_batch([], keep, threads)[0] == []
 
 
+@pytest.mark.parametrize('path', multi_files() + single_files()[:2])
+def test_load_reads_of_one_file(path):
+    """f5_load_reads: every read of a (multi-read) file through native threads equals the Python
+    reader's, whole or cut to the scanned ends, any sub-range, any thread count."""
+    want = python_reads(path)
+    for keep, threads in ((None, 1), (1000, 4), (6656, 0)):
+        ids, samples, offsets, status = fast5_native.load_reads(path, keep=keep, threads=threads)
+        assert ids == [w[0] for w in want] and (status == 0).all()
+        for i, (_, signal) in enumerate(want):
+            assert np.array_equal(samples[offsets[i]:offsets[i + 1]],
+                                  load_fast5s.keep_ends(signal, keep))
+    if len(want) > 6:
+        ids, samples, offsets, _ = fast5_native.load_reads(path, first=3, count=4, threads=2)
+        assert ids == [w[0] for w in want[3:7]]
+        assert np.array_equal(samples[offsets[1]:offsets[2]], want[4][1])
+    assert fast5_native.load_reads(path, first=len(want), count=0)[0] == []
+    with pytest.raises(OSError):
+        fast5_native.load_reads(path, first=len(want), count=1)
+    with pytest.raises(OSError):
+        fast5_native.load_reads(path + '.missing')
+
+
 def test_many_copies_in_parallel(tmp_path):
     """Thread-safety smoke test: 400 files on 16 threads give what one thread gives."""
     files = single_files()
@@ -180,6 +202,10 @@ def test_mutated_files_never_crash_and_agree_with_python_reader(tmp_path):
         except Exception:       # the Python reader may trip over damage it does not expect
             want = None
         got = list(fast5_native.iter_reads(path))
+        try:                                    # the threaded batch entry must not crash either
+            fast5_native.load_reads(path, keep=1000, threads=3)
+        except OSError:
+            pass
         if want is None or not want:
             # the native reader may still have salvaged reads the generator gave up on midway;
             # what matters here is that it returned at all

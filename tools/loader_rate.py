@@ -67,6 +67,25 @@ def main():
             out['native loader (libdeepbinner_fast5.so), batches of 256, scanned ends'] = {
                 'reads_per_s': rates}
 
+        if fast5_native.available():
+            # multi-read containers: all reads of a file through f5_load_reads (the three sample
+            # files hold 10 reads each, so this is the per-call floor rather than a streaming rate)
+            multi = sorted(load_fast5s.find_all_fast5s(os.path.join(os.path.dirname(FAST5_DIR),
+                                                                   'multi')))
+            rates = {}
+            for threads in (1, 4, 10):
+                t0 = time.perf_counter()
+                n = 0
+                for _ in range(200):
+                    for path in multi:
+                        n += len(fast5_native.load_reads(path, keep=6656, threads=threads)[0])
+                rates['%d threads' % threads] = round(n / (time.perf_counter() - t0))
+            os.environ['DEEPBINNER_FAST5_READER'] = 'python'
+            t0 = time.perf_counter()
+            n = sum(1 for _ in range(20) for path in multi for _ in load_fast5s.iter_reads(path))
+            rates['python reader'] = round(n / (time.perf_counter() - t0))
+            out['multi-read files (10 reads each), scanned ends'] = {'reads_per_s': rates}
+
         sm, si, em, ei, osz, _ = classify.load_and_check_models(
             os.path.join(MODELS, 'EXP-NBD103_read_starts.dbw'),
             os.path.join(MODELS, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
