@@ -173,6 +173,25 @@ def synchronize():
     check(load_library().dbh_device_synchronize(), 'dbh_device_synchronize')
 
 
+class Stream:
+    """A non-blocking HIP stream owned through the C ABI; ``ptr`` is the raw hipStream_t (what the
+    ``*_dev`` entry points take, and what ``torch.cuda.ExternalStream`` wraps)."""
+
+    def __init__(self):
+        self._lib = load_library()
+        s = ctypes.c_void_p()
+        check(self._lib.dbh_stream_create(ctypes.byref(s)), 'dbh_stream_create')
+        self.ptr = s.value
+
+    def synchronize(self):
+        check(self._lib.dbh_stream_synchronize(self.ptr), 'dbh_stream_synchronize')
+
+    def close(self):
+        if self.ptr:
+            self._lib.dbh_stream_destroy(self.ptr)
+            self.ptr = None
+
+
 class DeviceBuffer:
     """A raw HBM allocation owned through the C ABI (no torch / no other GPU library)."""
 
