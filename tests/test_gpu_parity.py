@@ -475,3 +475,39 @@ def test_cli_classify_two_ranks_share_one_gpu(hip):
     rows = dict(l.split('\t') for l in out.stdout.splitlines() if '\t' in l)
     assert rows.pop('read_ID') == 'barcode_call'
     assert rows == EXPECTED_END          # require_both column of the reference's tests
+
+
+@pytest.mark.skipif(os.environ.get('DEEPBINNER_SOAK') != '1',
+                    reason='minutes of CPU work: set DEEPBINNER_SOAK=1 (optionally '
+                           'DEEPBINNER_SOAK_READS=n)')
+def test_soak_against_c_port(hip, hip_models, weights):
+    """A large sample (default 500,000 distinct synthetic reads, both sides) against the oracle's
+    C port: identical calls except where best - second sits on the threshold, probabilities
+    within tolerance everywhere."""
+    from bench import synthetic_reads
+    from oracle import dbref
+    total = int(os.environ.get('DEEPBINNER_SOAK_READS', '500000'))
+    model = hip_models['EXP-NBD103_read_starts']
+    cm = dbref.CModel(weights['EXP-NBD103_read_starts'])
+    worst, on_threshold, chunk = 0.0, 0, 50000
+    for k, first in enumerate(range(0, total, chunk)):
+        n = min(chunk, total - first)
+        reads = synthetic_reads(n, 777 + k)
+        # make the sample less benign: scale / offset / clip some reads
+        rng = np.random.default_rng(k)
+        scale = rng.uniform(0.3, 3.0, size=(n, 1))
+        reads = np.clip(np.rint((reads - 450) * scale + rng.integers(0, 900, size=(n, 1))),
+                        -32768, 32767).astype(np.int16)
+        offsets = np.arange(n + 1, dtype=np.int64) * 1024
+        side = 'start' if k % 2 == 0 else 'end'
+        want_probs, want_calls = cm.classify(reads.reshape(-1), offsets, side, 512, 0.5)
+        probs, calls = model.classify_signals(list(reads), side, 512, 0.5)
+        worst = max(worst, float(np.abs(probs - want_probs).max()))
+        for i in np.flatnonzero(calls != want_calls):
+            top = np.sort(want_probs[i].astype(np.float64))[::-1]
+            assert abs((top[0] - top[1]) - 0.5) < 1e-5, (k, i)
+            on_threshold += 1
+    print('soak: {} reads, max |dp| {:.3e}, {} calls on the threshold'.format(total, worst,
+                                                                            on_threshold))
+    assert worst < PROB_TOL
+
