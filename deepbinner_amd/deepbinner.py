@@ -2,9 +2,10 @@
 Command line of the classify path: the ``classify`` and ``realtime`` sub-commands with the flags,
 defaults, validation and error messages of the reference's ``deepbinner/deepbinner.py``
 (:90-156 options, :283-345 checks and preset resolution), so that existing command lines keep
-working.  The options are declared as data (``OPTIONS``) and turned into argparse calls by one
-loop.  The reference's other sub-commands (bin, prep, balance, train, refine) are outside the GPU
-hot path and answer with a one-line refusal.
+working, plus ``bin`` (:159-176), the consumer of the table ``classify`` writes.  The options are
+declared as data (``OPTIONS``) and turned into argparse calls by one loop.  The reference's
+training-side sub-commands (prep, balance, train, refine) are outside the GPU hot path and answer
+with a one-line refusal.
 """
 
 import argparse
@@ -13,7 +14,7 @@ import sys
 
 from .version import __version__
 
-NOT_PROVIDED = ('bin', 'prep', 'balance', 'train', 'refine')
+NOT_PROVIDED = ('prep', 'balance', 'train', 'refine')
 PRESETS = {'native': ('EXP-NBD103_read_starts', 'EXP-NBD103_read_ends'),
            'rapid': ('SQK-RBK004_read_starts', None)}
 TWO_MODEL_FLAGS = ('require_either', 'require_start', 'require_both')
@@ -21,7 +22,7 @@ _IGNORED = 'Accepted for compatibility with the TensorFlow build (ignored)'
 _HELP = (('-h', '--help'), dict(action='help', default=argparse.SUPPRESS,
                                 help='Show this help message and exit'))
 
-# (group title, [(flags, argparse keywords)]) shared by both sub-commands
+# (group title, [(flags, argparse keywords)]) shared by classify and realtime
 OPTIONS = [
     ('Model presets', [
         (('--native',), dict(action='store_true',
@@ -69,7 +70,8 @@ OPTIONS = [
     ]),
 ]
 
-# per sub-command: description, groups in front of the shared ones, the 'Other' group behind them
+# per sub-command: description, groups in front of the shared ones (None in that list: no shared
+# ones), the 'Other' group behind them
 COMMANDS = {
     'classify': ('Classify fast5 reads',
                  [('Positional', [
@@ -92,7 +94,20 @@ COMMANDS = {
                                      help='Automatically stop when there are no more input reads '
                                           '(default: continue to run and wait for more reads)')),
                   _HELP]),
+    'bin': ('Bin fasta/q reads',
+            [('Required', [
+                (('--classes',), dict(type=str, required=True,
+                                      help='Deepbinner classification file (made with the '
+                                           'deepbinner classify command)')),
+                (('--reads',), dict(type=str, required=True, help='FASTA or FASTQ reads')),
+                (('--out_dir',), dict(type=str, required=True,
+                                      help='Directory to output binned read files'))]),
+             None],
+            [(('--threads',), dict(type=int, default=0,
+                                   help='Threads that compress the output (0 = automatic)')),
+             _HELP]),
 }
+USES_MODELS = ('classify', 'realtime')
 
 
 def _add_groups(parser, groups):
@@ -111,7 +126,8 @@ def build_parser():
     subparsers = parser.add_subparsers(title='Commands', dest='subparser_name')
     for name, (description, leading, other) in COMMANDS.items():
         sub = subparsers.add_parser(name, description=description, add_help=False)
-        _add_groups(sub, leading + OPTIONS + [('Other', other)])
+        shared = [] if None in leading else OPTIONS
+        _add_groups(sub, [g for g in leading if g] + shared + [('Other', other)])
     _add_groups(parser, [('Help', [
         _HELP, (('--version',), dict(action='version', version=__version__,
                                      help="Show program's version number and exit"))])])
@@ -125,16 +141,20 @@ def main(argv=None):
         parser.print_help(file=sys.stderr)
         sys.exit(1)
     if argv[0] in NOT_PROVIDED:
-        sys.exit('Error: the {} command is not part of this build - it covers the classify and '
-                 'realtime commands only'.format(argv[0]))
+        sys.exit('Error: the {} command is not part of this build - it covers the classify, '
+                 'realtime and bin commands only'.format(argv[0]))
     args = parser.parse_args(argv)
-    if args.subparser_name in COMMANDS:
+    if args.subparser_name in USES_MODELS:
         check_classify_and_realtime_arguments(args)
-        if args.subparser_name == 'classify':
-            from .classify import classify as run
-        else:
-            from .realtime import realtime as run
-        run(args)
+    if args.subparser_name == 'classify':
+        from .classify import classify as run
+    elif args.subparser_name == 'realtime':
+        from .realtime import realtime as run
+    elif args.subparser_name == 'bin':
+        from .bin import bin_reads as run
+    else:
+        return
+    run(args)
 
 
 def check_classify_and_realtime_arguments(args):
