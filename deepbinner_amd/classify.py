@@ -339,6 +339,22 @@ def combine_calls(start_call, end_call, args):
     return end_call if start_call == 'none' else 'none'
 
 
+def combine_call_numbers(start_calls, end_calls, args):
+    """``combine_calls`` over whole arrays of call numbers (0 = 'none'), as the device-side
+    ``dbh_combine_calls_dev`` does it."""
+    import numpy as np
+    start_calls, end_calls = np.asarray(start_calls), np.asarray(end_calls)
+    if args.require_both:
+        keep = np.zeros(len(start_calls), dtype=bool)
+        other = np.zeros_like(start_calls)
+    elif args.require_start:
+        keep, other = end_calls == 0, np.zeros_like(start_calls)
+    else:
+        assert args.require_either
+        keep, other = end_calls == 0, np.where(start_calls == 0, end_calls, 0)
+    return np.where(start_calls == end_calls, start_calls, np.where(keep, start_calls, other))
+
+
 def call_batch(input_size, output_size, read_ids, signals, model, args, side):
     """Reference classify.py:325-384 -> (barcode_calls, probabilities)."""
     assert side in ('start', 'end')

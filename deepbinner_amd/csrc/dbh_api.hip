@@ -523,6 +523,37 @@ int dbh_merge_calls_dev(const float* window_probs_dev, int64_t n_reads, int step
     return DBH_OK;
 }
 
+namespace {
+// classify.py:298-322 on call numbers (0 = 'none'); one read per thread, 12 bytes of traffic each
+__global__ void combine_calls_kernel(const int32_t* __restrict__ start_calls,
+                                     const int32_t* __restrict__ end_calls, long long n, int mode,
+                                     int32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = start_calls[i], e = end_calls[i];
+    int32_t call;
+    if (s == e) call = s;
+    else if (mode == DBH_REQUIRE_BOTH) call = DBH_CALL_NONE;
+    else if (e == DBH_CALL_NONE) call = s;
+    else if (mode == DBH_REQUIRE_START) call = DBH_CALL_NONE;
+    else call = (s == DBH_CALL_NONE) ? e : DBH_CALL_NONE;
+    out[i] = call;
+}
+}  // namespace
+
+int dbh_combine_calls_dev(const int32_t* start_calls_dev, const int32_t* end_calls_dev,
+                          int64_t n_reads, int mode, int32_t* out_dev, dbh_stream stream) {
+    if (n_reads < 0 || mode < DBH_REQUIRE_EITHER || mode > DBH_REQUIRE_BOTH)
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!start_calls_dev || !end_calls_dev || !out_dev) return DBH_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(combine_calls_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, start_calls_dev, end_calls_dev, (long long)n_reads,
+                       mode, out_dev);
+    DBH_HIP(hipGetLastError());
+    return DBH_OK;
+}
+
 int dbh_classify_workspace_bytes(const dbh_model* m, int64_t n_reads, int scan_size,
                                  size_t* bytes) {
     if (!m || !bytes || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;

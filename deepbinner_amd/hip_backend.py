@@ -104,6 +104,7 @@ def load_library():
                                               c_void_p]),
         'dbh_merge_calls_dev': (c_int, [c_void_p, c_i64, c_int, c_int, ctypes.c_double, c_void_p,
                                         c_void_p, c_void_p]),
+        'dbh_combine_calls_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
         'dbh_stage_floats': (c_int, [c_int, P(c_i64)]),
         'dbh_debug_forward': (c_int, [c_void_p, _f32(), c_i64, c_int, _f32()]),
         'dbh_forward_kernel_info': (c_int, [P(c_int), P(c_int), P(c_int)]),
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = [
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
-    'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev',
+    'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
     'dbh_forward_timing_read',
@@ -167,6 +168,17 @@ def device_name(ordinal=0):
 
 def set_device(ordinal):
     check(load_library().dbh_set_device(int(ordinal)), 'dbh_set_device')
+
+
+COMBINE_MODES = {'require_either': 0, 'require_start': 1, 'require_both': 2}
+
+
+def combine_calls_dev(start_calls_ptr, end_calls_ptr, n_reads, mode, out_ptr, stream=None):
+    """combine_calls (classify.py:298-322) over device arrays of call numbers; ``mode`` is one of
+    COMBINE_MODES.  Does not block."""
+    check(load_library().dbh_combine_calls_dev(start_calls_ptr, end_calls_ptr, int(n_reads),
+                                               COMBINE_MODES[mode], out_ptr, stream),
+          'dbh_combine_calls_dev')
 
 
 def synchronize():

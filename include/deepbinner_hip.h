@@ -126,6 +126,17 @@ int dbh_classify_i16_batched_dev(dbh_model* model, const int16_t* samples_dev,
                                  int side, int scan_size, double score_diff, float* probs_dev,
                                  int32_t* calls_dev, dbh_stream stream);
 
+/* combine_calls (classify.py:298-322) for whole arrays of start-model and end-model calls on the
+ * device: out[i] is the final call of read i (DBH_CALL_NONE or a barcode number).  Agreement
+ * stands; otherwise REQUIRE_BOTH refuses, REQUIRE_START keeps a start call the end model is silent
+ * on, REQUIRE_EITHER (the default, deepbinner.py:315-316) keeps whichever side called when the
+ * other is silent.  out_dev may alias either input.  Does not block the host. */
+#define DBH_REQUIRE_EITHER 0
+#define DBH_REQUIRE_START 1
+#define DBH_REQUIRE_BOTH 2
+int dbh_combine_calls_dev(const int32_t* start_calls_dev, const int32_t* end_calls_dev,
+                          int64_t n_reads, int mode, int32_t* out_dev, dbh_stream stream);
+
 /* ---- pieces of seam b2, exposed for parity tests ---------------------------------------- */
 /* windows_dev: (n_reads * steps) x 1024 fp32, read-major (window index = read*steps + step). */
 int dbh_normalise_windows_dev(const int16_t* samples_dev, const int64_t* offsets_dev,

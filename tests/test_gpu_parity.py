@@ -405,6 +405,43 @@ def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, sid
     assert np.array_equal(got_p, want_p)
 
 
+def test_combine_calls_on_the_device(hip):
+    """dbh_combine_calls_dev against the reference's truth table (tests/test_combine_calls.py,
+    via classify.combine_calls) for every pair of calls in every mode, in place and out of place,
+    and on 1M random pairs against the array form."""
+    import argparse
+    from deepbinner_amd import classify
+    grid = np.arange(13, dtype=np.int32)
+    starts, ends = np.repeat(grid, 13), np.tile(grid, 13)
+    name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+    rng = np.random.default_rng(9)
+    big_s = rng.integers(0, 13, size=1000003).astype(np.int32)
+    big_e = np.where(rng.random(1000003) < 0.5, big_s, rng.integers(0, 13, size=1000003)) \
+        .astype(np.int32)
+    for mode in ('require_either', 'require_start', 'require_both'):
+        args = argparse.Namespace(require_either=False, require_start=False, require_both=False)
+        setattr(args, mode, True)
+        d_s, d_e = hip.DeviceBuffer.from_array(starts), hip.DeviceBuffer.from_array(ends)
+        d_o = hip.DeviceBuffer(len(starts) * 4)
+        hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(starts), mode, d_o.ptr)
+        hip.synchronize()
+        got = d_o.download((len(starts),), np.int32)
+        assert [name(c) for c in got] == [classify.combine_calls(name(a), name(b), args)
+                                          for a, b in zip(starts, ends)], mode
+        hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(starts), mode, d_s.ptr)      # in place
+        hip.synchronize()
+        assert np.array_equal(d_s.download((len(starts),), np.int32), got)
+        d_s, d_e = hip.DeviceBuffer.from_array(big_s), hip.DeviceBuffer.from_array(big_e)
+        d_o = hip.DeviceBuffer(len(big_s) * 4)
+        hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(big_s), mode, d_o.ptr)
+        hip.synchronize()
+        assert np.array_equal(d_o.download((len(big_s),), np.int32),
+                              classify.combine_call_numbers(big_s, big_e, args)), mode
+    hip.combine_calls_dev(None, None, 0, 'require_both', None)                   # nothing to do
+    with pytest.raises(Exception):
+        hip.check(hip.load_library().dbh_combine_calls_dev(d_s.ptr, d_e.ptr, 5, 7, d_o.ptr, None))
+
+
 def test_bench_two_ranks_share_one_gpu(hip):
     """bench.py's N > 1 path (torchrun env, sharded reads, gather, MAX-over-ranks timing, one JSON
     line from rank 0) on a one-GPU box: both ranks use device 0, gather over gloo."""

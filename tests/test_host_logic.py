@@ -155,6 +155,24 @@ def test_combine_calls_truth_table(gold):
     assert len(gold['calls']['combine_table']) == 15
 
 
+def test_combine_call_numbers_is_combine_calls(gold):
+    """The array form (what dbh_combine_calls_dev computes) against the string form, on the
+    reference's truth table and on every pair of calls 0..12 in the three modes."""
+    number = lambda name: 0 if name == 'none' else int(name)          # noqa: E731
+    for key, want in gold['calls']['combine_table'].items():
+        mode, s, e = key.split('|')
+        got = classify.combine_call_numbers([number(s)], [number(e)], make_args(**{mode: True}))
+        assert int(got[0]) == number(want), key
+    grid = np.arange(13)
+    starts, ends = np.repeat(grid, 13), np.tile(grid, 13)
+    name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+    for mode in ('require_either', 'require_start', 'require_both'):
+        args = make_args(**{mode: True})
+        got = classify.combine_call_numbers(starts, ends, args)
+        assert [name(c) for c in got] == [classify.combine_calls(name(a), name(b), args)
+                                          for a, b in zip(starts, ends)]
+
+
 # ---- small functions ----------------------------------------------------------------------
 def test_barcode_call_rule():
     f = classify.get_barcode_call_from_probabilities

@@ -2,7 +2,7 @@
 """Rates of the other BASELINE.json configurations on one MI355X (they are parity-test cases, not
 bench lines; bench.py measures configs[1]).  Inputs resident in HBM, one fused launch per batch:
   configs[2]: EXP-NBD103 start + end models, 100,000 synthetic signals, batch 512, combine_calls
-              (require_either) on the host;
+              (require_either) on the host and on the device;
   configs[3]: SQK-RBK004_read_starts, this GPU's 125,000-read shard of 1,000,000, batch 256;
   default CLI geometry: 6,656-sample reads, scan_size 6144 (12 windows per read), batch 256.
 Parity of these configurations is the business of tests/test_gpu_parity.py; this tool only times them
@@ -63,12 +63,33 @@ def main():
     names_e = ['none' if c == 0 else str(int(c)) for c in calls_e]
     final = [classify.combine_calls(a, b, args) for a, b in zip(names_s, names_e)]
     t_c = time.perf_counter() - t0
+    # the same on the device: both models and combine_calls queued on one stream, one sync
+    d_cs, d_ce = hip_backend.DeviceBuffer(n * 4), hip_backend.DeviceBuffer(n * 4)
+    d_ps = hip_backend.DeviceBuffer(n * start.n_classes * 4)
+    d_pe = hip_backend.DeviceBuffer(n * end.n_classes * 4)
+    d_final = hip_backend.DeviceBuffer(n * 4)
+    t_all = None
+    for _ in range(4):
+        hip_backend.synchronize()
+        t0 = time.perf_counter()
+        start.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, 512, 'start', 512, 0.5,
+                                   d_ps.ptr, d_cs.ptr, None)
+        end.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, 512, 'end', 512, 0.5,
+                                 d_pe.ptr, d_ce.ptr, None)
+        hip_backend.combine_calls_dev(d_cs.ptr, d_ce.ptr, n, 'require_either', d_final.ptr)
+        hip_backend.synchronize()
+        dt = time.perf_counter() - t0
+        t_all = dt if t_all is None else min(t_all, dt)
+    on_device = d_final.download((n,), np.int32)
+    assert [('none' if c == 0 else str(int(c))) for c in on_device] == final
     out['configs[2] EXP-NBD103 start+end, 100k signals, batch 512'] = {
         'gpu_seconds_start_model': round(t_s, 5), 'gpu_seconds_end_model': round(t_e, 5),
         'host_combine_calls_seconds': round(t_c, 4),
         'reads_per_s_gpu_both_models': round(n / (t_s + t_e)),
         'windows_per_s_gpu': round(2 * n / (t_s + t_e)),
         'reads_per_s_incl_host_combine': round(n / (t_s + t_e + t_c)),
+        'gpu_seconds_both_models_and_combine_on_device': round(t_all, 5),
+        'reads_per_s_all_on_device': round(n / t_all),
         'called': int(sum(c != 'none' for c in final))}
 
     # ---- configs[3]: one GPU's shard of 1M reads, SQK-RBK004 --------------------------------
