@@ -447,8 +447,8 @@ int dtw_semi_global_batch(const double* refs, const int64_t* ref_offsets, const 
     for (int64_t p = 0; p < n_pairs; ++p) {
         const int64_t r = ref_offsets[p + 1] - ref_offsets[p];
         const int64_t q = query_offsets[p + 1] - query_offsets[p];
-        if (r < 1 || q < 1 || r > INT32_MAX || q > INT32_MAX) {
-            g_error = "every pair needs 1 .. 2^31-1 samples of reference and of query";
+        if (r < 1 || q < 1 || r > (1 << 30) || q > (1 << 30)) {
+            g_error = "every pair needs 1 .. 2^30 samples of reference and of query";
             return DTW_ERR_ARGUMENT;
         }
     }
