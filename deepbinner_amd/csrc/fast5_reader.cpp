@@ -62,6 +62,13 @@ struct SignalInfo {
     uint64_t addr = kUndef;    // contiguous data / chunk B-tree
     uint64_t compact_off = 0, compact_size = 0;
     int64_t chunk_elems = 0;
+    // chunk index: 0 = version-1 B-tree (layout message up to version 3); layout version 4
+    // (HDF5 1.10, libver latest): 1 = the single chunk itself, 2 = implicit (all chunks back to
+    // back), 3 = fixed array, 4 = extensible array
+    int index = 0;
+    uint64_t single_bytes = 0;
+    uint32_t single_mask = 0;
+    bool unfiltered_edge = false;   // layout flag: a partial last chunk is stored unfiltered
     std::vector<Filter> filters;
 };
 
@@ -162,7 +169,18 @@ class Fast5 {
             std::memset(out, 0, (size_t)count * 2);
             if (s.addr == kUndef) return;
             if (s.chunk_elems <= 0) throw FormatError("bad chunk size");
-            walk_chunks(s, s.addr, first, count, out, 0);
+            if (s.index == 0) {
+                walk_chunks(s, s.addr, first, count, out, 0);
+                return;
+            }
+            for (int64_t k = first / s.chunk_elems; k * s.chunk_elems < first + count; ++k) {
+                uint64_t addr = kUndef, nbytes = 0;
+                uint32_t mask = 0;
+                if (!indexed_chunk(s, (uint64_t)k, &addr, &nbytes, &mask)) continue;
+                const bool partial = (k + 1) * s.chunk_elems > s.n;
+                if (s.unfiltered_edge && partial) mask = ~0u;
+                copy_from_chunk(s, k * s.chunk_elems, addr, nbytes, mask, first, count, out);
+            }
         }
     }
 
@@ -621,7 +639,10 @@ class Fast5 {
             throw FormatError("Signal is not one-dimensional");
         SignalInfo s;
         const uint64_t n = u(ds->off + (ds_version == 1 ? 8 : 4), kL);
-        if (n > (1ull << 40)) throw FormatError("implausible Signal length");
+        // deflate expands at most 1032-fold, so a signal cannot be much longer than that many
+        // times the file (a damaged length would otherwise have the caller allocate terabytes)
+        if (n > (1ull << 40) || n / 1100 > len_ + 4096)
+            throw FormatError("implausible Signal length");
         s.n = (int64_t)n;
 
         const int version = b(lay->off);
@@ -660,6 +681,44 @@ class Fast5 {
                 s.layout = 2;
                 s.addr = u(p + 1, kO);
                 s.chunk_elems = (int64_t)u(p + 1 + kO, 4);
+            } else {
+                throw FormatError("unsupported data layout class");
+            }
+        } else if (version == 4) {
+            const int lcls = b(lay->off + 1);
+            uint64_t p = lay->off + 2;
+            if (lcls == 0) {
+                s.layout = 0;
+                s.compact_size = u(p, 2);
+                s.compact_off = p + 2;
+            } else if (lcls == 1) {
+                s.layout = 1;
+                s.addr = u(p, kO);
+            } else if (lcls == 2) {
+                const int flags = b(p), ndim = b(p + 1), enc = b(p + 2);
+                if (ndim != 2 || enc < 1 || enc > 8) throw FormatError("unexpected chunk rank");
+                s.layout = 2;
+                s.chunk_elems = (int64_t)u(p + 3, enc);
+                s.unfiltered_edge = (flags & 1) != 0;
+                p += 3 + 2ull * enc;
+                s.index = b(p);
+                p += 1;
+                if (s.index == 1) {
+                    s.single_bytes = (uint64_t)s.chunk_elems * 2;
+                    if (flags & 2) {
+                        s.single_bytes = u(p, kL);
+                        s.single_mask = (uint32_t)u(p + kL, 4);
+                        p += kL + 4;
+                    }
+                } else if (s.index == 2) {
+                } else if (s.index == 3) {
+                    p += 1;
+                } else if (s.index == 4) {
+                    p += 5;
+                } else {
+                    throw FormatError("unsupported chunk index type");
+                }
+                s.addr = u(p, kO);
             } else {
                 throw FormatError("unsupported data layout class");
             }
@@ -755,6 +814,155 @@ class Fast5 {
         if (raw->size() < (size_t)s.chunk_elems * 2) raw->resize((size_t)s.chunk_elems * 2, 0);
     }
 
+    // the part of [first, first + count) that the chunk starting at sample `lo` holds
+    void copy_from_chunk(const SignalInfo& s, int64_t lo, uint64_t addr, uint64_t nbytes,
+                         uint32_t mask, int64_t first, int64_t count, int16_t* out) {
+        const int64_t hi = std::min<int64_t>(lo + s.chunk_elems, s.n);
+        const int64_t a = std::max(lo, first), z = std::min(hi, first + count);
+        if (a >= z) return;
+        // the last chunk inflated stays around: a read stored as ONE chunk (common) is asked
+        // for twice, once per end, and deflate cannot be entered in the middle
+        if (cache_addr_ != addr || cache_bytes_ != nbytes) {
+            decode_chunk(s, addr, nbytes, mask, &cache_);
+            cache_addr_ = addr;
+            cache_bytes_ = nbytes;
+        }
+        std::memcpy(out + (a - first), cache_.data() + (size_t)(a - lo) * 2, (size_t)(z - a) * 2);
+    }
+
+    // ---- chunk indexes of layout version 4 (hdf5_lite._fixed_array / _extensible_array) ----------
+    // one record of a fixed / extensible array; false: the chunk was never written
+    bool index_record(uint64_t p, bool filtered, int elmt_size, uint64_t chunk_bytes,
+                      uint64_t* addr, uint64_t* nbytes, uint32_t* mask) const {
+        *addr = u(p, kO);
+        if (*addr == kUndef) return false;
+        if (!filtered) {
+            *nbytes = chunk_bytes;
+            *mask = 0;
+            return true;
+        }
+        const int size_len = elmt_size - kO - 4;
+        if (size_len < 1 || size_len > 8) throw FormatError("bad chunk record size");
+        *nbytes = u(p + kO, size_len);
+        *mask = (uint32_t)u(p + kO + size_len, 4);
+        return true;
+    }
+
+    static int log2_floor(uint64_t v) {
+        int r = -1;
+        while (v) {
+            v >>= 1;
+            ++r;
+        }
+        return r;
+    }
+
+    bool bit_set(uint64_t bitmap, uint64_t bit) const { return (b(bitmap + bit / 8) & (0x80u >> (bit % 8))) != 0; }
+
+    bool indexed_chunk(const SignalInfo& s, uint64_t k, uint64_t* addr, uint64_t* nbytes,
+                       uint32_t* mask) const {
+        const uint64_t chunk_bytes = (uint64_t)s.chunk_elems * 2;
+        if (s.index == 1) {
+            if (k != 0) return false;
+            *addr = s.addr;
+            *nbytes = s.single_bytes;
+            *mask = s.single_mask;
+            return true;
+        }
+        if (s.index == 2) {
+            *addr = s.addr + k * chunk_bytes;
+            *nbytes = chunk_bytes;
+            *mask = 0;
+            return true;
+        }
+        const uint64_t p = file_off(s.addr);
+        if (s.index == 3) {
+            if (!sig(p, "FAHD") || b(p + 4) != 0) throw FormatError("bad fixed array header");
+            const bool filtered = b(p + 5) == 1;
+            const int elmt_size = b(p + 6), page_bits = b(p + 7);
+            const uint64_t n = u(p + 8, kL);
+            if (k >= n || page_bits > 40) return false;
+            const uint64_t block = file_off(u(p + 8 + kL, kO));
+            if (!sig(block, "FADB")) throw FormatError("bad fixed array data block");
+            uint64_t q = block + 6 + kO;
+            const uint64_t page = 1ull << page_bits;
+            if (n > page) {            // paged: bitmap, checksum, then checksummed pages
+                const uint64_t n_pages = (n + page - 1) / page;
+                const uint64_t pg = k / page, within = k % page;
+                if (!bit_set(q, pg)) return false;
+                q += (n_pages + 7) / 8 + 4;
+                return index_record(q + pg * (page * elmt_size + 4) + within * elmt_size, filtered,
+                                    elmt_size, chunk_bytes, addr, nbytes, mask);
+            }
+            return index_record(q + k * elmt_size, filtered, elmt_size, chunk_bytes, addr, nbytes, mask);
+        }
+        // extensible array: the first records in the index block, then data blocks of doubling size,
+        // the early ones addressed from the index block, the later ones through super blocks
+        if (!sig(p, "EAHD") || b(p + 4) != 0) throw FormatError("bad extensible array header");
+        const bool filtered = b(p + 5) == 1;
+        const int elmt_size = b(p + 6), max_bits = b(p + 7), idx_elmts = b(p + 8),
+                  dblk_min = b(p + 9), sblk_min_ptrs = b(p + 10), page_bits = b(p + 11);
+        if (dblk_min < 1 || sblk_min_ptrs < 2 || max_bits > 64 || page_bits > 40 ||
+            (dblk_min & (dblk_min - 1)) || (sblk_min_ptrs & (sblk_min_ptrs - 1)))
+            throw FormatError("bad extensible array parameters");
+        const uint64_t index_block = u(p + 12 + 6 * kL, kO);
+        if (index_block == kUndef) return false;
+        const uint64_t q = file_off(index_block);
+        if (!sig(q, "EAIB")) throw FormatError("bad extensible array index block");
+        const uint64_t elements = q + 6 + kO;
+        if (k < (uint64_t)idx_elmts)
+            return index_record(elements + k * elmt_size, filtered, elmt_size, chunk_bytes, addr,
+                                nbytes, mask);
+        const int off_size = (max_bits + 7) / 8;
+        const int n_sblks = 1 + max_bits - log2_floor((uint64_t)dblk_min);
+        const int iblock_sblks = 2 * log2_floor((uint64_t)sblk_min_ptrs);
+        const uint64_t n_dblk_addrs = 2ull * (sblk_min_ptrs - 1);
+        const uint64_t dblk_addrs = elements + (uint64_t)idx_elmts * elmt_size;
+        const uint64_t sblk_addrs = dblk_addrs + n_dblk_addrs * kO;
+        uint64_t rel = k - idx_elmts;
+        const int s_idx = log2_floor(rel / dblk_min + 1);
+        if (s_idx >= n_sblks || s_idx > 62) return false;
+        // super block u: 2^(u/2) data blocks of 2^((u+1)/2) * dblk_min records
+        uint64_t first_elmt = 0, first_dblk = 0;
+        for (int v = 0; v < s_idx; ++v) {
+            first_elmt += (1ull << (v / 2)) * ((1ull << ((v + 1) / 2)) * dblk_min);
+            first_dblk += 1ull << (v / 2);
+        }
+        const uint64_t n_dblks = 1ull << (s_idx / 2);
+        const uint64_t dblk_elmts = (1ull << ((s_idx + 1) / 2)) * dblk_min;
+        rel -= first_elmt;
+        const uint64_t d_idx = rel / dblk_elmts, within = rel % dblk_elmts;
+        const uint64_t page = 1ull << page_bits;
+        uint64_t block_addr;
+        if (s_idx < iblock_sblks) {
+            block_addr = u(dblk_addrs + (first_dblk + d_idx) * kO, kO);
+        } else {
+            const uint64_t super_addr = u(sblk_addrs + (uint64_t)(s_idx - iblock_sblks) * kO, kO);
+            if (super_addr == kUndef) return false;
+            const uint64_t sb = file_off(super_addr);
+            if (!sig(sb, "EASB")) throw FormatError("bad extensible array super block");
+            uint64_t t = sb + 6 + kO + off_size;
+            if (dblk_elmts > page) {
+                // "page initialised" bits: a whole number of bytes per data block is reserved,
+                // but the bits are used as one run, `pages` per data block
+                const uint64_t pages = dblk_elmts / page;
+                if (!bit_set(t, d_idx * pages + within / page)) return false;
+                t += n_dblks * ((pages + 7) / 8);
+            }
+            block_addr = u(t + d_idx * kO, kO);
+        }
+        if (block_addr == kUndef) return false;
+        const uint64_t blk = file_off(block_addr);
+        if (!sig(blk, "EADB")) throw FormatError("bad extensible array data block");
+        uint64_t e = blk + 6 + kO + off_size;
+        uint64_t at = within;
+        if (dblk_elmts > page) {       // prefix checksum, then checksummed pages
+            e += 4 + (within / page) * (page * elmt_size + 4);
+            at = within % page;
+        }
+        return index_record(e + at * elmt_size, filtered, elmt_size, chunk_bytes, addr, nbytes, mask);
+    }
+
     // chunk index: version-1 B-tree of raw-data chunks, rank 1 (hdf5_lite._walk_chunk_btree)
     void walk_chunks(const SignalInfo& s, uint64_t addr, int64_t first, int64_t count, int16_t* out,
                      int depth) {
@@ -783,18 +991,7 @@ class Fast5 {
                 continue;
             }
             if (offset >= (uint64_t)s.n) continue;
-            const int64_t lo = (int64_t)offset;
-            const int64_t hi = std::min<int64_t>(lo + s.chunk_elems, s.n);
-            const int64_t a = std::max(lo, first), z = std::min(hi, first + count);
-            if (a >= z) continue;
-            // the last chunk inflated stays around: a read stored as ONE chunk (common) is asked
-            // for twice, once per end, and deflate cannot be entered in the middle
-            if (cache_addr_ != child || cache_bytes_ != nbytes) {
-                decode_chunk(s, child, nbytes, mask, &cache_);
-                cache_addr_ = child;
-                cache_bytes_ = nbytes;
-            }
-            std::memcpy(out + (a - first), cache_.data() + (size_t)(a - lo) * 2, (size_t)(z - a) * 2);
+            copy_from_chunk(s, (int64_t)offset, child, nbytes, mask, first, count, out);
         }
     }
 

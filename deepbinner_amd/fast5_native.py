@@ -33,7 +33,9 @@ class Fast5NativeError(OSError):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    """The in-tree build; DEEPBINNER_FAST5_LIB points somewhere else (a sanitizer build, say)."""
+    return os.environ.get('DEEPBINNER_FAST5_LIB') or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def available():

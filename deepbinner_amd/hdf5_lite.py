@@ -12,12 +12,17 @@ just the slice of the HDF5 file format those files use:
 * old-style groups (symbol-table message -> v1 B-tree -> SNOD nodes + local heap);
 * new-style groups: compact (link messages in the header) and dense (fractal heap indexed by a
   version-2 B-tree on link names);
-* datasets: compact / contiguous / chunked (v1 chunk B-tree) with deflate + shuffle filters;
+* datasets: compact / contiguous / chunked with deflate, shuffle and fletcher32 filters; the chunk
+  index is a v1 B-tree (layout message v1-v3) or, in files written with ``libver='latest'`` by
+  HDF5 >= 1.10 (layout message v4), the single chunk itself, an implicit run, a fixed array or an
+  extensible array (with their paged and super-block forms);
 * attributes (v1-v3) of fixed-point, float, fixed-length string and variable-length string type
   (global heap).
 
 It mirrors the small part of the h5py API the reference uses: ``File(path)``, ``.keys()``,
 ``.values()``, ``[name]`` with ``/``-separated paths, ``.attrs[...]`` and ``dataset[:]``.
+The reader is pinned to the real library: ``oracle/make_h5py_fixtures.py`` writes the variants
+with h5py (the image has one interpreter with it), ``tests/test_fast5_native.py`` reads them back.
 Anything outside that slice raises ``OSError`` — the same exception class h5py raises for an
 unreadable file, which ``load_fast5s.get_read_id_and_signal`` turns into ``(None, None)``.
 """
@@ -279,6 +284,10 @@ class Dataset(_Object):
             raise Hdf5FormatError('unsupported dataset datatype')
         dt = self._dtype.numpy
         count = int(np.prod(self.shape)) if self.shape else 1
+        # deflate expands at most 1032-fold: a dataset cannot be much larger than that many times
+        # the file (a damaged dataspace would otherwise ask numpy for terabytes)
+        if count * dt.itemsize // 1100 > len(buf) + 4096:
+            raise Hdf5FormatError('implausible dataset size')
         lay = self._first(0x0008)
         if lay is None:
             raise Hdf5FormatError('dataset without layout message')
@@ -316,7 +325,79 @@ class Dataset(_Object):
                 q = p + 1 + f._O
                 dims = [_u(buf, q + 4 * i, 4) for i in range(ndim)]
                 return self._read_chunked(addr, dims[:-1], dt)
+        if version == 4:
+            cls = buf[lay.off + 1]
+            p = lay.off + 2
+            if cls == 0:
+                size = _u(buf, p, 2)
+                raw = bytes(buf[p + 2:p + 2 + size])
+                return np.frombuffer(raw, dtype=dt, count=count).reshape(self.shape).copy()
+            if cls == 1:
+                addr = _u(buf, p, f._O)
+                return self._read_contiguous(addr, count, dt)
+            if cls == 2:
+                return self._read_chunked_v4(p, dt)
         raise Hdf5FormatError('unsupported data layout (version %d)' % version)
+
+    def _read_chunked_v4(self, p, dt):
+        """Layout message version 4 (HDF5 1.10, libver='latest'): the chunk index is no longer a
+        v1 B-tree but one of: the single chunk itself, an implicit run of equal chunks, a fixed
+        array, an extensible array (one unlimited dimension) or a v2 B-tree (several; not
+        handled - raw signals are one-dimensional)."""
+        f = self._file
+        buf = f._buf
+        flags = buf[p]
+        ndim = buf[p + 1]
+        enc = buf[p + 2]
+        p += 3
+        dims = [_u(buf, p + enc * i, enc) for i in range(ndim)]
+        p += enc * ndim
+        chunk_dims = dims[:-1]
+        if len(chunk_dims) != len(self.shape) or any(c < 1 for c in chunk_dims):
+            raise Hdf5FormatError('chunk rank does not match the dataset')
+        index_type = buf[p]
+        p += 1
+        chunk_bytes = int(np.prod(chunk_dims)) * dt.itemsize
+        grid = [-(-s // c) for s, c in zip(self.shape, chunk_dims)]
+        n_chunks = int(np.prod(grid)) if grid else 1
+
+        def offsets_of(k):
+            out = []
+            for g, c in zip(reversed(grid), reversed(chunk_dims)):
+                out.append((k % g) * c)
+                k //= g
+            return out[::-1]
+
+        if index_type == 1:                      # single chunk
+            size, mask = chunk_bytes, 0
+            if flags & 2:                        # ... with its filtered size and filter mask
+                size = _u(buf, p, f._L)
+                mask = _u(buf, p + f._L, 4)
+                p += f._L + 4
+            addr = _u(buf, p, f._O)
+            entries = [] if addr == _UNDEF else [(offsets_of(0), mask, addr, size)]
+        elif index_type == 2:                    # implicit: all chunks allocated, back to back
+            addr = _u(buf, p, f._O)
+            entries = [] if addr == _UNDEF else \
+                [(offsets_of(k), 0, addr + k * chunk_bytes, chunk_bytes) for k in range(n_chunks)]
+        elif index_type == 3:                    # fixed array
+            addr = _u(buf, p + 1, f._O)
+            entries = [] if addr == _UNDEF else \
+                [(offsets_of(k),) + e for k, e in enumerate(f._fixed_array(addr, chunk_bytes))
+                 if k < n_chunks and e is not None]
+        elif index_type == 4:                    # extensible array
+            if len(self.shape) != 1:
+                raise Hdf5FormatError('extensible-array chunk index with rank > 1')
+            addr = _u(buf, p + 5, f._O)
+            entries = [] if addr == _UNDEF else \
+                [(offsets_of(k),) + e
+                 for k, e in enumerate(f._extensible_array(addr, chunk_bytes, n_chunks))
+                 if e is not None]
+        else:
+            raise Hdf5FormatError('unsupported chunk index type %d' % index_type)
+        # flag bit 0: partial chunks on the boundary are stored unfiltered
+        unfiltered_edges = bool(flags & 1)
+        return self._assemble_chunks(entries, chunk_dims, dt, unfiltered_edges)
 
     def _read_contiguous(self, addr, count, dt):
         if addr == _UNDEF or count == 0:
@@ -330,15 +411,27 @@ class Dataset(_Object):
                              count=count).reshape(self.shape).copy()
 
     def _read_chunked(self, btree_addr, chunk_dims, dt):
+        if btree_addr == _UNDEF:
+            return np.zeros(self.shape, dtype=dt)
+        return self._assemble_chunks(self._file._walk_chunk_btree(btree_addr, len(self.shape)),
+                                     chunk_dims, dt, False)
+
+    def _assemble_chunks(self, entries, chunk_dims, dt, unfiltered_edges):
         f = self._file
         out = np.zeros(self.shape, dtype=dt)
-        if btree_addr == _UNDEF or out.size == 0:
+        if out.size == 0:
             return out
         filters = self._filters()
         rank = len(self.shape)
         chunk_elems = int(np.prod(chunk_dims))
-        for offsets, filter_mask, addr, nbytes in f._walk_chunk_btree(btree_addr, rank):
-            raw = bytes(f._buf[f._base + addr:f._base + addr + nbytes])
+        for offsets, filter_mask, addr, nbytes in entries:
+            start = f._base + addr
+            if start + nbytes > len(f._buf):
+                raise Hdf5FormatError('chunk extends past end of file')
+            raw = bytes(f._buf[start:start + nbytes])
+            if unfiltered_edges and any(o + c > s for o, c, s in
+                                        zip(offsets, chunk_dims, self.shape)):
+                filter_mask = ~0
             for i, (fid, cd) in reversed(list(enumerate(filters))):
                 if filter_mask & (1 << i):
                     continue
@@ -760,6 +853,130 @@ class File(Group):
                 yield from self._walk_chunk_btree(child, rank)
             else:
                 yield offsets, mask, child, nbytes
+
+    # -- chunk indexes of layout version 4 ------------------------------------------------------
+    def _index_element(self, p, filtered, elmt_size, chunk_bytes):
+        """One chunk record of a fixed / extensible array: (filter mask, address, bytes) or None
+        for a chunk that was never written."""
+        buf = self._buf
+        addr = _u(buf, p, self._O)
+        if addr == _UNDEF:
+            return None
+        if not filtered:
+            return (0, addr, chunk_bytes)
+        size_len = elmt_size - self._O - 4
+        return (_u(buf, p + self._O + size_len, 4), addr, _u(buf, p + self._O, size_len))
+
+    def _fixed_array(self, addr, chunk_bytes):
+        """Records of a fixed array (FAHD -> FADB, optionally paged), in index order."""
+        buf = self._buf
+        p = self._base + addr
+        if buf[p:p + 4] != b'FAHD' or buf[p + 4] != 0:
+            raise Hdf5FormatError('bad fixed array header')
+        filtered = buf[p + 5] == 1
+        elmt_size = buf[p + 6]
+        page_bits = buf[p + 7]
+        n = _u(buf, p + 8, self._L)
+        block = self._base + _u(buf, p + 8 + self._L, self._O)
+        if buf[block:block + 4] != b'FADB':
+            raise Hdf5FormatError('bad fixed array data block')
+        q = block + 6 + self._O
+        page = 1 << page_bits
+        if n > page:                             # paged: bitmap, checksum, then checksummed pages
+            n_pages = -(-n // page)
+            bitmap = bytes(buf[q:q + (n_pages + 7) // 8])
+            q += len(bitmap) + 4
+            for k in range(n):
+                pg, within = divmod(k, page)
+                if not bitmap[pg // 8] & (0x80 >> (pg % 8)):
+                    yield None
+                    continue
+                at = q + pg * (page * elmt_size + 4) + within * elmt_size
+                yield self._index_element(at, filtered, elmt_size, chunk_bytes)
+        else:
+            for k in range(n):
+                yield self._index_element(q + k * elmt_size, filtered, elmt_size, chunk_bytes)
+
+    def _extensible_array(self, addr, chunk_bytes, n_chunks):
+        """Records 0 .. n_chunks-1 of an extensible array (EAHD -> EAIB -> EADB / EASB): the first
+        few live in the index block, then data blocks of doubling size, the early ones addressed
+        from the index block, the later ones through super blocks; big data blocks are paged."""
+        buf = self._buf
+        O, L = self._O, self._L
+        p = self._base + addr
+        if buf[p:p + 4] != b'EAHD' or buf[p + 4] != 0:
+            raise Hdf5FormatError('bad extensible array header')
+        filtered = buf[p + 5] == 1
+        elmt_size, max_bits, idx_elmts, dblk_min, sblk_min_ptrs, page_bits = buf[p + 6:p + 12]
+        index_block = _u(buf, p + 12 + 6 * L, O)
+        if index_block == _UNDEF:
+            for _ in range(n_chunks):
+                yield None
+            return
+        off_size = (max_bits + 7) // 8
+        log2 = lambda v: v.bit_length() - 1                              # noqa: E731
+        n_sblks = 1 + max_bits - log2(dblk_min)
+        sblk = []                                 # (data blocks, elements per data block, first element, first data block)
+        start_idx = start_dblk = 0
+        for u in range(n_sblks):
+            n_dblks, dblk_elmts = 1 << (u // 2), (1 << ((u + 1) // 2)) * dblk_min
+            sblk.append((n_dblks, dblk_elmts, start_idx, start_dblk))
+            start_idx += n_dblks * dblk_elmts
+            start_dblk += n_dblks
+        iblock_sblks = 2 * log2(sblk_min_ptrs)
+        n_dblk_addrs = 2 * (sblk_min_ptrs - 1)
+        q = self._base + index_block
+        if buf[q:q + 4] != b'EAIB':
+            raise Hdf5FormatError('bad extensible array index block')
+        elements = q + 6 + O
+        dblk_addrs = elements + idx_elmts * elmt_size
+        sblk_addrs = dblk_addrs + n_dblk_addrs * O
+        page = 1 << page_bits
+
+        def in_data_block(block_addr, within, dblk_elmts):
+            if block_addr == _UNDEF:
+                return None
+            b = self._base + block_addr
+            if buf[b:b + 4] != b'EADB':
+                raise Hdf5FormatError('bad extensible array data block')
+            e = b + 6 + O + off_size
+            if dblk_elmts > page:                 # prefix checksum, then checksummed pages
+                pg, within = divmod(within, page)
+                e += 4 + pg * (page * elmt_size + 4)
+            return self._index_element(e + within * elmt_size, filtered, elmt_size, chunk_bytes)
+
+        for k in range(n_chunks):
+            if k < idx_elmts:
+                yield self._index_element(elements + k * elmt_size, filtered, elmt_size,
+                                          chunk_bytes)
+                continue
+            rel = k - idx_elmts
+            s_idx = log2(rel // dblk_min + 1)
+            n_dblks, dblk_elmts, first_elmt, first_dblk = sblk[s_idx]
+            rel -= first_elmt
+            d_idx, within = divmod(rel, dblk_elmts)
+            if s_idx < iblock_sblks:
+                block = _u(buf, dblk_addrs + (first_dblk + d_idx) * O, O)
+                yield in_data_block(block, within, dblk_elmts)
+                continue
+            super_addr = _u(buf, sblk_addrs + (s_idx - iblock_sblks) * O, O)
+            if super_addr == _UNDEF:
+                yield None
+                continue
+            sb = self._base + super_addr
+            if buf[sb:sb + 4] != b'EASB':
+                raise Hdf5FormatError('bad extensible array super block')
+            t = sb + 6 + O + off_size
+            if dblk_elmts > page:
+                # "page initialised" bits: room for a whole number of bytes per data block, but
+                # used as one run of bits, `pages` per data block (libhdf5 1.10.6 writes it so)
+                pages = dblk_elmts // page
+                bit = d_idx * pages + within // page
+                if not buf[t + bit // 8] & (0x80 >> (bit % 8)):
+                    yield None
+                    continue
+                t += n_dblks * ((pages + 7) // 8)
+            yield in_data_block(_u(buf, t + d_idx * O, O), within, dblk_elmts)
 
     # -- attributes --------------------------------------------------------------------------
     def _global_heap_object(self, coll_addr, index):

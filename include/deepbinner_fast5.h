@@ -12,8 +12,9 @@
  * It implements the same slice of the HDF5 file format as deepbinner_amd/hdf5_lite.py (superblock
  * v0-v3, object headers v1/v2, symbol-table / compact / dense groups, attributes incl. dense
  * storage and variable-length strings, compact / contiguous / chunked datasets with deflate,
- * shuffle and fletcher32 filters) and nothing else; every offset taken from the file is bounds
- * checked.  No HIP, no Python: plain pointers and sizes.
+ * shuffle and fletcher32 filters, chunk indexes of layout versions 1-4: v1 B-tree, single chunk,
+ * implicit, fixed array, extensible array) and nothing else; every offset taken from the file is
+ * bounds checked.  No HIP, no Python: plain pointers and sizes.
  *
  * Threading: f5_file handles are not shared between threads; f5_load_batch runs its own
  * worker threads and is itself safe to call from several threads at once.

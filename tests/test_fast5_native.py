@@ -1,9 +1,12 @@
 """The native fast5 loader (libdeepbinner_fast5.so, C ABI include/deepbinner_fast5.h) against the
 pure-Python reader (hdf5_lite) and the reference's own loader answers
 (reference tests/test_load_fast5s.py) - host only, no GPU."""
+import hashlib
+import json
 import os
 import re
 import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -97,6 +100,98 @@ def test_multi_read_files_match_python_reader(path):
         fast5_native.get_read_id_and_signal(path)
 
 
+# ---- files written by the real HDF5 library (oracle/make_h5py_fixtures.py) ---------------------
+VARIANT_DIR = os.path.join(REPO, 'tests', 'golden', 'fast5', 'h5py_variants')
+CONDA_PYTHON = '/opt/conda/bin/python3.9'          # the image's only interpreter with h5py
+
+
+def sha(signal):
+    return hashlib.sha256(np.ascontiguousarray(signal, dtype='<i2').tobytes()).hexdigest()
+
+
+def check_against_expected(folder):
+    """Every file of `folder` through both readers against what h5py read back from it."""
+    with open(os.path.join(folder, 'expected.json')) as f:
+        expected = json.load(f)['files']
+    for name, info in sorted(expected.items()):
+        path = os.path.join(folder, name)
+        want = [(r['read_id'], r['n'], r['sha256']) for r in info['reads']]
+        for reader in (load_fast5s._python_iter_reads, fast5_native.iter_reads):
+            got = [(rid, len(sig), sha(sig)) for rid, sig in reader(path)]
+            assert got == want, (name, reader.__module__)
+        # partial reads through the native chunk indexes: the scanned ends only
+        with fast5_native.File(path) as f:
+            for k, (_, n, _) in enumerate(want[:3]):
+                whole = f.read_signal(k, 0, n)
+                assert sha(whole) == want[k][2]
+                for first, count in ((0, min(n, 11)), (max(n - 11, 0), min(n, 11)), (n // 2, n // 4)):
+                    assert np.array_equal(f.read_signal(k, first, count), whole[first:first + count])
+    return len(expected)
+
+
+def test_files_written_by_h5py():
+    """Both on-disk generations (libver earliest / latest: layout messages v3 / v4 with single
+    chunk, implicit, fixed array and extensible array chunk indexes), all storage kinds and
+    filters, group sizes across the compact/dense boundary."""
+    assert check_against_expected(VARIANT_DIR) >= 30
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PYTHON), reason='no interpreter with h5py here')
+def test_files_written_by_h5py_just_now(tmp_path):
+    """The full profile with another seed: adds 700-read containers, a 100k-sample read, chunk
+    indexes with 2,000 .. 140,000 chunks (paged fixed arrays; extensible arrays with super blocks
+    and paged data blocks) and sparsely written datasets."""
+    script = os.path.join(REPO, 'oracle', 'make_h5py_fixtures.py')
+    done = subprocess.run([CONDA_PYTHON, script, str(tmp_path), '4242', 'full'],
+                          capture_output=True, text=True)
+    if done.returncode != 0 and 'No module named' in done.stderr:
+        pytest.skip('h5py is not importable: ' + done.stderr.strip().splitlines()[-1])
+    assert done.returncode == 0, done.stderr
+    assert check_against_expected(str(tmp_path)) >= 40
+
+
+def test_the_reference_loader_run_on_every_fixture():
+    """tests/golden/loader_reference.json is what the reference's own load_fast5s.py returned for
+    every committed fast5 (oracle/make_loader_golden.py, run under h5py in the build container).
+    The one case where this package deliberately differs: a variable-length-string read_id, which
+    h5py 3 hands the reference as str and the reference then fails to .decode() (an uncaught
+    AttributeError) - here the read loads."""
+    with open(os.path.join(REPO, 'tests', 'golden', 'loader_reference.json')) as f:
+        golden = json.load(f)
+    seen = set()
+    for rel, want in sorted(golden['files'].items()):
+        path = os.path.join(REPO, 'tests', 'golden', 'fast5', rel)
+        seen.add(want['result'])
+        assert sorted(load_fast5s.get_root_level_keys(path)) == want['root_keys'], rel
+        for reader in (load_fast5s._python_get_read_id_and_signal,
+                       fast5_native.get_read_id_and_signal):
+            if want['result'] == 'multi':
+                with pytest.raises(SystemExit) as e:
+                    reader(path)
+                assert str(e.value) == want['message']
+                continue
+            read_id, signal = reader(path)
+            if want['result'] == 'none':
+                assert read_id is None and signal is None
+            elif want['result'] == 'read':
+                assert (read_id, len(signal), str(signal.dtype), sha(signal)) == \
+                    (want['read_id'], want['n'], want['dtype'], want['sha256']), rel
+            else:
+                assert want['result'] == 'vlen' and len(read_id) == 36 and len(signal) > 0
+    assert seen >= {'read', 'multi', 'vlen'}
+    for sub, want in golden['directories'].items():
+        folder = os.path.join(REPO, 'tests', 'golden', 'fast5', sub)
+        files = sorted(os.path.join(folder, f) for f in os.listdir(folder) if f.endswith('.fast5'))
+        assert sorted({load_fast5s.determine_single_or_multi_fast5s([f]) for f in files}) == \
+            want['per_file']
+        if want['first_five'].startswith('exit: '):
+            with pytest.raises(SystemExit) as e:
+                load_fast5s.determine_single_or_multi_fast5s(files[:5])
+            assert str(e.value) == want['first_five'][6:]
+        else:
+            assert load_fast5s.determine_single_or_multi_fast5s(files[:5]) == want['first_five']
+
+
 def test_unreadable_files(tmp_path):
     assert fast5_native.get_read_id_and_signal(str(tmp_path / 'missing.fast5')) == (None, None)
     empty = tmp_path / 'empty.fast5'
@@ -175,13 +270,16 @@ def test_many_copies_in_parallel(tmp_path):
 
 
 def test_mutated_files_never_crash_and_agree_with_python_reader(tmp_path):
-    """400 seeded mutations (byte flips, zeroed runs, truncations) of real files: the native
+    """800 seeded mutations (byte flips, zeroed runs, truncations) of real files: the native
     reader must return what the Python reader returns - the same data or the same refusal."""
     rng = np.random.default_rng(20260927)
-    sources = [open(f, 'rb').read() for f in single_files()[:3] + multi_files()[:1]]
+    variants = [os.path.join(VARIANT_DIR, name + '.fast5') for name in (
+        'chunks_150_unlimited_new', 'chunks_40_fixed_new', 'chunks_sparse_new', 'multi_12_new',
+        'many_chunks_shuffle_fletcher_new', 'compact_new')]
+    sources = [open(f, 'rb').read() for f in single_files()[:3] + multi_files()[:1] + variants]
     path = str(tmp_path / 'mutant.fast5')
     outcomes = {'same data': 0, 'both refuse': 0}
-    for trial in range(400):
+    for trial in range(800):
         data = bytearray(sources[trial % len(sources)])
         kind = trial % 4
         if kind == 0:       # a few random byte flips, mostly in the metadata-heavy first 8 KB
