@@ -358,6 +358,36 @@ def test_hdf5_reader_rejects_garbage(tmp_path):
     assert classify.determine_input_type(FAST5_DIR) == 'directory'
 
 
+def test_shipped_weights_are_what_h5py_reads_from_the_reference_models():
+    """tests/golden/model_reference.json: every dataset of the reference's three Keras model files
+    as the real HDF5 library returns it (oracle/make_model_golden.py, build container).  The .dbw
+    blobs that ship - converted through this package's own HDF5 reader - must hold exactly those
+    numbers, layer by layer, and nothing else."""
+    import hashlib
+    import json
+    from conftest import GOLD, MODEL_DIR, MODELS
+    from deepbinner_amd.model_format import ModelWeights
+    with open(os.path.join(GOLD, 'model_reference.json')) as f:
+        golden = json.load(f)
+    digest = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype='<f4').tobytes()).hexdigest()  # noqa: E731
+    for name in MODELS:
+        want = golden[name]
+        assert want['keras_version'] == '2.1.4' and want['backend'] == 'tensorflow'
+        weights, _ = ModelWeights.load(os.path.join(MODEL_DIR, name + '.dbw'))
+        seen = {}
+        for i, (kernel, bias) in enumerate(weights.convs, start=1):
+            seen['conv1d_%d/conv1d_%d/kernel:0' % (i, i)] = kernel
+            seen['conv1d_%d/conv1d_%d/bias:0' % (i, i)] = bias
+        for i, bn in enumerate(weights.bns, start=1):
+            for part, values in zip(('gamma:0', 'beta:0', 'moving_mean:0', 'moving_variance:0'), bn):
+                seen['batch_normalization_%d/batch_normalization_%d/%s' % (i, i, part)] = values
+        assert sorted(seen) == sorted(want['datasets'])
+        for path, values in seen.items():
+            assert list(values.shape) == want['datasets'][path]['shape'], path
+            assert digest(values) == want['datasets'][path]['sha256'], path
+        assert weights.flat().size == want['n_parameters'] == 107197
+
+
 def test_keras_model_file_import():
     """The reference's own model files load through hdf5_lite (only where they are mounted)."""
     ref = '/root/reference/models/EXP-NBD103_read_starts'
