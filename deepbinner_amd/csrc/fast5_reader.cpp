@@ -72,6 +72,14 @@ struct SignalInfo {
     std::vector<Filter> filters;
 };
 
+// The chunk inflated last.  A read stored as ONE chunk (common) is asked for twice, once per end,
+// and deflate cannot be entered in the middle.  One per thread: a Fast5 whose reads are resolved
+// is read-only otherwise, so several threads can decode different reads of it at once.
+struct ChunkCache {
+    std::vector<uint8_t> data;
+    uint64_t addr = ~0ull, bytes = 0;
+};
+
 struct ReadEntry {
     uint64_t group_addr = 0;
     bool resolved = false;
@@ -150,7 +158,9 @@ class Fast5 {
         return r;
     }
 
-    void read_signal(const SignalInfo& s, int64_t first, int64_t count, int16_t* out) {
+    void read_signal(const SignalInfo& s, int64_t first, int64_t count, int16_t* out,
+                     ChunkCache* cache = nullptr) {
+        if (!cache) cache = &cache_;
         if (first < 0 || count < 0 || first + count > s.n) throw std::out_of_range("sample range");
         if (count == 0) return;
         if (s.layout == 0) {
@@ -170,7 +180,7 @@ class Fast5 {
             if (s.addr == kUndef) return;
             if (s.chunk_elems <= 0) throw FormatError("bad chunk size");
             if (s.index == 0) {
-                walk_chunks(s, s.addr, first, count, out, 0);
+                walk_chunks(s, s.addr, first, count, out, 0, cache);
                 return;
             }
             for (int64_t k = first / s.chunk_elems; k * s.chunk_elems < first + count; ++k) {
@@ -179,7 +189,7 @@ class Fast5 {
                 if (!indexed_chunk(s, (uint64_t)k, &addr, &nbytes, &mask)) continue;
                 const bool partial = (k + 1) * s.chunk_elems > s.n;
                 if (s.unfiltered_edge && partial) mask = ~0u;
-                copy_from_chunk(s, k * s.chunk_elems, addr, nbytes, mask, first, count, out);
+                copy_from_chunk(s, k * s.chunk_elems, addr, nbytes, mask, first, count, out, cache);
             }
         }
     }
@@ -194,8 +204,7 @@ class Fast5 {
     uint64_t base_ = 0, root_addr_ = 0;
     int layout_ = F5_LAYOUT_NONE;
     std::vector<ReadEntry> reads_;
-    std::vector<uint8_t> cache_;                 // the chunk decoded last (see walk_chunks)
-    uint64_t cache_addr_ = kUndef, cache_bytes_ = 0;
+    ChunkCache cache_;                           // for callers that bring none (one thread)
 
     // ---- checked access to the mapped file ---------------------------------------------------
     void need(uint64_t off, uint64_t n) const {
@@ -787,7 +796,20 @@ class Fast5 {
                       std::vector<uint8_t>* raw) const {
         const uint64_t start = file_off(addr);
         need(start, nbytes);
-        raw->assign(buf_ + start, buf_ + start + nbytes);
+        if (mapped_ && fd_ >= 0) {
+            // large (multi-read) files: the payload comes through pread, not through the
+            // mapping - page faults of many threads queue on the address-space lock
+            raw->resize((size_t)nbytes);
+            uint64_t got = 0;
+            while (got < nbytes) {
+                const ssize_t k = ::pread(fd_, raw->data() + got, (size_t)(nbytes - got),
+                                          (off_t)(start + got));
+                if (k <= 0) throw FormatError("cannot read chunk");
+                got += (uint64_t)k;
+            }
+        } else {
+            raw->assign(buf_ + start, buf_ + start + nbytes);
+        }
         std::vector<uint8_t> tmp;
         for (int i = (int)s.filters.size() - 1; i >= 0; --i) {
             if (mask & (1u << i)) continue;
@@ -816,18 +838,20 @@ class Fast5 {
 
     // the part of [first, first + count) that the chunk starting at sample `lo` holds
     void copy_from_chunk(const SignalInfo& s, int64_t lo, uint64_t addr, uint64_t nbytes,
-                         uint32_t mask, int64_t first, int64_t count, int16_t* out) {
+                         uint32_t mask, int64_t first, int64_t count, int16_t* out,
+                         ChunkCache* cache) const {
         const int64_t hi = std::min<int64_t>(lo + s.chunk_elems, s.n);
         const int64_t a = std::max(lo, first), z = std::min(hi, first + count);
         if (a >= z) return;
         // the last chunk inflated stays around: a read stored as ONE chunk (common) is asked
         // for twice, once per end, and deflate cannot be entered in the middle
-        if (cache_addr_ != addr || cache_bytes_ != nbytes) {
-            decode_chunk(s, addr, nbytes, mask, &cache_);
-            cache_addr_ = addr;
-            cache_bytes_ = nbytes;
+        if (cache->addr != addr || cache->bytes != nbytes) {
+            cache->addr = ~0ull;
+            decode_chunk(s, addr, nbytes, mask, &cache->data);
+            cache->addr = addr;
+            cache->bytes = nbytes;
         }
-        std::memcpy(out + (a - first), cache_.data() + (size_t)(a - lo) * 2, (size_t)(z - a) * 2);
+        std::memcpy(out + (a - first), cache->data.data() + (size_t)(a - lo) * 2, (size_t)(z - a) * 2);
     }
 
     // ---- chunk indexes of layout version 4 (hdf5_lite._fixed_array / _extensible_array) ----------
@@ -965,7 +989,7 @@ class Fast5 {
 
     // chunk index: version-1 B-tree of raw-data chunks, rank 1 (hdf5_lite._walk_chunk_btree)
     void walk_chunks(const SignalInfo& s, uint64_t addr, int64_t first, int64_t count, int16_t* out,
-                     int depth) {
+                     int depth, ChunkCache* cache) const {
         if (depth > kMaxDepth) throw FormatError("chunk B-tree too deep");
         const uint64_t p = file_off(addr);
         if (!sig(p, "TREE")) throw FormatError("bad chunk B-tree signature");
@@ -987,11 +1011,11 @@ class Fast5 {
                     if ((int64_t)next <= first) continue;
                 }
                 if ((int64_t)offset >= first + count) break;
-                walk_chunks(s, child, first, count, out, depth + 1);
+                walk_chunks(s, child, first, count, out, depth + 1, cache);
                 continue;
             }
             if (offset >= (uint64_t)s.n) continue;
-            copy_from_chunk(s, (int64_t)offset, child, nbytes, mask, first, count, out);
+            copy_from_chunk(s, (int64_t)offset, child, nbytes, mask, first, count, out, cache);
         }
     }
 
@@ -1213,21 +1237,22 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
     *out = nullptr;
     f5_batch* batch = nullptr;
     try {
-        // every worker thread parses the file for itself (the reader object is not shared: it
-        // caches the chunk it inflated last); the reads are then dealt out one by one, in two
-        // passes like f5_load_batch: lengths, prefix sum, inflate into place
+        // ONE reader for all worker threads: the file is opened and its root group parsed once;
+        // pass 1 resolves the reads (every read by exactly one thread, each touching only its
+        // own entry), after which the reader is read-only and pass 2 needs per-thread state only
+        // for the chunk inflated last.  Two passes like f5_load_batch: lengths, prefix sum,
+        // inflate into place.
         int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
         threads = std::max(1, std::min(threads, 64));
         threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
-        std::vector<std::unique_ptr<Fast5>> readers((size_t)threads);
-        int open_status = F5_OK;
-        for (int t = 0; t < threads && open_status == F5_OK; ++t)
-            open_status = guarded([&] {
-                readers[(size_t)t].reset(new Fast5(path));
-                readers[(size_t)t]->parse();
-            });
+        std::unique_ptr<Fast5> shared;
+        const int open_status = guarded([&] {
+            shared.reset(new Fast5(path));
+            shared->parse();
+        });
         if (open_status != F5_OK) return open_status;
-        if (first + count > readers[0]->n_reads()) return F5_ERR_NO_READ;
+        if (first + count > shared->n_reads()) return F5_ERR_NO_READ;
+        std::vector<ChunkCache> caches((size_t)threads);
 
         batch = new f5_batch;
         batch->offsets.assign((size_t)count + 1, 0);
@@ -1235,11 +1260,11 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         batch->read_ids.assign((size_t)count * F5_READ_ID_MAX, 0);
         std::vector<int64_t> lengths((size_t)count, 0);
 
-        auto run_parallel = [&](const std::function<void(Fast5&, int64_t)>& fn) {
+        auto run_parallel = [&](const std::function<void(Fast5&, int64_t, ChunkCache*)>& fn) {
             std::atomic<int64_t> next(0);
             auto worker = [&](int t) {
                 for (int64_t i = next.fetch_add(1); i < count; i = next.fetch_add(1))
-                    fn(*readers[(size_t)t], i);
+                    fn(*shared, i, &caches[(size_t)t]);
             };
             if (threads == 1) {
                 worker(0);
@@ -1249,7 +1274,7 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
             for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t);
             for (std::thread& t : pool) t.join();
         };
-        run_parallel([&](Fast5& file, int64_t i) {
+        run_parallel([&](Fast5& file, int64_t i, ChunkCache*) {
             batch->status[(size_t)i] = guarded([&] {
                 const ReadEntry& r = file.read(first + i);
                 const int64_t n = r.signal.n;
@@ -1264,17 +1289,17 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         }
         batch->offsets[(size_t)count] = total;
         batch->samples.resize((size_t)total);
-        run_parallel([&](Fast5& file, int64_t i) {
+        run_parallel([&](Fast5& file, int64_t i, ChunkCache* cache) {
             if (batch->status[(size_t)i] != F5_OK) return;
             int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
             batch->status[(size_t)i] = guarded([&] {
                 const ReadEntry& r = file.read(first + i);
                 const int64_t n = r.signal.n;
                 if (keep > 0 && n > 2 * keep) {
-                    file.read_signal(r.signal, 0, keep, dst);
-                    file.read_signal(r.signal, n - keep, keep, dst + keep);
+                    file.read_signal(r.signal, 0, keep, dst, cache);
+                    file.read_signal(r.signal, n - keep, keep, dst + keep, cache);
                 } else {
-                    file.read_signal(r.signal, 0, n, dst);
+                    file.read_signal(r.signal, 0, n, dst, cache);
                 }
             });
         });

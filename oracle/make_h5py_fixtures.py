@@ -174,6 +174,9 @@ def cases(profile):
             add('chunks_9000_sparse_fixed_%s' % tag, libver=libver, layout='single_old',
                 lengths=[9000], signal=dict(storage='chunked', chunk=3,
                                             sparse=[0, 300, 4500, 8997]))
+    if full:    # a container over 8 MiB: the native reader maps those and preads the payloads
+        add('container_over_8MiB_old', libver='earliest', layout='multi', reads=40,
+            lengths=[120000, 90000], signal=dict(storage='chunked', chunk=30000))
     if full:    # 140,001 one-sample chunks: paged data blocks behind super blocks
         add('chunks_140k_unlimited_new', libver='latest', layout='single_old', lengths=[140001],
             signal=dict(storage='chunked', chunk=1, unlimited=True))

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] in the small: stream multi-read fast5 containers of MinKNOW's size
+(4,000 reads per file) through the native loader and both models, the way ``deepbinner realtime``
+does when it finds multi-read files (Session._tabulate_multi_read_files).
+
+The containers are written on the spot by the image's one interpreter with h5py
+(/opt/conda/bin/python3.9; gzip level 1, one chunk per read, the layout MinKNOW / ont_fast5_api
+write); without it the tool says so and exits.  Reported:
+  1. f5_load_reads alone (scanned ends only) at several thread counts, and the Python reader;
+  2. load + classify with start and end models, scan_size 6144, batch 256, loading of container
+     k + 1 overlapped with classification of container k on a background thread.
+Usage: python tools/multi_read_rate.py [--files 3] [--reads 4000] [--mean-length 27000]"""
+import argparse
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+CONDA_PYTHON = '/opt/conda/bin/python3.9'
+
+WRITER = r'''
+import sys, uuid
+import h5py, numpy as np
+path, n_reads, mean_length, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+rng = np.random.default_rng(seed)
+with h5py.File(path, 'w') as f:
+    f.attrs['file_version'] = np.bytes_('2.0')
+    for k in range(n_reads):
+        n = int(np.clip(rng.lognormal(np.log(mean_length) - 0.32, 0.8), 2000, 400000))
+        levels = rng.normal(450, 80, size=n // 8 + 1)
+        signal = np.clip(np.rint(np.repeat(levels, 8)[:n] + rng.normal(0, 8, size=n)), 0, 2047)
+        read_id = str(uuid.UUID(bytes=rng.bytes(16), version=4))
+        raw = f.create_group('read_' + read_id + '/Raw')
+        raw.attrs['read_id'] = np.bytes_(read_id)
+        raw.attrs['read_number'] = np.int32(k)
+        raw.attrs['start_time'] = np.uint64(k * 4000)
+        raw.attrs['duration'] = np.uint32(n)
+        raw.attrs['median_before'] = 220.0
+        raw.create_dataset('Signal', data=signal.astype('<i2'), chunks=(n,), compression='gzip',
+                           compression_opts=1)
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--files', type=int, default=3)
+    ap.add_argument('--reads', type=int, default=4000)
+    ap.add_argument('--mean-length', type=int, default=27000)
+    opts = ap.parse_args()
+    if not os.path.exists(CONDA_PYTHON):
+        sys.exit('no interpreter with h5py at {}: cannot write the containers'.format(CONDA_PYTHON))
+    from deepbinner_amd import classify, fast5_native, load_fast5s
+    out = {'files': opts.files, 'reads_per_file': opts.reads, 'host_threads': os.cpu_count()}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = [os.path.join(tmp, 'batch_%d.fast5' % k) for k in range(opts.files)]
+        t0 = time.perf_counter()
+        jobs = [subprocess.Popen([CONDA_PYTHON, '-c', WRITER, p, str(opts.reads),
+                                  str(opts.mean_length), str(100 + k)])
+                for k, p in enumerate(paths)]
+        if any(j.wait() != 0 for j in jobs):
+            sys.exit('writing the containers with h5py failed')
+        out['h5py_write_seconds'] = round(time.perf_counter() - t0, 1)
+        out['container_MB'] = round(sum(os.path.getsize(p) for p in paths) / 1e6 / opts.files, 1)
+
+        ids, samples, offsets, status = fast5_native.load_reads(paths[0], threads=8)
+        assert (status == 0).all() and len(ids) == opts.reads
+        out['mean_samples_per_read'] = int(offsets[-1] // opts.reads)
+        rates = {}
+        for threads in (1, 8, 16, 32, 64, 128):
+            if threads > (os.cpu_count() or 1):
+                continue
+            t0 = time.perf_counter()
+            for p in paths:
+                fast5_native.load_reads(p, keep=6656, threads=threads)
+            rates['%d threads' % threads] = round(opts.files * opts.reads /
+                                                  (time.perf_counter() - t0))
+        os.environ['DEEPBINNER_FAST5_READER'] = 'python'
+        t0 = time.perf_counter()
+        n = 0
+        for _, _ in load_fast5s.iter_reads(paths[0]):
+            n += 1
+            if n == 500:
+                break
+        rates['python reader (500 reads)'] = round(n / (time.perf_counter() - t0))
+        os.environ['DEEPBINNER_FAST5_READER'] = 'native'
+        out['f5_load_reads, scanned ends'] = {'reads_per_s': rates}
+
+        models = os.path.join(REPO, 'deepbinner_amd', 'models')
+        sm, si, em, ei, osz, _ = classify.load_and_check_models(
+            os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
+            os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
+        args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144, score_diff=0.5,
+                                  require_either=True, require_start=False, require_both=False)
+        threads = min(32, max(1, (os.cpu_count() or 4) // 4))
+
+        def load(path, box):
+            box.append(fast5_native.load_reads(path, keep=6144 + 512, threads=threads))
+
+        calls = {}
+        t0 = time.perf_counter()
+        box = []
+        worker = threading.Thread(target=load, args=(paths[0], box))
+        worker.start()
+        for k in range(opts.files):
+            worker.join()
+            ids, samples, offsets, _ = box.pop()
+            if k + 1 < opts.files:
+                worker = threading.Thread(target=load, args=(paths[k + 1], box))
+                worker.start()
+            signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
+            for lo in range(0, len(ids), args.batch_size):
+                classify.classify_read_batch(ids[lo:lo + args.batch_size],
+                                             signals[lo:lo + args.batch_size], sm, si, em, ei,
+                                             osz, args, calls)
+        dt = time.perf_counter() - t0
+        out['load + classify (start and end models, scan 6144, batch 256)'] = {
+            'loader_threads': threads, 'seconds': round(dt, 3),
+            'reads_per_s': round(opts.files * opts.reads / dt), 'distinct_reads': len(calls)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
