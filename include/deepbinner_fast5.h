@@ -68,8 +68,9 @@ typedef struct f5_batch f5_batch;
 int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n_threads,
                   f5_batch** out);
 /* The same for reads [first, first + count) of ONE file - the way into multi-read fast5 files
- * (realtime.py:183-190 unpacks those with an external tool first): every worker thread opens the
- * file for itself, the reads are dealt out one by one.  Layout of the result as above. */
+ * (realtime.py:183-190 unpacks those with an external tool first): the file is opened and parsed
+ * once, the worker threads share it and are dealt the reads one by one.  Layout of the result as
+ * above. */
 int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
                   f5_batch** out);
 const int16_t* f5_batch_samples(const f5_batch* batch);
