@@ -15,6 +15,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -75,9 +77,21 @@ struct SignalInfo {
 // The chunk inflated last.  A read stored as ONE chunk (common) is asked for twice, once per end,
 // and deflate cannot be entered in the middle.  One per thread: a Fast5 whose reads are resolved
 // is read-only otherwise, so several threads can decode different reads of it at once.
+// It also owns what decoding needs over and over - the second buffer of the filter pipeline and
+// the inflate state - so that a thread working through thousands of reads does not allocate and
+// free ~150 KB per read (in a fresh malloc arena that is a heap grow / trim per read, which
+// serialises the threads on the address-space lock).
 struct ChunkCache {
-    std::vector<uint8_t> data;
+    std::vector<uint8_t> data, scratch;
     uint64_t addr = ~0ull, bytes = 0;
+    z_stream zs;
+    bool zs_ready = false;
+    ChunkCache() { std::memset(&zs, 0, sizeof(zs)); }
+    ~ChunkCache() {
+        if (zs_ready) inflateEnd(&zs);
+    }
+    ChunkCache(const ChunkCache&) = delete;
+    ChunkCache& operator=(const ChunkCache&) = delete;
 };
 
 struct ReadEntry {
@@ -761,10 +775,15 @@ class Fast5 {
     }
 
     static void inflate_all(const uint8_t* src, size_t src_len, size_t hint,
-                            std::vector<uint8_t>* out) {
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (inflateInit(&zs) != Z_OK) throw FormatError("zlib init failed");
+                            std::vector<uint8_t>* out, ChunkCache* cache) {
+        z_stream& zs = cache->zs;
+        if (cache->zs_ready) {
+            if (inflateReset(&zs) != Z_OK) throw FormatError("zlib reset failed");
+        } else {
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit(&zs) != Z_OK) throw FormatError("zlib init failed");
+            cache->zs_ready = true;
+        }
         out->resize(std::max<size_t>(hint, 64));
         zs.next_in = const_cast<Bytef*>(src);
         zs.avail_in = (uInt)src_len;
@@ -775,25 +794,22 @@ class Fast5 {
             const int rc = inflate(&zs, Z_NO_FLUSH);
             produced = out->size() - zs.avail_out;
             if (rc == Z_STREAM_END) break;
-            if (rc != Z_OK || (zs.avail_in == 0 && zs.avail_out != 0)) {
-                inflateEnd(&zs);
+            if (rc != Z_OK || (zs.avail_in == 0 && zs.avail_out != 0))
                 throw FormatError("corrupt deflate stream");
-            }
             if (zs.avail_out == 0) {
-                if (out->size() > (1u << 30)) {
-                    inflateEnd(&zs);
+                if (out->size() > (1u << 30))
                     throw FormatError("chunk inflates to an implausible size");
-                }
                 out->resize(out->size() * 2);
             }
         }
-        inflateEnd(&zs);
         out->resize(produced);
     }
 
     // one stored chunk -> its elements (filters undone in reverse order, short chunks zero-extended)
     void decode_chunk(const SignalInfo& s, uint64_t addr, uint64_t nbytes, uint32_t mask,
-                      std::vector<uint8_t>* raw) const {
+                      ChunkCache* cache) const {
+        std::vector<uint8_t>* raw = &cache->data;
+        std::vector<uint8_t>& tmp = cache->scratch;
         const uint64_t start = file_off(addr);
         need(start, nbytes);
         if (mapped_ && fd_ >= 0) {
@@ -810,12 +826,11 @@ class Fast5 {
         } else {
             raw->assign(buf_ + start, buf_ + start + nbytes);
         }
-        std::vector<uint8_t> tmp;
         for (int i = (int)s.filters.size() - 1; i >= 0; --i) {
             if (mask & (1u << i)) continue;
             const Filter& f = s.filters[(size_t)i];
             if (f.id == 1) {
-                inflate_all(raw->data(), raw->size(), (size_t)s.chunk_elems * 2 + 8, &tmp);
+                inflate_all(raw->data(), raw->size(), (size_t)s.chunk_elems * 2 + 8, &tmp, cache);
                 raw->swap(tmp);
             } else if (f.id == 2) {
                 const size_t esize = f.cd.empty() ? 2 : f.cd[0];
@@ -847,7 +862,7 @@ class Fast5 {
         // for twice, once per end, and deflate cannot be entered in the middle
         if (cache->addr != addr || cache->bytes != nbytes) {
             cache->addr = ~0ull;
-            decode_chunk(s, addr, nbytes, mask, &cache->data);
+            decode_chunk(s, addr, nbytes, mask, cache);
             cache->addr = addr;
             cache->bytes = nbytes;
         }
@@ -1078,8 +1093,21 @@ struct f5_file {
     explicit f5_file(const char* path) : impl(path) {}
 };
 
+// Packed samples of a batch.  Deliberately NOT value-initialised: a std::vector would zero 100+ MB
+// on the calling thread before the workers start (a third of the time of a 4,000-read container
+// at 64 threads); this way the pages are first touched by the threads that fill them.
+struct SampleBuffer {
+    std::unique_ptr<int16_t[]> store;
+    size_t count = 0;
+    void resize(size_t n) {
+        store.reset(n ? new int16_t[n] : nullptr);
+        count = n;
+    }
+    int16_t* data() const { return store.get(); }
+};
+
 struct f5_batch {
-    std::vector<int16_t> samples;
+    SampleBuffer samples;
     std::vector<int64_t> offsets;
     std::vector<int32_t> status;
     std::vector<char> read_ids;
@@ -1177,18 +1205,23 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
         auto decode_one = [&](int64_t i) {
             if (batch->status[(size_t)i] != F5_OK) return;
             int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
+            // buffers and inflate state live as long as the worker thread; what they hold is
+            // another file's chunk, so the key is cleared
+            thread_local ChunkCache cache;
+            cache.addr = ~0ull;
             const int rc = guarded([&] {
                 Fast5& file = *files[(size_t)i];
                 const ReadEntry& r = file.read(0);
                 const int64_t n = r.signal.n;
                 if (keep > 0 && n > 2 * keep) {
-                    file.read_signal(r.signal, 0, keep, dst);
-                    file.read_signal(r.signal, n - keep, keep, dst + keep);
+                    file.read_signal(r.signal, 0, keep, dst, &cache);
+                    file.read_signal(r.signal, n - keep, keep, dst + keep, &cache);
                 } else {
-                    file.read_signal(r.signal, 0, n, dst);
+                    file.read_signal(r.signal, 0, n, dst, &cache);
                 }
             });
             files[(size_t)i].reset();
+            if (rc != F5_OK) std::memset(dst, 0, (size_t)lengths[(size_t)i] * 2);
             batch->status[(size_t)i] = rc;
         };
 
@@ -1233,7 +1266,7 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
 
 int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
                   f5_batch** out) {
-    if (!path || !out || first < 0 || count < 0) return F5_ERR_ARGUMENT;
+    if (!path || !out || first < 0) return F5_ERR_ARGUMENT;
     *out = nullptr;
     f5_batch* batch = nullptr;
     try {
@@ -1242,17 +1275,25 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         // own entry), after which the reader is read-only and pass 2 needs per-thread state only
         // for the chunk inflated last.  Two passes like f5_load_batch: lengths, prefix sum,
         // inflate into place.
-        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-        threads = std::max(1, std::min(threads, 64));
-        threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
+        const bool timing = std::getenv("DEEPBINNER_FAST5_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto t_start = now();
         std::unique_ptr<Fast5> shared;
         const int open_status = guarded([&] {
             shared.reset(new Fast5(path));
             shared->parse();
         });
         if (open_status != F5_OK) return open_status;
+        if (count < 0) count = std::max<int64_t>(shared->n_reads() - first, 0);   // to the end
         if (first + count > shared->n_reads()) return F5_ERR_NO_READ;
+        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        threads = std::max(1, std::min(threads, 64));
+        threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
         std::vector<ChunkCache> caches((size_t)threads);
+        const auto t_parsed = now();
 
         batch = new f5_batch;
         batch->offsets.assign((size_t)count + 1, 0);
@@ -1282,6 +1323,7 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
                 copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
             });
         });
+        const auto t_resolved = now();
         int64_t total = 0;
         for (int64_t i = 0; i < count; ++i) {
             batch->offsets[(size_t)i] = total;
@@ -1289,10 +1331,11 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         }
         batch->offsets[(size_t)count] = total;
         batch->samples.resize((size_t)total);
+        const auto t_allocated = now();
         run_parallel([&](Fast5& file, int64_t i, ChunkCache* cache) {
             if (batch->status[(size_t)i] != F5_OK) return;
             int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
-            batch->status[(size_t)i] = guarded([&] {
+            const int rc = guarded([&] {
                 const ReadEntry& r = file.read(first + i);
                 const int64_t n = r.signal.n;
                 if (keep > 0 && n > 2 * keep) {
@@ -1302,10 +1345,18 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
                     file.read_signal(r.signal, 0, n, dst, cache);
                 }
             });
+            if (rc != F5_OK) std::memset(dst, 0, (size_t)lengths[(size_t)i] * 2);
+            batch->status[(size_t)i] = rc;
         });
         for (int64_t i = 0; i < count; ++i)
             if (batch->status[(size_t)i] != F5_OK)
                 std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+        if (timing)
+            std::fprintf(stderr,
+                         "f5_load_reads: %lld reads, %d threads: open+parse %.1f ms, resolve %.1f ms, "
+                         "allocate %.1f ms, inflate %.1f ms\n",
+                         (long long)count, threads, ms(t_start, t_parsed), ms(t_parsed, t_resolved),
+                         ms(t_resolved, t_allocated), ms(t_allocated, now()));
     } catch (const std::exception&) {
         delete batch;
         return F5_ERR_OPEN;
@@ -1314,6 +1365,7 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
     return F5_OK;
 }
 
+int64_t f5_batch_size(const f5_batch* batch) { return batch ? (int64_t)batch->status.size() : 0; }
 const int16_t* f5_batch_samples(const f5_batch* batch) { return batch ? batch->samples.data() : nullptr; }
 const int64_t* f5_batch_offsets(const f5_batch* batch) { return batch ? batch->offsets.data() : nullptr; }
 const int32_t* f5_batch_status(const f5_batch* batch) { return batch ? batch->status.data() : nullptr; }

@@ -23,7 +23,7 @@ LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 
 EXPORTED_SYMBOLS = [
     'f5_version', 'f5_status_string', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
-    'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
+    'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_size', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
     'f5_batch_read_ids', 'f5_batch_free',
 ]
 
@@ -64,6 +64,7 @@ def load_library():
                                    np.ctypeslib.ndpointer(np.int16, flags='C_CONTIGUOUS')]),
         'f5_load_batch': (c_int, [P(c_char_p), c_i64, c_i64, c_int, P(c_void_p)]),
         'f5_load_reads': (c_int, [c_char_p, c_i64, c_i64, c_i64, c_int, P(c_void_p)]),
+        'f5_batch_size': (ctypes.c_int64, [c_void_p]),
         'f5_batch_samples': (P(ctypes.c_int16), [c_void_p]),
         'f5_batch_offsets': (P(c_i64), [c_void_p]),
         'f5_batch_status': (P(ctypes.c_int32), [c_void_p]),
@@ -187,14 +188,19 @@ def _unpack_batch(lib, handle, n):
     else:
         samples = np.empty(0, dtype=np.int16)
         lib.f5_batch_free(handle)
-    read_ids = []
-    for i in range(n):
-        slot = raw[i * F5_READ_ID_MAX:(i + 1) * F5_READ_ID_MAX]
-        try:
-            read_ids.append(slot.split(b'\x00')[0].decode() if st[i] == F5_OK else None)
-        except UnicodeDecodeError:          # a damaged id: treat the read as unreadable
-            read_ids.append(None)
-            st[i] = F5_ERR_FORMAT
+    # the slots are NUL padded: numpy's fixed-width bytes type strips that in C
+    slots = np.frombuffer(raw, dtype='S%d' % F5_READ_ID_MAX).tolist() if n else []
+    readable = (st == F5_OK).tolist()
+    try:
+        read_ids = [slot.decode() if ok else None for slot, ok in zip(slots, readable)]
+    except UnicodeDecodeError:              # a damaged id somewhere: one by one
+        read_ids = []
+        for i, (slot, ok) in enumerate(zip(slots, readable)):
+            try:
+                read_ids.append(slot.decode() if ok else None)
+            except UnicodeDecodeError:      # treat the read as unreadable
+                read_ids.append(None)
+                st[i] = F5_ERR_FORMAT
     return read_ids, samples, offsets, st
 
 
@@ -218,12 +224,10 @@ def load_reads(fast5_file, first=0, count=None, keep=None, threads=0):
     """Reads [first, first + count) of one (multi-read) fast5 file, loaded by native threads:
     (read_ids, samples, offsets, status) as from load_batch.  count None = to the end."""
     lib = load_library()
-    if count is None:
-        with File(fast5_file) as f:
-            count = max(f.n_reads - first, 0)
     handle = ctypes.c_void_p()
-    status = lib.f5_load_reads(os.fsencode(str(fast5_file)), int(first), int(count),
-                               int(keep or 0), int(threads), ctypes.byref(handle))
+    status = lib.f5_load_reads(os.fsencode(str(fast5_file)), int(first),
+                               -1 if count is None else int(count), int(keep or 0),
+                               int(threads), ctypes.byref(handle))
     if status != F5_OK:
         raise Fast5NativeError('{}: {}'.format(fast5_file, status_string(status)))
-    return _unpack_batch(lib, handle, int(count))
+    return _unpack_batch(lib, handle, int(lib.f5_batch_size(handle)))

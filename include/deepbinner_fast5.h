@@ -72,7 +72,8 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
  * once, the worker threads share it and are dealt the reads one by one.  Layout of the result as
  * above. */
 int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
-                  f5_batch** out);
+                  f5_batch** out);                        /* count < 0: from `first` to the end */
+int64_t f5_batch_size(const f5_batch* batch);             /* files / reads in the batch */
 const int16_t* f5_batch_samples(const f5_batch* batch);
 const int64_t* f5_batch_offsets(const f5_batch* batch);   /* n_files + 1 */
 const int32_t* f5_batch_status(const f5_batch* batch);    /* n_files */
