@@ -20,6 +20,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 from . import classify
@@ -168,21 +169,46 @@ class Session:
         return [(rid, samples[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(ids)
                 if rid is not None]
 
+    def _containers(self, fast5s):
+        """(path, reads) per file, file k + 1 being loaded on a background thread (the native
+        loader releases the GIL) while the caller classifies file k."""
+        box = {}
+
+        def load(path):
+            try:
+                box[path] = list(self._reads_of(path))
+            except Exception as e:          # surfaces on the consuming side
+                box[path] = e
+
+        worker = None
+        for k, path in enumerate(fast5s):
+            if worker is None:
+                load(path)
+            else:
+                worker.join()
+            if k + 1 < len(fast5s):
+                worker = threading.Thread(target=load, args=(fast5s[k + 1],), daemon=True)
+                worker.start()
+            reads = box.pop(path)
+            if isinstance(reads, Exception):
+                raise reads
+            yield path, reads
+
     def _tabulate_multi_read_files(self, fast5s):
-        reads = [(read_id, signal, path) for path in fast5s
-                 for read_id, signal in self._reads_of(path)]
-        calls, rows = {}, []
-        total = max(len(reads), 1)
-        classify.print_classification_progress(0, total, 'reads', out_dest=sys.stdout)
-        for chunk in classify.chunker(reads, self.args.batch_size):
-            ids = [r[0] for r in chunk]
-            classify.classify_read_batch(ids, [r[1] for r in chunk], *self._models(), self.args,
-                                         calls)
-            rows.extend('{}\t{}\t{}'.format(rid, calls[rid], path) for rid, _, path in chunk)
-            classify.print_classification_progress(len(calls), total, 'reads',
-                                                   out_dest=sys.stdout)
+        calls, done = {}, 0
         with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
-            table.writelines(row + '\n' for row in rows)
+            for n_files, (path, reads) in enumerate(self._containers(fast5s), start=1):
+                # the total is known once the last container is open; until then, extrapolate
+                total = max((done + len(reads)) * len(fast5s) // n_files, 1)
+                classify.print_classification_progress(done, total, 'reads', out_dest=sys.stdout)
+                for chunk in classify.chunker(reads, self.args.batch_size):
+                    ids = [r[0] for r in chunk]
+                    classify.classify_read_batch(ids, [r[1] for r in chunk], *self._models(),
+                                                 self.args, calls)
+                    table.writelines('{}\t{}\t{}\n'.format(rid, calls[rid], path) for rid in ids)
+                    done += len(ids)
+                    classify.print_classification_progress(min(done, total), total, 'reads',
+                                                           out_dest=sys.stdout)
         return calls
 
 
