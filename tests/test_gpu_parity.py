@@ -215,7 +215,9 @@ def test_live_kernel_timing_brackets(hip_models):
         assert np.array_equal(model.predict(base), want)
     ms, launches, windows = model.timing_read()
     assert launches == 6 and windows == 6 * 32 and ms > 0
-    assert 0.005 < ms / launches < 5.0       # tens of microseconds per launch
+    # tens of microseconds per launch, plus whatever the host did between the two blocking
+    # predict() calls of a bracket (seen: 9 ms once, in the middle of the full suite)
+    assert 0.005 < ms / launches < 100.0
     model.timing_enable(3, 3)
     for _ in range(5):                       # bracket {0,1,2} closed, {3,4,..} still open
         model.predict(base)
