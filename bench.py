@@ -42,7 +42,7 @@ N_READS = 10000
 BATCH = 256
 SCAN_SIZE = 512
 SCORE_DIFF = 0.5
-TIMING_STRIDE = 8           # an event bracket opens at every 8th forward launch ...
+TIMING_STRIDE = 20          # an event bracket opens at every 20th forward launch ...
 TIMING_SPAN = 4             # ... and covers 4 consecutive (full, 256-window) launches
 
 
@@ -177,7 +177,7 @@ def main():
     sync()
     barrier()
     sync()
-    # One HIP event pair around launches 8k .. 8k+3 of the 40 launches of a step (all full,
+    # One HIP event pair around launches 20k .. 20k+3 of the 40 launches of a step (all full,
     # 256-window launches; the 16-window tail launch is never inside a bracket).  A pair around
     # EVERY launch costs ~7 us of queue time per batch and slows what is being measured, and a
     # pair around a single launch includes ~2.5 us of dispatch latency that back-to-back launches
