@@ -132,6 +132,8 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
             read_id_to_fast5_file[read_id] = fast5_file
             read_ids.append(read_id)
             signals.append(signal)
+        if getattr(loaded, 'complete', False):      # nothing was skipped: the packed buffer
+            signals = PackedSignals(signals, loaded.samples, loaded.offsets)   # is these reads
 
         lines = classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
                                     end_input_size, output_size, args, classifications)
@@ -196,8 +198,29 @@ def _native_batches(fast5_files, args):
             pending = executor.submit(load, batches[i + 1]) if i + 1 < len(batches) else None
             if (status == fast5_native.F5_ERR_MULTI).any():
                 sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
-            yield [(f, read_ids[k], samples[offsets[k]:offsets[k + 1]] if read_ids[k] is not None
-                    else None) for k, f in enumerate(batch)]
+            loaded = PackedBatch((f, read_ids[k], samples[offsets[k]:offsets[k + 1]]
+                                  if read_ids[k] is not None else None)
+                                 for k, f in enumerate(batch))
+            loaded.samples, loaded.offsets = samples, offsets
+            loaded.complete = all(r is not None for r in read_ids)
+            yield loaded
+
+
+class PackedBatch(list):
+    """What the native loader returns for a batch - the (fast5_file, read_id, signal) triples the
+    reference's loop builds - together with the packed buffer the signals are slices of:
+    ``samples`` / ``offsets`` in exactly the layout the C ABI takes (dbh_classify_i16), so that
+    a batch without unreadable files can go to the GPU as it is (``complete``)."""
+    samples = offsets = None
+    complete = False
+
+
+class PackedSignals(list):
+    """The list of signals ``call_batch`` is handed, plus the packed form of the same reads."""
+
+    def __init__(self, signals, samples, offsets):
+        super().__init__(signals)
+        self.packed = (samples, offsets)
 
 
 def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
@@ -367,7 +390,13 @@ def call_batch(input_size, output_size, read_ids, signals, model, args, side):
 
     if hasattr(model, 'classify_signals'):
         # Seam b2: the whole of this function runs on the GPU.
-        probs, calls = model.classify_signals(signals, side, int(args.scan_size), args.score_diff)
+        packed = getattr(signals, 'packed', None)
+        if packed is not None and hasattr(model, 'classify_packed'):
+            probs, calls = model.classify_packed(packed[0], packed[1], side, int(args.scan_size),
+                                                 args.score_diff)
+        else:
+            probs, calls = model.classify_signals(signals, side, int(args.scan_size),
+                                                  args.score_diff)
         barcode_calls = ['none' if c == 0 else str(int(c)) for c in calls]
         return barcode_calls, [row for row in probs]
 

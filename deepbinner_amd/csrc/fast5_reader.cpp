@@ -16,11 +16,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -103,7 +105,10 @@ struct ReadEntry {
 
 class Fast5 {
   public:
-    explicit Fast5(const char* path) {
+    // `reuse`: a buffer of the caller's (a worker thread's) that small files are read into
+    // instead of one allocated per file - a few hundred KB per file is above malloc's mmap
+    // threshold, i.e. an mmap + munmap per file, which many threads queue up on
+    explicit Fast5(const char* path, std::vector<uint8_t>* reuse = nullptr) {
         fd_ = ::open(path, O_RDONLY);
         if (fd_ < 0) throw std::runtime_error("cannot open file");
         struct stat st;
@@ -116,10 +121,11 @@ class Fast5 {
         if (len_ <= kReadWhole) {
             // one-read files are a few hundred KB: read() them - with many loader threads every
             // mmap/munmap would queue on the process-wide address-space lock
-            owned_.resize((size_t)len_);
+            std::vector<uint8_t>& bytes = reuse ? *reuse : owned_;
+            if (bytes.size() < len_) bytes.resize((size_t)len_);
             uint64_t got = 0;
             while (got < len_) {
-                const ssize_t k = ::pread(fd_, owned_.data() + got, (size_t)(len_ - got), (off_t)got);
+                const ssize_t k = ::pread(fd_, bytes.data() + got, (size_t)(len_ - got), (off_t)got);
                 if (k <= 0) {
                     ::close(fd_);
                     fd_ = -1;
@@ -129,7 +135,7 @@ class Fast5 {
             }
             ::close(fd_);
             fd_ = -1;
-            buf_ = owned_.data();
+            buf_ = bytes.data();
             return;
         }
         void* p = mmap(nullptr, len_, PROT_READ, MAP_PRIVATE, fd_, 0);
@@ -1088,6 +1094,115 @@ void copy_read_id(const std::string& id, char* dst) {
 
 }  // namespace
 
+// Worker threads that outlive the call: a batch of 256 one-read files is 3-4 ms of work, and
+// starting and joining 32-64 threads twice per batch was a third of it.  One job at a time; a
+// caller that finds the pool busy (several threads in f5_load_batch at once) starts threads of its
+// own as before.  The calling thread always works too (slot 0).
+class WorkerPool {
+  public:
+    using Job = std::function<void(int64_t item, int slot)>;
+
+    ~WorkerPool() {
+        if (getpid() != owner_) {      // a forked child: the threads exist in the parent only
+            for (std::thread& t : workers_) t.detach();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+
+    // items 0 .. count-1, each exactly once, on up to `threads` threads; slot < threads
+    void run(int threads, int64_t count, const Job& job) {
+        threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, count));
+        if (threads == 1) {
+            for (int64_t i = 0; i < count; ++i) job(i, 0);
+            return;
+        }
+        std::unique_lock<std::mutex> owner(busy_, std::try_to_lock);
+        if (!owner.owns_lock() || getpid() != owner_) {
+            run_on_new_threads(threads, count, job);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            while ((int)workers_.size() < threads - 1) {
+                const int slot = (int)workers_.size() + 1;
+                workers_.emplace_back([this, slot] { worker(slot); });
+            }
+            job_ = &job;
+            count_ = count;
+            next_.store(0);
+            helpers_ = threads - 1;
+            unfinished_ = threads - 1;
+            ++generation_;
+        }
+        wake_.notify_all();
+        drain(job, 0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return unfinished_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void drain(const Job& job, int slot) {
+        for (int64_t i = next_.fetch_add(1); i < count_; i = next_.fetch_add(1)) {
+            try {
+                job(i, slot);
+            } catch (...) {    // jobs report through their own status fields; never unwind a worker
+            }
+        }
+    }
+    void worker(int slot) {
+        uint64_t seen = 0;
+        for (;;) {
+            const Job* job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return stop_ || (generation_ != seen && slot <= helpers_); });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+            }
+            drain(*job, slot);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --unfinished_;
+            }
+            done_.notify_one();
+        }
+    }
+    static void run_on_new_threads(int threads, int64_t count, const Job& job) {
+        std::atomic<int64_t> next(0);
+        auto body = [&](int slot) {
+            for (int64_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) job(i, slot);
+        };
+        std::vector<std::thread> extra;
+        for (int t = 1; t < threads; ++t) extra.emplace_back(body, t);
+        body(0);
+        for (std::thread& t : extra) t.join();
+    }
+
+    const pid_t owner_ = getpid();
+    std::mutex busy_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> workers_;
+    const Job* job_ = nullptr;
+    int64_t count_ = 0;
+    std::atomic<int64_t> next_{0};
+    int helpers_ = 0, unfinished_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+WorkerPool& worker_pool() {
+    static WorkerPool pool;
+    return pool;
+}
+
 struct f5_file {
     Fast5 impl;
     explicit f5_file(const char* path) : impl(path) {}
@@ -1178,71 +1293,63 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
         batch->offsets.assign((size_t)n_files + 1, 0);
         batch->status.assign((size_t)n_files, F5_ERR_OPEN);
         batch->read_ids.assign((size_t)n_files * F5_READ_ID_MAX, 0);
-        // Two parallel passes: (1) open + parse every file and learn how many samples it will
-        // contribute, (2) after a prefix sum, inflate straight into the packed buffer.
-        std::vector<std::unique_ptr<Fast5>> files((size_t)n_files);
+        // Pass 1, per file and entirely on one worker thread: read the file into the thread's
+        // buffer, parse it, inflate what is asked for into a staging block of its own.  Pass 2,
+        // after a prefix sum of the lengths: copy the staging blocks into the packed buffer.
+        // (Keeping the parsed files from a first pass to a second one cost an mmap-sized
+        // allocation per file; the extra copy of 13-26 KB per read is nothing beside it.)
+        std::vector<std::unique_ptr<int16_t[]>> staged((size_t)n_files);
         std::vector<int64_t> lengths((size_t)n_files, 0);
 
-        auto open_one = [&](int64_t i) {
+        auto load_one = [&](int64_t i) {
+            thread_local std::vector<uint8_t> file_bytes;
+            thread_local ChunkCache cache;
+            cache.addr = ~0ull;            // what it holds is another file's chunk
             bool multi = false;
             int rc = paths[i] ? F5_OK : F5_ERR_ARGUMENT;
             if (rc == F5_OK) rc = guarded([&] {
-                std::unique_ptr<Fast5> file(new Fast5(paths[i]));
-                file->parse();
-                if (file->layout() == F5_LAYOUT_MULTI) {
+                Fast5 file(paths[i], &file_bytes);
+                file.parse();
+                if (file.layout() == F5_LAYOUT_MULTI) {
                     multi = true;
                     return;
                 }
-                const ReadEntry& r = file->read(0);
-                const int64_t n = r.signal.n;
-                lengths[(size_t)i] = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
-                copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
-                files[(size_t)i] = std::move(file);
-            });
-            if (multi) rc = F5_ERR_MULTI;
-            batch->status[(size_t)i] = rc;
-        };
-        auto decode_one = [&](int64_t i) {
-            if (batch->status[(size_t)i] != F5_OK) return;
-            int16_t* dst = batch->samples.data() + batch->offsets[(size_t)i];
-            // buffers and inflate state live as long as the worker thread; what they hold is
-            // another file's chunk, so the key is cleared
-            thread_local ChunkCache cache;
-            cache.addr = ~0ull;
-            const int rc = guarded([&] {
-                Fast5& file = *files[(size_t)i];
                 const ReadEntry& r = file.read(0);
                 const int64_t n = r.signal.n;
-                if (keep > 0 && n > 2 * keep) {
-                    file.read_signal(r.signal, 0, keep, dst, &cache);
-                    file.read_signal(r.signal, n - keep, keep, dst + keep, &cache);
+                const int64_t kept = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                std::unique_ptr<int16_t[]> block(new int16_t[(size_t)std::max<int64_t>(kept, 1)]);
+                if (kept < n) {
+                    file.read_signal(r.signal, 0, keep, block.get(), &cache);
+                    file.read_signal(r.signal, n - keep, keep, block.get() + keep, &cache);
                 } else {
-                    file.read_signal(r.signal, 0, n, dst, &cache);
+                    file.read_signal(r.signal, 0, n, block.get(), &cache);
                 }
+                copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
+                lengths[(size_t)i] = kept;
+                staged[(size_t)i] = std::move(block);
             });
-            files[(size_t)i].reset();
-            if (rc != F5_OK) std::memset(dst, 0, (size_t)lengths[(size_t)i] * 2);
+            if (multi) rc = F5_ERR_MULTI;
+            if (rc != F5_OK) {      // unreadable, or damaged where only inflating shows it
+                lengths[(size_t)i] = 0;
+                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            }
             batch->status[(size_t)i] = rc;
+        };
+        auto pack_one = [&](int64_t i) {
+            if (!staged[(size_t)i]) return;
+            std::memcpy(batch->samples.data() + batch->offsets[(size_t)i], staged[(size_t)i].get(),
+                        (size_t)lengths[(size_t)i] * 2);
+            staged[(size_t)i].reset();
         };
 
         int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
         threads = std::max(1, std::min(threads, 64));
         threads = (int)std::min<int64_t>(threads, std::max<int64_t>(n_files, 1));
         auto run_parallel = [&](const std::function<void(int64_t)>& fn) {
-            std::atomic<int64_t> next(0);
-            auto worker = [&] {
-                for (int64_t i = next.fetch_add(1); i < n_files; i = next.fetch_add(1)) fn(i);
-            };
-            if (threads == 1) {
-                worker();
-                return;
-            }
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-            for (std::thread& t : pool) t.join();
+            worker_pool().run(threads, n_files, [&](int64_t i, int) { fn(i); });
         };
 
-        run_parallel(open_one);
+        run_parallel(load_one);
         int64_t total = 0;
         for (int64_t i = 0; i < n_files; ++i) {
             batch->offsets[(size_t)i] = total;
@@ -1250,12 +1357,7 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
         }
         batch->offsets[(size_t)n_files] = total;
         batch->samples.resize((size_t)total);
-        run_parallel(decode_one);
-        // a read whose Signal failed to decode keeps its (zero-filled) slot but loses its id,
-        // exactly like a file that could not be opened: callers skip it by status
-        for (int64_t i = 0; i < n_files; ++i)
-            if (batch->status[(size_t)i] != F5_OK)
-                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+        run_parallel(pack_one);
     } catch (const std::exception&) {
         delete batch;
         return F5_ERR_OPEN;
@@ -1302,18 +1404,9 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         std::vector<int64_t> lengths((size_t)count, 0);
 
         auto run_parallel = [&](const std::function<void(Fast5&, int64_t, ChunkCache*)>& fn) {
-            std::atomic<int64_t> next(0);
-            auto worker = [&](int t) {
-                for (int64_t i = next.fetch_add(1); i < count; i = next.fetch_add(1))
-                    fn(*shared, i, &caches[(size_t)t]);
-            };
-            if (threads == 1) {
-                worker(0);
-                return;
-            }
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t);
-            for (std::thread& t : pool) t.join();
+            worker_pool().run(threads, count, [&](int64_t i, int slot) {
+                fn(*shared, i, &caches[(size_t)slot]);
+            });
         };
         run_parallel([&](Fast5& file, int64_t i, ChunkCache*) {
             batch->status[(size_t)i] = guarded([&] {

@@ -370,6 +370,27 @@ class HipModel:
                   'dbh_classify_i16')
         return probs, calls
 
+    def classify_packed(self, samples, offsets, side, scan_size, score_diff):
+        """``classify_signals`` for reads that are already packed the way the C ABI takes them:
+        read i is ``samples[offsets[i]:offsets[i+1]]`` (int16, int64).  A long read may have had
+        its middle dropped as long as the first and the last ``scan_size + input_size // 2``
+        samples are there (what the loaders keep): no window reaches further."""
+        samples = np.ascontiguousarray(samples, dtype=np.int16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        if n < 0 or (n and (offsets[0] != 0 or offsets[-1] != len(samples))):
+            raise ValueError('offsets do not describe the sample buffer')
+        if samples.size == 0:
+            samples = np.zeros(1, dtype=np.int16)
+        probs = np.empty((max(n, 0), self.n_classes), dtype=np.float32)
+        calls = np.empty(max(n, 0), dtype=np.int32)
+        if n > 0:
+            check(self._lib.dbh_classify_i16(self._handle, samples, offsets, n,
+                                             SIDE_START if side == 'start' else SIDE_END,
+                                             int(scan_size), float(score_diff), probs, calls),
+                  'dbh_classify_i16')
+        return probs, calls
+
     # -- device-resident entry points (inputs/outputs are raw device pointers) -----------------
     def workspace_bytes(self, n_reads, scan_size):
         n = ctypes.c_size_t(0)

@@ -61,16 +61,16 @@ int f5_read_signal(f5_file* file, int64_t index, int64_t first, int64_t count, i
  * thread, at most 64).  keep > 0: reads longer than 2*keep contribute their first and last `keep`
  * samples only (windows are cut from those: reference classify.py:337-349); keep <= 0: whole
  * reads.  Read i occupies samples[offsets[i] .. offsets[i+1]); a file that could not be read has
- * status != F5_OK and an empty id (the reference skips such files, load_fast5s.py:47-49); its
- * range is empty, or - when the damage only showed while its Signal was being inflated - zero
- * filled: go by the status.  The result owns its memory until f5_batch_free. */
+ * status != F5_OK, an empty id and an empty range (the reference skips such files,
+ * load_fast5s.py:47-49).  The result owns its memory until f5_batch_free. */
 typedef struct f5_batch f5_batch;
 int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n_threads,
                   f5_batch** out);
 /* The same for reads [first, first + count) of ONE file - the way into multi-read fast5 files
  * (realtime.py:183-190 unpacks those with an external tool first): the file is opened and parsed
  * once, the worker threads share it and are dealt the reads one by one.  Layout of the result as
- * above. */
+ * above, except that a read whose damage only shows while its Signal is inflated keeps its range,
+ * zero filled: go by the status. */
 int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
                   f5_batch** out);                        /* count < 0: from `first` to the end */
 int64_t f5_batch_size(const f5_batch* batch);             /* files / reads in the batch */

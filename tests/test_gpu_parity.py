@@ -407,6 +407,50 @@ def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, sid
     assert np.array_equal(got_p, want_p)
 
 
+def test_packed_batches_from_the_native_loader_go_to_the_gpu_as_they_are(hip_models):
+    """classify_packed on what f5_load_batch returns (first and last scan_size + 512 samples of
+    long reads, back to back) == classify_signals on the whole signals, both sides, and the same
+    through classify_fast5_files with either reader."""
+    import argparse
+    import io
+    import contextlib
+    from conftest import REPO
+    from deepbinner_amd import classify, fast5_native, load_fast5s
+    folder = os.path.join(REPO, 'tests', 'golden', 'fast5', 'single')
+    files = sorted(os.path.join(folder, f) for f in os.listdir(folder)) * 40
+    whole = [load_fast5s._python_get_read_id_and_signal(f)[1] for f in files[:7]] * 40
+    for scan in (6144, 512, 3072):
+        ids, samples, offsets, status = fast5_native.load_batch(files, scan + 512, 4)
+        assert (status == 0).all()
+        for name, side in PLAN:
+            model = hip_models[name]
+            got_p, got_c = model.classify_packed(samples, offsets, side, scan, 0.5)
+            want_p, want_c = model.classify_signals(whole, side, scan, 0.5)
+            assert np.array_equal(got_c, want_c) and np.array_equal(got_p, want_p), (scan, name)
+    with pytest.raises(ValueError):
+        model.classify_packed(samples, offsets[:-1], 'start', 6144, 0.5)
+    p, c = model.classify_packed(np.zeros(0, np.int16), np.zeros(1, np.int64), 'start', 6144, 0.5)
+    assert p.shape == (0, model.n_classes) and c.shape == (0,)
+
+    # the CLI loop: native reader (packed fast path) and Python reader print the same table
+    args = argparse.Namespace(verbose=True, batch_size=64, scan_size=6144, score_diff=0.5,
+                              require_either=True, require_start=False, require_both=False,
+                              loader_procs=0)
+    tables = {}
+    for reader in ('native', 'python'):
+        os.environ['DEEPBINNER_FAST5_READER'] = reader
+        try:
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out), contextlib.redirect_stderr(io.StringIO()):
+                classify.classify_fast5_files(
+                    files[:100], hip_models['EXP-NBD103_read_starts'], 1024,
+                    hip_models['EXP-NBD103_read_ends'], 1024, 13, args, verified_single_read=True)
+            tables[reader] = out.getvalue()
+        finally:
+            del os.environ['DEEPBINNER_FAST5_READER']
+    assert tables['native'] == tables['python'] and tables['native'].count('\n') == 101
+
+
 def test_combine_calls_on_the_device(hip):
     """dbh_combine_calls_dev against the reference's truth table (tests/test_combine_calls.py,
     via classify.combine_calls) for every pair of calls in every mode, in place and out of place,
