@@ -166,8 +166,11 @@ class Session:
                 threads=int(getattr(self.args, 'loader_procs', 0) or 0))
         except OSError:
             return []
-        return [(rid, samples[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(ids)
-                if rid is not None]
+        reads = classify.PackedBatch((rid, samples[offsets[i]:offsets[i + 1]])
+                                     for i, rid in enumerate(ids) if rid is not None)
+        if len(reads) == len(ids):          # nothing dropped: the packed buffer is these reads
+            reads.samples, reads.offsets, reads.complete = samples, offsets, True
+        return reads
 
     def _containers(self, fast5s):
         """(path, reads) per file, file k + 1 being loaded on a background thread (the native
@@ -176,7 +179,8 @@ class Session:
 
         def load(path):
             try:
-                box[path] = list(self._reads_of(path))
+                reads = self._reads_of(path)
+                box[path] = reads if isinstance(reads, list) else list(reads)
             except Exception as e:          # surfaces on the consuming side
                 box[path] = e
 
@@ -201,10 +205,16 @@ class Session:
                 # the total is known once the last container is open; until then, extrapolate
                 total = max((done + len(reads)) * len(fast5s) // n_files, 1)
                 classify.print_classification_progress(done, total, 'reads', out_dest=sys.stdout)
-                for chunk in classify.chunker(reads, self.args.batch_size):
+                for at, chunk in enumerate(classify.chunker(reads, self.args.batch_size)):
                     ids = [r[0] for r in chunk]
-                    classify.classify_read_batch(ids, [r[1] for r in chunk], *self._models(),
-                                                 self.args, calls)
+                    signals = [r[1] for r in chunk]
+                    if getattr(reads, 'complete', False):
+                        # this chunk's part of the container's packed buffer, as the C ABI takes it
+                        lo = at * self.args.batch_size
+                        offsets = reads.offsets[lo:lo + len(chunk) + 1]
+                        signals = classify.PackedSignals(
+                            signals, reads.samples[offsets[0]:offsets[-1]], offsets - offsets[0])
+                    classify.classify_read_batch(ids, signals, *self._models(), self.args, calls)
                     table.writelines('{}\t{}\t{}\n'.format(rid, calls[rid], path) for rid in ids)
                     done += len(ids)
                     classify.print_classification_progress(min(done, total), total, 'reads',

@@ -9,6 +9,7 @@ tighter bounds where the arithmetic allows.  Integer work (calls) must be identi
 import argparse
 import io
 import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -449,6 +450,37 @@ def test_packed_batches_from_the_native_loader_go_to_the_gpu_as_they_are(hip_mod
         finally:
             del os.environ['DEEPBINNER_FAST5_READER']
     assert tables['native'] == tables['python'] and tables['native'].count('\n') == 101
+
+    # realtime on multi-read containers: packed chunks (native) == per-read lists (Python reader)
+    import shutil
+    import deepbinner_amd.realtime as realtime
+    from conftest import MODEL_DIR
+    multi = os.path.join(REPO, 'tests', 'golden', 'fast5', 'multi')
+    rows = {}
+    for reader in ('native', 'python'):
+        os.environ['DEEPBINNER_FAST5_READER'] = reader
+        work = tempfile.mkdtemp()
+        try:
+            in_dir, out_dir = os.path.join(work, 'in'), os.path.join(work, 'out')
+            shutil.copytree(multi, in_dir)
+            rt_args = argparse.Namespace(
+                in_dir=in_dir, out_dir=out_dir, stop=True, scan_size=6144.0, score_diff=0.5,
+                start_model=os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+                end_model=os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw'), batch_size=7,
+                require_either=True, require_start=False, require_both=False)
+            realtime.POLL_SECONDS, keep_poll = 0, realtime.POLL_SECONDS
+            which, shutil.which = shutil.which, (lambda name: None)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    realtime.realtime(rt_args)
+            finally:
+                realtime.POLL_SECONDS, shutil.which = keep_poll, which
+            with open(os.path.join(out_dir, 'multi_read_classifications.tsv')) as f:
+                rows[reader] = sorted(line.split('\t')[:2] for line in f.read().splitlines())
+        finally:
+            del os.environ['DEEPBINNER_FAST5_READER']
+            shutil.rmtree(work)
+    assert rows['native'] == rows['python'] and len(rows['native']) == 30
 
 
 def test_combine_calls_on_the_device(hip):
