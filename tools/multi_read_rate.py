@@ -115,9 +115,10 @@ def main():
                 worker.start()
             signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
             for lo in range(0, len(ids), args.batch_size):
-                classify.classify_read_batch(ids[lo:lo + args.batch_size],
-                                             signals[lo:lo + args.batch_size], sm, si, em, ei,
-                                             osz, args, calls)
+                hi = min(lo + args.batch_size, len(ids))
+                chunk = classify.PackedSignals(signals[lo:hi], samples[offsets[lo]:offsets[hi]],
+                                               offsets[lo:hi + 1] - offsets[lo])
+                classify.classify_read_batch(ids[lo:hi], chunk, sm, si, em, ei, osz, args, calls)
         dt = time.perf_counter() - t0
         out['load + classify (start and end models, scan 6144, batch 256)'] = {
             'loader_threads': threads, 'seconds': round(dt, 3),
