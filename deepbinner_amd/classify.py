@@ -223,6 +223,24 @@ class PackedSignals(list):
         self.packed = (samples, offsets)
 
 
+_HELPER = None
+
+
+def _helper_thread():
+    global _HELPER
+    if _HELPER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-end-model')
+    return _HELPER
+
+
+def _independent_models(start_model, end_model):
+    """Two distinct GPU models can be driven from two threads at once; anything else (one model
+    object used for both sides, a stand-in without the packed entry point) is called in turn."""
+    return (start_model is not end_model and hasattr(start_model, 'classify_packed')
+            and hasattr(end_model, 'classify_packed'))
+
+
 def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
                         end_input_size, output_size, args, classifications):
     """The body of the reference's per-batch loop (classify.py:141-171) for reads already in
@@ -230,12 +248,21 @@ def classify_read_batch(read_ids, signals, start_model, start_input_size, end_mo
     using_read_starts = start_model is not None
     using_read_ends = end_model is not None
     start_calls = start_probs = end_calls = end_probs = None
-    if using_read_starts:
+    if using_read_starts and using_read_ends and _independent_models(start_model, end_model):
+        # the two models' host <-> device round trips side by side: the end model's call runs on
+        # a helper thread (the C ABI releases the GIL and each model has its own streams)
+        pending = _helper_thread().submit(call_batch, end_input_size, output_size, read_ids,
+                                          signals, end_model, args, 'end')
         start_calls, start_probs = call_batch(start_input_size, output_size, read_ids, signals,
                                               start_model, args, 'start')
-    if using_read_ends:
-        end_calls, end_probs = call_batch(end_input_size, output_size, read_ids, signals,
-                                          end_model, args, 'end')
+        end_calls, end_probs = pending.result()
+    else:
+        if using_read_starts:
+            start_calls, start_probs = call_batch(start_input_size, output_size, read_ids,
+                                                  signals, start_model, args, 'start')
+        if using_read_ends:
+            end_calls, end_probs = call_batch(end_input_size, output_size, read_ids, signals,
+                                              end_model, args, 'end')
     lines = []
     for i, read_id in enumerate(read_ids):
         if using_read_starts and using_read_ends:

@@ -467,6 +467,7 @@ int dbh_predict_dev(dbh_model* m, const float* x_dev, int64_t n, float* probs_de
 int dbh_predict(dbh_model* m, const float* x_host, int64_t n, float* probs_host) {
     if (!m || n < 0 || (n > 0 && (!x_host || !probs_host))) return DBH_ERR_INVALID_ARGUMENT;
     if (n == 0) return DBH_OK;
+    DBH_HIP(hipSetDevice(m->device));      // (see dbh_classify_i16)
     // bounded staging: 65,536 windows (256 MiB of fp32 input) per round trip
     const int64_t kChunk = 65536;
     const int64_t cap = n < kChunk ? n : kChunk;
@@ -656,6 +657,9 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
     if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
         (side != DBH_SIDE_START && side != DBH_SIDE_END))
         return DBH_ERR_INVALID_ARGUMENT;
+    // the current device is a per-thread setting: a caller on another thread than the one that
+    // created the model (two models driven from two threads, say) gets the model's device
+    DBH_HIP(hipSetDevice(m->device));
     // Reads travel in groups through two staging slots, each with its own stream: while the GPU
     // works on group g, the host packs and uploads group g+1 and the results of group g-1 come
     // back - H2D, kernels and D2H of neighbouring groups overlap.

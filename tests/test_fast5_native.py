@@ -192,6 +192,23 @@ def test_the_reference_loader_run_on_every_fixture():
             assert load_fast5s.determine_single_or_multi_fast5s(files[:5]) == want['first_five']
 
 
+def test_both_inflaters_give_the_same_samples(monkeypatch):
+    """Chunks are inflated by libdeflate where the system has it, by zlib otherwise or when
+    DEEPBINNER_FAST5_INFLATE=zlib says so: same samples either way, file by file."""
+    paths = single_files() + [os.path.join(VARIANT_DIR, n) for n in sorted(os.listdir(VARIANT_DIR))
+                              if n.endswith('.fast5')]
+    results = {}
+    for mode in ('zlib', 'libdeflate'):
+        monkeypatch.setenv('DEEPBINNER_FAST5_INFLATE', mode)
+        batch = fast5_native.load_batch(single_files() * 3, 6656, 3)
+        per_file = [fast5_native.load_reads(p, threads=2) for p in paths]
+        results[mode] = (batch, per_file)
+    a, b = results['zlib'], results['libdeflate']
+    assert a[0][0] == b[0][0] and np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[0][2], b[0][2])
+    for x, y in zip(a[1], b[1]):
+        assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[3], y[3])
+
+
 def test_unreadable_files(tmp_path):
     assert fast5_native.get_read_id_and_signal(str(tmp_path / 'missing.fast5')) == (None, None)
     empty = tmp_path / 'empty.fast5'
