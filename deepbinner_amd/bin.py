@@ -13,7 +13,8 @@ the closing ``Barcode / Reads / File`` table (:182-205).
 
 What is this package's own: the input is scanned in 16 MB blocks with one compiled pattern per
 record instead of line by line, and every output is written once, already compressed - 1 MB
-blocks deflated on worker threads (zlib releases the GIL) and appended in order as gzip members -
+blocks deflated on worker threads (libdeflate when the system has it, else zlib; both release
+the GIL) and appended in order as gzip members -
 where the reference writes plain files and runs ``gzip``/``pigz`` over them afterwards (:111-113,
 186-198).  The decompressed contents are byte for byte what the reference writes.
 
@@ -25,11 +26,13 @@ counted, left out and listed in the table with no file.
 
 import collections
 import concurrent.futures
+import ctypes
 import gzip
 import os
 import pathlib
 import re
 import sys
+import threading
 import zlib
 
 UUID = re.compile(rb'[0-9a-fA-F]{8}-[0-9a-fA-F]{4}-[0-9a-fA-F]{4}-[0-9a-fA-F]{4}-[0-9a-fA-F]{12}')
@@ -146,6 +149,55 @@ def make_output_dir(out_dir, out_filenames):
     print()
 
 
+class _LibDeflate:
+    """gzip members through libdeflate when the system has it (about twice zlib's speed at the
+    same level; ctypes releases the GIL around the call), one compressor per worker thread.
+    DEEPBINNER_BIN_DEFLATE=zlib keeps it out."""
+
+    def __init__(self):
+        self.lib = None
+        if os.environ.get('DEEPBINNER_BIN_DEFLATE') == 'zlib':
+            return
+        try:
+            lib = ctypes.CDLL('libdeflate.so.0')
+            lib.libdeflate_alloc_compressor.restype = ctypes.c_void_p
+            lib.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
+            lib.libdeflate_gzip_compress.restype = ctypes.c_size_t
+            lib.libdeflate_gzip_compress.argtypes = [ctypes.c_void_p, ctypes.c_char_p,
+                                                     ctypes.c_size_t, ctypes.c_char_p,
+                                                     ctypes.c_size_t]
+            lib.libdeflate_gzip_compress_bound.restype = ctypes.c_size_t
+            lib.libdeflate_gzip_compress_bound.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        except (OSError, AttributeError):
+            return
+        self.lib = lib
+        self.local = threading.local()
+
+    def member(self, data):
+        """One gzip member holding `data`, or None if libdeflate is not to be had."""
+        if self.lib is None:
+            return None
+        compressor = getattr(self.local, 'compressor', None)
+        if compressor is None:
+            compressor = self.local.compressor = self.lib.libdeflate_alloc_compressor(6)
+            if not compressor:
+                return None
+        room = self.lib.libdeflate_gzip_compress_bound(compressor, len(data))
+        out = ctypes.create_string_buffer(room)
+        used = self.lib.libdeflate_gzip_compress(compressor, data, len(data), out, room)
+        return out.raw[:used] if used else None
+
+
+_DEFLATE = None
+
+
+def _deflater():
+    global _DEFLATE
+    if _DEFLATE is None:
+        _DEFLATE = _LibDeflate()
+    return _DEFLATE
+
+
 class GzipSink:
     """One output file.  Text is collected up to MEMBER_BYTES, deflated on a pool thread as a
     gzip member of its own and appended in submission order."""
@@ -159,7 +211,7 @@ class GzipSink:
 
     @staticmethod
     def _member(data):
-        return gzip.compress(data, compresslevel=6, mtime=0)
+        return _deflater().member(data) or gzip.compress(data, compresslevel=6, mtime=0)
 
     def write(self, data):
         self.buffer += data
