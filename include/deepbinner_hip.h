@@ -84,6 +84,11 @@ int dbh_model_destroy(dbh_model* model);
 int dbh_model_input_size(const dbh_model* model, int* input_size);   /* model.inputs[0].shape[1], classify.py:93-96  */
 int dbh_model_output_size(const dbh_model* model, int* n_classes);   /* model.outputs[0].shape[1], classify.py:94-97 */
 
+/* The host-buffer entry points (dbh_predict, dbh_classify_i16) make the model's device the calling
+ * thread's current device (HIP keeps that per thread), so a model may be driven from any thread -
+ * two models from two threads at once, each on its own streams and staging buffers.  One model is
+ * for one caller at a time.  The *_dev entry points work on the caller's device pointers and
+ * leave the current device alone. */
 /* ---- seam b1: model.predict (classify.py:361) ------------------------------------------ */
 /* x: n_windows x 1024 fp32 (already normalised);  probs: n_windows x n_classes fp32 softmax. */
 int dbh_predict(dbh_model* model, const float* x_host, int64_t n_windows, float* probs_host);
