@@ -58,7 +58,7 @@ def classify(args):
 
 
 def load_and_check_models(start_model_filename, end_model_filename, scan_size,
-                          out_dest=sys.stderr):
+                          out_dest=None):
     """-> (start_model, start_input_size, end_model, end_input_size, output_size, model_count)
     (reference classify.py:58-83): either file name may be None; input sizes must fit the scan
     size and two models must agree on the number of classes."""
@@ -78,10 +78,12 @@ def load_and_check_models(start_model_filename, end_model_filename, scan_size,
             class_counts[0] if class_counts else None, len(class_counts))
 
 
-def load_trained_model(model_file, out_dest=sys.stderr):
+def load_trained_model(model_file, out_dest=None):
     """-> (model, input_size, output_size) from one of the reference's Keras-2.1.4 HDF5 model
     files or one of this package's ``.dbw`` weight files (reference classify.py:86-103, same
-    messages)."""
+    messages; ``out_dest`` defaults to the stderr of the moment of the call, where the reference
+    binds the one of import time)."""
+    out_dest = sys.stderr if out_dest is None else out_dest
     if not pathlib.Path(model_file).is_file():
         sys.exit('Error: {} does not exist'.format(model_file))
     print('Loading {}... '.format(model_file), file=out_dest, end='', flush=True)
@@ -481,7 +483,8 @@ def check_input_size(input_size, scan_size):
                  'acceptable values for --scan_size are ' + examples)
 
 
-def print_classification_progress(completed, total, label, out_dest=sys.stderr):
+def print_classification_progress(completed, total, label, out_dest=None):
+    out_dest = sys.stderr if out_dest is None else out_dest
     out_dest.write('\rClassifying %s: %s / %s (%.1f%%)' % (label, completed, total,
                                                           100.0 * completed / total))
     out_dest.flush()

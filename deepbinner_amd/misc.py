@@ -5,7 +5,8 @@ import collections
 import sys
 
 
-def print_summary_table(classifications, output=sys.stderr):
+def print_summary_table(classifications, output=None):
+    output = sys.stderr if output is None else output      # (looked up when called, not imported)
     counts = collections.Counter(classifications.values())
     numeric = sorted(int(b) for b in counts if _is_int(b))
     other = sorted(b for b in counts if not _is_int(b))

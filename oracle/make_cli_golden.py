@@ -1,0 +1,116 @@
+#!/opt/conda/bin/python3.9
+"""
+ORACLE tooling - the reference's own command line, end to end, on the committed fast5 fixtures.
+
+Run with the image's conda interpreter (the one with h5py), in the build container where
+/root/reference is mounted:    /opt/conda/bin/python3.9 oracle/make_cli_golden.py
+Everything is the reference's code as it is - ``deepbinner/deepbinner.py`` (argument parsing,
+presets, checks), ``classify.py`` (the loop, ``call_batch``, merge, calls, ``combine_calls``, the
+printed table), ``load_fast5s.py`` on real h5py, ``misc.py`` - except the one thing this image
+cannot provide: Keras/TensorFlow.  ``keras.models.load_model`` is replaced by a loader that reads
+the same model file (h5py) into this repository's fp64 NumPy restatement of the network
+(oracle/network_ref.py, itself pinned in tests/test_oracle_golden.py); ``model.predict`` is the
+only call that does not run reference code.
+Output: tests/golden/reference_cli.json - for every command line below the reference's stdout and
+the summary it prints on stderr (data only).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+from deepbinner_amd.model_format import ModelWeights      # noqa: E402  (NumPy + own HDF5 reader)
+from oracle import network_ref                            # noqa: E402
+
+SINGLE = os.path.join(REPO, 'tests', 'golden', 'fast5', 'single')
+MODELS = os.path.join(REF, 'models')
+
+
+class _Tensor:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class KerasStandIn:
+    """What classify.py touches of a Keras model: inputs/outputs shapes and predict()."""
+
+    def __init__(self, path):
+        self.weights, shape = ModelWeights.load(path)
+        self.inputs = [_Tensor(tuple(shape))]
+        self.outputs = [_Tensor((None, self.weights.n_classes))]
+
+    def predict(self, x, batch_size=None):
+        x = np.asarray(x)
+        return network_ref.forward(self.weights, x.astype(np.float32),
+                                   dtype=np.float64).astype(np.float32)
+
+
+def install_stand_ins():
+    keras = types.ModuleType('keras')
+    keras.models = types.ModuleType('keras.models')
+    keras.models.load_model = KerasStandIn
+    keras.backend = types.ModuleType('keras.backend')
+    keras.backend.set_session = lambda session: None
+    tensorflow = types.ModuleType('tensorflow')
+    tensorflow.ConfigProto = lambda **kw: None
+    tensorflow.Session = lambda **kw: None
+    for name, module in (('keras', keras), ('keras.models', keras.models),
+                         ('keras.backend', keras.backend), ('tensorflow', tensorflow)):
+        sys.modules[name] = module
+
+
+COMMANDS = {
+    'start_model': ['classify', '-s', 'EXP-NBD103_read_starts', SINGLE],
+    'start_model_verbose': ['classify', '-s', 'EXP-NBD103_read_starts', '--verbose', SINGLE],
+    'end_model_verbose': ['classify', '-e', 'EXP-NBD103_read_ends', '--verbose', SINGLE],
+    'native_preset': ['classify', '--native', SINGLE],
+    'native_preset_verbose': ['classify', '--native', '--verbose', SINGLE],
+    'native_require_start': ['classify', '--native', '--require_start', SINGLE],
+    'native_require_both_verbose': ['classify', '--native', '--require_both', '--verbose', SINGLE],
+    'rapid_preset_verbose': ['classify', '--rapid', '--verbose', SINGLE],
+    'scan_3072_score_0.9': ['classify', '--native', '--scan_size', '3072', '--score_diff', '0.9',
+                            '--verbose', SINGLE],
+    'batch_size_3': ['classify', '--native', '--batch_size', '3', '--verbose', SINGLE],
+    'one_file': ['classify', '-s', 'EXP-NBD103_read_starts', '--verbose',
+                 os.path.join(SINGLE, sorted(os.listdir(SINGLE))[0])],
+}
+
+
+def main():
+    install_stand_ins()
+    sys.path.insert(0, REF)
+    # one stderr buffer for the imports and all runs: the reference binds sys.stderr as a default
+    # argument when its modules are imported (misc.print_summary_table)
+    real_stderr, stderr = sys.stderr, io.StringIO()
+    sys.stderr = stderr
+    import deepbinner.deepbinner as ref_cli
+    out = {}
+    for name, argv in COMMANDS.items():
+        argv = [os.path.join(MODELS, a) if a in os.listdir(MODELS) else a for a in argv]
+        stdout = io.StringIO()
+        stderr.seek(0)
+        stderr.truncate()
+        sys.argv = ['deepbinner'] + argv
+        with contextlib.redirect_stdout(stdout):
+            ref_cli.main()
+        rows = stdout.getvalue().splitlines()
+        assert 'Barcode     Count' in stderr.getvalue(), stderr.getvalue()
+        summary = stderr.getvalue().split('Barcode     Count')[-1].split()
+        out[name] = {'argv': [a.replace(REPO + '/', '').replace(MODELS + '/', 'MODELS/')
+                              for a in argv],
+                     'header': rows[0], 'rows': sorted(rows[1:]), 'summary': summary}
+        print(name, len(rows) - 1, 'rows', summary, file=real_stderr)
+    sys.stderr = real_stderr
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_cli.json'), 'wt') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

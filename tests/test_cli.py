@@ -98,3 +98,45 @@ def test_realtime_multi_read_direct(oracle_backend, tmp_path, capsys, monkeypatc
     realtime.realtime(args)
     rows = open(out_dir / 'multi_read_classifications.tsv').read().splitlines()
     assert len(rows) == 30 and all(len(r.split('\t')) == 3 for r in rows)
+
+
+# ---- the reference's own command line, end to end (oracle/make_cli_golden.py) -------------------
+def reference_cli_cases():
+    import json
+    from conftest import GOLD
+    with open(os.path.join(GOLD, 'reference_cli.json')) as f:
+        return json.load(f)
+
+
+def run_like_the_reference(case, capsys):
+    """Our command line on the argv the reference was run with (models mapped to the .dbw
+    files): (header, sorted rows, the summary table's tokens)."""
+    from conftest import MODEL_DIR, REPO
+    argv = []
+    for a in case['argv']:
+        if a.startswith('MODELS/'):
+            a = os.path.join(MODEL_DIR, a[len('MODELS/'):] + '.dbw')
+        elif a.startswith('tests/'):
+            a = os.path.join(REPO, a)
+        argv.append(a)
+    capsys.readouterr()
+    cli.main(argv)
+    captured = capsys.readouterr()
+    rows = captured.out.splitlines()
+    assert 'Barcode     Count' in captured.err
+    return rows[0], sorted(rows[1:]), captured.err.split('Barcode     Count')[-1].split()
+
+
+@pytest.mark.parametrize('name', sorted(reference_cli_cases()))
+def test_same_table_as_the_reference_command_line(name, oracle_backend, capsys, monkeypatch):
+    """tests/golden/reference_cli.json: stdout and summary of the reference's own deepbinner.py +
+    classify.py + load_fast5s.py (on h5py) for eleven command lines, with only model.predict
+    replaced (by the oracle's network).  Same header, same rows (probabilities to two decimals,
+    per-model calls, final call), same summary - here with the oracle behind seam b1 too."""
+    for reader in ('python', 'native'):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        case = reference_cli_cases()[name]
+        header, rows, summary = run_like_the_reference(case, capsys)
+        assert header == case['header']
+        assert rows == case['rows']
+        assert summary == case['summary']

@@ -626,3 +626,42 @@ def test_soak_against_c_port(hip, hip_models, weights):
                                                                             on_threshold))
     assert worst < PROB_TOL
 
+
+
+# ---- the reference's own command line, end to end, on the real backend --------------------------
+def _reference_cli_cases():
+    import json
+    with open(os.path.join(GOLD, 'reference_cli.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('name', sorted(_reference_cli_cases()))
+def test_command_line_prints_the_reference_table(hip, name, capsys, monkeypatch):
+    """tests/golden/reference_cli.json is what the reference's deepbinner.py / classify.py /
+    load_fast5s.py (h5py) printed with the oracle's network behind model.predict
+    (oracle/make_cli_golden.py).  The same command lines here, HIP kernels behind every seam:
+    same header, same calls, same summary; printed probabilities ('%.2f') equal unless a value
+    sits within 1e-4 of a rounding boundary."""
+    from conftest import MODEL_DIR, REPO
+    from deepbinner_amd import deepbinner as cli
+    case = _reference_cli_cases()[name]
+    argv = [os.path.join(MODEL_DIR, a[7:] + '.dbw') if a.startswith('MODELS/')
+            else os.path.join(REPO, a) if a.startswith('tests/') else a for a in case['argv']]
+    for reader in ('native', 'python'):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        capsys.readouterr()
+        cli.main(argv)
+        captured = capsys.readouterr()
+        rows = captured.out.splitlines()
+        assert rows[0] == case['header']
+        assert captured.err.split('Barcode     Count')[-1].split() == case['summary']
+        got = sorted(rows[1:])
+        assert len(got) == len(case['rows'])
+        for mine, theirs in zip(got, case['rows']):
+            if mine == theirs:
+                continue
+            a, b = mine.split('\t'), theirs.split('\t')
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                if x != y:          # both must be probabilities, one rounding step apart
+                    assert abs(float(x) - float(y)) < 0.0101, (mine, theirs)
