@@ -12,7 +12,8 @@ the same model file (h5py) into this repository's fp64 NumPy restatement of the 
 (oracle/network_ref.py, itself pinned in tests/test_oracle_golden.py); ``model.predict`` is the
 only call that does not run reference code.
 Output: tests/golden/reference_cli.json - for every command line below the reference's stdout and
-the summary it prints on stderr (data only).
+the summary it prints on stderr; for ``realtime`` its stdout and the directory tree it leaves
+(data only).  tests/golden/training_data.txt is written here too (an input fixture).
 """
 import contextlib
 import io
@@ -31,6 +32,7 @@ from oracle import network_ref                            # noqa: E402
 
 SINGLE = os.path.join(REPO, 'tests', 'golden', 'fast5', 'single')
 MODELS = os.path.join(REF, 'models')
+TRAINING_DATA = os.path.join(REPO, 'tests', 'golden', 'training_data.txt')
 
 
 class _Tensor:
@@ -80,11 +82,59 @@ COMMANDS = {
     'batch_size_3': ['classify', '--native', '--batch_size', '3', '--verbose', SINGLE],
     'one_file': ['classify', '-s', 'EXP-NBD103_read_starts', '--verbose',
                  os.path.join(SINGLE, sorted(os.listdir(SINGLE))[0])],
+    'training_data_start_model': ['classify', '-s', 'EXP-NBD103_read_starts', '--verbose',
+                                  '--scan_size', '2048', '--batch_size', '2', TRAINING_DATA],
+    'training_data_end_model': ['classify', '-e', 'EXP-NBD103_read_ends', '--scan_size', '2048',
+                                '--batch_size', '2', TRAINING_DATA],
 }
+
+
+def write_training_data(path):
+    """Five lines of ``label<TAB>v1,v2,...`` (what ``deepbinner prep`` writes and ``classify``
+    also accepts: classify.py:183-239) cut from the fixture reads - committed beside the golden."""
+    from deepbinner_amd import hdf5_lite
+    lines = []
+    for k, name in enumerate(sorted(os.listdir(SINGLE))[:5]):
+        with hdf5_lite.File(os.path.join(SINGLE, name)) as f:
+            group = list(f['Raw/Reads/'].values())[0] if 'Raw' in f.keys() else \
+                f[[key for key in f.keys() if key.startswith('read_')][0] + '/Raw/']
+            signal = group['Signal'][:]
+        lines.append('{}\t{}\n'.format(k + 1, ','.join(str(int(v)) for v in signal[:2600])))
+    with open(path, 'wt') as f:
+        f.writelines(lines)
+
+
+def run_realtime(ref_cli, stderr):
+    """``deepbinner realtime --native --stop`` of the reference on a copy of the single-read
+    fixtures: its stdout and the tree it leaves behind."""
+    import shutil
+    import tempfile
+    import time
+    work = tempfile.mkdtemp()
+    try:
+        in_dir, out_dir = os.path.join(work, 'in'), os.path.join(work, 'out')
+        shutil.copytree(SINGLE, in_dir)
+        stdout = io.StringIO()
+        sys.argv = ['deepbinner', 'realtime', '--in_dir', in_dir, '--out_dir', out_dir, '--stop',
+                    '-s', os.path.join(MODELS, 'EXP-NBD103_read_starts'),
+                    '-e', os.path.join(MODELS, 'EXP-NBD103_read_ends')]
+        sleep, time.sleep = time.sleep, (lambda seconds: None)
+        try:
+            with contextlib.redirect_stdout(stdout):
+                ref_cli.main()
+        finally:
+            time.sleep = sleep
+        tree = {d: sorted(os.listdir(os.path.join(out_dir, d))) for d in sorted(os.listdir(out_dir))}
+        left = sorted(os.listdir(in_dir))
+        text = stdout.getvalue().replace(work, '<WORK>').replace(MODELS + '/', 'MODELS/')
+        return {'stdout': text, 'tree': tree, 'left_in_in_dir': left}
+    finally:
+        shutil.rmtree(work)
 
 
 def main():
     install_stand_ins()
+    write_training_data(TRAINING_DATA)
     sys.path.insert(0, REF)
     # one stderr buffer for the imports and all runs: the reference binds sys.stderr as a default
     # argument when its modules are imported (misc.print_summary_table)
@@ -107,6 +157,8 @@ def main():
                               for a in argv],
                      'header': rows[0], 'rows': sorted(rows[1:]), 'summary': summary}
         print(name, len(rows) - 1, 'rows', summary, file=real_stderr)
+    out['realtime_two_models'] = run_realtime(ref_cli, stderr)
+    print('realtime', out['realtime_two_models']['tree'], file=real_stderr)
     sys.stderr = real_stderr
     with open(os.path.join(REPO, 'tests', 'golden', 'reference_cli.json'), 'wt') as f:
         json.dump(out, f, indent=1, sort_keys=True)

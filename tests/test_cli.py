@@ -127,10 +127,45 @@ def run_like_the_reference(case, capsys):
     return rows[0], sorted(rows[1:]), captured.err.split('Barcode     Count')[-1].split()
 
 
-@pytest.mark.parametrize('name', sorted(reference_cli_cases()))
+def classify_cases():
+    return sorted(k for k, v in reference_cli_cases().items() if 'argv' in v)
+
+
+def run_realtime_like_the_reference(tmp_path, capsys, monkeypatch):
+    """Our `realtime --stop` with both NBD103 models on a copy of the single-read fixtures:
+    (stdout with the paths made relative, the tree under out_dir, what is left in in_dir)."""
+    import shutil
+    from conftest import GOLD, MODEL_DIR
+    import deepbinner_amd.realtime as realtime
+    monkeypatch.setattr(realtime, 'POLL_SECONDS', 0)
+    in_dir, out_dir = tmp_path / 'in', tmp_path / 'out'
+    shutil.copytree(os.path.join(GOLD, 'fast5', 'single'), in_dir)
+    capsys.readouterr()
+    cli.main(['realtime', '--in_dir', str(in_dir), '--out_dir', str(out_dir), '--stop',
+              '-s', os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+              '-e', os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw')])
+    text = capsys.readouterr().out.replace(str(tmp_path), '<WORK>') \
+        .replace(MODEL_DIR + '/', 'MODELS/').replace('.dbw', '')
+    tree = {d: sorted(os.listdir(out_dir / d)) for d in sorted(os.listdir(out_dir))}
+    return text, tree, sorted(os.listdir(in_dir))
+
+
+def test_realtime_as_the_reference_runs_it(oracle_backend, tmp_path, capsys, monkeypatch):
+    """The reference's realtime.py run end to end by oracle/make_cli_golden.py (same stand-in for
+    Keras as above): same stdout - progress lines included - and the same files in the same bins."""
+    want = reference_cli_cases()['realtime_two_models']
+    for k, reader in enumerate(('python', 'native')):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        text, tree, left = run_realtime_like_the_reference(tmp_path / str(k), capsys, monkeypatch)
+        assert text == want['stdout']
+        assert tree == want['tree'] and left == want['left_in_in_dir']
+
+
+@pytest.mark.parametrize('name', classify_cases())
 def test_same_table_as_the_reference_command_line(name, oracle_backend, capsys, monkeypatch):
     """tests/golden/reference_cli.json: stdout and summary of the reference's own deepbinner.py +
-    classify.py + load_fast5s.py (on h5py) for eleven command lines, with only model.predict
+    classify.py + load_fast5s.py (on h5py) for thirteen command lines (two of them on a
+    training-data text file), with only model.predict
     replaced (by the oracle's network).  Same header, same rows (probabilities to two decimals,
     per-model calls, final call), same summary - here with the oracle behind seam b1 too."""
     for reader in ('python', 'native'):

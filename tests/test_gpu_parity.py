@@ -635,7 +635,34 @@ def _reference_cli_cases():
         return json.load(f)
 
 
-@pytest.mark.parametrize('name', sorted(_reference_cli_cases()))
+def test_realtime_as_the_reference_runs_it_on_the_gpu(hip, tmp_path, capsys, monkeypatch):
+    """The reference's realtime.py end to end (oracle/make_cli_golden.py): same stdout, same files
+    in the same bins, with the HIP kernels doing the classification."""
+    import shutil
+    from conftest import MODEL_DIR
+    from deepbinner_amd import deepbinner as cli
+    import deepbinner_amd.realtime as realtime
+    want = _reference_cli_cases()['realtime_two_models']
+    monkeypatch.setattr(realtime, 'POLL_SECONDS', 0)
+    for k, reader in enumerate(('native', 'python')):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        work = tmp_path / str(k)
+        in_dir, out_dir = work / 'in', work / 'out'
+        shutil.copytree(os.path.join(GOLD, 'fast5', 'single'), in_dir)
+        capsys.readouterr()
+        cli.main(['realtime', '--in_dir', str(in_dir), '--out_dir', str(out_dir), '--stop',
+                  '-s', os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+                  '-e', os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw')])
+        text = capsys.readouterr().out.replace(str(work), '<WORK>') \
+            .replace(MODEL_DIR + '/', 'MODELS/').replace('.dbw', '')
+        assert text == want['stdout']
+        assert {d: sorted(os.listdir(out_dir / d)) for d in sorted(os.listdir(out_dir))} == \
+            want['tree']
+        assert sorted(os.listdir(in_dir)) == want['left_in_in_dir']
+
+
+@pytest.mark.parametrize('name', sorted(k for k, v in _reference_cli_cases().items()
+                                        if 'argv' in v))
 def test_command_line_prints_the_reference_table(hip, name, capsys, monkeypatch):
     """tests/golden/reference_cli.json is what the reference's deepbinner.py / classify.py /
     load_fast5s.py (h5py) printed with the oracle's network behind model.predict
