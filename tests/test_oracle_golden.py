@@ -121,3 +121,24 @@ def test_c_restatement_matches_numpy_oracle(gold, all_signals, weights):
     assert ['none' if c == 0 else str(c) for c in calls] == want_calls
     ref = np.load(os.path.join(GOLD, 'merged_EXP-NBD103_read_starts_start.npy'))
     assert np.abs(probs - ref).max() < 1e-5
+
+
+def test_the_reference_test_suite_passed_on_the_oracle():
+    """tests/golden/reference_tests_report.json: the reference's OWN tests (its tests/ directory,
+    unittest, run from its root) against the oracle's network behind a stand-in for Keras, with
+    its classify.py / load_fast5s.py (h5py) untouched - produced by oracle/run_reference_tests.py in
+    the build container.  Everything on the classify path passed; the one module that builds a
+    real Keras graph could not be imported."""
+    import json
+    with open(os.path.join(GOLD, 'reference_tests_report.json')) as f:
+        report = json.load(f)
+    by_module = {}
+    for test, outcome in report['outcomes'].items():
+        by_module.setdefault(test.split('.')[1] if test.startswith('tests.') else test,
+                             []).append(outcome)
+    assert by_module['test_classify'] == ['ok'] * 14
+    assert by_module['test_combine_calls'] == ['ok'] * 3
+    assert by_module['test_load_fast5s'] == ['ok'] * 8
+    others = {m: o for m, o in by_module.items()
+              if m not in ('test_classify', 'test_combine_calls', 'test_load_fast5s')}
+    assert all('test_network_architecture' in m for m in others), others
