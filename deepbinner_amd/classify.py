@@ -243,12 +243,49 @@ def _independent_models(start_model, end_model):
             and hasattr(end_model, 'classify_packed'))
 
 
+_CALL_NAMES = ['none'] + [str(i) for i in range(1, 256)]
+
+
+def _array_path(signals, start_model, end_model):
+    """A packed batch and GPU models only: the calls can stay arrays until the table is printed."""
+    models = [m for m in (start_model, end_model) if m is not None]
+    return (getattr(signals, 'packed', None) is not None and bool(models)
+            and all(hasattr(m, 'classify_packed') for m in models)
+            and (len(models) == 1 or models[0] is not models[1]))
+
+
+def _classify_packed_batch(read_ids, signals, start_model, end_model, args, classifications):
+    """classify_read_batch without the per-read Python of call_batch / combine_calls: the two
+    models' call numbers are combined as arrays (combine_call_numbers) and turned into the same
+    strings and table rows at the end.  Non-verbose output only (no probabilities to print)."""
+    samples, offsets = signals.packed
+    scan_size = int(args.scan_size)
+
+    def numbers(model, side):
+        return model.classify_packed(samples, offsets, side, scan_size, args.score_diff)[1]
+
+    if start_model is not None and end_model is not None:
+        pending = _helper_thread().submit(numbers, end_model, 'end')
+        start_numbers = numbers(start_model, 'start')
+        final = combine_call_numbers(start_numbers, pending.result(), args)
+    elif start_model is not None:
+        final = numbers(start_model, 'start')
+    else:
+        final = numbers(end_model, 'end')
+    names = [_CALL_NAMES[c] for c in final.tolist()]
+    classifications.update(zip(read_ids, names))
+    return [read_id + '\t' + name for read_id, name in zip(read_ids, names)]
+
+
 def classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
                         end_input_size, output_size, args, classifications):
     """The body of the reference's per-batch loop (classify.py:141-171) for reads already in
     memory: run the model(s), combine, record calls, and return the TSV lines."""
     using_read_starts = start_model is not None
     using_read_ends = end_model is not None
+    if not args.verbose and _array_path(signals, start_model, end_model):
+        return _classify_packed_batch(read_ids, signals, start_model, end_model, args,
+                                      classifications)
     start_calls = start_probs = end_calls = end_probs = None
     if using_read_starts and using_read_ends and _independent_models(start_model, end_model):
         # the two models' host <-> device round trips side by side: the end model's call runs on
