@@ -101,6 +101,8 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
             id_to_file[read_id] = fast5_file
             read_ids.append(read_id)
             signals.append(signal)
+        if getattr(loaded, 'complete', False):      # the loader's packed buffer is these reads
+            signals = c.PackedSignals(signals, loaded.samples, loaded.offsets)
         lines += c.classify_read_batch(read_ids, signals, start_model, start_input_size,
                                        end_model, end_input_size, output_size, args,
                                        classifications)
