@@ -200,12 +200,29 @@ def _native_batches(fast5_files, args):
             pending = executor.submit(load, batches[i + 1]) if i + 1 < len(batches) else None
             if (status == fast5_native.F5_ERR_MULTI).any():
                 sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
+            warn_about_filters(status)
             loaded = PackedBatch((f, read_ids[k], samples[offsets[k]:offsets[k + 1]]
                                   if read_ids[k] is not None else None)
                                  for k, f in enumerate(batch))
             loaded.samples, loaded.offsets = samples, offsets
             loaded.complete = all(r is not None for r in read_ids)
             yield loaded
+
+
+_FILTER_WARNING_GIVEN = False
+
+
+def warn_about_filters(status):
+    """The reference (h5py without the plugin) skips VBZ-compressed files without a word, and so
+    does this package - but it says so once, on stderr, since a whole run of them classifies
+    nothing."""
+    global _FILTER_WARNING_GIVEN
+    from . import fast5_native
+    skipped = int((status == fast5_native.F5_ERR_FILTER).sum())
+    if skipped and not _FILTER_WARNING_GIVEN:
+        _FILTER_WARNING_GIVEN = True
+        print('\nWarning: skipping reads whose signal is compressed with a filter this build '
+              'cannot decode (VBZ?); convert them with compress_fast5 -c gzip', file=sys.stderr)
 
 
 class PackedBatch(list):

@@ -40,6 +40,12 @@ struct FormatError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// a compression filter this reader does not implement (ONT's VBZ, id 32020, is the one in the
+// field): reported apart from damage, so that the caller can say what is the matter
+struct UnsupportedFilter : FormatError {
+    using FormatError::FormatError;
+};
+
 struct Msg {
     uint32_t type;
     uint64_t off;
@@ -810,6 +816,8 @@ class Fast5 {
                 for (uint64_t k = 0; k < ncd; ++k) f.cd.push_back((uint32_t)u(p + 4 * k, 4));
                 p += 4 * ncd;
                 if (fversion == 1 && (ncd % 2) == 1) p += 4;
+                if (f.id != 1 && f.id != 2 && f.id != 3 && s.layout == 2)
+                    throw UnsupportedFilter("Signal uses a filter other than deflate/shuffle/fletcher32");
                 s.filters.push_back(f);
             }
         }
@@ -1125,6 +1133,8 @@ int guarded(Fn&& fn) {
     try {
         fn();
         return F5_OK;
+    } catch (const UnsupportedFilter&) {
+        return F5_ERR_FILTER;
     } catch (const FormatError&) {
         return F5_ERR_FORMAT;
     } catch (const std::out_of_range&) {
@@ -1289,6 +1299,7 @@ const char* f5_status_string(int status) {
         case F5_ERR_NO_READ: return "no such read (or read without read_id / Signal)";
         case F5_ERR_MULTI: return "multi-read fast5 file";
         case F5_ERR_ARGUMENT: return "invalid argument";
+        case F5_ERR_FILTER: return "Signal compressed with an unsupported filter (VBZ?)";
         default: return "unknown status";
     }
 }

@@ -17,7 +17,8 @@ import numpy as np
 _LIB_NAME = 'libdeepbinner_fast5.so'
 _lib = None
 
-F5_OK, F5_ERR_OPEN, F5_ERR_FORMAT, F5_ERR_NO_READ, F5_ERR_MULTI, F5_ERR_ARGUMENT = range(6)
+(F5_OK, F5_ERR_OPEN, F5_ERR_FORMAT, F5_ERR_NO_READ, F5_ERR_MULTI, F5_ERR_ARGUMENT,
+ F5_ERR_FILTER) = range(7)
 F5_READ_ID_MAX = 64
 LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 

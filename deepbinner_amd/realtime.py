@@ -161,11 +161,12 @@ class Session:
             return iter_reads(path)
         from . import fast5_native
         try:
-            ids, samples, offsets, _ = fast5_native.load_reads(
+            ids, samples, offsets, status = fast5_native.load_reads(
                 path, keep=int(self.args.scan_size) + 512,
                 threads=int(getattr(self.args, 'loader_procs', 0) or 0))
         except OSError:
             return []
+        classify.warn_about_filters(status)
         reads = classify.PackedBatch((rid, samples[offsets[i]:offsets[i + 1]])
                                      for i, rid in enumerate(ids) if rid is not None)
         if len(reads) == len(ids):          # nothing dropped: the packed buffer is these reads

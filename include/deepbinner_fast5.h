@@ -34,6 +34,8 @@ extern "C" {
 #define F5_ERR_NO_READ 3   /* no read in the file / index out of range / no read_id or Signal */
 #define F5_ERR_MULTI 4     /* several reads where the caller asked for a one-read file */
 #define F5_ERR_ARGUMENT 5
+#define F5_ERR_FILTER 6    /* Signal compressed with a filter other than deflate / shuffle /
+                              fletcher32 (e.g. ONT's VBZ, HDF5 filter 32020) */
 
 #define F5_READ_ID_MAX 64  /* bytes per read id slot, NUL terminated (a read id is a 36-char UUID) */
 

@@ -209,6 +209,31 @@ def test_both_inflaters_give_the_same_samples(monkeypatch):
         assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[3], y[3])
 
 
+def test_a_filter_that_is_not_implemented_is_reported_as_such(tmp_path, capsys):
+    """A deflate-compressed file whose filter id is patched to 32020 (ONT's VBZ) stands in for a
+    VBZ file: both readers refuse it, the native one with a status of its own, and the classify
+    loop says once why reads are being skipped."""
+    import struct
+    from deepbinner_amd import classify
+    source = open(os.path.join(VARIANT_DIR, 'single_old_layout_old.fast5'), 'rb').read()
+    # v1 filter pipeline entry: id 1, name of 8 bytes, flags optional, one client value
+    entry = struct.pack('<HHHH', 1, 8, 1, 1) + b'deflate\x00'
+    assert source.count(entry) == 1
+    path = str(tmp_path / 'vbz_like.fast5')
+    with open(path, 'wb') as f:
+        f.write(source.replace(entry, struct.pack('<HHHH', 32020, 8, 1, 1) + b'vbz\x00\x00\x00\x00\x00'))
+    assert fast5_native.get_read_id_and_signal(path) == (None, None)
+    assert load_fast5s._python_get_read_id_and_signal(path) == (None, None)
+    ids, samples, offsets, status = fast5_native.load_batch([path, single_files()[0]], 6656, 2)
+    assert list(status) == [fast5_native.F5_ERR_FILTER, 0] and ids[0] is None and ids[1]
+    assert offsets[1] == 0 and offsets[2] == len(samples)
+    assert fast5_native.load_reads(path)[3][0] == fast5_native.F5_ERR_FILTER
+    classify._FILTER_WARNING_GIVEN = False
+    classify.warn_about_filters(status)
+    classify.warn_about_filters(status)
+    assert capsys.readouterr().err.count('cannot decode (VBZ?)') == 1
+
+
 def test_unreadable_files(tmp_path):
     assert fast5_native.get_read_id_and_signal(str(tmp_path / 'missing.fast5')) == (None, None)
     empty = tmp_path / 'empty.fast5'
