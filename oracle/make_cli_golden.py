@@ -132,6 +132,48 @@ def run_realtime(ref_cli, stderr):
         shutil.rmtree(work)
 
 
+def run_sample_reads(ref_cli):
+    """BASELINE.json configs[0], the walk-through of the reference's README (:128): the six fast5
+    files of sample_reads.tar.gz (the six 5210_* fixtures are those files) through ``classify
+    --native`` into a table, then ``bin`` on the archive's basecalled.fastq.gz (committed under
+    tests/golden/sample_reads/) with that table."""
+    import gzip
+    import hashlib
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp()
+    try:
+        fast5_dir = os.path.join(work, 'sample_reads')
+        os.makedirs(fast5_dir)
+        for name in sorted(os.listdir(SINGLE)):
+            if name.startswith('5210_'):
+                os.symlink(os.path.join(SINGLE, name), os.path.join(fast5_dir, name))
+        table, stdout = os.path.join(work, 'classifications'), io.StringIO()
+        sys.argv = ['deepbinner', 'classify', '--native', fast5_dir]
+        with contextlib.redirect_stdout(stdout):
+            ref_cli.main()
+        with open(table, 'wt') as f:
+            f.write(stdout.getvalue())
+        reads = os.path.join(REPO, 'tests', 'golden', 'sample_reads', 'basecalled.fastq.gz')
+        out_dir, bin_stdout = os.path.join(work, 'binned'), io.StringIO()
+        sys.argv = ['deepbinner', 'bin', '--classes', table, '--reads', reads, '--out_dir', out_dir]
+        with contextlib.redirect_stdout(bin_stdout):
+            ref_cli.main()
+        files = {}
+        for name in sorted(os.listdir(out_dir)):
+            with gzip.open(os.path.join(out_dir, name), 'rb') as f:
+                data = f.read()
+            files[name] = {'bytes': len(data), 'records': data.count(b'\n+\n'),
+                           'sha256': hashlib.sha256(data).hexdigest()}
+        rows = stdout.getvalue().splitlines()
+        import re
+        text = re.sub(r'Writing reads: [\d,]+ \r', '', bin_stdout.getvalue()).replace(work, '<WORK>')
+        return {'classify_header': rows[0], 'classify_rows': sorted(rows[1:]),
+                'bin_stdout': text, 'bin_files': files}
+    finally:
+        shutil.rmtree(work)
+
+
 def main():
     install_stand_ins()
     write_training_data(TRAINING_DATA)
@@ -157,6 +199,8 @@ def main():
                               for a in argv],
                      'header': rows[0], 'rows': sorted(rows[1:]), 'summary': summary}
         print(name, len(rows) - 1, 'rows', summary, file=real_stderr)
+    out['sample_reads_walkthrough'] = run_sample_reads(ref_cli)
+    print('sample reads', out['sample_reads_walkthrough']['bin_files'], file=real_stderr)
     out['realtime_two_models'] = run_realtime(ref_cli, stderr)
     print('realtime', out['realtime_two_models']['tree'], file=real_stderr)
     sys.stderr = real_stderr

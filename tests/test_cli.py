@@ -175,3 +175,15 @@ def test_same_table_as_the_reference_command_line(name, oracle_backend, capsys, 
         assert header == case['header']
         assert rows == case['rows']
         assert summary == case['summary']
+
+
+def test_the_readme_walkthrough(oracle_backend, tmp_path, capsys, monkeypatch):
+    """BASELINE.json configs[0]: sample_reads.tar.gz through classify and bin, as the reference's
+    own code did it (oracle/make_cli_golden.py): same table, same binned FASTQ files, same words."""
+    from conftest import check_the_readme_walkthrough, run_the_readme_walkthrough
+    want = reference_cli_cases()['sample_reads_walkthrough']
+    for k, reader in enumerate(('python', 'native')):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        work = tmp_path / str(k)
+        work.mkdir()
+        check_the_readme_walkthrough(run_the_readme_walkthrough(work, capsys), want)

@@ -692,3 +692,15 @@ def test_command_line_prints_the_reference_table(hip, name, capsys, monkeypatch)
             for x, y in zip(a, b):
                 if x != y:          # both must be probabilities, one rounding step apart
                     assert abs(float(x) - float(y)) < 0.0101, (mine, theirs)
+
+
+def test_the_readme_walkthrough_on_the_gpu(hip, tmp_path, capsys, monkeypatch):
+    """BASELINE.json configs[0] on the real backend: sample_reads.tar.gz through classify
+    --native and bin gives the table and the binned files the reference's own code gave."""
+    from conftest import check_the_readme_walkthrough, run_the_readme_walkthrough
+    want = _reference_cli_cases()['sample_reads_walkthrough']
+    for k, reader in enumerate(('native', 'python')):
+        monkeypatch.setenv('DEEPBINNER_FAST5_READER', reader)
+        work = tmp_path / str(k)
+        work.mkdir()
+        check_the_readme_walkthrough(run_the_readme_walkthrough(work, capsys), want)
