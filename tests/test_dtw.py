@@ -232,3 +232,67 @@ def test_gpu_bad_arguments():
     with pytest.raises(ValueError):
         dtw.semi_global_dtw_batch([np.zeros(5)], [])
     assert dtw.semi_global_dtw_batch([], []) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get('DEEPBINNER_SOAK') != '1',
+                    reason='opt-in: DEEPBINNER_SOAK=1 (about two minutes of CPU for the reference)')
+def test_gpu_rate_and_soak_beside_the_reference(capsys):
+    """6,000 random pairs of four signal kinds in one batched call, every distance, position and
+    path compared with the reference's own code (oracle/_ref/dtw.so when it travelled with the
+    repository, else the restatement); then the kernel rate at four query lengths with the CPU
+    code timed beside it on one core.  Prints JSON lines (kept in profiles/r01_dtw/)."""
+    import json
+    import time
+    kind = 'reference' if dtw_ref.available('reference') else 'restatement'
+    rng = np.random.default_rng(7)
+    refs, queries = [], []
+    for k in range(6000):
+        r = int(rng.integers(1, 4000)) if k % 11 else int(rng.integers(1, 70))
+        q = int(rng.integers(1, 1500)) if k % 13 else int(rng.integers(1000, 3500))
+        style = k % 4
+        if style == 0:
+            refs.append(rng.normal(size=r))
+            queries.append(rng.normal(size=q))
+        elif style == 1:      # squiggle-like: levels held for a few samples, small noise
+            refs.append(np.repeat(rng.normal(size=r // 6 + 1), 6)[:r] + rng.normal(0, .05, r))
+            queries.append(np.repeat(rng.normal(size=q // 6 + 1), 6)[:q] + rng.normal(0, .05, q))
+        elif style == 2:      # the query is a noisy, rescaled piece of the reference
+            ref = rng.normal(size=max(r, 2))
+            a = int(rng.integers(0, len(ref) - 1))
+            piece = ref[a:int(rng.integers(a + 1, len(ref) + 1))][:q]
+            refs.append(ref)
+            queries.append(1.1 * piece + 0.1 + rng.normal(0, .1, len(piece)))
+        else:                 # large offsets and scales
+            refs.append(rng.normal(400, 90, size=r))
+            queries.append(rng.normal(450, 60, size=q))
+    t0 = time.perf_counter()
+    got = dtw.semi_global_dtw_batch(refs, queries)
+    gpu_seconds = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cells = 0
+    for k, (ref, query) in enumerate(zip(refs, queries)):
+        want = dtw_ref.semi_global_dtw(ref, query, kind)
+        cells += len(ref) * len(query)
+        assert got[k][0] == want[0] and got[k][1:3] == want[1:3], (k, len(ref), len(query))
+        assert np.array_equal(got[k][3], np.array(want[3], dtype=np.int32).reshape(-1, 2)), k
+    lines = [{'soak_pairs': 6000, 'cells': cells, 'checked_against': kind, 'identical': True,
+              'gpu_call_seconds': round(gpu_seconds, 3),
+              'cpu_seconds': round(time.perf_counter() - t0, 1)}]
+    for q in (200, 500, 1000, 2000):
+        refs = [rng.normal(size=4000) for _ in range(4096)]
+        queries = [rng.normal(size=q) for _ in range(4096)]
+        dtw.semi_global_dtw_batch(refs[:64], queries[:64])
+        results = dtw.semi_global_dtw_batch(refs, queries)
+        ms, n_cells = dtw.last_kernel_time()
+        t0 = time.perf_counter()
+        for k in range(12):
+            want = dtw_ref.semi_global_dtw(refs[k], queries[k], kind)
+            assert results[k][0] == want[0] and results[k][1:3] == want[1:3]
+        cpu = 12 * 4000 * q / (time.perf_counter() - t0) / 1e9
+        lines.append({'query_len': q, 'pairs': 4096, 'kernel_ms': ms,
+                      'kernel_GCUPS': n_cells / (ms * 1e-3) / 1e9,
+                      'cpu': {'kind': kind, 'cores': 1, 'GCUPS': cpu}})
+    with capsys.disabled():
+        for line in lines:
+            print(json.dumps(line))
