@@ -82,6 +82,9 @@ __global__ __launch_bounds__(kLanes) void dtw_kernel(
     double* __restrict__ edges, double* __restrict__ distances, int32_t* __restrict__ positions,
     int32_t* __restrict__ path_lengths, int32_t* __restrict__ alignment) {
     constexpr int kPanel = kLanes * C;
+    // only the widest variant ever sees a query of more than one panel (cells_per_lane): the
+    // narrower ones drop the edge-column hand-over from their step altogether
+    constexpr bool kMultiPanel = (C == 16);
     const PairJob job = jobs[blockIdx.x];
     const int lane = threadIdx.x;
     const int R = job.ref_len, Q = job.query_len;
@@ -125,25 +128,28 @@ __global__ __launch_bounds__(kLanes) void dtw_kernel(
             return (at < R) ? base[at] : 0.0;
         };
         double ref_block = block_at(ref, 0), ref_ahead = 0.0;
-        double edge_block = (p > 0) ? block_at(edge_in, 0) : 0.0, edge_ahead = 0.0;
+        double edge_block = 0.0, edge_ahead = 0.0;
+        if constexpr (kMultiPanel) edge_block = (p > 0) ? block_at(edge_in, 0) : 0.0;
         double r = 0.0;
         for (int s = 0; s < R + kLanes - 1; ++s) {
             const int i = s - lane;
             const int k = s % kLanes;
             if (k == 0) {
                 ref_ahead = block_at(ref, s + kLanes);
-                if (p > 0) edge_ahead = block_at(edge_in, s + kLanes);
+                if constexpr (kMultiPanel)
+                    if (p > 0) edge_ahead = block_at(edge_in, s + kLanes);
             }
             double left_in = from_left_lane(newest_last);
             r = from_left_lane(r);
-            const double ref_s = lane_value(ref_block, k), edge_s = lane_value(edge_block, k);
-            if (lane == 0) {
-                r = ref_s;
-                if (p > 0) left_in = edge_s;
+            const double ref_s = lane_value(ref_block, k);
+            if (lane == 0) r = ref_s;
+            if constexpr (kMultiPanel) {
+                const double edge_s = lane_value(edge_block, k);
+                if (lane == 0 && p > 0) left_in = edge_s;
             }
             if (k == kLanes - 1) {
                 ref_block = ref_ahead;
-                edge_block = edge_ahead;
+                if constexpr (kMultiPanel) edge_block = edge_ahead;
             }
             if (i < 0 || i >= R) continue;
             double left = left_in, diag = diag_in;
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(kLanes) void dtw_kernel(
             words[((size_t)p * kSteps + s) * kLanes + lane] = word;
             newest_last = cost[C - 1];
             diag_in = left_in;
-            if (lane == kLanes - 1 && p + 1 < panels) edge_out[i] = newest_last;
+            if constexpr (kMultiPanel)
+                if (lane == kLanes - 1 && p + 1 < panels) edge_out[i] = newest_last;
             if (tracks_end && i >= 1) {    // dtw.cpp:113-122: first smallest over rows 1..R-1
                 const double v = cost[last_c];   // uniform index: s_set_gpr_idx + v_mov
                 if (v < best) {
