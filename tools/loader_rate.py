@@ -4,7 +4,7 @@
 geometry (scan_size 6144, batch 256) - how fast the host loader feeds the GPU.
   1. loader alone: serial (the reference's loop) and LoaderPool at several process counts;
   2. classify_fast5_files on the HIP backend with the same loader settings.
-Usage: python tools/loader_rate.py [n_files]"""
+Usage: python tools/loader_rate.py [n_files [batch_size]]"""
 import argparse
 import contextlib
 import io
@@ -24,6 +24,7 @@ MODELS = os.path.join(REPO, 'deepbinner_amd', 'models')
 
 def main():
     n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    batch_size = int(sys.argv[2]) if len(sys.argv) > 2 else 256      # --batch_size of the classify runs
     sources = sorted(load_fast5s.find_all_fast5s(FAST5_DIR))
     out = {'files': n_files, 'host_threads': os.cpu_count()}
     with tempfile.TemporaryDirectory() as tmp:
@@ -94,7 +95,7 @@ def main():
                                                  and not fast5_native.available()):
                 continue
             os.environ['DEEPBINNER_FAST5_READER'] = reader
-            args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144,
+            args = argparse.Namespace(verbose=False, batch_size=batch_size, scan_size=6144,
                                       score_diff=0.5, require_either=True, require_start=False,
                                       require_both=False, loader_procs=procs)
             subset = files if (procs > 1 or reader == 'native') else files[:1024]
