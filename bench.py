@@ -19,7 +19,6 @@ Prints ONE JSON line (rank 0).  Extra objects:
 """
 
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -130,7 +129,6 @@ def main():
 
     weights, _ = ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models', MODEL + '.dbw'))
     model = hip_backend.HipModel(weights)
-    lib = hip_backend.load_library()
 
     # ---- inputs resident in HBM (rank-specific seed: every GPU has its own 10,000 reads) ------
     reads = synthetic_reads(N_READS, 20260927 + rank)

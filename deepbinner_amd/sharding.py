@@ -68,7 +68,6 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
     single-process path prints (reference classify.py:106-180).  Returns the same
     ``(classifications, read_id_to_fast5_file)`` on rank 0 and ``({}, {})`` elsewhere."""
     import sys
-    import numpy as np
     import torch
     from . import classify as c
     from .load_fast5s import determine_single_or_multi_fast5s

@@ -1,7 +1,6 @@
 """Argument handling of the classify / realtime commands (reference deepbinner.py:283-345)."""
 import argparse
 import os
-import sys
 
 import pytest
 

@@ -4,8 +4,6 @@ import socket
 import subprocess
 import sys
 
-import numpy as np
-
 from conftest import REPO
 from deepbinner_amd.sharding import shard_bounds
 
