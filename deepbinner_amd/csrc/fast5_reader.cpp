@@ -4,7 +4,8 @@
 // slice of the HDF5 file format those files use, restated in C++ from the format specification
 // exactly as deepbinner_amd/hdf5_lite.py restates it in Python (that module stays the readable
 // description and the parity reference for this one: tests/test_fast5_native.py).
-// Host-only: g++ -O2 -shared -fPIC fast5_reader.cpp -lz -pthread.
+// Host-only: g++ -O2 -shared -fPIC fast5_reader.cpp -lz -ldl -pthread (libdeflate, if the system has
+// it, is looked up at run time).
 #include "../../include/deepbinner_fast5.h"
 
 #include <dlfcn.h>
