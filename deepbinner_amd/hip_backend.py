@@ -23,6 +23,11 @@ from numpy.ctypeslib import ndpointer
 
 from .model_format import ModelWeights
 
+# Kernel arguments in device memory: 54.4 us per forward launch against 56.5 us with the
+# arguments fetched from host memory (HIP_FORCE_DEV_KERNARG=0), same box.  It is this image's
+# default; say so before the HIP runtime starts, unless the user said otherwise.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 _LIB_NAME = 'libdeepbinner_hip.so'
 _lib = None
 
