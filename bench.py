@@ -2,23 +2,42 @@
 """
 bench.py — reads classified/sec on the Deepbinner classify hot path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): EXP-NBD103_read_starts, 10,000 synthetic 1024-sample int16
-signals, batch 256, per GPU.  One STEP = one pass of the whole hot path over those 10,000 reads in
-batches of 256 through seam b2 (`dbh_classify_i16_batched_dev`: window slice + fp64 z-normalise + the
-20-conv CNN + merge + renormalise + barcode call), with `--scan_size 512` so each 1024-sample read
-is exactly one full window (classify.py:401-402 accepts it) — i.e. 1 read = 1 window = one
-classification.  Inputs are resident in HBM before the timed region; per-read calls are gathered
-over RCCL when N > 1 (weak scaling: every rank classifies its own 10,000 reads per step).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}]
+
+--config 1 (default; the configuration the metric is quoted on): BASELINE.json configs[1],
+    EXP-NBD103_read_starts, 10,000 synthetic 1024-sample int16 signals per GPU, batch 256.
+--config 2: configs[2], EXP-NBD103 start + end models over 100,000 signals per GPU, batch 512,
+    combine_calls (require_either) on the device.
+--config 3: configs[3], SQK-RBK004_read_starts, 1,000,000 signals sharded over the N GPUs
+    (strong scaling: the total is fixed), batch 256, all-gather of the calls.
+
+One STEP = one pass of the whole hot path over the configuration's reads through seam b2
+(`dbh_classify_i16_batched_dev`: window slice + fp64 z-normalise + the 20-conv CNN + renormalise +
+barcode call), with `--scan_size 512` so that each 1024-sample read is exactly one window
+(classify.py:401-402 accepts it): 1 read = 1 window = one classification.  Inputs are resident in
+HBM before the timed region; inside it every step ends with the all-gather of the per-read calls
+(RCCL between GPUs when N > 1) and a copy of the gathered calls to pinned host memory.
+
+N > 1 runs either way, with no torch anywhere:
+  * `python bench.py --gpus N`: ONE process drives the N devices (a thread per device,
+    ncclCommInitAll behind the C ABI);
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (how the driver
+    launches it): one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the environment, RCCL's
+    unique id and the barrier / MAX-over-ranks of the timing over deepbinner_amd.sharding's own
+    socket rendezvous.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the forward kernel (dominant, compute-bound: 33,629,952 FLOP per window on the
-                fp32 matrix pipe) — average launch duration measured live with HIP events on the
-                launch stream inside the timed region;
+  roofline      the forward kernel (dominant, compute-bound: 33,629,952 algorithmic FLOP per
+                window on the fp32 matrix pipe), average launch duration measured live with HIP
+                events on the launch stream inside the timed region; `frac` counts the direct
+                convolution's FLOP, `frac_executed` the MFMAs the kernel really issues (the
+                Winograd layers issue fewer) = what the matrix pipe is busy with;
   cpu_baseline  the oracle's C restatement (oracle/dbref.c, OpenMP) on a bounded sample of the same
-                reads on this box's host cores.
+                reads on this box's host cores (N = 1 only).
 """
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -31,18 +50,26 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from deepbinner_amd import hip_backend                       # noqa: E402
+from deepbinner_amd import sharding                          # noqa: E402
 from deepbinner_amd.model_format import ModelWeights         # noqa: E402
-from deepbinner_amd.sharding import env_world                # noqa: E402
 
 FLOP_PER_WINDOW = 33629952          # 16,814,976 MAC in the 20 convolutions
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
-MODEL = 'EXP-NBD103_read_starts'
-N_READS = 10000
-BATCH = 256
+PEAK_HBM_BYTES_PER_S = 8.0e12
 SCAN_SIZE = 512
 SCORE_DIFF = 0.5
 TIMING_STRIDE = 20          # an event bracket opens at every 20th forward launch ...
-TIMING_SPAN = 4             # ... and covers 4 consecutive (full, 256-window) launches
+TIMING_SPAN = 4             # ... and covers 4 consecutive (full) launches
+
+CONFIGS = {
+    1: {'name': 'BASELINE.json configs[1]', 'models': ['EXP-NBD103_read_starts'],
+        'sides': ['start'], 'reads': 10000, 'batch': 256, 'scaling': 'weak'},
+    2: {'name': 'BASELINE.json configs[2]',
+        'models': ['EXP-NBD103_read_starts', 'EXP-NBD103_read_ends'], 'sides': ['start', 'end'],
+        'reads': 100000, 'batch': 512, 'scaling': 'weak', 'combine': 'require_either'},
+    3: {'name': 'BASELINE.json configs[3]', 'models': ['SQK-RBK004_read_starts'],
+        'sides': ['start'], 'reads': 1000000, 'batch': 256, 'scaling': 'strong'},
+}
 
 
 def synthetic_reads(n, seed):
@@ -59,35 +86,184 @@ def synthetic_reads(n, seed):
     return out
 
 
-def cpu_baseline(weights, reads, gpu_calls, gpu_probs):
+def real_windows(limit):
+    """1024-sample windows cut from the 37 real reads of the reference's test set
+    (tests/golden/reads.npz) at 64-sample shifts over their first 6,144 samples: unlike the
+    synthetic squiggles (all 'none') these exercise the barcode classes."""
+    path = os.path.join(REPO, 'tests', 'golden', 'reads.npz')
+    if not os.path.isfile(path):
+        return np.zeros((0, 1024), dtype=np.int16)
+    data = np.load(path)
+    cut = []
+    for samples, offsets in ((data['samples'], data['offsets']),
+                             (data['multi_samples'], data['multi_offsets'])):
+        for i in range(len(offsets) - 1):
+            read = samples[offsets[i]:offsets[i + 1]]
+            for s in range(0, min(len(read) - 1024, 5120) + 1, 64):
+                cut.append(read[s:s + 1024])
+    cut = np.asarray(cut, dtype=np.int16)
+    if len(cut) > limit:
+        cut = cut[np.linspace(0, len(cut) - 1, limit).astype(np.int64)]
+    return cut
+
+
+def config_reads(n, seed):
+    """n reads of 1,024 samples: seeded synthetic signals in chunks of 10,000 (the first 50,000
+    are distinct; beyond that they repeat, rolled by the tile number), every tenth read of the
+    first 10,000 replaced by a window of a real read."""
+    unique = min(n, 50000)
+    base = np.concatenate([synthetic_reads(min(10000, unique - a), seed + a // 10000)
+                           for a in range(0, unique, 10000)])
+    real = real_windows(min(unique, 10000) // 10)
+    base[0:10 * len(real):10] = real
+    if n <= unique:
+        return base
+    out = np.empty((n, 1024), dtype=np.int16)
+    for tile, a in enumerate(range(0, n, unique)):
+        b = min(a + unique, n)
+        out[a:b] = np.roll(base[:b - a], 17 * tile, axis=1) if tile else base[:b - a]
+    return out
+
+
+class ShardJob:
+    """One device's share of the benchmark, living on that device's thread (or on the rank's
+    main thread): resident reads, per-model outputs, and the step that queues the launches."""
+
+    def __init__(self, shard, cfg, weights, reads, block, timing_model):
+        self.shard, self.cfg = shard, cfg
+        self.models = [shard.model] + [shard.add_model(w) for w in weights[1:]]
+        n = len(reads)
+        shard.upload(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * 1024, block)
+        self.n = n
+        dual = len(self.models) == 2
+        self.probs = [hip_backend.DeviceBuffer(max(n, 1) * m.n_classes * 4) for m in self.models]
+        self.side_calls = [hip_backend.DeviceBuffer(max(n, 1) * 4) for _ in self.models] if dual else []
+        if os.environ.get('DEEPBINNER_BENCH_NO_HINT') != '1':      # (A/B knob)
+            for m in self.models:      # all reads are 1,024 samples long: say so (checked per read)
+                m.set_read_length_hint(1024, n * 1024)
+        self.timing_model = self.models[0] if timing_model else None
+
+    def step(self):
+        s, cfg = self.shard, self.cfg
+        if not self.side_calls:
+            self.models[0].classify_batched_dev(s.samples.ptr, s.offsets.ptr, self.n, cfg['batch'],
+                                                cfg['sides'][0], SCAN_SIZE, SCORE_DIFF,
+                                                self.probs[0].ptr, s.calls.ptr, s.stream.ptr)
+            return
+        for m, side, probs, calls in zip(self.models, cfg['sides'], self.probs, self.side_calls):
+            m.classify_batched_dev(s.samples.ptr, s.offsets.ptr, self.n, cfg['batch'], side,
+                                   SCAN_SIZE, SCORE_DIFF, probs.ptr, calls.ptr, s.stream.ptr)
+        hip_backend.combine_calls_dev(self.side_calls[0].ptr, self.side_calls[1].ptr, self.n,
+                                      cfg['combine'], s.calls.ptr, s.stream.ptr)
+
+
+class PinnedCalls:
+    """Pinned host landing buffer for the gathered calls (async D2H inside the timed region)."""
+
+    def __init__(self, count):
+        self.lib = hip_backend.load_library()
+        self.count = int(count)
+        ptr = ctypes.c_void_p()
+        hip_backend.check(self.lib.dbh_malloc_host(ctypes.byref(ptr), max(self.count, 1) * 4))
+        self.ptr = ptr.value
+
+    def fetch(self, dev_ptr, stream):
+        hip_backend.check(self.lib.dbh_memcpy_d2h(self.ptr, dev_ptr, self.count * 4, stream),
+                          'dbh_memcpy_d2h')
+
+    def array(self):
+        return np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_int32)),
+                                     shape=(self.count,)).copy()
+
+
+def cpu_baseline(cfg, weights, reads, gpu_calls, gpu_probs):
     """Time the oracle's C port on a bounded sample (about 10-20 s of CPU work)."""
     from oracle import dbref
-    model = dbref.CModel(weights)
+    from oracle import classify_ref
+    models = [dbref.CModel(w) for w in weights]
     offsets = lambda k: np.arange(k + 1, dtype=np.int64) * 1024
+
+    def run(sample_reads):
+        out = [m.classify(sample_reads.ravel(), offsets(len(sample_reads)), side, SCAN_SIZE,
+                          SCORE_DIFF) for m, side in zip(models, cfg['sides'])]
+        calls = out[0][1]
+        if len(out) == 2:
+            names = [['none' if c == 0 else str(int(c)) for c in o[1]] for o in out]
+            final = [classify_ref.combine_calls(a, b, cfg['combine']) for a, b in zip(*names)]
+            calls = np.array([0 if c == 'none' else int(c) for c in final], dtype=np.int32)
+        return out[0][0], calls
+
     # calibrate on growing warm probes (the first call also spins up the OpenMP team), then size
-    # the timed sample for about 15 s of CPU work, cycling through the 10,000 reads if needed
+    # the timed sample for about 15 s of CPU work, cycling through the reads if needed
     probe_n, rate = 256, 0.0
     for _ in range(3):
         t0 = time.perf_counter()
-        model.classify(reads[:probe_n].ravel(), offsets(probe_n), 'start', SCAN_SIZE, SCORE_DIFF)
+        run(reads[:probe_n])
         rate = probe_n / max(time.perf_counter() - t0, 1e-6)
         probe_n = int(min(len(reads), max(probe_n, rate * 1.0)))
     sample = int(max(1024, rate * 15))
     idx = np.arange(sample) % len(reads)
     big = np.ascontiguousarray(reads[idx])
     t0 = time.perf_counter()
-    probs, calls = model.classify(big.ravel(), offsets(sample), 'start', SCAN_SIZE, SCORE_DIFF)
+    probs, calls = run(big)
     dt = time.perf_counter() - t0
-    gpu_calls, gpu_probs = gpu_calls[idx], gpu_probs[idx]
-    agree = bool(np.array_equal(calls, gpu_calls[:sample]))
-    max_dp = float(np.abs(probs - gpu_probs[:sample]).max())
-    return {'value': sample / dt, 'unit': 'reads/s', 'cores': int(model.threads_used),
-            'kind': 'port',
-            'sample': '{} reads (the {} synthetic reads, cycled), oracle/dbref.c (gcc -O3 -fopenmp), '
-                      '{} host threads of {} cpus, {:.1f} s'.format(sample, len(reads),
-                                                                   model.threads_used,
-                                                                   os.cpu_count(), dt),
-            'calls_match_gpu': agree, 'max_abs_dp_vs_gpu': max_dp}
+    threads = int(models[0].threads_used)
+    return {'value': sample / dt, 'unit': 'reads/s', 'cores': threads, 'kind': 'port',
+            'sample': '{} reads (the first {} reads of the workload, cycled), oracle/dbref.c '
+                      '(gcc -O3 -fopenmp), {} host threads of {} cpus, {:.1f} s'
+                      .format(sample, len(reads), threads, os.cpu_count(), dt),
+            'calls_match_gpu': bool(np.array_equal(calls, gpu_calls[idx])),
+            'calls_not_none_in_sample': int((calls != 0).sum()),
+            'max_abs_dp_vs_gpu': float(np.abs(probs - gpu_probs[idx]).max())}
+
+
+def side_rates(weights, reads):
+    """Two rates of configs[1] that are NOT `value` (N = 1 only): without the uniform-read-length
+    hint, and PCIe-inclusive through the host-buffer entry point dbh_classify_i16 (pack -> H2D ->
+    kernels -> D2H on two streams) over 20 copies of the reads."""
+    n = len(reads)
+    model = hip_backend.HipModel(weights)
+    d_samples = hip_backend.DeviceBuffer.from_array(reads)
+    d_offsets = hip_backend.DeviceBuffer.from_array(np.arange(n + 1, dtype=np.int64) * 1024)
+    d_probs = hip_backend.DeviceBuffer(n * model.n_classes * 4)
+    d_calls = hip_backend.DeviceBuffer(n * 4)
+    out = {}
+    best = None
+    for _ in range(4):
+        hip_backend.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, 256, 'start', SCAN_SIZE,
+                                       SCORE_DIFF, d_probs.ptr, d_calls.ptr, None)
+        hip_backend.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        best = dt if best is None else min(best, dt)
+    out['value_no_hint'] = n / best
+    tiles = 20
+    big = np.ascontiguousarray(np.tile(reads, (tiles, 1))).reshape(-1)
+    offsets = np.arange(n * tiles + 1, dtype=np.int64) * 1024
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        model.classify_packed(big, offsets, 'start', SCAN_SIZE, SCORE_DIFF)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out['value_pcie_inclusive'] = n * tiles / best
+    out['pcie_inclusive_note'] = ('{} reads per dbh_classify_i16 call from pageable host memory, '
+                                  'results back in host arrays; {:.2f} GB/s of int16 over PCIe'
+                                  .format(n * tiles, big.nbytes / best / 1e9))
+    model.close()
+    return out
+
+
+def pmc_constants():
+    """Static counters of the committed rocprofv3 PMC runs of this build (profiles/pmc_traffic.json,
+    written by tools/summarise_profile.py): HBM bytes per launch and matrix-pipe busy fraction."""
+    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    if os.path.isfile(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
 
 
 def main():
@@ -95,92 +271,89 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-rates', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='experiment: skip the per-launch HIP events (roofline object omitted)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
-    rank, local_rank, world = env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 '
-                         '--nproc-per-node {} --master-addr 127.0.0.1 bench.py --gpus {}'
-                         .format(args.gpus, args.gpus))
-
-    # DEEPBINNER_BENCH_SHARE_GPU=1 is a TEST mode for boxes with one GPU: every rank uses
-    # device 0 and the gather runs over gloo on host copies (RCCL refuses two ranks per device).
-    share_gpu = os.environ.get('DEEPBINNER_BENCH_SHARE_GPU') == '1'
-    # DEEPBINNER_BENCH_FORCE_DIST=1 is a TEST mode too: take the multi-rank code path (process
-    # group, RCCL all-gather, MAX-over-ranks) even with a single rank, so that a one-GPU box
-    # exercises exactly what the N > 1 runs execute.
-    use_dist = world > 1 or os.environ.get('DEEPBINNER_BENCH_FORCE_DIST') == '1'
-    device = 0 if share_gpu else local_rank
-    dist = torch = None
-    if use_dist:
-        import torch
-        from deepbinner_amd.sharding import init_process_group
-        if share_gpu:
-            dist = init_process_group('gloo')
-        else:
-            torch.cuda.set_device(local_rank)
-            dist = init_process_group('nccl', local_rank)
-    hip_backend.set_device(device)
-
-    weights, _ = ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models', MODEL + '.dbw'))
-    model = hip_backend.HipModel(weights)
-
-    # ---- inputs resident in HBM (rank-specific seed: every GPU has its own 10,000 reads) ------
-    reads = synthetic_reads(N_READS, 20260927 + rank)
-    d_samples = hip_backend.DeviceBuffer.from_array(reads)
-    d_offsets = hip_backend.DeviceBuffer.from_array(np.arange(N_READS + 1, dtype=np.int64) * 1024)
-    d_probs = hip_backend.DeviceBuffer(N_READS * model.n_classes * 4)
-    if use_dist and not share_gpu:
-        calls_t = torch.empty(N_READS, dtype=torch.int32, device='cuda')
-        calls_ptr = calls_t.data_ptr()
-        gathered = torch.empty(world * N_READS, dtype=torch.int32, device='cuda')
+    rank, local_rank, env_size = sharding.env_world()
+    # a launcher started one process per GPU (DEEPBINNER_BENCH_FORCE_RANKS=1: TEST mode that
+    # takes this path - rendezvous, ncclCommInitRank, RCCL all-gather - with a single rank, so
+    # that a one-GPU box executes exactly what the N > 1 runs execute, minus the peers)
+    per_rank = env_size > 1 or os.environ.get('DEEPBINNER_BENCH_FORCE_RANKS') == '1'
+    if per_rank and env_size != args.gpus:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, env_size))
+    world = args.gpus
+    if cfg['scaling'] == 'strong':
+        bounds = [sharding.shard_bounds(cfg['reads'], world, r) for r in range(world)]
     else:
-        d_calls = hip_backend.DeviceBuffer(N_READS * 4)
-        calls_ptr = d_calls.ptr
-    # the synthetic reads are all 1,024 samples long: say so (checked on the device per read)
-    if os.environ.get('DEEPBINNER_BENCH_NO_HINT') != '1':      # (A/B knob)
-        model.set_read_length_hint(1024, N_READS * 1024)
-    # One C-ABI call per step: the library walks the 10,000 reads in batches of 256, one fused
-    # kernel launch per batch, back to back on one stream - which is also where the HIP events
-    # that time every launch are recorded.
+        bounds = [(0, cfg['reads'])] * world
+    shard_sizes = [b - a for a, b in bounds]
+    block = max(shard_sizes)
+    weights = [ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models', m + '.dbw'))[0]
+               for m in cfg['models']]
+
+    def reads_of(r):
+        if cfg['scaling'] == 'strong':      # one global set, this rank's contiguous block
+            a, b = bounds[r]
+            return config_reads(cfg['reads'], 20260927)[a:b] if world == 1 else \
+                config_reads(b - a, 20260927 + 1000 * r)
+        return config_reads(cfg['reads'], 20260927 + 1000 * r)   # weak: own reads per GPU
+
+    rdzv = None
+    if per_rank:
+        rdzv = sharding.Rendezvous(rank, world)
+        group = sharding.RankGroup(weights[0], rdzv)
+        my_reads = reads_of(rank)
+        jobs = [ShardJob(group.shard, cfg, weights, my_reads, block, rank == 0)]
+        group.shard_sizes = shard_sizes
+        run_all = lambda fn: [fn(jobs[0])]
+        lead = jobs[0]
+        all_reads0 = my_reads if rank == 0 else None
+        transport = group.transport
+    else:
+        group = sharding.DeviceGroup(weights[0], world)
+        group.shard_sizes = shard_sizes
+        all_reads0 = reads_of(0)
+        jobs = group.run_indexed(lambda i: ShardJob(group.shards[i], cfg, weights,
+                                                    all_reads0 if i == 0 else reads_of(i), block,
+                                                    i == 0))
+        run_all = lambda fn: group.run_indexed(lambda i: fn(jobs[i]))
+        lead = jobs[0]
+        transport = group.transport
+    is_lead = rank == 0
+    pinned = PinnedCalls(block * world) if is_lead else None
+
+    def fetch():
+        pinned.fetch(lead.shard.gathered.ptr, lead.shard.stream.ptr)
+
     def step():
-        model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, N_READS, BATCH, 'start',
-                                   SCAN_SIZE, SCORE_DIFF, d_probs.ptr, calls_ptr, None)
-        if use_dist and share_gpu:
-            host = torch.from_numpy(d_calls.download((N_READS,), np.int32))
-            out = [torch.empty_like(host) for _ in range(world)]
-            dist.all_gather(out, host)
-        elif use_dist:
-            # In line with the classification, not overlapped with the next step's: a launch is
-            # exactly one wave of 256 workgroups on 256 CUs, and a collective kernel running
-            # beside it pushes some of them into a second wave (measured: +6 % per step).
-            dist.all_gather_into_tensor(gathered, calls_t)
+        run_all(lambda j: j.step())
+        group.all_gather()
+        if is_lead:       # the gathered calls reach the host inside the timed region
+            fetch() if per_rank else group.run_on(0, fetch)
 
     def sync():
-        hip_backend.synchronize()
-        if use_dist and not share_gpu:
-            torch.cuda.synchronize()
+        run_all(lambda j: j.shard.synchronize())
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
 
     for _ in range(args.warmup):
         step()
     sync()
     barrier()
     sync()
-    # One HIP event pair around launches 20k .. 20k+3 of the 40 launches of a step (all full,
-    # 256-window launches; the 16-window tail launch is never inside a bracket).  A pair around
-    # EVERY launch costs ~7 us of queue time per batch and slows what is being measured, and a
+    # One HIP event pair around launches 20k .. 20k+3 of a step's launches (all full launches; a
+    # pair around EVERY launch costs ~7 us of queue time per batch and slows what it measures, a
     # pair around a single launch includes ~2.5 us of dispatch latency that back-to-back launches
-    # do not pay (rocprofv3's per-kernel duration is that much shorter).
-    model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
+    # do not pay - rocprofv3's per-kernel duration is that much shorter).
+    if lead.timing_model is not None:
+        lead.timing_model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -188,67 +361,93 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches, windows = model.timing_read()
-    model.timing_enable(False)
+    kernel_ms = launches = windows = 0
+    if lead.timing_model is not None:
+        kernel_ms, launches, windows = lead.timing_model.timing_read()
+        lead.timing_model.timing_enable(False)
+    if rdzv is not None:
+        elapsed = rdzv.max_float(elapsed)
 
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total_reads = N_READS * world * args.steps
-    value = total_reads / elapsed
+    n_models = len(cfg['models'])
+    reads_per_step = sum(shard_sizes)
+    value = reads_per_step * args.steps / elapsed
     result = {
         'metric': 'reads classified/sec (1024-sample windows, batch 256)',
         'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE.json configs[1]: {} model, {} synthetic 1024-sample int16 '
-                               'signals per GPU per step, batch {}, seam b2 (slice + normalise + '
-                               'CNN + renormalise + call fused in one launch per batch), '
-                               'scan_size {} => 1 window per read, inputs resident in HBM, uniform read '
-                               'length declared (dbh_model_set_read_length_hint)'.format(MODEL, N_READS, BATCH, SCAN_SIZE),
-                   'reads_per_step_per_gpu': N_READS, 'batch': BATCH, 'windows_per_read': 1,
-                   'launches_per_batch': 1,
-                   'parallelism': 'reads sharded, {} rank(s), RCCL all_gather of calls'.format(world)
-                   if world > 1 else 'single GPU'},
+        'config': {
+            'workload': '{}: {} model{}, {} synthetic 1024-sample int16 signals {} per step, batch '
+                        '{}, seam b2 (slice + normalise + CNN + renormalise + call fused in one '
+                        'launch per batch{}), scan_size {} => 1 window per read and model, inputs '
+                        'resident in HBM, uniform read length declared '
+                        '(dbh_model_set_read_length_hint), gathered calls copied to pinned host '
+                        'memory every step'.format(
+                            cfg['name'], ' + '.join(cfg['models']), 's' if n_models > 1 else '',
+                            cfg['reads'], 'in total' if cfg['scaling'] == 'strong' else 'per GPU',
+                            cfg['batch'],
+                            ', combine_calls on the device' if n_models > 1 else '', SCAN_SIZE),
+            'reads_per_step': reads_per_step, 'reads_per_step_per_gpu': shard_sizes,
+            'batch': cfg['batch'], 'windows_per_read': n_models, 'launches_per_batch': n_models,
+            'real_read_windows_in_first_10000': int(len(real_windows(1000))),
+            'parallelism': ('reads sharded over {} GPUs, {}, all-gather of int32 calls over {}'
+                            .format(world, 'one process per GPU' if per_rank
+                                    else 'one process, a thread per device', transport)
+                            if world > 1 else 'single GPU')},
+        'windows_per_s': value * n_models,
+        'gather': {'transport': transport if (world > 1 or group.comm is not None) else 'none',
+                   'fallback_reason': group.fallback_reason},
     }
-    if rank == 0 and args.no_kernel_timing:
-        print(json.dumps(result))
-    elif rank == 0:
+    if is_lead:
+        calls_host = pinned.array()
+        gathered = np.concatenate([calls_host[r * block:r * block + shard_sizes[r]]
+                                   for r in range(world)])
+        result['calls_not_none_rank0'] = int((gathered[:shard_sizes[0]] != 0).sum())
+    if is_lead and not args.no_kernel_timing:
         avg_ms = kernel_ms / max(launches, 1)
         windows_per_launch = windows / max(launches, 1)
-        achieved = FLOP_PER_WINDOW * windows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
-        traffic = None
-        pmc_path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
-        if os.path.isfile(pmc_path):
-            with open(pmc_path) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
+        rate = windows_per_launch / (avg_ms * 1e-3) if launches else 0.0
+        achieved = FLOP_PER_WINDOW * rate / 1e12
+        mfmas, executed_flop = hip_backend.forward_executed_mfmas(lead.models[0].n_classes)
+        pmc = pmc_constants()
+        bytes_per_window = 1024 * 2 + lead.models[0].n_classes * 4 + 4
         result['roofline'] = {
             'bound': 'mfma', 'kernel': 'dbh_forward_kernel', 'achieved': achieved,
             'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
-            'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
+            'frac_counts': 'algorithmic FLOP of the direct convolutions; the Winograd layers '
+                           'issue fewer MFMAs, so this can exceed 1 - see frac_executed',
+            'executed_mfma_per_window': mfmas, 'executed_flop_per_window': executed_flop,
+            'achieved_executed': executed_flop * rate / 1e12,
+            'frac_executed': executed_flop * rate / 1e12 / PEAK_FP32_TFLOPS,
+            'mfma_pipe_util': pmc.get('mfma_pipe_util'),
+            'mfma_pipe_util_source': pmc.get('mfma_pipe_util_source'),
+            'traffic': pmc.get('hbm_bytes_per_launch'),
+            'traffic_windows_per_launch': pmc.get('windows_per_launch'),
+            'avg_launch_ms': avg_ms, 'launches_timed': launches,
             'timed_every_nth_launch': TIMING_STRIDE, 'launches_per_event_bracket': TIMING_SPAN,
             'windows_per_launch': windows_per_launch,
             'algorithmic_flop_per_window': FLOP_PER_WINDOW,
             # fused seam b2: int16 samples in, fp32 probabilities + int32 call out
-            'algorithmic_hbm_bytes_per_window': 1024 * 2 + model.n_classes * 4 + 4,
-            'hbm_frac_at_algorithmic_bytes': (value * (1024 * 2 + model.n_classes * 4 + 4) / world)
-                                             / 8.0e12,
+            'algorithmic_hbm_bytes_per_window': bytes_per_window,
+            'hbm_frac_at_algorithmic_bytes': rate * bytes_per_window / PEAK_HBM_BYTES_PER_S,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            if use_dist and not share_gpu:       # (forced single-rank RCCL test mode)
-                gpu_calls = calls_t.cpu().numpy()
-            else:
-                gpu_calls = d_calls.download((N_READS,), np.int32)
-            gpu_probs = d_probs.download((N_READS, model.n_classes), np.float32)
-            result['cpu_baseline'] = cpu_baseline(weights, reads, gpu_calls, gpu_probs)
-        result['device'] = hip_backend.device_name(device)
+    if is_lead and world == 1:
+        if args.config == 1 and not args.no_side_rates:
+            result.update(side_rates(weights[0], all_reads0))
+        if not args.no_cpu_baseline:
+            n0 = shard_sizes[0]
+            gpu_probs = lead.probs[0].download((n0, lead.models[0].n_classes), np.float32)
+            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_reads0[:min(n0, 50000)],
+                                                  gathered[:n0], gpu_probs)
+    if is_lead:
+        result['device'] = hip_backend.device_name(lead.shard.device)
         print(json.dumps(result))
+        sys.stdout.flush()
     barrier()
-    if use_dist:
-        dist.destroy_process_group()
+    group.close()
+    if rdzv is not None:
+        rdzv.close()
 
 
 if __name__ == '__main__':

@@ -282,6 +282,7 @@ const char* dbh_status_string(int status) {
         case DBH_ERR_BAD_WEIGHTS: return "weight blob does not match the Deepbinner architecture";
         case DBH_ERR_UNSUPPORTED: return "unsupported model geometry";
         case DBH_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case DBH_ERR_COMM: return "multi-device exchange failed";
         default: return "unknown status";
     }
 }
@@ -759,6 +760,15 @@ int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs) 
     if (threads_per_block) *threads_per_block = dbh::kThreads;
     if (lds_bytes) *lds_bytes = (int)attr.sharedSizeBytes;
     if (vgprs) *vgprs = attr.numRegs;
+    return DBH_OK;
+}
+
+int dbh_forward_executed_mfmas(int n_classes, int64_t* mfmas_per_window,
+                                int64_t* flop_per_window) {
+    if (n_classes < 2 || n_classes > dbh::kMaxClasses) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t n = dbh::forward_mfmas(n_classes);
+    if (mfmas_per_window) *mfmas_per_window = n;
+    if (flop_per_window) *flop_per_window = n * 2048;      // 16 x 16 x 4 multiply-adds
     return DBH_OK;
 }
 

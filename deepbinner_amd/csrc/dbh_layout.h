@@ -47,6 +47,29 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {1, 48, 32, 1, 0},    // conv1d_20  (n_classes <= 32, zero padded)
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
+// positions each convolution produces (after its stride, before any pooling)
+constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
+                                      64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
+
+// v_mfma_f32_16x16x4_f32 instructions the forward kernel ISSUES for convolution i of one window
+// (2,048 FLOP each): M tiles of 16 positions (pairs / quads for the Winograd layers) x N tiles of
+// 16 channels x k-steps of 4 input channels per tap (transformed matrix).  The direct count of
+// the same layer is what SURVEY.md's 33,629,952 FLOP per window adds up; the Winograd layers
+// issue 4/6 and 6/12 of it.
+constexpr int conv_mfmas(int i, int n_classes) {
+    const int units = kConvLout[i] / (kConv[i].wino ? kConv[i].wino : 1);
+    const int m_tiles = (units + 15) / 16;
+    const int n_tiles = i == kNumConvs - 1 ? (n_classes <= 16 ? 1 : 2) : kConv[i].cout_pad / 16;
+    const int mats = kConv[i].wino == 4 ? 6 : kConv[i].wino == 2 ? 4 : kConv[i].taps;
+    const int k_steps = kConv[i].cin == 1 ? 1 : mats * kConv[i].cin / 4;
+    return m_tiles * n_tiles * k_steps;
+}
+constexpr int forward_mfmas(int n_classes) {
+    int n = 0;
+    for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
+    return n;
+}
+static_assert(forward_mfmas(13) == 10116, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {

@@ -114,6 +114,7 @@ def load_library():
         'dbh_debug_forward': (c_int, [c_void_p, _f32(), c_i64, c_int, _f32()]),
         'dbh_forward_kernel_info': (c_int, [P(c_int), P(c_int), P(c_int)]),
         'dbh_forward_truncated_dev': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+        'dbh_forward_executed_mfmas': (c_int, [c_int, P(c_i64), P(c_i64)]),
         'dbh_forward_timeline': (c_int, [c_void_p, _f32(), c_i64,
                                          ndpointer(np.int64, flags='C_CONTIGUOUS')]),
         'dbh_model_set_read_length_hint': (c_int, [c_void_p, c_i64, c_i64]),
@@ -122,6 +123,15 @@ def load_library():
         'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_timing_enable_span': (c_int, [c_void_p, c_int, c_int]),
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
+        'dbh_comm_available': (c_int, []),
+        'dbh_comm_last_error': (ctypes.c_char_p, []),
+        'dbh_comm_init_all': (c_int, [c_int, P(c_int), c_int, P(c_void_p)]),
+        'dbh_comm_unique_id': (c_int, [ctypes.c_char_p]),
+        'dbh_comm_init_rank': (c_int, [ctypes.c_char_p, c_int, c_int, P(c_void_p)]),
+        'dbh_comm_info': (c_int, [c_void_p, P(c_int), P(c_int), P(c_int)]),
+        'dbh_comm_all_gather_i32': (c_int, [c_void_p, P(c_void_p), P(c_void_p), c_i64,
+                                            P(c_void_p)]),
+        'dbh_comm_destroy': (c_int, [c_void_p]),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(lib, name)     # AttributeError here = header and library out of step
@@ -141,8 +151,10 @@ EXPORTED_SYMBOLS = [
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
-    'dbh_forward_truncated_dev', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
+    'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
     'dbh_forward_timing_read',
+    'dbh_comm_available', 'dbh_comm_last_error', 'dbh_comm_init_all', 'dbh_comm_unique_id',
+    'dbh_comm_init_rank', 'dbh_comm_info', 'dbh_comm_all_gather_i32', 'dbh_comm_destroy',
 ]
 
 
@@ -150,7 +162,7 @@ def check(status, what='libdeepbinner_hip call'):
     if status != 0:
         lib = load_library()
         msg = lib.dbh_status_string(status).decode()
-        detail = lib.dbh_last_error().decode()
+        detail = (lib.dbh_comm_last_error() if status == 7 else lib.dbh_last_error()).decode()
         raise HipBackendError('{} failed: {}{}'.format(what, msg,
                                                        ' ({})'.format(detail) if detail else ''))
 
@@ -474,6 +486,15 @@ class HipModel:
         shapes = {0: (512, 48), 1: (256, 48), 2: (128, 48), 3: (64, 48), 4: (32, 192),
                   5: (16, 48), 6: (8, 48), 7: (32,)}
         return out.reshape((x.shape[0],) + shapes[idx])
+
+
+def forward_executed_mfmas(n_classes):
+    """(MFMA instructions, FLOP) the forward kernel issues per window."""
+    lib = load_library()
+    n, f = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.dbh_forward_executed_mfmas(int(n_classes), ctypes.byref(n), ctypes.byref(f)),
+          'dbh_forward_executed_mfmas')
+    return n.value, f.value
 
 
 def forward_kernel_info():

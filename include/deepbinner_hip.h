@@ -35,7 +35,8 @@ typedef enum {
     DBH_ERR_HIP = 3,              /* a HIP runtime call failed; see dbh_last_error() */
     DBH_ERR_BAD_WEIGHTS = 4,      /* blob size does not match the Deepbinner architecture */
     DBH_ERR_UNSUPPORTED = 5,      /* e.g. input_size != 1024 or n_classes > 32 */
-    DBH_ERR_OUT_OF_MEMORY = 6
+    DBH_ERR_OUT_OF_MEMORY = 6,
+    DBH_ERR_COMM = 7              /* RCCL missing or a collective failed; see dbh_comm_last_error() */
 } dbh_status;
 
 typedef struct dbh_model dbh_model;      /* opaque: packed weights resident in HBM */
@@ -142,6 +143,37 @@ int dbh_classify_i16_batched_dev(dbh_model* model, const int16_t* samples_dev,
 int dbh_combine_calls_dev(const int32_t* start_calls_dev, const int32_t* end_calls_dev,
                           int64_t n_reads, int mode, int32_t* out_dev, dbh_stream stream);
 
+/* ---- multi-device: reads shard over the GPUs of one node, calls are all-gathered ---------- */
+/* The reference is single-device (its only knob: set_tensorflow_threads, classify.py:416-423).
+ * Reads are independent, so every GPU classifies a contiguous shard with its own model replica
+ * (dbh_model_create under dbh_set_device) and no data-path collective; the one exchange is an
+ * all-gather of the per-read int32 calls over RCCL / xGMI.  Two host
+ * models, same entry points:
+ *   one process, n devices:  dbh_comm_init_all (ncclCommInitAll); the arrays handed to
+ *                            dbh_comm_all_gather_i32 have one entry per device;
+ *   one process per GPU:     rank 0 calls dbh_comm_unique_id and ships the DBH_COMM_ID_BYTES bytes
+ *                            to the other ranks over any host channel; every rank then calls
+ *                            dbh_comm_init_rank with ITS device current; arrays have one entry.
+ * librccl.so.1 is looked up at the first of these calls (dlopen), not at load time. */
+typedef struct dbh_comm dbh_comm;
+#define DBH_COMM_ID_BYTES 128
+#define DBH_COMM_RCCL 0                  /* ncclAllGather                                        */
+#define DBH_COMM_COPY 1                  /* hipMemcpy(Peer)Async copies, single-process form only:
+                                            for boxes where two "devices" are one physical GPU,
+                                            which RCCL refuses                                    */
+int dbh_comm_available(void);            /* 1 if librccl could be loaded                          */
+const char* dbh_comm_last_error(void);
+int dbh_comm_init_all(int n_devices, const int* ordinals /* NULL = 0..n-1 */, int transport,
+                      dbh_comm** comm);
+int dbh_comm_unique_id(void* id_out /* DBH_COMM_ID_BYTES */);
+int dbh_comm_init_rank(const void* id, int n_ranks, int rank, dbh_comm** comm);
+int dbh_comm_info(const dbh_comm* comm, int* n_ranks, int* n_local, int* transport);
+/* recv_dev[i] (n_ranks * count int32 on local device i) = the send_dev blocks of all ranks in rank
+ * order; queued on streams[i] behind whatever produced send_dev[i]; does not block the host. */
+int dbh_comm_all_gather_i32(dbh_comm* comm, const int32_t* const* send_dev,
+                            int32_t* const* recv_dev, int64_t count, const dbh_stream* streams);
+int dbh_comm_destroy(dbh_comm* comm);
+
 /* ---- pieces of seam b2, exposed for parity tests ---------------------------------------- */
 /* windows_dev: (n_reads * steps) x 1024 fp32, read-major (window index = read*steps + step). */
 int dbh_normalise_windows_dev(const int16_t* samples_dev, const int64_t* offsets_dev,
@@ -159,6 +191,12 @@ int dbh_debug_forward(dbh_model* model, const float* x_host, int64_t n_windows, 
                       float* out_host);
 /* name and static resource use of the forward kernel, for bench/roofline bookkeeping */
 int dbh_forward_kernel_info(int* threads_per_block, int* lds_bytes, int* vgprs);
+/* Matrix instructions (v_mfma_f32_16x16x4_f32, 2,048 FLOP each) the forward kernel ISSUES per
+ * window for a model of n_classes classes - fewer than the 33,629,952 algorithmic FLOP of the
+ * direct convolutions because six layers run as Winograd F(4,3) / F(2,3).  A constant of the build
+ * (dbh_layout.h), checked against rocprofv3's SQ_INSTS_MFMA in profiles/. */
+int dbh_forward_executed_mfmas(int n_classes, int64_t* mfmas_per_window,
+                               int64_t* flop_per_window);
 /* Run the forward kernel only up to and including stage last_stage (0 = 'A' .. 6 = 'G'), writing
  * nothing: lets a profiler attribute kernel time to stages by differencing. */
 int dbh_forward_truncated_dev(dbh_model* model, const float* x_dev, int64_t n_windows,

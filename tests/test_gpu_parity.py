@@ -483,29 +483,35 @@ def test_packed_batches_from_the_native_loader_go_to_the_gpu_as_they_are(hip_mod
     assert rows['native'] == rows['python'] and len(rows['native']) == 30
 
 
-def test_combine_calls_on_the_device(hip):
-    """dbh_combine_calls_dev against the reference's truth table (tests/test_combine_calls.py,
-    via classify.combine_calls) for every pair of calls in every mode, in place and out of place,
-    and on 1M random pairs against the array form."""
-    import argparse
-    from deepbinner_amd import classify
+def test_combine_calls_on_the_device(hip, gold):
+    """dbh_combine_calls_dev against the ORACLE: the reference's own truth table
+    (tests/test_combine_calls.py as committed in calls.json:combine_table, produced by the
+    reference's combine_calls) and oracle.classify_ref.combine_calls for every pair of calls in
+    every mode, in place and out of place, and on 1M random pairs through the oracle's 13 x 13
+    table."""
     grid = np.arange(13, dtype=np.int32)
     starts, ends = np.repeat(grid, 13), np.tile(grid, 13)
     name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+    number = lambda s: 0 if s == 'none' else int(s)                   # noqa: E731
     rng = np.random.default_rng(9)
     big_s = rng.integers(0, 13, size=1000003).astype(np.int32)
     big_e = np.where(rng.random(1000003) < 0.5, big_s, rng.integers(0, 13, size=1000003)) \
         .astype(np.int32)
+    table = gold['calls']['combine_table']
+    assert len(table) == 15
     for mode in ('require_either', 'require_start', 'require_both'):
-        args = argparse.Namespace(require_either=False, require_start=False, require_both=False)
-        setattr(args, mode, True)
+        want = np.array([number(classify_ref.combine_calls(name(a), name(b), mode))
+                         for a, b in zip(starts, ends)], dtype=np.int32)
         d_s, d_e = hip.DeviceBuffer.from_array(starts), hip.DeviceBuffer.from_array(ends)
         d_o = hip.DeviceBuffer(len(starts) * 4)
         hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(starts), mode, d_o.ptr)
         hip.synchronize()
         got = d_o.download((len(starts),), np.int32)
-        assert [name(c) for c in got] == [classify.combine_calls(name(a), name(b), args)
-                                          for a, b in zip(starts, ends)], mode
+        assert np.array_equal(got, want), mode
+        for key, answer in table.items():          # the reference's own rows
+            m, a, b = key.split('|')
+            if m == mode:
+                assert got[number(a) * 13 + number(b)] == number(answer), key
         hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(starts), mode, d_s.ptr)      # in place
         hip.synchronize()
         assert np.array_equal(d_s.download((len(starts),), np.int32), got)
@@ -514,64 +520,142 @@ def test_combine_calls_on_the_device(hip):
         hip.combine_calls_dev(d_s.ptr, d_e.ptr, len(big_s), mode, d_o.ptr)
         hip.synchronize()
         assert np.array_equal(d_o.download((len(big_s),), np.int32),
-                              classify.combine_call_numbers(big_s, big_e, args)), mode
+                              want.reshape(13, 13)[big_s, big_e]), mode
     hip.combine_calls_dev(None, None, 0, 'require_both', None)                   # nothing to do
     with pytest.raises(Exception):
         hip.check(hip.load_library().dbh_combine_calls_dev(d_s.ptr, d_e.ptr, 5, 7, d_o.ptr, None))
 
 
-def test_bench_two_ranks_share_one_gpu(hip):
-    """bench.py's N > 1 path (torchrun env, sharded reads, gather, MAX-over-ranks timing, one JSON
-    line from rank 0) on a one-GPU box: both ranks use device 0, gather over gloo."""
+def _run_bench(extra_args, env_extra, launcher=None):
     import json
     import socket
     import subprocess
     import sys
     from conftest import REPO
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, DEEPBINNER_BENCH_SHARE_GPU='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(env_extra)
+    cmd = [sys.executable]
+    if launcher:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd += ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(launcher),
+                '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    cmd += [os.path.join(REPO, 'bench.py')] + extra_args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
-    result = json.loads(lines[0])
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_share_one_gpu(hip):
+    """bench.py's one-process-per-GPU path as the driver launches it (torch.distributed.run env,
+    own rendezvous, sharded reads, gather, MAX-over-ranks timing, one JSON line from rank 0) on a
+    one-GPU box: both ranks use device 0, so the calls are gathered through host memory (RCCL
+    refuses two ranks per device)."""
+    result = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1'],
+                        {'DEEPBINNER_DEVICE_ORDINALS': '0,0', 'DEEPBINNER_COMM': 'host'},
+                        launcher=2)
     assert result['n_gpus'] == 2 and result['steps'] == 3 and result['value'] > 0
     assert result['scaling'] == 'weak' and 'roofline' in result
+    assert result['gather']['transport'] == 'host'
+    assert result['config']['reads_per_step'] == 20000
+
+
+def test_bench_one_process_two_devices(hip):
+    """`python bench.py --gpus 2` started plainly: one process, a thread per device, grouped
+    all-gather behind the C ABI (device copies here, since both "devices" are GPU 0)."""
+    result = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1'],
+                        {'DEEPBINNER_DEVICE_ORDINALS': '0,0'})
+    assert result['n_gpus'] == 2 and result['value'] > 0 and 'roofline' in result
+    assert result['gather']['transport'] == 'copy'
+    assert result['config']['reads_per_step'] == 20000
+    assert result['calls_not_none_rank0'] > 0          # the real-read windows classify
 
 
 def test_bench_rccl_path_single_rank(hip):
-    """The RCCL code path of bench.py (device-bound process group, all_gather_into_tensor of the
-    calls on the GPU, MAX-over-ranks, destroy) forced on with ONE rank under torchrun - what the
-    N = 2/4/8 runs execute, minus the peers."""
-    import json
-    import socket
-    import subprocess
-    import sys
-    from conftest import REPO
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, DEEPBINNER_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
-           '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
-    result = json.loads(lines[0])
+    """The RCCL code path of bench.py (rendezvous, ncclGetUniqueId / ncclCommInitRank through the
+    C ABI, ncclAllGather of the calls on the launch stream, MAX-over-ranks) forced on with ONE rank
+    under the driver's launcher - what the N = 2/4/8 runs execute, minus the peers."""
+    result = _run_bench(['--gpus', '1', '--steps', '3', '--warmup', '1'],
+                        {'DEEPBINNER_BENCH_FORCE_RANKS': '1', 'DEEPBINNER_COMM_FORCE': '1'},
+                        launcher=1)
     assert result['n_gpus'] == 1 and result['value'] > 0 and 'roofline' in result
+    assert result['gather'] == {'transport': 'rccl', 'fallback_reason': None}
     assert result['cpu_baseline']['calls_match_gpu'] is True
+    assert result['cpu_baseline']['calls_not_none_in_sample'] > 0
+
+
+def test_bench_rccl_single_process_form(hip):
+    """ncclCommInitAll + grouped ncclAllGather (the `python bench.py --gpus N` form), one device."""
+    result = _run_bench(['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                         '--no-side-rates'], {'DEEPBINNER_COMM_FORCE': '1'})
+    assert result['gather'] == {'transport': 'rccl', 'fallback_reason': None}
+    assert result['calls_not_none_rank0'] > 0
+
+
+@pytest.mark.parametrize('config', [2, 3])
+def test_bench_other_configs_run(hip, config):
+    """--config 2 (two models + device combine, batch 512) and --config 3 (1M reads, RBK004)."""
+    result = _run_bench(['--config', str(config), '--steps', '2', '--warmup', '1',
+                         '--no-cpu-baseline'], {})
+    assert result['value'] > 0 and 'roofline' in result
+    assert result['config']['reads_per_step'] == (100000 if config == 2 else 1000000)
+    assert result['scaling'] == ('weak' if config == 2 else 'strong')
+
+
+def test_device_group_matches_single_device(hip, hip_models, weights, all_signals):
+    """Two "devices" (both ordinal 0) through the single-process multi-device front: contiguous
+    read shards, a model replica and a stream per device, the all-gather of the calls - the same
+    calls and probabilities a single device gives, for ragged real reads and for a count that does
+    not divide evenly."""
+    from deepbinner_amd import sharding
+    signals = (all_signals * 3)[:101]
+    samples, offsets = pack(signals)
+    want_probs, want_calls = hip_models['EXP-NBD103_read_starts'].classify_packed(
+        samples, offsets, 'start', 6144, 0.5)
+    for transport in ('copy', 'host'):
+        group = sharding.DeviceGroup(weights['EXP-NBD103_read_starts'], 2, devices=[0, 0],
+                                     transport=transport)
+        assert group.transport == transport
+        group.upload_sharded(samples, offsets)
+        assert group.shard_sizes == [51, 50]
+        group.run(lambda s: s.classify(8, 'start', 6144, 0.5))
+        group.all_gather()
+        group.synchronize()
+        for device_index in (0, 1):        # every device holds the whole job's calls
+            assert np.array_equal(group.gathered_calls(device_index), want_calls)
+        probs = np.concatenate(group.run(
+            lambda s: s.probs.download((s.n_reads, 13), np.float32, s.stream.ptr)))
+        assert np.array_equal(probs, want_probs)
+        group.close()
+
+
+def test_rccl_all_gather_through_the_c_abi(hip):
+    """dbh_comm_* with RCCL itself: both forms of communicator set-up with the one GPU this box
+    has (ncclCommInitAll over [0]; ncclGetUniqueId + ncclCommInitRank with one rank)."""
+    from deepbinner_amd import sharding
+    assert hip.load_library().dbh_comm_available() == 1
+    data = np.arange(1000, dtype=np.int32) * 7 - 3
+    for make in (lambda: sharding.Communicator.init_all([0]),
+                 lambda: sharding.Communicator.init_rank(sharding.Rendezvous(0, 1))):
+        hip.set_device(0)
+        comm = make()
+        assert (comm.n_ranks, comm.n_local, comm.transport) == (1, 1, sharding.TRANSPORT_RCCL)
+        stream = hip.Stream()
+        send = hip.DeviceBuffer.from_array(data)
+        recv = hip.DeviceBuffer(data.nbytes)
+        comm.all_gather_i32([send.ptr], [recv.ptr], len(data), [stream.ptr])
+        assert np.array_equal(recv.download(data.shape, np.int32, stream.ptr), data)
+        comm.close()
+        stream.close()
 
 
 def test_cli_classify_two_ranks_share_one_gpu(hip):
-    """The real CLI under torchrun with 2 ranks on this box's single GPU (gather over gloo):
-    rank 0 prints every read once with the reference's expected calls."""
+    """The real CLI under the driver's launcher with 2 ranks on this box's single GPU (calls
+    gathered through host memory): every read printed once, in file order, with the reference's
+    expected calls; rank 0 prints the summary."""
     import socket
     import subprocess
     import sys
@@ -580,7 +664,7 @@ def test_cli_classify_two_ranks_share_one_gpu(hip):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=REPO, DEEPBINNER_DIST_BACKEND='gloo', DEEPBINNER_DEVICE='0')
+    env = dict(os.environ, PYTHONPATH=REPO, DEEPBINNER_COMM='host', DEEPBINNER_DEVICE='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'deepbinner_amd',
            'classify', '--native', '--require_both', '--batch_size', '2',
@@ -590,6 +674,7 @@ def test_cli_classify_two_ranks_share_one_gpu(hip):
     rows = dict(l.split('\t') for l in out.stdout.splitlines() if '\t' in l)
     assert rows.pop('read_ID') == 'barcode_call'
     assert rows == EXPECTED_END          # require_both column of the reference's tests
+    assert 'Barcode     Count' in out.stderr
 
 
 @pytest.mark.skipif(os.environ.get('DEEPBINNER_SOAK') != '1',

@@ -1,8 +1,14 @@
-"""N>1 path on CPU: world_size-2 gloo process group, read sharding + gather of calls."""
+"""N>1 path on CPU: world_size-2 runs of the torch-free multi-process layer
+(deepbinner_amd/sharding.py: socket rendezvous, read sharding, gather of calls) - started plainly
+with RANK/WORLD_SIZE in the environment and under torch.distributed.run, the launcher the driver
+uses (only the LAUNCHER is torch; the ranks import none of it)."""
 import os
 import socket
 import subprocess
 import sys
+import uuid
+
+import pytest
 
 from conftest import REPO
 from deepbinner_amd.sharding import shard_bounds
@@ -18,19 +24,43 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_no_torch_in_the_product():
+    """north_star: 'no PyTorch' - neither the package nor bench.py imports it."""
+    import re
+    offenders = []
+    paths = [os.path.join(REPO, 'bench.py')]
+    for root, _, names in os.walk(os.path.join(REPO, 'deepbinner_amd')):
+        paths += [os.path.join(root, n) for n in names if n.endswith('.py')]
+    for path in paths:
+        with open(path) as f:
+            if re.search(r'^\s*(import torch|from torch)', f.read(), re.M):
+                offenders.append(path)
+    assert not offenders, offenders
+
+
 WORKER = r'''
-import os, sys
+import os, struct, sys
 import numpy as np
-import torch
 sys.path.insert(0, sys.argv[1])
-from deepbinner_amd.sharding import init_process_group, gather_calls, shard_bounds, env_world
+assert 'torch' not in sys.modules
+from deepbinner_amd.sharding import Rendezvous, gather_calls, shard_bounds, env_world
 from deepbinner_amd.model_format import ModelWeights
 from deepbinner_amd import classify
 from oracle import network_ref
 import argparse
 
 rank, local_rank, world = env_world()
-dist = init_process_group('gloo')
+rdzv = Rendezvous(rank, world)
+# the primitives
+parts = rdzv.all_gather(('rank%d' % rank).encode() * (rank + 1))
+assert parts == [b'rank0', b'rank1rank1'][:world], parts
+assert rdzv.broadcast(b'from-zero' if rank == 0 else None) == b'from-zero'
+assert rdzv.max_float(1.5 + rank) == 1.5 + (world - 1)
+assert rdzv.agree(True) == (True, '')
+ok, why = rdzv.agree(rank != 1, 'rank %d failed' % rank)
+assert (ok, why) == (False, 'rank 1 failed'), (ok, why)
+rdzv.barrier()
+
 reads = np.load(os.path.join(sys.argv[1], 'tests', 'golden', 'reads.npz'))
 offs = reads['multi_offsets']
 signals = [reads['multi_samples'][offs[i]:offs[i + 1]] for i in range(len(offs) - 1)][:9]
@@ -44,30 +74,80 @@ class M:
 
 args = argparse.Namespace(scan_size=1024, batch_size=8, score_diff=0.5)
 calls, _ = classify.call_batch(1024, 13, list(range(a, b)), signals[a:b], M(), args, 'start')
-local = torch.tensor([0 if c == 'none' else int(c) for c in calls], dtype=torch.int32)
-full = gather_calls(local, len(signals), world, rank)
+local = np.array([0 if c == 'none' else int(c) for c in calls], dtype=np.int32)
+counts = [struct.unpack('<q', p)[0] for p in rdzv.all_gather(struct.pack('<q', len(local)))]
+full = gather_calls(local, counts, rdzv)
 if rank == 0:
     all_calls, _ = classify.call_batch(1024, 13, list(range(len(signals))), signals, M(), args, 'start')
     want = [0 if c == 'none' else int(c) for c in all_calls]
     assert full.tolist() == want, (full.tolist(), want)
     print('GATHER_OK', full.tolist())
-dist.barrier()
-dist.destroy_process_group()
+rdzv.barrier()
+rdzv.close()
+assert 'torch' not in sys.modules
 '''
 
 
-def test_two_rank_gloo_gather(tmp_path):
-    script = tmp_path / 'worker.py'
-    script.write_text(WORKER)
+def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2')
+        return s.getsockname()[1]
+
+
+def _run_ranks_plainly(script, world, extra_env=None, timeout=600):
+    """Start `world` ranks the way any launcher would: RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment, one rendezvous name for the launch."""
+    name = 'deepbinner-test-' + uuid.uuid4().hex
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', RANK=str(rank),
+                   LOCAL_RANK=str(rank), WORLD_SIZE=str(world), DEEPBINNER_RDZV=name,
+                   DEEPBINNER_RDZV_TIMEOUT='300')
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    return [(p.returncode, o, e) for p, (o, e) in zip(procs, outs)]
+
+
+def test_two_ranks_rendezvous_and_gather(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    results = _run_ranks_plainly(script, 2, {'DEEPBINNER_COMM': 'host'})
+    for rc, out, err in results:
+        assert rc == 0, out + err
+    assert 'GATHER_OK' in results[0][1]
+
+
+def test_two_ranks_under_torch_distributed_run(tmp_path):
+    """The same worker under the driver's launcher: the rendezvous name is derived from
+    MASTER_PORT and the launcher's pid, nothing is passed by hand."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', DEEPBINNER_COMM='host')
+    env.pop('DEEPBINNER_RDZV', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), REPO]
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script), REPO]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'GATHER_OK' in out.stdout
+
+
+def test_a_missing_rank_is_an_error_not_a_hang(tmp_path):
+    script = tmp_path / 'lonely.py'
+    script.write_text(r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+from deepbinner_amd.sharding import Rendezvous, RendezvousError
+try:
+    Rendezvous(0, 2, timeout=1.0)
+except RendezvousError as e:
+    print('TIMED_OUT', e)
+''')
+    env = dict(os.environ, PYTHONPATH=REPO, DEEPBINNER_RDZV='deepbinner-test-' + uuid.uuid4().hex)
+    out = subprocess.run([sys.executable, str(script), REPO], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and 'TIMED_OUT' in out.stdout, out.stdout + out.stderr
 
 
 CLI_WORKER = r'''
@@ -80,24 +160,22 @@ from deepbinner_amd import deepbinner as cli
 from conftest import OracleModel
 classify.build_model = lambda w: OracleModel(w)      # CPU box: oracle-backed model double
 classify.set_tensorflow_threads = lambda args: None  # ... and no GPU to select
-cli.main(['classify', '--native', '--verbose', '--batch_size', '3',
-          os.path.join(sys.argv[1], 'tests', 'golden', 'fast5', 'single')])
+target = sys.argv[2] if len(sys.argv) > 2 else os.path.join(sys.argv[1], 'tests', 'golden', 'fast5', 'single')
+cli.main(['classify', '--native', '--verbose', '--batch_size', '3', target])
 '''
 
 
 def test_cli_classify_sharded_over_two_ranks(tmp_path):
-    """`deepbinner classify DIR` under torchrun with 2 ranks (gloo): rank 0 prints the same TSV
-    the single-process run prints, each read exactly once, with the reference's expected calls."""
+    """`deepbinner classify DIR` with 2 ranks under torch.distributed.run: the ranks print their
+    rows in turn - the same TSV the single-process run prints, each read exactly once, with the
+    reference's expected calls - and rank 0 the summary."""
     from test_oracle_golden import EXPECTED_START
     script = tmp_path / 'cli_worker.py'
     script.write_text(CLI_WORKER)
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', DEEPBINNER_DIST_BACKEND='gloo')
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', DEEPBINNER_COMM='host')
     env.pop('LOCAL_RANK', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), REPO]
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script), REPO]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if '\t' in l]
@@ -108,3 +186,25 @@ def test_cli_classify_sharded_over_two_ranks(tmp_path):
     assert {k: v[1] for k, v in rows.items()} == EXPECTED_START
     assert all(len(v) == 30 for v in rows.values())
     assert 'Barcode     Count' in out.stderr
+    # rows come out in sorted-file order = rank order: the single-process table
+    single = subprocess.run([sys.executable, str(script), REPO],
+                            env=dict(env, WORLD_SIZE='1'), capture_output=True, text=True,
+                            timeout=900)
+    assert single.returncode == 0, single.stderr[-3000:]
+    assert sorted(l for l in single.stdout.splitlines() if '\t' in l) == sorted(lines)
+
+
+def test_a_rank_local_fatal_error_ends_every_rank(tmp_path):
+    """a `sys.exit('Error: ...')` on one rank must not leave the others waiting in a
+    collective - all ranks leave with that message (here: a directory without fast5 files)."""
+    script = tmp_path / 'cli_worker.py'
+    script.write_text(CLI_WORKER.replace(
+        "cli.main(", "import deepbinner_amd.sharding as sh\n"
+        "files = []\n"
+        "args = __import__('argparse').Namespace(verbose=False, batch_size=3, scan_size=6144,\n"
+        "                                        score_diff=0.5)\n"
+        "sh.classify_fast5_files_sharded(files, None, None, None, None, 13, args)\n"
+        "raise SystemExit('not reached')\n(lambda *a: None)("))
+    results = _run_ranks_plainly(script, 2, {'DEEPBINNER_COMM': 'host'}, timeout=300)
+    for rc, out, err in results:
+        assert rc != 0 and 'Error: no fast5 files found' in err, out + err
