@@ -58,8 +58,14 @@ PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MF
 PEAK_HBM_BYTES_PER_S = 8.0e12
 SCAN_SIZE = 512
 SCORE_DIFF = 0.5
-TIMING_STRIDE = 20          # an event bracket opens at every 20th forward launch ...
-TIMING_SPAN = 4             # ... and covers 4 consecutive (full) launches
+# The forward kernel is persistent: one launch carries a whole step's reads through the batches
+# (DEEPBINNER_LAUNCH_PER_BATCH=1: the library launches once per batch instead, for comparison).
+LAUNCH_PER_BATCH = os.environ.get('DEEPBINNER_LAUNCH_PER_BATCH') == '1'
+# HIP event brackets on the launch stream: every launch when there is one per step; with a launch
+# per batch, one bracket at every 20th launch covering 4 consecutive (full) launches - a pair
+# around EVERY short launch costs ~7 us of queue time per batch and slows what it measures, a pair
+# around a single one includes ~2.5 us of dispatch latency that back-to-back launches do not pay.
+TIMING_STRIDE, TIMING_SPAN = (20, 4) if LAUNCH_PER_BATCH else (1, 1)
 
 CONFIGS = {
     1: {'name': 'BASELINE.json configs[1]', 'models': ['EXP-NBD103_read_starts'],
@@ -348,10 +354,6 @@ def main():
     sync()
     barrier()
     sync()
-    # One HIP event pair around launches 20k .. 20k+3 of a step's launches (all full launches; a
-    # pair around EVERY launch costs ~7 us of queue time per batch and slows what it measures, a
-    # pair around a single launch includes ~2.5 us of dispatch latency that back-to-back launches
-    # do not pay - rocprofv3's per-kernel duration is that much shorter).
     if lead.timing_model is not None:
         lead.timing_model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
     t0 = time.perf_counter()
@@ -380,7 +382,9 @@ def main():
         'config': {
             'workload': '{}: {} model{}, {} synthetic 1024-sample int16 signals {} per step, batch '
                         '{}, seam b2 (slice + normalise + CNN + renormalise + call fused in one '
-                        'launch per batch{}), scan_size {} => 1 window per read and model, inputs '
+                        'kernel, ' + ('one launch per batch' if LAUNCH_PER_BATCH else
+                                      'the batches of a step walked by ONE persistent launch per '
+                                      'model') + '{}), scan_size {} => 1 window per read and model, inputs '
                         'resident in HBM, uniform read length declared '
                         '(dbh_model_set_read_length_hint), gathered calls copied to pinned host '
                         'memory every step'.format(
@@ -389,7 +393,9 @@ def main():
                             cfg['batch'],
                             ', combine_calls on the device' if n_models > 1 else '', SCAN_SIZE),
             'reads_per_step': reads_per_step, 'reads_per_step_per_gpu': shard_sizes,
-            'batch': cfg['batch'], 'windows_per_read': n_models, 'launches_per_batch': n_models,
+            'batch': cfg['batch'], 'windows_per_read': n_models,
+            'forward_launches_per_step': (n_models * -(-max(shard_sizes) // cfg['batch'])
+                                          if LAUNCH_PER_BATCH else n_models),
             'real_read_windows_in_first_10000': int(len(real_windows(1000))),
             'parallelism': ('reads sharded over {} GPUs, {}, all-gather of int32 calls over {}'
                             .format(world, 'one process per GPU' if per_rank

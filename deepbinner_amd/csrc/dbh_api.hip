@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -146,6 +147,8 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
 struct dbh_model {
     int n_classes = 0;
     int device = 0;
+    int cus = 256;               // workgroups of a persistent forward launch (one per CU)
+    bool launch_per_batch = false;   // DEEPBINNER_LAUNCH_PER_BATCH=1: one launch per batch (A/B)
     float* d_packed = nullptr;
     // workspace for the host-pointer entry points, grown on demand
     void* d_in = nullptr;      size_t in_bytes = 0;
@@ -241,19 +244,34 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
                 }
             }
         }
-        hipLaunchKernelGGL(debug_stage == 300 ? dbh_timeline::dbh_forward_kernel
-                                              : dbh::dbh_forward_kernel,
-                           dim3((unsigned)cnt), dim3(dbh::kThreads), 0, stream, m->d_packed, x_dev ? x_dev + off * dbh::kWindow : nullptr,
-                           probs_dev ? probs_dev + off * m->n_classes : nullptr, m->n_classes,
-                           debug_stage,
-                           debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 || debug_stage > 7 ? 0 : debug_stage]
-                                     : nullptr,
-                           in.samples,
-                           in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr,
-                           in.steps, in.side, in.score_diff,
-                           in.calls ? (int*)(in.calls + off / in.steps) : nullptr,
-                           (long long)(in.read0 + off / in.steps), (long long)in.len_hint,
-                           (long long)in.hint_cap);
+        // production launches are persistent: at most one workgroup per CU, each walking its
+        // share of the windows; the debug / timeline modes keep one workgroup per window
+        const bool one_per_window = debug_stage >= 0;
+        const unsigned grid = (unsigned)(one_per_window || cnt < m->cus ? cnt : m->cus);
+        dbh::ForwardArgs a;
+        a.packed = m->d_packed;
+        a.x = x_dev ? x_dev + off * dbh::kWindow : nullptr;
+        a.probs = probs_dev ? probs_dev + off * m->n_classes : nullptr;
+        a.debug_out = debug_dev ? debug_dev + off * dbh::kStageFloats[debug_stage < 0 || debug_stage > 7 ? 0 : debug_stage]
+                                : nullptr;
+        a.samples = in.samples;
+        a.offsets = in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr;
+        a.calls = in.calls ? (int*)(in.calls + off / in.steps) : nullptr;
+        a.score_diff = in.score_diff;
+        a.read0 = (long long)(in.read0 + off / in.steps);
+        a.len_hint = (long long)in.len_hint;
+        a.hint_cap = (long long)in.hint_cap;
+        a.n_windows = (long long)cnt;
+        a.n_classes = m->n_classes;
+        a.debug_stage = debug_stage;
+        a.steps = in.steps;
+        a.side = in.side;
+        if (debug_stage == 300)
+            hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads),
+                               0, stream, reinterpret_cast<dbh_timeline::ForwardArgs&>(a));
+        else
+            hipLaunchKernelGGL(dbh::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads), 0, stream,
+                               a);
         DBH_HIP(hipGetLastError());
         if (ev_stop) {
             DBH_HIP(hipEventRecord(ev_stop, stream));
@@ -413,6 +431,15 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
     if (!m) return DBH_ERR_OUT_OF_MEMORY;
     m->n_classes = n_classes;
     hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) {
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+        if (e == hipSuccess && cus > 0) m->cus = cus;
+    }
+    {
+        const char* knob = std::getenv("DEEPBINNER_LAUNCH_PER_BATCH");
+        m->launch_per_batch = knob && knob[0] == '1';
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy(m->d_packed, packed.data(), packed.size() * sizeof(float),
@@ -561,8 +588,10 @@ int dbh_classify_workspace_bytes(const dbh_model* m, int64_t n_reads, int scan_s
     if (!m || !bytes || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
     const int steps = steps_for(scan_size);
     if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size) return DBH_ERR_INVALID_ARGUMENT;
+    // the per-window probabilities the merge kernel reads; one scan step needs nothing (the
+    // forward kernel finishes the read itself), and the windows themselves never leave LDS
     const size_t windows = (size_t)n_reads * steps;
-    *bytes = windows * dbh::kWindow * sizeof(float) + windows * m->n_classes * sizeof(float) + 256;
+    *bytes = steps == 1 ? 0 : windows * m->n_classes * sizeof(float) + 256;
     return DBH_OK;
 }
 
@@ -631,15 +660,26 @@ int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
                                  int32_t* calls_dev, dbh_stream stream) {
     if (!m || n_reads < 0 || batch_size <= 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
+    // The reference walks its reads batch by batch because model.predict does (classify.py:130,
+    // 361); a read's result does not depend on its batch.  Here the forward kernel is
+    // persistent - one workgroup per CU walking windows in read order - so the batches flow
+    // through ONE launch without a boundary between them (DEEPBINNER_LAUNCH_PER_BATCH=1 brings
+    // the launch per batch back, for comparison).  Reads with several scan steps go in chunks
+    // whose per-window probabilities fit a bounded workspace, one merge launch per chunk.
+    const int steps = steps_for(scan_size);
+    if (steps <= 0) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t chunk = m->launch_per_batch ? (int64_t)batch_size
+                                              : (steps == 1 ? n_reads : ((int64_t)1 << 20) / steps);
     size_t work = 0;
-    int st = dbh_classify_workspace_bytes(m, batch_size, scan_size, &work);
+    int st = dbh_classify_workspace_bytes(m, chunk < n_reads ? chunk : n_reads, scan_size, &work);
     if (st != DBH_OK) return st;
-    st = ensure(&m->d_work, &m->work_bytes, work);
-    if (st != DBH_OK) return st;
-    // in-order on the caller's stream: each batch is one launch (scan_size 512) or two, so the
-    // CNN launches run back to back and the workspace can be reused batch after batch
-    for (int64_t r0 = 0; r0 < n_reads; r0 += batch_size) {
-        const int64_t cnt = (n_reads - r0 < batch_size) ? (n_reads - r0) : batch_size;
+    if (work) {
+        st = ensure(&m->d_work, &m->work_bytes, work);
+        if (st != DBH_OK) return st;
+    }
+    // in-order on the caller's stream, so the workspace can be reused chunk after chunk
+    for (int64_t r0 = 0; r0 < n_reads; r0 += chunk) {
+        const int64_t cnt = (n_reads - r0 < chunk) ? (n_reads - r0) : chunk;
         st = classify_i16_dev(m, samples_dev, offsets_dev + r0, cnt, side, scan_size, score_diff,
                               probs_dev + r0 * m->n_classes, calls_dev + r0, m->d_work, stream, r0,
                               m->hint_len, m->hint_cap);
@@ -678,16 +718,26 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         pending[k].live = false;
         return DBH_OK;
     };
+    // an error in the middle of the loop must not leave the other slot's copies in flight: its
+    // pinned buffers belong to the next call
+    auto fail = [&](int status) -> int {
+        for (auto& sl : m->slot)
+            if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        return status;
+    };
     int64_t g = 0;
     for (int64_t r0 = 0; r0 < n_reads; r0 += group, ++g) {
         const int k = (int)(g & 1);
         dbh_model::Slot& sl = m->slot[k];
         int st = drain(k);
-        if (st != DBH_OK) return st;
-        if (!sl.stream) DBH_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        if (st != DBH_OK) return fail(st);
+        if (!sl.stream) {
+            hipError_t e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreateWithFlags"));
+        }
         const int64_t cnt = (n_reads - r0 < group) ? (n_reads - r0) : group;
         const int64_t s0 = offsets_host[r0], s1 = offsets_host[r0 + cnt];
-        if (s1 < s0) return DBH_ERR_INVALID_ARGUMENT;
+        if (s1 < s0) return fail(DBH_ERR_INVALID_ARGUMENT);
         const size_t sample_bytes = ((size_t)(s1 - s0) * sizeof(int16_t) + 255) & ~(size_t)255;
         const size_t off_bytes = (size_t)(cnt + 1) * sizeof(int64_t);
         const size_t in_bytes = sample_bytes + off_bytes;
@@ -698,11 +748,11 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         if (st == DBH_OK) st = ensure_host(&sl.h_out, &sl.h_out_bytes, out_bytes);
         if (st == DBH_OK) st = ensure(&sl.d_in, &sl.d_in_bytes, in_bytes);
         if (st == DBH_OK) st = ensure(&sl.d_out, &sl.d_out_bytes, out_bytes);
-        if (st == DBH_OK) st = ensure(&sl.d_work, &sl.d_work_bytes, work);
-        if (st != DBH_OK) return st;
+        if (st == DBH_OK && work) st = ensure(&sl.d_work, &sl.d_work_bytes, work);
+        if (st != DBH_OK) return fail(st);
 
         if (s1 > s0) {
-            if (!samples_host) return DBH_ERR_INVALID_ARGUMENT;
+            if (!samples_host) return fail(DBH_ERR_INVALID_ARGUMENT);
             std::memcpy(sl.h_in, samples_host + s0, (size_t)(s1 - s0) * sizeof(int16_t));
         }
         int64_t* rel = (int64_t*)((char*)sl.h_in + sample_bytes);
@@ -711,22 +761,29 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         int64_t uniform = rel[1];
         for (int64_t i = 1; i <= cnt && uniform > 0; ++i)
             if (rel[i] != i * uniform) uniform = 0;
-        DBH_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, sl.stream));
+        {
+            hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, sl.stream);
+            if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync H2D"));
+        }
         float* d_probs = (float*)sl.d_out;
         int32_t* d_calls = (int32_t*)((char*)sl.d_out + (size_t)cnt * C * sizeof(float));
         st = classify_i16_dev(m, (const int16_t*)sl.d_in,
                               (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side, scan_size,
                               score_diff, d_probs, d_calls, sl.d_work, (dbh_stream)sl.stream, 0,
                               uniform, s1 - s0);
-        if (st != DBH_OK) return st;
-        DBH_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream));
+        if (st != DBH_OK) return fail(st);
+        {
+            hipError_t e = hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream);
+            if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync D2H"));
+        }
         pending[k].r0 = r0;
         pending[k].cnt = cnt;
         pending[k].live = true;
     }
     int st = drain(0);
-    if (st != DBH_OK) return st;
-    return drain(1);
+    if (st != DBH_OK) return fail(st);
+    st = drain(1);
+    return st == DBH_OK ? st : fail(st);
 }
 
 int dbh_stage_floats(int stage, int64_t* floats_per_window) {
@@ -790,9 +847,19 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
     DBH_HIP(hipMemcpyAsync(m->d_in, x_host, (size_t)n * dbh::kWindow * sizeof(float),
                            hipMemcpyHostToDevice, 0));
     DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
-    hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0,
-                       0, m->d_packed, (const float*)m->d_in, (float*)m->d_out, m->n_classes, 300,
-                       (float*)m->d_work, nullptr, nullptr, 1, 0, 0.0, nullptr, 0LL, 0LL, 0LL);
+    {
+        dbh_timeline::ForwardArgs a = {};
+        a.packed = m->d_packed;
+        a.x = (const float*)m->d_in;
+        a.probs = (float*)m->d_out;
+        a.debug_out = (float*)m->d_work;
+        a.n_windows = (long long)n;
+        a.n_classes = m->n_classes;
+        a.debug_stage = 300;
+        a.steps = 1;
+        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
+                           dim3(dbh::kThreads), 0, 0, a);
+    }
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
     DBH_HIP(hipStreamSynchronize(0));
@@ -818,11 +885,24 @@ int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t 
     DBH_HIP(hipMemcpyAsync(d_offsets, offsets.data(), offset_bytes, hipMemcpyHostToDevice, 0));
     DBH_HIP(hipMemsetAsync(m->d_work, 0, stamp_bytes, 0));
     DBH_HIP(hipStreamSynchronize(0));
-    hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n), dim3(dbh::kThreads), 0,
-                       0, m->d_packed, nullptr, (float*)m->d_out, m->n_classes, 300,
-                       (float*)m->d_work, (const int16_t*)m->d_in, (const long long*)d_offsets, 1,
-                       0, 0.5, (int*)((float*)m->d_out + n * m->n_classes), 0LL,
-                       (long long)m->hint_len, (long long)m->hint_cap);
+    {
+        dbh_timeline::ForwardArgs a = {};
+        a.packed = m->d_packed;
+        a.probs = (float*)m->d_out;
+        a.debug_out = (float*)m->d_work;
+        a.samples = (const int16_t*)m->d_in;
+        a.offsets = (const long long*)d_offsets;
+        a.calls = (int*)((float*)m->d_out + n * m->n_classes);
+        a.score_diff = 0.5;
+        a.len_hint = (long long)m->hint_len;
+        a.hint_cap = (long long)m->hint_cap;
+        a.n_windows = (long long)n;
+        a.n_classes = m->n_classes;
+        a.debug_stage = 300;
+        a.steps = 1;
+        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
+                           dim3(dbh::kThreads), 0, 0, a);
+    }
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
     DBH_HIP(hipStreamSynchronize(0));

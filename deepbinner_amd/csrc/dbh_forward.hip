@@ -1422,8 +1422,45 @@ __device__ __forceinline__ void mean_std(long long s1, long long s2, int cnt, do
     }
 }
 
+// Arguments of the forward kernel (one by-value struct = the kernel-argument segment).
+struct ForwardArgs {
+    const float* packed;         // packed parameters (dbh_layout.h)
+    const float* x;              // seam b1: [n_windows][1024] normalised windows, or null
+    float* probs;                // [n_windows][n_classes]
+    float* debug_out;
+    const int16_t* samples;      // seam b2: int16 signals, or null
+    const long long* offsets;    //          read r = samples[offsets[r] .. offsets[r+1])
+    int* calls;                  //          barcode calls (one scan step per read), or null
+    double score_diff;
+    long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
+    long long n_windows;
+    int n_classes, debug_stage, steps, side;
+};
+
+// Seam-b2 input of one window, straight from the read's int16 samples: this lane's two samples
+// for the window statistics (positions tid and tid + 512 of the slice) and its four A-fragment
+// samples for conv1d_1 (position 2*(16*(m0+m)+n) + q of the zero-padded window; q = tap).
+__device__ __forceinline__ void fetch_window(const int16_t* __restrict__ samples, long long base,
+                                             long long len, int step, int side, int tid, int m0,
+                                             int n, int q, int& cnt, int& v0, int& v1,
+                                             int (&raw)[4], bool (&inside)[4]) {
+    long long wa, wb;
+    window_bounds(len, step, side, &wa, &wb);
+    cnt = (int)(wb - wa);
+    const int16_t* src = samples + base + wa;
+    const int pad_left = (side == 0) ? 0 : kWindow - cnt;
+    v0 = tid < cnt ? (int)src[tid] : 0;
+    v1 = tid + 512 < cnt ? (int)src[tid + 512] : 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
+        inside[m] = q < 3 && k >= 0 && k < cnt;
+        raw[m] = inside[m] ? (int)src[k] : 0;
+    }
+}
+
 // =============================================================================================
-// The kernel.  grid = n_windows, block = 512.
+// The kernel.  grid <= n_windows (persistent: a workgroup walks windows b, b + grid, ...), block = 512.
 //   x      [n_windows][1024]   normalised windows (fp32)
 //   probs  [n_windows][n_classes]
 //   debug_stage in [0,7]: write the activations after stage 'A'+debug_stage to debug_out and
@@ -1432,25 +1469,65 @@ __device__ __forceinline__ void mean_std(long long s1, long long s2, int cnt, do
 //   Fused seam-b2 mode (samples != nullptr): window w = (read w / steps, scan step w % steps) is
 //   sliced and z-normalised from the int16 signal inside stage A, and when calls != nullptr
 //   (steps == 1) the read is finished here too: renormalise + barcode call, no merge kernel.
-__global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
-    const float* __restrict__ packed, const float* __restrict__ x, float* __restrict__ probs,
-    int n_classes, int debug_stage, float* __restrict__ debug_out,
-    const int16_t* __restrict__ samples, const long long* __restrict__ offsets, int steps,
-    int side, double score_diff, int* __restrict__ calls, long long read0, long long len_hint,
-    long long hint_cap) {
+__global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by_value) {
+    (void)by_value;
+    // The arguments are read from the kernel-argument segment where they are used, through a
+    // pointer made opaque each time: held in SGPRs across the persistent loop they (33 registers)
+    // pushed the loop body into spilling scalars to vector lanes.
+    typedef const __attribute__((address_space(4))) ForwardArgs* ArgsPtr;
+    auto args = []() -> ArgsPtr {
+        ArgsPtr p = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+    const float* __restrict__ packed_entry = args()->packed;
+    const int debug_stage = args()->debug_stage;
+    const long long n_windows = args()->n_windows;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
-    const int tid = threadIdx.x;
+    const int tid_entry = threadIdx.x;
+    // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
+    const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
+
+    // The LDS copy of the later layers' epilogue parameters: once per workgroup (published by
+    // the first window's stage-A barrier; nothing below ever writes lds[kParams..]).
+    {
+        constexpr int kParamRounds = (kParamFloats + kThreads - 1) / kThreads;
+#pragma unroll
+        for (int i = 0; i < kParamRounds; ++i)
+            if (tid_entry + i * kThreads < kParamFloats)
+                lds[kParams + tid_entry + i * kThreads] =
+                    packed_entry[kWeightFloats + tid_entry + i * kThreads];
+    }
+
+    // Seam-b2 input of the window in hand: this lane's two samples for the statistics, its
+    // A-fragment samples for conv1d_1 and which of those lie inside the window.  Filled by
+    // fetch(): for a workgroup's first window at the top of stage A, for every later one at the
+    // top of stage E of the window before it (see there), so that only the first fetch of a
+    // launch is exposed.
+    constexpr int kMtA = 512 / 16 / kWaves;
+    int in_cnt = 0, in_v0 = 0, in_v1 = 0, in_raw[kMtA] = {};
+    bool in_inside[kMtA] = {};
+    bool prefetched = false;
+
+    // PERSISTENT GRID: the launch has at most one workgroup per CU (what 160 KiB of LDS allows
+    // anyway) and workgroup b walks windows b, b + gridDim.x, ... - no launch per batch, no cold
+    // start per window.
+    for (long win = blockIdx.x; win < n_windows; win += gridDim.x) {
+    // The thread index and the parameter pointer are made opaque once per round: otherwise the
+    // loop-invariant-code pass hoists every lane address and constant of the (fully unrolled)
+    // body out of the loop and keeps them alive across it - 245 spilled VGPRs instead of none.
+    int tid = tid_entry;
+    asm volatile("" : "+v"(tid));
+    const float* __restrict__ packed = packed_entry;
+    asm volatile("" : "+s"(packed));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
-    const long win = blockIdx.x;
-    // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
-    const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
     long long* ts = nullptr;
     if (debug_stage == 300 && lane == 0)
-        ts = reinterpret_cast<long long*>(debug_out) + (win * kWaves + wave) * 64;
+        ts = reinterpret_cast<long long*>(args()->debug_out) + (win * kWaves + wave) * 64;
     mark(ts, 0);
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
@@ -1468,6 +1545,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         // retires every outstanding request of the wave, and waiting there for 36 KB of weights
         // (~3.5k cycles at the cold start of a launch) would hold up the normalisation for
         // nothing; issued behind it, they arrive under the normalisation, conv1 and its epilogue.
+        const int16_t* __restrict__ samples = args()->samples;
         if (samples == nullptr) fetch_conv2_weights();
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
@@ -1476,18 +1554,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         EpiParams<3, true> ep;
         ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
                 packed + bn_shift_offset(0) + n);
-        // the LDS copy of the later layers' epilogue parameters (published by this stage's barrier)
-        constexpr int kParamRounds = (kParamFloats + kThreads - 1) / kThreads;
-        float pv[kParamRounds];
-#pragma unroll
-        for (int i = 0; i < kParamRounds; ++i)
-            pv[i] = (tid + i * kThreads < kParamFloats) ? packed[kWeightFloats + tid + i * kThreads]
-                                                        : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
             bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
         if (samples == nullptr) {
-            const float* xw = x + win * kWindow;
+            // a later window of this workgroup: the window before it may still be read (stage H)
+            if (win != (long)blockIdx.x) __syncthreads();
+            const float* xw = args()->x + win * kWindow;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
@@ -1495,36 +1568,29 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             }
         } else {
             // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
-            const long long read = win / steps;
-            const int step = (int)(win - read * steps);
-            int cnt, v0, v1, raw[MT];
-            bool inside[MT];
-            // this lane's two samples for the statistics and its A-fragment samples, together
-            auto fetch = [&](long long base, long long len) {
-                long long wa, wb;
-                window_bounds(len, step, side, &wa, &wb);
-                cnt = (int)(wb - wa);
-                const int16_t* src = samples + base + wa;
-                const int pad_left = (side == 0) ? 0 : kWindow - cnt;
-                v0 = tid < cnt ? (int)src[tid] : 0;
-                v1 = tid + kThreads < cnt ? (int)src[tid + kThreads] : 0;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
-                    inside[m] = q < 3 && k >= 0 && k < cnt;
-                    raw[m] = inside[m] ? (int)src[k] : 0;
-                }
-            };
-            // Where a read starts is itself in memory (offsets[read]), and at the top of a kernel
-            // a dependent load costs ~3k cycles.  If the caller says that all reads are len_hint
-            // samples long, the samples are requested from where that puts them TOGETHER with the
-            // offsets, and fetched again only if the offsets disagree.
-            const long long guess = (read0 + read) * len_hint;
-            const bool speculate = len_hint > 0 && guess + len_hint <= hint_cap;
-            if (speculate) fetch(guess, len_hint);
-            const long long base = offsets[read];
-            const long long len = offsets[read + 1] - base;
-            if (!speculate || base != guess || len != len_hint) fetch(base, len);
+            if (!prefetched) {
+                ArgsPtr a = args();
+                const int steps = a->steps, side = a->side;
+                const long long read0 = a->read0, len_hint = a->len_hint, hint_cap = a->hint_cap;
+                const long long* __restrict__ offsets = a->offsets;
+                const long long read = win / steps;
+                const int step = (int)(win - read * steps);
+                // Where a read starts is itself in memory (offsets[read]), and at the top of a
+                // kernel a dependent load costs ~3k cycles.  If the caller says that all reads are
+                // len_hint samples long, the samples are requested from where that puts them
+                // TOGETHER with the offsets, and fetched again only if the offsets disagree.
+                const long long guess = (read0 + read) * len_hint;
+                const bool speculate = len_hint > 0 && guess + len_hint <= hint_cap;
+                if (speculate)
+                    fetch_window(samples, guess, len_hint, step, side, tid, m0, n, q, in_cnt,
+                                 in_v0, in_v1, in_raw, in_inside);
+                const long long base = offsets[read];
+                const long long len = offsets[read + 1] - base;
+                if (!speculate || base != guess || len != len_hint)
+                    fetch_window(samples, base, len, step, side, tid, m0, n, q, in_cnt, in_v0,
+                                 in_v1, in_raw, in_inside);
+            }
+            const int cnt = in_cnt, v0 = in_v0, v1 = in_v1;
             // exact integer sums: sum(x) and sum(x^2) split in 16-bit halves so that every
             // wave-wide partial stays below 2^31
             const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
@@ -1553,7 +1619,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             mean_std(s1, s2, cnt, &mean, &inv);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                a[m] = inside[m] ? (float)(((double)raw[m] - mean) * inv) : 0.f;
+                a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
         }
         f4 acc[MT][3];
 #pragma unroll
@@ -1567,16 +1633,24 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         mark(ts, 60);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
-#pragma unroll
-        for (int i = 0; i < kParamRounds; ++i)
-            if (tid + i * kThreads < kParamFloats) lds[kParams + tid + i * kThreads] = pv[i];
         __syncthreads();
         mark(ts, 1);
     }
     if (stop_stage == 0) {
         if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 512, 48, debug_out + win * kStageFloats[0], tid);
+            dump_stage(lds + kActOff, kS48, 512, 48, args()->debug_out + win * kStageFloats[0], tid);
         return;
+    }
+    // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
+    const long next_win = win + gridDim.x;
+    const bool has_next = args()->samples != nullptr && next_win < n_windows;
+    long long next_base = 0, next_len = 0;
+    if (has_next) {
+        ArgsPtr a = args();
+        const long long* __restrict__ offsets = a->offsets;
+        const long long next_read = next_win / a->steps;
+        next_base = offsets[next_read];
+        next_len = offsets[next_read + 1] - next_base;
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
@@ -1603,7 +1677,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                           });
     if (stop_stage == 1) {
         if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 256, 48, debug_out + win * kStageFloats[1], tid);
+            dump_stage(lds + kActOff, kS48, 256, 48, args()->debug_out + win * kStageFloats[1], tid);
         return;
     }
 
@@ -1622,7 +1696,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         [] {});
     if (stop_stage == 2) {
         if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 128, 48, debug_out + win * kStageFloats[2], tid);
+            dump_stage(lds + kActOff, kS48, 128, 48, args()->debug_out + win * kStageFloats[2], tid);
         return;
     }
 
@@ -1651,12 +1725,21 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         });
     if (stop_stage == 3) {
         if (debug_stage < 100)
-            dump_stage(lds + kEX, kS48, 64, 48, debug_out + win * kStageFloats[3], tid);
+            dump_stage(lds + kEX, kS48, 64, 48, args()->debug_out + win * kStageFloats[3], tid);
         return;
     }
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
     {
+        // The next window's samples start their trip from HBM now (stages E-H, ~25k cycles, are
+        // far more than it takes) and are used at the top of the next round's stage A; the
+        // registers they land in were last read in this window's stage A.
+        prefetched = has_next;
+        if (has_next) {
+            ArgsPtr a = args();
+            fetch_window(a->samples, next_base, next_len, (int)(next_win % a->steps), a->side, tid,
+                         wave * kMtA, n, q, in_cnt, in_v0, in_v1, in_raw, in_inside);
+        }
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
         // 384 threads, each one channel and eight consecutive positions: ten row reads for eight
@@ -1752,7 +1835,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     }
     if (stop_stage == 4) {
         if (debug_stage < 100)
-            dump_stage(lds + kECat, kS192, 32, 192, debug_out + win * kStageFloats[4], tid);
+            dump_stage(lds + kECat, kS192, 32, 192, args()->debug_out + win * kStageFloats[4], tid);
         return;
     }
 
@@ -1768,7 +1851,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
                                                    ts, 41);
     if (stop_stage == 5) {
         if (debug_stage < 100)
-            dump_stage(lds + kFOut, kS48, 16, 48, debug_out + win * kStageFloats[5], tid);
+            dump_stage(lds + kFOut, kS48, 16, 48, args()->debug_out + win * kStageFloats[5], tid);
         return;
     }
 
@@ -1789,7 +1872,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
     striped_layer<18, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave, ts, 49);
     if (stop_stage == 6) {
         if (debug_stage < 100)
-            dump_stage(lds + kG2, kS48, 8, 48, debug_out + win * kStageFloats[6], tid);
+            dump_stage(lds + kG2, kS48, 8, 48, args()->debug_out + win * kStageFloats[6], tid);
         return;
     }
 
@@ -1817,6 +1900,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         rows_i32(__builtin_bit_cast(int, s), &even, &odd);
         return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) * 0.125f;
     };
+    const int n_classes = args()->n_classes;
     if (n_classes <= 16) {
         // every class is in N tile 0: wave 0 goes from the MFMAs to the call without leaving its
         // registers - no logits in LDS, no barrier, classes in lanes 0..15
@@ -1828,13 +1912,16 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
             const float e = valid ? expf(v - mx) : 0.f;
             const float sum = lane_value(row16_sum(e), 0);
             if (debug_stage == 7) {
-                if (lane < 32) debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+                if (lane < 32) args()->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
                 return;
             }
             const float p = e / sum;
+            ArgsPtr a = args();
+            float* __restrict__ probs = a->probs;
+            int* __restrict__ calls = a->calls;
             if (calls != nullptr) {
                 if (lane < 32)
-                    renormalise_and_call(valid ? p : 0.f, lane, n_classes, score_diff,
+                    renormalise_and_call(valid ? p : 0.f, lane, n_classes, a->score_diff,
                                          probs + win * n_classes, calls + win);
             } else if (valid) {
                 probs[win * n_classes + lane] = p;
@@ -1843,7 +1930,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         mark(ts, 53);
         mark(ts, 54);
         mark(ts, 55);
-        return;
+        continue;
     }
     if (wave < 2) {
         const float logit = conv20_logit();
@@ -1862,20 +1949,24 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(
         const float rsum = row16_sum(e);
         const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
         if (debug_stage == 7) {
-            if (lane < 32) debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+            if (lane < 32) args()->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
             return;
         }
         const float p = e / sum;
+        ArgsPtr a = args();
+        float* __restrict__ probs = a->probs;
+        int* __restrict__ calls = a->calls;
         if (calls != nullptr) {
             // single scan step: this window IS the read (classify.py:368-382 with one range)
             if (lane < 32)
-                renormalise_and_call(valid ? p : 0.f, lane, n_classes, score_diff,
+                renormalise_and_call(valid ? p : 0.f, lane, n_classes, a->score_diff,
                                      probs + win * n_classes, calls + win);
         } else if (valid) {
             probs[win * n_classes + lane] = p;
         }
     }
     mark(ts, 55);
+    }   // persistent loop over this workgroup's windows
 }
 
 // =============================================================================================
