@@ -154,6 +154,9 @@ struct dbh_model {
     void* d_in = nullptr;      size_t in_bytes = 0;
     void* d_work = nullptr;    size_t work_bytes = 0;
     void* d_out = nullptr;     size_t out_bytes = 0;
+    // conv17 outputs parked per workgroup until the batched tail runs (dbh_forward.hip); one
+    // buffer per stream a model launches on: this one for the caller's stream, one per staging slot
+    void* d_tail = nullptr;    size_t tail_bytes = 0;
     // double-buffered host <-> device staging of dbh_classify_i16 (overlapped H2D / D2H)
     struct Slot {
         hipStream_t stream = nullptr;
@@ -162,6 +165,7 @@ struct dbh_model {
         void* d_in = nullptr;   size_t d_in_bytes = 0;
         void* d_out = nullptr;  size_t d_out_bytes = 0;
         void* d_work = nullptr; size_t d_work_bytes = 0;
+        void* d_tail = nullptr; size_t d_tail_bytes = 0;
     } slot[2];
     // live timing of the forward kernel (dbh_forward_timing_*)
     int64_t hint_len = 0, hint_cap = 0;   // dbh_model_set_read_length_hint
@@ -200,6 +204,9 @@ struct FusedInput {          // seam-b2 mode of the forward kernel (all null/zer
     // "every read is len_hint samples long": offsets[0] belongs to read number read0 of the
     // sample buffer, which holds at least hint_cap samples (see dbh_model_set_read_length_hint)
     int64_t read0 = 0, len_hint = 0, hint_cap = 0;
+    // where this launch parks its conv17 outputs (null = the model's own buffer)
+    void** tail = nullptr;
+    size_t* tail_bytes = nullptr;
 };
 
 int ensure_host(void** ptr, size_t* have, size_t need) {
@@ -246,8 +253,15 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         }
         // production launches are persistent: at most one workgroup per CU, each walking its
         // share of the windows; the debug / timeline modes keep one workgroup per window
-        const bool one_per_window = debug_stage >= 0;
+        const bool one_per_window = debug_stage >= 0 && debug_stage != 301;
         const unsigned grid = (unsigned)(one_per_window || cnt < m->cus ? cnt : m->cus);
+        void** tail = in.tail ? in.tail : &m->d_tail;
+        size_t* tail_bytes = in.tail_bytes ? in.tail_bytes : &m->tail_bytes;
+        {
+            const int st = ensure(tail, tail_bytes, (size_t)grid * dbh::kTailBatch *
+                                                        dbh::kTailSlotFloats * sizeof(float));
+            if (st != DBH_OK) return st;
+        }
         dbh::ForwardArgs a;
         a.packed = m->d_packed;
         a.x = x_dev ? x_dev + off * dbh::kWindow : nullptr;
@@ -257,6 +271,7 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.samples = in.samples;
         a.offsets = in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr;
         a.calls = in.calls ? (int*)(in.calls + off / in.steps) : nullptr;
+        a.tail_scratch = (float*)*tail;
         a.score_diff = in.score_diff;
         a.read0 = (long long)(in.read0 + off / in.steps);
         a.len_hint = (long long)in.len_hint;
@@ -459,6 +474,7 @@ int dbh_model_destroy(dbh_model* m) {
     if (m->d_in) (void)hipFree(m->d_in);
     if (m->d_work) (void)hipFree(m->d_work);
     if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_tail) (void)hipFree(m->d_tail);
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -470,6 +486,7 @@ int dbh_model_destroy(dbh_model* m) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.d_work) (void)hipFree(sl.d_work);
+        if (sl.d_tail) (void)hipFree(sl.d_tail);
     }
     delete m;
     return DBH_OK;
@@ -601,7 +618,8 @@ namespace {
 int classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* offsets_dev,
                      int64_t n_reads, int side, int scan_size, double score_diff,
                      float* probs_dev, int32_t* calls_dev, void* workspace_dev, dbh_stream stream,
-                     int64_t read0, int64_t len_hint, int64_t hint_cap) {
+                     int64_t read0, int64_t len_hint, int64_t hint_cap, void** tail = nullptr,
+                     size_t* tail_bytes = nullptr) {
     if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
     const int steps = steps_for(scan_size);
@@ -618,6 +636,8 @@ int classify_i16_dev(dbh_model* m, const int16_t* samples_dev, const int64_t* of
     in.read0 = read0;
     in.len_hint = len_hint;
     in.hint_cap = hint_cap;
+    in.tail = tail;
+    in.tail_bytes = tail_bytes;
     if (steps == 1) {
         // one window per read: slice + normalise + CNN + renormalise + call in ONE launch
         in.calls = calls_dev;
@@ -770,7 +790,7 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         st = classify_i16_dev(m, (const int16_t*)sl.d_in,
                               (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side, scan_size,
                               score_diff, d_probs, d_calls, sl.d_work, (dbh_stream)sl.stream, 0,
-                              uniform, s1 - s0);
+                              uniform, s1 - s0, &sl.d_tail, &sl.d_tail_bytes);
         if (st != DBH_OK) return fail(st);
         {
             hipError_t e = hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream);
@@ -857,6 +877,10 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
         a.n_classes = m->n_classes;
         a.debug_stage = 300;
         a.steps = 1;
+        st = ensure(&m->d_tail, &m->tail_bytes,
+                    (size_t)n * dbh::kTailBatch * dbh::kTailSlotFloats * sizeof(float));
+        if (st != DBH_OK) return st;
+        a.tail_scratch = (float*)m->d_tail;
         hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
                            dim3(dbh::kThreads), 0, 0, a);
     }
@@ -898,10 +922,16 @@ int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t 
         a.hint_cap = (long long)m->hint_cap;
         a.n_windows = (long long)n;
         a.n_classes = m->n_classes;
-        a.debug_stage = 300;
+        // more windows than CUs: a persistent launch, as in production (stamps per window)
+        a.debug_stage = n > m->cus ? 301 : 300;
         a.steps = 1;
-        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
-                           dim3(dbh::kThreads), 0, 0, a);
+        st = ensure(&m->d_tail, &m->tail_bytes, (size_t)(n > m->cus ? m->cus : n) *
+                                                    dbh::kTailBatch * dbh::kTailSlotFloats *
+                                                    sizeof(float));
+        if (st != DBH_OK) return st;
+        a.tail_scratch = (float*)m->d_tail;
+        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel,
+                           dim3((unsigned)(n > m->cus ? m->cus : n)), dim3(dbh::kThreads), 0, 0, a);
     }
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));

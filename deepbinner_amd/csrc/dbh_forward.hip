@@ -286,8 +286,10 @@ struct EpiParams {
 // part of it, else in global memory.
 template <int OFF>
 __device__ __forceinline__ const float* param_ptr(const float* lds, const float* packed) {
-    if constexpr (OFF >= kWeightFloats && OFF - kWeightFloats < kParamFloats)
-        return lds + kParams + (OFF - kWeightFloats);
+    if constexpr (OFF >= kTabBias0 && OFF < kTabBias1)
+        return lds + kParams + (OFF - kTabBias0);
+    else if constexpr (OFF >= kTabBn0 && OFF < kTabBn1)
+        return lds + kParams + (kTabBias1 - kTabBias0) + (OFF - kTabBn0);
     else
         return packed + OFF;
 }
@@ -813,19 +815,56 @@ __device__ __forceinline__ void w43_phase(const float* a_lane, const float* slot
     w43_step<PHASE, 0>(a_addr, b_addr, buf, acc);
 }
 
-// dma0/1: the DMA requests issued at the top of phase 0/1 (see the call sites).
-template <int CONV, bool POOL, int BNI, class Dma0, class Dma1>
+// A workgroup-wide "everybody has passed point P" that is not a barrier: a wave ARRIVES
+// (lds_arrive: one ds_add on a counter word, after everything it asked of memory has landed) and
+// carries on with work that does not depend on the others; where it does depend on them it WAITS
+// for the counter to reach 8 x the number of rounds so far.  Unlike s_barrier, which stops every
+// wave until the last one is there, the waves keep whatever stagger they have - which is the point:
+// the two waves of a SIMD share its matrix pipe, and one wave's epilogue (VALU + LDS stores) is
+// free when it runs beside the other's MFMAs and costs its full length when both run it together
+// behind a barrier.
+__device__ __forceinline__ void lds_arrive(float* lds, int lane) {
+    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync);
+    // release: this wave's LDS reads are done and its LDS-DMA pieces have landed (vmcnt)
+    if (lane == 0)
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait(float* lds, unsigned target) {
+    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync);
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                 target) < 0)
+        __builtin_amdgcn_s_sleep(1);
+}
+
+// Stage B keeps its activations in eight REGIONS of kRegionRows = 66 rows, one per wave: row 0 a
+// copy of the row before the wave's 64 positions, rows 1..64 its own positions, row 65 a copy of
+// the row after them.  A wave's six-row input tiles (d0..d5 = region rows 4j .. 4j+5 for its
+// quad j) then lie inside its own region, only the owner reads or writes rows 1..64, and the one
+// thing that crosses waves is the two halo rows each wave copies into its neighbours' regions
+// when it stores a layer's output.  Phase 0 of a layer (V1..V4: rows d1..d4) needs no halo at all,
+// so a wave goes from its own epilogue straight into the next layer's phase 0; the layer's one
+// barrier sits between phase 0 and phase 1 (which reads d0 and d5).
+//
+// One F(4,3) layer, from its phase 0 to the point where the next layer's phase 0 can start:
+//   [acc = bias] phase 0 (slots 0+1) | BARRIER: halos of the layer before and this layer's last
+//   third (slot 2) are there, slots 0+1 are free | dma_mid() | phase 1 (slot 2) |
+//   LAST = false: arrive | output transform, own rows stored | wait: every wave is through phase 1
+//                 (my halo rows in the neighbours' regions are no longer read, slot 2 is free, the
+//                 next layer's slots 0+1 have landed) | halo rows stored | dma_tail()
+//   LAST = true : barrier | pooled output to the CONTIGUOUS rows stage C reads | barrier
+template <int CONV, bool POOL, int BNI, bool LAST, class DmaMid, class DmaTail>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
-                                          const Dma0& dma0, const Dma1& dma1) {
+                                          int ts_end, unsigned& sync_rounds,
+                                          const DmaMid& dma_mid, const DmaTail& dma_tail) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    static_assert(LAST == POOL, "the pooled layer is the one that leaves the region layout");
     constexpr int L = 512;
     static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
     constexpr int LOUT = POOL ? L / 2 : L;
     constexpr bool BN = BNI >= 0;
     const int n = lane & 15, q = lane >> 4;
 
-    dma0();
     EpiParams<3, BN> ep;
     load_epi<CONV, BNI>(ep, lds, packed, n);
     // M1 enters all four outputs with weight +1, so it is the accumulator that starts at the bias
@@ -840,29 +879,33 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // MFMA row m = 4q'+r' of the wave's tile works on quad pm(m) = 2q' + (r'&1) + 8(r'>>1), so
     // that in the epilogue the four lane groups of one store (m = 4q+r, q = 0..3) write quads
     // 2 apart = 16-bank-aligned quarters of the 64 LDS banks instead of colliding two by two.
-    // quad j = wave*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
+    // quad j' = pm(n) of this wave reads region rows 4j' .. 4j'+5
     const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
-    const float* a_lane = lds + kActOff + (wave * 64 + 4 * pm_n) * kS48 + 2 * q;
-    if (ts_base == 2) mark(ts, 58);
+    const float* a_lane = lds + kActOff + (wave * kRegionRows + 4 * pm_n) * kS48 + 2 * q;
     w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc);
-    if (ts_base == 2) mark(ts, 56);
-    __syncthreads();      // last third landed in slot 2; slots 0 and 1 free
-    if (ts_base == 2) mark(ts, 57);
-    dma1();
+    mark(ts, ts_base);
+    __syncthreads();
+    mark(ts, ts_base + 1);
+    dma_mid();
     w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc);
+    mark(ts, ts_base + 2);
+    if constexpr (!LAST) {
+        lds_arrive(lds, lane);
+    } else {
+        __syncthreads();      // every wave has finished reading the regions
+    }
 
     // Output transform + ReLU (+ pooling, BN) in registers, then the stores.  Register PAIRS
-    // (v_pk_add_f32 / v_pk_fma_f32: two rows of the tile per instruction - no MFMA is in flight,
-    // so packed fp32 runs at full rate) halve the VALU count of this VALU-bound phase; ReLU and
-    // pooling stay scalar (no packed fp32 max).
+    // (v_pk_add_f32 / v_pk_fma_f32: two rows of the tile per instruction) halve the VALU count;
+    // ReLU and pooling stay scalar (no packed fp32 max).
     constexpr int NV = POOL ? 2 : 4;
     float o[3][2][2][NV];
-    auto transform = [&] {
+    {
         const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
-    #pragma unroll
+#pragma unroll
         for (int t = 0; t < 3; ++t) {
             const float sc = ep.sc[t], sh = ep.sh[t];
-    #pragma unroll
+#pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f2 a0 = f2{acc[0][t][2 * h], acc[0][t][2 * h + 1]};
                 const f2 a1 = f2{acc[1][t][2 * h], acc[1][t][2 * h + 1]};
@@ -875,7 +918,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
                 const f2 y1 = __builtin_elementwise_fma(k2, d34, d12);
                 const f2 y2 = __builtin_elementwise_fma(k4, s34, s12);
                 const f2 y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
-    #pragma unroll
+#pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
                     float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
@@ -899,33 +942,53 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
                 }
             }
         }
-    };
-    mark(ts, ts_base);
-
-    __syncthreads();      // every wave has finished reading the old activations
-    mark(ts, ts_base + 1);
-    // (Doing this arithmetic ahead of the barrier - all waves, or only the older wave of each
-    // SIMD - was measured and does not pay: it slows the partner's last MFMAs by as much as it
-    // saves here.)
-    transform();
-
-    float* out = lds + kActOff + n;
+    }
+    if constexpr (!LAST) {
+        // own rows: quad j' = 2q + e + 8h = pm(4q + 2h + e) -> region rows 1 + 4j' .. 4 + 4j'
+        float* out = lds + kActOff + (wave * kRegionRows + 1) * kS48 + n;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int j = wave * 16 + 2 * q + e + 8 * h;      // pm(4q + 2h + e)
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * q + e + 8 * h;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) out[(1 + NV * j + i) * kS48 + t * 16] = o[t][h][e][i];
-            }
-    zero_row(lds + kActOff, 0, kS48, 48, tid);
-    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
-    mark(ts, ts_base + 2);
-
-    __syncthreads();
-    mark(ts, ts_base + 3);
+                    for (int i = 0; i < 4; ++i) out[(4 * j + i) * kS48 + t * 16] = o[t][h][e][i];
+                }
+        mark(ts, ts_base + 3);
+        sync_rounds += kWaves;
+        lds_wait(lds, sync_rounds);
+        // halo rows: my first position (quad 0, y0: lanes q = 0, h = e = 0) is the row after the
+        // positions of the wave below, my last (quad 15, y3: lanes q = 3, h = e = 1) the row before
+        // those of the wave above
+        if ((q == 0 && wave > 0) || (q == 3 && wave < kWaves - 1)) {
+            float* halo = lds + kActOff + n +
+                          (q == 0 ? (wave - 1) * kRegionRows + kRegionRows - 1
+                                  : (wave + 1) * kRegionRows) * kS48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) halo[t * 16] = q == 0 ? o[t][0][0][0] : o[t][1][1][3];
+        }
+        dma_tail();
+    } else {
+        mark(ts, ts_base + 3);
+        float* out = lds + kActOff + n;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = wave * 16 + 2 * q + e + 8 * h;      // pm(4q + 2h + e)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) out[(1 + NV * j + i) * kS48 + t * 16] = o[t][h][e][i];
+                }
+        zero_row(lds + kActOff, 0, kS48, 48, tid);
+        zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
+        __syncthreads();
+        dma_tail();
+    }
+    mark(ts, ts_end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1089,7 +1152,9 @@ struct SmallMRegs {
     }
 };
 
-template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN>
+// TO_GLOBAL: out_region is a dense [16][48] block in global memory (row 0 = position 0) instead
+// of an LDS activation buffer, and the layer ends without a barrier of its own.
+template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
                                               const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
                                               int wave, long long* ts, int ts_base) {
@@ -1144,8 +1209,13 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
             for (int ks = 1; ks < KS; ++ks)
                 sum[0][0] +=
                     *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
-            float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
-            epilogue<1, 1, kS48, POOL, BN>(sum, out_lane, regs.ep);
+            if constexpr (TO_GLOBAL) {
+                static_assert(!POOL, "");
+                epilogue<1, 1, 48, false, BN>(sum, out_region + 4 * q * 48 + t * 16 + n, regs.ep);
+            } else {
+                float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
+                epilogue<1, 1, kS48, POOL, BN>(sum, out_lane, regs.ep);
+            }
         }
     } else {
         static_assert(NTW == 1, "direct path: one N tile per wave");
@@ -1157,7 +1227,7 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         }
     }
     mark(ts, ts_base + 2);
-    __syncthreads();
+    if constexpr (!TO_GLOBAL) __syncthreads();
     mark(ts, ts_base + 3);
 }
 
@@ -1431,6 +1501,7 @@ struct ForwardArgs {
     const int16_t* samples;      // seam b2: int16 signals, or null
     const long long* offsets;    //          read r = samples[offsets[r] .. offsets[r+1])
     int* calls;                  //          barcode calls (one scan step per read), or null
+    float* tail_scratch;         // [grid][kTailBatch][16][48]: conv17 outputs parked per workgroup
     double score_diff;
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
@@ -1489,16 +1560,17 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
     const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
 
-    // The LDS copy of the later layers' epilogue parameters: once per workgroup (published by
-    // the first window's stage-A barrier; nothing below ever writes lds[kParams..]).
-    {
-        constexpr int kParamRounds = (kParamFloats + kThreads - 1) / kThreads;
-#pragma unroll
-        for (int i = 0; i < kParamRounds; ++i)
-            if (tid_entry + i * kThreads < kParamFloats)
-                lds[kParams + tid_entry + i * kThreads] =
-                    packed_entry[kWeightFloats + tid_entry + i * kThreads];
+    // The LDS copy of stage B-D's epilogue parameters (biases of conv2..9, BN2..4) and the counter
+    // of the split barrier: once per workgroup, published by the first window's first barrier;
+    // nothing below writes lds[kParams..] again.
+    for (int i = tid_entry; i < kParamFloats; i += kThreads) {
+        const int src = i < kTabBias1 - kTabBias0 ? kTabBias0 + i
+                                                  : kTabBn0 + (i - (kTabBias1 - kTabBias0));
+        lds[kParams + i] = packed_entry[src];
     }
+    if (tid_entry == 0) *reinterpret_cast<unsigned*>(lds + kSync) = 0u;
+    unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
+    int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
 
     // Seam-b2 input of the window in hand: this lane's two samples for the statistics, its
     // A-fragment samples for conv1d_1 and which of those lie inside the window.  Filled by
@@ -1526,7 +1598,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const int n = lane & 15, q = lane >> 4;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
     long long* ts = nullptr;
-    if (debug_stage == 300 && lane == 0)
+    if (debug_stage >= 300 && lane == 0)        // 301: the same in a persistent launch
         ts = reinterpret_cast<long long*>(args()->debug_out) + (win * kWaves + wave) * 64;
     mark(ts, 0);
 
@@ -1628,17 +1700,35 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             for (int t = 0; t < 3; ++t)
                 acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
         mark(ts, 59);
-        float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
+        // the wave's 64 positions are rows 1..64 of ITS region (see w43_layer), its first and
+        // last position also the halo rows 65 / 0 of the regions below / above
+        float* out_lane = lds + kActOff + (wave * kRegionRows + 1 + 4 * q) * kS48 + n;
         epilogue<MT, 3, kS48, false, true, false>(acc, out_lane, ep);
+        if ((q == 0 && wave > 0) || (q == 3 && wave < kWaves - 1)) {
+            float* halo = lds + kActOff + n +
+                          (q == 0 ? (wave - 1) * kRegionRows + kRegionRows - 1
+                                  : (wave + 1) * kRegionRows) * kS48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                // the epilogue's arithmetic once more for the two rows (conv + bias is in acc)
+                const float v = fmaxf(q == 0 ? acc[0][t].x : acc[MT - 1][t].w, 0.f);
+                halo[t * 16] = fmaf(v, ep.sc[t], ep.sh[t]);
+            }
+        }
         mark(ts, 60);
-        zero_row(lds + kActOff, 0, kS48, 48, tid);
-        zero_row(lds + kActOff, 513, kS48, 48, tid);
+        zero_row(lds + kActOff, 0, kS48, 48, tid);                            // before position 0
+        zero_row(lds + kActOff, kWaves * kRegionRows - 1, kS48, 48, tid);     // after position 511
         __syncthreads();
         mark(ts, 1);
     }
     if (stop_stage == 0) {
-        if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 512, 48, args()->debug_out + win * kStageFloats[0], tid);
+        if (debug_stage < 100) {
+            float* out = args()->debug_out + win * kStageFloats[0];
+            for (int idx = tid; idx < 512 * 48; idx += kThreads) {
+                const int r = idx / 48, c = idx - r * 48;
+                out[idx] = lds[kActOff + ((r >> 6) * kRegionRows + 1 + (r & 63)) * kS48 + c];
+            }
+        }
         return;
     }
     // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
@@ -1654,27 +1744,30 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd F(4,3) layers.  Third p of a layer always lives in slot p.  Phase 0 (xi 1..4)
-    // reads slots 0+1 while this layer's last third streams into slot 2; phase 1 (xi 0,5)
-    // reads slot 2 while the NEXT layer's first two thirds stream into slots 0+1.
+    // Winograd F(4,3) layers over the region layout (see w43_layer).  Third p of a layer always
+    // lives in slot p: phase 0 (xi 1..4) reads slots 0+1, phase 1 (xi 0,5) slot 2.  A layer's last
+    // third is requested as soon as every wave has left the phase 1 before it; the NEXT layer's
+    // first two thirds behind the layer's barrier, when every wave has left phase 0.
     auto third = [&](int conv, int p, float* dst) {
         dma_weights<kWinoHalf>(packed + weight_offset(conv) + p * kWinoHalf, dst, lane, wave);
     };
-    w43_layer<1, false, -1>(lds, packed, tid, lane, wave, ts, 2,
-                            [&] { third(1, 2, lds + kSlot2); },
-                            [&] { third(2, 0, lds + kSlot0); third(2, 1, lds + kSlot1); });
-    w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6,
-                            [&] { third(2, 2, lds + kSlot2); },
-                            [&] { third(3, 0, lds + kSlot0); third(3, 1, lds + kSlot1); });
-    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 during phase 1
-    w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10,
-                          [&] { third(3, 2, lds + kSlot2); },
-                          [&] {
-                              dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
-                                                                 lds + kW5, lane, wave);
-                              dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                 lds + kW6, lane, wave);
-                          });
+    third(1, 2, lds + kSlot2);
+    w43_layer<1, false, -1, false>(lds, packed, tid, lane, wave, ts, 2, 61, sync_rounds,
+                                   [&] { third(2, 0, lds + kSlot0); third(2, 1, lds + kSlot1); },
+                                   [&] { third(2, 2, lds + kSlot2); });
+    w43_layer<2, false, -1, false>(lds, packed, tid, lane, wave, ts, 6, 62, sync_rounds,
+                                   [&] { third(3, 0, lds + kSlot0); third(3, 1, lds + kSlot1); },
+                                   [&] { third(3, 2, lds + kSlot2); });
+    // conv4 + MaxPool + BN2 -> contiguous rows; conv5's and conv6's weights take over slot 0
+    // during phase 1
+    w43_layer<3, true, 1, true>(lds, packed, tid, lane, wave, ts, 10, 63, sync_rounds,
+                                [&] {
+                                    dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
+                                                                       lds + kW5, lane, wave);
+                                    dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                       lds + kW6, lane, wave);
+                                },
+                                [] {});
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, args()->debug_out + win * kStageFloats[1], tid);
@@ -1779,7 +1872,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         constexpr int w16 = kEW + weight_offset(15) - weight_offset(9);
         const float* sc5 = lds + kEBn5 + n;
         const float* sh5 = lds + kEBn5 + 192 + n;
-        const float* bias_tab = lds + kParams - kWeightFloats + n;     // + bias_offset(conv)
+        const float* bias_tab = packed + n;     // + bias_offset(conv): L2 (not in the LDS table)
 
         // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
         if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
@@ -1840,132 +1933,163 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48 ---------
-    zero_row(lds + kFOut, 0, kS48, 48, tid);
-    zero_row(lds + kFOut, 17, kS48, 48, tid);
-    zero_row(lds + kG1, 0, kS48, 48, tid);
-    zero_row(lds + kG1, 17, kS48, 48, tid);
-    for (int idx = tid; idx < 18 * kS48; idx += kThreads) lds[kG2 + idx] = 0.f;
-    StripedRegs<17, false> r18;
-    r18.prefetch(packed, 0, lane, wave);
-    small_m_layer<16, kS192, 2, 8, 3, false, true>(lds, lds + kECat, lds + kFOut, r17, lane, wave,
-                                                   ts, 41);
-    if (stop_stage == 5) {
-        if (debug_stage < 100)
-            dump_stage(lds + kFOut, kS48, 16, 48, args()->debug_out + win * kStageFloats[5], tid);
-        return;
+    // The last layers (conv18-20 on 16 and 8 positions, softmax, call) are too small to fill a
+    // workgroup: per window they cost ~9k cycles of barriers and LDS round trips for ~1.7k cycles
+    // of matrix work.  So conv17's output (3 KB) is parked in a global-memory slot of this
+    // workgroup and the rest runs for kTailBatch windows at a time, ONE WAVE PER WINDOW, with no
+    // cross-wave step at all (batched_tail below).
+    const bool batch_ends = tail_slot == kTailBatch - 1 || win + (long)gridDim.x >= n_windows;
+    if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
+        dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
+        dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
+        dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
     }
+    {
+        float* slot = args()->tail_scratch +
+                      ((size_t)blockIdx.x * kTailBatch + tail_slot) * kTailSlotFloats;
+        small_m_layer<16, kS192, 2, 8, 3, false, true, true>(lds, lds + kECat, slot, r17, lane,
+                                                             wave, ts, 41);
+    }
+    ++tail_slot;
+    if (!batch_ends) continue;
 
-    // ---------------- stage G: conv18, conv19 (L=16) + MaxPool + BN7 -> 8 x 48 ----------------
-    StripedRegs<18, true> r19;
-    r19.prefetch(packed, 6, lane, wave);
-    striped_layer<17, false, false>(lds, lds + kFOut, lds + kG1, r18, lane, wave, ts, 45);
-    // conv20's fragments and bias: fetched before conv19 runs
-    f2 b20[6];
-    float bias20 = 0.f;
-    if (wave < 2) {
+    // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
+    // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
+    {
+        const int n_batch = tail_slot;
+        const long first_win = win - (long)(n_batch - 1) * (long)gridDim.x;
+        tail_slot = 0;
+        ArgsPtr a = args();
+        const int n_classes = a->n_classes;
+        const bool mine = wave < n_batch;
+        const long my_win = first_win + (long)wave * (long)gridDim.x;
+        float* X = lds + kTX + wave * 2 * kTailBuf;
+        float* Y = X + kTailBuf;
+        // epilogue parameters of the three layers, asked for before anything waits
+        EpiParams<3, false> ep18;
+        EpiParams<3, true> ep19;
+        ep18.load(packed + bias_offset(17) + n, nullptr, nullptr);
+        ep19.load(packed + bias_offset(18) + n, packed + bn_scale_offset(6) + n,
+                  packed + bn_shift_offset(6) + n);
+        const float bias20a = packed[bias_offset(19) + n];
+        const float bias20b = packed[bias_offset(19) + 16 + n];
+        __syncthreads();      // conv17's stores of this window are out; kRed / the concat buffer free
+        mark(ts, 45);
+        if (mine) {
+            const float* src = a->tail_scratch +
+                               ((size_t)blockIdx.x * kTailBatch + wave) * kTailSlotFloats;
+            f4 v[3];
 #pragma unroll
-        for (int sp = 0; sp < 6; ++sp)
-            b20[sp] = *reinterpret_cast<const f2*>(packed + weight_offset(19) +
-                                                   (sp * 2 + wave) * 128 + lane * 2);
-        bias20 = packed[bias_offset(19) + wave * 16 + n];
-    }
-    striped_layer<18, true, true>(lds, lds + kG1, lds + kG2, r19, lane, wave, ts, 49);
-    if (stop_stage == 6) {
-        if (debug_stage < 100)
-            dump_stage(lds + kG2, kS48, 8, 48, args()->debug_out + win * kStageFloats[6], tid);
-        return;
-    }
-
-    // ---------------- stage H: conv20 (1x1 -> classes) + ReLU + GlobalAveragePool + Softmax ---
-    // Wave t computes N tile t of conv20 (classes 16t .. 16t+15) and leaves their global-average
-    // logits in the q = 0 lanes.
-    auto conv20_logit = [&]() -> float {
-        const float* a_lane = lds + kG2 + (n + 1) * kS48 + 2 * q;
-        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f4*>(src + i * 256 + lane * 4);
+            if (lane < kS48) {       // zero rows before position 0 and after position 15, X and Y
+                X[lane] = 0.f;
+                X[17 * kS48 + lane] = 0.f;
+                Y[lane] = 0.f;
+                Y[17 * kS48 + lane] = 0.f;
+            }
 #pragma unroll
-        for (int sp = 0; sp < 6; ++sp) {
-            const f2 a = *reinterpret_cast<const f2*>(a_lane + sp * 8);
-            acc0 = mfma4(a.x, b20[sp].x, acc0);
-            acc1 = mfma4(a.y, b20[sp].y, acc1);
+            for (int i = 0; i < 3; ++i) {
+                const int idx = i * 256 + lane * 4, row = idx / 48, ch = idx - row * 48;
+                float* dst = X + (1 + row) * kS48 + ch;        // 8-byte aligned
+                *reinterpret_cast<f2*>(dst) = f2{v[i].x, v[i].y};
+                *reinterpret_cast<f2*>(dst + 2) = f2{v[i].z, v[i].w};
+            }
         }
-        const f4 acc = acc0 + acc1;
-        const float b = bias20;
-        float s = 0.f;
-        if (q < 2) {   // rows 4q..4q+3 of the tile; only positions 0..7 exist
-            s = fmaxf(acc.x + b, 0.f) + fmaxf(acc.y + b, 0.f) + fmaxf(acc.z + b, 0.f) +
-                fmaxf(acc.w + b, 0.f);
+        __syncthreads();      // the batch's weights have landed (vmcnt(0) rides on the barrier)
+        mark(ts, 46);
+        if (debug_stage >= 0 && stop_stage == 5) {
+            if (debug_stage < 100)
+                dump_stage(lds + kTX, kS48, 16, 48, a->debug_out + win * kStageFloats[5], tid);
+            return;
         }
-        // rows q = 0 and q = 1 hold the two halves of the position sum
-        int even, odd;
-        rows_i32(__builtin_bit_cast(int, s), &even, &odd);
-        return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) * 0.125f;
-    };
-    const int n_classes = args()->n_classes;
-    if (n_classes <= 16) {
-        // every class is in N tile 0: wave 0 goes from the MFMAs to the call without leaving its
-        // registers - no logits in LDS, no barrier, classes in lanes 0..15
-        if (wave == 0) {
-            const float logit = conv20_logit();
+        if (mine) {
+            // conv18: 16 positions x 48 -> 48, k = 3, bias + ReLU -> Y
+            {
+                f4 acc[1][3];
+                bias_acc(acc, ep18);
+                conv_tiles<3, 6, 6, 1, 3, 3, kS48, 16>(X + n * kS48 + 2 * q,
+                                                       lds + kTW18 + lane * 2, acc);
+                epilogue<1, 3, kS48, false, false, false>(acc, Y + (1 + 4 * q) * kS48 + n, ep18);
+            }
+            mark(ts, 47);
+            // conv19 + MaxPool + BN7 -> 8 positions, into X (rows 9.. keep conv17's values: the
+            // positions 8..15 conv20's tile computes from them are never looked at)
+            {
+                f4 acc[1][3];
+                bias_acc(acc, ep19);
+                conv_tiles<3, 6, 6, 1, 3, 3, kS48, 16>(Y + n * kS48 + 2 * q,
+                                                       lds + kTW19 + lane * 2, acc);
+                epilogue<1, 3, kS48, true, true, false>(acc, X + (1 + 2 * q) * kS48 + n, ep19);
+            }
+            mark(ts, 49);
+        }
+        if (debug_stage >= 0 && stop_stage == 6) {
+            __syncthreads();
+            if (debug_stage < 100)
+                dump_stage(lds + kTX, kS48, 8, 48, a->debug_out + win * kStageFloats[6], tid);
+            return;
+        }
+        if (mine) {
+            // conv20 (1x1 -> classes, one or two N tiles) + ReLU + global average: the logit of
+            // class 16t + n ends up in the q = 0 lanes
+            auto conv20_logit = [&](int t, float bias) -> float {
+                const float* a_lane = X + (n + 1) * kS48 + 2 * q;
+                const float* b_lane = lds + kTW20 + t * 128 + lane * 2;
+                f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < 6; ++sp) {
+                    const f2 av = *reinterpret_cast<const f2*>(a_lane + sp * 8);
+                    const f2 bv = *reinterpret_cast<const f2*>(b_lane + sp * 2 * 128);
+                    acc0 = mfma4(av.x, bv.x, acc0);
+                    acc1 = mfma4(av.y, bv.y, acc1);
+                }
+                const f4 acc = acc0 + acc1;
+                float sum = 0.f;
+                if (q < 2)     // rows 4q..4q+3 of the tile; only positions 0..7 exist
+                    sum = fmaxf(acc.x + bias, 0.f) + fmaxf(acc.y + bias, 0.f) +
+                          fmaxf(acc.z + bias, 0.f) + fmaxf(acc.w + bias, 0.f);
+                int even, odd;     // rows q = 0 and q = 1 hold the two halves of the position sum
+                rows_i32(__builtin_bit_cast(int, sum), &even, &odd);
+                return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) * 0.125f;
+            };
+            float logit = conv20_logit(0, bias20a);        // classes 0..15 in lanes 0..15
+            if (n_classes > 16) {
+                // classes 16..31: through the wave's own 32 LDS words into lanes 16..31
+                const float upper = conv20_logit(1, bias20b);
+                float* wl = lds + kTLog + wave * 32;
+                if (q == 0) wl[16 + n] = upper;
+                const float moved = wl[lane & 31];
+                if (lane >= 16) logit = moved;
+            }
             const bool valid = lane < n_classes;
             const float v = valid ? logit : -INFINITY;
-            const float mx = lane_value(row16_max(v), 0);
+            // classes live in lanes 0..31 = two 16-lane rows
+            const float rmx = row16_max(v);
+            const float mx = fmaxf(lane_value(rmx, 0), lane_value(rmx, 16));
             const float e = valid ? expf(v - mx) : 0.f;
-            const float sum = lane_value(row16_sum(e), 0);
+            const float rsum = row16_sum(e);
+            const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
             if (debug_stage == 7) {
-                if (lane < 32) args()->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
-                return;
-            }
-            const float p = e / sum;
-            ArgsPtr a = args();
-            float* __restrict__ probs = a->probs;
-            int* __restrict__ calls = a->calls;
-            if (calls != nullptr) {
-                if (lane < 32)
-                    renormalise_and_call(valid ? p : 0.f, lane, n_classes, a->score_diff,
-                                         probs + win * n_classes, calls + win);
-            } else if (valid) {
-                probs[win * n_classes + lane] = p;
+                if (lane < 32) a->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+            } else {
+                const float p = e / sum;
+                float* __restrict__ probs = a->probs;
+                int* __restrict__ calls = a->calls;
+                if (calls != nullptr) {
+                    // single scan step: this window IS the read (classify.py:368-382, one range)
+                    if (lane < 32)
+                        renormalise_and_call(valid ? p : 0.f, lane, n_classes, a->score_diff,
+                                             probs + my_win * n_classes, calls + my_win);
+                } else if (valid) {
+                    probs[my_win * n_classes + lane] = p;
+                }
             }
         }
         mark(ts, 53);
-        mark(ts, 54);
+        if (debug_stage == 7) return;
+        __syncthreads();      // the next window's stage A writes over all of this
         mark(ts, 55);
-        continue;
     }
-    if (wave < 2) {
-        const float logit = conv20_logit();
-        if (q == 0) lds[kLogits + wave * 16 + n] = logit;
-    }
-    mark(ts, 53);
-    __syncthreads();
-    mark(ts, 54);
-    if (wave == 0) {
-        const bool valid = lane < n_classes;
-        const float v = valid ? lds[kLogits + (lane & 31)] : -INFINITY;
-        // classes live in lanes 0..31 = two 16-lane rows
-        const float rmx = row16_max(v);
-        const float mx = fmaxf(lane_value(rmx, 0), lane_value(rmx, 16));
-        const float e = valid ? expf(v - mx) : 0.f;
-        const float rsum = row16_sum(e);
-        const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
-        if (debug_stage == 7) {
-            if (lane < 32) args()->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
-            return;
-        }
-        const float p = e / sum;
-        ArgsPtr a = args();
-        float* __restrict__ probs = a->probs;
-        int* __restrict__ calls = a->calls;
-        if (calls != nullptr) {
-            // single scan step: this window IS the read (classify.py:368-382 with one range)
-            if (lane < 32)
-                renormalise_and_call(valid ? p : 0.f, lane, n_classes, a->score_diff,
-                                     probs + win * n_classes, calls + win);
-        } else if (valid) {
-            probs[win * n_classes + lane] = p;
-        }
-    }
-    mark(ts, 55);
     }   // persistent loop over this workgroup's windows
 }
 

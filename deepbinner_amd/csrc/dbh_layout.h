@@ -127,11 +127,14 @@ constexpr int kS192 = 196;
 // (kW0, kW1); the Winograd layers of stage B as three 4,608-float slots (two transformed
 // matrices each) rotated so that the half a layer needs next is always already in flight.
 constexpr int kActOff = 0;
-constexpr int kActFloats = (512 + 2) * kS48;               // 25,700
+// stage B: eight regions of 66 rows, one per wave: [row before | 64 positions | row after]
+// (dbh_forward.hip: w43_layer); stages C, D: positions 0..L-1 in rows 1..L, rows 0 / L+1 zero
+constexpr int kRegionRows = 66;
+constexpr int kActFloats = 8 * kRegionRows * kS48;         // 26,400
 constexpr int kWFloats = 3 * 48 * 48;                      // 6,912
 constexpr int kW0 = kActOff + kActFloats;
 constexpr int kW1 = kW0 + kWFloats;
-constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 39,524
+constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 40,224
 constexpr int kWinoHalf = 2 * 48 * 48;                     // 4,608: two transformed matrices
 // F(4,3) matrices are stored V1,V2 | V3,V4 | V0,V5: the first two thirds need only rows d1..d4
 // of the six-row input tile and share their sub-expressions; kW43Slot[xi] = position of V_xi.
@@ -173,29 +176,46 @@ constexpr int kX9 = (kEW + kEWFloats + 3) / 4 * 4;         // conv9's exchange s
 constexpr int kW9 = kX9 + kXchgFloats;                     // conv9's four Winograd matrices
 constexpr int kLdsFloatsD = kW9 + 4 * 48 * 48;
 
-// stages F-H (reuse the front of the arena; the concat buffer stays where it is)
-constexpr int kFOut = 0;                                   // conv17+BN6 out, 18 rows x 52
-constexpr int kG1 = kFOut + 18 * kS48;                     // conv18 out
-constexpr int kG2 = kG1 + 18 * kS48;                       // conv19+pool+BN7 out (8 rows + pads)
-constexpr int kRed = kG2 + 18 * kS48;                      // split-K partial tiles, 24 x 256
-constexpr int kLogits = kRed + 24 * 256;                   // 32 floats
-constexpr int kTailEnd = kLogits + 32;
+// stage F (conv17, per window): split-K partial tiles at the front of the arena; the concat buffer
+// stays where it is.  conv17's 16 x 48 output goes to a per-workgroup slot in global memory.
+constexpr int kRed = 0;                                    // 24 x 256 partial tiles
+constexpr int kTailEnd = kRed + 24 * 256;
 static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
-
+// stages G-H (conv18, conv19, conv20, softmax, call) run for kTailBatch windows at a time, ONE
+// WAVE PER WINDOW (dbh_forward.hip: batched tail): the three layers' weights in fragment order
+// (LDS-DMA'd during the batch's last conv17, so they sit clear of kRed and the concat buffer),
+// then two 18 x 50 activation buffers per wave (X: conv17 out, later conv19 out; Y: conv18 out),
+// which may use the concat buffer's place - it is dead by then.
+constexpr int kTailBatch = 8;
+constexpr int kTW18 = kTailEnd;                            // 6,144
+constexpr int kTW19 = kTW18 + conv_weight_floats(17);      // + 6,912
+constexpr int kTW20 = kTW19 + conv_weight_floats(18);
+constexpr int kTWEnd = kTW20 + conv_weight_floats(19);     // 21,504
+static_assert(kTWEnd <= kECat, "tail weights would land on the concat buffer conv17 reads");
+constexpr int kTailBuf = 18 * kS48;                        // 900 floats
+constexpr int kTX = kTWEnd;                                // wave w: X at kTX + w * 2 * kTailBuf
+constexpr int kTLog = kTX + kTailBatch * 2 * kTailBuf;     // 32 logits per wave
+constexpr int kTEnd = kTLog + kTailBatch * 32;
+constexpr int kTailSlotFloats = 16 * 48;                   // conv17 output of one window
 // BN5's scale and shift (2 x 192 floats), parked above stage E's buffers for the inception block
 constexpr int kEBn5 = kLdsFloatsE;
 static_assert(kEBn5 + 2 * 192 <= (kLdsFloatsAD > kLdsFloatsD ? kLdsFloatsAD : kLdsFloatsD), "");
+static_assert(kTEnd <= kLdsFloatsAD, "batched tail overflows the arena");
 constexpr int kArenaFloats =
     (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
         ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
         : kLdsFloatsD;
-// Above the arena, for the whole kernel: a copy of every bias and of BN1..BN4's scale/shift
-// (packed[kWeightFloats ..), so that a layer's epilogue parameters come from LDS (~100 cycles)
-// instead of L2 (~700 cycles, exposed at the top of every layer).  BN5..BN7 do not fit; their
-// users fetch them from global memory well ahead of use.
+// Above the arena, for the whole kernel: a copy of the biases of conv2..conv9 and of BN2..BN4's
+// scale/shift (two contiguous runs of the packed image), so that the epilogue parameters of the
+// in-place layers of stages B-D come from LDS (~100 cycles) instead of L2 (~700 cycles, exposed
+// at the top of every layer); everything else is fetched from global memory well ahead of use.
+// Then one word: the arrival counter of the split barrier (dbh_forward.hip: lds_arrive/lds_wait).
 constexpr int kParams = kArenaFloats;
-constexpr int kParamFloats = (kBiasEnd - kWeightFloats) + 2 * (48 + 48 + 48 + 48);
-constexpr int kLdsFloats = kParams + kParamFloats;
+constexpr int kTabBias0 = bias_offset(1), kTabBias1 = bias_offset(9);
+constexpr int kTabBn0 = bn_scale_offset(1), kTabBn1 = bn_scale_offset(4);
+constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 352 + 288
+constexpr int kSync = kParams + kParamFloats;
+constexpr int kLdsFloats = kSync + 1;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])

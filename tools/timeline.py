@@ -14,18 +14,25 @@ sys.path.insert(0, REPO)
 from deepbinner_amd import hip_backend                      # noqa: E402
 from deepbinner_amd.model_format import ModelWeights        # noqa: E402
 
-LAYERS = ['conv2', 'conv3', 'conv4', 'conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 NAMES = {0: 'start', 1: 'A done'}
+# stage B (region layout, dbh_forward.hip: w43_layer): per layer P0 done | barrier | P1 done |
+# own rows stored (conv4: transform done) | end (halos + DMA issued; conv4: stores + barrier)
+for base, end, l in ((2, 61, 'conv2'), (6, 62, 'conv3'), (10, 63, 'conv4')):
+    for j, what in enumerate(['phase0 done', 'barrier', 'phase1 done', 'own rows stored']):
+        NAMES[base + j] = '%s %s' % (l, what)
+    NAMES[end] = '%s end' % l
+LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
-        NAMES[2 + 4 * i + j] = '%s %s' % (l, what)
+        NAMES[14 + 4 * i + j] = '%s %s' % (l, what)
 NAMES.update({34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
               38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
 for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
     for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
         NAMES[base + j] = '%s %s' % (l, what)
 NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
-EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 58: 'conv2 prologue done', 56: 'conv2 phase0 done', 57: 'conv2 mid barrier'}
+ORDER = [0, 1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63] + list(range(14, 56))
+EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued'}
 
 
 def main():
@@ -43,7 +50,17 @@ def main():
     run = model.timeline_i16 if fused else model.timeline
     run(x)                                  # warm-up
     st = run(x)                             # [n, 8 waves, 64]
-    ids = sorted(NAMES)
+    ids = ORDER
+    if n > 256:
+        # persistent launch: window w is the (w // grid)-th of workgroup w % grid; leave out every
+        # workgroup's first window (cold) and report the steady state, plus the period from one
+        # window's start to the next one's on the same workgroup
+        grid = 256
+        starts = st[:, :, 0].min(axis=1)
+        period = (starts[grid:] - starts[:-grid])
+        print('steady-state period per window (start to start, same workgroup): %.0f cycles '
+              '(first windows: %.0f)' % (np.median(period[grid:]), np.median(period[:grid])))
+        st = st[grid:]
     t0 = st[:, :, 0].min(axis=1, keepdims=True)          # block start
     rel = st[:, :, ids] - t0[:, :, None]                 # cycles since block start
     last = rel.max(axis=1)                               # slowest wave reaches each mark
@@ -59,6 +76,12 @@ def main():
     print('%-26s %10s %9s %7s %10s' % ('mark', 'cum_cycles', 'delta', 'pct', 'wave_skew'))
     for name, cum, d, skew in rows:
         print('%-26s %10.0f %9.0f %6.1f%% %10.0f' % (name, cum, d, 100 * d / total, skew))
+    if os.environ.get('DEEPBINNER_TIMELINE_WAVES') == '1':
+        # per wave (waves w and w + 4 share a SIMD): when each reaches the marks of stage B
+        print('%-26s' % 'mark (mean cycle per wave)' + ''.join('%9s' % ('w%d' % w) for w in range(8)))
+        for k, i in enumerate(ids):
+            if i in (1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63, 14):
+                print('%-26s' % NAMES[i] + ''.join('%9.0f' % rel[:, w, k].mean() for w in range(8)))
     for i, name in EXTRA.items():
         r = st[:, :, i] - t0
         print('%-26s first wave %8.0f  last wave %8.0f' % (name, r.min(axis=1).mean(), r.max(axis=1).mean()))
