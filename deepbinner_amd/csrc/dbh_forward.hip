@@ -1154,10 +1154,18 @@ struct SmallMRegs {
 
 // TO_GLOBAL: out_region is a dense [16][48] block in global memory (row 0 = position 0) instead
 // of an LDS activation buffer, and the layer ends without a barrier of its own.
-template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// pre_barrier / post_barrier: work of the caller's that rides on the layer's one barrier (every
+// wave calls pre_barrier before it, post_barrier after it).
+template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false,
+          class PreBarrier = NoHook, class PostBarrier = NoHook>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
                                               const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
-                                              int wave, long long* ts, int ts_base) {
+                                              int wave, long long* ts, int ts_base,
+                                              const PreBarrier& pre_barrier = PreBarrier(),
+                                              const PostBarrier& post_barrier = PostBarrier()) {
     using R = SmallMRegs<CONV, KS, NTW, BN>;
     constexpr int TAPS = R::TAPS, SP = R::SP;
     const int n = lane & 15, q = lane >> 4;
@@ -1198,9 +1206,11 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
             for (int t = 0; t < 3; ++t)
                 *reinterpret_cast<f4*>(lds + kRed + (wave * 3 + t) * 256 + lane * 4) = acc[0][t];
         }
+        pre_barrier();
         mark(ts, ts_base);
         __syncthreads();
         mark(ts, ts_base + 1);
+        post_barrier();
         if (wave < 3) {
             const int t = wave;
             f4 sum[1][1];
@@ -1492,6 +1502,14 @@ __device__ __forceinline__ void mean_std(long long s1, long long s2, int cnt, do
     }
 }
 
+// A pointer read from the kernel-argument segment is a generic ("flat") pointer to the compiler,
+// and flat accesses are slower than global ones AND count against the LDS counter the hand-written
+// fragment pipelines wait on.  glob() says what the pointer is: global memory.
+template <class T>
+__device__ __forceinline__ T* glob(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
 // Arguments of the forward kernel (one by-value struct = the kernel-argument segment).
 struct ForwardArgs {
     const float* packed;         // packed parameters (dbh_layout.h)
@@ -1506,7 +1524,38 @@ struct ForwardArgs {
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
     int n_classes, debug_stage, steps, side;
+    int tune;                    // DEEPBINNER_TUNE: experiment switches, 0 in production
 };
+
+// Window statistics, step 1: exact integer sums of this lane's two samples, sum(x) and sum(x^2)
+// split in 16-bit halves so that every wave-wide partial stays below 2^31, reduced over the wave
+// with DPP and left in the workgroup's kStatRed words.  Step 2 (after a barrier): mean and 1/std.
+__device__ __forceinline__ void window_partial_sums(float* lds, int cnt, int v0, int v1, int tid,
+                                                    int lane, int wave) {
+    const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
+    const unsigned sq0 = (unsigned)(v0 * v0), sq1 = (unsigned)(v1 * v1);   // <= 2^30
+    const int present = (tid < cnt ? 1 : 0) + (tid + kThreads < cnt ? 1 : 0);
+    const int w_sum = wave_sum_i32((tid < cnt ? biased0 : 0) + (tid + kThreads < cnt ? biased1 : 0));
+    const int w_cnt = wave_sum_i32(present);
+    const int w_lo = wave_sum_i32((int)(sq0 & 0xFFFF) + (int)(sq1 & 0xFFFF));
+    const int w_hi = wave_sum_i32((int)(sq0 >> 16) + (int)(sq1 >> 16));
+    long long* red = reinterpret_cast<long long*>(lds + kStatRed);
+    if (lane == 0) {
+        red[wave] = (long long)w_sum - 32768LL * w_cnt;
+        red[kWaves + wave] = ((long long)w_hi << 16) + (long long)w_lo;
+    }
+}
+__device__ __forceinline__ void window_mean_inv(const float* lds, int cnt, double* mean,
+                                                double* inv) {
+    const long long* red = reinterpret_cast<const long long*>(lds + kStatRed);
+    long long s1 = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) {
+        s1 += red[i];
+        s2 += red[kWaves + i];
+    }
+    mean_std(s1, s2, cnt, mean, inv);
+}
 
 // Seam-b2 input of one window, straight from the read's int16 samples: this lane's two samples
 // for the window statistics (positions tid and tid + 512 of the slice) and its four A-fragment
@@ -1551,7 +1600,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         asm volatile("" : "+s"(p));
         return p;
     };
-    const float* __restrict__ packed_entry = args()->packed;
+    const float* __restrict__ packed_entry = glob(args()->packed);
     const int debug_stage = args()->debug_stage;
     const long long n_windows = args()->n_windows;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -1569,6 +1618,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds[kParams + i] = packed_entry[src];
     }
     if (tid_entry == 0) *reinterpret_cast<unsigned*>(lds + kSync) = 0u;
+    {
+        const int tune = args()->tune;
+        const int w = __builtin_amdgcn_readfirstlane(tid_entry >> 6);
+        if ((tune & 1) && w < 4) __builtin_amdgcn_s_setprio(1);
+        if ((tune & 2) && w >= 4) __builtin_amdgcn_s_setprio(1);
+        if ((tune & 4) && w < 4) __builtin_amdgcn_s_setprio(3);
+        if ((tune & 8) && w >= 4) __builtin_amdgcn_s_setprio(3);
+    }
     unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
 
@@ -1591,15 +1648,17 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // body out of the loop and keeps them alive across it - 245 spilled VGPRs instead of none.
     int tid = tid_entry;
     asm volatile("" : "+v"(tid));
-    const float* __restrict__ packed = packed_entry;
-    asm volatile("" : "+s"(packed));
+    const __attribute__((address_space(1))) float* packed_opaque =
+        (const __attribute__((address_space(1))) float*)packed_entry;
+    asm volatile("" : "+s"(packed_opaque));
+    const float* __restrict__ packed = (const float*)packed_opaque;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
     long long* ts = nullptr;
     if (debug_stage >= 300 && lane == 0)        // 301: the same in a persistent launch
-        ts = reinterpret_cast<long long*>(args()->debug_out) + (win * kWaves + wave) * 64;
+        ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
     mark(ts, 0);
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
@@ -1617,7 +1676,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         // retires every outstanding request of the wave, and waiting there for 36 KB of weights
         // (~3.5k cycles at the cold start of a launch) would hold up the normalisation for
         // nothing; issued behind it, they arrive under the normalisation, conv1 and its epilogue.
-        const int16_t* __restrict__ samples = args()->samples;
+        const int16_t* __restrict__ samples = glob(args()->samples);
         if (samples == nullptr) fetch_conv2_weights();
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
@@ -1632,7 +1691,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (samples == nullptr) {
             // a later window of this workgroup: the window before it may still be read (stage H)
             if (win != (long)blockIdx.x) __syncthreads();
-            const float* xw = args()->x + win * kWindow;
+            const float* xw = glob(args()->x) + win * kWindow;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
@@ -1644,7 +1703,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 ArgsPtr a = args();
                 const int steps = a->steps, side = a->side;
                 const long long read0 = a->read0, len_hint = a->len_hint, hint_cap = a->hint_cap;
-                const long long* __restrict__ offsets = a->offsets;
+                const long long* __restrict__ offsets = glob(a->offsets);
                 const long long read = win / steps;
                 const int step = (int)(win - read * steps);
                 // Where a read starts is itself in memory (offsets[read]), and at the top of a
@@ -1662,33 +1721,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                     fetch_window(samples, base, len, step, side, tid, m0, n, q, in_cnt, in_v0,
                                  in_v1, in_raw, in_inside);
             }
-            const int cnt = in_cnt, v0 = in_v0, v1 = in_v1;
-            // exact integer sums: sum(x) and sum(x^2) split in 16-bit halves so that every
-            // wave-wide partial stays below 2^31
-            const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
-            const unsigned sq0 = (unsigned)(v0 * v0), sq1 = (unsigned)(v1 * v1);   // <= 2^30
-            const int present = (tid < cnt ? 1 : 0) + (tid + kThreads < cnt ? 1 : 0);
-            const int w_sum = wave_sum_i32((tid < cnt ? biased0 : 0) +
-                                           (tid + kThreads < cnt ? biased1 : 0));
-            const int w_cnt = wave_sum_i32(present);
-            const int w_lo = wave_sum_i32((int)(sq0 & 0xFFFF) + (int)(sq1 & 0xFFFF));
-            const int w_hi = wave_sum_i32((int)(sq0 >> 16) + (int)(sq1 >> 16));
-            // slot 2 of the weight area is idle until conv2 starts its first DMA
-            long long* red = reinterpret_cast<long long*>(lds + kSlot2);
-            if (lane == 0) {
-                red[wave] = (long long)w_sum - 32768LL * w_cnt;
-                red[kWaves + wave] = ((long long)w_hi << 16) + (long long)w_lo;
-            }
-            __syncthreads();
-            fetch_conv2_weights();
-            long long s1 = 0, s2 = 0;
-#pragma unroll
-            for (int i = 0; i < kWaves; ++i) {
-                s1 += red[i];
-                s2 += red[kWaves + i];
-            }
             double mean, inv;
-            mean_std(s1, s2, cnt, &mean, &inv);
+            if (!prefetched) {
+                window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
+                __syncthreads();
+                fetch_conv2_weights();
+                window_mean_inv(lds, in_cnt, &mean, &inv);
+            } else {
+                // the sums were taken and turned into mean and 1/std while the window before ran
+                // its conv17 (stage F below); this barrier publishes them - and keeps this
+                // window's activations off the LDS that window's last reads still use
+                __syncthreads();
+                fetch_conv2_weights();
+                const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
+                mean = stats[0];
+                inv = stats[1];
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
@@ -1723,7 +1771,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     if (stop_stage == 0) {
         if (debug_stage < 100) {
-            float* out = args()->debug_out + win * kStageFloats[0];
+            float* out = glob(args()->debug_out) + win * kStageFloats[0];
             for (int idx = tid; idx < 512 * 48; idx += kThreads) {
                 const int r = idx / 48, c = idx - r * 48;
                 out[idx] = lds[kActOff + ((r >> 6) * kRegionRows + 1 + (r & 63)) * kS48 + c];
@@ -1737,7 +1785,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     long long next_base = 0, next_len = 0;
     if (has_next) {
         ArgsPtr a = args();
-        const long long* __restrict__ offsets = a->offsets;
+        const long long* __restrict__ offsets = glob(a->offsets);
         const long long next_read = next_win / a->steps;
         next_base = offsets[next_read];
         next_len = offsets[next_read + 1] - next_base;
@@ -1770,7 +1818,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                 [] {});
     if (stop_stage == 1) {
         if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 256, 48, args()->debug_out + win * kStageFloats[1], tid);
+            dump_stage(lds + kActOff, kS48, 256, 48, glob(args()->debug_out) + win * kStageFloats[1], tid);
         return;
     }
 
@@ -1789,7 +1837,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         [] {});
     if (stop_stage == 2) {
         if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 128, 48, args()->debug_out + win * kStageFloats[2], tid);
+            dump_stage(lds + kActOff, kS48, 128, 48, glob(args()->debug_out) + win * kStageFloats[2], tid);
         return;
     }
 
@@ -1801,24 +1849,34 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     r17.prefetch_epilogue(packed, 5, lane, wave);
     wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
         lds, packed, tid, lane, wave, ts, 26,
+#ifdef DBH_EXP_D1
+        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave);
+              r17.template prefetch_slice<0, 27>(packed, lane, wave); }, NoSide());
+#else
         [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
         interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
             constexpr int IT = decltype(tag)::value;
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
         }));
+#endif
     // BN5's scale/shift (384 floats, too many for the parameter table): one per thread, fetched
     // here, parked in LDS at the top of stage E
     const float bn5v = tid < 2 * 192 ? packed[bn_scale_offset(4) + tid] : 0.f;
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
-        lds, packed, tid, lane, wave, ts, 30, [] {},
+        lds, packed, tid, lane, wave, ts, 30,
+#ifdef DBH_EXP_D2
+        [&] { dma_weights<kEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave); }, NoSide());
+#else
+        [] {},
         [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
             dma_weights_slice<kEWFloats, decltype(tag)::value, 6>(packed + weight_offset(9),
                                                                   lds + kEW, lane, wave);
         });
+#endif
     if (stop_stage == 3) {
         if (debug_stage < 100)
-            dump_stage(lds + kEX, kS48, 64, 48, args()->debug_out + win * kStageFloats[3], tid);
+            dump_stage(lds + kEX, kS48, 64, 48, glob(args()->debug_out) + win * kStageFloats[3], tid);
         return;
     }
 
@@ -1830,7 +1888,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         prefetched = has_next;
         if (has_next) {
             ArgsPtr a = args();
-            fetch_window(a->samples, next_base, next_len, (int)(next_win % a->steps), a->side, tid,
+            fetch_window(glob(a->samples), next_base, next_len, (int)(next_win % a->steps), a->side, tid,
                          wave * kMtA, n, q, in_cnt, in_v0, in_v1, in_raw, in_inside);
         }
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
@@ -1928,7 +1986,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     if (stop_stage == 4) {
         if (debug_stage < 100)
-            dump_stage(lds + kECat, kS192, 32, 192, args()->debug_out + win * kStageFloats[4], tid);
+            dump_stage(lds + kECat, kS192, 32, 192, glob(args()->debug_out) + win * kStageFloats[4], tid);
         return;
     }
 
@@ -1945,10 +2003,27 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
     }
     {
-        float* slot = args()->tail_scratch +
+        float* slot = glob(args()->tail_scratch) +
                       ((size_t)blockIdx.x * kTailBatch + tail_slot) * kTailSlotFloats;
-        small_m_layer<16, kS192, 2, 8, 3, false, true, true>(lds, lds + kECat, slot, r17, lane,
-                                                             wave, ts, 41);
+        // The next window's statistics ride on conv17's barrier: every wave leaves its partial
+        // sums before it; behind it wave 7 (idle while waves 0-2 reduce conv17) turns them into
+        // mean and 1/std, which the barrier at the top of the next stage A publishes.
+        small_m_layer<16, kS192, 2, 8, 3, false, true, true>(
+            lds, lds + kECat, slot, r17, lane, wave, ts, 41,
+            [&] {
+                if (prefetched) window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
+            },
+            [&] {
+                if (prefetched && wave == kWaves - 1) {
+                    double mean, inv;
+                    window_mean_inv(lds, in_cnt, &mean, &inv);
+                    double* stats = reinterpret_cast<double*>(lds + kStatOut);
+                    if (lane == 0) {
+                        stats[0] = mean;
+                        stats[1] = inv;
+                    }
+                }
+            });
     }
     ++tail_slot;
     if (!batch_ends) continue;
@@ -1976,7 +2051,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         __syncthreads();      // conv17's stores of this window are out; kRed / the concat buffer free
         mark(ts, 45);
         if (mine) {
-            const float* src = a->tail_scratch +
+            const float* src = glob(a->tail_scratch) +
                                ((size_t)blockIdx.x * kTailBatch + wave) * kTailSlotFloats;
             f4 v[3];
 #pragma unroll
@@ -1999,7 +2074,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 46);
         if (debug_stage >= 0 && stop_stage == 5) {
             if (debug_stage < 100)
-                dump_stage(lds + kTX, kS48, 16, 48, a->debug_out + win * kStageFloats[5], tid);
+                dump_stage(lds + kTX, kS48, 16, 48, glob(a->debug_out) + win * kStageFloats[5], tid);
             return;
         }
         if (mine) {
@@ -2026,7 +2101,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (debug_stage >= 0 && stop_stage == 6) {
             __syncthreads();
             if (debug_stage < 100)
-                dump_stage(lds + kTX, kS48, 8, 48, a->debug_out + win * kStageFloats[6], tid);
+                dump_stage(lds + kTX, kS48, 8, 48, glob(a->debug_out) + win * kStageFloats[6], tid);
             return;
         }
         if (mine) {
@@ -2070,11 +2145,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             const float rsum = row16_sum(e);
             const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
             if (debug_stage == 7) {
-                if (lane < 32) a->debug_out[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+                if (lane < 32) glob(a->debug_out)[win * kStageFloats[7] + lane] = valid ? v : 0.f;
             } else {
                 const float p = e / sum;
-                float* __restrict__ probs = a->probs;
-                int* __restrict__ calls = a->calls;
+                float* __restrict__ probs = glob(a->probs);
+                int* __restrict__ calls = glob(a->calls);
                 if (calls != nullptr) {
                     // single scan step: this window IS the read (classify.py:368-382, one range)
                     if (lane < 32)

@@ -215,7 +215,11 @@ constexpr int kTabBias0 = bias_offset(1), kTabBias1 = bias_offset(9);
 constexpr int kTabBn0 = bn_scale_offset(1), kTabBn1 = bn_scale_offset(4);
 constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 352 + 288
 constexpr int kSync = kParams + kParamFloats;
-constexpr int kLdsFloats = kSync + 1;
+// window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
+constexpr int kStatRed = kSync + 2;
+constexpr int kStatOut = kStatRed + 32;
+static_assert(kStatRed % 2 == 0, "64-bit words");
+constexpr int kLdsFloats = kStatOut + 4;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])

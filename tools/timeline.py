@@ -27,11 +27,12 @@ for i, l in enumerate(LAYERS):
         NAMES[14 + 4 * i + j] = '%s %s' % (l, what)
 NAMES.update({34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
               38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
-for base, l in ((41, 'conv17'), (45, 'conv18'), (49, 'conv19')):
-    for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue', 'barrier2']):
-        NAMES[base + j] = '%s %s' % (l, what)
-NAMES.update({53: 'conv20 compute', 54: 'H barrier', 55: 'end'})
-ORDER = [0, 1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63] + list(range(14, 56))
+for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global)', 'end']):
+    NAMES[41 + j] = 'conv17 %s' % what
+# the batched tail (every 8th window of a workgroup, or its last): one wave per window
+TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 47: 'tail: conv18 done',
+        49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
+ORDER = [0, 1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63] + list(range(14, 45))
 EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued'}
 
 
@@ -80,8 +81,19 @@ def main():
         # per wave (waves w and w + 4 share a SIMD): when each reaches the marks of stage B
         print('%-26s' % 'mark (mean cycle per wave)' + ''.join('%9s' % ('w%d' % w) for w in range(8)))
         for k, i in enumerate(ids):
-            if i in (1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63, 14):
+            if i in (1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63) or 14 <= i <= 44:
                 print('%-26s' % NAMES[i] + ''.join('%9.0f' % rel[:, w, k].mean() for w in range(8)))
+    # the batched tail: windows whose workgroup ran it right after them (mark 55 stamped)
+    ran = st[:, :, 55].max(axis=1) > 0
+    if ran.any():
+        tl = st[ran]
+        base = tl[:, :, 44].max(axis=1)                   # slowest wave leaves conv17
+        prev = base
+        print('batched tail (%d of %d windows end a batch), cycles after conv17:' % (ran.sum(), len(st)))
+        for i in sorted(TAIL):
+            stamps = np.where(tl[:, :, i] > 0, tl[:, :, i], 0).max(axis=1)
+            print('  %-34s %8.0f  (+%.0f)' % (TAIL[i], (stamps - base).mean(), (stamps - prev).mean()))
+            prev = stamps
     for i, name in EXTRA.items():
         r = st[:, :, i] - t0
         print('%-26s first wave %8.0f  last wave %8.0f' % (name, r.min(axis=1).mean(), r.max(axis=1).mean()))
