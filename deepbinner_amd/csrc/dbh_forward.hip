@@ -735,15 +735,18 @@ __device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
         for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[h][t]));
 }
 
-template <int PHASE, int SP_IDX>
+template <int PHASE, int SP_IDX, class Side>
 __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
-                                         W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3]) {
+                                         W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3],
+                                         const Side& side) {
     using F = W43Frags<PHASE>;
     constexpr int kXi = F::kXi;
     if constexpr (SP_IDX + 1 < 6) {
         w43_load<PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
+        side(IntC<SP_IDX>{});      // this step's share of the layer's LDS-DMA requests
         w43_wait<F::kLoads>(buf[SP_IDX & 1]);
     } else {
+        side(IntC<SP_IDX>{});
         w43_wait<0>(buf[SP_IDX & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -771,6 +774,13 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
     // one (tools/microbench/mfma_issue.hip) and does twice the work
     const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
     const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
+#ifdef DBH_EXP_X1      // timing only: no input transform at all
+    if constexpr (PHASE == 0) {
+        u[0] = f.d[0]; u[1] = f.d[1]; u[2] = f.d[2]; u[3] = f.d[3];
+    } else {
+        u[0] = f.d[0]; u[1] = f.d[5];
+    }
+#else
     if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
         const f2 d1 = f.d[0], d2 = f.d[1], d3 = f.d[2], d4 = f.d[3];
         const f2 a = __builtin_elementwise_fma(m4, d2, d4), b = __builtin_elementwise_fma(m4, d1, d3);
@@ -783,6 +793,7 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
         u[0] = __builtin_elementwise_fma(p4, f.d[0], __builtin_elementwise_fma(m5, f.d[2], f.d[4]));
         u[1] = __builtin_elementwise_fma(p4, f.d[1], __builtin_elementwise_fma(m5, f.d[3], f.d[5]));
     }
+#endif
 #endif
 #pragma unroll
     for (int x = 0; x < kXi; ++x) asm volatile("" : "+v"(u[x]));
@@ -803,16 +814,16 @@ __device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
 #pragma unroll
         for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[F::xi(x)][t]));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc);
+    if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, side);
 }
 
-template <int PHASE>
+template <int PHASE, class Side>
 __device__ __forceinline__ void w43_phase(const float* a_lane, const float* slot_lane,
-                                          f4 (&acc)[6][3]) {
+                                          f4 (&acc)[6][3], const Side& side) {
     const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
     W43Frags<PHASE> buf[2];
     w43_load<PHASE, 0>(buf[0], a_addr, b_addr);
-    w43_step<PHASE, 0>(a_addr, b_addr, buf, acc);
+    w43_step<PHASE, 0>(a_addr, b_addr, buf, acc, side);
 }
 
 // A workgroup-wide "everybody has passed point P" that is not a barrier: a wave ARRIVES
@@ -852,11 +863,14 @@ __device__ __forceinline__ void lds_wait(float* lds, unsigned target) {
 //                 (my halo rows in the neighbours' regions are no longer read, slot 2 is free, the
 //                 next layer's slots 0+1 have landed) | halo rows stored | dma_tail()
 //   LAST = true : barrier | pooled output to the CONTIGUOUS rows stage C reads | barrier
-template <int CONV, bool POOL, int BNI, bool LAST, class DmaMid, class DmaTail>
+// side0 / side1(IntC<step>): the LDS-DMA requests that ride on the six steps of phase 0 / 1 -
+// this layer's last third into slot 2 (every wave has left the phase 1 before it) / the next
+// layer's first two thirds into slots 0+1 (every wave has left phase 0).
+template <int CONV, bool POOL, int BNI, bool LAST, class Side0, class Side1>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
                                           int ts_end, unsigned& sync_rounds,
-                                          const DmaMid& dma_mid, const DmaTail& dma_tail) {
+                                          const Side0& side0, const Side1& side1) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     static_assert(LAST == POOL, "the pooled layer is the one that leaves the region layout");
     constexpr int L = 512;
@@ -882,15 +896,15 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // quad j' = pm(n) of this wave reads region rows 4j' .. 4j'+5
     const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
     const float* a_lane = lds + kActOff + (wave * kRegionRows + 4 * pm_n) * kS48 + 2 * q;
-    w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc);
+    w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc, side0);
     mark(ts, ts_base);
     __syncthreads();
     mark(ts, ts_base + 1);
-    dma_mid();
-    w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc);
+    w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc, side1);
     mark(ts, ts_base + 2);
     if constexpr (!LAST) {
         lds_arrive(lds, lane);
+        if (ts_base == 6) mark(ts, 56);
     } else {
         __syncthreads();      // every wave has finished reading the regions
     }
@@ -943,6 +957,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
             }
         }
     }
+    if (ts_base == 6) mark(ts, 57);
     if constexpr (!LAST) {
         // own rows: quad j' = 2q + e + 8h = pm(4q + 2h + e) -> region rows 1 + 4j' .. 4 + 4j'
         float* out = lds + kActOff + (wave * kRegionRows + 1) * kS48 + n;
@@ -959,6 +974,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
         mark(ts, ts_base + 3);
         sync_rounds += kWaves;
         lds_wait(lds, sync_rounds);
+        if (ts_base == 6) mark(ts, 58);
         // halo rows: my first position (quad 0, y0: lanes q = 0, h = e = 0) is the row after the
         // positions of the wave below, my last (quad 15, y3: lanes q = 3, h = e = 1) the row before
         // those of the wave above
@@ -969,7 +985,6 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 3; ++t) halo[t * 16] = q == 0 ? o[t][0][0][0] : o[t][1][1][3];
         }
-        dma_tail();
     } else {
         mark(ts, ts_base + 3);
         float* out = lds + kActOff + n;
@@ -986,7 +1001,6 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
         __syncthreads();
-        dma_tail();
     }
     mark(ts, ts_end);
 }
@@ -1626,6 +1640,17 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if ((tune & 4) && w < 4) __builtin_amdgcn_s_setprio(3);
         if ((tune & 8) && w >= 4) __builtin_amdgcn_s_setprio(3);
     }
+    // conv1d_1's three taps (B operand: k = lane >> 4 picks the tap) and its bias / BN1
+    EpiParams<3, true> ep_a;
+    float bw_a[3];
+    {
+        const int n_e = tid_entry & 15, q_e = (tid_entry & 63) >> 4;
+        ep_a.load(packed_entry + bias_offset(0) + n_e, packed_entry + bn_scale_offset(0) + n_e,
+                  packed_entry + bn_shift_offset(0) + n_e);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            bw_a[t] = (q_e < 3) ? packed_entry[weight_offset(0) + q_e * 48 + t * 16 + n_e] : 0.f;
+    }
     unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
 
@@ -1680,14 +1705,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (samples == nullptr) fetch_conv2_weights();
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
-        float a[MT], bw[3];
-        // everything this stage needs from memory is requested up front, in one round trip
-        EpiParams<3, true> ep;
-        ep.load(packed + bias_offset(0) + n, packed + bn_scale_offset(0) + n,
-                packed + bn_shift_offset(0) + n);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            bw[t] = (q < 3) ? packed[weight_offset(0) + q * 48 + t * 16 + n] : 0.f;
+        float a[MT];
+        const EpiParams<3, true>& ep = ep_a;      // conv1's weights and epilogue parameters:
+        const float(&bw)[3] = bw_a;               // fetched once per workgroup, before the loop
         if (samples == nullptr) {
             // a later window of this workgroup: the window before it may still be read (stage H)
             if (win != (long)blockIdx.x) __syncthreads();
@@ -1796,26 +1816,26 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // lives in slot p: phase 0 (xi 1..4) reads slots 0+1, phase 1 (xi 0,5) slot 2.  A layer's last
     // third is requested as soon as every wave has left the phase 1 before it; the NEXT layer's
     // first two thirds behind the layer's barrier, when every wave has left phase 0.
-    auto third = [&](int conv, int p, float* dst) {
-        dma_weights<kWinoHalf>(packed + weight_offset(conv) + p * kWinoHalf, dst, lane, wave);
-    };
-    third(1, 2, lds + kSlot2);
-    w43_layer<1, false, -1, false>(lds, packed, tid, lane, wave, ts, 2, 61, sync_rounds,
-                                   [&] { third(2, 0, lds + kSlot0); third(2, 1, lds + kSlot1); },
-                                   [&] { third(2, 2, lds + kSlot2); });
-    w43_layer<2, false, -1, false>(lds, packed, tid, lane, wave, ts, 6, 62, sync_rounds,
-                                   [&] { third(3, 0, lds + kSlot0); third(3, 1, lds + kSlot1); },
-                                   [&] { third(3, 2, lds + kSlot2); });
-    // conv4 + MaxPool + BN2 -> contiguous rows; conv5's and conv6's weights take over slot 0
-    // during phase 1
-    w43_layer<3, true, 1, true>(lds, packed, tid, lane, wave, ts, 10, 63, sync_rounds,
-                                [&] {
-                                    dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
-                                                                       lds + kW5, lane, wave);
-                                    dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                       lds + kW6, lane, wave);
-                                },
-                                [] {});
+    // a step's share (1/6) of the DMA of `floats` weights from the packed image into LDS
+#define DBH_DMA_STEPS(floats, src, dst) \
+    [&](auto tag) { dma_weights_slice<(floats), decltype(tag)::value, 6>((src), (dst), lane, wave); }
+    w43_layer<1, false, -1, false>(
+        lds, packed, tid, lane, wave, ts, 2, 61, sync_rounds,
+        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(1) + 2 * kWinoHalf, lds + kSlot2),
+        DBH_DMA_STEPS(2 * kWinoHalf, packed + weight_offset(2), lds + kSlot0));
+    w43_layer<2, false, -1, false>(
+        lds, packed, tid, lane, wave, ts, 6, 62, sync_rounds,
+        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(2) + 2 * kWinoHalf, lds + kSlot2),
+        DBH_DMA_STEPS(2 * kWinoHalf, packed + weight_offset(3), lds + kSlot0));
+    // conv4 + MaxPool + BN2 -> contiguous rows; conv5's and conv6's weights (adjacent in the
+    // packed image and in LDS) take over slot 0 during phase 1
+    static_assert(kW6 == kW5 + conv_weight_floats(4) && kSlot1 == kSlot0 + kWinoHalf, "");
+    w43_layer<3, true, 1, true>(
+        lds, packed, tid, lane, wave, ts, 10, 63, sync_rounds,
+        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(3) + 2 * kWinoHalf, lds + kSlot2),
+        DBH_DMA_STEPS(conv_weight_floats(4) + conv_weight_floats(5), packed + weight_offset(4),
+                      lds + kW5));
+#undef DBH_DMA_STEPS
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, glob(args()->debug_out) + win * kStageFloats[1], tid);
@@ -1852,6 +1872,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
 #ifdef DBH_EXP_D1
         [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave);
               r17.template prefetch_slice<0, 27>(packed, lane, wave); }, NoSide());
+#elif defined(DBH_EXP_D3)      // timing only: conv17's weights fetched late (before stage E)
+        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
+        NoSide());
 #else
         [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
         interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
@@ -1881,6 +1904,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
+#ifdef DBH_EXP_D3
+    r17.template prefetch_slice<0, 27>(packed, lane, wave);
+#endif
     {
         // The next window's samples start their trip from HBM now (stages E-H, ~25k cycles, are
         // far more than it takes) and are used at the top of the next round's stage A; the

@@ -33,7 +33,8 @@ for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global
 TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 47: 'tail: conv18 done',
         49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
 ORDER = [0, 1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63] + list(range(14, 45))
-EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued'}
+EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 8: 'conv3 phase1 done', 56: 'conv3 arrived',
+         57: 'conv3 transform done', 9: 'conv3 own rows stored', 58: 'conv3 wait done', 62: 'conv3 end'}
 
 
 def main():
@@ -96,7 +97,8 @@ def main():
             prev = stamps
     for i, name in EXTRA.items():
         r = st[:, :, i] - t0
-        print('%-26s first wave %8.0f  last wave %8.0f' % (name, r.min(axis=1).mean(), r.max(axis=1).mean()))
+        print('%-26s first wave %8.0f  last wave %8.0f   waves 0-3 %8.0f  waves 4-7 %8.0f' % (
+            name, r.min(axis=1).mean(), r.max(axis=1).mean(), r[:, :4].mean(), r[:, 4:].mean()))
     print(json.dumps({'total_cycles': float(total), 'n_windows': n}))
 
 
