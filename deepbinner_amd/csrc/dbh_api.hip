@@ -99,15 +99,12 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                                 if (co < cout)
                                     for (int tap = 0; tap < 3; ++tap)
                                         v += G[tap] * (double)kernel[((size_t)tap * cin + ci) * cout + co];
-                                // F(2,3): matrix-major [xi][sp][t][lane][e].  F(4,3): the
-                                // matrices go in the order V1,V2 | V3,V4 | V0,V5 (see
-                                // kW43Order), the two of a third interleaved per lane,
-                                // [third][sp][t][lane][slot&1][e], so one 16-byte LDS read
-                                // fetches both fragments.
-                                const int slot = kW43Slot[xi];
+                                // F(2,3): matrix-major [xi][sp][t][lane][e].  F(4,3): by N tile,
+                                // [t][sp][xi >> 1][lane][xi & 1][e], so that one 16-byte LDS read
+                                // fetches the fragments of two matrices for two k-steps.
                                 const size_t idx =
                                     kConv[i].wino == 4
-                                        ? (((((size_t)(slot >> 1) * sp_n + sp) * nt + t) * 64 + lane) * 2 + (slot & 1)) * 2 + e
+                                        ? (((((size_t)t * sp_n + sp) * 3 + (xi >> 1)) * 64 + lane) * 2 + (xi & 1)) * 2 + e
                                         : ((((size_t)xi * sp_n + sp) * nt + t) * 64 + lane) * 2 + e;
                                 dst[idx] = (float)v;
                             }

@@ -675,204 +675,208 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 //   6 products per output quad instead of 12: HALF the MFMAs of the direct convolution.  The
 //   extra fp32 round-off is ~2x the direct form's (end-to-end |dp| 1.7e-6 vs 0.8e-6 against the
 //   fp64 oracle, tolerance 1e-4).
-// One wave owns one tile of 16 quads (64 positions) and all 3 channel tiles: 18 accumulators.
-// The six V matrices come as three thirds in the order V1,V2 | V3,V4 | V0,V5 (kW43Slot), each
-// with a fixed LDS slot; phase 0 multiplies by the first two thirds, phase 1 by the last, and
-// every third is fetched at least a phase ahead of its use (see the DMA requests at the call
-// sites).
+// One wave owns one tile of 16 quads (64 positions).  How a layer runs (timeline evidence in
+// with the transform inside the MFMA loop and one epilogue per layer, all eight waves
+// reached their epilogues together, the LDS store path serialised them for ~1.2k cycles and the
+// matrix pipe idled ~3k cycles per layer):
+//   1. U PHASE: the wave reads ALL its input rows (36 ds_read_b64) and keeps the six transformed
+//      inputs of all 48 channels in registers (U[xi][sp]: 72 VGPRs).  After the barrier that
+//      follows, nobody reads the activation buffer again during this layer - so the outputs may be
+//      stored in place at any time, in any layout, with no hazard and no halo rows.
+//   2. Three N TILES of 16 output channels, one after the other: 72 MFMAs each (six matrices x
+//      twelve k-steps) whose inner loop is nothing but three ds_read_b128 of B fragments and
+//      twelve MFMAs per step - no VALU beside the fp32 MFMAs, which share the vector ALUs.
+//   3. The epilogue of tile t (output transform, ReLU, [pool, BN], stores) is cut in two pieces
+//      and issued inside tile t+1's MFMA steps; only the last tile's epilogue is exposed.
+// Weights: "third" t of a layer's image = everything N tile t needs ([sp][matrix pair][lane]
+// [matrix of the pair][e]: one ds_read_b128 = the B fragments of two matrices for two k-steps),
+// always in LDS slot t.  Slot t of the NEXT layer is requested once every wave has left tile t
+// (split barrier below), one tile later, so that the wait is never a wait.
 // ---------------------------------------------------------------------------------------------
-// Phase 0 covers xi = 1..4 (slots 0 and 1, which are adjacent, so the four matrices are one
-// contiguous image): these need only rows d1..d4 and share their sub-expressions,
-//     a = d4-4d2, b = d3-4d1: U1 = a+b, U2 = a-b;   c = d4-d2, e = d3-d1: U3 = c+2e, U4 = c-2e
-// - 8 VALU per component.  Phase 1 covers xi = 0, 5 (slot 2) from all six rows, 4 VALU per
-// component.  VALU issued between MFMAs is not free on this chip (tools/microbench/
-// mfma_issue.hip: ~2.6 cycles of matrix-pipe time each when bunched, ~6 for a lone one, packed
-// fp32 ~12), so the transform is kept as short as the algebra allows, scalar, and in ONE block
-// ahead of the step's MFMAs.
-template <int PHASE>
-struct W43Frags {
-    static constexpr int kThirds = PHASE == 0 ? 2 : 1;   // thirds (pairs of matrices) covered
-    static constexpr int kXi = 2 * kThirds;
-    static constexpr int kFirst = PHASE == 0 ? 1 : 0;    // first row read
-    static constexpr int kRows = PHASE == 0 ? 4 : 6;
-    static constexpr int kLoads = kRows + 3 * kThirds;
-    // accumulator (= xi) of the x-th matrix of this phase
-    static constexpr int xi(int x) { return PHASE == 0 ? 1 + x : (x == 0 ? 0 : 5); }
-    f2 d[kRows];
-    f4 b[kThirds][3];     // {first of the pair .x/.y, second .x/.y} per channel tile
-};
-
-template <int PHASE, int SP_IDX>
-__device__ __forceinline__ void w43_load(W43Frags<PHASE>& f, unsigned a_addr, unsigned b_addr) {
-    using F = W43Frags<PHASE>;
-    f.d[0] = ds_read_f2<((F::kFirst + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    f.d[1] = ds_read_f2<((F::kFirst + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    f.d[2] = ds_read_f2<((F::kFirst + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    f.d[3] = ds_read_f2<((F::kFirst + 3) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    if constexpr (F::kRows == 6) {
-        f.d[4] = ds_read_f2<((F::kFirst + 4) * kS48 + SP_IDX * 8) * 4>(a_addr);
-        f.d[5] = ds_read_f2<((F::kFirst + 5) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    }
-    // a third is [sp][t][lane][which of the pair][e]: 256 floats per (sp, t)
-    f.b[0][0] = ds_read_f4<((SP_IDX * 3 + 0) * 256) * 4>(b_addr);
-    f.b[0][1] = ds_read_f4<((SP_IDX * 3 + 1) * 256) * 4>(b_addr);
-    f.b[0][2] = ds_read_f4<((SP_IDX * 3 + 2) * 256) * 4>(b_addr);
-    if constexpr (F::kThirds == 2) {
-        f.b[1][0] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 0) * 256) * 4>(b_addr);
-        f.b[1][1] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 1) * 256) * 4>(b_addr);
-        f.b[1][2] = ds_read_f4<(kWinoHalf + (SP_IDX * 3 + 2) * 256) * 4>(b_addr);
-    }
-}
-
-template <int PENDING, int PHASE>
-__device__ __forceinline__ void w43_wait(W43Frags<PHASE>& f) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
-#pragma unroll
-    for (int k = 0; k < W43Frags<PHASE>::kRows; ++k) asm volatile("" : "+v"(f.d[k]));
-#pragma unroll
-    for (int h = 0; h < W43Frags<PHASE>::kThirds; ++h)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[h][t]));
-}
-
-template <int PHASE, int SP_IDX, class Side>
-__device__ __forceinline__ void w43_step(unsigned a_addr, unsigned b_addr,
-                                         W43Frags<PHASE> (&buf)[2], f4 (&acc)[6][3],
-                                         const Side& side) {
-    using F = W43Frags<PHASE>;
-    constexpr int kXi = F::kXi;
-    if constexpr (SP_IDX + 1 < 6) {
-        w43_load<PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
-        side(IntC<SP_IDX>{});      // this step's share of the layer's LDS-DMA requests
-        w43_wait<F::kLoads>(buf[SP_IDX & 1]);
-    } else {
-        side(IntC<SP_IDX>{});
-        w43_wait<0>(buf[SP_IDX & 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const F& f = buf[SP_IDX & 1];
-    f2 u[kXi];
-#ifdef DBH_W43_SCALAR_TRANSFORM
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
-            const float d1 = f.d[0][e], d2 = f.d[1][e], d3 = f.d[2][e], d4 = f.d[3][e];
-            const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-            const float c = d4 - d2, g = d3 - d1;
-            u[0][e] = a + b;
-            u[1][e] = a - b;
-            u[2][e] = fmaf(2.f, g, c);
-            u[3][e] = fmaf(-2.f, g, c);
-        } else {                           // rows d0..d5
-            u[0][e] = fmaf(4.f, f.d[0][e], fmaf(-5.f, f.d[2][e], f.d[4][e]));
-            u[1][e] = fmaf(4.f, f.d[1][e], fmaf(-5.f, f.d[3][e], f.d[5][e]));
-        }
-    }
-#else
-    // both components of a fragment at once (v_pk_fma_f32 / v_pk_add_f32): in ONE block ahead of
-    // the MFMAs a packed instruction costs the matrix pipe 4.3 cycles against 3.4 for a scalar
-    // one (tools/microbench/mfma_issue.hip) and does twice the work
-    const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
-    const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
-#ifdef DBH_EXP_X1      // timing only: no input transform at all
-    if constexpr (PHASE == 0) {
-        u[0] = f.d[0]; u[1] = f.d[1]; u[2] = f.d[2]; u[3] = f.d[3];
-    } else {
-        u[0] = f.d[0]; u[1] = f.d[5];
-    }
-#else
-    if constexpr (PHASE == 0) {        // rows d1..d4 at index 0..3
-        const f2 d1 = f.d[0], d2 = f.d[1], d3 = f.d[2], d4 = f.d[3];
-        const f2 a = __builtin_elementwise_fma(m4, d2, d4), b = __builtin_elementwise_fma(m4, d1, d3);
-        const f2 c = d4 - d2, g = d3 - d1;
-        u[0] = a + b;
-        u[1] = a - b;
-        u[2] = __builtin_elementwise_fma(p2, g, c);
-        u[3] = __builtin_elementwise_fma(m2, g, c);
-    } else {                           // rows d0..d5
-        u[0] = __builtin_elementwise_fma(p4, f.d[0], __builtin_elementwise_fma(m5, f.d[2], f.d[4]));
-        u[1] = __builtin_elementwise_fma(p4, f.d[1], __builtin_elementwise_fma(m5, f.d[3], f.d[5]));
-    }
-#endif
-#endif
-#pragma unroll
-    for (int x = 0; x < kXi; ++x) asm volatile("" : "+v"(u[x]));
-    __builtin_amdgcn_sched_barrier(0);
-    // f.b[h][t] = {V(pair h, first).e0, .e1, V(pair h, second).e0, .e1} for this lane's (k, n)
-#pragma unroll
-    for (int x = 0; x < kXi; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            acc[F::xi(x)][t] = mfma4(u[x].x, f.b[x >> 1][t][2 * (x & 1)], acc[F::xi(x)][t]);
-#pragma unroll
-    for (int x = 0; x < kXi; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            acc[F::xi(x)][t] = mfma4(u[x].y, f.b[x >> 1][t][2 * (x & 1) + 1], acc[F::xi(x)][t]);
-#pragma unroll
-    for (int x = 0; x < kXi; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[F::xi(x)][t]));
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP_IDX + 1 < 6) w43_step<PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, side);
-}
-
-template <int PHASE, class Side>
-__device__ __forceinline__ void w43_phase(const float* a_lane, const float* slot_lane,
-                                          f4 (&acc)[6][3], const Side& side) {
-    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
-    W43Frags<PHASE> buf[2];
-    w43_load<PHASE, 0>(buf[0], a_addr, b_addr);
-    w43_step<PHASE, 0>(a_addr, b_addr, buf, acc, side);
-}
-
 // A workgroup-wide "everybody has passed point P" that is not a barrier: a wave ARRIVES
 // (lds_arrive: one ds_add on a counter word, after everything it asked of memory has landed) and
 // carries on with work that does not depend on the others; where it does depend on them it WAITS
-// for the counter to reach 8 x the number of rounds so far.  Unlike s_barrier, which stops every
-// wave until the last one is there, the waves keep whatever stagger they have - which is the point:
-// the two waves of a SIMD share its matrix pipe, and one wave's epilogue (VALU + LDS stores) is
-// free when it runs beside the other's MFMAs and costs its full length when both run it together
-// behind a barrier.
-__device__ __forceinline__ void lds_arrive(float* lds, int lane) {
-    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync);
+// for the counter to reach 8 x the number of rounds so far.
+// Two counter words (which = 0, 1), because a count of arrivals only means "all eight" if no wave
+// can arrive twice before another has arrived once: each word is arrived at once per layer.
+__device__ __forceinline__ void lds_arrive(float* lds, int lane, int which) {
+    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync) + which;
     // release: this wave's LDS reads are done and its LDS-DMA pieces have landed (vmcnt)
     if (lane == 0)
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void lds_wait(float* lds, unsigned target) {
-    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync);
+__device__ __forceinline__ void lds_wait(float* lds, int which, unsigned target) {
+    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync) + which;
     while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
                  target) < 0)
         __builtin_amdgcn_s_sleep(1);
 }
 
-// Stage B keeps its activations in eight REGIONS of kRegionRows = 66 rows, one per wave: row 0 a
-// copy of the row before the wave's 64 positions, rows 1..64 its own positions, row 65 a copy of
-// the row after them.  A wave's six-row input tiles (d0..d5 = region rows 4j .. 4j+5 for its
-// quad j) then lie inside its own region, only the owner reads or writes rows 1..64, and the one
-// thing that crosses waves is the two halo rows each wave copies into its neighbours' regions
-// when it stores a layer's output.  Phase 0 of a layer (V1..V4: rows d1..d4) needs no halo at all,
-// so a wave goes from its own epilogue straight into the next layer's phase 0; the layer's one
-// barrier sits between phase 0 and phase 1 (which reads d0 and d5).
-//
-// One F(4,3) layer, from its phase 0 to the point where the next layer's phase 0 can start:
-//   [acc = bias] phase 0 (slots 0+1) | BARRIER: halos of the layer before and this layer's last
-//   third (slot 2) are there, slots 0+1 are free | dma_mid() | phase 1 (slot 2) |
-//   LAST = false: arrive | output transform, own rows stored | wait: every wave is through phase 1
-//                 (my halo rows in the neighbours' regions are no longer read, slot 2 is free, the
-//                 next layer's slots 0+1 have landed) | halo rows stored | dma_tail()
-//   LAST = true : barrier | pooled output to the CONTIGUOUS rows stage C reads | barrier
-// side0 / side1(IntC<step>): the LDS-DMA requests that ride on the six steps of phase 0 / 1 -
-// this layer's last third into slot 2 (every wave has left the phase 1 before it) / the next
-// layer's first two thirds into slots 0+1 (every wave has left phase 0).
-template <int CONV, bool POOL, int BNI, bool LAST, class Side0, class Side1>
+struct W43U {
+    f2 u[6][6];      // [xi][sp]: channels 8 sp + 2 (lane >> 4) + {0, 1} of quad pm(lane & 15)
+};
+
+template <int SP>
+__device__ __forceinline__ void w43_load_rows(f2 (&d)[6], unsigned a_addr) {
+    d[0] = ds_read_f2<(0 * kS48 + SP * 8) * 4>(a_addr);
+    d[1] = ds_read_f2<(1 * kS48 + SP * 8) * 4>(a_addr);
+    d[2] = ds_read_f2<(2 * kS48 + SP * 8) * 4>(a_addr);
+    d[3] = ds_read_f2<(3 * kS48 + SP * 8) * 4>(a_addr);
+    d[4] = ds_read_f2<(4 * kS48 + SP * 8) * 4>(a_addr);
+    d[5] = ds_read_f2<(5 * kS48 + SP * 8) * 4>(a_addr);
+}
+
+// U[.][SP] from the six input rows of channel group SP: both components of a fragment at once
+// (v_pk_fma_f32 / v_pk_add_f32), as ONE block of VALU ahead of the step's MFMAs - beside fp32
+// MFMAs (same ALUs) a VALU instruction costs ~4 cycles in a block, ~12 on its own
+// (tools/microbench/mfma_issue.hip).  Shared sub-expressions:
+//   a = d4-4d2, b = d3-4d1: U1 = a+b, U2 = a-b;   c = d4-d2, g = d3-d1: U3 = c+2g, U4 = c-2g
+template <int SP>
+__device__ __forceinline__ void w43_transform(W43U& U, const f2 (&d)[6]) {
+    const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
+    const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
+    const f2 a = __builtin_elementwise_fma(m4, d[2], d[4]), b = __builtin_elementwise_fma(m4, d[1], d[3]);
+    const f2 c = d[4] - d[2], g = d[3] - d[1];
+    U.u[0][SP] = __builtin_elementwise_fma(p4, d[0], __builtin_elementwise_fma(m5, d[2], d[4]));
+    U.u[1][SP] = a + b;
+    U.u[2][SP] = a - b;
+    U.u[3][SP] = __builtin_elementwise_fma(p2, g, c);
+    U.u[4][SP] = __builtin_elementwise_fma(m2, g, c);
+    U.u[5][SP] = __builtin_elementwise_fma(p4, d[1], __builtin_elementwise_fma(m5, d[3], d[5]));
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(U.u[x][SP]));
+}
+
+// the B fragments of one step: [matrix pair p][lane] -> {V(2p).e0, V(2p).e1, V(2p+1).e0, .e1}
+template <int SP>
+__device__ __forceinline__ void w43_load_b(f4 (&b)[3], unsigned b_addr) {
+    b[0] = ds_read_f4<((SP * 3 + 0) * 256) * 4>(b_addr);
+    b[1] = ds_read_f4<((SP * 3 + 1) * 256) * 4>(b_addr);
+    b[2] = ds_read_f4<((SP * 3 + 2) * 256) * 4>(b_addr);
+}
+
+// Step 0 STARTS the six accumulator chains: five from the constant 0 (an inline operand of the
+// MFMA - no v_mov per register, and VALU work is not free beside fp32 MFMAs), M1's from the bias.
+// TILE0: the step also fetches the input rows of the NEXT channel group and turns this one's
+// into U[.][SP] - tile 0 builds the register-resident U that tiles 1 and 2 reuse.
+template <bool TILE0, int SP, class Side>
+__device__ __forceinline__ void w43_tile_step(W43U& U, unsigned a_addr, unsigned b_addr,
+                                              f2 (&dbuf)[2][6], f4 (&buf)[2][3], f4 (&acc)[6],
+                                              float bias, const Side& side) {
+    if constexpr (SP + 1 < 6) {
+        if constexpr (TILE0) w43_load_rows<SP + 1>(dbuf[(SP + 1) & 1], a_addr);
+        w43_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
+        if constexpr (TILE0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[3] = buf[SP & 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    if constexpr (TILE0) {
+        f2(&d)[6] = dbuf[SP & 1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(d[k]));
+        __builtin_amdgcn_sched_barrier(0);
+        w43_transform<SP>(U, d);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP == 0) {
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], zero);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2],
+                                   p == 0 ? f4{bias, bias, bias, bias} : zero);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    side(IntC<SP>{});      // the caller's work for this step (a piece of the tile before's epilogue)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP + 1 < 6)
+        w43_tile_step<TILE0, SP + 1>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
+}
+
+template <bool TILE0, class Side>
+__device__ __forceinline__ void w43_tile(W43U& U, const float* a_lane, const float* slot_lane,
+                                         f4 (&acc)[6], float bias, const Side& side) {
+    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
+    f2 dbuf[2][6];
+    f4 buf[2][3];
+    if constexpr (TILE0) w43_load_rows<0>(dbuf[0], a_addr);
+    w43_load_b<0>(buf[0], b_addr);
+    w43_tile_step<TILE0, 0>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
+}
+
+// Half (h = rows 2h, 2h+1 of every accumulator = quads 2q + 8h, 2q + 1 + 8h of the wave's tile)
+// of the epilogue of N tile T: output transform, ReLU (+ MaxPool2 + BatchNorm), stores in place.
+// MFMA row m = 4q'+r' of the wave's tile works on quad pm(m) = 2q' + (r'&1) + 8(r'>>1), so that the
+// four lane groups of one store write quads 2 apart = 16-bank-aligned quarters of the LDS banks.
+template <int T, bool POOL, bool BN>
+__device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, float sc, float sh,
+                                                  float* out_lane, int wave, int q) {
+    constexpr int NV = POOL ? 2 : 4;
+    const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+    const f2 a0 = f2{acc[0][2 * h], acc[0][2 * h + 1]};
+    const f2 a1 = f2{acc[1][2 * h], acc[1][2 * h + 1]};
+    const f2 a2 = f2{acc[2][2 * h], acc[2][2 * h + 1]};
+    const f2 a3 = f2{acc[3][2 * h], acc[3][2 * h + 1]};
+    const f2 a4 = f2{acc[4][2 * h], acc[4][2 * h + 1]};
+    const f2 a5 = f2{acc[5][2 * h], acc[5][2 * h + 1]};
+    const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+    const f2 y0 = a0 + s12 + s34;
+    const f2 y1 = __builtin_elementwise_fma(k2, d34, d12);
+    const f2 y2 = __builtin_elementwise_fma(k4, s34, s12);
+    const f2 y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
+        float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
+        const int j = wave * 16 + 2 * q + e + 8 * h;          // pm(4q + 2h + e)
+        float* dst = out_lane + (1 + NV * j) * kS48 + T * 16;
+        if constexpr (POOL) {
+            f2 p = f2{fmaxf(v0, v1), fmaxf(v2, v3)};
+            if (BN) p = __builtin_elementwise_fma(p, f2{sc, sc}, f2{sh, sh});
+            dst[0] = p.x;
+            dst[kS48] = p.y;
+        } else {
+            if (BN) {
+                v0 = fmaf(v0, sc, sh);
+                v1 = fmaf(v1, sc, sh);
+                v2 = fmaf(v2, sc, sh);
+                v3 = fmaf(v3, sc, sh);
+            }
+            dst[0] = v0;
+            dst[kS48] = v1;
+            dst[2 * kS48] = v2;
+            dst[3 * kS48] = v3;
+        }
+    }
+}
+
+// One F(4,3) layer.  On entry the layer's input is complete in LDS (a barrier has passed since
+// the last store) and the layer's three weight thirds are in slots 0..2 or on their way (they land
+// before the barrier below releases).  next_third(t, dst): request third t of the NEXT layer's
+// weights (or whatever takes slot t's place) - called once every wave has left tile t.
+template <int CONV, bool POOL, int BNI, class NextThird>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
-                                          int ts_end, unsigned& sync_rounds,
-                                          const Side0& side0, const Side1& side1) {
+                                          unsigned& sync_rounds, const NextThird& next_third) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
-    static_assert(LAST == POOL, "the pooled layer is the one that leaves the region layout");
     constexpr int L = 512;
     static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
     constexpr int LOUT = POOL ? L / 2 : L;
@@ -881,129 +885,45 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
 
     EpiParams<3, BN> ep;
     load_epi<CONV, BNI>(ep, lds, packed, n);
-    // M1 enters all four outputs with weight +1, so it is the accumulator that starts at the bias
-    f4 acc[6][3];
-#pragma unroll
-    for (int x = 0; x < 6; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float v = x == 1 ? ep.b[t] : 0.f;
-            acc[x][t] = f4{v, v, v, v};
-        }
-    // MFMA row m = 4q'+r' of the wave's tile works on quad pm(m) = 2q' + (r'&1) + 8(r'>>1), so
-    // that in the epilogue the four lane groups of one store (m = 4q+r, q = 0..3) write quads
-    // 2 apart = 16-bank-aligned quarters of the 64 LDS banks instead of colliding two by two.
-    // quad j' = pm(n) of this wave reads region rows 4j' .. 4j'+5
+    // quad j = wave*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
     const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
-    const float* a_lane = lds + kActOff + (wave * kRegionRows + 4 * pm_n) * kS48 + 2 * q;
-    w43_phase<0>(a_lane, lds + kSlot0 + lane * 4, acc, side0);
+    const float* a_lane = lds + kActOff + (wave * 64 + 4 * pm_n) * kS48 + 2 * q;
+    float* out_lane = lds + kActOff + n;
+    W43U U;
+    f4 acc[2][6];
+    // tile 0: reads the wave's input rows step by step and builds U on the way
+    w43_tile<true>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
     mark(ts, ts_base);
-    __syncthreads();
-    mark(ts, ts_base + 1);
-    w43_phase<1>(a_lane, lds + kSlot2 + lane * 4, acc, side1);
-    mark(ts, ts_base + 2);
-    if constexpr (!LAST) {
-        lds_arrive(lds, lane);
-        if (ts_base == 6) mark(ts, 56);
-    } else {
-        __syncthreads();      // every wave has finished reading the regions
-    }
-
-    // Output transform + ReLU (+ pooling, BN) in registers, then the stores.  Register PAIRS
-    // (v_pk_add_f32 / v_pk_fma_f32: two rows of the tile per instruction) halve the VALU count;
-    // ReLU and pooling stay scalar (no packed fp32 max).
-    constexpr int NV = POOL ? 2 : 4;
-    float o[3][2][2][NV];
-    {
-        const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float sc = ep.sc[t], sh = ep.sh[t];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 a0 = f2{acc[0][t][2 * h], acc[0][t][2 * h + 1]};
-                const f2 a1 = f2{acc[1][t][2 * h], acc[1][t][2 * h + 1]};
-                const f2 a2 = f2{acc[2][t][2 * h], acc[2][t][2 * h + 1]};
-                const f2 a3 = f2{acc[3][t][2 * h], acc[3][t][2 * h + 1]};
-                const f2 a4 = f2{acc[4][t][2 * h], acc[4][t][2 * h + 1]};
-                const f2 a5 = f2{acc[5][t][2 * h], acc[5][t][2 * h + 1]};
-                const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
-                const f2 y0 = a0 + s12 + s34;
-                const f2 y1 = __builtin_elementwise_fma(k2, d34, d12);
-                const f2 y2 = __builtin_elementwise_fma(k4, s34, s12);
-                const f2 y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
-                    float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
-                    if constexpr (POOL) {
-                        f2 p = f2{fmaxf(v0, v1), fmaxf(v2, v3)};
-                        if (BN) p = __builtin_elementwise_fma(p, f2{sc, sc}, f2{sh, sh});
-                        o[t][h][e][0] = p.x;
-                        o[t][h][e][1] = p.y;
-                    } else {
-                        if (BN) {
-                            v0 = fmaf(v0, sc, sh);
-                            v1 = fmaf(v1, sc, sh);
-                            v2 = fmaf(v2, sc, sh);
-                            v3 = fmaf(v3, sc, sh);
-                        }
-                        o[t][h][e][0] = v0;
-                        o[t][h][e][1] = v1;
-                        o[t][h][e][2] = v2;
-                        o[t][h][e][3] = v3;
-                    }
-                }
-            }
-        }
-    }
+    __syncthreads();      // every wave has read all its input rows (and has left tile 0): from
+    mark(ts, ts_base + 1);   // here on the outputs may be stored in place
+    if (POOL) zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);   // (row 0 is zero already)
+    next_third(0, lds + kSlot0);
+    // tile 1, with tile 0's epilogue inside its steps 1 and 3
+    w43_tile<false>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
+        constexpr int SP = decltype(tag)::value;
+        if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_lane, wave, q);
+        if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_lane, wave, q);
+    });
+    lds_arrive(lds, lane, 0);
+    sync_rounds += kWaves;
     if (ts_base == 6) mark(ts, 57);
-    if constexpr (!LAST) {
-        // own rows: quad j' = 2q + e + 8h = pm(4q + 2h + e) -> region rows 1 + 4j' .. 4 + 4j'
-        float* out = lds + kActOff + (wave * kRegionRows + 1) * kS48 + n;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = 2 * q + e + 8 * h;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) out[(4 * j + i) * kS48 + t * 16] = o[t][h][e][i];
-                }
-        mark(ts, ts_base + 3);
-        sync_rounds += kWaves;
-        lds_wait(lds, sync_rounds);
-        if (ts_base == 6) mark(ts, 58);
-        // halo rows: my first position (quad 0, y0: lanes q = 0, h = e = 0) is the row after the
-        // positions of the wave below, my last (quad 15, y3: lanes q = 3, h = e = 1) the row before
-        // those of the wave above
-        if ((q == 0 && wave > 0) || (q == 3 && wave < kWaves - 1)) {
-            float* halo = lds + kActOff + n +
-                          (q == 0 ? (wave - 1) * kRegionRows + kRegionRows - 1
-                                  : (wave + 1) * kRegionRows) * kS48;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) halo[t * 16] = q == 0 ? o[t][0][0][0] : o[t][1][1][3];
-        }
-    } else {
-        mark(ts, ts_base + 3);
-        float* out = lds + kActOff + n;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = wave * 16 + 2 * q + e + 8 * h;      // pm(4q + 2h + e)
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) out[(1 + NV * j + i) * kS48 + t * 16] = o[t][h][e][i];
-                }
-        zero_row(lds + kActOff, 0, kS48, 48, tid);
-        zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
-        __syncthreads();
-    }
-    mark(ts, ts_end);
+    // tile 2, with tile 1's epilogue inside
+    w43_tile<false>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
+        constexpr int SP = decltype(tag)::value;
+        if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_lane, wave, q);
+        if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_lane, wave, q);
+    });
+    lds_wait(lds, 0, sync_rounds);      // every wave has left tile 1
+    next_third(1, lds + kSlot1);
+    mark(ts, ts_base + 2);
+    w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    if (ts_base == 6) mark(ts, 58);
+    __syncthreads();      // the layer is stored; every wave has left tile 2
+    next_third(2, lds + kSlot2);
+    mark(ts, ts_base + 3);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // The same Winograd layer at L = 128, where there are only four 16-pair tiles for eight waves:
@@ -1631,7 +1551,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                                   : kTabBn0 + (i - (kTabBias1 - kTabBias0));
         lds[kParams + i] = packed_entry[src];
     }
-    if (tid_entry == 0) *reinterpret_cast<unsigned*>(lds + kSync) = 0u;
+    if (tid_entry < 2) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
     {
         const int tune = args()->tune;
         const int w = __builtin_amdgcn_readfirstlane(tid_entry >> 6);
@@ -1693,9 +1613,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     {
         // conv2's transformed weights: (V1,V2) -> slot 0, (V3,V4) -> slot 1; (V0,V5) follow
         // during conv2's own first phase
-        auto fetch_conv2_weights = [&] {
-            dma_weights<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
-            dma_weights<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
+        auto fetch_conv2_weights = [&] {      // all three thirds (slots 0..2 are adjacent)
+            dma_weights<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         };
         // seam b1: at once.  Seam b2: only after the barrier of the window statistics - a barrier
         // retires every outstanding request of the wave, and waiting there for 36 KB of weights
@@ -1768,35 +1687,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             for (int t = 0; t < 3; ++t)
                 acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
         mark(ts, 59);
-        // the wave's 64 positions are rows 1..64 of ITS region (see w43_layer), its first and
-        // last position also the halo rows 65 / 0 of the regions below / above
-        float* out_lane = lds + kActOff + (wave * kRegionRows + 1 + 4 * q) * kS48 + n;
+        float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
         epilogue<MT, 3, kS48, false, true, false>(acc, out_lane, ep);
-        if ((q == 0 && wave > 0) || (q == 3 && wave < kWaves - 1)) {
-            float* halo = lds + kActOff + n +
-                          (q == 0 ? (wave - 1) * kRegionRows + kRegionRows - 1
-                                  : (wave + 1) * kRegionRows) * kS48;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                // the epilogue's arithmetic once more for the two rows (conv + bias is in acc)
-                const float v = fmaxf(q == 0 ? acc[0][t].x : acc[MT - 1][t].w, 0.f);
-                halo[t * 16] = fmaf(v, ep.sc[t], ep.sh[t]);
-            }
-        }
         mark(ts, 60);
-        zero_row(lds + kActOff, 0, kS48, 48, tid);                            // before position 0
-        zero_row(lds + kActOff, kWaves * kRegionRows - 1, kS48, 48, tid);     // after position 511
+        zero_row(lds + kActOff, 0, kS48, 48, tid);
+        zero_row(lds + kActOff, 513, kS48, 48, tid);
         __syncthreads();
         mark(ts, 1);
     }
     if (stop_stage == 0) {
-        if (debug_stage < 100) {
-            float* out = glob(args()->debug_out) + win * kStageFloats[0];
-            for (int idx = tid; idx < 512 * 48; idx += kThreads) {
-                const int r = idx / 48, c = idx - r * 48;
-                out[idx] = lds[kActOff + ((r >> 6) * kRegionRows + 1 + (r & 63)) * kS48 + c];
-            }
-        }
+        if (debug_stage < 100)
+            dump_stage(lds + kActOff, kS48, 512, 48,
+                       glob(args()->debug_out) + win * kStageFloats[0], tid);
         return;
     }
     // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
@@ -1812,30 +1714,26 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd F(4,3) layers over the region layout (see w43_layer).  Third p of a layer always
-    // lives in slot p: phase 0 (xi 1..4) reads slots 0+1, phase 1 (xi 0,5) slot 2.  A layer's last
-    // third is requested as soon as every wave has left the phase 1 before it; the NEXT layer's
-    // first two thirds behind the layer's barrier, when every wave has left phase 0.
-    // a step's share (1/6) of the DMA of `floats` weights from the packed image into LDS
-#define DBH_DMA_STEPS(floats, src, dst) \
-    [&](auto tag) { dma_weights_slice<(floats), decltype(tag)::value, 6>((src), (dst), lane, wave); }
-    w43_layer<1, false, -1, false>(
-        lds, packed, tid, lane, wave, ts, 2, 61, sync_rounds,
-        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(1) + 2 * kWinoHalf, lds + kSlot2),
-        DBH_DMA_STEPS(2 * kWinoHalf, packed + weight_offset(2), lds + kSlot0));
-    w43_layer<2, false, -1, false>(
-        lds, packed, tid, lane, wave, ts, 6, 62, sync_rounds,
-        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(2) + 2 * kWinoHalf, lds + kSlot2),
-        DBH_DMA_STEPS(2 * kWinoHalf, packed + weight_offset(3), lds + kSlot0));
-    // conv4 + MaxPool + BN2 -> contiguous rows; conv5's and conv6's weights (adjacent in the
-    // packed image and in LDS) take over slot 0 during phase 1
-    static_assert(kW6 == kW5 + conv_weight_floats(4) && kSlot1 == kSlot0 + kWinoHalf, "");
-    w43_layer<3, true, 1, true>(
-        lds, packed, tid, lane, wave, ts, 10, 63, sync_rounds,
-        DBH_DMA_STEPS(kWinoHalf, packed + weight_offset(3) + 2 * kWinoHalf, lds + kSlot2),
-        DBH_DMA_STEPS(conv_weight_floats(4) + conv_weight_floats(5), packed + weight_offset(4),
-                      lds + kW5));
-#undef DBH_DMA_STEPS
+    // Winograd F(4,3) layers (see w43_layer).  Third t of a layer (= what N tile t needs) always
+    // lives in slot t; the next layer's third t is requested when every wave has left tile t.
+    auto third = [&](int conv, int t, float* dst) {
+        dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
+    };
+    w43_layer<1, false, -1>(lds, packed, tid, lane, wave, ts, 2, sync_rounds,
+                            [&](int t, float* dst) { third(2, t, dst); });
+    w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6, sync_rounds,
+                            [&](int t, float* dst) { third(3, t, dst); });
+    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 when tile 0 is done
+    // (conv7's follow while conv5 runs)
+    w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
+                          [&](int t, float*) {
+                              if (t == 0) {
+                                  dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
+                                                                     lds + kW5, lane, wave);
+                                  dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                     lds + kW6, lane, wave);
+                              }
+                          });
     if (stop_stage == 1) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, glob(args()->debug_out) + win * kStageFloats[1], tid);

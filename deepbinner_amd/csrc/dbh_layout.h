@@ -127,18 +127,14 @@ constexpr int kS192 = 196;
 // (kW0, kW1); the Winograd layers of stage B as three 4,608-float slots (two transformed
 // matrices each) rotated so that the half a layer needs next is always already in flight.
 constexpr int kActOff = 0;
-// stage B: eight regions of 66 rows, one per wave: [row before | 64 positions | row after]
-// (dbh_forward.hip: w43_layer); stages C, D: positions 0..L-1 in rows 1..L, rows 0 / L+1 zero
-constexpr int kRegionRows = 66;
-constexpr int kActFloats = 8 * kRegionRows * kS48;         // 26,400
+constexpr int kActFloats = (512 + 2) * kS48;               // 25,700
 constexpr int kWFloats = 3 * 48 * 48;                      // 6,912
 constexpr int kW0 = kActOff + kActFloats;
 constexpr int kW1 = kW0 + kWFloats;
-constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 40,224
+constexpr int kLdsFloatsAD = kW1 + kWFloats;               // 39,524
 constexpr int kWinoHalf = 2 * 48 * 48;                     // 4,608: two transformed matrices
-// F(4,3) matrices are stored V1,V2 | V3,V4 | V0,V5: the first two thirds need only rows d1..d4
-// of the six-row input tile and share their sub-expressions; kW43Slot[xi] = position of V_xi.
-constexpr int kW43Slot[6] = {4, 0, 1, 2, 3, 5};
+// An F(4,3) layer's image is three thirds of kWinoHalf floats, third t = everything N tile t
+// (output channels 16t..16t+15) needs: [sp 0..5][matrix pair 0..2][lane][matrix of the pair][e].
 constexpr int kSlot0 = kW0;
 constexpr int kSlot1 = kW0 + kWinoHalf;
 constexpr int kSlot2 = kW0 + 2 * kWinoHalf;

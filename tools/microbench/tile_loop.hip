@@ -1,0 +1,146 @@
+// Micro-benchmark of the stage-B tile loop of dbh_forward.hip (w43_tile): per step three
+// ds_read_b128 of B fragments (double-buffered, hand-counted waits) and twelve
+// v_mfma_f32_16x16x4_f32 whose A operands are 72 register-resident values.  Variants isolate what
+// costs what: B as six ds_read_b64, no LDS at all, one wave per SIMD, reuse distance of the
+// accumulators.  Prints cycles per MFMA per SIMD (32.0 = the matrix pipe's limit).
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench/tile_loop.hip -o tools/microbench/_build/tile_loop
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ f4 ds_read_f4(unsigned addr) {
+    f4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f2 ds_read_f2(unsigned addr) {
+    f2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+    return v;
+}
+struct U72 { f2 u[6][6]; };
+
+// MODE 0: 3 x b128 per step; 1: 6 x b64 per step; 2: no LDS (B fixed in registers)
+template <int MODE, int SP>
+__device__ __forceinline__ void load_b(f4 (&b)[3], unsigned addr) {
+    if constexpr (MODE == 0) {
+        b[0] = ds_read_f4<((SP * 3 + 0) * 256) * 4>(addr);
+        b[1] = ds_read_f4<((SP * 3 + 1) * 256) * 4>(addr);
+        b[2] = ds_read_f4<((SP * 3 + 2) * 256) * 4>(addr);
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f2 lo, hi;
+            if (p == 0) { lo = ds_read_f2<((SP * 6 + 0) * 128) * 4>(addr); hi = ds_read_f2<((SP * 6 + 1) * 128) * 4>(addr); }
+            if (p == 1) { lo = ds_read_f2<((SP * 6 + 2) * 128) * 4>(addr); hi = ds_read_f2<((SP * 6 + 3) * 128) * 4>(addr); }
+            if (p == 2) { lo = ds_read_f2<((SP * 6 + 4) * 128) * 4>(addr); hi = ds_read_f2<((SP * 6 + 5) * 128) * 4>(addr); }
+            b[p] = f4{lo.x, lo.y, hi.x, hi.y};
+        }
+    }
+}
+template <int MODE, int SP>
+__device__ __forceinline__ void step(const U72& U, unsigned addr, f4 (&buf)[2][3], f4 (&acc)[6]) {
+    if constexpr (MODE != 2) {
+        if constexpr (SP + 1 < 6) {
+            load_b<MODE, SP + 1>(buf[(SP + 1) & 1], addr);
+            if (MODE == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    f4(&b)[3] = buf[MODE == 2 ? 0 : (SP & 1)];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP + 1 < 6) step<MODE, SP + 1>(U, addr, buf, acc);
+}
+
+template <int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile(float* out, long long* cyc, int tiles) {
+    __shared__ f4 sh[6144];   // 96 KiB: one block per CU
+    for (int i = threadIdx.x; i < 6144; i += blockDim.x) sh[i] = f4{1, 2, 3, 4} * (1.f / (1 + i));
+    U72 U;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) U.u[x][s] = f2{threadIdx.x * 0.001f + x, s * 0.01f};
+    f4 acc[6];
+    for (int i = 0; i < 6; ++i) acc[i] = f4{0, 0, 0, 0};
+    const unsigned addr = (unsigned)(size_t)sh + (threadIdx.x & 63) * 16;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < tiles; ++t) {
+        f4 buf[2][3];
+        if (MODE == 2) { buf[0][0] = f4{1, 2, 3, 4}; buf[0][1] = f4{2, 3, 4, 5}; buf[0][2] = f4{3, 4, 5, 6}; }
+        else load_b<MODE, 0>(buf[0], addr);
+        step<MODE, 0>(U, addr, buf, acc);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    __syncthreads();
+    f4 s4 = acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s4.x + s4.y + s4.z + s4.w;
+    if ((threadIdx.x & 63) == 0) {
+        cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0;
+        cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1;
+    }
+}
+
+typedef void (*kern_t)(float*, long long*, int);
+static void run(const char* name, kern_t k, int threads) {
+    float* out;
+    long long* cyc;
+    (void)hipMalloc(&out, 256 * 1024 * 4);
+    (void)hipMalloc(&cyc, 256 * 16 * 16);
+    const int tiles = 100;
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, out, cyc, tiles);
+    (void)hipDeviceSynchronize();
+    static long long h[256 * 32];
+    (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double span = 0, w0 = 0;
+    for (int b = 0; b < 256; ++b) {
+        long long lo = h[b * 32], hi = h[b * 32 + 1];
+        for (int w = 1; w < threads / 64; ++w) {
+            lo = std::min(lo, h[(b * 16 + w) * 2]);
+            hi = std::max(hi, h[(b * 16 + w) * 2 + 1]);
+        }
+        span += double(hi - lo);
+        w0 += double(h[b * 32 + 1] - h[b * 32]);
+    }
+    span /= 256;
+    w0 /= 256;
+    printf("%-64s %6.2f cycles/MFMA/SIMD   (wave 0: %6.2f per own MFMA)\n", name,
+           span / (tiles * 72.0 * (threads / 256.0)), w0 / (tiles * 72.0));
+    (void)hipFree(out);
+    (void)hipFree(cyc);
+}
+
+int main() {
+    run("tile loop: 3 b128 + 12 MFMA per step, 2 waves/SIMD", k_tile<0, 512>, 512);
+    run("tile loop: 3 b128 + 12 MFMA per step, 1 wave/SIMD", k_tile<0, 256>, 256);
+    run("tile loop: 6 b64 + 12 MFMA per step, 2 waves/SIMD", k_tile<1, 512>, 512);
+    run("tile loop: 6 b64 + 12 MFMA per step, 1 wave/SIMD", k_tile<1, 256>, 256);
+    run("tile loop: no LDS, 12 MFMA per step, 2 waves/SIMD", k_tile<2, 512>, 512);
+    run("tile loop: no LDS, 12 MFMA per step, 1 wave/SIMD", k_tile<2, 256>, 256);
+    return 0;
+}

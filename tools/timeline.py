@@ -15,12 +15,11 @@ from deepbinner_amd import hip_backend                      # noqa: E402
 from deepbinner_amd.model_format import ModelWeights        # noqa: E402
 
 NAMES = {0: 'start', 1: 'A done'}
-# stage B (region layout, dbh_forward.hip: w43_layer): per layer P0 done | barrier | P1 done |
-# own rows stored (conv4: transform done) | end (halos + DMA issued; conv4: stores + barrier)
-for base, end, l in ((2, 61, 'conv2'), (6, 62, 'conv3'), (10, 63, 'conv4')):
-    for j, what in enumerate(['phase0 done', 'barrier', 'phase1 done', 'own rows stored']):
+# stage B (dbh_forward.hip: w43_layer): per layer U phase done | barrier | tile 2's MFMAs done |
+# end (last epilogue + barrier + DMA request)
+for base, l in ((2, 'conv2'), (6, 'conv3'), (10, 'conv4')):
+    for j, what in enumerate(['U phase done', 'barrier', 'tile 2 done', 'end']):
         NAMES[base + j] = '%s %s' % (l, what)
-    NAMES[end] = '%s end' % l
 LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
@@ -32,9 +31,9 @@ for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global
 # the batched tail (every 8th window of a workgroup, or its last): one wave per window
 TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 47: 'tail: conv18 done',
         49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
-ORDER = [0, 1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63] + list(range(14, 45))
-EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 8: 'conv3 phase1 done', 56: 'conv3 arrived',
-         57: 'conv3 transform done', 9: 'conv3 own rows stored', 58: 'conv3 wait done', 62: 'conv3 end'}
+ORDER = list(range(0, 45))
+EXTRA = {59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 6: 'conv3 U phase done', 7: 'conv3 barrier',
+         56: 'conv3 tile 0 done', 57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
 
 
 def main():
@@ -82,7 +81,7 @@ def main():
         # per wave (waves w and w + 4 share a SIMD): when each reaches the marks of stage B
         print('%-26s' % 'mark (mean cycle per wave)' + ''.join('%9s' % ('w%d' % w) for w in range(8)))
         for k, i in enumerate(ids):
-            if i in (1, 2, 3, 4, 5, 61, 6, 7, 8, 9, 62, 10, 11, 12, 13, 63) or 14 <= i <= 44:
+            if 1 <= i <= 44:
                 print('%-26s' % NAMES[i] + ''.join('%9.0f' % rel[:, w, k].mean() for w in range(8)))
     # the batched tail: windows whose workgroup ran it right after them (mark 55 stamped)
     ran = st[:, :, 55].max(axis=1) > 0
