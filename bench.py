@@ -416,8 +416,8 @@ def main():
         rate = windows_per_launch / (avg_ms * 1e-3) if launches else 0.0
         achieved = FLOP_PER_WINDOW * rate / 1e12
         mfmas, executed_flop = hip_backend.forward_executed_mfmas(lead.models[0].n_classes)
-        pmc = pmc_constants()
         bytes_per_window = 1024 * 2 + lead.models[0].n_classes * 4 + 4
+        pmc = pmc_constants()
         result['roofline'] = {
             'bound': 'mfma', 'kernel': 'dbh_forward_kernel', 'achieved': achieved,
             'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
@@ -426,10 +426,15 @@ def main():
             'executed_mfma_per_window': mfmas, 'executed_flop_per_window': executed_flop,
             'achieved_executed': executed_flop * rate / 1e12,
             'frac_executed': executed_flop * rate / 1e12 / PEAK_FP32_TFLOPS,
-            'mfma_pipe_util': pmc.get('mfma_pipe_util'),
-            'mfma_pipe_util_source': pmc.get('mfma_pipe_util_source'),
-            'traffic': pmc.get('hbm_bytes_per_launch'),
-            'traffic_windows_per_launch': pmc.get('windows_per_launch'),
+            # matrix-pipe busy fraction: rocprofv3's SQ_VALU_MFMA_BUSY_CYCLES per window (a constant
+            # of the build, profiles/pmc_traffic.json) over this run's launch time on 1,024 SIMDs
+            'mfma_pipe_util': (pmc['mfma_busy_cycles_per_window'] * rate / (1024 * 2.4e9)
+                               if 'mfma_busy_cycles_per_window' in pmc else None),
+            'mfma_pipe_util_source': pmc.get('source'),
+            # HBM bytes per launch from the PMC passes, scaled to this run's windows per launch
+            'traffic': (pmc['hbm_bytes_per_launch'] * windows_per_launch / pmc['windows_per_launch']
+                        if 'hbm_bytes_per_launch' in pmc and windows_per_launch else None),
+            'traffic_algorithmic': bytes_per_window * windows_per_launch,
             'avg_launch_ms': avg_ms, 'launches_timed': launches,
             'timed_every_nth_launch': TIMING_STRIDE, 'launches_per_event_bracket': TIMING_SPAN,
             'windows_per_launch': windows_per_launch,

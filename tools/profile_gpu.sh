@@ -5,16 +5,15 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/tools/stage_times.py 256 50 > $OUT/stage_times_256.txt 2>&1
-python $R/tools/stage_times.py 4096 10 > $OUT/stage_times_4096.txt 2>&1
+DEEPBINNER_TIMELINE_FUSED=1 DEEPBINNER_TIMELINE_WAVES=1 python $R/tools/timeline.py 5120 > $OUT/timeline_5120_fused.txt 2>&1
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- \
-    python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_stats_bench.log 2>&1
+    python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-side-rates > $OUT/prof_stats_bench.log 2>&1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/prof_pmc_$tag -o pmc -- \
-      python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_pmc_$tag.log 2>&1
+      python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-side-rates > $OUT/prof_pmc_$tag.log 2>&1
 done
 ls -R $OUT | head -60

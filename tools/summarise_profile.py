@@ -13,6 +13,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, 'gpurun_out')
 KERNEL = 'dbh_forward_kernel'
+WINDOWS_PER_LAUNCH = 10000      # bench.py --config 1: one persistent launch per step
+CLOCK_GHZ = 2.4
 
 
 def pmc_summary():
@@ -26,7 +28,8 @@ def pmc_summary():
         sums, counts = {}, {}
         with open(path) as f:
             for row in csv.DictReader(f):
-                # full 256-window launches only (the last launch of a bench step is partial)
+                # the persistent launches of bench.py's steps: 256 workgroups x 512 threads, each
+                # launch = WINDOWS_PER_LAUNCH windows (profile runs skip bench.py's side rates)
                 if KERNEL not in row['Kernel_Name'] or int(row['Grid_Size']) != 256 * 512:
                     continue
                 name = row['Counter_Name']
@@ -52,7 +55,7 @@ def main():
     stats = os.path.join(SRC, 'prof_stats', 'bench_kernel_stats.csv')
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(dst, 'rocprofv3_kernel_stats.csv'))
-    for name in ('stage_times_256.txt', 'stage_times_4096.txt'):
+    for name in ('timeline_5120_fused.txt',):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     log = os.path.join(SRC, 'prof_stats_bench.log')
@@ -68,17 +71,31 @@ def main():
         # 1,024-byte units and FETCH_SIZE under-reports by 2x on gfx950
         traffic = {
             'kernel': KERNEL,
-            'windows_per_launch': 256,
+            'windows_per_launch': WINDOWS_PER_LAUNCH,
             'FETCH_SIZE_KB': s['FETCH_SIZE'],
             'WRITE_SIZE_KB': s['WRITE_SIZE'],
             'hbm_bytes_per_launch': (2.0 * s['FETCH_SIZE'] + s['WRITE_SIZE']) * 1024.0,
+            'algorithmic_bytes_per_launch': WINDOWS_PER_LAUNCH * (2048 + 52 + 4),
             'source': os.path.relpath(dst, REPO) + '/pmc_summary.json',
             'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes '
-                    '(tools/profile_gpu.sh), averaged over the 256-window launches; FETCH_SIZE '
-                    'doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); '
-                    'algorithmic bytes per launch = 256 x (2048 B int16 in + 52 B probs + 4 B '
-                    'call) = 538,624 B in fused seam-b2 mode',
+                    '(tools/profile_gpu.sh), averaged over the persistent 10,000-window launches of '
+                    'bench.py --config 1; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 '
+                    'counts 128-B requests as 64 B); algorithmic bytes per window = 2048 B int16 '
+                    'in + 52 B probs + 4 B call in fused seam-b2 mode',
         }
+        # matrix-pipe busy cycles (summed over the chip's 1,024 SIMDs): a constant of the build per
+        # window (32 cycles x the MFMAs issued); bench.py divides it by ITS launch duration - the
+        # PMC passes themselves run ~8 % slower than an unprofiled launch
+        dur = s.get('_dur_ns_prof_pmc_SQ_WAVE_CYCLES')
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in s and dur:
+            traffic['mfma_busy_cycles_per_window'] = s['SQ_VALU_MFMA_BUSY_CYCLES'] / WINDOWS_PER_LAUNCH
+            traffic['mfma_pipe_util_in_the_pmc_pass'] = (
+                s['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * dur * CLOCK_GHZ))
+            traffic['pmc_pass_launch_ns'] = dur
+            traffic['mfma_per_window_measured'] = s.get('SQ_INSTS_MFMA', 0) / WINDOWS_PER_LAUNCH
+            traffic['valu_per_mfma'] = s.get('SQ_INSTS_VALU', 0) / max(s.get('SQ_INSTS_MFMA', 1), 1)
+            traffic['lds_conflict_fraction'] = (s.get('SQ_LDS_BANK_CONFLICT', 0) /
+                                                max(s.get('SQ_LDS_IDX_ACTIVE', 1), 1))
         json.dump(traffic, open(os.path.join(REPO, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(s, indent=1, sort_keys=True))
 
