@@ -26,11 +26,78 @@ from .model_format import ModelWeights
 from .trim_signal import normalise
 
 
+_DEVICES = None        # HIP ordinals the models are replicated on (set_tensorflow_threads)
+
+
 def build_model(weights):
     """ModelWeights -> device-resident model.  The single place a backend is chosen; there is no
-    CPU implementation to fall back to."""
+    CPU implementation to fall back to.  With several devices (``--devices N``) the model is
+    replicated, one copy per GPU, for the batch dispatcher (``dispatch_batches``)."""
     from .hip_backend import HipModel
+    if _DEVICES and len(_DEVICES) > 1:
+        return ReplicatedModel([HipModel(weights, device=d) for d in _DEVICES])
     return HipModel(weights)
+
+
+class ReplicatedModel:
+    """One trained model resident on several GPUs.  It looks like the model on the first of
+    them (``inputs`` / ``outputs`` / ``predict`` / ``classify_signals`` / ``classify_packed``:
+    what ``load_trained_model`` and ``call_batch`` use); ``replicas`` is what the dispatcher
+    deals batches to."""
+
+    def __init__(self, replicas):
+        self.replicas = list(replicas)
+        first = self.replicas[0]
+        self.inputs, self.outputs = first.inputs, first.outputs
+        self.n_classes, self.input_size = first.n_classes, first.input_size
+        self.predict = first.predict
+        self.classify_signals = first.classify_signals
+        self.classify_packed = first.classify_packed
+
+    def close(self):
+        for r in self.replicas:
+            r.close()
+
+
+def device_replicas(start_model, end_model):
+    """[(start replica, end replica)] per device the models live on; one pair for plain models."""
+    counts = {len(m.replicas) for m in (start_model, end_model) if isinstance(m, ReplicatedModel)}
+    if not counts:
+        return [(start_model, end_model)]
+    n = counts.pop()
+    assert not counts, 'start and end models are replicated on different device sets'
+    pick = lambda m, d: m.replicas[d] if isinstance(m, ReplicatedModel) else m   # noqa: E731
+    return [(pick(start_model, d), pick(end_model, d)) for d in range(n)]
+
+
+def dispatch_batches(batches, replicas, work, depth=2):
+    """The single-process multi-device dispatcher (BASELINE.json configs[4]: one host feeding
+    several GPUs): ``batches`` (any iterator - the loaders produce them ahead of time on their
+    own threads) are dealt round-robin to the devices; device d's worker thread runs
+    ``work(batch, *replicas[d])`` on that device's model replicas - each with its own streams and
+    pinned double buffers behind the C ABI, so the devices' H2D copies, kernels and D2H copies all
+    overlap; at most ``depth`` batches per device are in flight; results come back in the order
+    the batches went in.  The reference is one loop on one device (classify.py:141-171)."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    if len(replicas) == 1:
+        for batch in batches:
+            yield work(batch, *replicas[0])
+        return
+    pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-device-%d' % d)
+             for d in range(len(replicas))]
+    pending = collections.deque()
+    try:
+        for k, batch in enumerate(batches):
+            d = k % len(replicas)
+            pending.append(pools[d].submit(work, batch, *replicas[d]))
+            if len(pending) >= depth * len(replicas):
+                yield pending.popleft().result()
+        while pending:
+            yield pending.popleft().result()
+    finally:
+        for pool in pools:
+            pool.shutdown(wait=True)
 
 
 def classify(args):
@@ -126,23 +193,31 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
         print_output_header(args.verbose, using_read_starts, using_read_ends, output_size)
 
     classifications, read_id_to_fast5_file = {}, {}
-    for loaded in load_in_batches(fast5_files, args):
-        read_ids, signals = [], []
+
+    def classify_loaded(loaded, start_replica, end_replica):
+        """One loaded batch on one device -> (its reads' files, calls, table rows)."""
+        files, read_ids, signals = {}, [], []
         for fast5_file, read_id, signal in loaded:
             if signal is None:
                 continue
-            read_id_to_fast5_file[read_id] = fast5_file
+            files[read_id] = fast5_file
             read_ids.append(read_id)
             signals.append(signal)
         if getattr(loaded, 'complete', False):      # nothing was skipped: the packed buffer
             signals = PackedSignals(signals, loaded.samples, loaded.offsets)   # is these reads
+        calls = {}
+        lines = classify_read_batch(read_ids, signals, start_replica, start_input_size,
+                                    end_replica, end_input_size, output_size, args, calls)
+        return files, calls, lines
 
-        lines = classify_read_batch(read_ids, signals, start_model, start_input_size, end_model,
-                                    end_input_size, output_size, args, classifications)
+    for files, calls, lines in dispatch_batches(load_in_batches(fast5_files, args),
+                                                device_replicas(start_model, end_model),
+                                                classify_loaded):
+        read_id_to_fast5_file.update(files)
+        classifications.update(calls)
         if full_output:
             for line in lines:
                 print(line)
-
         print_classification_progress(len(classifications), len(fast5_files), 'fast5s',
                                       out_dest=out_dest)
 
@@ -242,15 +317,16 @@ class PackedSignals(list):
         self.packed = (samples, offsets)
 
 
-_HELPER = None
+_HELPER = __import__('threading').local()
 
 
 def _helper_thread():
-    global _HELPER
-    if _HELPER is None:
+    """The thread that drives the end model beside the calling thread's start model - one per
+    calling thread, i.e. one per device when the dispatcher runs several."""
+    if getattr(_HELPER, 'pool', None) is None:
         from concurrent.futures import ThreadPoolExecutor
-        _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-end-model')
-    return _HELPER
+        _HELPER.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-end-model')
+    return _HELPER.pool
 
 
 def _independent_models(start_model, end_model):
@@ -546,8 +622,25 @@ def print_classification_progress(completed, total, label, out_dest=None):
 
 def set_tensorflow_threads(args):
     """Reference classify.py:416-423 configured a TensorFlow session.  Here the only runtime
-    choice is which GPU to use: ``DEEPBINNER_DEVICE`` or, under a one-process-per-GPU launcher,
-    ``LOCAL_RANK``.  The TensorFlow thread flags are accepted and ignored."""
+    choice is which GPU(s) to use: ``--devices N`` / ``DEEPBINNER_DEVICES=N`` replicates the models
+    on GPUs 0..N-1 (``DEEPBINNER_DEVICE_ORDINALS=0,0`` names them explicitly - several replicas on
+    one GPU are a test mode for one-GPU boxes) and deals the batches out to them; otherwise
+    ``DEEPBINNER_DEVICE`` or, under a one-process-per-GPU launcher, ``LOCAL_RANK`` picks the one
+    GPU.  The TensorFlow thread flags are accepted and ignored."""
+    global _DEVICES
+    n = int(getattr(args, 'devices', 0) or os.environ.get('DEEPBINNER_DEVICES', 0) or 0)
+    if n > 1:
+        explicit = os.environ.get('DEEPBINNER_DEVICE_ORDINALS')
+        _DEVICES = [int(v) for v in explicit.split(',')] if explicit else list(range(n))
+        if len(_DEVICES) != n:
+            sys.exit('Error: DEEPBINNER_DEVICE_ORDINALS names {} devices, {} asked for'
+                     .format(len(_DEVICES), n))
+        from . import hip_backend
+        visible = hip_backend.device_count()
+        if max(_DEVICES) >= visible:
+            sys.exit('Error: {} GPUs asked for, {} visible'.format(max(_DEVICES) + 1, visible))
+        return
+    _DEVICES = None
     ordinal = os.environ.get('DEEPBINNER_DEVICE', os.environ.get('LOCAL_RANK'))
     if ordinal is not None:
         from . import hip_backend

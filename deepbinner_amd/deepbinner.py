@@ -62,6 +62,9 @@ OPTIONS = [
                                    help='Threads (native reader) or processes (Python reader) '
                                         'that load and decompress fast5 files ahead of the GPU '
                                         '(0 = automatic)')),
+        (('--devices',), dict(type=int, default=0,
+                              help='GPUs to spread the batches over, one model replica each '
+                                   '(0 = DEEPBINNER_DEVICES or one)')),
         # TensorFlow knobs of the reference
         (('--intra_op_parallelism_threads',), dict(type=int, default=12, help=_IGNORED)),
         (('--inter_op_parallelism_threads',), dict(type=int, default=1, help=_IGNORED)),

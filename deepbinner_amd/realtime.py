@@ -206,16 +206,32 @@ class Session:
                 # the total is known once the last container is open; until then, extrapolate
                 total = max((done + len(reads)) * len(fast5s) // n_files, 1)
                 classify.print_classification_progress(done, total, 'reads', out_dest=sys.stdout)
-                for at, chunk in enumerate(classify.chunker(reads, self.args.batch_size)):
-                    ids = [r[0] for r in chunk]
-                    signals = [r[1] for r in chunk]
-                    if getattr(reads, 'complete', False):
-                        # this chunk's part of the container's packed buffer, as the C ABI takes it
-                        lo = at * self.args.batch_size
-                        offsets = reads.offsets[lo:lo + len(chunk) + 1]
-                        signals = classify.PackedSignals(
-                            signals, reads.samples[offsets[0]:offsets[-1]], offsets - offsets[0])
-                    classify.classify_read_batch(ids, signals, *self._models(), self.args, calls)
+                def chunks():
+                    for at, chunk in enumerate(classify.chunker(reads, self.args.batch_size)):
+                        ids = [r[0] for r in chunk]
+                        signals = [r[1] for r in chunk]
+                        if getattr(reads, 'complete', False):
+                            # this chunk's part of the container's packed buffer, as the C ABI
+                            # takes it
+                            lo = at * self.args.batch_size
+                            offsets = reads.offsets[lo:lo + len(chunk) + 1]
+                            signals = classify.PackedSignals(
+                                signals, reads.samples[offsets[0]:offsets[-1]],
+                                offsets - offsets[0])
+                        yield ids, signals
+
+                def classify_chunk(chunk, start_replica, end_replica):
+                    ids, signals = chunk
+                    found = {}
+                    classify.classify_read_batch(ids, signals, start_replica, self.start_size,
+                                                 end_replica, self.end_size, self.n_classes,
+                                                 self.args, found)
+                    return ids, found
+
+                # the chunks go round the devices the models are replicated on (one, usually)
+                replicas = classify.device_replicas(self.start_model, self.end_model)
+                for ids, found in classify.dispatch_batches(chunks(), replicas, classify_chunk):
+                    calls.update(found)
                     table.writelines('{}\t{}\t{}\n'.format(rid, calls[rid], path) for rid in ids)
                     done += len(ids)
                     classify.print_classification_progress(min(done, total), total, 'reads',

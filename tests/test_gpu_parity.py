@@ -746,6 +746,80 @@ def test_realtime_as_the_reference_runs_it_on_the_gpu(hip, tmp_path, capsys, mon
         assert sorted(os.listdir(in_dir)) == want['left_in_in_dir']
 
 
+def test_dispatcher_two_device_queues_reproduce_the_reference(hip, tmp_path, capsys, monkeypatch):
+    """BASELINE.json configs[4] in the small: the single-process multi-device dispatcher with TWO
+    device queues (both on GPU 0: DEEPBINNER_DEVICE_ORDINALS=0,0), batches dealt round-robin,
+    results re-ordered - `classify --devices 2` prints the reference's table, `realtime --devices 2`
+    reproduces the reference's own realtime run (stdout and bins), and a multi-read container is
+    tabulated with the calls the one-read files of the same reads get."""
+    import shutil
+    from conftest import MODEL_DIR, REPO
+    from deepbinner_amd import classify, deepbinner as cli
+    import deepbinner_amd.realtime as realtime
+    monkeypatch.setenv('DEEPBINNER_DEVICE_ORDINALS', '0,0')
+    cases = _reference_cli_cases()
+    models = ['-s', os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+              '-e', os.path.join(MODEL_DIR, 'EXP-NBD103_read_ends.dbw')]
+    # classify: the two-model verbose case of the reference's command-line goldens, batch size 2
+    # so that the seven reads are four batches over the two queues
+    case = cases['native_preset_verbose']           # --native = EXP-NBD103 start + end models
+    argv = [os.path.join(MODEL_DIR, a[7:] + '.dbw') if a.startswith('MODELS/')
+            else os.path.join(REPO, a) if a.startswith('tests/') else a for a in case['argv']]
+    capsys.readouterr()
+    cli.main(argv + ['--devices', '2', '--batch_size', '2'])
+    assert classify._DEVICES == [0, 0]
+    captured = capsys.readouterr()
+    rows = captured.out.splitlines()
+    assert rows[0] == case['header'] and len(rows) - 1 == len(case['rows'])
+    assert [r.split('\t')[:2] for r in sorted(rows[1:])] == \
+        [r.split('\t')[:2] for r in case['rows']]
+    assert captured.err.split('Barcode     Count')[-1].split() == case['summary']
+    # realtime on one-read files: the reference's own run
+    want = cases['realtime_two_models']
+    monkeypatch.setattr(realtime, 'POLL_SECONDS', 0)
+    work = tmp_path / 'single'
+    in_dir, out_dir = work / 'in', work / 'out'
+    shutil.copytree(os.path.join(GOLD, 'fast5', 'single'), in_dir)
+    capsys.readouterr()
+    cli.main(['realtime', '--in_dir', str(in_dir), '--out_dir', str(out_dir), '--stop',
+              '--devices', '2', '--batch_size', '2'] + models)
+    text = capsys.readouterr().out.replace(str(work), '<WORK>') \
+        .replace(MODEL_DIR + '/', 'MODELS/').replace('.dbw', '')
+    # four batches of two reads instead of the reference's one of seven: three more progress
+    # updates on the line; everything else is the reference's output
+    import re
+    text = re.sub(r'\rClassifying fast5s: [246] / 7 \(\d+\.\d%\)', '', text)
+    assert text == want['stdout']
+    assert {d: sorted(os.listdir(out_dir / d)) for d in sorted(os.listdir(out_dir))} == want['tree']
+    # realtime on a multi-read container: every read tabulated once, with the calls a single
+    # device gives (chunks of 4 reads over the two queues)
+    multi = sorted(os.listdir(os.path.join(GOLD, 'fast5', 'multi')))
+    work = tmp_path / 'multi'
+    in_dir, out_dir = work / 'in', work / 'out'
+    os.makedirs(in_dir)
+    for name in multi:
+        shutil.copy(os.path.join(GOLD, 'fast5', 'multi', name), in_dir / name)
+    monkeypatch.setattr(shutil, 'which', lambda tool: None)       # no multi_to_single_fast5
+    cli.main(['realtime', '--in_dir', str(in_dir), '--out_dir', str(out_dir), '--stop',
+              '--devices', '2', '--batch_size', '4'] + models)
+    capsys.readouterr()
+    table = [l.split('\t') for l in
+             (out_dir / 'multi_read_classifications.tsv').read_text().splitlines()]
+    monkeypatch.delenv('DEEPBINNER_DEVICE_ORDINALS')
+    single_dir, single_out = tmp_path / 'multi1' / 'in', tmp_path / 'multi1' / 'out'
+    os.makedirs(single_dir)
+    for name in multi:
+        shutil.copy(os.path.join(GOLD, 'fast5', 'multi', name), single_dir / name)
+    cli.main(['realtime', '--in_dir', str(single_dir), '--out_dir', str(single_out), '--stop',
+              '--batch_size', '4'] + models)
+    assert classify._DEVICES is None
+    capsys.readouterr()
+    want_table = [l.split('\t') for l in
+                  (single_out / 'multi_read_classifications.tsv').read_text().splitlines()]
+    assert len(table) == len(want_table) > 20
+    assert [r[:2] for r in table] == [r[:2] for r in want_table]
+
+
 @pytest.mark.parametrize('name', sorted(k for k, v in _reference_cli_cases().items()
                                         if 'argv' in v))
 def test_command_line_prints_the_reference_table(hip, name, capsys, monkeypatch):

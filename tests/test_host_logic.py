@@ -397,3 +397,58 @@ def test_keras_model_file_import():
     w, shape = ModelWeights.load(ref)
     assert shape == [None, 1024, 1] and w.n_classes == 13
     assert np.array_equal(w.flat(), ModelWeights.load(START_MODEL)[0].flat())
+
+
+def test_dispatch_batches_keeps_order_and_spreads_the_work():
+    """The multi-device dispatcher: batches go round the devices, at most `depth` per device in
+    flight, results come back in input order whatever the devices' speeds."""
+    import threading
+    import time
+    from deepbinner_amd import classify
+    seen, lock, in_flight, peak = [], threading.Lock(), [0], [0]
+
+    def work(batch, start_replica, end_replica):
+        with lock:
+            in_flight[0] += 1
+            peak[0] = max(peak[0], in_flight[0])
+        time.sleep(0.02 if start_replica == 's0' else 0.001)      # device 0 is the slow one
+        with lock:
+            in_flight[0] -= 1
+            seen.append((batch, start_replica, end_replica, threading.current_thread().name))
+        return batch * 10
+
+    replicas = [('s0', 'e0'), ('s1', 'e1'), ('s2', 'e2')]
+    out = list(classify.dispatch_batches(iter(range(20)), replicas, work, depth=2))
+    assert out == [b * 10 for b in range(20)]
+    for batch, s_rep, e_rep, thread in seen:
+        d = batch % 3
+        assert (s_rep, e_rep) == replicas[d] and thread.startswith('deepbinner-device-%d' % d)
+    assert 1 < peak[0] <= 6
+    # one device: no threads at all
+    assert list(classify.dispatch_batches(iter(range(3)), [('s', None)],
+                                          lambda b, s_rep, e_rep: (b, s_rep))) == \
+        [(0, 's'), (1, 's'), (2, 's')]
+    # an exception on a device reaches the caller
+    def boom(batch, *_):
+        if batch == 4:
+            raise RuntimeError('device fell over')
+        return batch
+    try:
+        list(classify.dispatch_batches(iter(range(8)), replicas, boom))
+        assert False
+    except RuntimeError as e:
+        assert 'fell over' in str(e)
+
+
+def test_device_replicas_pairs_the_models_per_device():
+    from deepbinner_amd import classify
+
+    class Fake:
+        inputs = outputs = n_classes = input_size = predict = None
+        classify_signals = classify_packed = None
+
+    a, b, c, d = Fake(), Fake(), Fake(), Fake()
+    start, end = classify.ReplicatedModel([a, b]), classify.ReplicatedModel([c, d])
+    assert classify.device_replicas(start, end) == [(a, c), (b, d)]
+    assert classify.device_replicas(start, None) == [(a, None), (b, None)]
+    assert classify.device_replicas(a, None) == [(a, None)]
