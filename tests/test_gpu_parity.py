@@ -174,6 +174,96 @@ def test_baseline_configurations_match_oracle(hip, hip_models, weights, model_na
     model.set_read_length_hint(0)
 
 
+def _classify_resident(hip, model, d_samples, d_offsets, n, batch, side, stream=None):
+    d_p, d_c = hip.DeviceBuffer(n * model.n_classes * 4), hip.DeviceBuffer(n * 4)
+    model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, batch, side, 512, 0.5, d_p.ptr,
+                               d_c.ptr, stream)
+    hip.synchronize()
+    return d_p.download((n, model.n_classes), np.float32), d_c.download((n,), np.int32)
+
+
+def test_config2_at_full_size(hip, hip_models, weights):
+    """BASELINE.json configs[2] as stated: 100,000 signals (bench.py's, with real-read windows in
+    them) through the EXP-NBD103 start AND end models, batch 512, combine_calls (require_either)
+    on the device.  Parity with the oracle's C port + combine_calls on a 2,000-read subsample
+    spread over the whole set; on all of it: the combined calls follow the oracle's table, a
+    different batch size and the reversed read order give the same bits."""
+    from bench import config_reads
+    from oracle import dbref
+    n = 100000
+    reads = config_reads(n, 20260927)
+    offsets = np.arange(n + 1, dtype=np.int64) * 1024
+    d_s, d_o = hip.DeviceBuffer.from_array(reads), hip.DeviceBuffer.from_array(offsets)
+    start, end = hip_models['EXP-NBD103_read_starts'], hip_models['EXP-NBD103_read_ends']
+    p_s, c_s = _classify_resident(hip, start, d_s, d_o, n, 512, 'start')
+    p_e, c_e = _classify_resident(hip, end, d_s, d_o, n, 512, 'end')
+    d_cs, d_ce = hip.DeviceBuffer.from_array(c_s), hip.DeviceBuffer.from_array(c_e)
+    d_f = hip.DeviceBuffer(n * 4)
+    hip.combine_calls_dev(d_cs.ptr, d_ce.ptr, n, 'require_either', d_f.ptr)
+    hip.synchronize()
+    final = d_f.download((n,), np.int32)
+    name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+    table = np.array([[0 if classify_ref.combine_calls(name(a), name(b), 'require_either') == 'none'
+                       else int(classify_ref.combine_calls(name(a), name(b), 'require_either'))
+                       for b in range(13)] for a in range(13)], dtype=np.int32)
+    assert np.array_equal(final, table[c_s, c_e])
+    assert (c_s != 0).sum() > 100 and (final != 0).sum() > 100       # the real windows do classify
+    # the oracle on a subsample spread over the whole set
+    pick = np.linspace(0, n - 1, 2000).astype(np.int64)
+    sub = np.ascontiguousarray(reads[pick])
+    sub_off = np.arange(len(pick) + 1, dtype=np.int64) * 1024
+    for model_name, side, probs, calls in (('EXP-NBD103_read_starts', 'start', p_s, c_s),
+                                           ('EXP-NBD103_read_ends', 'end', p_e, c_e)):
+        want_probs, want_calls = dbref.CModel(weights[model_name]).classify(
+            sub.reshape(-1), sub_off, side, 512, 0.5)
+        assert np.abs(probs[pick] - want_probs).max() < PROB_TOL
+        for i in np.flatnonzero(calls[pick] != want_calls):     # only on the threshold itself
+            top = np.sort(want_probs[i])[::-1]
+            assert abs((top[0] - top[1]) - 0.5) < 1e-5
+    # invariants on all of it: batch size, read order
+    p2, c2 = _classify_resident(hip, start, d_s, d_o, n, 4096, 'start')
+    assert np.array_equal(p2, p_s) and np.array_equal(c2, c_s)
+    d_r = hip.DeviceBuffer.from_array(np.ascontiguousarray(reads[::-1]))
+    p3, c3 = _classify_resident(hip, end, d_r, d_o, n, 512, 'end')
+    assert np.array_equal(p3[::-1], p_e) and np.array_equal(c3[::-1], c_e)
+
+
+def test_config3_at_full_size(hip, hip_models, weights):
+    """BASELINE.json configs[3]: SQK-RBK004_read_starts, batch 256.  One GPU's 125,000-read shard
+    of the 1,000,000 against the oracle's C port (2,000-read subsample); then all 1,000,000 reads
+    on this GPU (what `bench.py --config 3` times at N = 1): probabilities are distributions, the
+    first shard's results are unchanged inside the whole, and reversing the order of the reads
+    reverses the results bit for bit."""
+    from bench import config_reads
+    from oracle import dbref
+    model = hip_models['SQK-RBK004_read_starts']
+    n = 1000000
+    reads = config_reads(n, 20260927)
+    shard = 125000
+    offsets = np.arange(n + 1, dtype=np.int64) * 1024
+    d_o = hip.DeviceBuffer.from_array(offsets)
+    d_s = hip.DeviceBuffer.from_array(reads[:shard])
+    p_shard, c_shard = _classify_resident(hip, model, d_s, d_o, shard, 256, 'start')
+    pick = np.linspace(0, shard - 1, 2000).astype(np.int64)
+    sub = np.ascontiguousarray(reads[pick])
+    want_probs, want_calls = dbref.CModel(weights['SQK-RBK004_read_starts']).classify(
+        sub.reshape(-1), np.arange(len(pick) + 1, dtype=np.int64) * 1024, 'start', 512, 0.5)
+    assert np.abs(p_shard[pick] - want_probs).max() < PROB_TOL
+    for i in np.flatnonzero(c_shard[pick] != want_calls):
+        top = np.sort(want_probs[i])[::-1]
+        assert abs((top[0] - top[1]) - 0.5) < 1e-5
+    del d_s
+    d_all = hip.DeviceBuffer.from_array(reads)
+    p_all, c_all = _classify_resident(hip, model, d_all, d_o, n, 256, 'start')
+    assert np.array_equal(p_all[:shard], p_shard) and np.array_equal(c_all[:shard], c_shard)
+    assert np.abs(p_all.sum(axis=1) - 1).max() < 1e-5 and p_all.min() >= 0
+    assert ((c_all >= 0) & (c_all < 13)).all() and (c_all != 0).sum() > 100
+    del d_all
+    d_rev = hip.DeviceBuffer.from_array(np.ascontiguousarray(reads[::-1]))
+    p_rev, c_rev = _classify_resident(hip, model, d_rev, d_o, n, 1024, 'start')
+    assert np.array_equal(p_rev[::-1], p_all) and np.array_equal(c_rev[::-1], c_all)
+
+
 @pytest.mark.parametrize('n_classes', [2, 13, 16, 17, 25, 32])
 def test_other_class_counts(hip, weights, all_signals, n_classes):
     """Both endings of the kernel - every class in one N tile (<= 16, no LDS round) and two N

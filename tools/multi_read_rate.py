@@ -8,7 +8,10 @@ The containers are written on the spot by the image's one interpreter with h5py
 write); without it the tool says so and exits.  Reported:
   1. f5_load_reads alone (scanned ends only) at several thread counts, and the Python reader;
   2. load + classify with start and end models, scan_size 6144, batch 256, loading of container
-     k + 1 overlapped with classification of container k on a background thread.
+     k + 1 overlapped with classification of container k on a background thread;
+  3. per number of device queues of the single-process dispatcher (classify.dispatch_batches; on a
+     one-GPU box the queues beyond the first share GPU 0): the GPU side alone (batches already in
+     memory), the loader alone, both together - and which of the two bounds the whole.
 Usage: python tools/multi_read_rate.py [--files 3] [--reads 4000] [--mean-length 27000]"""
 import argparse
 import io
@@ -123,6 +126,70 @@ def main():
         out['load + classify (start and end models, scan 6144, batch 256)'] = {
             'loader_threads': threads, 'seconds': round(dt, 3),
             'reads_per_s': round(opts.files * opts.reads / dt), 'distinct_reads': len(calls)}
+        # ---- 3. the dispatcher, per number of device queues -------------------------------
+        from deepbinner_amd import hip_backend
+        visible = hip_backend.device_count()
+        loaded = [fast5_native.load_reads(p, keep=6144 + 512, threads=threads) for p in paths]
+
+        def batches_of(container):
+            ids, samples, offsets, _ = container
+            signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
+            for lo in range(0, len(ids), args.batch_size):
+                hi = min(lo + args.batch_size, len(ids))
+                yield ids[lo:hi], classify.PackedSignals(
+                    signals[lo:hi], samples[offsets[lo]:offsets[hi]],
+                    offsets[lo:hi + 1] - offsets[lo])
+
+        def work(batch, start_replica, end_replica):
+            found = {}
+            classify.classify_read_batch(batch[0], batch[1], start_replica, si, end_replica, ei,
+                                         osz, args, found)
+            return len(found)
+
+        t0 = time.perf_counter()
+        for p in paths:
+            fast5_native.load_reads(p, keep=6144 + 512, threads=threads)
+        loader_rate = opts.files * opts.reads / (time.perf_counter() - t0)
+        per_devices = {}
+        for n_queues in (1, 2, 4, 8):
+            ordinals = [d % max(visible, 1) for d in range(n_queues)]
+            if n_queues > 1 and visible == 1 and n_queues > 2:
+                continue                    # more than two queues on one GPU says nothing new
+            os.environ['DEEPBINNER_DEVICE_ORDINALS'] = ','.join(map(str, ordinals))
+            classify.set_tensorflow_threads(argparse.Namespace(devices=n_queues))
+            sm_n, _, em_n, _, _, _ = classify.load_and_check_models(
+                os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
+                os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
+            replicas = classify.device_replicas(sm_n, em_n)
+            every = [b for c in loaded for b in batches_of(c)]
+            list(classify.dispatch_batches(iter(every[:8]), replicas, work))          # warm-up
+            t0 = time.perf_counter()
+            done = sum(classify.dispatch_batches(iter(every), replicas, work))
+            gpu_rate = done / (time.perf_counter() - t0)
+
+            def stream():                   # containers loaded one ahead, as realtime does
+                box = []
+                worker = threading.Thread(target=load, args=(paths[0], box))
+                worker.start()
+                for k in range(opts.files):
+                    worker.join()
+                    container = box.pop()
+                    if k + 1 < opts.files:
+                        worker = threading.Thread(target=load, args=(paths[k + 1], box))
+                        worker.start()
+                    yield from batches_of(container)
+
+            t0 = time.perf_counter()
+            done = sum(classify.dispatch_batches(stream(), replicas, work))
+            both = done / (time.perf_counter() - t0)
+            per_devices['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
+                'gpu_side_alone_reads_per_s': round(gpu_rate),
+                'loader_alone_reads_per_s': round(loader_rate),
+                'load_and_classify_reads_per_s': round(both),
+                'bound_by': 'loader' if loader_rate < gpu_rate else 'gpu side (incl. its host work)'}
+        os.environ.pop('DEEPBINNER_DEVICE_ORDINALS', None)
+        out['dispatcher (start + end models, scan 6144, batch 256, %d loader threads)' % threads] = \
+            per_devices
     print(json.dumps(out, indent=1))
 
 
