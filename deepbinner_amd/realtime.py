@@ -10,8 +10,11 @@ the models and the bookkeeping, a ``MoveTally`` does the filing, and multi-read 
 classified straight from the container with this package's fast5 readers
 (``load_fast5s.iter_reads``) - the reference shells out to ``multi_to_single_fast5`` and bins the
 unpacked copies (:183-190), which is still done when that tool is installed.  A multi-read file
-holds reads of many barcodes and cannot be moved into one bin, so without the tool every pass
-appends ``read_id<TAB>barcode<TAB>source_file`` rows to ``<out_dir>/multi_read_classifications.tsv``.
+holds reads of many barcodes and cannot be moved into one bin; without the tool every read is
+written out as a one-read fast5 of its own into its bin by this package's HDF5 writer
+(``hdf5_write``: ``<out_dir>/barcodeNN/<read_id>.fast5``, whole signal, deflate level 1) and every
+pass appends ``read_id<TAB>barcode<TAB>source_file`` rows to
+``<out_dir>/multi_read_classifications.tsv`` (``DEEPBINNER_REALTIME_TABLE_ONLY=1``: only those).
 """
 
 import os
@@ -96,6 +99,7 @@ class Session:
          _) = classify.load_and_check_models(args.start_model, args.end_model, args.scan_size,
                                              out_dest=sys.stdout)
         self.unmovable = set()
+        self.table_only = os.environ.get('DEEPBINNER_REALTIME_TABLE_ONLY') == '1'
         self._prepare_out_dir()
 
     def _prepare_out_dir(self):
@@ -155,21 +159,24 @@ class Session:
 
     def _reads_of(self, path):
         """(read_id, signal) of every read in a multi-read file.  With the native reader the
-        whole file is inflated by its worker threads in one call, and only the scanned ends of
-        long reads come back (all that call_batch looks at)."""
+        whole file is inflated by its worker threads in one call.  When the reads are only
+        tabulated, only the scanned ends of long reads come back (all that call_batch looks at);
+        when they are binned too, the whole signals do."""
         if reader_kind() != 'native':
             return iter_reads(path)
         from . import fast5_native
+        keep = int(self.args.scan_size) + 512 if self.table_only else None
         try:
             ids, samples, offsets, status = fast5_native.load_reads(
-                path, keep=int(self.args.scan_size) + 512,
-                threads=int(getattr(self.args, 'loader_procs', 0) or 0))
+                path, keep=keep, threads=int(getattr(self.args, 'loader_procs', 0) or 0))
         except OSError:
             return []
         classify.warn_about_filters(status)
         reads = classify.PackedBatch((rid, samples[offsets[i]:offsets[i + 1]])
                                      for i, rid in enumerate(ids) if rid is not None)
-        if len(reads) == len(ids):          # nothing dropped: the packed buffer is these reads
+        if len(reads) == len(ids) and keep is not None:
+            # nothing dropped, long reads already cut to their scanned ends: the packed buffer is
+            # what the C ABI takes
             reads.samples, reads.offsets, reads.complete = samples, offsets, True
         return reads
 
@@ -200,9 +207,20 @@ class Session:
             yield path, reads
 
     def _tabulate_multi_read_files(self, fast5s):
-        calls, done = {}, 0
+        from concurrent.futures import ThreadPoolExecutor
+        from .hdf5_write import write_single_read_fast5
+        calls, done, written = {}, 0, []
+        writers = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4),
+                                     thread_name_prefix='deepbinner-fast5-writer')
+
+        def bin_read(read_id, signal, call):
+            target = self.out_dir / bin_name(call)
+            os.makedirs(str(target), exist_ok=True)
+            write_single_read_fast5(str(target / (read_id + '.fast5')), read_id, signal)
+
         with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
             for n_files, (path, reads) in enumerate(self._containers(fast5s), start=1):
+                signals_of = dict(reads) if not self.table_only else {}
                 # the total is known once the last container is open; until then, extrapolate
                 total = max((done + len(reads)) * len(fast5s) // n_files, 1)
                 classify.print_classification_progress(done, total, 'reads', out_dest=sys.stdout)
@@ -233,9 +251,19 @@ class Session:
                 for ids, found in classify.dispatch_batches(chunks(), replicas, classify_chunk):
                     calls.update(found)
                     table.writelines('{}\t{}\t{}\n'.format(rid, calls[rid], path) for rid in ids)
+                    if not self.table_only:      # zlib and file writes release the GIL
+                        written += [writers.submit(bin_read, rid, signals_of[rid], calls[rid])
+                                    for rid in ids]
                     done += len(ids)
                     classify.print_classification_progress(min(done, total), total, 'reads',
                                                            out_dest=sys.stdout)
+        for job in written:
+            job.result()
+        writers.shutdown()
+        if written:
+            print()
+            print('Wrote {:,} one-read fast5 files into {}'.format(len(written), self.out_dir),
+                  end='')
         return calls
 
 

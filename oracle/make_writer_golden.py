@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""
+ORACLE / fixture generator (build container only): pins deepbinner_amd/hdf5_write.py to the real
+HDF5 library and to the reference's own loader.
+
+Writes the seeded one-read fast5 files of tests/test_hdf5_write.py::cases() with this package's
+writer, then - under the image's interpreter that has h5py (/opt/conda/bin/python3.9) - reads every
+file back (a) with h5py directly and (b) with the reference's deepbinner/load_fast5s.py
+(get_read_id_and_signal, get_root_level_keys, determine_single_or_multi_fast5s), imported from
+/root/reference as it is.  What they return goes to tests/golden/writer_reference.json.
+
+Usage: python oracle/make_writer_golden.py
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+CONDA_PYTHON = '/opt/conda/bin/python3.9'
+
+READER = r'''
+import hashlib, json, sys
+sys.path.insert(0, '/root/reference')
+import h5py
+from deepbinner import load_fast5s
+out = {}
+for path in sys.argv[1:]:
+    with h5py.File(path, 'r') as f:
+        keys = list(f.keys())
+        raw = f[keys[0] + '/Raw']
+        sig = raw['Signal']
+        direct = {'keys': keys, 'attrs': sorted(raw.attrs.keys()),
+                  'read_id': raw.attrs['read_id'].decode(), 'shape': list(sig.shape),
+                  'dtype': str(sig.dtype), 'compression': sig.compression,
+                  'sha256': hashlib.sha256(sig[:].astype('<i2').tobytes()).hexdigest()}
+    read_id, signal = load_fast5s.get_read_id_and_signal(path)
+    out[path.split('/')[-1]] = {
+        'h5py': direct,
+        'reference_loader': {'read_id': read_id, 'length': int(len(signal)),
+                             'dtype': str(signal.dtype),
+                             'sha256': hashlib.sha256(signal.astype('<i2').tobytes()).hexdigest(),
+                             'root_keys': load_fast5s.get_root_level_keys(path)},
+    }
+out['determine_single_or_multi_fast5s'] = load_fast5s.determine_single_or_multi_fast5s(list(sys.argv[1:]))
+print(json.dumps(out))
+'''
+
+
+def main():
+    from test_hdf5_write import cases
+    from deepbinner_amd import hdf5_write
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, want = [], {}
+        for name, read_id, signal, compress in cases():
+            path = os.path.join(tmp, name + '.fast5')
+            hdf5_write.write_single_read_fast5(path, read_id, signal, compress=compress)
+            paths.append(path)
+            want[name + '.fast5'] = {'read_id': read_id, 'length': int(len(signal)),
+                                     'sha256': hashlib.sha256(signal.astype('<i2').tobytes()).hexdigest()}
+        got = json.loads(subprocess.check_output([CONDA_PYTHON, '-c', READER] + paths))
+    for name, expect in want.items():
+        for reader in ('h5py', 'reference_loader'):
+            assert got[name][reader]['read_id'] == expect['read_id'], (name, reader)
+            assert got[name][reader]['sha256'] == expect['sha256'], (name, reader)
+    out = os.path.join(REPO, 'tests', 'golden', 'writer_reference.json')
+    with open(out, 'w') as f:
+        json.dump({'written': want, 'read_back': got}, f, indent=1, sort_keys=True)
+    print('wrote', out, '-', len(want), 'files read back identically by h5py and the reference')
+
+
+if __name__ == '__main__':
+    main()
