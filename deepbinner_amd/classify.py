@@ -169,6 +169,10 @@ def load_trained_model(model_file, out_dest=None):
     out_shape = tuple(model.outputs[0].shape)
     if len(out_shape) < 2:
         sys.exit(invalid)
+    if hasattr(model, 'classify_packed') and int(shapes[0][1]) != MODEL_INPUT_SIZE:
+        # the loaders keep scanned_end_samples() of each read end, sized for this input length
+        sys.exit('Error: model input size {} is not supported (the loaders and the device library '
+                 'are built for {})'.format(int(shapes[0][1]), MODEL_INPUT_SIZE))
     return model, int(shapes[0][1]), int(out_shape[1])
 
 
@@ -228,6 +232,17 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
     return classifications, read_id_to_fast5_file
 
 
+MODEL_INPUT_SIZE = 1024        # every shipped model; dbh_model_create refuses anything else
+
+
+def scanned_end_samples(scan_size, input_size=MODEL_INPUT_SIZE):
+    """Samples at either end of a read that some window can touch: the loaders may drop the
+    middle of longer reads.  Windows start every input_size // 2 samples up to scan_size and are
+    input_size long (reference classify.py:330-349).  The loaders run before any model object is
+    in reach, hence the constant - which is also what the device library insists on."""
+    return int(scan_size) + input_size // 2
+
+
 def load_in_batches(fast5_files, args):
     """The reference's ``for fast5_batch in chunker(...)`` + per-file load (classify.py:141-150):
     yields, per batch of ``args.batch_size`` files, the list of (fast5_file, read_id, signal).
@@ -242,7 +257,7 @@ def load_in_batches(fast5_files, args):
             yield [(f,) + tuple(get_read_id_and_signal(f)) for f in fast5_batch]
         return
     # only the scanned ends of a read matter to call_batch: spare the result pipe the middle
-    keep = int(args.scan_size) + 512
+    keep = scanned_end_samples(args.scan_size)
     with LoaderPool(procs) as pool:
         batch = []
         for item in pool.load(list(fast5_files), keep):
@@ -261,7 +276,7 @@ def _native_batches(fast5_files, args):
     call releases the GIL - while the caller classifies the current one."""
     from concurrent.futures import ThreadPoolExecutor
     from . import fast5_native
-    keep = int(args.scan_size) + 512
+    keep = scanned_end_samples(args.scan_size)
     threads = int(getattr(args, 'loader_procs', 0) or 0) or max(1, min(32, (os.cpu_count() or 4) // 4))
     batches = list(chunker(fast5_files, args.batch_size))
 
@@ -439,6 +454,12 @@ def classify_training_data(input_file, start_model, start_input_size, end_model,
         read_ids = ['line_{}_barcode_{}'.format(first + k + 1, label)
                     for k, (label, _) in enumerate(batch)]
         signals = [np.array([int(v) for v in values.split(',')]) for _, values in batch]
+        for k, signal in enumerate(signals):
+            # the device path carries raw signals as int16, which is what a sequencer produces;
+            # the reference would normalise any integers (float64) - say which line it is
+            if len(signal) and (signal.min() < -32768 or signal.max() > 32767):
+                sys.exit('Error: line {} of {} holds signal values outside the int16 range'
+                         .format(first + k + 1, input_file))
         calls, probs = call_batch(input_size, output_size, read_ids, signals, model, args, 'start')
         for read_id, call, row in zip(read_ids, calls, probs):
             classifications[read_id] = call

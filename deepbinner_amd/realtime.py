@@ -165,7 +165,7 @@ class Session:
         if reader_kind() != 'native':
             return iter_reads(path)
         from . import fast5_native
-        keep = int(self.args.scan_size) + 512 if self.table_only else None
+        keep = classify.scanned_end_samples(self.args.scan_size) if self.table_only else None
         try:
             ids, samples, offsets, status = fast5_native.load_reads(
                 path, keep=keep, threads=int(getattr(self.args, 'loader_procs', 0) or 0))

@@ -186,3 +186,29 @@ def test_the_readme_walkthrough(oracle_backend, tmp_path, capsys, monkeypatch):
         work = tmp_path / str(k)
         work.mkdir()
         check_the_readme_walkthrough(run_the_readme_walkthrough(work, capsys), want)
+
+
+def test_training_data_outside_int16_is_an_error_with_a_line_number(oracle_backend, tmp_path,
+                                                                     monkeypatch):
+    """the device path carries int16; an out-of-range value in a training-data file is
+    reported as an Error naming the line instead of a traceback from deep inside."""
+    import deepbinner_amd.classify as classify
+
+    class Int16Only:            # stands for the device model: it has the packed entry point
+        def __init__(self, w):
+            self.inner = __import__('conftest').OracleModel(w)
+            self.inputs, self.outputs = self.inner.inputs, self.inner.outputs
+
+        def predict(self, x, batch_size=None):
+            return self.inner.predict(x)
+
+    monkeypatch.setattr(classify, 'build_model', lambda w: Int16Only(w))
+    from conftest import MODEL_DIR
+    path = tmp_path / 'train.txt'
+    ok = ','.join(str(400 + (i * 37) % 200) for i in range(1100))
+    bad = ','.join(str(400 + (i * 37) % 200) for i in range(500)) + ',70000,' + ok
+    path.write_text('1\t%s\n2\t%s\n' % (ok, bad))
+    with pytest.raises(SystemExit) as e:
+        cli.main(['classify', '-s', os.path.join(MODEL_DIR, 'EXP-NBD103_read_starts.dbw'),
+                  '--scan_size', '1024', str(path)])
+    assert 'line 2' in str(e.value) and 'int16' in str(e.value)
