@@ -137,6 +137,16 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// The two waves of a SIMD share its matrix pipe, and the older one wins every tie: it runs ahead,
+// finishes its share of a phase early, and the younger one then runs ALONE - at 57 % of the pipe's
+// rate (a lone wave cannot keep the fp32 matrix pipe fed: tools/microbench/tile_loop.hip).  So a
+// wave's priority falls as it gets further into the stretch between two barriers (STEP of STEPS):
+// whoever is behind catches up and both reach the barrier together.  (+0.6 % on the whole kernel.)
+template <int STEP, int STEPS>
+__device__ __forceinline__ void progress_priority() {
+    __builtin_amdgcn_s_setprio(3 - (4 * STEP) / STEPS);
+}
+
 template <int MT, int NT>
 struct Frags {
     f2 a[MT];
@@ -213,6 +223,7 @@ __device__ __forceinline__ void conv_step(unsigned a_addr, unsigned b_addr, Frag
         frag_wait<0>(buf[IT & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    progress_priority<IT, NIT>();
     const Frags<MT, NT>& f = buf[IT & 1];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -528,6 +539,7 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
         wino_wait<0>(buf[SP_IDX & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    progress_priority<SP_IDX, 6>();
     const WinoFrags<MT>& f = buf[SP_IDX & 1];
     f2 u[2][MT];     // both components at once (v_pk_add_f32), in one block ahead of the MFMAs
 #pragma unroll
@@ -759,7 +771,7 @@ __device__ __forceinline__ void w43_load_b(f4 (&b)[3], unsigned b_addr) {
 // MFMA - no v_mov per register, and VALU work is not free beside fp32 MFMAs), M1's from the bias.
 // TILE0: the step also fetches the input rows of the NEXT channel group and turns this one's
 // into U[.][SP] - tile 0 builds the register-resident U that tiles 1 and 2 reuse.
-template <bool TILE0, int SP, class Side>
+template <bool TILE0, int STEP0, int STEPS, int SP, class Side>
 __device__ __forceinline__ void w43_tile_step(W43U& U, unsigned a_addr, unsigned b_addr,
                                               f2 (&dbuf)[2][6], f4 (&buf)[2][3], f4 (&acc)[6],
                                               float bias, const Side& side) {
@@ -774,6 +786,7 @@ __device__ __forceinline__ void w43_tile_step(W43U& U, unsigned a_addr, unsigned
     f4(&b)[3] = buf[SP & 1];
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    progress_priority<STEP0 + SP, STEPS>();
     if constexpr (TILE0) {
         f2(&d)[6] = dbuf[SP & 1];
 #pragma unroll
@@ -808,10 +821,11 @@ __device__ __forceinline__ void w43_tile_step(W43U& U, unsigned a_addr, unsigned
     side(IntC<SP>{});      // the caller's work for this step (a piece of the tile before's epilogue)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP + 1 < 6)
-        w43_tile_step<TILE0, SP + 1>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
+        w43_tile_step<TILE0, STEP0, STEPS, SP + 1>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
 }
 
-template <bool TILE0, class Side>
+// STEP0 of STEPS: where this tile's six steps lie in the stretch between two barriers
+template <bool TILE0, int STEP0, int STEPS, class Side>
 __device__ __forceinline__ void w43_tile(W43U& U, const float* a_lane, const float* slot_lane,
                                          f4 (&acc)[6], float bias, const Side& side) {
     const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
@@ -819,7 +833,7 @@ __device__ __forceinline__ void w43_tile(W43U& U, const float* a_lane, const flo
     f4 buf[2][3];
     if constexpr (TILE0) w43_load_rows<0>(dbuf[0], a_addr);
     w43_load_b<0>(buf[0], b_addr);
-    w43_tile_step<TILE0, 0>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
+    w43_tile_step<TILE0, STEP0, STEPS, 0>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
 }
 
 // Half (h = rows 2h, 2h+1 of every accumulator = quads 2q + 8h, 2q + 1 + 8h of the wave's tile)
@@ -892,14 +906,14 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     W43U U;
     f4 acc[2][6];
     // tile 0: reads the wave's input rows step by step and builds U on the way
-    w43_tile<true>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
+    w43_tile<true, 0, 6>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
     mark(ts, ts_base);
     __syncthreads();      // every wave has read all its input rows (and has left tile 0): from
     mark(ts, ts_base + 1);   // here on the outputs may be stored in place
     if (POOL) zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);   // (row 0 is zero already)
     next_third(0, lds + kSlot0);
     // tile 1, with tile 0's epilogue inside its steps 1 and 3
-    w43_tile<false>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
+    w43_tile<false, 0, 12>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
         if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_lane, wave, q);
         if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_lane, wave, q);
@@ -908,7 +922,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     sync_rounds += kWaves;
     if (ts_base == 6) mark(ts, 57);
     // tile 2, with tile 1's epilogue inside
-    w43_tile<false>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
+    w43_tile<false, 6, 12>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
         if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_lane, wave, q);
         if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_lane, wave, q);
@@ -964,14 +978,17 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     }
     const float* a_lane = lds + kActOff + (m * 32 + 2 * n) * kS48 + 2 * q;
     float* mine = lds + XCHG + (wave & 3) * 6 * 256 + lane * 4;     // slot shared by the pair
+    if (ts_base == 26) mark(ts, 48);
     if (!high) {
         wino_phase<1, 0>(a_lane, lds + SLOT_A + lane * 2, acc, step_side);
+        if (ts_base == 26) mark(ts, 50);
         if (!POOL) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(mine + t * 256) = acc[1][0][t];
         }
     } else {
         wino_phase<1, 1>(a_lane, lds + SLOT_B + lane * 2, acc, step_side);
+        if (ts_base == 26) mark(ts, 50);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             *reinterpret_cast<f4*>(mine + (3 + t) * 256) = acc[2][0][t];
