@@ -1511,6 +1511,21 @@ __device__ __forceinline__ void window_mean_inv(const float* lds, int cnt, doubl
 // Seam-b2 input of one window, straight from the read's int16 samples: this lane's two samples
 // for the window statistics (positions tid and tid + 512 of the slice) and its four A-fragment
 // samples for conv1d_1 (position 2*(16*(m0+m)+n) + q of the zero-padded window; q = tap).
+__device__ __forceinline__ void fetch_window_at(const int16_t* __restrict__ src, int cnt,
+                                                int pad_left, int tid, int m0, int n, int q,
+                                                int& v0, int& v1, int (&raw)[4],
+                                                bool (&inside)[4]) {
+    // src = first sample of the window's slice (wave-uniform), cnt of them; every index below is
+    // a 32-bit lane offset from it
+    v0 = tid < cnt ? (int)src[(unsigned)tid] : 0;
+    v1 = tid + 512 < cnt ? (int)src[(unsigned)(tid + 512)] : 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
+        inside[m] = q < 3 && k >= 0 && k < cnt;
+        raw[m] = inside[m] ? (int)src[(unsigned)(inside[m] ? k : 0)] : 0;
+    }
+}
 __device__ __forceinline__ void fetch_window(const int16_t* __restrict__ samples, long long base,
                                              long long len, int step, int side, int tid, int m0,
                                              int n, int q, int& cnt, int& v0, int& v1,
@@ -1518,16 +1533,8 @@ __device__ __forceinline__ void fetch_window(const int16_t* __restrict__ samples
     long long wa, wb;
     window_bounds(len, step, side, &wa, &wb);
     cnt = (int)(wb - wa);
-    const int16_t* src = samples + base + wa;
-    const int pad_left = (side == 0) ? 0 : kWindow - cnt;
-    v0 = tid < cnt ? (int)src[tid] : 0;
-    v1 = tid + 512 < cnt ? (int)src[tid + 512] : 0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
-        inside[m] = q < 3 && k >= 0 && k < cnt;
-        raw[m] = inside[m] ? (int)src[k] : 0;
-    }
+    fetch_window_at(samples + base + wa, cnt, (side == 0) ? 0 : kWindow - cnt, tid, m0, n, q, v0,
+                    v1, raw, inside);
 }
 
 // =============================================================================================
@@ -1776,6 +1783,19 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         return;
     }
 
+    // the next window's slice of its read (scalar arithmetic on the offsets asked for after stage
+    // A): by stage E only the loads themselves are left to issue
+    const int16_t* next_src = nullptr;
+    int next_cnt = 0, next_pad = 0;
+    if (has_next) {
+        ArgsPtr a = args();
+        long long wa, wb;
+        const int nside = a->side;
+        window_bounds(next_len, (int)(next_win % a->steps), nside, &wa, &wb);
+        next_cnt = (int)(wb - wa);
+        next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
+        next_src = glob(a->samples) + next_base + wa;
+    }
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
     // while conv8 runs, long before stage F needs them; conv9's Winograd matrices go to the top
@@ -1819,18 +1839,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
-#ifdef DBH_EXP_D3
-    r17.template prefetch_slice<0, 27>(packed, lane, wave);
-#endif
     {
         // The next window's samples start their trip from HBM now (stages E-H, ~25k cycles, are
         // far more than it takes) and are used at the top of the next round's stage A; the
         // registers they land in were last read in this window's stage A.
         prefetched = has_next;
         if (has_next) {
-            ArgsPtr a = args();
-            fetch_window(glob(a->samples), next_base, next_len, (int)(next_win % a->steps), a->side, tid,
-                         wave * kMtA, n, q, in_cnt, in_v0, in_v1, in_raw, in_inside);
+            in_cnt = next_cnt;
+            fetch_window_at(next_src, next_cnt, next_pad, tid, wave * kMtA, n, q, in_v0, in_v1,
+                            in_raw, in_inside);
         }
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
