@@ -105,7 +105,9 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                                 const size_t idx =
                                     kConv[i].wino == 4
                                         ? (((((size_t)t * sp_n + sp) * 3 + (xi >> 1)) * 64 + lane) * 2 + (xi & 1)) * 2 + e
-                                        : ((((size_t)xi * sp_n + sp) * nt + t) * 64 + lane) * 2 + e;
+                                        : wino2_by_tile(i)
+                                              ? (((((size_t)t * sp_n + sp) * 2 + (xi >> 1)) * 64 + lane) * 2 + (xi & 1)) * 2 + e
+                                              : ((((size_t)xi * sp_n + sp) * nt + t) * 64 + lane) * 2 + e;
                                 dst[idx] = (float)v;
                             }
             }

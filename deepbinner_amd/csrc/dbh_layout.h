@@ -47,6 +47,9 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {1, 48, 32, 1, 0},    // conv1d_20  (n_classes <= 32, zero padded)
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
+// F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
+// N-tile-outer loops of dbh_forward.hip (conv1d_7); the others are matrix-major.
+constexpr bool wino2_by_tile(int i) { return i == 6; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
