@@ -163,6 +163,19 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier, and
+// the fence drains EVERYTHING the wave has in flight - s_waitcnt vmcnt(0) - including the global
+// prefetches this kernel deliberately keeps running across layers (the next window's samples,
+// conv17's weight fragments, LDS-DMA pieces for a later layer): each such barrier then exposes
+// an L2/HBM round trip.  Use this where the waves exchange data through LDS alone and nothing
+// that was DMA'd since the last full barrier is read before the next one.
+// VM = how many of the wave's most recent vector-memory requests may stay in flight (63 = all).
+template <int VM = 63>
+__device__ __forceinline__ void lds_barrier() {
+    static_assert(VM >= 0 && VM <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
 // One ds_read_b64 the compiler cannot see.  hipcc's own wait-count pass drains ALL outstanding LDS
 // reads (lgkmcnt(0)) in front of every second MFMA group of this loop, exposing a full LDS
 // round trip each time; issuing the reads from inline asm and counting them by hand
@@ -448,7 +461,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc, side);
     mark(ts, ts_base);
 
-    __syncthreads();   // every wave has finished reading the old activations and weights
+    lds_barrier();     // every wave has finished reading the old activations and weights
     mark(ts, ts_base + 1);
 
     float* out_lane = lds + kActOff +
@@ -814,7 +827,7 @@ __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float*
     f4 acc[2][4];
     w23_tile<true, 0, 6>(U, a_lane, lds + W_LDS + lane * 4, acc[0], ep.b[0], NoSide(), begin);
     mark(ts, ts_base);
-    __syncthreads();      // every wave has read all its input rows: outputs may go in place
+    lds_barrier();        // every wave has read all its input rows: outputs may go in place
     mark(ts, ts_base + 1);
     zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);       // (row 0 is zero already)
     w23_tile<false, 0, 12>(U, a_lane, lds + W_LDS + kTile + lane * 4, acc[1], ep.b[1], [&](auto tag) {
@@ -1154,7 +1167,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     }
     mark(ts, ts_base);
 
-    __syncthreads();      // activations fully read; exchange tiles visible
+    lds_barrier();        // activations fully read; exchange tiles visible
     mark(ts, ts_base + 1);
 
     float* out = lds + kActOff + n;
@@ -1316,7 +1329,7 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         }
         pre_barrier();
         mark(ts, ts_base);
-        __syncthreads();
+        lds_barrier();
         mark(ts, ts_base + 1);
         post_barrier();
         if (wave < 3) {
@@ -1577,6 +1590,19 @@ __device__ __forceinline__ void renormalise_and_call(float merged, int c, int n_
     if (c == 0) *call_out = (best.i != 0 && (best.v - second) >= score_diff) ? best.i : 0;
 }
 
+// Window w of a launch = (read w / steps, scan step w % steps).  Window indices fit 32 bits
+// (n_windows is an int) and steps == 1 - whole reads, the classify path - needs no division at
+// all; a 64-bit division is ~150 scalar instructions that every wave would run per window.
+__device__ __forceinline__ void split_window(unsigned win, int steps, unsigned* read, int* step) {
+    if (steps == 1) {
+        *read = win;
+        *step = 0;
+    } else {
+        *read = win / (unsigned)steps;
+        *step = (int)(win - *read * (unsigned)steps);
+    }
+}
+
 // Window bounds of scan step `step` inside a read of `len` samples (classify.py:337-349).
 __device__ __forceinline__ void window_bounds(long long len, int step, int side, long long* a,
                                               long long* b) {
@@ -1824,8 +1850,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 const int steps = a->steps, side = a->side;
                 const long long read0 = a->read0, len_hint = a->len_hint, hint_cap = a->hint_cap;
                 const long long* __restrict__ offsets = glob(a->offsets);
-                const long long read = win / steps;
-                const int step = (int)(win - read * steps);
+                unsigned read;
+                int step;
+                split_window((unsigned)win, steps, &read, &step);
                 // Where a read starts is itself in memory (offsets[read]), and at the top of a
                 // kernel a dependent load costs ~3k cycles.  If the caller says that all reads are
                 // len_hint samples long, the samples are requested from where that puts them
@@ -1886,10 +1913,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const long next_win = win + gridDim.x;
     const bool has_next = args()->samples != nullptr && next_win < n_windows;
     long long next_base = 0, next_len = 0;
+    int next_step = 0;
     if (has_next) {
         ArgsPtr a = args();
         const long long* __restrict__ offsets = glob(a->offsets);
-        const long long next_read = next_win / a->steps;
+        unsigned next_read;
+        split_window((unsigned)next_win, a->steps, &next_read, &next_step);
         next_base = offsets[next_read];
         next_len = offsets[next_read + 1] - next_base;
     }
@@ -1947,7 +1976,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         ArgsPtr a = args();
         long long wa, wb;
         const int nside = a->side;
-        window_bounds(next_len, (int)(next_win % a->steps), nside, &wa, &wb);
+        window_bounds(next_len, next_step, nside, &wa, &wb);
         next_cnt = (int)(wb - wa);
         next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
         next_src = glob(a->samples) + next_base + wa;
@@ -1960,34 +1989,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     r17.prefetch_epilogue(packed, 5, lane, wave);
     wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
         lds, packed, tid, lane, wave, ts, 26,
-#ifdef DBH_EXP_D1
-        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave);
-              r17.template prefetch_slice<0, 27>(packed, lane, wave); }, NoSide());
-#elif defined(DBH_EXP_D3)      // timing only: conv17's weights fetched late (before stage E)
-        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
-        NoSide());
-#else
         [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
         interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
             constexpr int IT = decltype(tag)::value;
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
         }));
-#endif
     // BN5's scale/shift (384 floats, too many for the parameter table): one per thread, fetched
     // here, parked in LDS at the top of stage E
     const float bn5v = tid < 2 * 192 ? packed[bn_scale_offset(4) + tid] : 0.f;
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
         lds, packed, tid, lane, wave, ts, 30,
-#ifdef DBH_EXP_D2
-        [&] { dma_weights<kEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave); }, NoSide());
-#else
         [] {},
         [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
             dma_weights_slice<kEWFloats, decltype(tag)::value, 6>(packed + weight_offset(9),
                                                                   lds + kEW, lane, wave);
         });
-#endif
     if (stop_stage == 3) {
         if (debug_stage < 100)
             dump_stage(lds + kEX, kS48, 64, 48, glob(args()->debug_out) + win * kStageFloats[3], tid);
@@ -2032,7 +2049,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         zero_row(lds + kECat, 0, kS192, 192, tid);
         zero_row(lds + kECat, 33, kS192, 192, tid);
         if (tid < 2 * 192) lds[kEBn5 + tid] = bn5v;
-        __syncthreads();
+        lds_barrier();
         mark(ts, 34);
 
         constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
@@ -2065,7 +2082,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                           bias_tab + bias_offset(13), nullptr, nullptr, 0, lane);
         }
         mark(ts, 35);
-        __syncthreads();
+        lds_barrier();
         mark(ts, 36);
 
         // E2: conv15 (16->48, k3) -> T4b, the only input of E3 not ready yet
@@ -2076,7 +2093,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                                      nullptr, nullptr, t, m0, lane);
         }
         mark(ts, 37);
-        __syncthreads();
+        lds_barrier();
         mark(ts, 38);
 
         // E3: conv16 (48->48, k3) -> concat 144..191 on waves 0-5 and conv13 (16->48, k3) ->
@@ -2095,7 +2112,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                                      sh5 + 96, 0, m0, lane);
         }
         mark(ts, 39);
-        __syncthreads();
+        lds_barrier();
         mark(ts, 40);
     }
     if (stop_stage == 4) {

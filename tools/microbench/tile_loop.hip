@@ -103,6 +103,8 @@ __global__ __launch_bounds__(THREADS) void k_tile(float* out, long long* cyc, in
     if ((threadIdx.x & 63) == 0) {
         cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0;
         cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1;
+        // HW_ID (hardware register 4): SIMD_ID = bits 5:4, CU_ID = bits 11:8
+        if (blockIdx.x == 0) cyc[256 * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 }
 
@@ -111,7 +113,7 @@ static void run(const char* name, kern_t k, int threads) {
     float* out;
     long long* cyc;
     (void)hipMalloc(&out, 256 * 1024 * 4);
-    (void)hipMalloc(&cyc, 256 * 16 * 16);
+    (void)hipMalloc(&cyc, 256 * 16 * 16 + 16 * 8);
     const int tiles = 100;
     for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, out, cyc, tiles);
     (void)hipDeviceSynchronize();
@@ -131,6 +133,16 @@ static void run(const char* name, kern_t k, int threads) {
     w0 /= 256;
     printf("%-64s %6.2f cycles/MFMA/SIMD   (wave 0: %6.2f per own MFMA)\n", name,
            span / (tiles * 72.0 * (threads / 256.0)), w0 / (tiles * 72.0));
+    // block 0, wave by wave: which SIMD it ran on, when it started and ended (relative to the
+    // block's first start): how the two waves of a SIMD share the matrix pipe
+    long long ids[16];
+    (void)hipMemcpy(ids, cyc + 256 * 32, sizeof(ids), hipMemcpyDeviceToHost);
+    long long first = h[0];
+    for (int w = 1; w < threads / 64; ++w) first = std::min(first, h[w * 2]);
+    for (int w = 0; w < threads / 64; ++w)
+        printf("    wave %d  simd %lld  cu %lld  start %8lld  end %8lld  (%.2f per own MFMA)\n", w,
+               (ids[w] >> 4) & 3, (ids[w] >> 8) & 15, h[w * 2] - first, h[w * 2 + 1] - first,
+               double(h[w * 2 + 1] - h[w * 2]) / (tiles * 72.0));
     (void)hipFree(out);
     (void)hipFree(cyc);
 }
