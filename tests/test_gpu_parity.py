@@ -474,6 +474,31 @@ def test_batched_pipeline_matches_single_call(hip, hip_models, all_signals, side
         assert np.array_equal(d_p.download((n, 13), np.float32), want_p)
 
 
+@pytest.mark.parametrize('cap', [1, 3, 4])
+def test_workgroups_take_their_windows_two_at_a_time(hip, hip_models, weights, all_signals, cap,
+                                                     monkeypatch):
+    """A workgroup with more than one window runs stage D (conv8, conv9) for two of them at a time
+    - the first parked in global memory after conv7, its conv9 output after that - and a last
+    window of an odd share alone.  DEEPBINNER_GRID_CAP makes shares long out of few windows: the
+    results must equal, bit for bit, those of one window per workgroup (what fewer windows than
+    CUs get), on both seams, for odd and even shares and across batched-tail boundaries."""
+    wide = hip_models['EXP-NBD103_read_starts']
+    monkeypatch.setenv('DEEPBINNER_GRID_CAP', str(cap))
+    narrow = hip.HipModel(weights['EXP-NBD103_read_starts'], device=0)
+    monkeypatch.delenv('DEEPBINNER_GRID_CAP')
+    base = np.load(os.path.join(GOLD, 'windows_start.npy')).reshape(-1, 1024)
+    rng = np.random.default_rng(cap)
+    for n in (1, 2, 3, 8 * cap, 8 * cap + 1, 17 * cap + 2, 37):
+        x = base[rng.integers(0, len(base), size=n)] + \
+            (rng.standard_normal((n, 1024)) * 0.01).astype(np.float32)
+        assert np.array_equal(narrow.predict(x), wide.predict(x)), n
+    signals = [all_signals[i % len(all_signals)][:int(rng.integers(0, 3000))] for i in range(45)]
+    for side, scan in (('start', 512), ('end', 512), ('start', 2048)):
+        want_p, want_c = wide.classify_signals(signals, side, scan, 0.5)
+        got_p, got_c = narrow.classify_signals(signals, side, scan, 0.5)
+        assert np.array_equal(got_c, want_c) and np.array_equal(got_p, want_p), (side, scan)
+
+
 @pytest.mark.parametrize('side,scan', [('start', 6144), ('end', 6144), ('start', 512), ('end', 512)])
 def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, side, scan):
     """slice+normalise (and, at one scan step, renormalise+call) fused into the CNN kernel must
