@@ -253,12 +253,13 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         }
         // production launches are persistent: at most one workgroup per CU, each walking its
         // share of the windows; the debug / timeline modes keep one workgroup per window
-        const bool one_per_window = debug_stage >= 0 && debug_stage != 301 && debug_stage != 302;
+        const bool one_per_window = debug_stage >= 0 && debug_stage != 301;
         const unsigned grid = (unsigned)(one_per_window || cnt < m->cus ? cnt : m->cus);
         void** tail = in.tail ? in.tail : &m->d_tail;
         size_t* tail_bytes = in.tail_bytes ? in.tail_bytes : &m->tail_bytes;
         {
-            const int st = ensure(tail, tail_bytes, (size_t)grid * dbh::kWgScratchFloats * sizeof(float));
+            const int st = ensure(tail, tail_bytes, (size_t)grid * dbh::kTailBatch *
+                                                        dbh::kTailSlotFloats * sizeof(float));
             if (st != DBH_OK) return st;
         }
         dbh::ForwardArgs a;
@@ -451,7 +452,8 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
         if (e == hipSuccess && cus > 0) m->cus = cus;
         // DEEPBINNER_GRID_CAP=n: at most n workgroups per launch (tests: long shares of windows
-        // per workgroup - pairs, odd shares, full tail batches - out of a few hundred windows)
+        // per workgroup - prefetch across windows, full and partial tail batches - out of a few
+        // hundred windows)
         if (const char* cap = std::getenv("DEEPBINNER_GRID_CAP")) {
             const int c = std::atoi(cap);
             if (c > 0 && c < m->cus) m->cus = c;
@@ -886,7 +888,7 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
         a.debug_stage = 300;
         a.steps = 1;
         st = ensure(&m->d_tail, &m->tail_bytes,
-                    (size_t)n * dbh::kWgScratchFloats * sizeof(float));
+                    (size_t)n * dbh::kTailBatch * dbh::kTailSlotFloats * sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;
         hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
@@ -932,12 +934,9 @@ int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t 
         a.n_classes = m->n_classes;
         // more windows than CUs: a persistent launch, as in production (stamps per window)
         a.debug_stage = n > m->cus ? 301 : 300;
-        // DEEPBINNER_TIMELINE_PROFILE=1: per-workgroup phase totals instead of per-window stamps
-        if (const char* knob = std::getenv("DEEPBINNER_TIMELINE_PROFILE"))
-            if (knob[0] == '1' && n > m->cus) a.debug_stage = 302;
         a.steps = 1;
         st = ensure(&m->d_tail, &m->tail_bytes, (size_t)(n > m->cus ? m->cus : n) *
-                                                    dbh::kWgScratchFloats *
+                                                    dbh::kTailBatch * dbh::kTailSlotFloats *
                                                     sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;

@@ -65,27 +65,6 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 // ---------------------------------------------------------------------------------------------
 // Cycle-stamp for the timeline mode (debug_stage 300): ts is non-null only in lane 0 of each
 // wave and points at that wave's 64 slots.
-// Phase profile (debug_stage 302, timeline build only): unlike the stamps - a global store per
-// mark, which every full barrier then waits for - a wave only reads the clock at a handful of
-// phase boundaries and adds the difference to a scalar accumulator; written out once, at the end.
-struct PhaseProfile {
-    long long last;
-    unsigned acc[8];
-};
-__device__ __forceinline__ void phase(PhaseProfile& p, bool on, int k) {
-#if DBH_TIMELINE
-    if (on) {
-        const long long now = (long long)__builtin_readcyclecounter();
-        p.acc[k] += (unsigned)(now - p.last);
-        p.last = now;
-    }
-#else
-    (void)p;
-    (void)on;
-    (void)k;
-#endif
-}
-
 __device__ __forceinline__ void mark(long long* ts, int id) {
 #if DBH_TIMELINE
     if (ts) ts[id] = (long long)__builtin_readcyclecounter();
@@ -717,8 +696,7 @@ __device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// F(2,3) with whole tiles per wave (conv7 at L = 256; conv8, conv9 at L = 128 for two windows at
-// a time: one tile of 16 pairs per wave), run the way
+// F(2,3) with whole tiles per wave (conv7, L = 256: one tile of 16 pairs per wave), run the way
 // the F(4,3) layers below are (see there for the why): N tile by N tile, the transformed inputs
 // U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3 built inside tile 0's steps and kept in registers
 // (48 VGPRs), tiles 1 and 2 pure ds_read_b128 + MFMA loops that carry the previous tile's epilogue,
@@ -814,85 +792,58 @@ __device__ __forceinline__ void w23_tile(W23U& U, const float* a_lane, const flo
 }
 
 // rows 2h, 2h+1 of the accumulators = pairs 4q + 2h, 4q + 2h + 1 of the wave's tile, N tile T:
-// output transform, ReLU, (MaxPool over the pair,) BatchNorm, then store(IntC<T>, r, v0, v1):
-// pooled -> v0 is the pair's one output; otherwise v0, v1 are positions 2j and 2j + 1.
-template <int T, bool POOL, bool BN, class Store>
-__device__ __forceinline__ void w23_epilogue_half(const f4 (&acc)[4], int h, float sc, float sh,
-                                                  const Store& store) {
+// output transform, ReLU, MaxPool over the pair, BatchNorm, store (pooled position = pair)
+template <int T, bool BN>
+__device__ __forceinline__ void w23_pooled_epilogue_half(const f4 (&acc)[4], int h, float sc,
+                                                         float sh, float* out_lane, int wave,
+                                                         int q) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * h + e;
         const float even = acc[0][r] + acc[1][r] + acc[2][r];
         const float odd = acc[1][r] - acc[2][r] - acc[3][r];
-        if constexpr (POOL) {
-            float o = fmaxf(fmaxf(even, 0.f), fmaxf(odd, 0.f));
-            if (BN) o = fmaf(o, sc, sh);
-            store(IntC<T>{}, r, o, 0.f);
-        } else {
-            float v0 = fmaxf(even, 0.f), v1 = fmaxf(odd, 0.f);
-            if (BN) {
-                v0 = fmaf(v0, sc, sh);
-                v1 = fmaf(v1, sc, sh);
-            }
-            store(IntC<T>{}, r, v0, v1);
-        }
+        float o = fmaxf(fmaxf(even, 0.f), fmaxf(odd, 0.f));
+        if (BN) o = fmaf(o, sc, sh);
+        const int j = wave * 16 + 4 * q + r;
+        out_lane[(1 + j) * kS48 + T * 16] = o;
     }
 }
 
-// One wave = one tile of 16 pairs, all 48 output channels (conv7: eight tiles of one window at
-// L = 256; conv8 and conv9: four tiles each of the two windows of a pair at L = 128).
-//   first_row   : physical row of the tile's first input row (pair j reads rows first_row + 2j .. + 3)
-//   store       : where an output goes (see w23_epilogue_half); called after the mid-layer barrier
-//   begin()     : one-off requests behind the first loads;  extra(IntC<0..17>): per-step requests
-//   END_VM      : see the closing barrier
-//   pre_mid / post_mid : the caller's work on either side of the mid-layer barrier (by which every
-//                 wave has read all its input rows - the layer's inputs are dead behind it)
-template <int CONV, bool POOL, int BNI, int W_LDS, int END_VM, class Store, class Begin, class Extra,
-          class PreMid, class PostMid>
-__device__ __forceinline__ void wino_ntile_layer(float* lds, const float* __restrict__ packed,
-                                                 int lane, int wave, long long* ts, int ts_base,
-                                                 int first_row, const Store& store,
-                                                 const Begin& begin, const Extra& extra,
-                                                 const PreMid& pre_mid, const PostMid& post_mid,
-                                                 bool nothing_to_retire = false) {
-    static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV), "");
+template <int CONV, int L, int BNI, int W_LDS, class Begin>
+__device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float* __restrict__ packed,
+                                                        int tid, int lane, int wave, long long* ts,
+                                                        int ts_base, const Begin& begin) {
+    static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV) && L / 32 == kWaves, "");
+    constexpr int LOUT = L / 2;
     constexpr bool BN = BNI >= 0;
     constexpr int kTile = 6 * 2 * 256;       // floats of one N tile's weights
     const int n = lane & 15, q = lane >> 4;
     EpiParams<3, BN> ep;
     load_epi<CONV, BNI>(ep, lds, packed, n);
-    // pair j of the tile needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3 of its region
-    const float* a_lane = lds + kActOff + (first_row + 2 * n) * kS48 + 2 * q;
+    // pair j = wave*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
+    const float* a_lane = lds + kActOff + (wave * 32 + 2 * n) * kS48 + 2 * q;
+    float* out_lane = lds + kActOff + n;
     W23U U;
     f4 acc[2][4];
-    w23_tile<true, 0, 6>(U, a_lane, lds + W_LDS + lane * 4, acc[0], ep.b[0],
-                         [&](auto tag) { extra(tag); }, begin);
-    pre_mid();
+    w23_tile<true, 0, 6>(U, a_lane, lds + W_LDS + lane * 4, acc[0], ep.b[0], NoSide(), begin);
     mark(ts, ts_base);
     lds_barrier();        // every wave has read all its input rows: outputs may go in place
     mark(ts, ts_base + 1);
-    post_mid();
+    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);       // (row 0 is zero already)
     w23_tile<false, 0, 12>(U, a_lane, lds + W_LDS + kTile + lane * 4, acc[1], ep.b[1], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], store);
-        if constexpr (SP == 3) w23_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], store);
-        extra(IntC<6 + SP>{});
+        if constexpr (SP == 1) w23_pooled_epilogue_half<0, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_lane, wave, q);
+        if constexpr (SP == 3) w23_pooled_epilogue_half<0, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_lane, wave, q);
     });
     w23_tile<false, 6, 12>(U, a_lane, lds + W_LDS + 2 * kTile + lane * 4, acc[0], ep.b[2], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], store);
-        if constexpr (SP == 3) w23_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], store);
-        extra(IntC<12 + SP>{});
+        if constexpr (SP == 1) w23_pooled_epilogue_half<1, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_lane, wave, q);
+        if constexpr (SP == 3) w23_pooled_epilogue_half<1, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_lane, wave, q);
     });
     mark(ts, ts_base + 2);
-    w23_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], store);
-    w23_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], store);
-    // END_VM: how many of a wave's latest vector-memory requests (register prefetches issued
-    // behind the layer's DMA) may still be in flight; 0 = a full __syncthreads()
-    // (nothing_to_retire: nothing the wave has in flight is needed behind this barrier)
-    if (nothing_to_retire) lds_barrier();
-    else if constexpr (END_VM == 0) __syncthreads();
-    else lds_barrier<END_VM>();
+    w23_pooled_epilogue_half<2, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    w23_pooled_epilogue_half<2, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    __syncthreads();
     mark(ts, ts_base + 3);
 }
 
@@ -1829,20 +1780,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
-    // THE PAIR.  Stage D (conv8, conv9: L = 128, four 16-pair tiles) keeps half the matrix work
-    // of eight waves in exchange traffic when it runs for one window; for two windows it is eight
-    // tiles, one per wave, like conv7.  So a workgroup takes its windows two at a time: the first
-    // runs stages A-C, parks its conv7 output (25 KiB) in the workgroup's global scratch and
-    // makes way (have_parked); the second runs A-C, the parked rows come back by LDS-DMA next to
-    // its own, D runs for both, then E and F once per window (the stage-E buffers of two windows
-    // do not fit).  The launch's last window of an odd share runs alone, half of D idle.
-    bool have_parked = false;
-    long parked_win = 0;
-    PhaseProfile prof = {};
-    const bool profiling = debug_stage == 302;
-    prof.last = (long long)__builtin_readcyclecounter();
-    if (tid_entry < kS48)         // row 65 of the parked conv9 image: the zero row after position 63
-        (glob(args()->tail_scratch) + (size_t)blockIdx.x * kWgScratchFloats + kWgPark2)[64 * kS48 + tid_entry] = 0.f;
 
     // Seam-b2 input of the window in hand: this lane's two samples for the statistics, its
     // A-fragment samples for conv1d_1 and which of those lie inside the window.  Filled by
@@ -1870,16 +1807,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
-    // this window waits for the next one of the workgroup (persistent launches only: the debug
-    // modes run one window per workgroup)
-    const bool will_park = (debug_stage < 0 || debug_stage >= 301) && !have_parked &&
-                           win + (long)gridDim.x < n_windows;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
     long long* ts = nullptr;
-    if (debug_stage >= 300 && debug_stage != 302 && lane == 0)   // 301: the same in a persistent launch
+    if (debug_stage >= 300 && lane == 0)        // 301: the same in a persistent launch
         ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
     mark(ts, 0);
-    phase(prof, profiling, 0);      // 0: between windows (loop control, tail's closing barrier)
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
     // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
@@ -1945,9 +1877,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             } else {
                 // the sums were taken and turned into mean and 1/std while the window before ran
                 // its conv17 (stage F below); this barrier publishes them - and keeps this
-                // window's activations off the LDS that window's last reads still use.  (LDS only:
-                // the stores that park the pair's first window need not be waited for here)
-                lds_barrier();
+                // window's activations off the LDS that window's last reads still use
+                __syncthreads();
                 fetch_conv2_weights();
                 const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
                 mean = stats[0];
@@ -1978,7 +1909,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                        glob(args()->debug_out) + win * kStageFloats[0], tid);
         return;
     }
-    phase(prof, profiling, 1);      // 1: stage A
     // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
     const long next_win = win + gridDim.x;
     const bool has_next = args()->samples != nullptr && next_win < n_windows;
@@ -2020,8 +1950,26 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         return;
     }
 
+    // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
+    // conv5's and conv6's weights sit side by side at the bottom of the weight area (DMA'd
+    // during conv4); conv7's four Winograd matrices follow them, fetched while conv5 runs.
+    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
+        lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
+    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0>(
+        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
+    // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
+    // activation buffer meanwhile
+    wino_ntile_pooled_layer<6, 256, 2, kW7a>(
+        lds, packed, tid, lane, wave, ts, 22,
+        [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); });
+    if (stop_stage == 2) {
+        if (debug_stage < 100)
+            dump_stage(lds + kActOff, kS48, 128, 48, glob(args()->debug_out) + win * kStageFloats[2], tid);
+        return;
+    }
+
     // the next window's slice of its read (scalar arithmetic on the offsets asked for after stage
-    // A): after this only the loads themselves are left to issue
+    // A): by stage E only the loads themselves are left to issue
     const int16_t* next_src = nullptr;
     int next_cnt = 0, next_pad = 0;
     if (has_next) {
@@ -2033,185 +1981,43 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
         next_src = glob(a->samples) + next_base + wa;
     }
-    float* const wg_scratch = glob(args()->tail_scratch) + (size_t)blockIdx.x * kWgScratchFloats;
-    phase(prof, profiling, 2);      // 2: stage B
-
-    // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
-    // conv5's and conv6's weights sit side by side at the bottom of the weight area (DMA'd
-    // during conv4); conv7's four Winograd matrices follow them, fetched while conv5 runs.
-    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
-        lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
-    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0>(
-        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
-    // conv7 (Winograd) + MaxPool + BN3, in place.  Behind its mid-layer barrier rows 130.. are
-    // dead: the pair's parked window comes back there by LDS-DMA (conv8's weights go to the
-    // upper half of the activation buffer meanwhile)
-    {
-        // a window that waits for its partner: its outputs go straight to the workgroup's
-        // scratch (rows 1..128 as they would lie), not to LDS
-        float* out7 = lds + kActOff + (1 + wave * 16 + 4 * q) * kS48 + n;
-        float* out7g = wg_scratch + kWgPark1 + (wave * 16 + 4 * q) * kS48 + n;
-        wino_ntile_layer<6, true, 2, kW7a, 0>(
-            lds, packed, lane, wave, ts, 22, wave * 32,
-            [&](auto tile, int r, float v, float) {
-                if (will_park) out7g[r * kS48 + decltype(tile)::value * 16] = v;
-                else out7[r * kS48 + decltype(tile)::value * 16] = v;
-            },
-            [&] {
-                if (!will_park) {
-                    dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave);
-                } else if (has_next) {
-                    // the pair's second window runs next: its samples start their trip from HBM
-                    // now (behind conv6's closing barrier, which would wait for them), and its
-                    // statistics ride on this layer's mid-layer barrier (as on conv17's otherwise)
-                    prefetched = true;
-                    in_cnt = next_cnt;
-                    fetch_window_at(next_src, next_cnt, next_pad, tid, wave * kMtA, n, q, in_v0,
-                                    in_v1, in_raw, in_inside);
-                }
-            },
-            NoSide(),
-            [&] {
-#ifndef DBH_EXP_X2
-                if (will_park && prefetched) window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
-#endif
-            },
-            [&] {
-                zero_row(lds + kActOff, 129, kS48, 48, tid);       // (row 0 is zero already)
-                if (will_park) {
-#ifndef DBH_EXP_X2
-                    if (prefetched && wave == kWaves - 1) {
-                        double mean, inv;
-                        window_mean_inv(lds, in_cnt, &mean, &inv);
-                        double* stats = reinterpret_cast<double*>(lds + kStatOut);
-                        if (lane == 0) {
-                            stats[0] = mean;
-                            stats[1] = inv;
-                        }
-                    }
-#endif
-                } else if (have_parked) {
-#ifndef DBH_EXP_X1
-                    dma_weights<kParkFloats>(wg_scratch + kWgPark1,
-                                             lds + kActOff + (kPairRow1 + 1) * kS48, lane, wave);
-#endif
-                    zero_row(lds + kActOff, kPairRow1, kS48, 48, tid);
-                    zero_row(lds + kActOff, kPairRow1 + 129, kS48, 48, tid);
-                }
-            },
-            will_park);     // (its stores to the scratch are not read before the partner's conv7)
-    }
-    if (stop_stage == 2) {
-        if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 128, 48, glob(args()->debug_out) + win * kStageFloats[2], tid);
-        return;
-    }
-    phase(prof, profiling, 3);      // 3: stage C
-    if (will_park) {      // parked (conv7's epilogue wrote to the scratch): on to the partner
-        have_parked = true;
-        parked_win = win;
-        continue;
-    }
-
-    // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4, for the pair ---------------
-    // Waves 0-3: the four tiles of region 0 (this window), waves 4-7: region 1 (the parked window;
-    // garbage when this window runs alone - its outputs go nowhere).
+    // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
     // while conv8 runs, long before stage F needs them; conv9's Winograd matrices go to the top
     // of the arena by DMA.
     SmallMRegs<16, 8, 3, true> r17;
     r17.prefetch_epilogue(packed, 5, lane, wave);
-    const int region = wave >> 2, pair_tile = wave & 3;
-#ifndef DBH_EXP_X5
-    {
-        // in place: positions 2j, 2j + 1 of the region -> its physical rows 1 + 2j, 2 + 2j
-        float* out8 = lds + kActOff + (region * kPairRow1 + 1 + 2 * (pair_tile * 16 + 4 * q)) * kS48 + n;
-        wino_ntile_layer<7, false, -1, kUpper, 27>(
-            lds, packed, lane, wave, ts, 26, region * kPairRow1 + pair_tile * 32,
-            [&](auto tile, int r, float v0, float v1) {
-                out8[(2 * r) * kS48 + decltype(tile)::value * 16] = v0;
-                out8[(2 * r + 1) * kS48 + decltype(tile)::value * 16] = v1;
-            },
-            [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
-            [&](auto tag) {      // 18 steps: conv17's 27 fragments go one or two to a step
-                constexpr int G = decltype(tag)::value;
-                r17.template prefetch_slice<G * 27 / 18, (G + 1) * 27 / 18>(packed, lane, wave);
-            },
-            NoHook(), NoHook());
-    }
-#endif
+    wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
+        lds, packed, tid, lane, wave, ts, 26,
+        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
+        interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
+            constexpr int IT = decltype(tag)::value;
+            r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
+        }));
     // BN5's scale/shift (384 floats, too many for the parameter table): one per thread, fetched
     // here, parked in LDS at the top of stage E
     const float bn5v = tid < 2 * 192 ? packed[bn_scale_offset(4) + tid] : 0.f;
-#ifndef DBH_EXP_X5
-    {
-        // conv9 + MaxPool + BN4.  Stage E runs one window at a time, the pair's earlier (parked)
-        // one first: region 1's outputs go straight to kEX, region 0's wait in the workgroup's
-        // scratch (rows 1..64 as they will lie).  A window on its own: region 0 -> kEX.
-        // ALL inception weights (conv10..16) arrive in their stage-E home behind the mid-layer
-        // barrier (it overlaps region 1's input rows).
-        const bool to_lds = region == 1 ? have_parked : !have_parked;
-        const bool to_scratch = region == 0 && have_parked;
-        float* out9 = lds + kEX + (1 + pair_tile * 16 + 4 * q) * kS48 + n;
-        float* out9g = wg_scratch + kWgPark2 + (pair_tile * 16 + 4 * q) * kS48 + n;
-        wino_ntile_layer<8, true, 3, kW9, 0>(
-            lds, packed, lane, wave, ts, 30, region * kPairRow1 + pair_tile * 32,
-            [&](auto tile, int r, float v, float) {
-                if (to_lds) out9[r * kS48 + decltype(tile)::value * 16] = v;
-                else if (to_scratch) out9g[r * kS48 + decltype(tile)::value * 16] = v;
-            },
-            [] {},
-            [&](auto tag) {      // 69 DMA pieces over steps 6..14; the last three cover their trip
-                constexpr int G = decltype(tag)::value;
-                if constexpr (G >= 6 && G < 15)
-                    dma_weights_slice<kEWFloats, G - 6, 9>(packed + weight_offset(9), lds + kEW, lane, wave);
-            },
-            NoHook(),
-            [&] {
-                zero_row(lds + kEX, 0, kS48, 48, tid);
-                zero_row(lds + kEX, 65, kS48, 48, tid);
-            });
-    }
-#else
-    r17.template prefetch_slice<0, 27>(packed, lane, wave);
-    dma_weights<kEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave);
-    __syncthreads();
-#endif
+    // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
+    wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
+        lds, packed, tid, lane, wave, ts, 30,
+        [] {},
+        [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
+            dma_weights_slice<kEWFloats, decltype(tag)::value, 6>(packed + weight_offset(9),
+                                                                  lds + kEW, lane, wave);
+        });
     if (stop_stage == 3) {
         if (debug_stage < 100)
             dump_stage(lds + kEX, kS48, 64, 48, glob(args()->debug_out) + win * kStageFloats[3], tid);
         return;
     }
 
-    phase(prof, profiling, 4);      // 4: stage D (the pair)
-    // Stages E and F, one window at a time: the pair's earlier window (pass 0, if there is one),
-    // then this one (pass 1).
-    const int tid_outer = tid;
-#ifdef DBH_EXP_X4
-    for (int pass = 1; pass < 2; ++pass) {
-#else
-    for (int pass = have_parked ? 0 : 1; pass < 2; ++pass) {
-#endif
-    const bool second_of_pair = pass == 1 && have_parked;
-    const long cur_win = pass == 0 ? parked_win : win;
-    // (opaque per pass, for the reason given at the top of the window loop)
-#ifndef DBH_EXP_Y1
-    int tid = tid_outer;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, q = lane >> 4;
-#endif
-    // (timeline mode: a pass stamps the record of the window it works on)
-    long long* const ts_outer = ts;
-    long long* ts = ts_outer ? ts_outer + (cur_win - win) * (kWaves * 64) : nullptr;
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
     {
         // The next window's samples start their trip from HBM now (stages E-H, ~25k cycles, are
         // far more than it takes) and are used at the top of the next round's stage A; the
         // registers they land in were last read in this window's stage A.
-        if (!second_of_pair) prefetched = has_next;
-        if (has_next && !second_of_pair) {
+        prefetched = has_next;
+        if (has_next) {
             in_cnt = next_cnt;
             fetch_window_at(next_src, next_cnt, next_pad, tid, wave * kMtA, n, q, in_v0, in_v1,
                             in_raw, in_inside);
@@ -2243,14 +2049,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         zero_row(lds + kECat, 0, kS192, 192, tid);
         zero_row(lds + kECat, 33, kS192, 192, tid);
         if (tid < 2 * 192) lds[kEBn5 + tid] = bn5v;
-        // (the pair's second window: the first 12 pieces of the stage-E weights, overwritten by
-        // the first window's conv17 and asked for again after it, must have landed)
-#ifdef DBH_EXP_X3
         lds_barrier();
-#else
-        if (second_of_pair) __syncthreads();
-        else lds_barrier();
-#endif
         mark(ts, 34);
 
         constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
@@ -2285,11 +2084,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 35);
         lds_barrier();
         mark(ts, 36);
-        // kEX is dead: the pair's second window (rows 1..65 of its conv9 output) lands there
-#ifndef DBH_EXP_Y3
-        if (pass == 0)
-            dma_weights<kPark2Floats>(wg_scratch + kWgPark2, lds + kEX + kS48, lane, wave);
-#endif
 
         // E2: conv15 (16->48, k3) -> T4b, the only input of E3 not ready yet
         if (wave < 6) {
@@ -2333,24 +2127,25 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // of matrix work.  So conv17's output (3 KB) is parked in a global-memory slot of this
     // workgroup and the rest runs for kTailBatch windows at a time, ONE WAVE PER WINDOW, with no
     // cross-wave step at all (batched_tail below).
-    const bool batch_ends = tail_slot == kTailBatch - 1 || cur_win + (long)gridDim.x >= n_windows;
+    const bool batch_ends = tail_slot == kTailBatch - 1 || win + (long)gridDim.x >= n_windows;
     if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
         dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
         dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
         dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
     }
     {
-        float* slot = wg_scratch + tail_slot * kTailSlotFloats;
+        float* slot = glob(args()->tail_scratch) +
+                      ((size_t)blockIdx.x * kTailBatch + tail_slot) * kTailSlotFloats;
         // The next window's statistics ride on conv17's barrier: every wave leaves its partial
         // sums before it; behind it wave 7 (idle while waves 0-2 reduce conv17) turns them into
         // mean and 1/std, which the barrier at the top of the next stage A publishes.
         small_m_layer<16, kS192, 2, 8, 3, false, true, true>(
             lds, lds + kECat, slot, r17, lane, wave, ts, 41,
             [&] {
-                if (prefetched && pass == 1) window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
+                if (prefetched) window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
             },
             [&] {
-                if (prefetched && pass == 1 && wave == kWaves - 1) {
+                if (prefetched && wave == kWaves - 1) {
                     double mean, inv;
                     window_mean_inv(lds, in_cnt, &mean, &inv);
                     double* stats = reinterpret_cast<double*>(lds + kStatOut);
@@ -2362,21 +2157,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             });
     }
     ++tail_slot;
-    phase(prof, profiling, 5);      // 5: stages E + F (per window)
-#ifndef DBH_EXP_Y2
-    if (pass == 0) {
-        // conv17's partial tiles are read and the concat buffer is free; the stage-E weights they
-        // lay on come again (E0 of the second window covers their trip)
-        __syncthreads();
-        dma_weights<kRedOnEWFloats>(packed + weight_offset(9), lds + kEW, lane, wave);
-    }
-#endif
-    if (batch_ends) {
+    if (!batch_ends) continue;
+
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
     {
         const int n_batch = tail_slot;
-        const long first_win = cur_win - (long)(n_batch - 1) * (long)gridDim.x;
+        const long first_win = win - (long)(n_batch - 1) * (long)gridDim.x;
         tail_slot = 0;
         ArgsPtr a = args();
         const int n_classes = a->n_classes;
@@ -2395,7 +2182,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         __syncthreads();      // conv17's stores of this window are out; kRed / the concat buffer free
         mark(ts, 45);
         if (mine) {
-            const float* src = wg_scratch + wave * kTailSlotFloats;
+            const float* src = glob(a->tail_scratch) +
+                               ((size_t)blockIdx.x * kTailBatch + wave) * kTailSlotFloats;
             f4 v[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f4*>(src + i * 256 + lane * 4);
@@ -2508,18 +2296,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         __syncthreads();      // the next window's stage A writes over all of this
         mark(ts, 55);
     }
-    }       // if (batch_ends)
-    phase(prof, profiling, 6);      // 6: between the passes, and the batched tail
-    }       // the two passes of stages E and F
-    have_parked = false;
     }   // persistent loop over this workgroup's windows
-#if DBH_TIMELINE
-    if (profiling && (tid_entry & 63) == 0) {
-        long long* out = reinterpret_cast<long long*>(glob(args()->debug_out)) +
-                         ((size_t)blockIdx.x * kWaves + (tid_entry >> 6)) * 64;
-        for (int k = 0; k < 8; ++k) out[k] = prof.acc[k];
-    }
-#endif
 }
 
 // =============================================================================================

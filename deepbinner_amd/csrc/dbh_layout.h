@@ -48,8 +48,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_7, conv1d_8, conv1d_9).
-constexpr bool wino2_by_tile(int i) { return i >= 6 && i <= 8; }
+// N-tile-outer loops of dbh_forward.hip (conv1d_7); the others are matrix-major.
+constexpr bool wino2_by_tile(int i) { return i == 6; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
@@ -142,19 +142,9 @@ constexpr int kSlot0 = kW0;
 constexpr int kSlot1 = kW0 + kWinoHalf;
 constexpr int kSlot2 = kW0 + 2 * kWinoHalf;
 static_assert(kSlot2 + kWinoHalf == kLdsFloatsAD, "three Winograd slots fill the weight area");
-// Stage D runs for TWO windows of the workgroup at a time (dbh_forward.hip: the pair): L = 128
-// gives only four 16-pair tiles, one window keeps half the waves' matrix work in exchange
-// traffic.  Region 0 = rows 0..129 (the later window, left there by its conv7), region 1 = rows
-// 131..260 (the earlier one, parked in global memory after its conv7 and brought back by LDS-DMA:
-// its first data row, 132, starts on a 16-byte boundary).
-constexpr int kPairRow1 = 131;
-constexpr int kPairRows = kPairRow1 + 130;                  // 261
-static_assert(((kPairRow1 + 1) * kS48 * 4) % 16 == 0, "LDS-DMA destination alignment");
-constexpr int kParkFloats = 128 * kS48;                     // rows 1..128 as they lie (6,400 = 25 KiB)
-static_assert(kParkFloats % 256 == 0, "whole 1 KiB DMA pieces");
-// stage C onwards the activations need at most 258 rows (261 in stage D), so the upper half of
-// the activation buffer doubles as one more weight buffer (conv8's matrices)
-constexpr int kUpper = (kPairRows * kS48 + 3) / 4 * 4;     // 13,052
+// stage C onwards the activations need at most 258 rows, so the upper half of the activation
+// buffer doubles as one more weight buffer
+constexpr int kUpper = 258 * kS48;                          // 12,900
 static_assert(kUpper + 4 * 48 * 48 <= kW0, "upper weight buffer must stay below the weight area");
 // conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
 constexpr int kW5 = kW0;
@@ -162,37 +152,32 @@ constexpr int kW6 = kW5 + 1 * 48 * 16;
 constexpr int kW7a = kW6 + 3 * 16 * 48;
 constexpr int kW7b = kW7a + kWinoHalf;
 static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the weight area");
-// stage D: conv8's weights in the upper buffer, conv9's at the top of the arena, clear of the
-// stage-E weights that arrive while conv9's N tiles 1 and 2 run (when its input rows are dead).
+// stage D (L = 128, Winograd split over wave pairs): conv8's weights in the upper buffer, its
+// pair-exchange scratch right above the activations; conv9's weights at the top of the arena
+// and its exchange scratch below them, both clear of the stage-E weights arriving meanwhile.
+constexpr int kXchgFloats = 4 * 6 * 256;                   // 4 sender waves x 6 tiles x 256
+constexpr int kX8 = 130 * kS48 + 8;                        // 6,768
+static_assert(kX8 % 4 == 0 && kX8 + kXchgFloats <= kUpper, "conv8 exchange scratch hits its weights");
 
-// stage E (inception block, L = 64), one window at a time: the pair's earlier window first - its
-// conv9 output is written straight to kEX - then the later one, whose conv9 output waits in
-// global memory (kPark2Floats: rows 1..65 as they lie, row 65 zero) and comes back by LDS-DMA
-// once the first window's kEX is dead.  kEX is 2 floats in so that row 1 is 16-byte aligned.
-constexpr int kEX = 2;                                     // BN4 output, 66 rows x 50
-static_assert(((kEX + kS48) * 4) % 16 == 0, "LDS-DMA destination alignment");
-constexpr int kPark2Floats = 13 * 256;                     // 65 rows (3,250 floats) in 1 KiB pieces
-constexpr int kEAP = (kEX + 66 * kS48 + 3) / 4 * 4;        // avg-pooled copy (3,304)
-static_assert(kEX + kS48 + kPark2Floats <= kEAP + 2 * kS48, "the DMA's overshoot stays in kEAP's unused rows 0-1");
-constexpr int kEW = kEAP + 66 * kS48;                      // weights of conv10..16 (6,604)
-static_assert((kEW * 4) % 16 == 0, "LDS-DMA destination alignment");
+// stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
+// their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
+constexpr int kEX = 0;                                     // BN4 output, 66 rows x 52
+constexpr int kEAP = kEX + 66 * kS48;                      // avg-pooled copy
+constexpr int kEW = kEAP + 66 * kS48;                      // weights of conv10..16
 constexpr int kEWFloats = weight_offset(16) - weight_offset(9);   // 17,664
 constexpr int kET3 = kEW + kEWFloats;                      // conv12 out, 66 x 20
 constexpr int kET4a = kET3 + 66 * kS16;                    // conv14 out, 66 x 20
 constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 52
 constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
 constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
-constexpr int kW9 = 30408;                                 // conv9's four Winograd matrices
-static_assert(kW9 >= kEW + kEWFloats && kW9 >= kUpper + 4 * 48 * 48 && (kW9 * 4) % 16 == 0, "");
+static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
+constexpr int kX9 = (kEW + kEWFloats + 3) / 4 * 4;         // conv9's exchange scratch
+constexpr int kW9 = kX9 + kXchgFloats;                     // conv9's four Winograd matrices
 constexpr int kLdsFloatsD = kW9 + 4 * 48 * 48;
 
-// stage F (conv17, per window): split-K partial tiles where the avg-pooled copy was (NOT on kEX:
-// the pair's second window lands there meanwhile) and on the first 12 pieces of the stage-E
-// weights, which are fetched again for the pair's second window; the concat buffer stays where
-// it is.  conv17's 16 x 48 output goes to a per-workgroup slot in global memory.
-constexpr int kRed = kEAP;                                 // 24 x 256 partial tiles
-constexpr int kRedOnEWFloats = 12 * 256;                   // pieces of kEW the partial tiles hit
-static_assert(kRed + 24 * 256 <= kEW + kRedOnEWFloats, "");
+// stage F (conv17, per window): split-K partial tiles at the front of the arena; the concat buffer
+// stays where it is.  conv17's 16 x 48 output goes to a per-workgroup slot in global memory.
+constexpr int kRed = 0;                                    // 24 x 256 partial tiles
 constexpr int kTailEnd = kRed + 24 * 256;
 static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
 // stages G-H (conv18, conv19, conv20, softmax, call) run for kTailBatch windows at a time, ONE
@@ -211,11 +196,6 @@ constexpr int kTX = kTWEnd;                                // wave w: X at kTX +
 constexpr int kTLog = kTX + kTailBatch * 2 * kTailBuf;     // 32 logits per wave
 constexpr int kTEnd = kTLog + kTailBatch * 32;
 constexpr int kTailSlotFloats = 16 * 48;                   // conv17 output of one window
-// per-workgroup scratch in global memory: kTailBatch conv17 outputs | the pair's parked conv7
-// output | the pair's parked conv9 output
-constexpr int kWgPark1 = kTailBatch * kTailSlotFloats;
-constexpr int kWgPark2 = kWgPark1 + kParkFloats;
-constexpr int kWgScratchFloats = kWgPark2 + kPark2Floats;  // 15,872 (62 KiB)
 // BN5's scale and shift (2 x 192 floats), parked above stage E's buffers for the inception block
 constexpr int kEBn5 = kLdsFloatsE;
 static_assert(kEBn5 + 2 * 192 <= (kLdsFloatsAD > kLdsFloatsD ? kLdsFloatsAD : kLdsFloatsD), "");

@@ -475,13 +475,13 @@ def test_batched_pipeline_matches_single_call(hip, hip_models, all_signals, side
 
 
 @pytest.mark.parametrize('cap', [1, 3, 4])
-def test_workgroups_take_their_windows_two_at_a_time(hip, hip_models, weights, all_signals, cap,
-                                                     monkeypatch):
-    """A workgroup with more than one window runs stage D (conv8, conv9) for two of them at a time
-    - the first parked in global memory after conv7, its conv9 output after that - and a last
-    window of an odd share alone.  DEEPBINNER_GRID_CAP makes shares long out of few windows: the
+def test_long_shares_of_windows_per_workgroup(hip, hip_models, weights, all_signals, cap,
+                                              monkeypatch):
+    """The production kernel is persistent: a workgroup walks many windows, prefetching the next
+    one's samples and statistics under the current one's last stages and finishing them eight at
+    a time (the batched tail).  DEEPBINNER_GRID_CAP makes the shares long out of few windows: the
     results must equal, bit for bit, those of one window per workgroup (what fewer windows than
-    CUs get), on both seams, for odd and even shares and across batched-tail boundaries."""
+    CUs get), on both seams, for full, partial and single-window tail batches."""
     wide = hip_models['EXP-NBD103_read_starts']
     monkeypatch.setenv('DEEPBINNER_GRID_CAP', str(cap))
     narrow = hip.HipModel(weights['EXP-NBD103_read_starts'], device=0)

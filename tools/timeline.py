@@ -62,19 +62,7 @@ def main():
         period = (starts[grid:] - starts[:-grid])
         print('steady-state period per window (start to start, same workgroup): %.0f cycles '
               '(first windows: %.0f)' % (np.median(period[grid:]), np.median(period[:grid])))
-        # A workgroup takes its windows two at a time (dbh_forward.hip: the pair): the windows of
-        # even rounds run stages A-C, wait (parked) while the next one runs A-D, then run E-F;
-        # those of odd rounds run everything.  Report the two kinds separately, leaving out the
-        # first pair (cold).
-        rounds = np.arange(len(st)) // grid
-        pair_period = starts[2 * grid:] - starts[:-2 * grid]
-        print('steady-state period per PAIR of windows: %.0f cycles = %.0f per window' % (
-            np.median(pair_period[2 * grid:]), np.median(pair_period[2 * grid:]) / 2))
-        keep = rounds >= 2
-        which = os.environ.get('DEEPBINNER_TIMELINE_KIND', 'second')
-        keep &= (rounds % 2 == (0 if which == 'first' else 1))
-        print('windows shown: the %s of each pair' % which)
-        st = st[keep]
+        st = st[grid:]
     t0 = st[:, :, 0].min(axis=1, keepdims=True)          # block start
     rel = st[:, :, ids] - t0[:, :, None]                 # cycles since block start
     last = rel.max(axis=1)                               # slowest wave reaches each mark
