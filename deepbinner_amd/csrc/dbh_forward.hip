@@ -2085,31 +2085,40 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds_barrier();
         mark(ts, 36);
 
-        // E2: conv15 (16->48, k3) -> T4b, the only input of E3 not ready yet
-        if (wave < 6) {
-            const int t = wave % 3, m0 = (wave / 3) * 2;
-            inception_k3<2, 2, 1, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, t * 16,
-                                                     bias_tab + bias_offset(14) + t * 16,
-                                                     nullptr, nullptr, t, m0, lane);
+        // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, on waves 0-3, and
+        // conv13 (16->48, k3) -> concat 96..143 on waves 4-7: one position tile and all three
+        // channel tiles each, 36 MFMAs per wave.
+        if (wave < 4) {
+            inception_k3<2, 1, 3, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, 0,
+                                                     bias_tab + bias_offset(14), nullptr, nullptr,
+                                                     0, wave, lane);
+        } else {
+            inception_k3<2, 1, 3, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
+                                                     bias_tab + bias_offset(12), sc5 + 96,
+                                                     sh5 + 96, 0, wave - 4, lane);
         }
         mark(ts, 37);
         lds_barrier();
         mark(ts, 38);
 
-        // E3: conv16 (48->48, k3) -> concat 144..191 on waves 0-5 and conv13 (16->48, k3) ->
-        // concat 96..143 on waves 6-7: 72 MFMAs per wave on every wave.
-        if (wave < 6) {
-            const int t = wave % 3, m0 = (wave / 3) * 2;
+        // E3: conv16 (48->48, k3) -> concat 144..191: twelve (position tile, channel tile) units
+        // of 36 MFMAs - two on each of waves 0-3, one on each of waves 4-7, 108 MFMAs per SIMD.
+        //   w0: t0 m0,1   w1: t1 m0,1   w2: t2 m0,1   w3: t0 m2,3
+        //   w4: t1 m2     w5: t1 m3     w6: t2 m2     w7: t2 m3
+        if (wave < 4) {
+            const int t = wave < 3 ? wave : 0, m0 = wave < 3 ? 0 : 2;
             inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
                                                      144 + t * 16,
                                                      bias_tab + bias_offset(15) + t * 16,
                                                      sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
                                                      lane);
         } else {
-            const int m0 = (wave - 6) * 2;
-            inception_k3<2, 2, 3, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
-                                                     bias_tab + bias_offset(12), sc5 + 96,
-                                                     sh5 + 96, 0, m0, lane);
+            const int t = 1 + ((wave - 4) >> 1), m0 = 2 + ((wave - 4) & 1);
+            inception_k3<6, 1, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
+                                                     144 + t * 16,
+                                                     bias_tab + bias_offset(15) + t * 16,
+                                                     sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
+                                                     lane);
         }
         mark(ts, 39);
         lds_barrier();
