@@ -148,7 +148,6 @@ struct dbh_model {
     int device = 0;
     int cus = 256;               // workgroups of a persistent forward launch (one per CU)
     bool launch_per_batch = false;   // DEEPBINNER_LAUNCH_PER_BATCH=1: one launch per batch (A/B)
-    int tune = 0;                // DEEPBINNER_TUNE: kernel experiment switches
     float* d_packed = nullptr;
     // workspace for the host-pointer entry points, grown on demand
     void* d_in = nullptr;      size_t in_bytes = 0;
@@ -281,7 +280,6 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.debug_stage = debug_stage;
         a.steps = in.steps;
         a.side = in.side;
-        a.tune = m->tune;
         if (debug_stage == 300)
             hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads),
                                0, stream, reinterpret_cast<dbh_timeline::ForwardArgs&>(a));
@@ -462,8 +460,6 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
     {
         const char* knob = std::getenv("DEEPBINNER_LAUNCH_PER_BATCH");
         m->launch_per_batch = knob && knob[0] == '1';
-        const char* tune = std::getenv("DEEPBINNER_TUNE");
-        m->tune = tune ? std::atoi(tune) : 0;
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
     if (e == hipSuccess)

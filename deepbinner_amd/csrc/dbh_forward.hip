@@ -620,81 +620,6 @@ __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slo
 // this layer's (V0,V1) / (V2,V3).
 // next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
 // at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
-template <int CONV, int L, bool POOL, int BNI, int SLOT_A, int SLOT_B, class Dma1, class Dma2>
-__device__ __forceinline__ void wino_layer(float* lds, const float* __restrict__ packed, int tid,
-                                           int lane, int wave, long long* ts, int ts_base,
-                                           const Dma1& next1, const Dma2& next2) {
-    static_assert(kConv[CONV].wino == 2 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
-    constexpr int MT = (L / 32) / kWaves;
-    static_assert(MT >= 1 && MT * kWaves * 32 == L, "layer does not tile over the waves");
-    constexpr int LOUT = POOL ? L / 2 : L;
-    constexpr bool BN = BNI >= 0;
-    const int n = lane & 15, q = lane >> 4;
-    const int m0 = wave * MT;
-
-    next1();
-    EpiParams<3, BN> ep;
-    load_epi<CONV, BNI>(ep, lds, packed, n);
-    // M0 starts at +bias and M3 at -bias, so even = M0+M1+M2 and odd = M1-M2-M3 both arrive
-    // with the bias already added
-    f4 acc[4][MT][3];
-    zero_acc(acc[1]);
-    zero_acc(acc[2]);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            acc[0][m][t] = f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]};
-            acc[3][m][t] = f4{-ep.b[t], -ep.b[t], -ep.b[t], -ep.b[t]};
-        }
-    // pair j = m0*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
-    const float* a_lane = lds + kActOff + (m0 * 32 + 2 * n) * kS48 + 2 * q;
-    wino_phase<MT, 0>(a_lane, lds + SLOT_A + lane * 2, acc);
-    __syncthreads();      // (V2,V3) have landed for everyone; SLOT_A may be overwritten
-    next2();
-    wino_phase<MT, 1>(a_lane, lds + SLOT_B + lane * 2, acc);
-    mark(ts, ts_base);
-
-    __syncthreads();      // every wave has finished reading the old activations
-    mark(ts, ts_base + 1);
-
-    // output transform + bias + ReLU (+ MaxPool over the pair) (+ BN); lane holds pairs 4q+r
-    float* out = lds + kActOff + n;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const float sc = ep.sc[t], sh = ep.sh[t];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const f4 even = acc[0][m][t] + acc[1][m][t] + acc[2][m][t];
-            const f4 odd = acc[1][m][t] - acc[2][m][t] - acc[3][m][t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float ye = fmaxf(even[r], 0.f);
-                float yo = fmaxf(odd[r], 0.f);
-                const int j = (m0 + m) * 16 + 4 * q + r;
-                if (POOL) {
-                    float o = fmaxf(ye, yo);
-                    if (BN) o = fmaf(o, sc, sh);
-                    out[(1 + j) * kS48 + t * 16] = o;
-                } else {
-                    if (BN) {
-                        ye = fmaf(ye, sc, sh);
-                        yo = fmaf(yo, sc, sh);
-                    }
-                    out[(1 + 2 * j) * kS48 + t * 16] = ye;
-                    out[(2 + 2 * j) * kS48 + t * 16] = yo;
-                }
-            }
-        }
-    }
-    zero_row(lds + kActOff, 0, kS48, 48, tid);
-    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
-    mark(ts, ts_base + 2);
-
-    __syncthreads();
-    mark(ts, ts_base + 3);
-}
-
 // ---------------------------------------------------------------------------------------------
 // F(2,3) with whole tiles per wave (conv7, L = 256: one tile of 16 pairs per wave), run the way
 // the F(4,3) layers below are (see there for the why): N tile by N tile, the transformed inputs
@@ -1362,100 +1287,6 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
     mark(ts, ts_base + 3);
 }
 
-// ---------------------------------------------------------------------------------------------
-// conv18 / conv19 (48 -> 48, k = 3, one 16-position tile): 108 MFMAs.  Three waves with a whole
-// N tile each (36 MFMAs, no reduction) leave one SIMD idle and the others with a lone wave; here
-// the 54 (tap, channel-step, N tile) units - fragment u of the packed layer IS unit u - are dealt
-// out round robin to all eight waves (unit u -> wave u % 8: 7 units on waves 0-5, 6 on 6-7), so
-// every SIMD multiplies for 27 MFMAs, every wave fetches 7 B fragments instead of 18, and the
-// per-wave partial tiles are summed through LDS as conv17's are.  A wave's j-th unit works on N
-// tile (wave + 2j) % 3: one of three compile-time patterns, picked by wave % 3.
-// ---------------------------------------------------------------------------------------------
-template <int CONV, bool BN>
-struct StripedRegs {
-    static_assert(kConv[CONV].taps == 3 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
-    static constexpr int kUnits = 3 * 6 * 3, kPer = (kUnits + kWaves - 1) / kWaves;
-    f2 b[kPer];
-    EpiParams<1, BN> ep;
-    __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int bn_index,
-                                             int lane, int wave) {
-        const float* b_lane = packed + weight_offset(CONV) + lane * 2;
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            // unconditional (a wave without a 7th unit re-reads the last fragment and never uses
-            // it): a select on a freshly loaded value would make hipcc wait for the load at once
-            const int u = wave + kWaves * j < kUnits ? wave + kWaves * j : kUnits - 1;
-            b[j] = *reinterpret_cast<const f2*>(b_lane + u * 128);
-        }
-        // epilogue parameters: used by waves 0-2 (one N tile each), fetched by all - a branch
-        // here would cost hipcc its exact vmcnt bookkeeping, and every later use of an EARLIER
-        // prefetch would wait for this one too
-        const int ch = (wave % 3) * 16 + (lane & 15);
-        ep.load(packed + bias_offset(CONV) + ch,
-                packed + (BN ? bn_scale_offset(bn_index) : 0) + ch,
-                packed + (BN ? bn_shift_offset(bn_index) : 0) + ch);
-    }
-};
-
-template <int CONV, bool BN, int V>
-__device__ __forceinline__ void striped_units(const float* in_region,
-                                              const StripedRegs<CONV, BN>& regs, int lane, int wave,
-                                              f4 (&acc)[3]) {
-    using R = StripedRegs<CONV, BN>;
-    const int n = lane & 15, q = lane >> 4;
-    const float* a_lane = in_region + n * kS48 + 2 * q;    // 'same' k=3: physical row p + tap
-    f2 a[R::kPer];
-#pragma unroll
-    for (int j = 0; j < R::kPer; ++j) {
-        const int u = wave + kWaves * j;
-        const int k = (u < R::kUnits ? u : 0) / 3;             // tap * 6 + channel step
-        a[j] = *reinterpret_cast<const f2*>(a_lane + (k / 6) * kS48 + (k % 6) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < R::kPer; ++j) {
-        const int t = (V + 2 * j) % 3;
-        if (j == R::kPer - 1 && wave + kWaves * j >= R::kUnits) break;   // waves 6, 7: 6 units
-        acc[t] = mfma4(a[j].x, regs.b[j].x, acc[t]);
-        acc[t] = mfma4(a[j].y, regs.b[j].y, acc[t]);
-    }
-}
-
-template <int CONV, bool POOL, bool BN>
-__device__ __forceinline__ void striped_layer(float* lds, const float* in_region, float* out_region,
-                                              const StripedRegs<CONV, BN>& regs, int lane, int wave,
-                                              long long* ts, int ts_base) {
-    const int n = lane & 15, q = lane >> 4;
-    f4 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-    const int v = wave % 3;
-    if (v == 0)
-        striped_units<CONV, BN, 0>(in_region, regs, lane, wave, acc);
-    else if (v == 1)
-        striped_units<CONV, BN, 1>(in_region, regs, lane, wave, acc);
-    else
-        striped_units<CONV, BN, 2>(in_region, regs, lane, wave, acc);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        *reinterpret_cast<f4*>(lds + kRed + (wave * 3 + t) * 256 + lane * 4) = acc[t];
-    mark(ts, ts_base);
-    __syncthreads();
-    mark(ts, ts_base + 1);
-    if (wave < 3) {
-        const int t = wave;
-        f4 sum[1][1];
-        sum[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w)
-            sum[0][0] += *reinterpret_cast<const f4*>(lds + kRed + (w * 3 + t) * 256 + lane * 4);
-        float* out_lane = out_region + (1 + (POOL ? 2 * q : 4 * q)) * kS48 + t * 16 + n;
-        epilogue<1, 1, kS48, POOL, BN>(sum, out_lane, regs.ep);
-    }
-    mark(ts, ts_base + 2);
-    __syncthreads();
-    mark(ts, ts_base + 3);
-}
-
 // One wave's share of the 1x1 convolutions of the inception block (4 position tiles x 1 N tile).
 template <int NTTOT, int S_OUT, bool POOLBN>
 __device__ __forceinline__ void inception_1x1(const float* in_region, const float* w_lds,
@@ -1658,7 +1489,6 @@ struct ForwardArgs {
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
     int n_classes, debug_stage, steps, side;
-    int tune;                    // DEEPBINNER_TUNE: experiment switches, 0 in production
 };
 
 // Window statistics, step 1: exact integer sums of this lane's two samples, sum(x) and sum(x^2)
@@ -1759,14 +1589,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds[kParams + i] = packed_entry[src];
     }
     if (tid_entry < 2) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
-    {
-        const int tune = args()->tune;
-        const int w = __builtin_amdgcn_readfirstlane(tid_entry >> 6);
-        if ((tune & 1) && w < 4) __builtin_amdgcn_s_setprio(1);
-        if ((tune & 2) && w >= 4) __builtin_amdgcn_s_setprio(1);
-        if ((tune & 4) && w < 4) __builtin_amdgcn_s_setprio(3);
-        if ((tune & 8) && w >= 4) __builtin_amdgcn_s_setprio(3);
-    }
     // conv1d_1's three taps (B operand: k = lane >> 4 picks the tap) and its bias / BN1
     EpiParams<3, true> ep_a;
     float bw_a[3];
