@@ -108,6 +108,113 @@ __global__ __launch_bounds__(THREADS) void k_tile(float* out, long long* cyc, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The ladder: the same loop with the ingredients of dbh_forward.hip's stage-B tiles 1 and 2 added
+// one at a time (FLAGS: 1 = s_setprio by progress through a pair of tiles, 2 = the F(4,3) output
+// transform + ReLU of the tile before (10 packed + 8 scalar VALU per half) inside steps 1 and 3,
+// 4 = its 8 ds_write_b32 per half, 8 = transform WITHOUT the eight v_max), to see which of them
+// takes the loop from 32.6 cycles per MFMA to the 38 the kernel's timeline shows.
+// ---------------------------------------------------------------------------------------------
+template <int FLAGS, int STEP0, int SP>
+__device__ __forceinline__ void lstep(const U72& U, unsigned addr, f4 (&buf)[2][3], f4 (&acc)[6],
+                                      const f4 (&prev)[6], float* out_lane, f2& sink) {
+    if constexpr (SP + 1 < 6) {
+        load_b<0, SP + 1>(buf[(SP + 1) & 1], addr);
+        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[3] = buf[SP & 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    if constexpr (FLAGS & 1) __builtin_amdgcn_s_setprio(3 - (4 * (STEP0 + SP)) / 12);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((FLAGS & (2 | 4 | 8)) != 0 && (SP == 1 || SP == 3)) {
+        constexpr int h = SP == 1 ? 0 : 1;
+        f2 y0 = f2{prev[0][2 * h], prev[0][2 * h + 1]}, y1 = y0, y2 = y0, y3 = y0;
+        if constexpr (FLAGS & (2 | 8)) {
+            const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+            const f2 a0 = f2{prev[0][2 * h], prev[0][2 * h + 1]}, a1 = f2{prev[1][2 * h], prev[1][2 * h + 1]};
+            const f2 a2 = f2{prev[2][2 * h], prev[2][2 * h + 1]}, a3 = f2{prev[3][2 * h], prev[3][2 * h + 1]};
+            const f2 a4 = f2{prev[4][2 * h], prev[4][2 * h + 1]}, a5 = f2{prev[5][2 * h], prev[5][2 * h + 1]};
+            const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+            y0 = a0 + s12 + s34;
+            y1 = __builtin_elementwise_fma(k2, d34, d12);
+            y2 = __builtin_elementwise_fma(k4, s34, s12);
+            y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
+            if constexpr (FLAGS & 2) {
+                y0 = f2{fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f)};
+                y1 = f2{fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f)};
+                y2 = f2{fmaxf(y2.x, 0.f), fmaxf(y2.y, 0.f)};
+                y3 = f2{fmaxf(y3.x, 0.f), fmaxf(y3.y, 0.f)};
+            }
+        }
+        if constexpr (FLAGS & 4) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float* dst = out_lane + (8 * h + e) * 4 * 50;
+                dst[0] = y0[e];
+                dst[50] = y1[e];
+                dst[100] = y2[e];
+                dst[150] = y3[e];
+            }
+        } else {
+            sink = sink + y0 + y1 + y2 + y3;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP + 1 < 6) lstep<FLAGS, STEP0, SP + 1>(U, addr, buf, acc, prev, out_lane, sink);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(512) void k_ladder(float* out, long long* cyc, int tiles) {
+    __shared__ f4 sh[6144 + 1700];   // 96 KiB of "weights" + 27 KB of "activations"
+    for (int i = threadIdx.x; i < 6144 + 1700; i += blockDim.x) sh[i] = f4{1, 2, 3, 4} * (1.f / (1 + i));
+    U72 U;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) U.u[x][s] = f2{threadIdx.x * 0.001f + x, s * 0.01f};
+    f4 acc[2][6];
+    for (int i = 0; i < 6; ++i) acc[0][i] = acc[1][i] = f4{0, 0, 0, 0};
+    const unsigned addr = (unsigned)(size_t)sh + (threadIdx.x & 63) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* out_lane = reinterpret_cast<float*>(sh + 6144) + (wave * 16 + 2 * (lane >> 4)) * 4 * 50 % 6000 + (lane & 15);
+    f2 sink = f2{0.f, 0.f};
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < tiles; t += 2) {
+        f4 buf[2][3];
+        load_b<0, 0>(buf[0], addr);
+        lstep<FLAGS, 0, 0>(U, addr, buf, acc[1], acc[0], out_lane, sink);
+        load_b<0, 0>(buf[0], addr);
+        lstep<FLAGS, 6, 0>(U, addr, buf, acc[0], acc[1], out_lane, sink);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    __syncthreads();
+    f4 s4 = acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[0][4] + acc[0][5] + acc[1][0] + acc[1][5];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s4.x + s4.y + s4.z + s4.w + sink.x + sink.y;
+    if ((threadIdx.x & 63) == 0) {
+        cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0;
+        cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1;
+        if (blockIdx.x == 0) cyc[256 * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+}
+
 typedef void (*kern_t)(float*, long long*, int);
 static void run(const char* name, kern_t k, int threads) {
     float* out;
@@ -154,5 +261,12 @@ int main() {
     run("tile loop: 6 b64 + 12 MFMA per step, 1 wave/SIMD", k_tile<1, 256>, 256);
     run("tile loop: no LDS, 12 MFMA per step, 2 waves/SIMD", k_tile<2, 512>, 512);
     run("tile loop: no LDS, 12 MFMA per step, 1 wave/SIMD", k_tile<2, 256>, 256);
+    run("ladder 0: plain", k_ladder<0>, 512);
+    run("ladder 1: + setprio by progress", k_ladder<1>, 512);
+    run("ladder 3: + setprio + transform + ReLU (VALU only)", k_ladder<3>, 512);
+    run("ladder 9: + setprio + transform, no ReLU (VALU only)", k_ladder<9>, 512);
+    run("ladder 5: + setprio + stores only", k_ladder<5>, 512);
+    run("ladder 7: + setprio + transform + ReLU + stores", k_ladder<7>, 512);
+    run("ladder 6: transform + ReLU + stores, no setprio", k_ladder<6>, 512);
     return 0;
 }
