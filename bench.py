@@ -356,6 +356,8 @@ def main():
     sync()
     if lead.timing_model is not None:
         lead.timing_model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
+        # two stores per workgroup and launch: the shader clock against the 100 MHz wall clock
+        lead.timing_model.clock_enable(not args.no_kernel_timing)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -364,9 +366,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = launches = windows = 0
+    shader_ghz = None
     if lead.timing_model is not None:
         kernel_ms, launches, windows = lead.timing_model.timing_read()
         lead.timing_model.timing_enable(False)
+        if not args.no_kernel_timing:
+            shader_ghz = lead.timing_model.clock_read()      # of the timed region's last launch
+            lead.timing_model.clock_enable(False)
     if rdzv is not None:
         elapsed = rdzv.max_float(elapsed)
 
@@ -431,6 +437,18 @@ def main():
             'mfma_pipe_util': (pmc['mfma_busy_cycles_per_window'] * rate / (1024 * 2.4e9)
                                if 'mfma_busy_cycles_per_window' in pmc else None),
             'mfma_pipe_util_source': pmc.get('source'),
+            # The peak above is the data sheet's, at 2.4 GHz.  Under this kernel the shader clock
+            # runs lower (power management); measured inside the timed region's last launch by
+            # every workgroup (s_memtime against the 100 MHz s_memrealtime, median).  In CYCLES -
+            # which is what "how busy is the pipe" means - the matrix pipe is this busy:
+            'shader_clock_ghz': shader_ghz,
+            'mfma_pipe_util_at_shader_clock': (
+                pmc['mfma_busy_cycles_per_window'] * rate / (1024 * shader_ghz * 1e9)
+                if shader_ghz and 'mfma_busy_cycles_per_window' in pmc else None),
+            'peak_at_shader_clock': PEAK_FP32_TFLOPS * shader_ghz / 2.4 if shader_ghz else None,
+            'frac_executed_at_shader_clock': (
+                executed_flop * rate / 1e12 / (PEAK_FP32_TFLOPS * shader_ghz / 2.4)
+                if shader_ghz else None),
             # HBM bytes per launch from the PMC passes, scaled to this run's windows per launch
             'traffic': (pmc['hbm_bytes_per_launch'] * windows_per_launch / pmc['windows_per_launch']
                         if 'hbm_bytes_per_launch' in pmc and windows_per_launch else None),

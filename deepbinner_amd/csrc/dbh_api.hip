@@ -3,6 +3,7 @@
 // owns the device buffers, launches the kernels of dbh_forward.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,8 @@ struct dbh_model {
     // conv17 outputs parked per workgroup until the batched tail runs (dbh_forward.hip); one
     // buffer per stream a model launches on: this one for the caller's stream, one per staging slot
     void* d_tail = nullptr;    size_t tail_bytes = 0;
+    void* d_clock = nullptr;   size_t clock_bytes = 0;     // dbh_forward_clock_enable
+    bool clock_probe = false;  unsigned clock_grid = 0;
     // double-buffered host <-> device staging of dbh_classify_i16 (overlapped H2D / D2H)
     struct Slot {
         hipStream_t stream = nullptr;
@@ -271,6 +274,13 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.offsets = in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr;
         a.calls = in.calls ? (int*)(in.calls + off / in.steps) : nullptr;
         a.tail_scratch = (float*)*tail;
+        a.clock_out = nullptr;
+        if (m->clock_probe && debug_stage < 0) {
+            const int st = ensure(&m->d_clock, &m->clock_bytes, (size_t)grid * 4 * sizeof(int64_t));
+            if (st != DBH_OK) return st;
+            a.clock_out = (long long*)m->d_clock;
+            m->clock_grid = grid;
+        }
         a.score_diff = in.score_diff;
         a.read0 = (long long)(in.read0 + off / in.steps);
         a.len_hint = (long long)in.len_hint;
@@ -481,6 +491,7 @@ int dbh_model_destroy(dbh_model* m) {
     if (m->d_work) (void)hipFree(m->d_work);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_tail) (void)hipFree(m->d_tail);
+    if (m->d_clock) (void)hipFree(m->d_clock);
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -978,6 +989,36 @@ int dbh_forward_timing_read(dbh_model* m, double* total_ms, int64_t* launches, i
     m->timed_windows = 0;
     m->timed_launches = 0;
     m->open_stop = nullptr;
+    return DBH_OK;
+}
+
+int dbh_forward_clock_enable(dbh_model* m, int enable) {
+    if (!m) return DBH_ERR_INVALID_ARGUMENT;
+    m->clock_probe = enable != 0;
+    if (!enable) m->clock_grid = 0;
+    return DBH_OK;
+}
+
+int dbh_forward_clock_read(dbh_model* m, double* shader_ghz) {
+    if (!m || !shader_ghz) return DBH_ERR_INVALID_ARGUMENT;
+    *shader_ghz = 0.0;
+    if (!m->clock_probe || m->clock_grid == 0 || !m->d_clock) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipSetDevice(m->device));
+    DBH_HIP(hipDeviceSynchronize());
+    std::vector<int64_t> c((size_t)m->clock_grid * 4);
+    DBH_HIP(hipMemcpy(c.data(), m->d_clock, c.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    int wall_khz = 0;      // the rate of s_memrealtime (100 MHz on this hardware)
+    DBH_HIP(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, m->device));
+    if (wall_khz <= 0) return DBH_ERR_HIP;
+    std::vector<double> ratios;
+    for (unsigned b = 0; b < m->clock_grid; ++b) {
+        const double shader = (double)(c[b * 4 + 2] - c[b * 4]);
+        const double wall = (double)(c[b * 4 + 3] - c[b * 4 + 1]);
+        if (shader > 0 && wall > 0) ratios.push_back(shader / wall);
+    }
+    if (ratios.empty()) return DBH_ERR_HIP;
+    std::nth_element(ratios.begin(), ratios.begin() + ratios.size() / 2, ratios.end());
+    *shader_ghz = ratios[ratios.size() / 2] * (double)wall_khz * 1e-6;
     return DBH_OK;
 }
 

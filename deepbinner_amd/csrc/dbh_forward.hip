@@ -65,6 +65,17 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 // ---------------------------------------------------------------------------------------------
 // Cycle-stamp for the timeline mode (debug_stage 300): ts is non-null only in lane 0 of each
 // wave and points at that wave's 64 slots.
+// The constant 100 MHz clock beside the shader clock of mark(): two of these per window give the
+// shader clock's frequency while the kernel runs (tools/timeline.py) - it is below the 2.4 GHz the
+// peak figures assume.
+__device__ __forceinline__ void mark_realtime(long long* ts, int id) {
+#if DBH_TIMELINE
+    if (ts) ts[id] = (long long)__builtin_amdgcn_s_memrealtime();
+#else
+    (void)ts;
+    (void)id;
+#endif
+}
 __device__ __forceinline__ void mark(long long* ts, int id) {
 #if DBH_TIMELINE
     if (ts) ts[id] = (long long)__builtin_readcyclecounter();
@@ -1485,6 +1496,8 @@ struct ForwardArgs {
     const long long* offsets;    //          read r = samples[offsets[r] .. offsets[r+1])
     int* calls;                  //          barcode calls (one scan step per read), or null
     float* tail_scratch;         // [grid][kTailBatch][16][48]: conv17 outputs parked per workgroup
+    long long* clock_out;        // [grid][4] or null: shader clock and 100 MHz clock at a
+                                 // workgroup's start and end (dbh_forward_clock_read)
     double score_diff;
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
@@ -1577,6 +1590,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
     const int tid_entry = threadIdx.x;
+    // clock probe (off unless asked for): how fast the shader clock really runs under this load
+    if (args()->clock_out != nullptr && tid_entry == 0) {
+        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * 4;
+        c[0] = (long long)__builtin_readcyclecounter();
+        c[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
     const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
 
@@ -1634,6 +1653,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     if (debug_stage >= 300 && lane == 0)        // 301: the same in a persistent launch
         ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
     mark(ts, 0);
+    mark_realtime(ts, 62);
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
     // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
@@ -1987,6 +2007,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 }
             });
     }
+    mark_realtime(ts, 63);
     ++tail_slot;
     if (!batch_ends) continue;
 
@@ -2128,6 +2149,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 55);
     }
     }   // persistent loop over this workgroup's windows
+    if (args()->clock_out != nullptr && tid_entry == 0) {
+        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * 4;
+        c[2] = (long long)__builtin_readcyclecounter();
+        c[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // =============================================================================================

@@ -123,6 +123,8 @@ def load_library():
         'dbh_forward_timing_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_timing_enable_span': (c_int, [c_void_p, c_int, c_int]),
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
+        'dbh_forward_clock_enable': (c_int, [c_void_p, c_int]),
+        'dbh_forward_clock_read': (c_int, [c_void_p, P(ctypes.c_double)]),
         'dbh_comm_available': (c_int, []),
         'dbh_comm_last_error': (ctypes.c_char_p, []),
         'dbh_comm_init_all': (c_int, [c_int, P(c_int), c_int, P(c_void_p)]),
@@ -152,7 +154,7 @@ EXPORTED_SYMBOLS = [
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
-    'dbh_forward_timing_read',
+    'dbh_forward_timing_read', 'dbh_forward_clock_enable', 'dbh_forward_clock_read',
     'dbh_comm_available', 'dbh_comm_last_error', 'dbh_comm_init_all', 'dbh_comm_unique_id',
     'dbh_comm_init_rank', 'dbh_comm_info', 'dbh_comm_all_gather_i32', 'dbh_comm_destroy',
 ]
@@ -465,6 +467,19 @@ class HipModel:
         every n-th launch (0/False = off, True = every launch on its own)."""
         check(self._lib.dbh_forward_timing_enable_span(self._handle, int(every_nth), int(span)),
               'dbh_forward_timing_enable_span')
+
+    def clock_enable(self, on=True):
+        """Have production launches of the forward kernel note the shader clock against the wall
+        clock (see dbh_forward_clock_enable)."""
+        check(self._lib.dbh_forward_clock_enable(self._handle, 1 if on else 0),
+              'dbh_forward_clock_enable')
+
+    def clock_read(self):
+        """Shader clock (GHz) during this model's latest forward launch."""
+        ghz = ctypes.c_double(0)
+        check(self._lib.dbh_forward_clock_read(self._handle, ctypes.byref(ghz)),
+              'dbh_forward_clock_read')
+        return ghz.value
 
     def timing_read(self):
         ms, launches, windows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)

@@ -224,6 +224,16 @@ int dbh_forward_timing_enable_span(dbh_model* model, int every_nth, int span);
 int dbh_forward_timing_read(dbh_model* model, double* total_ms, int64_t* launches,
                             int64_t* windows);
 
+/* Clock probe.  The MFMA peak of the data sheet assumes 2.4 GHz; under this kernel's load the
+ * shader clock runs lower (power management), and "how busy is the matrix pipe" is a ratio of
+ * CYCLES.  With the probe on, every workgroup of a production launch of the forward kernel notes
+ * the shader clock counter (s_memtime) and the constant-rate wall clock (s_memrealtime,
+ * hipDeviceAttributeWallClockRate) at its start and at its end (two stores per workgroup);
+ * dbh_forward_clock_read synchronises the device and returns the median ratio of the model's
+ * latest launch as a frequency in GHz. */
+int dbh_forward_clock_enable(dbh_model* model, int enable);
+int dbh_forward_clock_read(dbh_model* model, double* shader_ghz);
+
 #ifdef __cplusplus
 }
 #endif

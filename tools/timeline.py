@@ -53,6 +53,14 @@ def main():
     run(x)                                  # warm-up
     st = run(x)                             # [n, 8 waves, 64]
     ids = ORDER
+    # shader clock while the kernel runs: stamps 0 / 44 are s_memtime (shader clock), 62 / 63
+    # s_memrealtime (constant 100 MHz) at the same two places of every window
+    d_shader = (st[:, :, 44] - st[:, :, 0]).astype(np.float64)
+    d_real = (st[:, :, 63] - st[:, :, 62]).astype(np.float64)
+    ok = (d_real > 0) & (d_shader > 0)
+    if ok.any():
+        print('shader clock during the run: %.3f GHz (s_memtime against the 100 MHz s_memrealtime, '
+              'median over %d wave-windows)' % (np.median(d_shader[ok] / d_real[ok]) * 0.1, ok.sum()))
     if n > 256:
         # persistent launch: window w is the (w // grid)-th of workgroup w % grid; leave out every
         # workgroup's first window (cold) and report the steady state, plus the period from one
