@@ -126,7 +126,7 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                             }
         }
         float* bdst = packed.data() + bias_offset(i);
-        for (int c = 0; c < cout; ++c) bdst[c] = bias[c];
+        for (int c = 0; c < cout; ++c) bdst[c] = bias[c] * kActScale;      // (exact: a power of two)
     }
     for (int i = 0; i < kNumBn; ++i) {
         const int c_n = kBnChannels[i];
@@ -137,7 +137,7 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
         for (int c = 0; c < c_n; ++c) {
             const double scale = (double)gamma[c] / std::sqrt((double)var[c] + 1e-3);
             sc[c] = (float)scale;
-            sh[c] = (float)((double)beta[c] - (double)mean[c] * scale);
+            sh[c] = (float)((double)beta[c] - (double)mean[c] * scale) * kActScale;
         }
     }
 }

@@ -187,6 +187,16 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
 }
 
+// A per-lane LDS pointer computed ONCE and kept in a register (made opaque as an integer, so that
+// the compiler neither recomputes it at every use - a 64-bit multiply-add each - nor forgets that
+// it points into LDS: through a generic pointer the stores would be flat_store).
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ lds_float* lds_pinned(const float* p) {
+    unsigned a = lds_addr(p);
+    asm volatile("" : "+v"(a));
+    return (lds_float*)(size_t)a;
+}
+
 // One ds_read_b64 the compiler cannot see.  hipcc's own wait-count pass drains ALL outstanding LDS
 // reads (lgkmcnt(0)) in front of every second MFMA group of this loop, exposing a full LDS
 // round trip each time; issuing the reads from inline asm and counting them by hand
@@ -433,7 +443,7 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
                                            int channels, float* __restrict__ out, int tid) {
     for (int idx = tid; idx < rows * channels; idx += kThreads) {
         const int r = idx / channels, c = idx - r * channels;
-        out[idx] = region[(r + 1) * stride + c];
+        out[idx] = region[(r + 1) * stride + c] * kActUnscale;      // (see kActScale)
     }
 }
 
@@ -554,6 +564,23 @@ __device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// ReLU for free: the `clamp` output modifier ([0, 1]) on the instruction that produces the value -
+// activations are held times 2^-60 (dbh_layout.h: kActScale), so 1.0 is out of their reach.
+__device__ __forceinline__ f2 pk_add_relu(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (k: a constant pair, from scalar registers)
+__device__ __forceinline__ f2 pk_fma_relu(f2 k, f2 b, f2 c) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(k), "v"(b), "v"(c));
+    return r;
+}
+// NB: the operands of these must come from instructions the compiler can see.  hipcc pads the
+// distance between an MFMA and the first VALU instruction that reads its result with s_nop, but
+// it does not look into inline asm: an accumulator read HERE straight after the MFMA chain (the
+// exposed epilogue of a layer's last tile) arrives stale.
 
 template <int MT, int PHASE, int SP_IDX, class Side>
 __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
@@ -731,8 +758,7 @@ __device__ __forceinline__ void w23_tile(W23U& U, const float* a_lane, const flo
 // output transform, ReLU, MaxPool over the pair, BatchNorm, store (pooled position = pair)
 template <int T, bool BN>
 __device__ __forceinline__ void w23_pooled_epilogue_half(const f4 (&acc)[4], int h, float sc,
-                                                         float sh, float* out_lane, int wave,
-                                                         int q) {
+                                                         float sh, lds_float* out_q) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * h + e;
@@ -740,8 +766,7 @@ __device__ __forceinline__ void w23_pooled_epilogue_half(const f4 (&acc)[4], int
         const float odd = acc[1][r] - acc[2][r] - acc[3][r];
         float o = fmaxf(fmaxf(even, 0.f), fmaxf(odd, 0.f));
         if (BN) o = fmaf(o, sc, sh);
-        const int j = wave * 16 + 4 * q + r;
-        out_lane[(1 + j) * kS48 + T * 16] = o;
+        out_q[r * kS48 + T * 16] = o;      // pair wave*16 + 4q + r (out_q: this lane's place in pair wave*16 + 4q)
     }
 }
 
@@ -758,7 +783,7 @@ __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float*
     load_epi<CONV, BNI>(ep, lds, packed, n);
     // pair j = wave*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
     const float* a_lane = lds + kActOff + (wave * 32 + 2 * n) * kS48 + 2 * q;
-    float* out_lane = lds + kActOff + n;
+    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + wave * 16 + 4 * q) * kS48);
     W23U U;
     f4 acc[2][4];
     w23_tile<true, 0, 6>(U, a_lane, lds + W_LDS + lane * 4, acc[0], ep.b[0], NoSide(), begin);
@@ -768,17 +793,17 @@ __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float*
     zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);       // (row 0 is zero already)
     w23_tile<false, 0, 12>(U, a_lane, lds + W_LDS + kTile + lane * 4, acc[1], ep.b[1], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_pooled_epilogue_half<0, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_lane, wave, q);
-        if constexpr (SP == 3) w23_pooled_epilogue_half<0, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_lane, wave, q);
+        if constexpr (SP == 1) w23_pooled_epilogue_half<0, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_q);
+        if constexpr (SP == 3) w23_pooled_epilogue_half<0, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_q);
     });
     w23_tile<false, 6, 12>(U, a_lane, lds + W_LDS + 2 * kTile + lane * 4, acc[0], ep.b[2], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_pooled_epilogue_half<1, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_lane, wave, q);
-        if constexpr (SP == 3) w23_pooled_epilogue_half<1, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_lane, wave, q);
+        if constexpr (SP == 1) w23_pooled_epilogue_half<1, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_q);
+        if constexpr (SP == 3) w23_pooled_epilogue_half<1, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_q);
     });
     mark(ts, ts_base + 2);
-    w23_pooled_epilogue_half<2, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_lane, wave, q);
-    w23_pooled_epilogue_half<2, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    w23_pooled_epilogue_half<2, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
+    w23_pooled_epilogue_half<2, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
     __syncthreads();
     mark(ts, ts_base + 3);
 }
@@ -948,7 +973,7 @@ __device__ __forceinline__ void w43_tile(W43U& U, const float* a_lane, const flo
 // four lane groups of one store write quads 2 apart = 16-bank-aligned quarters of the LDS banks.
 template <int T, bool POOL, bool BN>
 __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, float sc, float sh,
-                                                  float* out_lane, int wave, int q) {
+                                                  lds_float* out_q) {
     constexpr int NV = POOL ? 2 : 4;
     const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
     const f2 a0 = f2{acc[0][2 * h], acc[0][2 * h + 1]};
@@ -958,16 +983,17 @@ __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, flo
     const f2 a4 = f2{acc[4][2 * h], acc[4][2 * h + 1]};
     const f2 a5 = f2{acc[5][2 * h], acc[5][2 * h + 1]};
     const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
-    const f2 y0 = a0 + s12 + s34;
-    const f2 y1 = __builtin_elementwise_fma(k2, d34, d12);
-    const f2 y2 = __builtin_elementwise_fma(k4, s34, s12);
-    const f2 y3 = __builtin_elementwise_fma(k8, d34, d12) + a5;
+    // (ReLU = the clamp modifier of each output's last instruction)
+    const f2 y0 = pk_add_relu(a0 + s12, s34);
+    const f2 y1 = pk_fma_relu(k2, d34, d12);
+    const f2 y2 = pk_fma_relu(k4, s34, s12);
+    const f2 y3 = pk_fma_relu(k8, d34, d12 + a5);      // (a5 through a visible add: see pk_fma_relu)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        float v0 = fmaxf(y0[e], 0.f), v1 = fmaxf(y1[e], 0.f);
-        float v2 = fmaxf(y2[e], 0.f), v3 = fmaxf(y3[e], 0.f);
-        const int j = wave * 16 + 2 * q + e + 8 * h;          // pm(4q + 2h + e)
-        float* dst = out_lane + (1 + NV * j) * kS48 + T * 16;
+        float v0 = y0[e], v1 = y1[e], v2 = y2[e], v3 = y3[e];
+        // quad j = wave*16 + 2q + e + 8h = pm(4q + 2h + e); out_q = this lane's place in quad
+        // wave*16 + 2q (one address per layer; the rest are immediate offsets of the stores)
+        lds_float* dst = out_q + NV * (e + 8 * h) * kS48 + T * 16;
         if constexpr (POOL) {
             f2 p = f2{fmaxf(v0, v1), fmaxf(v2, v3)};
             if (BN) p = __builtin_elementwise_fma(p, f2{sc, sc}, f2{sh, sh});
@@ -1008,7 +1034,8 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // quad j = wave*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
     const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
     const float* a_lane = lds + kActOff + (wave * 64 + 4 * pm_n) * kS48 + 2 * q;
-    float* out_lane = lds + kActOff + n;
+    // this lane's place in output quad wave*16 + 2q (NV rows per quad after pooling or not)
+    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + (POOL ? 2 : 4) * (wave * 16 + 2 * q)) * kS48);
     W43U U;
     f4 acc[2][6];
     // tile 0: reads the wave's input rows step by step and builds U on the way
@@ -1021,8 +1048,8 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // tile 1, with tile 0's epilogue inside its steps 1 and 3
     w43_tile<false, 0, 12>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_lane, wave, q);
-        if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_lane, wave, q);
+        if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_q);
+        if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_q);
     });
     lds_arrive(lds, lane, 0);
     sync_rounds += kWaves;
@@ -1030,14 +1057,14 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // tile 2, with tile 1's epilogue inside
     w43_tile<false, 6, 12>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_lane, wave, q);
-        if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_lane, wave, q);
+        if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_q);
+        if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_q);
     });
     lds_wait(lds, 0, sync_rounds);      // every wave has left tile 1
     next_third(1, lds + kSlot1);
     mark(ts, ts_base + 2);
-    w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_lane, wave, q);
-    w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_lane, wave, q);
+    w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
+    w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
     if (ts_base == 6) mark(ts, 58);
     __syncthreads();      // the layer is stored; every wave has left tile 2
     next_third(2, lds + kSlot2);
@@ -1683,7 +1710,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
-                a[m] = (q < 3 && idx < kWindow) ? xw[idx] : 0.f;      // idx == 1024: right padding
+                a[m] = (q < 3 && idx < kWindow) ? xw[idx] * kActScale : 0.f;   // idx == 1024: right padding
             }
         } else {
             // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
@@ -1726,6 +1753,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 mean = stats[0];
                 inv = stats[1];
             }
+            inv *= (double)kActScale;      // (exact; see kActScale)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
@@ -2108,7 +2136,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                           fmaxf(acc.z + bias, 0.f) + fmaxf(acc.w + bias, 0.f);
                 int even, odd;     // rows q = 0 and q = 1 hold the two halves of the position sum
                 rows_i32(__builtin_bit_cast(int, sum), &even, &odd);
-                return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) * 0.125f;
+                // the mean over the 8 positions, and out of the kernel's activation scale
+                return (__builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd)) *
+                       (0.125f * kActUnscale);
             };
             float logit = conv20_logit(0, bias20a);        // classes 0..15 in lanes 0..15
             if (n_classes > 16) {

@@ -81,9 +81,23 @@ constexpr int conv_weight_floats(int i) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// THE ACTIVATION SCALE.  Inside the forward kernel every activation is held as its value times
+// kActScale = 2^-60: the input is scaled on the way in, biases and BN shifts are packed scaled,
+// the logits are scaled back before the softmax.  A power of two commutes with every fp32
+// rounding (nothing here comes near the subnormal range or overflow), so all values are exactly
+// 2^-60 times what they would be - and ReLU becomes the `clamp` output modifier ([0, 1]: no
+// activation of this network comes near 2^60 - the largest, before BN2, are ~1e8) of whatever instruction produces the value: the
+// output transforms of the Winograd layers end in a packed add or fma, and there is no packed
+// fp32 max in the ISA, so this takes a third of their epilogues' vector instructions away.
+// ---------------------------------------------------------------------------------------------
+constexpr float kActScale = 1.f / 1152921504606846976.f;       // 2^-60
+constexpr float kActUnscale = 1152921504606846976.f;
+
+// ---------------------------------------------------------------------------------------------
 // Packed parameter buffer (floats).  [ weights of conv 1..20 | bias of conv 1..20 (cout_pad
 // each) | BN scale,shift of bn 1..7 ].  BN is pre-folded on the host in fp64:
 //   scale = gamma / sqrt(var + 1e-3),  shift = beta - mean * scale.
+// Biases and shifts are stored times kActScale (see above).
 // ---------------------------------------------------------------------------------------------
 constexpr int weight_offset(int i) {
     int off = 0;
