@@ -452,9 +452,12 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
 //   CONV    : 0-based layer index; its weights are already in lds + W_CUR
 //   L       : input length;  POOL/BNI: fused MaxPool2 / batch-norm index (-1 = none)
 //   NEXT_N  : floats of the next block of weights, DMA'd from next_g into next_lds meanwhile
+//   IN_OFF / OUT_OFF : where the input and the output rows start in LDS.  Equal = in place: a
+//             barrier between the MFMA loop and the stores (every wave must have read everything
+//             first).  Different buffers: none - a wave stores as soon as it has multiplied.
 // ---------------------------------------------------------------------------------------------
 template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N,
-          class Side = NoSide>
+          int IN_OFF = kActOff, int OUT_OFF = kActOff, class Side = NoSide>
 __device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
                                               const float* __restrict__ next_g, float* next_lds,
                                               int tid, int lane, int wave, long long* ts,
@@ -477,19 +480,20 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     bias_acc(acc, ep);
     const int m0 = wave * MT;
     // 'same' k=3: logical row p+tap-1 = physical row p+tap; k=1: physical row p+1.
-    const float* a_lane = lds + kActOff + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
+    const float* a_lane = lds + IN_OFF + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
     const float* b_lane = lds + W_CUR + lane * 2;
     conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc, side);
     mark(ts, ts_base);
 
-    lds_barrier();     // every wave has finished reading the old activations and weights
+    if constexpr (IN_OFF == OUT_OFF)
+        lds_barrier();     // every wave has finished reading the old activations and weights
     mark(ts, ts_base + 1);
 
-    float* out_lane = lds + kActOff +
+    float* out_lane = lds + OUT_OFF +
                       (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
     epilogue<MT, NT, S_OUT, POOL, BN, false>(acc, out_lane, ep);
-    zero_row(lds + kActOff, 0, S_OUT, NT * 16, tid);
-    zero_row(lds + kActOff, LOUT + 1, S_OUT, NT * 16, tid);
+    zero_row(lds + OUT_OFF, 0, S_OUT, NT * 16, tid);
+    zero_row(lds + OUT_OFF, LOUT + 1, S_OUT, NT * 16, tid);
     mark(ts, ts_base + 2);
 
     __syncthreads();
@@ -1823,9 +1827,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
     // conv5's and conv6's weights sit side by side at the bottom of the weight area (DMA'd
     // during conv4); conv7's four Winograd matrices follow them, fetched while conv5 runs.
-    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6)>(
+    // conv5's 16-channel output goes beside the activation buffer (kMid16: the upper buffer, idle
+    // until conv8's weights arrive during conv7) and conv6 brings it back: neither layer works in
+    // place, so neither needs the barrier between multiplying and storing.
+    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6), kActOff, kMid16>(
         lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
-    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0>(
+    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0, kMid16, kActOff>(
         lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile

@@ -160,6 +160,9 @@ static_assert(kSlot2 + kWinoHalf == kLdsFloatsAD, "three Winograd slots fill the
 // buffer doubles as one more weight buffer
 constexpr int kUpper = 258 * kS48;                          // 12,900
 static_assert(kUpper + 4 * 48 * 48 <= kW0, "upper weight buffer must stay below the weight area");
+// ... and, before that, as the home of conv5's 16-channel output (258 rows x kS16)
+constexpr int kMid16 = kUpper;
+static_assert(kMid16 + 258 * kS16 <= kW0, "");
 // conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
 constexpr int kW5 = kW0;
 constexpr int kW6 = kW5 + 1 * 48 * 16;
