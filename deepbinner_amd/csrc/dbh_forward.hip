@@ -181,6 +181,11 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // an L2/HBM round trip.  Use this where the waves exchange data through LDS alone and nothing
 // that was DMA'd since the last full barrier is read before the next one.
 // VM = how many of the wave's most recent vector-memory requests may stay in flight (63 = all).
+// The full barrier, spelled out: the LDS-DMA requests below are inline asm, which the compiler's
+// own wait-count insertion does not see - a __syncthreads() would NOT wait for them.
+__device__ __forceinline__ void full_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <int VM = 63>
 __device__ __forceinline__ void lds_barrier() {
     static_assert(VM >= 0 && VM <= 63, "vmcnt is a 6-bit field");
@@ -403,18 +408,30 @@ __device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lan
 // 64 lanes x 16 B = one 1 KiB piece per wave-instruction, destination = wave-uniform base +
 // lane*16) while the current layer's MFMAs run; no VGPRs, no ds_write.  The __syncthreads()
 // that ends the layer carries the vmcnt(0) that retires them.
+// One 1 KiB piece: 64 lanes x 16 B from the wave-uniform global address `g_piece` (in scalar
+// registers: the instruction's SADDR form, the lane's 16 lane bytes as its 32-bit offset - no
+// 64-bit vector add per piece) to the wave-uniform LDS address in M0 + lane * 16.
+// Inline asm: the compiler neither counts this request (see full_barrier) nor knows M0 changes -
+// nothing else in this kernel uses M0.
+__device__ __forceinline__ void dma_piece(const float* g_piece, const float* lds_piece,
+                                          unsigned lane_bytes) {
+    const unsigned m0v = lds_addr(lds_piece);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(m0v), "v"(lane_bytes), "s"(g_piece)
+                 : "memory");
+}
+
 template <int NFLOATS>
 __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* lds_dst, int lane,
                                             int wave) {
     static_assert(NFLOATS % 256 == 0, "weight blocks are whole 1 KiB pieces");
     constexpr int kPieces = NFLOATS / 256;
+    const unsigned lane_bytes = (unsigned)lane * 16u;
 #pragma unroll
     for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
         const int piece = wave + kWaves * i;   // wave-uniform
-        if (piece < kPieces)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + piece * 256 + lane * 4),
-                (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+        if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, lane_bytes);
     }
 }
 
@@ -424,13 +441,11 @@ __device__ __forceinline__ void dma_weights_slice(const float* __restrict__ g, f
                                                   int lane, int wave) {
     constexpr int kPieces = NFLOATS / 256;
     constexpr int kPerWave = (kPieces + kWaves - 1) / kWaves;
+    const unsigned lane_bytes = (unsigned)lane * 16u;
 #pragma unroll
     for (int i = IT * kPerWave / NIT; i < (IT + 1) * kPerWave / NIT; ++i) {
         const int piece = wave + kWaves * i;
-        if (piece < kPieces)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + piece * 256 + lane * 4),
-                (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+        if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, lane_bytes);
     }
 }
 
@@ -496,7 +511,7 @@ __device__ __forceinline__ void inplace_layer(float* lds, const float* __restric
     zero_row(lds + OUT_OFF, LOUT + 1, S_OUT, NT * 16, tid);
     mark(ts, ts_base + 2);
 
-    __syncthreads();
+    full_barrier();  
     mark(ts, ts_base + 3);
 }
 
@@ -808,7 +823,7 @@ __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float*
     mark(ts, ts_base + 2);
     w23_pooled_epilogue_half<2, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
     w23_pooled_epilogue_half<2, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
-    __syncthreads();
+    full_barrier();  
     mark(ts, ts_base + 3);
 }
 
@@ -848,7 +863,9 @@ __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float*
 // can arrive twice before another has arrived once: each word is arrived at once per layer.
 __device__ __forceinline__ void lds_arrive(float* lds, int lane, int which) {
     unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync) + which;
-    // release: this wave's LDS reads are done and its LDS-DMA pieces have landed (vmcnt)
+    // release: this wave's LDS reads are done and its LDS-DMA pieces have landed (explicitly: the
+    // compiler does not see the inline-asm DMA requests)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (lane == 0)
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -1045,7 +1062,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // tile 0: reads the wave's input rows step by step and builds U on the way
     w43_tile<true, 0, 6>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
     mark(ts, ts_base);
-    __syncthreads();      // every wave has read all its input rows (and has left tile 0): from
+    full_barrier();        // every wave has read all its input rows (and has left tile 0): from
     mark(ts, ts_base + 1);   // here on the outputs may be stored in place
     if (POOL) zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);   // (row 0 is zero already)
     next_third(0, lds + kSlot0);
@@ -1070,7 +1087,7 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
     w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
     if (ts_base == 6) mark(ts, 58);
-    __syncthreads();      // the layer is stored; every wave has left tile 2
+    full_barrier();        // the layer is stored; every wave has left tile 2
     next_third(2, lds + kSlot2);
     mark(ts, ts_base + 3);
 }
@@ -1178,7 +1195,7 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
     mark(ts, ts_base + 2);
 
-    __syncthreads();
+    full_barrier();  
     mark(ts, ts_base + 3);
 }
 
@@ -1325,7 +1342,7 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         }
     }
     mark(ts, ts_base + 2);
-    if constexpr (!TO_GLOBAL) __syncthreads();
+    if constexpr (!TO_GLOBAL) full_barrier();  
     mark(ts, ts_base + 3);
 }
 
@@ -1709,7 +1726,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         const float(&bw)[3] = bw_a;               // fetched once per workgroup, before the loop
         if (samples == nullptr) {
             // a later window of this workgroup: the window before it may still be read (stage H)
-            if (win != (long)blockIdx.x) __syncthreads();
+            if (win != (long)blockIdx.x) full_barrier();  
             const float* xw = glob(args()->x) + win * kWindow;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -1744,14 +1761,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             double mean, inv;
             if (!prefetched) {
                 window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
-                __syncthreads();
+                full_barrier();  
                 fetch_conv2_weights();
                 window_mean_inv(lds, in_cnt, &mean, &inv);
             } else {
                 // the sums were taken and turned into mean and 1/std while the window before ran
                 // its conv17 (stage F below); this barrier publishes them - and keeps this
                 // window's activations off the LDS that window's last reads still use
-                __syncthreads();
+                full_barrier();  
                 fetch_conv2_weights();
                 const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
                 mean = stats[0];
@@ -1774,7 +1791,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 60);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
-        __syncthreads();
+        full_barrier();  
         mark(ts, 1);
     }
     if (stop_stage == 0) {
@@ -2066,7 +2083,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                   packed + bn_shift_offset(6) + n);
         const float bias20a = packed[bias_offset(19) + n];
         const float bias20b = packed[bias_offset(19) + 16 + n];
-        __syncthreads();      // conv17's stores of this window are out; kRed / the concat buffer free
+        full_barrier();        // conv17's stores of this window are out; kRed / the concat buffer free
         mark(ts, 45);
         if (mine) {
             const float* src = glob(a->tail_scratch) +
@@ -2088,7 +2105,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 *reinterpret_cast<f2*>(dst + 2) = f2{v[i].z, v[i].w};
             }
         }
-        __syncthreads();      // the batch's weights have landed (vmcnt(0) rides on the barrier)
+        full_barrier();        // the batch's weights have landed (vmcnt(0) rides on the barrier)
         mark(ts, 46);
         if (debug_stage >= 0 && stop_stage == 5) {
             if (debug_stage < 100)
@@ -2117,7 +2134,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             mark(ts, 49);
         }
         if (debug_stage >= 0 && stop_stage == 6) {
-            __syncthreads();
+            full_barrier();  
             if (debug_stage < 100)
                 dump_stage(lds + kTX, kS48, 8, 48, glob(a->debug_out) + win * kStageFloats[6], tid);
             return;
@@ -2182,7 +2199,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         }
         mark(ts, 53);
         if (debug_stage == 7) return;
-        __syncthreads();      // the next window's stage A writes over all of this
+        full_barrier();        // the next window's stage A writes over all of this
         mark(ts, 55);
     }
     }   // persistent loop over this workgroup's windows

@@ -145,6 +145,9 @@ __device__ __forceinline__ void lstep(const U72& U, unsigned addr, f4 (&buf)[2][
     __builtin_amdgcn_sched_barrier(0);
     if constexpr ((FLAGS & (2 | 4 | 8)) != 0 && (SP == 1 || SP == 3)) {
         constexpr int h = SP == 1 ? 0 : 1;
+        // 16 / 32: the epilogue block at the highest / lowest priority, then back to the step's
+        if constexpr (FLAGS & 16) __builtin_amdgcn_s_setprio(3);
+        if constexpr (FLAGS & 32) __builtin_amdgcn_s_setprio(0);
         f2 y0 = f2{prev[0][2 * h], prev[0][2 * h + 1]}, y1 = y0, y2 = y0, y3 = y0;
         if constexpr (FLAGS & (2 | 8)) {
             const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
@@ -175,6 +178,7 @@ __device__ __forceinline__ void lstep(const U72& U, unsigned addr, f4 (&buf)[2][
         } else {
             sink = sink + y0 + y1 + y2 + y3;
         }
+        if constexpr (FLAGS & (16 | 32)) __builtin_amdgcn_s_setprio(3 - (4 * (STEP0 + SP)) / 12);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP + 1 < 6) lstep<FLAGS, STEP0, SP + 1>(U, addr, buf, acc, prev, out_lane, sink);
@@ -268,5 +272,7 @@ int main() {
     run("ladder 5: + setprio + stores only", k_ladder<5>, 512);
     run("ladder 7: + setprio + transform + ReLU + stores", k_ladder<7>, 512);
     run("ladder 6: transform + ReLU + stores, no setprio", k_ladder<6>, 512);
+    run("ladder 23: 7 with the epilogue block at priority 3", k_ladder<23>, 512);
+    run("ladder 39: 7 with the epilogue block at priority 0", k_ladder<39>, 512);
     return 0;
 }
