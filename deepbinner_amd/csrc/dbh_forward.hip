@@ -408,6 +408,20 @@ __device__ __forceinline__ void epilogue(const f4 (&acc)[MT][NT], float* out_lan
 // 64 lanes x 16 B = one 1 KiB piece per wave-instruction, destination = wave-uniform base +
 // lane*16) while the current layer's MFMAs run; no VGPRs, no ds_write.  The __syncthreads()
 // that ends the layer carries the vmcnt(0) that retires them.
+// A read-only view of a global array for buffer loads: scalar base + per-lane 32-bit byte offset +
+// scalar byte offset, all in the instruction - where a global_load needs a 64-bit vector add per
+// address that its 13-bit immediate cannot reach.  (No bounds: the range covers any image.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_view(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f2 buffer_load_f2(__amdgpu_buffer_rsrc_t view, unsigned lane_bytes,
+                                             unsigned uniform_bytes) {
+    // (two dword loads: this hipcc lowers the b64 / b128 forms of the builtin to ONE dword, splat)
+    const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(view, (int)lane_bytes, (int)uniform_bytes, 0);
+    const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(view, (int)lane_bytes + 4, (int)uniform_bytes, 0);
+    return f2{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
+}
+
 // One 1 KiB piece: 64 lanes x 16 B from the wave-uniform global address `g_piece` (in scalar
 // registers: the instruction's SADDR form, the lane's 16 lane bytes as its 32-bit offset - no
 // 64-bit vector add per piece) to the wave-uniform LDS address in M0 + lane * 16.
@@ -1247,11 +1261,15 @@ struct SmallMRegs {
                                                    int wave) {
         if (ACTIVE == kWaves || wave < ACTIVE) {
             const int t0 = (wave % NGROUPS) * NTW, ks = wave / NGROUPS;
-            const float* b_lane = packed + weight_offset(CONV) + (ks * SP * 3 + t0) * 128 + lane * 2;
+            // buffer loads: the wave's part of the address is scalar, the lane's one shift
+            const __amdgpu_buffer_rsrc_t view = buffer_view(packed + weight_offset(CONV));
+            const unsigned wave_bytes = (unsigned)((ks * SP * 3 + t0) * 128) * 4u;
+            const unsigned lane_bytes = (unsigned)lane * 8u;
 #pragma unroll
             for (int k = K0; k < K1; ++k) {
                 const int t = k % NTW, sp = (k / NTW) % SP, tap = k / (NTW * SP);
-                b[k] = *reinterpret_cast<const f2*>(b_lane + ((tap * SPTOT + sp) * 3 + t) * 128);
+                b[k] = buffer_load_f2(view, lane_bytes,
+                                      wave_bytes + (unsigned)(((tap * SPTOT + sp) * 3 + t) * 128) * 4u);
             }
         }
     }
