@@ -803,6 +803,140 @@ __device__ __forceinline__ void w23_pooled_epilogue_half(const f4 (&acc)[4], int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// F(2,3) with 16 input channels (conv6: 16 -> 48, L = 256, no pooling): 384 MFMAs instead of the
+// direct form's 576.  One tile of 16 pairs per wave as in conv7, but with two channel groups a
+// tile is only two steps of eight MFMAs, so the three N tiles run as ONE six-step pipeline: steps
+// 0-1 build U (eight register pairs) and multiply for tile 0, steps 2-3 tile 1 with tile 0's
+// outputs stored inside them, steps 4-5 tile 2 with tile 1's.  Input and output live in different
+// buffers (IN_OFF at pitch kS16, OUT_OFF at pitch kS48): no barrier before the stores.
+// Weights by N tile: [t][sp][matrix pair][lane][matrix of the pair][e].
+// ---------------------------------------------------------------------------------------------
+struct W23U16 {
+    f2 u[4][2];      // [xi][sp]
+};
+struct W23Pipe16 {
+    f2 rows[2][4];   // [step parity][input row]
+    f4 b[2][2];      // [step parity][matrix pair]
+};
+
+template <int G, class Side>
+__device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned b_addr,
+                                            W23Pipe16& pipe, f4 (&acc)[3][4], const float (&bias)[3],
+                                            const Side& side) {
+    constexpr int T = G / 2, SP = G % 2;
+    auto loads = [&](auto step_tag) {
+        constexpr int N = decltype(step_tag)::value;
+        if constexpr (N < 2) {
+            pipe.rows[N & 1][0] = ds_read_f2<(0 * kS16 + N * 8) * 4>(a_addr);
+            pipe.rows[N & 1][1] = ds_read_f2<(1 * kS16 + N * 8) * 4>(a_addr);
+            pipe.rows[N & 1][2] = ds_read_f2<(2 * kS16 + N * 8) * 4>(a_addr);
+            pipe.rows[N & 1][3] = ds_read_f2<(3 * kS16 + N * 8) * 4>(a_addr);
+        }
+        pipe.b[N & 1][0] = ds_read_f4<((N * 2 + 0) * 256) * 4>(b_addr);
+        pipe.b[N & 1][1] = ds_read_f4<((N * 2 + 1) * 256) * 4>(b_addr);
+    };
+    if constexpr (G == 0) loads(IntC<0>{});
+    if constexpr (G + 1 < 6) {
+        loads(IntC<G + 1>{});
+        if constexpr (G + 1 < 2) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[2] = pipe.b[G & 1];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(b[p]));
+    progress_priority<G, 6>();
+    if constexpr (T == 0) {
+        f2(&d)[4] = pipe.rows[G & 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[k]));
+        __builtin_amdgcn_sched_barrier(0);
+        U.u[0][SP] = pk_sub(d[0], d[2]);
+        U.u[1][SP] = pk_add(d[1], d[2]);
+        U.u[2][SP] = pk_sub(d[2], d[1]);
+        U.u[3][SP] = pk_sub(d[1], d[3]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) asm volatile("" : "+v"(U.u[x][SP]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP == 0) {
+        // M0 starts at +bias, M3 at -bias (even = M0+M1+M2, odd = M1-M2-M3 both get the bias)
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        const float bv = bias[T];
+        acc[T][0] = mfma4(U.u[0][SP].x, b[0][0], f4{bv, bv, bv, bv});
+        acc[T][1] = mfma4(U.u[1][SP].x, b[0][2], zero);
+        acc[T][2] = mfma4(U.u[2][SP].x, b[1][0], zero);
+        acc[T][3] = mfma4(U.u[3][SP].x, b[1][2], f4{-bv, -bv, -bv, -bv});
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            acc[T][2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[T][2 * p]);
+            acc[T][2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[T][2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        acc[T][2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[T][2 * p]);
+        acc[T][2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[T][2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) asm volatile("" : "+v"(acc[T][x]));
+    __builtin_amdgcn_sched_barrier(0);
+    side(IntC<G>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < 6) w23c16_step<G + 1>(U, a_addr, b_addr, pipe, acc, bias, side);
+}
+
+template <int CONV, int W_LDS, int IN_OFF, int OUT_OFF>
+__device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restrict__ packed,
+                                                int tid, int lane, int wave, long long* ts,
+                                                int ts_base) {
+    static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV) && kConv[CONV].cin == 16 &&
+                  kConv[CONV].cout_pad == 48 && IN_OFF != OUT_OFF, "");
+    constexpr int L = 256;
+    const int n = lane & 15, q = lane >> 4;
+    EpiParams<3, false> ep;
+    load_epi<CONV, -1>(ep, lds, packed, n);
+    // pair j = wave*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
+    const unsigned a_addr = lds_addr(lds + IN_OFF + (wave * 32 + 2 * n) * kS16 + 2 * q);
+    const unsigned b_addr = lds_addr(lds + W_LDS + lane * 4);
+    // this lane's place in output position 2 (wave*16 + 4q): pairs 4q + r follow 2 rows apart
+    lds_float* out_q = lds_pinned(lds + OUT_OFF + n + (1 + 2 * (wave * 16 + 4 * q)) * kS48);
+    W23U16 U;
+    W23Pipe16 pipe;
+    f4 acc[3][4];
+    // rows 2h, 2h+1 of N tile t's accumulators: output transform, ReLU, stores
+    auto finish_half = [&](auto tile_tag, int h) {
+        constexpr int t = decltype(tile_tag)::value;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * h + e;
+            const float even = acc[t][0][r] + acc[t][1][r] + acc[t][2][r];
+            const float odd = acc[t][1][r] - acc[t][2][r] - acc[t][3][r];
+            out_q[(2 * r) * kS48 + t * 16] = fmaxf(even, 0.f);
+            out_q[(2 * r + 1) * kS48 + t * 16] = fmaxf(odd, 0.f);
+        }
+    };
+    w23c16_step<0>(U, a_addr, b_addr, pipe, acc, ep.b, [&](auto tag) {
+        constexpr int G = decltype(tag)::value;
+        if constexpr (G == 2) finish_half(IntC<0>{}, 0);
+        if constexpr (G == 3) finish_half(IntC<0>{}, 1);
+        if constexpr (G == 4) finish_half(IntC<1>{}, 0);
+        if constexpr (G == 5) finish_half(IntC<1>{}, 1);
+    });
+    mark(ts, ts_base);
+    mark(ts, ts_base + 1);
+    finish_half(IntC<2>{}, 0);
+    finish_half(IntC<2>{}, 1);
+    zero_row(lds + OUT_OFF, 0, kS48, 48, tid);
+    zero_row(lds + OUT_OFF, L + 1, kS48, 48, tid);
+    mark(ts, ts_base + 2);
+    full_barrier();
+    mark(ts, ts_base + 3);
+}
+
 template <int CONV, int L, int BNI, int W_LDS, class Begin>
 __device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float* __restrict__ packed,
                                                         int tid, int lane, int wave, long long* ts,
@@ -1867,8 +2001,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // place, so neither needs the barrier between multiplying and storing.
     inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6), kActOff, kMid16>(
         lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
-    inplace_layer<5, kW6, 256, kS16, kS48, false, -1, 0, kMid16, kActOff>(
-        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 18);
+    w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile
     wino_ntile_pooled_layer<6, 256, 2, kW7a>(

@@ -30,7 +30,7 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {3, 48, 48, 1, 4},        // conv1d_3
     {3, 48, 48, 1, 4},        // conv1d_4
     {1, 48, 16, 1, 0},    // conv1d_5
-    {3, 16, 48, 1, 0},    // conv1d_6
+    {3, 16, 48, 1, 2},        // conv1d_6
     {3, 48, 48, 1, 2},        // conv1d_7
     {3, 48, 48, 1, 2},        // conv1d_8
     {3, 48, 48, 1, 2},        // conv1d_9
@@ -48,8 +48,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_7); the others are matrix-major.
-constexpr bool wino2_by_tile(int i) { return i == 6; }
+// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_7); the others are matrix-major.
+constexpr bool wino2_by_tile(int i) { return i == 5 || i == 6; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
@@ -72,7 +72,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 10116, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
+static_assert(forward_mfmas(13) == 9924, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -166,7 +166,7 @@ static_assert(kMid16 + 258 * kS16 <= kW0, "");
 // conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
 constexpr int kW5 = kW0;
 constexpr int kW6 = kW5 + 1 * 48 * 16;
-constexpr int kW7a = kW6 + 3 * 16 * 48;
+constexpr int kW7a = kW6 + 4 * 16 * 48;      // (conv6: four transformed matrices)
 constexpr int kW7b = kW7a + kWinoHalf;
 static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the weight area");
 // stage D (L = 128, Winograd split over wave pairs): conv8's weights in the upper buffer, its
