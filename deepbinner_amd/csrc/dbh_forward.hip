@@ -1242,6 +1242,203 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
 
 
 // ---------------------------------------------------------------------------------------------
+// F(4,3) at L = 256 (conv7 + MaxPool + BN): 64 quads = four tiles of 16 for eight waves, 864 MFMAs
+// instead of F(2,3)'s 1,152.  The two waves of a SIMD, w and w + 4, share tile w & 3 and split its
+// OUTPUT CHANNELS: w takes N tile 0 and the first three channel groups of N tile 1's sum, w + 4
+// N tile 2 and the last three - 108 MFMAs each.  Both build all of U (72 VGPRs) while they
+// multiply for their own N tile (six steps of twelve MFMAs); behind the mid-layer barrier (every
+// input row read: outputs may go in place) come the three steps of the shared N tile, with the
+// own tile's epilogue inside them.  The output transform is linear, so each wave applies it to its
+// partial sums of the shared tile and only two of the four outputs per quad - two f4 per lane -
+// cross LDS each way, announced on a per-pair counter word: w finishes outputs 0,1 (the first
+// pooled position of a quad), w + 4 outputs 2,3 (the second).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_signal(float* lds, int word, int lane) {
+    // (plain LDS instructions: requests of one wave are served in order, so the counter add lands
+    // after the data stored before it; a C++ release atomic would also wait for the wave's global
+    // prefetches)
+    const unsigned addr = lds_addr(lds + kPairSync + word);
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void pair_wait(float* lds, int word, unsigned target) {
+    const unsigned addr = lds_addr(lds + kPairSync + word);
+    for (;;) {
+        unsigned seen;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(addr) : "memory");
+        if ((int)(__builtin_amdgcn_readfirstlane(seen) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct W43nsPipe {
+    f2 rows[2][6];   // [step parity][input row]
+    f4 b[2][3];      // [step parity][matrix pair]
+};
+
+// Step G of a wave's nine: G < 6 = channel group G of its own N tile (TOWN) and of U; G >= 6 =
+// channel group SP0 + G - 6 of the shared N tile 1.  One software pipeline.
+template <int TOWN, int SP0, bool WITH_BIAS, int G, class Side>
+__device__ __forceinline__ void w43ns_step(W43U& U, unsigned a_addr, unsigned b_addr,
+                                           W43nsPipe& pipe, f4 (&own)[6], f4 (&shared)[6],
+                                           float bias_own, float bias_shared, const Side& side) {
+    auto loads = [&](auto step_tag) {
+        constexpr int N = decltype(step_tag)::value;
+        if constexpr (N < 6) w43_load_rows<N>(pipe.rows[N & 1], a_addr);
+        constexpr int T = N < 6 ? TOWN : 1, SP = N < 6 ? N : SP0 + N - 6;
+        pipe.b[N & 1][0] = ds_read_f4<(T * kWinoHalf + (SP * 3 + 0) * 256) * 4>(b_addr);
+        pipe.b[N & 1][1] = ds_read_f4<(T * kWinoHalf + (SP * 3 + 1) * 256) * 4>(b_addr);
+        pipe.b[N & 1][2] = ds_read_f4<(T * kWinoHalf + (SP * 3 + 2) * 256) * 4>(b_addr);
+    };
+    if constexpr (G == 0) loads(IntC<0>{});
+    if constexpr (G + 1 < 9) {
+        loads(IntC<G + 1>{});
+        if constexpr (G + 1 < 6) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[3] = pipe.b[G & 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    if constexpr (G < 6) progress_priority<G, 6>();
+    else progress_priority<G - 6, 3>();
+    constexpr int SP = G < 6 ? G : SP0 + G - 6;      // which channel group of U this step uses
+    if constexpr (G < 6) {
+        f2(&d)[6] = pipe.rows[G & 1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(d[k]));
+        __builtin_amdgcn_sched_barrier(0);
+        w43_transform<G>(U, d);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f4(&acc)[6] = G < 6 ? own : shared;
+    if constexpr (G == 0 || G == 6) {
+        // the chains start here: five from the MFMA's constant 0, M1's from the bias (every output
+        // of the transform takes M1 with weight 1) - for the shared tile in ONE of the two waves
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        const float bv = G == 0 ? bias_own : bias_shared;
+        const bool with_bias = G == 0 || WITH_BIAS;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], zero);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2],
+                                   (p == 0 && with_bias) ? f4{bv, bv, bv, bv} : zero);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    side(IntC<G>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G != 5 && G + 1 < 9)
+        w43ns_step<TOWN, SP0, WITH_BIAS, G + 1>(U, a_addr, b_addr, pipe, own, shared, bias_own,
+                                                bias_shared, side);
+}
+
+// rows 2h, 2h+1 of partial accumulators -> the partial outputs (no ReLU: they are partial sums)
+__device__ __forceinline__ void w43_partial_outputs(const f4 (&acc)[6], int h, f2 (&y)[4]) {
+    const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+    const f2 a0 = f2{acc[0][2 * h], acc[0][2 * h + 1]}, a1 = f2{acc[1][2 * h], acc[1][2 * h + 1]};
+    const f2 a2 = f2{acc[2][2 * h], acc[2][2 * h + 1]}, a3 = f2{acc[3][2 * h], acc[3][2 * h + 1]};
+    const f2 a4 = f2{acc[4][2 * h], acc[4][2 * h + 1]}, a5 = f2{acc[5][2 * h], acc[5][2 * h + 1]};
+    const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+    y[0] = a0 + s12 + s34;
+    y[1] = __builtin_elementwise_fma(k2, d34, d12);
+    y[2] = __builtin_elementwise_fma(k4, s34, s12);
+    y[3] = __builtin_elementwise_fma(k8, d34, d12) + a5;
+}
+
+// One wave's half (HIGH = wave >= 4) of conv7.  begin(): the layer's one-off LDS-DMA requests.
+template <int CONV, int BNI, bool HIGH, class Begin>
+__device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restrict__ packed,
+                                                int tid, int lane, int wave, long long* ts,
+                                                int ts_base, unsigned& pair_rounds,
+                                                const Begin& begin) {
+    constexpr int TOWN = HIGH ? 2 : 0, SP0 = HIGH ? 3 : 0;
+    const int n = lane & 15, q = lane >> 4;
+    const int m = wave & 3;
+    EpiParams<3, true> ep;
+    load_epi<CONV, BNI>(ep, lds, packed, n);
+    // quad j = m*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
+    const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
+    const unsigned a_addr = lds_addr(lds + kActOff + (m * 64 + 4 * pm_n) * kS48 + 2 * q);
+    const unsigned b_addr = lds_addr(lds + kSlot0 + lane * 4);
+    // this lane's place in the (pooled) output of quad m*16 + 2q
+    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + 2 * (m * 16 + 2 * q)) * kS48);
+    float* mine = lds + kX7 + wave * 512 + lane * 4;
+    const float* theirs = lds + kX7 + (wave ^ 4) * 512 + lane * 4;
+    W43U U;
+    W43nsPipe pipe;
+    f4 own[6], shared[6];
+    w43ns_step<TOWN, SP0, !HIGH, 0>(U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1],
+                                    [&](auto tag) {
+                                        if constexpr (decltype(tag)::value == 0) begin();
+                                    });
+    mark(ts, ts_base);
+    lds_barrier();        // every wave has read all its input rows: outputs may go in place
+    mark(ts, ts_base + 1);
+    zero_row(lds + kActOff, 129, kS48, 48, tid);       // (row 0 is zero already)
+    w43ns_step<TOWN, SP0, !HIGH, 6>(
+        U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1], [&](auto tag) {
+            constexpr int G = decltype(tag)::value;
+            if constexpr (G == 6) w43_epilogue_half<TOWN, true, true>(own, 0, ep.sc[TOWN], ep.sh[TOWN], out_q);
+            if constexpr (G == 7) w43_epilogue_half<TOWN, true, true>(own, 1, ep.sc[TOWN], ep.sh[TOWN], out_q);
+        });
+    // the shared N tile: the partial outputs of this wave's three channel groups
+    f2 y[2][4];
+    w43_partial_outputs(shared, 0, y[0]);
+    w43_partial_outputs(shared, 1, y[1]);
+    constexpr int kKeep = HIGH ? 2 : 0, kShip = HIGH ? 0 : 2;
+    // the two outputs of each quad the partner finishes: rows 0..3 of output kShip, then kShip + 1
+    *reinterpret_cast<f4*>(mine) = f4{y[0][kShip].x, y[0][kShip].y, y[1][kShip].x, y[1][kShip].y};
+    *reinterpret_cast<f4*>(mine + 256) =
+        f4{y[0][kShip + 1].x, y[0][kShip + 1].y, y[1][kShip + 1].x, y[1][kShip + 1].y};
+    pair_signal(lds, 2 * m + (HIGH ? 1 : 0), lane);
+    mark(ts, ts_base + 2);
+    pair_wait(lds, 2 * m + (HIGH ? 0 : 1), pair_rounds + 1);
+    pair_rounds += 1;
+    const f4 t0 = *reinterpret_cast<const f4*>(theirs);
+    const f4 t1 = *reinterpret_cast<const f4*>(theirs + 256);
+    const float sc = ep.sc[1], sh = ep.sh[1];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ya = y[h][kKeep][e] + t0[2 * h + e];
+            const float yb = y[h][kKeep + 1][e] + t1[2 * h + e];
+            float p = fmaxf(fmaxf(ya, yb), 0.f);       // ReLU, then MaxPool over the two positions
+            p = fmaf(p, sc, sh);
+            // quad offset e + 8h from the lane's first (pm(4q + 2h + e)); pooled row HIGH ? 1 : 0
+            out_q[(2 * (e + 8 * h) + (HIGH ? 1 : 0)) * kS48 + 16] = p;
+        }
+    full_barrier();
+    mark(ts, ts_base + 3);
+}
+
+template <int CONV, int BNI, class Begin>
+__device__ __forceinline__ void w43_nsplit_pooled_layer(float* lds, const float* __restrict__ packed,
+                                                        int tid, int lane, int wave, long long* ts,
+                                                        int ts_base, unsigned& pair_rounds,
+                                                        const Begin& begin) {
+    static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
+    if (wave < 4)
+        w43_nsplit_half<CONV, BNI, false>(lds, packed, tid, lane, wave, ts, ts_base, pair_rounds, begin);
+    else
+        w43_nsplit_half<CONV, BNI, true>(lds, packed, tid, lane, wave, ts, ts_base, pair_rounds, begin);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same Winograd layer at L = 128, where there are only four 16-pair tiles for eight waves:
 // wave w takes tile w&3 and ONE half of the transform pair (w < 4: M0,M1 from V0,V1; w >= 4:
 // M2,M3 from V2,V3), 72 MFMAs each, and partner waves (w, w+4) swap what the other needs
@@ -1808,6 +2005,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds[kParams + i] = packed_entry[src];
     }
     if (tid_entry < 2) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
+    if (tid_entry < 8) reinterpret_cast<unsigned*>(lds + kPairSync)[tid_entry] = 0u;
     // conv1d_1's three taps (B operand: k = lane >> 4 picks the tap) and its bias / BN1
     EpiParams<3, true> ep_a;
     float bw_a[3];
@@ -1821,6 +2019,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
+    unsigned pair_rounds = 0;     // exchanges the wave pairs of conv7 have made so far
 
     // Seam-b2 input of the window in hand: this lane's two samples for the statistics, its
     // A-fragment samples for conv1d_1 and which of those lie inside the window.  Filled by
@@ -1976,10 +2175,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                             [&](int t, float* dst) { third(2, t, dst); });
     w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6, sync_rounds,
                             [&](int t, float* dst) { third(3, t, dst); });
-    // conv4 + MaxPool + BN2; conv5's and conv6's weights take over slot 0 when tile 0 is done
-    // (conv7's follow while conv5 runs)
+    // conv4 + MaxPool + BN2; conv7's thirds follow conv4's out of the slots, and conv5's and
+    // conv6's weights go to the upper buffer once conv4 has read the rows there (tile 0 done)
     w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
-                          [&](int t, float*) {
+                          [&](int t, float* dst) {
+                              third(6, t, dst);      // conv7's six F(4,3) matrices, a third a slot
                               if (t == 0) {
                                   dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
                                                                      lds + kW5, lane, wave);
@@ -1994,18 +2194,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
-    // conv5's and conv6's weights sit side by side at the bottom of the weight area (DMA'd
-    // during conv4); conv7's four Winograd matrices follow them, fetched while conv5 runs.
+    // conv5's and conv6's weights sit side by side in the upper buffer (DMA'd during conv4),
+    // conv7's six Winograd matrices in the three slots.
     // conv5's 16-channel output goes beside the activation buffer (kMid16: the upper buffer, idle
     // until conv8's weights arrive during conv7) and conv6 brings it back: neither layer works in
     // place, so neither needs the barrier between multiplying and storing.
-    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, conv_weight_floats(6), kActOff, kMid16>(
-        lds, packed, packed + weight_offset(6), lds + kW7a, tid, lane, wave, ts, 14);
+    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, 0, kActOff, kMid16>(
+        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 14);
     w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile
-    wino_ntile_pooled_layer<6, 256, 2, kW7a>(
-        lds, packed, tid, lane, wave, ts, 22,
+    w43_nsplit_pooled_layer<6, 2>(
+        lds, packed, tid, lane, wave, ts, 22, pair_rounds,
         [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); });
     if (stop_stage == 2) {
         if (debug_stage < 100)

@@ -31,7 +31,7 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {3, 48, 48, 1, 4},        // conv1d_4
     {1, 48, 16, 1, 0},    // conv1d_5
     {3, 16, 48, 1, 2},        // conv1d_6
-    {3, 48, 48, 1, 2},        // conv1d_7
+    {3, 48, 48, 1, 4},        // conv1d_7
     {3, 48, 48, 1, 2},        // conv1d_8
     {3, 48, 48, 1, 2},        // conv1d_9
     {1, 48, 48, 1, 0},    // conv1d_10
@@ -48,8 +48,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_7); the others are matrix-major.
-constexpr bool wino2_by_tile(int i) { return i == 5 || i == 6; }
+// N-tile-outer loops of dbh_forward.hip (conv1d_6); conv1d_8 and conv1d_9 are matrix-major.
+constexpr bool wino2_by_tile(int i) { return i == 5; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
@@ -72,7 +72,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 9924, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
+static_assert(forward_mfmas(13) == 9636, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -163,12 +163,15 @@ static_assert(kUpper + 4 * 48 * 48 <= kW0, "upper weight buffer must stay below 
 // ... and, before that, as the home of conv5's 16-channel output (258 rows x kS16)
 constexpr int kMid16 = kUpper;
 static_assert(kMid16 + 258 * kS16 <= kW0, "");
-// conv5 | conv6 | conv7 (Winograd, two halves) side by side in the weight area
-constexpr int kW5 = kW0;
+// conv7's six F(4,3) matrices take the whole weight area (thirds by N tile in slots 0..2, like a
+// stage-B layer's: requested as conv4 leaves each slot); conv5's and conv6's weights live in the
+// upper buffer behind conv5's output (rows conv4 has finished reading by its mid-layer barrier)
+constexpr int kW5 = kMid16 + 258 * kS16;     // 18,060
 constexpr int kW6 = kW5 + 1 * 48 * 16;
-constexpr int kW7a = kW6 + 4 * 16 * 48;      // (conv6: four transformed matrices)
-constexpr int kW7b = kW7a + kWinoHalf;
-static_assert(kW7b + kWinoHalf <= kLdsFloatsAD, "conv5..7 weights overflow the weight area");
+static_assert((kW5 * 4) % 16 == 0 && (kW6 * 4) % 16 == 0 && kW6 + 4 * 16 * 48 <= kW0, "");
+// conv7's pair exchange: two f4 per lane and wave, in activation rows its pooled output leaves free
+constexpr int kX7 = 130 * kS48;
+static_assert((kX7 * 4) % 16 == 0 && kX7 + 8 * 512 <= 258 * kS48, "");
 // stage D (L = 128, Winograd split over wave pairs): conv8's weights in the upper buffer, its
 // pair-exchange scratch right above the activations; conv9's weights at the top of the arena
 // and its exchange scratch below them, both clear of the stage-E weights arriving meanwhile.
@@ -235,7 +238,9 @@ constexpr int kSync = kParams + kParamFloats;
 constexpr int kStatRed = kSync + 2;
 constexpr int kStatOut = kStatRed + 32;
 static_assert(kStatRed % 2 == 0, "64-bit words");
-constexpr int kLdsFloats = kStatOut + 4;
+// one counter word per half of each of conv7's four wave pairs (dbh_forward.hip: pair_signal)
+constexpr int kPairSync = kStatOut + 4;
+constexpr int kLdsFloats = kPairSync + 8;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])
