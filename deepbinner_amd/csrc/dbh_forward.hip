@@ -692,118 +692,6 @@ __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slo
 // next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
 // at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
 // ---------------------------------------------------------------------------------------------
-// F(2,3) with whole tiles per wave (conv7, L = 256: one tile of 16 pairs per wave), run the way
-// the F(4,3) layers below are (see there for the why): N tile by N tile, the transformed inputs
-// U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3 built inside tile 0's steps and kept in registers
-// (48 VGPRs), tiles 1 and 2 pure ds_read_b128 + MFMA loops that carry the previous tile's epilogue,
-// outputs stored in place once every wave has read its rows.  Weights by N tile:
-// [t][sp][matrix pair][lane][matrix of the pair][e], all 36 KB resident before the layer starts.
-// ---------------------------------------------------------------------------------------------
-struct W23U {
-    f2 u[4][6];      // [xi][sp]
-};
-
-template <int SP>
-__device__ __forceinline__ void w23_load_rows(f2 (&d)[4], unsigned a_addr) {
-    d[0] = ds_read_f2<(0 * kS48 + SP * 8) * 4>(a_addr);
-    d[1] = ds_read_f2<(1 * kS48 + SP * 8) * 4>(a_addr);
-    d[2] = ds_read_f2<(2 * kS48 + SP * 8) * 4>(a_addr);
-    d[3] = ds_read_f2<(3 * kS48 + SP * 8) * 4>(a_addr);
-}
-template <int SP>
-__device__ __forceinline__ void w23_load_b(f4 (&b)[2], unsigned b_addr) {
-    b[0] = ds_read_f4<((SP * 2 + 0) * 256) * 4>(b_addr);
-    b[1] = ds_read_f4<((SP * 2 + 1) * 256) * 4>(b_addr);
-}
-
-template <bool TILE0, int STEP0, int STEPS, int SP, class Side>
-__device__ __forceinline__ void w23_tile_step(W23U& U, unsigned a_addr, unsigned b_addr,
-                                              f2 (&dbuf)[2][4], f4 (&buf)[2][2], f4 (&acc)[4],
-                                              float bias, const Side& side) {
-    if constexpr (SP + 1 < 6) {
-        if constexpr (TILE0) w23_load_rows<SP + 1>(dbuf[(SP + 1) & 1], a_addr);
-        w23_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
-        if constexpr (TILE0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    f4(&b)[2] = buf[SP & 1];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(b[p]));
-    progress_priority<STEP0 + SP, STEPS>();
-    if constexpr (TILE0) {
-        f2(&d)[4] = dbuf[SP & 1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[k]));
-        __builtin_amdgcn_sched_barrier(0);
-        U.u[0][SP] = pk_sub(d[0], d[2]);
-        U.u[1][SP] = pk_add(d[1], d[2]);
-        U.u[2][SP] = pk_sub(d[2], d[1]);
-        U.u[3][SP] = pk_sub(d[1], d[3]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) asm volatile("" : "+v"(U.u[x][SP]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP == 0) {
-        // the chains start here: M0 at +bias and M3 at -bias (even = M0+M1+M2 and odd = M1-M2-M3
-        // then both arrive with the bias added), M1 and M2 at the MFMA's constant 0
-        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-        acc[0] = mfma4(U.u[0][SP].x, b[0][0], f4{bias, bias, bias, bias});
-        acc[1] = mfma4(U.u[1][SP].x, b[0][2], zero);
-        acc[2] = mfma4(U.u[2][SP].x, b[1][0], zero);
-        acc[3] = mfma4(U.u[3][SP].x, b[1][2], f4{-bias, -bias, -bias, -bias});
-    } else {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
-            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
-        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) asm volatile("" : "+v"(acc[x]));
-    __builtin_amdgcn_sched_barrier(0);
-    side(IntC<SP>{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP + 1 < 6)
-        w23_tile_step<TILE0, STEP0, STEPS, SP + 1>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
-}
-
-template <bool TILE0, int STEP0, int STEPS, class Side, class Begin = NoBegin>
-__device__ __forceinline__ void w23_tile(W23U& U, const float* a_lane, const float* tile_lane,
-                                         f4 (&acc)[4], float bias, const Side& side,
-                                         const Begin& begin = Begin()) {
-    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(tile_lane);
-    f2 dbuf[2][4];
-    f4 buf[2][2];
-    if constexpr (TILE0) w23_load_rows<0>(dbuf[0], a_addr);
-    w23_load_b<0>(buf[0], b_addr);
-    begin();
-    w23_tile_step<TILE0, STEP0, STEPS, 0>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
-}
-
-// rows 2h, 2h+1 of the accumulators = pairs 4q + 2h, 4q + 2h + 1 of the wave's tile, N tile T:
-// output transform, ReLU, MaxPool over the pair, BatchNorm, store (pooled position = pair)
-template <int T, bool BN>
-__device__ __forceinline__ void w23_pooled_epilogue_half(const f4 (&acc)[4], int h, float sc,
-                                                         float sh, lds_float* out_q) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int r = 2 * h + e;
-        const float even = acc[0][r] + acc[1][r] + acc[2][r];
-        const float odd = acc[1][r] - acc[2][r] - acc[3][r];
-        float o = fmaxf(fmaxf(even, 0.f), fmaxf(odd, 0.f));
-        if (BN) o = fmaf(o, sc, sh);
-        out_q[r * kS48 + T * 16] = o;      // pair wave*16 + 4q + r (out_q: this lane's place in pair wave*16 + 4q)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // F(2,3) with 16 input channels (conv6: 16 -> 48, L = 256, no pooling): 384 MFMAs instead of the
 // direct form's 576.  One tile of 16 pairs per wave as in conv7, but with two channel groups a
 // tile is only two steps of eight MFMAs, so the three N tiles run as ONE six-step pipeline: steps
@@ -937,43 +825,6 @@ __device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restr
     mark(ts, ts_base + 3);
 }
 
-template <int CONV, int L, int BNI, int W_LDS, class Begin>
-__device__ __forceinline__ void wino_ntile_pooled_layer(float* lds, const float* __restrict__ packed,
-                                                        int tid, int lane, int wave, long long* ts,
-                                                        int ts_base, const Begin& begin) {
-    static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV) && L / 32 == kWaves, "");
-    constexpr int LOUT = L / 2;
-    constexpr bool BN = BNI >= 0;
-    constexpr int kTile = 6 * 2 * 256;       // floats of one N tile's weights
-    const int n = lane & 15, q = lane >> 4;
-    EpiParams<3, BN> ep;
-    load_epi<CONV, BNI>(ep, lds, packed, n);
-    // pair j = wave*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
-    const float* a_lane = lds + kActOff + (wave * 32 + 2 * n) * kS48 + 2 * q;
-    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + wave * 16 + 4 * q) * kS48);
-    W23U U;
-    f4 acc[2][4];
-    w23_tile<true, 0, 6>(U, a_lane, lds + W_LDS + lane * 4, acc[0], ep.b[0], NoSide(), begin);
-    mark(ts, ts_base);
-    lds_barrier();        // every wave has read all its input rows: outputs may go in place
-    mark(ts, ts_base + 1);
-    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);       // (row 0 is zero already)
-    w23_tile<false, 0, 12>(U, a_lane, lds + W_LDS + kTile + lane * 4, acc[1], ep.b[1], [&](auto tag) {
-        constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_pooled_epilogue_half<0, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_q);
-        if constexpr (SP == 3) w23_pooled_epilogue_half<0, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_q);
-    });
-    w23_tile<false, 6, 12>(U, a_lane, lds + W_LDS + 2 * kTile + lane * 4, acc[0], ep.b[2], [&](auto tag) {
-        constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w23_pooled_epilogue_half<1, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_q);
-        if constexpr (SP == 3) w23_pooled_epilogue_half<1, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_q);
-    });
-    mark(ts, ts_base + 2);
-    w23_pooled_epilogue_half<2, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
-    w23_pooled_epilogue_half<2, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
-    full_barrier();  
-    mark(ts, ts_base + 3);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Winograd F(4,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1) at L = 512, in place.

@@ -24,7 +24,8 @@ LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
         NAMES[14 + 4 * i + j] = '%s %s' % (l, what)
-NAMES.update({34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
+NAMES.update({22: 'conv7 own N tile done', 23: 'conv7 barrier', 24: 'conv7 shared tile done, partials published', 25: 'conv7 end',
+              34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
               38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
 for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global)', 'end']):
     NAMES[41 + j] = 'conv17 %s' % what
