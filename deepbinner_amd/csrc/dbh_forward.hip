@@ -1,28 +1,34 @@
-// dbh_forward.hip — the Deepbinner forward pass as ONE gfx950 kernel: one 512-thread workgroup
-// (8 wave64s, 2 per SIMD) carries one 1024-sample window through all 20 convolutions with the
-// activations resident in LDS the whole way; HBM sees 4 KiB in and n_classes floats out per
-// window, the 429 KB of weights stream from L2.
+// dbh_forward.hip — the Deepbinner forward pass as ONE persistent gfx950 kernel: at most one
+// 512-thread workgroup (8 wave64s, 2 per SIMD) per CU, each walking windows b, b + grid, ... and
+// carrying every 1024-sample window through all 20 convolutions with the activations resident in
+// LDS the whole way; HBM sees 2 KiB of int16 in and n_classes floats + a call out per window, the
+// weights stream from L2 by LDS-DMA.
 //
 // What it computes: reference deepbinner/network_architecture.py:18-95 as evaluated by
 // model.predict (deepbinner/classify.py:361) — see oracle/network_ref.py for the operator
-// semantics (TensorFlow SAME padding, valid-count average pooling, BN after ReLU/pool).
+// semantics (TensorFlow SAME padding, valid-count average pooling, BN after ReLU/pool) — and, in
+// seam-b2 mode, the slicing and z-normalisation in front of it (classify.py:337-357,
+// trim_signal.py:61-69) and the renormalise + call behind it (classify.py:285-295, 387-393).
 //
-// How (DESIGN.md section 4 has the full account):
+// How (DESIGN.md section 4 has the full account and the measurements behind each choice):
 //   - every convolution is a sum of [positions x C_in] . [C_in x C_out] products on the fp32
 //     matrix pipe (v_mfma_f32_16x16x4_f32: M = 16 positions, N = 16 output channels, K = 4 input
-//     channels; exact fp32 FMA chains at the vector-ALU rate, VALU free for the epilogues);
-//   - the six 48->48 k=3 layers at L >= 128 (84 % of the FLOPs) run as Winograd F(2,3): four
-//     transformed products per output pair instead of six, 1.5x fewer MFMAs;
-//   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row stride
-//     C+4 floats, conflict-free), issued from inline asm one step ahead with hand-counted waits;
-//   - B fragments (weights): ds_read_b64 from a fragment-ordered copy that LDS-DMA
-//     (global_load_lds_dwordx4) brought in one layer ahead, or - for the single-tile tail layers,
-//     where a weight is used once per window - global loads straight into registers, trickled
-//     out several stages ahead;
-//   - accumulators hold a whole layer, so the 104 KiB activation buffer is updated in place
-//     (barrier, fused bias/ReLU/MaxPool/BatchNorm epilogue, barrier);
-//   - in seam-b2 mode the kernel also slices and z-normalises its int16 window (fp64, exact
-//     integer sums) and, for one-window reads, renormalises and makes the barcode call.
+//     channels).  The pipe is shared with the vector ALU: every other vector instruction costs
+//     matrix time, so the code counts them;
+//   - the k = 3 layers with enough positions run as Winograd: F(4,3) for conv2,3,4 (L = 512, one
+//     tile of 16 quads per wave, N tile by N tile with the transformed inputs in registers) and
+//     conv7 (L = 256, a tile per wave PAIR, split by output channels), F(2,3) for conv6, conv8,
+//     conv9 - 9,636 MFMAs per window instead of the direct form's 16,452;
+//   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row pitch
+//     50 floats), B fragments (weights): ds_read_b128 / b64 from fragment-ordered copies that
+//     LDS-DMA brought in a phase ahead; both issued from inline asm one step ahead with
+//     hand-counted waits.  conv17's weights, used once per window, go to registers by buffer loads;
+//   - outputs are stored in place once every wave has read its inputs (one barrier mid-layer),
+//     the epilogue of an N tile inside the MFMA steps of the next one;
+//   - activations are held times 2^-60 so that ReLU is the clamp modifier of the instruction that
+//     produces a value (dbh_layout.h: kActScale);
+//   - the last three layers run for eight windows at a time, one wave per window (batched tail);
+//   - the next window's samples and statistics are fetched under the current one's last stages.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
