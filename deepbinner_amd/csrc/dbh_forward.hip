@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, flo
 // the last store) and the layer's three weight thirds are in slots 0..2 or on their way (they land
 // before the barrier below releases).  next_third(t, dst): request third t of the NEXT layer's
 // weights (or whatever takes slot t's place) - called once every wave has left tile t.
-template <int CONV, bool POOL, int BNI, class NextThird>
+template <int CONV, bool POOL, int BNI, bool END_BARRIER, class NextThird>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
                                           unsigned& sync_rounds, const NextThird& next_third) {
@@ -1092,8 +1092,12 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
     w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
     if (ts_base == 6) mark(ts, 58);
-    full_barrier();        // the layer is stored; every wave has left tile 2
-    next_third(2, lds + kSlot2);
+    // END_BARRIER false: the caller's next layer reads only rows this wave wrote itself (conv5, a
+    // 1x1 convolution, after conv4) and takes care of slot 2 behind its own barrier
+    if constexpr (END_BARRIER) {
+        full_barrier();        // the layer is stored; every wave has left tile 2
+        next_third(2, lds + kSlot2);
+    }
     mark(ts, ts_base + 3);
 }
 
@@ -2028,13 +2032,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     auto third = [&](int conv, int t, float* dst) {
         dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
     };
-    w43_layer<1, false, -1>(lds, packed, tid, lane, wave, ts, 2, sync_rounds,
+    w43_layer<1, false, -1, true>(lds, packed, tid, lane, wave, ts, 2, sync_rounds,
                             [&](int t, float* dst) { third(2, t, dst); });
-    w43_layer<2, false, -1>(lds, packed, tid, lane, wave, ts, 6, sync_rounds,
+    w43_layer<2, false, -1, true>(lds, packed, tid, lane, wave, ts, 6, sync_rounds,
                             [&](int t, float* dst) { third(3, t, dst); });
     // conv4 + MaxPool + BN2; conv7's thirds follow conv4's out of the slots, and conv5's and
     // conv6's weights go to the upper buffer once conv4 has read the rows there (tile 0 done)
-    w43_layer<3, true, 1>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
+    w43_layer<3, true, 1, false>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
                           [&](int t, float* dst) {
                               third(6, t, dst);      // conv7's six F(4,3) matrices, a third a slot
                               if (t == 0) {
@@ -2045,6 +2049,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                               }
                           });
     if (stop_stage == 1) {
+        full_barrier();      // (conv4 ends without one)
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 256, 48, glob(args()->debug_out) + win * kStageFloats[1], tid);
         return;
@@ -2056,8 +2061,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // conv5's 16-channel output goes beside the activation buffer (kMid16: the upper buffer, idle
     // until conv8's weights arrive during conv7) and conv6 brings it back: neither layer works in
     // place, so neither needs the barrier between multiplying and storing.
+    // conv5 is a 1x1 convolution over exactly the rows a wave has just written (32 pooled
+    // positions = its two position tiles), its weights are complete once conv4's split barrier
+    // has been passed (every wave's DMA pieces landed before it arrived there): no workgroup
+    // barrier between conv4 and conv5.  Slot 2 - every wave has left conv4's tile 2 behind
+    // conv5's barrier - gets conv7's last third then.
     inplace_layer<4, kW5, 256, kS48, kS16, false, -1, 0, kActOff, kMid16>(
         lds, packed, nullptr, nullptr, tid, lane, wave, ts, 14);
+    third(6, 2, lds + kSlot2);
     w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile
