@@ -714,7 +714,8 @@ struct W23Pipe16 {
     f4 b[2][2];      // [step parity][matrix pair]
 };
 
-template <int G, class Side>
+// NSTEPS: two per N tile the wave works on (b_addr = the first of them).
+template <int G, int NSTEPS, class Side>
 __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned b_addr,
                                             W23Pipe16& pipe, f4 (&acc)[3][4], const float (&bias)[3],
                                             const Side& side) {
@@ -731,7 +732,7 @@ __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned
         pipe.b[N & 1][1] = ds_read_f4<((N * 2 + 1) * 256) * 4>(b_addr);
     };
     if constexpr (G == 0) loads(IntC<0>{});
-    if constexpr (G + 1 < 6) {
+    if constexpr (G + 1 < NSTEPS) {
         loads(IntC<G + 1>{});
         if constexpr (G + 1 < 2) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
@@ -741,7 +742,7 @@ __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned
     f4(&b)[2] = pipe.b[G & 1];
 #pragma unroll
     for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(b[p]));
-    progress_priority<G, 6>();
+    progress_priority<G, NSTEPS>();
     if constexpr (T == 0) {
         f2(&d)[4] = pipe.rows[G & 1];
 #pragma unroll
@@ -780,7 +781,8 @@ __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned
     __builtin_amdgcn_sched_barrier(0);
     side(IntC<G>{});
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G + 1 < 6) w23c16_step<G + 1>(U, a_addr, b_addr, pipe, acc, bias, side);
+    if constexpr (G + 1 < NSTEPS)
+        w23c16_step<G + 1, NSTEPS>(U, a_addr, b_addr, pipe, acc, bias, side);
 }
 
 template <int CONV, int W_LDS, int IN_OFF, int OUT_OFF>
@@ -813,7 +815,7 @@ __device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restr
             out_q[(2 * r + 1) * kS48 + t * 16] = fmaxf(odd, 0.f);
         }
     };
-    w23c16_step<0>(U, a_addr, b_addr, pipe, acc, ep.b, [&](auto tag) {
+    w23c16_step<0, 6>(U, a_addr, b_addr, pipe, acc, ep.b, [&](auto tag) {
         constexpr int G = decltype(tag)::value;
         if constexpr (G == 2) finish_half(IntC<0>{}, 0);
         if constexpr (G == 3) finish_half(IntC<0>{}, 1);
@@ -1575,6 +1577,47 @@ __device__ __forceinline__ void inception_1x1(const float* in_region, const floa
     epilogue<4, 1, S_OUT, POOLBN, POOLBN, false>(acc, out_lane, ep);
 }
 
+// The 16 -> 48, k = 3 convolutions of the inception block (conv13, conv15; L = 64) as Winograd
+// F(2,3): pair tile m (16 pairs = 32 positions) x NT channel tiles from tile T0, 16 MFMAs per
+// (pair tile, channel tile) instead of the direct form's 24.  POOLBN: the pair's two outputs are
+// max-pooled (that IS MaxPool2) and batch-normalised into the concat buffer; otherwise both are
+// stored, ReLU'd.  Pointers are for channel tile T0.
+template <int NT, int S_OUT, bool POOLBN>
+__device__ __forceinline__ void inception_k3_wino(const float* in_region, const float* w_tile0,
+                                                  float* out_region, int out_ch,
+                                                  const float* __restrict__ bias_lane,
+                                                  const float* __restrict__ scale_lane,
+                                                  const float* __restrict__ shift_lane, int m,
+                                                  int lane) {
+    const int n = lane & 15, q = lane >> 4;
+    EpiParams<NT, POOLBN> ep;
+    ep.load(bias_lane, scale_lane, shift_lane);
+    float bias[3] = {ep.b[0], NT > 1 ? ep.b[NT > 1 ? 1 : 0] : 0.f, NT > 2 ? ep.b[NT > 2 ? 2 : 0] : 0.f};
+    // pair j = m*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
+    const unsigned a_addr = lds_addr(in_region + (m * 32 + 2 * n) * kS16 + 2 * q);
+    const unsigned b_addr = lds_addr(w_tile0 + lane * 4);
+    W23U16 U;
+    W23Pipe16 pipe;
+    f4 acc[3][4];
+    w23c16_step<0, 2 * NT>(U, a_addr, b_addr, pipe, acc, bias, NoSide());
+    // pair m*16 + 4q + r of the window -> pooled position (same number) or positions 2j, 2j + 1
+    float* out_lane = out_region + (1 + (POOLBN ? 1 : 2) * (m * 16 + 4 * q)) * S_OUT + out_ch + n;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float even = acc[t][0][r] + acc[t][1][r] + acc[t][2][r];
+            const float odd = acc[t][1][r] - acc[t][2][r] - acc[t][3][r];
+            if constexpr (POOLBN) {
+                const float o = fmaxf(fmaxf(even, odd), 0.f);
+                out_lane[r * S_OUT + t * 16] = fmaf(o, ep.sc[t], ep.sh[t]);
+            } else {
+                out_lane[(2 * r) * S_OUT + t * 16] = fmaxf(even, 0.f);
+                out_lane[(2 * r + 1) * S_OUT + t * 16] = fmaxf(odd, 0.f);
+            }
+        }
+}
+
 // k=3 convolution of the inception block: MT position tiles from tile m0 x NT channel tiles
 // from tile t (pointers are for channel tile t; NT > 1 walks on in steps of 16 channels).
 template <int SP, int MT, int NT, int S_IN, int S_OUT, bool POOLBN>
@@ -2115,8 +2158,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds, packed, tid, lane, wave, ts, 30,
         [] {},
         [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
-            dma_weights_slice<kEWFloats, decltype(tag)::value, 6>(packed + weight_offset(9),
-                                                                  lds + kEW, lane, wave);
+            dma_weights_slice<kEWEarly, decltype(tag)::value, 6>(packed + weight_offset(9),
+                                                                 lds + kEW, lane, wave);
         });
     if (stop_stage == 3) {
         if (debug_stage < 100)
@@ -2135,6 +2178,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             fetch_window_at(next_src, next_cnt, next_pad, tid, wave * kMtA, n, q, in_v0, in_v1,
                             in_raw, in_inside);
         }
+        // the end of conv16's weights (what did not fit beside conv9's exchange scratch)
+        dma_weights<kEWFloats - kEWEarly>(packed + weight_offset(9) + kEWEarly, lds + kEW + kEWEarly,
+                                          lane, wave);
         // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
         const float* X = lds + kEX;
         // 384 threads, each one channel and eight consecutive positions: ten row reads for eight
@@ -2198,20 +2244,33 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         lds_barrier();
         mark(ts, 36);
 
-        // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, on waves 0-3, and
-        // conv13 (16->48, k3) -> concat 96..143 on waves 4-7: one position tile and all three
-        // channel tiles each, 36 MFMAs per wave.
-        if (wave < 4) {
-            inception_k3<2, 1, 3, kS16, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, 0,
-                                                     bias_tab + bias_offset(14), nullptr, nullptr,
-                                                     0, wave, lane);
-        } else {
-            inception_k3<2, 1, 3, kS16, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
-                                                     bias_tab + bias_offset(12), sc5 + 96,
-                                                     sh5 + 96, 0, wave - 4, lane);
+        // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, and conv13
+        // (16->48, k3) -> concat 96..143, both as Winograd F(2,3): per convolution two pair tiles
+        // x three channel tiles = six units of 16 MFMAs, dealt so that every SIMD carries 48:
+        //   conv15: w0: m0 t0,1   w1: m1 t0,1   w2: m0 t2   w3: m1 t2
+        //   conv13: w6: m0 t0,1   w7: m1 t0,1   w4: m0 t2   w5: m1 t2
+        {
+            constexpr int kTile = 2 * 2 * 256;       // floats of one channel tile's weights
+            const int m = wave & 1;
+            if (wave < 2) {
+                inception_k3_wino<2, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, 0,
+                                                  bias_tab + bias_offset(14), nullptr, nullptr, m, lane);
+            } else if (wave < 4) {
+                inception_k3_wino<1, kS48, false>(lds + kET4a, lds + w15 + 2 * kTile, lds + kET4b, 32,
+                                                  bias_tab + bias_offset(14) + 32, nullptr, nullptr, m,
+                                                  lane);
+            } else if (wave < 6) {
+                inception_k3_wino<1, kS192, true>(lds + kET3, lds + w13 + 2 * kTile, lds + kECat, 96 + 32,
+                                                  bias_tab + bias_offset(12) + 32, sc5 + 96 + 32,
+                                                  sh5 + 96 + 32, m, lane);
+            } else {
+                inception_k3_wino<2, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
+                                                  bias_tab + bias_offset(12), sc5 + 96, sh5 + 96, m,
+                                                  lane);
+            }
         }
         mark(ts, 37);
-        lds_barrier();
+        full_barrier();      // (also: the late part of conv16's weights, asked for in E0, has landed)
         mark(ts, 38);
 
         // E3: conv16 (48->48, k3) -> concat 144..191: twelve (position tile, channel tile) units

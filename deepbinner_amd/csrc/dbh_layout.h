@@ -37,9 +37,9 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {1, 48, 48, 1, 0},    // conv1d_10
     {1, 48, 48, 1, 0},    // conv1d_11
     {1, 48, 16, 1, 0},    // conv1d_12
-    {3, 16, 48, 1, 0},    // conv1d_13
+    {3, 16, 48, 1, 2},        // conv1d_13
     {1, 48, 16, 1, 0},    // conv1d_14
-    {3, 16, 48, 1, 0},    // conv1d_15
+    {3, 16, 48, 1, 2},        // conv1d_15
     {3, 48, 48, 1, 0},    // conv1d_16
     {3, 192, 48, 2, 0},   // conv1d_17
     {3, 48, 48, 1, 0},    // conv1d_18
@@ -48,8 +48,9 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_6); conv1d_8 and conv1d_9 are matrix-major.
-constexpr bool wino2_by_tile(int i) { return i == 5; }
+// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_13, conv1d_15); conv1d_8 and conv1d_9 are
+// matrix-major.
+constexpr bool wino2_by_tile(int i) { return i == 5 || i == 12 || i == 14; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
@@ -72,7 +73,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 9636, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
+static_assert(forward_mfmas(13) == 9540, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -184,14 +185,18 @@ static_assert(kX8 % 4 == 0 && kX8 + kXchgFloats <= kUpper, "conv8 exchange scrat
 constexpr int kEX = 0;                                     // BN4 output, 66 rows x 52
 constexpr int kEAP = kEX + 66 * kS48;                      // avg-pooled copy
 constexpr int kEW = kEAP + 66 * kS48;                      // weights of conv10..16
-constexpr int kEWFloats = weight_offset(16) - weight_offset(9);   // 17,664
+constexpr int kEWFloats = weight_offset(16) - weight_offset(9);   // 19,200
+// what of them arrives while conv9 runs (the rest - the end of conv16's - would land on conv9's
+// exchange scratch and comes at the top of stage E instead, long before conv16 needs it)
+constexpr int kEWEarly = 17664;
+static_assert(kEWEarly % 256 == 0 && (kEWFloats - kEWEarly) % 256 == 0 && kEWEarly <= kEWFloats, "");
 constexpr int kET3 = kEW + kEWFloats;                      // conv12 out, 66 x 20
 constexpr int kET4a = kET3 + 66 * kS16;                    // conv14 out, 66 x 20
 constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 52
 constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
 constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
 static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
-constexpr int kX9 = (kEW + kEWFloats + 3) / 4 * 4;         // conv9's exchange scratch
+constexpr int kX9 = (kEW + kEWEarly + 3) / 4 * 4;          // conv9's exchange scratch
 constexpr int kW9 = kX9 + kXchgFloats;                     // conv9's four Winograd matrices
 constexpr int kLdsFloatsD = kW9 + 4 * 48 * 48;
 
