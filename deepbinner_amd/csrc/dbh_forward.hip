@@ -18,7 +18,7 @@
 //   - the k = 3 layers with enough positions run as Winograd: F(4,3) for conv2,3,4 (L = 512, one
 //     tile of 16 quads per wave, N tile by N tile with the transformed inputs in registers) and
 //     conv7 (L = 256, a tile per wave PAIR, split by output channels), F(2,3) for conv6, conv8,
-//     conv9 - 9,636 MFMAs per window instead of the direct form's 16,452;
+//     conv9, conv13, conv15 - 9,540 MFMAs per window instead of the direct form's 16,452;
 //   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row pitch
 //     50 floats), B fragments (weights): ds_read_b128 / b64 from fragment-ordered copies that
 //     LDS-DMA brought in a phase ahead; both issued from inline asm one step ahead with
