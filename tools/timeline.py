@@ -33,9 +33,9 @@ for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global
 TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 47: 'tail: conv18 done',
         49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
 ORDER = list(range(0, 45))
-EXTRA = {25: 'conv7 barrier2', 48: 'conv8 prologue done (epi params, acc init)', 50: 'conv8 MFMA loop done', 26: 'conv8 exchange stored', 27: 'conv8 barrier1',
+EXTRA = {25: 'conv7 end', 26: 'conv8 exchange stored', 27: 'conv8 barrier1',
          59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 6: 'conv3 U phase done', 7: 'conv3 barrier',
-         56: 'conv3 tile 0 done', 57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
+         57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
 
 
 def main():
