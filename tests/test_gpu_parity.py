@@ -700,6 +700,10 @@ def test_bench_rccl_path_single_rank(hip):
     assert result['gather'] == {'transport': 'rccl', 'fallback_reason': None}
     assert result['cpu_baseline']['calls_match_gpu'] is True
     assert result['cpu_baseline']['calls_not_none_in_sample'] > 0
+    assert result['cpu_baseline']['published']['source'] == 'README.md:213'
+    assert result['config']['workload'].startswith(
+        'BASELINE.json configs[1]: EXP-NBD103_read_starts model, 10000 synthetic')
+    assert 'value_with_hint' in result and 'value_no_hint' not in result
 
 
 def test_bench_rccl_single_process_form(hip):

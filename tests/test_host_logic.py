@@ -452,3 +452,19 @@ def test_device_replicas_pairs_the_models_per_device():
     assert classify.device_replicas(start, end) == [(a, c), (b, d)]
     assert classify.device_replicas(start, None) == [(a, None), (b, None)]
     assert classify.device_replicas(a, None) == [(a, None)]
+
+
+# ---- bench.py's line (CPU-checkable parts) --------------------------------------------------
+def test_bench_workload_string_names_the_configuration():
+    """`config.workload` is the one description the driver's record keeps: it must start with the
+    BASELINE.json configuration and carry no unformatted placeholder (round-2 verdict)."""
+    import bench
+    for number, cfg in bench.CONFIGS.items():
+        text = bench.workload_string(cfg)
+        assert text.startswith('BASELINE.json configs[{}]: {} model'.format(number, cfg['models'][0]))
+        assert '{' not in text and '}' not in text
+        assert 'batch {}'.format(cfg['batch']) in text and str(cfg['reads']) in text
+    assert bench.workload_string(bench.CONFIGS[1]).startswith(
+        'BASELINE.json configs[1]: EXP-NBD103_read_starts model, 10000 synthetic')
+    assert bench.PUBLISHED_CPU == {'value': 15, 'unit': 'reads/s', 'threads': 12,
+                                   'source': 'README.md:213'}
