@@ -461,7 +461,7 @@ def test_bench_workload_string_names_the_configuration():
     import bench
     for number, cfg in bench.CONFIGS.items():
         text = bench.workload_string(cfg)
-        assert text.startswith('BASELINE.json configs[{}]: {} model'.format(number, cfg['models'][0]))
+        assert text.startswith('BASELINE.json configs[{}]: {}'.format(number, cfg['models'][0]))
         assert '{' not in text and '}' not in text
         assert 'batch {}'.format(cfg['batch']) in text and str(cfg['reads']) in text
     assert bench.workload_string(bench.CONFIGS[1]).startswith(
