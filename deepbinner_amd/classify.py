@@ -33,10 +33,16 @@ def build_model(weights):
     """ModelWeights -> device-resident model.  The single place a backend is chosen; there is no
     CPU implementation to fall back to.  With several devices (``--devices N``) the model is
     replicated, one copy per GPU, for the batch dispatcher (``dispatch_batches``)."""
-    from .hip_backend import HipModel
+    from .hip_backend import HipModel, use_pinned_loader_buffers
     if _DEVICES and len(_DEVICES) > 1:
-        return ReplicatedModel([HipModel(weights, device=d) for d in _DEVICES])
-    return HipModel(weights)
+        model = ReplicatedModel([HipModel(weights, device=d) for d in _DEVICES])
+    else:
+        model = HipModel(weights)
+    # the native loader's batches go to the GPU as they are: keep them in pinned host memory, so
+    # that the upload needs no staging copy (DEEPBINNER_PINNED_LOADER=0: pageable, for comparison)
+    if reader_kind() == 'native' and os.environ.get('DEEPBINNER_PINNED_LOADER', '1') != '0':
+        use_pinned_loader_buffers()
+    return model
 
 
 class ReplicatedModel:
@@ -354,6 +360,11 @@ def _independent_models(start_model, end_model):
 _CALL_NAMES = ['none'] + [str(i) for i in range(1, 256)]
 
 
+def call_name(number):
+    """'none' or the barcode number as the reference prints it (classify.py:289-295)."""
+    return _CALL_NAMES[number]
+
+
 def _array_path(signals, start_model, end_model):
     """A packed batch and GPU models only: the calls can stay arrays until the table is printed."""
     models = [m for m in (start_model, end_model) if m is not None]
@@ -362,24 +373,45 @@ def _array_path(signals, start_model, end_model):
             and (len(models) == 1 or models[0] is not models[1]))
 
 
-def _classify_packed_batch(read_ids, signals, start_model, end_model, args, classifications):
-    """classify_read_batch without the per-read Python of call_batch / combine_calls: the two
-    models' call numbers are combined as arrays (combine_call_numbers) and turned into the same
-    strings and table rows at the end.  Non-verbose output only (no probabilities to print)."""
-    samples, offsets = signals.packed
+def combine_mode(args):
+    """The DBH_REQUIRE_* name of the run's two-model rule (reference deepbinner.py:308-316)."""
+    if getattr(args, 'require_both', False):
+        return 'require_both'
+    if getattr(args, 'require_start', False):
+        return 'require_start'
+    assert args.require_either
+    return 'require_either'
+
+
+def classify_packed_numbers(samples, offsets, start_model, end_model, args):
+    """Final call numbers (0 = 'none') of a packed batch of any size, without the per-read Python
+    of call_batch / combine_calls.  Two GPU models on one device: ONE call of the C ABI
+    (``dbh_classify_pair_i16``: one upload - none if the loader left the batch in pinned memory -
+    both models' kernels, the merges and ``combine_calls`` on the device).  Otherwise each model's
+    own call, the end model's on a helper thread, combined as arrays."""
     scan_size = int(args.scan_size)
-
-    def numbers(model, side):
-        return model.classify_packed(samples, offsets, side, scan_size, args.score_diff)[1]
-
     if start_model is not None and end_model is not None:
+        if (hasattr(start_model, 'handle') and hasattr(end_model, 'handle') and
+                getattr(start_model, 'device', 0) == getattr(end_model, 'device', 1)):
+            from . import hip_backend
+            return hip_backend.classify_pair(start_model, end_model, samples, offsets, scan_size,
+                                             args.score_diff, combine_mode(args))
+
+        def numbers(model, side):
+            return model.classify_packed(samples, offsets, side, scan_size, args.score_diff)[1]
+
         pending = _helper_thread().submit(numbers, end_model, 'end')
         start_numbers = numbers(start_model, 'start')
-        final = combine_call_numbers(start_numbers, pending.result(), args)
-    elif start_model is not None:
-        final = numbers(start_model, 'start')
-    else:
-        final = numbers(end_model, 'end')
+        return combine_call_numbers(start_numbers, pending.result(), args)
+    model, side = (start_model, 'start') if start_model is not None else (end_model, 'end')
+    return model.classify_packed(samples, offsets, side, scan_size, args.score_diff)[1]
+
+
+def _classify_packed_batch(read_ids, signals, start_model, end_model, args, classifications):
+    """classify_read_batch for a packed batch and non-verbose output (no probabilities to print):
+    call numbers as arrays, turned into the same strings and table rows at the end."""
+    samples, offsets = signals.packed
+    final = classify_packed_numbers(samples, offsets, start_model, end_model, args)
     names = [_CALL_NAMES[c] for c in final.tolist()]
     classifications.update(zip(read_ids, names))
     return [read_id + '\t' + name for read_id, name in zip(read_ids, names)]

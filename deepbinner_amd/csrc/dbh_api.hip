@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -159,7 +160,10 @@ struct dbh_model {
     void* d_tail = nullptr;    size_t tail_bytes = 0;
     void* d_clock = nullptr;   size_t clock_bytes = 0;     // dbh_forward_clock_enable
     bool clock_probe = false;  unsigned clock_grid = 0;
-    // double-buffered host <-> device staging of dbh_classify_i16 (overlapped H2D / D2H)
+    // staging slots of the host-buffer entry points (classify_host: overlapped H2D / kernels / D2H)
+    static constexpr int kSlots = 3;
+    static constexpr int64_t kDefaultGroup = 32768;
+    int64_t host_group_windows = kDefaultGroup;     // dbh_model_set_host_group
     struct Slot {
         hipStream_t stream = nullptr;
         void* h_in = nullptr;   size_t h_in_bytes = 0;     // pinned
@@ -168,7 +172,7 @@ struct dbh_model {
         void* d_out = nullptr;  size_t d_out_bytes = 0;
         void* d_work = nullptr; size_t d_work_bytes = 0;
         void* d_tail = nullptr; size_t d_tail_bytes = 0;
-    } slot[2];
+    } slot[kSlots];
     // live timing of the forward kernel (dbh_forward_timing_*)
     int64_t hint_len = 0, hint_cap = 0;   // dbh_model_set_read_length_hint
     int timing = 0;              // 0 = off, n = open an event bracket at every n-th forward launch
@@ -725,37 +729,118 @@ int dbh_classify_i16_batched_dev(dbh_model* m, const int16_t* samples_dev,
     return DBH_OK;
 }
 
-int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* offsets_host,
-                     int64_t n_reads, int side, int scan_size, double score_diff,
-                     float* probs_host, int32_t* calls_host) {
+}  // extern "C"
+
+namespace {
+
+// Is [p, p + bytes) host memory the GPU's DMA engine can read in place (hipHostMalloc /
+// hipHostRegister: what dbh_malloc_host and dbh_host_alloc hand out)?
+bool is_pinned(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess ||
+        hipPointerGetAttributes(&a1, (const char*)p + bytes - 1) != hipSuccess) {
+        (void)hipGetLastError();      // "not a registered pointer" is an answer, not a failure
+        return false;
+    }
+    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+}
+
+// Pageable memory -> a pinned staging slot.  One thread moves ~10 GB/s; PCIe takes 50+.  Large
+// copies are cut up between the calling thread and a few helpers.
+void staged_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kPiece = 8u << 20;
+    const int helpers = bytes >= 4 * kPiece ? 3 : (bytes >= 2 * kPiece ? 1 : 0);
+    if (helpers == 0) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t share = ((bytes / (size_t)(helpers + 1)) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> team;
+    for (int t = 1; t <= helpers; ++t) {
+        const size_t lo = std::min(bytes, share * (size_t)t), hi = std::min(bytes, lo + share);
+        if (hi > lo)
+            team.emplace_back([=] { std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(bytes, share));
+    for (std::thread& t : team) t.join();
+}
+
+struct HostJob {
+    dbh_model* model[2] = {nullptr, nullptr};      // start model, end model (either may be null)
+    int side[2] = {DBH_SIDE_START, DBH_SIDE_END};
+    float* probs_host[2] = {nullptr, nullptr};     // per model: n_reads x C, or null
+    int32_t* calls_host[2] = {nullptr, nullptr};   // per model: n_reads, or null
+    int32_t* final_host = nullptr;                 // combine_calls of the two, or null
+    int combine_mode = DBH_REQUIRE_EITHER;
+};
+
+// The host-buffer pipeline behind dbh_classify_i16 and dbh_classify_pair_i16.  Reads travel in
+// groups of at most ~32k windows per model through kSlots staging slots, each with its own
+// stream: while the GPU works on group g, group g+1 is uploaded (straight from the caller's
+// buffer when that is pinned, through a pinned staging copy otherwise) and the results of group
+// g-1 come back.  Both models read the SAME uploaded samples; their kernels, the merge kernels and
+// the combine kernel of a group follow each other on the group's stream.
+int classify_host(const HostJob& job, const int16_t* samples_host, const int64_t* offsets_host,
+                  int64_t n_reads, int scan_size, double score_diff) {
+    dbh_model* m = job.model[0] ? job.model[0] : job.model[1];      // owns the slots
     if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_reads == 0) return DBH_OK;
-    if (!offsets_host || !probs_host || !calls_host) return DBH_ERR_INVALID_ARGUMENT;
+    if (!offsets_host) return DBH_ERR_INVALID_ARGUMENT;
     const int steps = steps_for(scan_size);
-    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size ||
-        (side != DBH_SIDE_START && side != DBH_SIDE_END))
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size) return DBH_ERR_INVALID_ARGUMENT;
+    const bool both = job.model[0] && job.model[1];
+    if (both && (job.model[0]->device != job.model[1]->device ||
+                 job.model[0]->n_classes != job.model[1]->n_classes))
         return DBH_ERR_INVALID_ARGUMENT;
+    if (job.final_host && !both) return DBH_ERR_INVALID_ARGUMENT;
     // the current device is a per-thread setting: a caller on another thread than the one that
-    // created the model (two models driven from two threads, say) gets the model's device
+    // created the model gets the model's device
     DBH_HIP(hipSetDevice(m->device));
-    // Reads travel in groups through two staging slots, each with its own stream: while the GPU
-    // works on group g, the host packs and uploads group g+1 and the results of group g-1 come
-    // back - H2D, kernels and D2H of neighbouring groups overlap.
     const int C = m->n_classes;
-    const int64_t group = (int64_t)(131072 / steps) > 0 ? (131072 / steps) : 1;
-    struct Pending { int64_t r0 = 0, cnt = 0; bool live = false; } pending[2];
+    const int64_t total_samples = offsets_host[n_reads] - offsets_host[0];
+    if (total_samples < 0 || (total_samples > 0 && !samples_host)) return DBH_ERR_INVALID_ARGUMENT;
+    const bool pinned = total_samples > 0 &&
+                        is_pinned(samples_host + offsets_host[0], (size_t)total_samples * 2);
+    const int64_t group = std::max<int64_t>(1, m->host_group_windows / steps);
+    constexpr int kSlots = dbh_model::kSlots;
+    struct Pending { int64_t r0 = 0, cnt = 0; bool live = false; } pending[kSlots];
+    // what comes back per read of a group, in this order
+    const size_t probs_bytes = (size_t)C * sizeof(float);
+    auto out_layout = [&](int64_t cnt, size_t (&off)[5]) -> size_t {
+        size_t at = 0;
+        for (int k = 0; k < 2; ++k) {
+            off[k] = at;
+            if (job.model[k]) at += (size_t)cnt * probs_bytes;
+        }
+        for (int k = 0; k < 2; ++k) {
+            off[2 + k] = at;
+            if (job.model[k]) at += (size_t)cnt * sizeof(int32_t);
+        }
+        off[4] = at;
+        if (both) at += (size_t)cnt * sizeof(int32_t);
+        return at;
+    };
     auto drain = [&](int k) -> int {
         dbh_model::Slot& sl = m->slot[k];
         if (!pending[k].live) return DBH_OK;
         DBH_HIP(hipStreamSynchronize(sl.stream));
         const int64_t cnt = pending[k].cnt, r0 = pending[k].r0;
-        std::memcpy(probs_host + r0 * C, sl.h_out, (size_t)cnt * C * sizeof(float));
-        std::memcpy(calls_host + r0, (char*)sl.h_out + (size_t)cnt * C * sizeof(float),
-                    (size_t)cnt * sizeof(int32_t));
+        size_t off[5];
+        out_layout(cnt, off);
+        const char* h = (const char*)sl.h_out;
+        for (int j = 0; j < 2; ++j) {
+            if (job.model[j] && job.probs_host[j])
+                std::memcpy(job.probs_host[j] + r0 * C, h + off[j], (size_t)cnt * probs_bytes);
+            if (job.model[j] && job.calls_host[j])
+                std::memcpy(job.calls_host[j] + r0, h + off[2 + j], (size_t)cnt * sizeof(int32_t));
+        }
+        if (both && job.final_host)
+            std::memcpy(job.final_host + r0, h + off[4], (size_t)cnt * sizeof(int32_t));
         pending[k].live = false;
         return DBH_OK;
     };
-    // an error in the middle of the loop must not leave the other slot's copies in flight: its
+    // an error in the middle of the loop must not leave another slot's copies in flight: its
     // pinned buffers belong to the next call
     auto fail = [&](int status) -> int {
         for (auto& sl : m->slot)
@@ -764,7 +849,7 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
     };
     int64_t g = 0;
     for (int64_t r0 = 0; r0 < n_reads; r0 += group, ++g) {
-        const int k = (int)(g & 1);
+        const int k = (int)(g % kSlots);
         dbh_model::Slot& sl = m->slot[k];
         int st = drain(k);
         if (st != DBH_OK) return fail(st);
@@ -775,52 +860,147 @@ int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* o
         const int64_t cnt = (n_reads - r0 < group) ? (n_reads - r0) : group;
         const int64_t s0 = offsets_host[r0], s1 = offsets_host[r0 + cnt];
         if (s1 < s0) return fail(DBH_ERR_INVALID_ARGUMENT);
-        const size_t sample_bytes = ((size_t)(s1 - s0) * sizeof(int16_t) + 255) & ~(size_t)255;
+        const size_t raw_bytes = (size_t)(s1 - s0) * sizeof(int16_t);
+        const size_t sample_bytes = (raw_bytes + 255) & ~(size_t)255;
         const size_t off_bytes = (size_t)(cnt + 1) * sizeof(int64_t);
-        const size_t in_bytes = sample_bytes + off_bytes;
-        const size_t out_bytes = (size_t)cnt * C * sizeof(float) + (size_t)cnt * sizeof(int32_t);
+        size_t out_off[5];
+        const size_t out_bytes = out_layout(cnt, out_off);
         size_t work = 0;
         st = dbh_classify_workspace_bytes(m, cnt, scan_size, &work);
-        if (st == DBH_OK) st = ensure_host(&sl.h_in, &sl.h_in_bytes, in_bytes);
+        // host side: the relative offsets always, the samples only when they have to be staged
+        if (st == DBH_OK)
+            st = ensure_host(&sl.h_in, &sl.h_in_bytes, off_bytes + (pinned ? 0 : sample_bytes));
         if (st == DBH_OK) st = ensure_host(&sl.h_out, &sl.h_out_bytes, out_bytes);
-        if (st == DBH_OK) st = ensure(&sl.d_in, &sl.d_in_bytes, in_bytes);
+        if (st == DBH_OK) st = ensure(&sl.d_in, &sl.d_in_bytes, sample_bytes + off_bytes);
         if (st == DBH_OK) st = ensure(&sl.d_out, &sl.d_out_bytes, out_bytes);
         if (st == DBH_OK && work) st = ensure(&sl.d_work, &sl.d_work_bytes, work);
         if (st != DBH_OK) return fail(st);
 
-        if (s1 > s0) {
-            if (!samples_host) return fail(DBH_ERR_INVALID_ARGUMENT);
-            std::memcpy(sl.h_in, samples_host + s0, (size_t)(s1 - s0) * sizeof(int16_t));
-        }
-        int64_t* rel = (int64_t*)((char*)sl.h_in + sample_bytes);
+        int64_t* rel = (int64_t*)sl.h_in;
         for (int64_t i = 0; i <= cnt; ++i) rel[i] = offsets_host[r0 + i] - s0;
         // all reads of the group equally long?  then the kernel need not wait for the offsets
         int64_t uniform = rel[1];
         for (int64_t i = 1; i <= cnt && uniform > 0; ++i)
             if (rel[i] != i * uniform) uniform = 0;
-        {
-            hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, sl.stream);
-            if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync H2D"));
+        const void* src = samples_host + s0;
+        if (raw_bytes && !pinned) {
+            staged_copy((char*)sl.h_in + off_bytes, src, raw_bytes);
+            src = (char*)sl.h_in + off_bytes;
         }
-        float* d_probs = (float*)sl.d_out;
-        int32_t* d_calls = (int32_t*)((char*)sl.d_out + (size_t)cnt * C * sizeof(float));
-        st = classify_i16_dev(m, (const int16_t*)sl.d_in,
-                              (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, side, scan_size,
-                              score_diff, d_probs, d_calls, sl.d_work, (dbh_stream)sl.stream, 0,
-                              uniform, s1 - s0, &sl.d_tail, &sl.d_tail_bytes);
-        if (st != DBH_OK) return fail(st);
-        {
-            hipError_t e = hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream);
-            if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync D2H"));
+        hipError_t e = hipSuccess;
+        if (raw_bytes) e = hipMemcpyAsync(sl.d_in, src, raw_bytes, hipMemcpyHostToDevice, sl.stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char*)sl.d_in + sample_bytes, rel, off_bytes, hipMemcpyHostToDevice,
+                               sl.stream);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync H2D"));
+        int32_t* d_calls[2] = {nullptr, nullptr};
+        for (int j = 0; j < 2; ++j) {
+            if (!job.model[j]) continue;
+            d_calls[j] = (int32_t*)((char*)sl.d_out + out_off[2 + j]);
+            st = classify_i16_dev(job.model[j], (const int16_t*)sl.d_in,
+                                  (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, job.side[j],
+                                  scan_size, score_diff, (float*)((char*)sl.d_out + out_off[j]),
+                                  d_calls[j], sl.d_work, (dbh_stream)sl.stream, 0, uniform, s1 - s0,
+                                  &sl.d_tail, &sl.d_tail_bytes);
+            if (st != DBH_OK) return fail(st);
         }
+        if (both) {
+            st = dbh_combine_calls_dev(d_calls[0], d_calls[1], cnt, job.combine_mode,
+                                       (int32_t*)((char*)sl.d_out + out_off[4]),
+                                       (dbh_stream)sl.stream);
+            if (st != DBH_OK) return fail(st);
+        }
+        e = hipMemcpyAsync(sl.h_out, sl.d_out, out_bytes, hipMemcpyDeviceToHost, sl.stream);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync D2H"));
         pending[k].r0 = r0;
         pending[k].cnt = cnt;
         pending[k].live = true;
     }
-    int st = drain(0);
-    if (st != DBH_OK) return fail(st);
-    st = drain(1);
-    return st == DBH_OK ? st : fail(st);
+    for (int i = 0; i < kSlots; ++i) {       // oldest first
+        const int st = drain((int)((g + i) % kSlots));
+        if (st != DBH_OK) return fail(st);
+    }
+    return DBH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dbh_classify_i16(dbh_model* m, const int16_t* samples_host, const int64_t* offsets_host,
+                     int64_t n_reads, int side, int scan_size, double score_diff,
+                     float* probs_host, int32_t* calls_host) {
+    if (!m || n_reads < 0) return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!offsets_host || !probs_host || !calls_host ||
+        (side != DBH_SIDE_START && side != DBH_SIDE_END))
+        return DBH_ERR_INVALID_ARGUMENT;
+    HostJob job;
+    job.model[0] = m;
+    job.side[0] = side;
+    job.probs_host[0] = probs_host;
+    job.calls_host[0] = calls_host;
+    return classify_host(job, samples_host, offsets_host, n_reads, scan_size, score_diff);
+}
+
+int dbh_classify_pair_i16(dbh_model* start_model, dbh_model* end_model,
+                          const int16_t* samples_host, const int64_t* offsets_host,
+                          int64_t n_reads, int scan_size, double score_diff, int combine_mode,
+                          int32_t* calls_host, int32_t* start_calls_host, int32_t* end_calls_host,
+                          float* start_probs_host, float* end_probs_host) {
+    if ((!start_model && !end_model) || n_reads < 0 || combine_mode < DBH_REQUIRE_EITHER ||
+        combine_mode > DBH_REQUIRE_BOTH)
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!offsets_host || !calls_host) return DBH_ERR_INVALID_ARGUMENT;
+    HostJob job;
+    job.model[0] = start_model;
+    job.model[1] = end_model;
+    job.probs_host[0] = start_probs_host;
+    job.probs_host[1] = end_probs_host;
+    job.calls_host[0] = start_calls_host;
+    job.calls_host[1] = end_calls_host;
+    job.combine_mode = combine_mode;
+    if (start_model && end_model) job.final_host = calls_host;
+    else if (start_model && !start_calls_host) job.calls_host[0] = calls_host;
+    else if (end_model && !end_calls_host) job.calls_host[1] = calls_host;
+    const int st = classify_host(job, samples_host, offsets_host, n_reads, scan_size, score_diff);
+    // one model and the caller wanted its calls twice (final + per side)
+    if (st == DBH_OK && !(start_model && end_model)) {
+        int32_t* side_calls = start_model ? start_calls_host : end_calls_host;
+        if (side_calls && side_calls != calls_host)
+            std::memcpy(calls_host, side_calls, (size_t)n_reads * sizeof(int32_t));
+    }
+    return st;
+}
+
+void* dbh_host_alloc(size_t bytes, void* user) {
+    (void)user;
+    void* p = nullptr;
+    // portable: the loader's threads allocate with no device of their own chosen, and with
+    // several GPUs any of them may be the one that reads the batch
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void dbh_host_release(void* ptr, void* user) {
+    (void)user;
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+int dbh_host_is_pinned(const void* ptr, size_t bytes, int* pinned) {
+    if (!pinned) return DBH_ERR_INVALID_ARGUMENT;
+    *pinned = is_pinned(ptr, bytes) ? 1 : 0;
+    return DBH_OK;
+}
+
+int dbh_model_set_host_group(dbh_model* m, int64_t windows_per_group) {
+    if (!m || windows_per_group < 0) return DBH_ERR_INVALID_ARGUMENT;
+    m->host_group_windows = windows_per_group > 0 ? windows_per_group : dbh_model::kDefaultGroup;
+    return DBH_OK;
 }
 
 int dbh_stage_floats(int stage, int64_t* floats_per_window) {

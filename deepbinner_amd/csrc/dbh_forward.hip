@@ -904,6 +904,26 @@ __device__ __forceinline__ void w43_load_rows(f2 (&d)[6], unsigned a_addr) {
 //   a = d4-4d2, b = d3-4d1: U1 = a+b, U2 = a-b;   c = d4-d2, g = d3-d1: U3 = c+2g, U4 = c-2g
 template <int SP>
 __device__ __forceinline__ void w43_transform(W43U& U, const f2 (&d)[6]) {
+#ifdef DBH_EXP_SCALAR_TRANSFORM
+    // A/B knob (tools/ab_variants.sh): the same arithmetic one component at a time - twice the
+    // instructions, none of them packed (MI355X_MICROARCH.md lists packed fp32 VALU beside MFMAs
+    // as an anti-lever; measured in THIS kernel: see DESIGN.md section 4)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e];
+        const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+        const float c = d4 - d2, g = d3 - d1;
+        U.u[0][SP][e] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        U.u[1][SP][e] = a + b;
+        U.u[2][SP][e] = a - b;
+        U.u[3][SP][e] = fmaf(2.f, g, c);
+        U.u[4][SP][e] = fmaf(-2.f, g, c);
+        U.u[5][SP][e] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(U.u[x][SP]));
+    return;
+#endif
     const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
     const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
     const f2 a = __builtin_elementwise_fma(m4, d[2], d[4]), b = __builtin_elementwise_fma(m4, d[1], d[3]);

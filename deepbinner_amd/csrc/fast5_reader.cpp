@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -127,6 +128,8 @@ const LibDeflate& libdeflate() {
 struct ChunkCache {
     std::vector<uint8_t> data, scratch;
     uint64_t addr = ~0ull, bytes = 0;
+    const void* owner = nullptr;        // the file the cached chunk came from (addresses repeat
+                                        // from file to file: a thread may serve several)
     z_stream zs;
     bool zs_ready = false;
     void* fast_inflater = nullptr;      // libdeflate's, when there is one
@@ -924,9 +927,10 @@ class Fast5 {
         if (a >= z) return;
         // the last chunk inflated stays around: a read stored as ONE chunk (common) is asked
         // for twice, once per end, and deflate cannot be entered in the middle
-        if (cache->addr != addr || cache->bytes != nbytes) {
+        if (cache->owner != this || cache->addr != addr || cache->bytes != nbytes) {
             cache->addr = ~0ull;
             decode_chunk(s, addr, nbytes, mask, cache);
+            cache->owner = this;
             cache->addr = addr;
             cache->bytes = nbytes;
         }
@@ -1258,6 +1262,13 @@ class WorkerPool {
     bool stop_ = false;
 };
 
+// n_threads as the ABI takes it: <= 0 = one per hardware thread, at most 64; an explicit count is
+// honoured up to 256
+int thread_count(int n_threads) {
+    if (n_threads > 0) return std::min(n_threads, 256);
+    return std::max(1, std::min((int)std::thread::hardware_concurrency(), 64));
+}
+
 WorkerPool& worker_pool() {
     static WorkerPool pool;
     return pool;
@@ -1268,17 +1279,137 @@ struct f5_file {
     explicit f5_file(const char* path) : impl(path) {}
 };
 
-// Packed samples of a batch.  Deliberately NOT value-initialised: a std::vector would zero 100+ MB
-// on the calling thread before the workers start (a third of the time of a 4,000-read container
-// at 64 threads); this way the pages are first touched by the threads that fill them.
+// Packed samples of a batch.  Deliberately NOT value-initialised (a std::vector would zero 100+ MB
+// on the calling thread before the workers start), and RECYCLED: a 4,000-read container's scanned
+// ends are 106 MB, and a fresh allocation of that size is an mmap whose 26,000 pages are then
+// faulted in by the worker threads one by one (they queue on the address-space lock: this, not the
+// inflating, was what stopped the loader scaling past 64 threads) and unmapped again when the
+// batch is freed.  Freed buffers wait in a pool (bounded: DEEPBINNER_FAST5_POOL_MB, default 2048)
+// for the next batch that fits.  The memory comes from malloc or from an allocator the caller
+// installs (f5_set_sample_allocator) - pinned host memory, so that the GPU's DMA engine reads the
+// batch where the loader threads wrote it.
+struct SampleAllocator {
+    f5_alloc_fn alloc = nullptr;
+    f5_free_fn release = nullptr;
+    void* user = nullptr;
+    uint64_t generation = 0;
+};
+
+class SamplePool {
+  public:
+    struct Block {
+        void* ptr = nullptr;
+        size_t bytes = 0;
+        SampleAllocator from;
+    };
+    ~SamplePool() { flush(); }
+
+    void set_allocator(f5_alloc_fn alloc, f5_free_fn release, void* user) {
+        std::vector<Block> old;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            allocator_.alloc = alloc;
+            allocator_.release = release;
+            allocator_.user = user;
+            ++allocator_.generation;
+            old.swap(idle_);
+            idle_bytes_ = 0;
+        }
+        for (Block& b : old) free_block(b);
+    }
+
+    Block take(size_t bytes) {
+        if (bytes == 0) return Block();
+        SampleAllocator from;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            // best fit among the idle blocks; one that is far too large stays for a larger batch
+            size_t best = idle_.size();
+            for (size_t i = 0; i < idle_.size(); ++i)
+                if (idle_[i].bytes >= bytes && idle_[i].bytes / 2 <= bytes + (1u << 20) &&
+                    (best == idle_.size() || idle_[i].bytes < idle_[best].bytes))
+                    best = i;
+            if (best != idle_.size()) {
+                Block b = idle_[best];
+                idle_[best] = idle_.back();
+                idle_.pop_back();
+                idle_bytes_ -= b.bytes;
+                return b;
+            }
+            from = allocator_;
+        }
+        // a little more than asked for: the next container is about, not exactly, as large
+        Block b;
+        b.bytes = (bytes + bytes / 8 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+        b.from = from;
+        b.ptr = from.alloc ? from.alloc(b.bytes, from.user) : std::malloc(b.bytes);
+        if (!b.ptr) throw std::bad_alloc();
+        return b;
+    }
+
+    void give(Block b) {
+        if (!b.ptr) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (b.from.generation == allocator_.generation && idle_bytes_ + b.bytes <= limit()) {
+                idle_.push_back(b);
+                idle_bytes_ += b.bytes;
+                return;
+            }
+        }
+        free_block(b);
+    }
+
+    void flush() {
+        std::vector<Block> old;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            old.swap(idle_);
+            idle_bytes_ = 0;
+        }
+        for (Block& b : old) free_block(b);
+    }
+
+  private:
+    static void free_block(Block& b) {
+        if (!b.ptr) return;
+        if (b.from.release) b.from.release(b.ptr, b.from.user);
+        else if (!b.from.alloc) std::free(b.ptr);
+        b.ptr = nullptr;
+    }
+    static size_t limit() {
+        static const size_t bytes = [] {
+            const char* mb = std::getenv("DEEPBINNER_FAST5_POOL_MB");
+            const long v = mb ? std::atol(mb) : 2048;
+            return (size_t)(v < 0 ? 0 : v) << 20;
+        }();
+        return bytes;
+    }
+    std::mutex m_;
+    std::vector<Block> idle_;
+    size_t idle_bytes_ = 0;
+    SampleAllocator allocator_;
+};
+
+SamplePool& sample_pool() {
+    static SamplePool* pool = new SamplePool;      // never destroyed: batches may outlive exit()
+    return *pool;
+}
+
 struct SampleBuffer {
-    std::unique_ptr<int16_t[]> store;
+    SamplePool::Block block;
     size_t count = 0;
+    SampleBuffer() = default;
+    SampleBuffer(const SampleBuffer&) = delete;
+    SampleBuffer& operator=(const SampleBuffer&) = delete;
+    ~SampleBuffer() { sample_pool().give(block); }
     void resize(size_t n) {
-        store.reset(n ? new int16_t[n] : nullptr);
+        sample_pool().give(block);
+        block = SamplePool::Block();
+        block = sample_pool().take(n * sizeof(int16_t));
         count = n;
     }
-    int16_t* data() const { return store.get(); }
+    int16_t* data() const { return static_cast<int16_t*>(block.ptr); }
 };
 
 struct f5_batch {
@@ -1403,8 +1534,7 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
             staged[(size_t)i].reset();
         };
 
-        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-        threads = std::max(1, std::min(threads, 64));
+        int threads = thread_count(n_threads);
         threads = (int)std::min<int64_t>(threads, std::max<int64_t>(n_files, 1));
         auto run_parallel = [&](const std::function<void(int64_t)>& fn) {
             worker_pool().run(threads, n_files, [&](int64_t i, int) { fn(i); });
@@ -1452,8 +1582,7 @@ int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, 
         if (open_status != F5_OK) return open_status;
         if (count < 0) count = std::max<int64_t>(shared->n_reads() - first, 0);   // to the end
         if (first + count > shared->n_reads()) return F5_ERR_NO_READ;
-        int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-        threads = std::max(1, std::min(threads, 64));
+        int threads = thread_count(n_threads);
         threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
         std::vector<ChunkCache> caches((size_t)threads);
         const auto t_parsed = now();
@@ -1525,5 +1654,278 @@ const int64_t* f5_batch_offsets(const f5_batch* batch) { return batch ? batch->o
 const int32_t* f5_batch_status(const f5_batch* batch) { return batch ? batch->status.data() : nullptr; }
 const char* f5_batch_read_ids(const f5_batch* batch) { return batch ? batch->read_ids.data() : nullptr; }
 void f5_batch_free(f5_batch* batch) { delete batch; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// f5_stream: multi-read containers in, packed batches out, SEVERAL containers in flight.
+// One f5_load_reads call per container leaves most of a many-core host idle most of the time:
+// opening a 4,000-read container and walking its root group is 6-10 ms on ONE thread, the reads
+// are resolved and inflated in two passes with a join after each, and the caller's own work per
+// batch happens while nothing loads.  Here a team of threads works on a window of `depth`
+// containers at once, always taking the oldest work there is: read ranges of a container that is
+// being inflated, else ranges of one being resolved, else a container that still has to be opened -
+// so that the next containers' serial parts run beside the current one's inflating, and the batches
+// still come out in path order.
+// ---------------------------------------------------------------------------------------------
+struct f5_stream {
+    enum Phase { kNew, kParsing, kResolve, kLayout, kInflate, kDone };
+    struct Container {
+        int64_t index = 0;
+        std::string path;
+        std::unique_ptr<Fast5> file;
+        int status = F5_OK;                 // why the container could not be opened / laid out
+        Phase phase = kNew;
+        int64_t count = 0, next = 0, done = 0;
+        f5_batch* batch = nullptr;
+        std::vector<int64_t> lengths;
+        ~Container() { delete batch; }
+    };
+    struct Task {
+        Container* c = nullptr;
+        Phase phase = kNew;
+        int64_t a = 0, b = 0;
+    };
+
+    std::vector<std::string> paths;
+    int64_t keep = 0;
+    int depth = 3;
+    std::mutex m;
+    std::condition_variable work_cv, done_cv;
+    std::deque<std::unique_ptr<Container>> inflight;      // in path order
+    int64_t next_path = 0;
+    bool stop = false;
+    std::vector<std::thread> workers;
+
+    static constexpr int64_t kInflateGrain = 8, kResolveGrain = 64;
+
+    ~f5_stream() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        work_cv.notify_all();
+        for (std::thread& t : workers) t.join();
+    }
+
+    void admit_locked() {
+        while ((int)inflight.size() < depth && next_path < (int64_t)paths.size()) {
+            std::unique_ptr<Container> c(new Container);
+            c->index = next_path;
+            c->path = paths[(size_t)next_path++];
+            inflight.push_back(std::move(c));
+        }
+    }
+
+    bool pick_locked(Task* t) {
+        for (auto& up : inflight) {
+            Container* c = up.get();
+            if ((c->phase == kInflate || c->phase == kResolve) && c->next < c->count) {
+                const int64_t grain = c->phase == kInflate ? kInflateGrain : kResolveGrain;
+                t->c = c;
+                t->phase = c->phase;
+                t->a = c->next;
+                t->b = std::min(c->count, c->next + grain);
+                c->next = t->b;
+                return true;
+            }
+        }
+        for (auto& up : inflight) {
+            Container* c = up.get();
+            if (c->phase == kNew) {
+                c->phase = kParsing;
+                t->c = c;
+                t->phase = kParsing;
+                return true;
+            }
+        }
+        return false;
+    }
+
+    void parse(Container* c) {
+        c->status = guarded([&] {
+            c->file.reset(new Fast5(c->path.c_str()));
+            c->file->parse();
+        });
+        if (c->status == F5_OK) {
+            c->count = c->file->n_reads();
+            try {
+                c->batch = new f5_batch;
+                c->batch->offsets.assign((size_t)c->count + 1, 0);
+                c->batch->status.assign((size_t)c->count, F5_ERR_OPEN);
+                c->batch->read_ids.assign((size_t)c->count * F5_READ_ID_MAX, 0);
+                c->lengths.assign((size_t)c->count, 0);
+            } catch (const std::exception&) {
+                c->status = F5_ERR_FORMAT;
+            }
+        }
+    }
+
+    void resolve(Container* c, int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i)
+            c->batch->status[(size_t)i] = guarded([&] {
+                const ReadEntry& r = c->file->read(i);
+                const int64_t n = r.signal.n;
+                c->lengths[(size_t)i] = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                copy_read_id(r.read_id, &c->batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
+            });
+    }
+
+    void layout(Container* c) {
+        int64_t total = 0;
+        for (int64_t i = 0; i < c->count; ++i) {
+            c->batch->offsets[(size_t)i] = total;
+            total += c->batch->status[(size_t)i] == F5_OK ? c->lengths[(size_t)i] : 0;
+        }
+        c->batch->offsets[(size_t)c->count] = total;
+        try {
+            c->batch->samples.resize((size_t)total);
+        } catch (const std::exception&) {
+            c->status = F5_ERR_FORMAT;
+        }
+    }
+
+    void inflate(Container* c, int64_t a, int64_t b) {
+        thread_local ChunkCache cache;
+        for (int64_t i = a; i < b; ++i) {
+            if (c->batch->status[(size_t)i] != F5_OK) continue;
+            int16_t* dst = c->batch->samples.data() + c->batch->offsets[(size_t)i];
+            const int rc = guarded([&] {
+                const ReadEntry& r = c->file->read(i);
+                const int64_t n = r.signal.n;
+                if (keep > 0 && n > 2 * keep) {
+                    c->file->read_signal(r.signal, 0, keep, dst, &cache);
+                    c->file->read_signal(r.signal, n - keep, keep, dst + keep, &cache);
+                } else {
+                    c->file->read_signal(r.signal, 0, n, dst, &cache);
+                }
+            });
+            if (rc != F5_OK) {
+                std::memset(dst, 0, (size_t)c->lengths[(size_t)i] * 2);
+                std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            }
+            c->batch->status[(size_t)i] = rc;
+        }
+    }
+
+    void finish(Container* c) {      // no read of it is being worked on any more
+        for (int64_t i = 0; i < c->count; ++i)
+            if (c->batch->status[(size_t)i] != F5_OK)
+                std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+        c->file.reset();             // unmap and close now, not when the caller frees the batch
+    }
+
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            Task t;
+            while (!stop && !pick_locked(&t)) work_cv.wait(lk);
+            if (stop) return;
+            Container* c = t.c;
+            lk.unlock();
+            if (t.phase == kParsing) parse(c);
+            else if (t.phase == kResolve) resolve(c, t.a, t.b);
+            else inflate(c, t.a, t.b);
+            lk.lock();
+            if (t.phase == kParsing) {
+                if (c->status != F5_OK) {
+                    c->phase = kDone;
+                    done_cv.notify_all();
+                    continue;
+                }
+                c->next = c->done = 0;
+                c->phase = c->count > 0 ? kResolve : kLayout;
+                if (c->count > 0) {
+                    work_cv.notify_all();
+                    continue;
+                }
+            } else {
+                c->done += t.b - t.a;
+                if (c->done < c->count) continue;
+                if (t.phase == kInflate) {
+                    lk.unlock();
+                    finish(c);
+                    lk.lock();
+                    c->phase = kDone;
+                    done_cv.notify_all();
+                    continue;
+                }
+                c->phase = kLayout;
+            }
+            // the last range of the resolve pass (or an empty container): sizes are known
+            lk.unlock();
+            layout(c);
+            if (c->status == F5_OK && c->count == 0) finish(c);
+            lk.lock();
+            if (c->status != F5_OK || c->count == 0) {
+                c->phase = kDone;
+                done_cv.notify_all();
+            } else {
+                c->next = c->done = 0;
+                c->phase = kInflate;
+                work_cv.notify_all();
+            }
+        }
+    }
+};
+
+extern "C" {
+
+int f5_set_sample_allocator(f5_alloc_fn alloc, f5_free_fn release, void* user) {
+    if ((alloc == nullptr) != (release == nullptr)) return F5_ERR_ARGUMENT;
+    sample_pool().set_allocator(alloc, release, user);
+    return F5_OK;
+}
+
+void f5_release_idle_buffers(void) { sample_pool().flush(); }
+
+int f5_stream_open(const char* const* paths, int64_t n_paths, int64_t keep, int n_threads,
+                   int depth, f5_stream** out) {
+    if (!out || n_paths < 0 || (n_paths > 0 && !paths)) return F5_ERR_ARGUMENT;
+    *out = nullptr;
+    for (int64_t i = 0; i < n_paths; ++i)
+        if (!paths[i]) return F5_ERR_ARGUMENT;
+    f5_stream* s = nullptr;
+    try {
+        s = new f5_stream;
+        s->paths.assign(paths, paths + n_paths);
+        s->keep = keep;
+        s->depth = depth > 0 ? std::min(depth, 64) : 3;
+        {
+            std::lock_guard<std::mutex> g(s->m);
+            s->admit_locked();
+        }
+        const int threads = thread_count(n_threads);
+        for (int t = 0; t < threads; ++t) s->workers.emplace_back([s] { s->worker(); });
+    } catch (const std::exception&) {
+        delete s;
+        return F5_ERR_OPEN;
+    }
+    *out = s;
+    return F5_OK;
+}
+
+int f5_stream_next(f5_stream* s, int64_t* index, int* container_status, f5_batch** batch) {
+    if (!s || !index || !container_status || !batch) return F5_ERR_ARGUMENT;
+    *batch = nullptr;
+    std::unique_lock<std::mutex> lk(s->m);
+    if (s->inflight.empty()) return F5_ERR_NO_READ;       // exhausted
+    f5_stream::Container* front = s->inflight.front().get();
+    s->done_cv.wait(lk, [&] { return front->phase == f5_stream::kDone; });
+    std::unique_ptr<f5_stream::Container> c = std::move(s->inflight.front());
+    s->inflight.pop_front();
+    s->admit_locked();
+    lk.unlock();
+    s->work_cv.notify_all();
+    *index = c->index;
+    *container_status = c->status;
+    if (c->status == F5_OK) {
+        *batch = c->batch;
+        c->batch = nullptr;
+    }
+    return F5_OK;
+}
+
+void f5_stream_close(f5_stream* s) { delete s; }
 
 }  // extern "C"

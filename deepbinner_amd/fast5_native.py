@@ -25,7 +25,8 @@ LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 EXPORTED_SYMBOLS = [
     'f5_version', 'f5_status_string', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
     'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_size', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
-    'f5_batch_read_ids', 'f5_batch_free',
+    'f5_batch_read_ids', 'f5_batch_free', 'f5_stream_open', 'f5_stream_next', 'f5_stream_close',
+    'f5_set_sample_allocator', 'f5_release_idle_buffers',
 ]
 
 
@@ -71,6 +72,11 @@ def load_library():
         'f5_batch_status': (P(ctypes.c_int32), [c_void_p]),
         'f5_batch_read_ids': (P(ctypes.c_char), [c_void_p]),
         'f5_batch_free': (None, [c_void_p]),
+        'f5_stream_open': (c_int, [P(c_char_p), c_i64, c_i64, c_int, c_int, P(c_void_p)]),
+        'f5_stream_next': (c_int, [c_void_p, P(c_i64), P(c_int), P(c_void_p)]),
+        'f5_stream_close': (None, [c_void_p]),
+        'f5_set_sample_allocator': (c_int, [c_void_p, c_void_p, c_void_p]),
+        'f5_release_idle_buffers': (None, []),
     }
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(lib, name)
@@ -232,3 +238,47 @@ def load_reads(fast5_file, first=0, count=None, keep=None, threads=0):
     if status != F5_OK:
         raise Fast5NativeError('{}: {}'.format(fast5_file, status_string(status)))
     return _unpack_batch(lib, handle, int(lib.f5_batch_size(handle)))
+
+
+def stream_reads(fast5_files, keep=None, threads=0, depth=0):
+    """Multi-read containers as a stream (``f5_stream_*``): yields, in the order of
+    ``fast5_files``, ``(index, read_ids, samples, offsets, status)`` per container as
+    ``load_reads`` would return them - or ``(index, None, None, None, container_status)`` for a
+    file that could not be opened - while a team of ``threads`` native threads works ``depth``
+    containers ahead (opening and walking the next containers beside the inflating of the current
+    one).  Closing the generator stops the team."""
+    lib = load_library()
+    n = len(fast5_files)
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
+    stream = ctypes.c_void_p()
+    status = lib.f5_stream_open(paths, n, int(keep or 0), int(threads), int(depth),
+                                ctypes.byref(stream))
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+    try:
+        index, container_status = ctypes.c_int64(0), ctypes.c_int(0)
+        handle = ctypes.c_void_p()
+        while lib.f5_stream_next(stream, ctypes.byref(index), ctypes.byref(container_status),
+                                 ctypes.byref(handle)) == F5_OK:
+            if container_status.value != F5_OK:
+                yield index.value, None, None, None, container_status.value
+                continue
+            batch = ctypes.c_void_p(handle.value)
+            yield (index.value,) + _unpack_batch(lib, batch, int(lib.f5_batch_size(batch)))
+    finally:
+        lib.f5_stream_close(stream)
+
+
+def set_sample_allocator(alloc_address=None, release_address=None, user=None):
+    """Where batches keep their packed samples: two C function pointers (as integers)
+    ``void* alloc(size_t, void*)`` / ``void release(void*, void*)`` - ``hip_backend.
+    use_pinned_loader_buffers()`` passes the pinned-host-memory pair of libdeepbinner_hip.so - or
+    nothing for malloc."""
+    status = load_library().f5_set_sample_allocator(alloc_address, release_address, user)
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+
+
+def release_idle_buffers():
+    """Free the sample buffers waiting in the library's pool."""
+    load_library().f5_release_idle_buffers()

@@ -99,6 +99,13 @@ def load_library():
                                      ndpointer(np.int64, flags='C_CONTIGUOUS'), c_i64, c_int,
                                      c_int, ctypes.c_double, _f32(),
                                      ndpointer(np.int32, flags='C_CONTIGUOUS')]),
+        'dbh_classify_pair_i16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                                          ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
+        'dbh_model_set_host_group': (c_int, [c_void_p, c_i64]),
+        'dbh_host_alloc': (c_void_p, [c_size_t, c_void_p]),
+        'dbh_host_release': (None, [c_void_p, c_void_p]),
+        'dbh_host_is_pinned': (c_int, [c_void_p, c_size_t, P(c_int)]),
         'dbh_classify_workspace_bytes': (c_int, [c_void_p, c_i64, c_int, P(c_size_t)]),
         'dbh_classify_i16_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -150,7 +157,9 @@ EXPORTED_SYMBOLS = [
     'dbh_stream_create', 'dbh_stream_destroy', 'dbh_stream_synchronize', 'dbh_event_create',
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
-    'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_workspace_bytes',
+    'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_pair_i16',
+    'dbh_model_set_host_group', 'dbh_host_alloc', 'dbh_host_release', 'dbh_host_is_pinned',
+    'dbh_classify_workspace_bytes',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
@@ -189,6 +198,12 @@ def set_device(ordinal):
     check(load_library().dbh_set_device(int(ordinal)), 'dbh_set_device')
 
 
+def get_device():
+    ordinal = ctypes.c_int(0)
+    check(load_library().dbh_get_device(ctypes.byref(ordinal)), 'dbh_get_device')
+    return ordinal.value
+
+
 COMBINE_MODES = {'require_either': 0, 'require_start': 1, 'require_both': 2}
 
 
@@ -202,6 +217,71 @@ def combine_calls_dev(start_calls_ptr, end_calls_ptr, n_reads, mode, out_ptr, st
 
 def synchronize():
     check(load_library().dbh_device_synchronize(), 'dbh_device_synchronize')
+
+
+def classify_pair(start_model, end_model, samples, offsets, scan_size, score_diff,
+                  mode='require_either', want_sides=False, want_probs=False):
+    """One batch of packed reads (``samples`` int16, ``offsets`` int64: read i is
+    ``samples[offsets[i]:offsets[i+1]]``, long reads possibly cut to their scanned ends) through
+    the start and the end model in ONE call of the C ABI: one upload, both models' kernels, the
+    min/max merges and ``combine_calls`` on the device -> final calls int32 [N] (0 = 'none').
+    Either model may be None.  ``want_sides`` / ``want_probs``: also return the per-side calls /
+    probabilities: (calls, (start_calls, end_calls), (start_probs, end_probs))."""
+    lib = load_library()
+    models = (start_model, end_model)
+    if start_model is None and end_model is None:
+        raise ValueError('no model')
+    samples = np.ascontiguousarray(samples, dtype=np.int16)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    if n < 0 or (n and (offsets[0] != 0 or offsets[-1] != len(samples))):
+        raise ValueError('offsets do not describe the sample buffer')
+    calls = np.empty(max(n, 0), dtype=np.int32)
+    n_classes = next(m.n_classes for m in models if m is not None)
+    side_calls = [np.empty(n, dtype=np.int32) if (want_sides and m is not None) else None
+                  for m in models]
+    side_probs = [np.empty((n, n_classes), dtype=np.float32) if (want_probs and m is not None)
+                  else None for m in models]
+    ptr = lambda a: a.ctypes.data if a is not None else None      # noqa: E731
+    if n > 0:
+        check(lib.dbh_classify_pair_i16(
+            start_model.handle if start_model is not None else None,
+            end_model.handle if end_model is not None else None,
+            samples.ctypes.data if samples.size else None, offsets.ctypes.data, n, int(scan_size),
+            float(score_diff), COMBINE_MODES[mode], calls.ctypes.data, ptr(side_calls[0]),
+            ptr(side_calls[1]), ptr(side_probs[0]), ptr(side_probs[1])), 'dbh_classify_pair_i16')
+    if want_sides or want_probs:
+        return calls, tuple(side_calls), tuple(side_probs)
+    return calls
+
+
+_PINNED_LOADER = False
+
+
+def use_pinned_loader_buffers(on=True):
+    """Have the native fast5 loader keep its packed batches in pinned host memory (this library's
+    ``dbh_host_alloc`` / ``dbh_host_release`` handed to ``f5_set_sample_allocator`` as plain C
+    function pointers: the two libraries do not link each other), so that ``classify_packed`` /
+    ``classify_pair`` upload them without a staging copy.  Needs a GPU; idempotent."""
+    global _PINNED_LOADER
+    from . import fast5_native
+    if on == _PINNED_LOADER:
+        return
+    if on:
+        lib = load_library()
+        fast5_native.set_sample_allocator(ctypes.cast(lib.dbh_host_alloc, ctypes.c_void_p).value,
+                                          ctypes.cast(lib.dbh_host_release, ctypes.c_void_p).value)
+    else:
+        fast5_native.set_sample_allocator(None, None)
+    _PINNED_LOADER = bool(on)
+
+
+def is_pinned(array):
+    """Does this numpy array lie in pinned host memory?"""
+    flag = ctypes.c_int(0)
+    check(load_library().dbh_host_is_pinned(array.ctypes.data, array.nbytes, ctypes.byref(flag)),
+          'dbh_host_is_pinned')
+    return bool(flag.value)
 
 
 class Stream:
@@ -314,6 +394,7 @@ class HipModel:
                                   '(gfx950) GPU; there is no CPU fallback')
         if device is not None:
             set_device(device)
+        self.device = get_device()
         self.weights = weights
         flat = weights.flat()
         handle = ctypes.c_void_p()
@@ -447,6 +528,11 @@ class HipModel:
         check(self._lib.dbh_forward_timeline(self._handle, x, x.shape[0], out),
               'dbh_forward_timeline')
         return out
+
+    def set_host_group(self, windows_per_group=0):
+        """Windows per model and group of the host-buffer pipeline (0 = the default 32,768)."""
+        check(self._lib.dbh_model_set_host_group(self._handle, int(windows_per_group)),
+              'dbh_model_set_host_group')
 
     def set_read_length_hint(self, read_length, capacity_samples=0):
         """Tell the ``*_dev`` entry points that every read is ``read_length`` samples long (0

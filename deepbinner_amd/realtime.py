@@ -99,6 +99,7 @@ class Session:
          _) = classify.load_and_check_models(args.start_model, args.end_model, args.scan_size,
                                              out_dest=sys.stdout)
         self.unmovable = set()
+        self._names_in_bin = {}
         self.table_only = os.environ.get('DEEPBINNER_REALTIME_TABLE_ONLY') == '1'
         self._prepare_out_dir()
 
@@ -157,114 +158,196 @@ class Session:
         tally.report()
         return calls
 
-    def _reads_of(self, path):
-        """(read_id, signal) of every read in a multi-read file.  With the native reader the
-        whole file is inflated by its worker threads in one call.  When the reads are only
-        tabulated, only the scanned ends of long reads come back (all that call_batch looks at);
-        when they are binned too, the whole signals do."""
-        if reader_kind() != 'native':
-            return iter_reads(path)
+    # ---- multi-read containers ---------------------------------------------------------------
+    # The reference unpacks them with an external tool and bins the copies (realtime.py:183-190).
+    # Here they are classified where they are: a container is ONE unit of work - loaded by the
+    # native loader's thread team several containers ahead (fast5_native.stream_reads), its packed
+    # buffer (pinned host memory when a GPU model is loaded) handed to the C ABI as it is, both
+    # models and combine_calls in one call (classify.classify_packed_numbers) on whichever device
+    # replica is next (classify.dispatch_batches) - BASELINE.json configs[4]: one host streaming
+    # multi-read files into several GPUs.
+    def _keep(self):
+        """Samples per read end the loaders keep: only the scanned ends when the reads are merely
+        tabulated (all that call_batch looks at), whole signals when they are binned too."""
+        return classify.scanned_end_samples(self.args.scan_size) if self.table_only else None
+
+    def _packed_containers(self, fast5s):
+        """(container number, path, read ids, samples, offsets) per readable container, in order;
+        unreadable reads are dropped (the reference skips what it cannot read,
+        load_fast5s.py:47-49)."""
+        import numpy as np
         from . import fast5_native
-        keep = classify.scanned_end_samples(self.args.scan_size) if self.table_only else None
-        try:
-            ids, samples, offsets, status = fast5_native.load_reads(
-                path, keep=keep, threads=int(getattr(self.args, 'loader_procs', 0) or 0))
-        except OSError:
-            return []
-        classify.warn_about_filters(status)
-        reads = classify.PackedBatch((rid, samples[offsets[i]:offsets[i + 1]])
-                                     for i, rid in enumerate(ids) if rid is not None)
-        if len(reads) == len(ids) and keep is not None:
-            # nothing dropped, long reads already cut to their scanned ends: the packed buffer is
-            # what the C ABI takes
-            reads.samples, reads.offsets, reads.complete = samples, offsets, True
-        return reads
+        threads = int(getattr(self.args, 'loader_procs', 0) or 0)
+        stream = fast5_native.stream_reads(fast5s, keep=self._keep(), threads=threads,
+                                           depth=int(os.environ.get('DEEPBINNER_LOADER_DEPTH', 0)))
+        for index, ids, samples, offsets, status in stream:
+            if ids is None:
+                continue
+            classify.warn_about_filters(status)
+            if any(rid is None for rid in ids):
+                ok = [i for i, rid in enumerate(ids) if rid is not None]
+                parts = [samples[offsets[i]:offsets[i + 1]] for i in ok]
+                lengths = [len(part) for part in parts]
+                samples = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int16)
+                offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+                ids = [ids[i] for i in ok]
+            yield index + 1, fast5s[index], ids, samples, offsets
 
-    def _containers(self, fast5s):
-        """(path, reads) per file, file k + 1 being loaded on a background thread (the native
-        loader releases the GIL) while the caller classifies file k."""
-        box = {}
+    def _classify_container(self, item, start_replica, end_replica):
+        number, path, ids, samples, offsets = item
+        numbers = classify.classify_packed_numbers(samples, offsets, start_replica, end_replica,
+                                                   self.args)
+        names = [classify.call_name(c) for c in numbers.tolist()]
+        signal = (lambda i: samples[offsets[i]:offsets[i + 1]]) if not self.table_only else None
+        return number, path, ids, names, signal
 
-        def load(path):
+    def _read_chunks(self, fast5s):
+        """The same units for the Python reader and for models without the packed entry point:
+        (container number, path, read ids, signals) per --batch_size reads."""
+        for number, path in enumerate(fast5s, start=1):
             try:
-                reads = self._reads_of(path)
-                box[path] = reads if isinstance(reads, list) else list(reads)
-            except Exception as e:          # surfaces on the consuming side
-                box[path] = e
+                reads = list(iter_reads(path))
+            except OSError:
+                continue
+            for chunk in classify.chunker(reads, self.args.batch_size):
+                yield number, path, [r[0] for r in chunk], [r[1] for r in chunk]
 
-        worker = None
-        for k, path in enumerate(fast5s):
-            if worker is None:
-                load(path)
-            else:
-                worker.join()
-            if k + 1 < len(fast5s):
-                worker = threading.Thread(target=load, args=(fast5s[k + 1],), daemon=True)
-                worker.start()
-            reads = box.pop(path)
-            if isinstance(reads, Exception):
-                raise reads
-            yield path, reads
+    def _classify_chunk(self, item, start_replica, end_replica):
+        number, path, ids, signals = item
+        found = {}
+        classify.classify_read_batch(ids, signals, start_replica, self.start_size, end_replica,
+                                     self.end_size, self.n_classes, self.args, found)
+        return number, path, ids, [found[rid] for rid in ids], signals.__getitem__
 
     def _tabulate_multi_read_files(self, fast5s):
         from concurrent.futures import ThreadPoolExecutor
         from .hdf5_write import write_single_read_fast5
-        calls, done, written = {}, 0, []
-        writers = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4),
+        calls, done, written = {}, 0, 0
+        n_writers = min(16, os.cpu_count() or 4)
+        writers = ThreadPoolExecutor(max_workers=n_writers,
                                      thread_name_prefix='deepbinner-fast5-writer')
+        # at most this many reads wait to be written (each holds its signal - and with it the
+        # container's buffer - in memory)
+        in_flight = threading.BoundedSemaphore(64 * n_writers)
+        failures = []
 
-        def bin_read(read_id, signal, call):
-            target = self.out_dir / bin_name(call)
-            os.makedirs(str(target), exist_ok=True)
-            write_single_read_fast5(str(target / (read_id + '.fast5')), read_id, signal)
+        def bin_read(name, read_id, signal, call, source, metadata):
+            try:
+                target = self.out_dir / bin_name(call)
+                os.makedirs(str(target), exist_ok=True)
+                write_single_read_fast5(str(target / (name + '.fast5')), read_id, signal,
+                                        metadata=metadata(source, read_id))
+            except Exception as e:                       # surfaces when the pass ends
+                failures.append(e)
+            finally:
+                in_flight.release()
 
+        models = [m for m in (self.start_model, self.end_model) if m is not None]
+        packed = reader_kind() == 'native' and all(hasattr(m, 'classify_packed') for m in models)
+        items, work = ((self._packed_containers(fast5s), self._classify_container) if packed
+                       else (self._read_chunks(fast5s), self._classify_chunk))
+        metadata = MetadataSource() if not self.table_only else None
+        # the units go round the devices the models are replicated on (one, usually)
+        replicas = classify.device_replicas(self.start_model, self.end_model)
         with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
-            for n_files, (path, reads) in enumerate(self._containers(fast5s), start=1):
-                signals_of = dict(reads) if not self.table_only else {}
+            classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
+            for number, path, ids, names, signal in classify.dispatch_batches(items, replicas, work):
+                calls.update(zip(ids, names))
+                table.writelines('{}\t{}\t{}\n'.format(rid, name, path)
+                                 for rid, name in zip(ids, names))
+                if not self.table_only:      # zlib and file writes release the GIL
+                    for i, (rid, name) in enumerate(zip(ids, names)):
+                        in_flight.acquire()
+                        writers.submit(bin_read, self._file_name(rid, name), rid, signal(i), name,
+                                       path, metadata)
+                        written += 1
+                done += len(ids)
                 # the total is known once the last container is open; until then, extrapolate
-                total = max((done + len(reads)) * len(fast5s) // n_files, 1)
-                classify.print_classification_progress(done, total, 'reads', out_dest=sys.stdout)
-                def chunks():
-                    for at, chunk in enumerate(classify.chunker(reads, self.args.batch_size)):
-                        ids = [r[0] for r in chunk]
-                        signals = [r[1] for r in chunk]
-                        if getattr(reads, 'complete', False):
-                            # this chunk's part of the container's packed buffer, as the C ABI
-                            # takes it
-                            lo = at * self.args.batch_size
-                            offsets = reads.offsets[lo:lo + len(chunk) + 1]
-                            signals = classify.PackedSignals(
-                                signals, reads.samples[offsets[0]:offsets[-1]],
-                                offsets - offsets[0])
-                        yield ids, signals
-
-                def classify_chunk(chunk, start_replica, end_replica):
-                    ids, signals = chunk
-                    found = {}
-                    classify.classify_read_batch(ids, signals, start_replica, self.start_size,
-                                                 end_replica, self.end_size, self.n_classes,
-                                                 self.args, found)
-                    return ids, found
-
-                # the chunks go round the devices the models are replicated on (one, usually)
-                replicas = classify.device_replicas(self.start_model, self.end_model)
-                for ids, found in classify.dispatch_batches(chunks(), replicas, classify_chunk):
-                    calls.update(found)
-                    table.writelines('{}\t{}\t{}\n'.format(rid, calls[rid], path) for rid in ids)
-                    if not self.table_only:      # zlib and file writes release the GIL
-                        written += [writers.submit(bin_read, rid, signals_of[rid], calls[rid])
-                                    for rid in ids]
-                    done += len(ids)
-                    classify.print_classification_progress(min(done, total), total, 'reads',
-                                                           out_dest=sys.stdout)
-        for job in written:
-            job.result()
-        writers.shutdown()
+                total = max(done * len(fast5s) // number, 1)
+                classify.print_classification_progress(min(done, total), total, 'reads',
+                                                       out_dest=sys.stdout)
+        writers.shutdown(wait=True)
+        if metadata is not None:
+            metadata.close()
+        if failures:
+            sys.exit('Error: failed to write {} one-read fast5 file{} into {} ({})'.format(
+                len(failures), '' if len(failures) == 1 else 's', self.out_dir, failures[0]))
         if written:
             print()
-            print('Wrote {:,} one-read fast5 files into {}'.format(len(written), self.out_dir),
-                  end='')
+            print('Wrote {:,} one-read fast5 files into {}'.format(written, self.out_dir), end='')
         return calls
+
+    def _file_name(self, read_id, call):
+        """File name (without .fast5) of a binned read.  The id is an attribute of an untrusted
+        file: one that is not a plain name (path separators, dots only, control characters,
+        over-long) is replaced by a digest of itself, and a name already used in this bin during
+        this run gets a numbered suffix instead of overwriting the earlier read."""
+        import hashlib
+        plain = (0 < len(read_id) <= 128 and read_id not in ('.', '..') and
+                 all(c.isalnum() or c in '-_.' for c in read_id))
+        name = read_id if plain else 'read_' + hashlib.sha256(read_id.encode()).hexdigest()[:32]
+        used = self._names_in_bin.setdefault(bin_name(call), set())
+        candidate, k = name, 1
+        while candidate in used:
+            candidate = '{}_{}'.format(name, k)
+            k += 1
+        used.add(candidate)
+        return candidate
+
+
+class MetadataSource:
+    """What a basecaller needs beside the signal: per read the attributes of ``Raw`` and of the
+    ``channel_id`` / ``tracking_id`` / ``context_tags`` groups of its container (ont_fast5_api's
+    multi_to_single_fast5 copies them; the reference bins its output, realtime.py:183-190).  Read
+    with this package's Python HDF5 reader, one open container at a time per writer thread."""
+
+    GROUPS = ('channel_id', 'tracking_id', 'context_tags')
+
+    def __init__(self):
+        self._local = threading.local()
+        self._files = []
+        self._lock = threading.Lock()
+
+    def _container(self, path):
+        from . import hdf5_lite
+        if getattr(self._local, 'path', None) != path:
+            if getattr(self._local, 'file', None) is not None:
+                self._local.file.close()
+            self._local.file, self._local.path = None, None
+            self._local.file = hdf5_lite.File(path, 'r')
+            self._local.path = path
+            self._local.shared = {}
+            with self._lock:
+                self._files.append(self._local)
+        return self._local.file
+
+    def __call__(self, path, read_id):
+        try:
+            container = self._container(path)
+            group = container['read_' + read_id]
+            found = {'read': dict(group.attrs.items()), 'Raw': dict(group['Raw'].attrs.items())}
+            for name in self.GROUPS:
+                if name in group:
+                    child = group[name]
+                    # the same channel / run for every read of a container, as a rule
+                    key = (name, getattr(child, 'addr', id(child)))
+                    if key not in self._local.shared:
+                        self._local.shared[key] = dict(child.attrs.items())
+                    found[name] = self._local.shared[key]
+            return found
+        except (OSError, KeyError, ValueError):
+            return None             # the signal and the read id are what binning cannot do without
+
+    def close(self):
+        with self._lock:
+            for local in self._files:
+                try:
+                    if local.file is not None:
+                        local.file.close()
+                except Exception:
+                    pass
+                local.file = local.path = None
+            self._files = []
 
 
 def realtime(args):

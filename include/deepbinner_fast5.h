@@ -22,6 +22,7 @@
 #ifndef DEEPBINNER_FAST5_H
 #define DEEPBINNER_FAST5_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -60,11 +61,12 @@ int f5_read_info(f5_file* file, int64_t index, char read_id[F5_READ_ID_MAX], int
 int f5_read_signal(f5_file* file, int64_t index, int64_t first, int64_t count, int16_t* out);
 
 /* One-read files -> packed signals, loaded by `n_threads` worker threads (<= 0: one per hardware
- * thread, at most 64).  keep > 0: reads longer than 2*keep contribute their first and last `keep`
- * samples only (windows are cut from those: reference classify.py:337-349); keep <= 0: whole
- * reads.  Read i occupies samples[offsets[i] .. offsets[i+1]); a file that could not be read has
- * status != F5_OK, an empty id and an empty range (the reference skips such files,
- * load_fast5s.py:47-49).  The result owns its memory until f5_batch_free. */
+ * thread, at most 64; an explicit count is honoured up to 256).  keep > 0: reads longer than
+ * 2*keep contribute their first and last `keep` samples only (windows are cut from those:
+ * reference classify.py:337-349); keep <= 0: whole reads.  Read i occupies
+ * samples[offsets[i] .. offsets[i+1]); a file that could not be read has status != F5_OK, an
+ * empty id and an empty range (the reference skips such files, load_fast5s.py:47-49).  The
+ * result owns its memory until f5_batch_free. */
 typedef struct f5_batch f5_batch;
 int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n_threads,
                   f5_batch** out);
@@ -75,6 +77,32 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
  * zero filled: go by the status. */
 int f5_load_reads(const char* path, int64_t first, int64_t count, int64_t keep, int n_threads,
                   f5_batch** out);                        /* count < 0: from `first` to the end */
+/* Multi-read containers as a STREAM (BASELINE.json configs[4]; the reference's flow is
+ * realtime.py:81-108 + :183-190, one file at a time through multi_to_single_fast5): the containers
+ * of `paths` are loaded by a team of n_threads threads (<= 0: one per hardware thread, at most
+ * 64; explicit counts up to 256) working on `depth` containers at once (<= 0: 3) - opening and
+ * walking container k+1, k+2 beside the inflating of container k - and handed out in path order.
+ * f5_stream_next blocks until the next container is ready: *index = its position in `paths`,
+ * *container_status = F5_OK or why it could not be opened (then *batch is NULL); the batch is laid
+ * out as f5_load_reads' and is the caller's to free.  Returns F5_ERR_NO_READ after the last one.
+ * One consumer thread per stream. */
+typedef struct f5_stream f5_stream;
+int f5_stream_open(const char* const* paths, int64_t n_paths, int64_t keep, int n_threads,
+                   int depth, f5_stream** out);
+int f5_stream_next(f5_stream* stream, int64_t* index, int* container_status, f5_batch** batch);
+void f5_stream_close(f5_stream* stream);
+
+/* Where the packed samples of a batch live.  Freed batches leave their sample buffer in a pool
+ * (bounded by DEEPBINNER_FAST5_POOL_MB, default 2048) for the next batch that fits, so that a
+ * steady stream of containers allocates - and page-faults - nothing.  A caller may supply the
+ * memory: alloc(bytes, user) / release(ptr, user), e.g. dbh_host_alloc / dbh_host_release of
+ * libdeepbinner_hip.so (pinned host memory: the GPU's DMA engine then reads a batch where the
+ * loader threads wrote it, deepbinner_hip.h).  NULL, NULL = malloc.  Batches alive at the time of
+ * the call keep (and later return) the memory they have. */
+typedef void* (*f5_alloc_fn)(size_t bytes, void* user);
+typedef void (*f5_free_fn)(void* ptr, void* user);
+int f5_set_sample_allocator(f5_alloc_fn alloc, f5_free_fn release, void* user);
+void f5_release_idle_buffers(void);
 int64_t f5_batch_size(const f5_batch* batch);             /* files / reads in the batch */
 const int16_t* f5_batch_samples(const f5_batch* batch);
 const int64_t* f5_batch_offsets(const f5_batch* batch);   /* n_files + 1 */

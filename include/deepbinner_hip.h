@@ -105,6 +105,35 @@ int dbh_predict_dev(dbh_model* model, const float* x_dev, int64_t n_windows, flo
 int dbh_classify_i16(dbh_model* model, const int16_t* samples_host, const int64_t* offsets_host,
                      int64_t n_reads, int side, int scan_size, double score_diff,
                      float* probs_host, int32_t* calls_host);
+/* Host buffers that are pinned (dbh_malloc_host / dbh_host_alloc) are read by the GPU's DMA engine
+ * where they lie; pageable ones go through a pinned staging copy first.  Either way the reads
+ * travel in groups (32,768 windows per model by default: dbh_model_set_host_group) through three
+ * slots, so that the upload of one group, the kernels of another and the results of a third
+ * overlap. */
+int dbh_model_set_host_group(dbh_model* model, int64_t windows_per_group /* 0 = default */);
+
+/* The body of the reference's per-batch loop (classify.py:141-171) for one batch of reads and BOTH
+ * models in one call: the samples are uploaded once, the start model scans the first and the end
+ * model the last scan_size samples of every read (call_batch with side 'start' / 'end',
+ * classify.py:325-384), and combine_calls (classify.py:298-322, DBH_REQUIRE_*) gives the final
+ * call - all queued on one stream per group, nothing but the calls (and whatever else is asked
+ * for) coming back.  Either model may be NULL: calls_host is then the other model's calls.
+ * calls_host: n_reads final calls.  Optional (NULL = not wanted): the per-side calls (n_reads
+ * int32 each) and per-side probabilities (n_reads x n_classes fp32 each) - what --verbose
+ * prints.  Both models must live on the same device and agree on n_classes. */
+int dbh_classify_pair_i16(dbh_model* start_model, dbh_model* end_model,
+                          const int16_t* samples_host, const int64_t* offsets_host,
+                          int64_t n_reads, int scan_size, double score_diff, int combine_mode,
+                          int32_t* calls_host, int32_t* start_calls_host, int32_t* end_calls_host,
+                          float* start_probs_host, float* end_probs_host);
+
+/* Pinned host memory behind the allocator signature libdeepbinner_fast5.so takes
+ * (deepbinner_fast5.h: f5_set_sample_allocator): the loader's threads then write a batch straight
+ * into memory the entry points above upload without a staging copy.  `user` is ignored. */
+void* dbh_host_alloc(size_t bytes, void* user);
+void dbh_host_release(void* ptr, void* user);
+int dbh_host_is_pinned(const void* ptr, size_t bytes, int* pinned);
+
 /* Optional hint for the *_dev entry points: "every read in the sample buffer is read_length
  * samples long and the buffer holds at least capacity_samples samples".  The forward kernel then
  * requests a read's samples from read_index * read_length TOGETHER with offsets[read_index]

@@ -297,6 +297,89 @@ def test_load_reads_of_one_file(path):
         fast5_native.load_reads(path + '.missing')
 
 
+def test_stream_of_containers(tmp_path):
+    """f5_stream_*: containers loaded several at once by one thread team come out in path order
+    with exactly what f5_load_reads gives for each - for every window depth and team size, with
+    one-read files, an unreadable file and a missing one among the containers, and with the same
+    container many times over (one chunk cache per thread serving several files)."""
+    bad = tmp_path / 'not_hdf5.fast5'
+    bad.write_bytes(b'nothing of the kind' * 100)
+    paths = (multi_files() + [str(bad)] + single_files()[:2] + [str(tmp_path / 'missing.fast5')] +
+             multi_files()[::-1] * 3)
+    want = {}
+    for p in set(paths):
+        try:
+            want[p] = {keep: fast5_native.load_reads(p, keep=keep, threads=1)
+                       for keep in (None, 700, 6656)}
+        except OSError:
+            want[p] = None
+    for keep, threads, depth in ((6656, 5, 3), (None, 2, 1), (700, 16, 8), (6656, 1, 2)):
+        seen = []
+        for index, ids, samples, offsets, status in fast5_native.stream_reads(
+                paths, keep=keep, threads=threads, depth=depth):
+            seen.append(index)
+            w = want[paths[index]]
+            if w is None:
+                assert ids is None and status != 0
+                continue
+            w_ids, w_samples, w_offsets, w_status = w[keep]
+            assert ids == w_ids and np.array_equal(offsets, w_offsets)
+            assert np.array_equal(samples, w_samples) and np.array_equal(status, w_status)
+        assert seen == list(range(len(paths)))
+    assert list(fast5_native.stream_reads([], keep=6656)) == []
+    # a consumer that stops early: closing the generator stops the team
+    stream = fast5_native.stream_reads(paths, keep=6656, threads=4, depth=4)
+    assert next(stream)[0] == 0
+    stream.close()
+
+
+def test_sample_buffers_are_recycled_and_can_come_from_the_caller():
+    """The packed samples of a batch come from a pool of recycled buffers, or from an allocator
+    the caller installs (pinned host memory on a GPU box; here: counted malloc)."""
+    import ctypes
+    path = multi_files()[0]
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    live, sizes = set(), []
+    ALLOC = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    FREE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
+
+    def alloc(nbytes, user):
+        ptr = libc.malloc(nbytes)
+        live.add(ptr)
+        sizes.append(nbytes)
+        return ptr
+
+    def release(ptr, user):
+        live.discard(ptr)
+        libc.free(ptr)
+
+    alloc_c, release_c = ALLOC(alloc), FREE(release)
+    want = fast5_native.load_reads(path, keep=6656, threads=2)
+    fast5_native.set_sample_allocator(ctypes.cast(alloc_c, ctypes.c_void_p).value,
+                                      ctypes.cast(release_c, ctypes.c_void_p).value)
+    try:
+        for _ in range(5):
+            ids, samples, offsets, status = fast5_native.load_reads(path, keep=6656, threads=2)
+            assert ids == want[0] and np.array_equal(samples, want[1])
+            address = samples.ctypes.data
+            assert address in live                      # the batch lies in the caller's memory
+            del samples
+        assert len(sizes) == 1                          # one allocation served all five batches
+        held = fast5_native.load_reads(path, keep=6656, threads=2)
+        assert held[1].ctypes.data == address
+    finally:
+        fast5_native.set_sample_allocator(None, None)   # flushes the pool of idle buffers ...
+    assert live == {address}                            # ... but not a batch still alive
+    assert np.array_equal(held[1], want[1])
+    del held
+    assert live == set()                                # freed through the allocator it came from
+    again = fast5_native.load_reads(path, keep=6656, threads=2)
+    assert np.array_equal(again[1], want[1]) and len(sizes) == 1
+
+
 def test_many_copies_in_parallel(tmp_path):
     """Thread-safety smoke test: 400 files on 16 threads give what one thread gives."""
     files = single_files()

@@ -1,0 +1,281 @@
+"""
+BASELINE.json configs[4] on the GPU (`-m gpu`): multi-read containers streamed through the native
+loader's thread team (f5_stream_*), pinned batches, both models in one call of the C ABI
+(dbh_classify_pair_i16), the dispatcher's device queues - at the configuration's own scale
+(>= 100,000 reads), with the reference's own calls (tests/golden/calls.json: its call_batch +
+combine_calls on the 37 fixture reads) as the anchor and bit-exact invariance everywhere else.
+"""
+import argparse
+import os
+import shutil
+import uuid
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, MODEL_DIR
+from oracle import classify_ref
+
+pytestmark = pytest.mark.gpu
+START, END = 'EXP-NBD103_read_starts', 'EXP-NBD103_read_ends'
+
+
+def pack(signals):
+    offsets = np.zeros(len(signals) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(s) for s in signals])
+    samples = (np.concatenate(signals) if len(signals) and offsets[-1] else
+               np.zeros(0)).astype(np.int16)
+    return samples, offsets
+
+
+def names(calls):
+    return ['none' if c == 0 else str(int(c)) for c in calls]
+
+
+def reference_final_calls(gold, mode='require_either'):
+    """{read id: final call} of the 37 fixture reads: the reference's own call_batch per side
+    (calls.json) through its combine_calls rule (oracle restatement, pinned to its truth table)."""
+    ids = gold['read_ids'] + gold['multi_read_ids']
+    starts = gold['calls'][START + '/start']
+    ends = gold['calls'][END + '/end']
+    args = argparse.Namespace(require_either=mode == 'require_either',
+                              require_start=mode == 'require_start',
+                              require_both=mode == 'require_both')
+    return {rid: classify_ref.combine_calls(s, e, args) for rid, s, e in zip(ids, starts, ends)}
+
+
+@pytest.mark.parametrize('mode', ['require_either', 'require_start', 'require_both'])
+def test_pair_entry_point_is_the_two_models_and_combine_calls(hip, hip_models, gold, all_signals,
+                                                              mode):
+    """dbh_classify_pair_i16 on ragged real reads: final calls = the reference's (calls.json),
+    per-side calls and probabilities bit-identical to each model's own dbh_classify_i16, for
+    pinned and pageable buffers, any group size, either model alone, empty and tiny reads."""
+    start, end = hip_models[START], hip_models[END]
+    signals = list(all_signals) + [np.zeros(0, np.int16), np.arange(5, dtype=np.int16),
+                                   np.full(300, 7, np.int16)]
+    samples, offsets = pack(signals)
+    want = reference_final_calls(gold, mode)
+    ids = gold['read_ids'] + gold['multi_read_ids']
+    s_probs, s_calls = start.classify_packed(samples, offsets, 'start', 6144, 0.5)
+    e_probs, e_calls = end.classify_packed(samples, offsets, 'end', 6144, 0.5)
+    combine = argparse.Namespace(require_either=mode == 'require_either',
+                                 require_start=mode == 'require_start',
+                                 require_both=mode == 'require_both')
+    expected = [classify_ref.combine_calls(s, e, combine)
+                for s, e in zip(names(s_calls), names(e_calls))]
+    assert expected[:37] == [want[rid] for rid in ids]
+
+    def check(calls, sides, probs):
+        assert names(calls) == expected
+        assert np.array_equal(sides[0], s_calls) and np.array_equal(sides[1], e_calls)
+        assert np.array_equal(probs[0], s_probs) and np.array_equal(probs[1], e_probs)
+
+    check(*hip.classify_pair(start, end, samples, offsets, 6144, 0.5, mode, True, True))
+    assert names(hip.classify_pair(start, end, samples, offsets, 6144, 0.5, mode)) == expected
+    # the same buffer in pinned memory: read by the DMA engine in place
+    lib = hip.load_library()
+    import ctypes
+    ptr = ctypes.c_void_p()
+    hip.check(lib.dbh_malloc_host(ctypes.byref(ptr), samples.nbytes))
+    try:
+        pinned = np.ctypeslib.as_array(ctypes.cast(ptr.value, ctypes.POINTER(ctypes.c_int16)),
+                                       shape=samples.shape)
+        pinned[:] = samples
+        assert hip.is_pinned(pinned) and not hip.is_pinned(samples)
+        check(*hip.classify_pair(start, end, pinned, offsets, 6144, 0.5, mode, True, True))
+        for windows in (12, 13 * 12, 5000):        # 1 read, 13 reads, all reads per group
+            start.set_host_group(windows)
+            end.set_host_group(windows)
+            check(*hip.classify_pair(start, end, pinned, offsets, 6144, 0.5, mode, True, True))
+            check(*hip.classify_pair(start, end, samples, offsets, 6144, 0.5, mode, True, True))
+    finally:
+        start.set_host_group(0)
+        end.set_host_group(0)
+        hip.check(lib.dbh_free_host(ptr))
+    # one model alone
+    assert np.array_equal(hip.classify_pair(start, None, samples, offsets, 6144, 0.5, mode), s_calls)
+    only_end = hip.classify_pair(None, end, samples, offsets, 6144, 0.5, mode, True, True)
+    assert np.array_equal(only_end[0], e_calls) and np.array_equal(only_end[1][1], e_calls)
+    assert only_end[1][0] is None and np.array_equal(only_end[2][1], e_probs)
+    # nothing to do / bad arguments
+    assert len(hip.classify_pair(start, end, np.zeros(0, np.int16), np.zeros(1, np.int64), 6144,
+                                 0.5, mode)) == 0
+    with pytest.raises(ValueError):
+        hip.classify_pair(None, None, samples, offsets, 6144, 0.5, mode)
+    other = hip_models['SQK-RBK004_read_starts']
+    if other.n_classes != start.n_classes:
+        with pytest.raises(hip.HipBackendError):
+            hip.classify_pair(start, other, samples, offsets, 6144, 0.5, mode)
+
+
+def test_host_path_at_one_window_per_read_is_the_device_path(hip, hip_models):
+    """dbh_classify_i16 over 70,000 one-window reads (three groups through the three slots) equals
+    the device-resident entry point bit for bit, pinned or pageable."""
+    from bench import config_reads
+    reads = config_reads(70000, 99)
+    model = hip_models[START]
+    n = len(reads)
+    offsets = np.arange(n + 1, dtype=np.int64) * 1024
+    d_samples = hip.DeviceBuffer.from_array(reads)
+    d_offsets = hip.DeviceBuffer.from_array(offsets)
+    d_probs = hip.DeviceBuffer(n * 13 * 4)
+    d_calls = hip.DeviceBuffer(n * 4)
+    model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, 256, 'start', 512, 0.5,
+                               d_probs.ptr, d_calls.ptr, None)
+    hip.synchronize()
+    want_probs = d_probs.download((n, 13), np.float32)
+    want_calls = d_calls.download((n,), np.int32)
+    probs, calls = model.classify_packed(reads.reshape(-1), offsets, 'start', 512, 0.5)
+    assert np.array_equal(calls, want_calls) and np.array_equal(probs, want_probs)
+    assert (calls != 0).sum() > 50
+
+
+# ---- the stream at scale ------------------------------------------------------------------------
+N_CONTAINERS, READS_PER_CONTAINER = 25, 4000        # 100,000 reads + the 30 fixture reads
+
+
+def build_containers(directory, gold):
+    """25 containers of 4,000 reads (+ the 30 multi-read fixture reads dealt over them), written
+    with this package's own container writer: 2,000 distinct seeded squiggles of 2,000-9,000
+    samples, deflated once each, under fresh read ids."""
+    from concurrent.futures import ThreadPoolExecutor
+    from deepbinner_amd import hdf5_write
+    rng = np.random.default_rng(20260928)
+    pool = []
+    for _ in range(2000):
+        n = int(rng.integers(2000, 9000))
+        levels = np.repeat(rng.normal(450, 80, n // 8 + 1), 8)[:n]
+        pool.append(np.clip(np.rint(levels + rng.normal(0, 8, n)), 0, 2047).astype(np.int16))
+    with ThreadPoolExecutor(16) as workers:
+        deflated = list(workers.map(lambda s: zlib.compress(s.tobytes(), 1), pool))
+    fixture = list(zip(gold['multi_read_ids'], gold['multi_signals']))
+    paths, every_id = [], []
+    jobs = []
+    for c in range(N_CONTAINERS):
+        reads = []
+        for k in range(READS_PER_CONTAINER):
+            j = int(rng.integers(0, len(pool)))
+            reads.append((str(uuid.UUID(bytes=rng.bytes(16), version=4)), pool[j], None,
+                          deflated[j]))
+        for rid, signal in fixture[c::N_CONTAINERS]:
+            reads.append((rid, signal))
+        every_id += [r[0] for r in reads]
+        path = os.path.join(directory, 'stream_%02d.fast5' % c)
+        paths.append(path)
+        jobs.append((path, reads))
+
+    def write(job):
+        with open(job[0], 'wb') as f:
+            f.write(hdf5_write.multi_read_fast5_bytes(job[1]))
+
+    with ThreadPoolExecutor(8) as workers:
+        list(workers.map(write, jobs))
+    return paths, every_id
+
+
+@pytest.fixture(scope='module')
+def containers(tmp_path_factory, gold):
+    directory = str(tmp_path_factory.mktemp('stream'))
+    paths, ids = build_containers(directory, gold)
+    yield directory, paths, ids
+    shutil.rmtree(directory, ignore_errors=True)
+
+
+def run_realtime(in_dir, out_dir, devices, monkeypatch, capsys, ordinals=None):
+    from deepbinner_amd import deepbinner as cli
+    import deepbinner_amd.realtime as realtime
+    monkeypatch.setattr(realtime, 'POLL_SECONDS', 0)
+    monkeypatch.setattr(shutil, 'which', lambda tool: None)       # no multi_to_single_fast5
+    monkeypatch.setenv('DEEPBINNER_REALTIME_TABLE_ONLY', '1')
+    if ordinals:
+        monkeypatch.setenv('DEEPBINNER_DEVICE_ORDINALS', ordinals)
+    else:
+        monkeypatch.delenv('DEEPBINNER_DEVICE_ORDINALS', raising=False)
+    argv = ['realtime', '--in_dir', in_dir, '--out_dir', out_dir, '--stop',
+            '-s', os.path.join(MODEL_DIR, START + '.dbw'),
+            '-e', os.path.join(MODEL_DIR, END + '.dbw')]
+    if devices > 1:
+        argv += ['--devices', str(devices)]
+    capsys.readouterr()
+    cli.main(argv)
+    text = capsys.readouterr().out
+    with open(os.path.join(out_dir, 'multi_read_classifications.tsv')) as f:
+        return [line.split('\t') for line in f.read().splitlines()], text
+
+
+def test_realtime_streams_100k_reads_of_multi_read_containers(hip, gold, containers, tmp_path,
+                                                              monkeypatch, capsys):
+    """configs[4] at its stated scale, one GPU: `deepbinner realtime` over 25 containers of 4,000
+    reads - loader team -> pinned batches -> dbh_classify_pair_i16 -> table.  Every read is
+    tabulated exactly once; the fixture reads get the reference's calls; two device queues (both
+    on GPU 0) or one, and the per-read path of `classify_signals`, give the same table bit for bit."""
+    import time
+    directory, paths, every_id = containers
+    t0 = time.perf_counter()
+    table, text = run_realtime(directory, str(tmp_path / 'one'), 1, monkeypatch, capsys)
+    seconds = time.perf_counter() - t0
+    assert len(table) == len(every_id) == N_CONTAINERS * READS_PER_CONTAINER + 30
+    assert sorted(r[0] for r in table) == sorted(every_id) and len(set(every_id)) == len(every_id)
+    assert {r[2] for r in table} == set(paths)
+    calls = {r[0]: r[1] for r in table}
+    want = reference_final_calls(gold)
+    for rid in gold['multi_read_ids']:
+        assert calls[rid] == want[rid]
+    assert sum(1 for r in table if r[1] != 'none') >= 10
+    # the summary tables of the passes add up to the reads (5 containers per pass: realtime.py:86-94)
+    assert text.count('Barcode     Count') == N_CONTAINERS // 5
+    print('realtime: %d reads in %.1f s = %.0f reads/s (table only, incl. model loading)'
+          % (len(table), seconds, len(table) / seconds))
+    # two device queues on the one GPU: same rows in the same order
+    table2, _ = run_realtime(directory, str(tmp_path / 'two'), 2, monkeypatch, capsys, '0,0')
+    assert table2 == table
+    # and the per-read route on a sample of the containers: call_batch per model through
+    # dbh_classify_i16 + combine_calls on the host
+    from deepbinner_amd import classify, fast5_native
+    from deepbinner_amd.model_format import ModelWeights
+    start = hip.HipModel(ModelWeights.load(os.path.join(MODEL_DIR, START + '.dbw'))[0])
+    end = hip.HipModel(ModelWeights.load(os.path.join(MODEL_DIR, END + '.dbw'))[0])
+    args = argparse.Namespace(scan_size=6144, score_diff=0.5, batch_size=256, verbose=True,
+                              require_either=True, require_start=False, require_both=False)
+    for path in paths[::12]:
+        ids, samples, offsets, status = fast5_native.load_reads(path, threads=8)
+        assert (status == 0).all()
+        signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
+        found = {}
+        for lo in range(0, len(ids), 1000):
+            classify.classify_read_batch(ids[lo:lo + 1000], signals[lo:lo + 1000], start, 1024,
+                                         end, 1024, 13, args, found)
+        assert all(calls[rid] == found[rid] for rid in ids)
+
+
+def test_realtime_bins_multi_read_reads_on_the_gpu(hip, gold, tmp_path, monkeypatch, capsys):
+    """The three fixture containers through `realtime` with the HIP backend, binning on: the table
+    is the reference's calls (calls.json: its call_batch + combine_calls), and every read sits in
+    the bin of its call as a one-read fast5 with its whole signal and its container's metadata."""
+    from deepbinner_amd import deepbinner as cli, hdf5_lite, load_fast5s
+    import deepbinner_amd.realtime as realtime
+    monkeypatch.setattr(realtime, 'POLL_SECONDS', 0)
+    monkeypatch.setattr(shutil, 'which', lambda tool: None)
+    monkeypatch.delenv('DEEPBINNER_REALTIME_TABLE_ONLY', raising=False)
+    in_dir, out_dir = tmp_path / 'in', tmp_path / 'out'
+    shutil.copytree(os.path.join(GOLD, 'fast5', 'multi'), in_dir)
+    cli.main(['realtime', '--in_dir', str(in_dir), '--out_dir', str(out_dir), '--stop',
+              '-s', os.path.join(MODEL_DIR, START + '.dbw'),
+              '-e', os.path.join(MODEL_DIR, END + '.dbw')])
+    assert 'Wrote 30 one-read fast5 files' in capsys.readouterr().out
+    rows = [r.split('\t') for r in
+            (out_dir / 'multi_read_classifications.tsv').read_text().splitlines()]
+    want = reference_final_calls(gold)
+    assert {r[0]: r[1] for r in rows} == {rid: want[rid] for rid in gold['multi_read_ids']}
+    originals = dict(zip(gold['multi_read_ids'], gold['multi_signals']))
+    for read_id, call, source in rows:
+        path = out_dir / realtime.bin_name(call) / (read_id + '.fast5')
+        got_id, got = load_fast5s.get_read_id_and_signal(str(path))
+        assert got_id == read_id and np.array_equal(got, originals[read_id])
+        with hdf5_lite.File(str(path), 'r') as f, hdf5_lite.File(source, 'r') as container:
+            mine, theirs = f['read_' + read_id], container['read_' + read_id]
+            assert sorted(mine.keys()) == sorted(theirs.keys())
+            for sub in ('channel_id', 'tracking_id', 'context_tags'):
+                assert dict(mine[sub].attrs.items()) == dict(theirs[sub].attrs.items())
+    assert sum(len(files) for _, _, files in os.walk(str(out_dir))) == 31

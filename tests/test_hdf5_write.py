@@ -129,7 +129,96 @@ def test_realtime_bins_the_reads_of_multi_read_files(oracle_backend, tmp_path, c
         assert got_id == read_id and np.array_equal(got, originals[read_id])
         with hdf5_lite.File(str(path), 'r') as f:
             assert list(f.keys()) == ['read_' + read_id]
+            # what multi_to_single_fast5 carries over besides the signal (basecallers need
+            # channel_id): every attribute of the read's groups, same names, types and values
+            source = [n for n in sorted(os.listdir(in_dir))
+                      if 'read_' + read_id in hdf5_lite.File(str(in_dir / n), 'r')][0]
+            with hdf5_lite.File(str(in_dir / source), 'r') as container:
+                want_group, got_group = container['read_' + read_id], f['read_' + read_id]
+                assert sorted(got_group.keys()) == sorted(want_group.keys()) == \
+                    ['Raw', 'channel_id', 'context_tags', 'tracking_id']
+                for sub in (None, 'Raw', 'channel_id', 'context_tags', 'tracking_id'):
+                    want_attrs = dict((want_group[sub] if sub else want_group).attrs.items())
+                    got_attrs = dict((got_group[sub] if sub else got_group).attrs.items())
+                    assert sorted(got_attrs) == sorted(want_attrs) and len(want_attrs) > 0
+                    for key, value in want_attrs.items():
+                        same = got_attrs[key] == value or (value != value and
+                                                           got_attrs[key] != got_attrs[key])
+                        assert same, (sub, key)            # (median_before is NaN in places)
+                        assert getattr(got_attrs[key], 'dtype', None) == \
+                            getattr(value, 'dtype', None), (sub, key)
         seen.add(read_id)
     assert seen == set(originals)
     n_files = sum(len(files) for _, _, files in os.walk(out_dir)) - 1      # minus the table
     assert n_files == 30
+    if os.path.exists(CONDA_PYTHON):
+        # the real HDF5 library: every binned file holds its container's groups, attributes
+        # (names, types, values) and signal
+        code = (
+            'import glob, sys\nimport h5py, numpy as np\n'
+            'containers = [h5py.File(c, "r") for c in glob.glob(sys.argv[2] + "/*.fast5")]\n'
+            'n = 0\n'
+            'for p in glob.glob(sys.argv[1] + "/*/*.fast5"):\n'
+            '    f = h5py.File(p, "r"); k = list(f.keys())[0]; g = f[k]\n'
+            '    src = [h[k] for h in containers if k in h][0]\n'
+            '    assert sorted(g.keys()) == sorted(src.keys())\n'
+            '    for sub in (".", "Raw", "channel_id", "tracking_id", "context_tags"):\n'
+            '        a = dict(g.attrs if sub == "." else g[sub].attrs)\n'
+            '        b = dict(src.attrs if sub == "." else src[sub].attrs)\n'
+            '        assert sorted(a) == sorted(b), sub\n'
+            '        for key in a:\n'
+            '            assert a[key] == b[key] or a[key] != a[key], key\n'
+            '            assert getattr(a[key], "dtype", None) == getattr(b[key], "dtype", None)\n'
+            '    assert np.array_equal(g["Raw/Signal"][()], src["Raw/Signal"][()])\n'
+            '    n += 1\n'
+            'print(n)\n')
+        import subprocess
+        done = subprocess.run([CONDA_PYTHON, '-c', code, str(out_dir), str(in_dir)],
+                              capture_output=True, text=True)
+        assert done.returncode == 0 and done.stdout.strip() == '30', done.stderr[-2000:]
+
+
+def test_multi_read_containers_are_written_too(tmp_path):
+    """hdf5_write.multi_read_fast5_bytes (the containers of the streaming tests and tools): 300
+    reads under one root group; both readers - and the real HDF5 library where the image has it -
+    find every read, its signal and its attributes."""
+    import uuid
+    from deepbinner_amd import fast5_native, hdf5_lite, hdf5_write, load_fast5s
+    rng = np.random.default_rng(5)
+    reads = []
+    for k in range(300):
+        signal = rng.integers(-300, 2047, int(rng.integers(0, 5000))).astype(np.int16)
+        meta = {'Raw': {'read_number': np.int32(k), 'start_mux': np.uint8(k % 4)},
+                'channel_id': {'digitisation': np.float64(8192.0), 'channel_number': b'%d' % k}}
+        reads.append((str(uuid.UUID(bytes=rng.bytes(16), version=4)), signal, meta))
+    path = str(tmp_path / 'container.fast5')
+    with open(path, 'wb') as f:
+        f.write(hdf5_write.multi_read_fast5_bytes(reads))
+    want = sorted(reads, key=lambda r: r[0])
+    assert load_fast5s.determine_single_or_multi_fast5s([path]) == 'multi'
+    if fast5_native.available():
+        ids, samples, offsets, status = fast5_native.load_reads(path, threads=3)
+        assert ids == [r[0] for r in want] and (status == 0).all()
+        for i, r in enumerate(want):
+            assert np.array_equal(samples[offsets[i]:offsets[i + 1]], r[1])
+    with hdf5_lite.File(path, 'r') as f:
+        assert list(f.keys()) == ['read_' + r[0] for r in want]
+        for read_id, signal, meta in want[::17]:
+            group = f['read_' + read_id]
+            assert np.array_equal(np.asarray(group['Raw/Signal']), signal)
+            assert group['Raw'].attrs['read_number'] == meta['Raw']['read_number']
+            assert group['channel_id'].attrs['channel_number'] == meta['channel_id']['channel_number']
+    with open(str(tmp_path / 'empty.fast5'), 'wb') as f:
+        f.write(hdf5_write.multi_read_fast5_bytes([]))
+    with hdf5_lite.File(str(tmp_path / 'empty.fast5'), 'r') as f:
+        assert list(f.keys()) == []
+    if os.path.exists(CONDA_PYTHON):
+        import subprocess
+        code = ('import h5py, sys\n'
+                'f = h5py.File(sys.argv[1], "r")\n'
+                'print(len(f), sum(int(f[k]["Raw/Signal"][()].astype("i8").sum()) for k in f),'
+                ' sum(int(f[k]["Raw"].attrs["read_number"]) for k in f))\n')
+        done = subprocess.run([CONDA_PYTHON, '-c', code, path], capture_output=True, text=True)
+        assert done.returncode == 0, done.stderr[-2000:]
+        assert done.stdout.split() == ['300', str(sum(int(r[1].astype('i8').sum()) for r in reads)),
+                                       str(sum(range(300)))]

@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4] in the small: stream multi-read fast5 containers of MinKNOW's size
-(4,000 reads per file) through the native loader and both models, the way ``deepbinner realtime``
-does when it finds multi-read files (Session._tabulate_multi_read_files).
+"""BASELINE.json configs[4] on one GPU box: stream multi-read fast5 containers of MinKNOW's size
+(4,000 reads per file, gzip level 1, one chunk per read) through the native loader and both
+models, the way ``deepbinner realtime`` does when it finds multi-read files
+(realtime.Session._tabulate_multi_read_files).
 
-The containers are written on the spot by the image's one interpreter with h5py
-(/opt/conda/bin/python3.9; gzip level 1, one chunk per read, the layout MinKNOW / ont_fast5_api
-write); without it the tool says so and exits.  Reported:
-  1. f5_load_reads alone (scanned ends only) at several thread counts, and the Python reader;
-  2. load + classify with start and end models, scan_size 6144, batch 256, loading of container
-     k + 1 overlapped with classification of container k on a background thread;
-  3. per number of device queues of the single-process dispatcher (classify.dispatch_batches; on a
-     one-GPU box the queues beyond the first share GPU 0): the GPU side alone (batches already in
-     memory), the loader alone, both together - and which of the two bounds the whole.
-Usage: python tools/multi_read_rate.py [--files 3] [--reads 4000] [--mean-length 27000]"""
+The containers are written on the spot by the image's interpreter with h5py
+(/opt/conda/bin/python3.9: the real HDF5 library, the layout MinKNOW / ont_fast5_api write), or,
+without it, by this package's own container writer (hdf5_write.multi_read_fast5_bytes).  Reported:
+  1. the loader alone (scanned ends only): one f5_load_reads call per container, as round 2
+     measured it, and the stream (f5_stream_*: a thread team working several containers ahead),
+     per team size, into pageable and into pinned buffers;
+  2. the GPU side alone: the containers' packed batches already in (pinned) host memory, both
+     models + combine_calls per container in one dbh_classify_pair_i16 call;
+  3. both together through the dispatcher, per number of device queues (on a one-GPU box the
+     queues beyond the first share GPU 0) - and which of the two bounds the whole.
+Usage: python tools/multi_read_rate.py [--files 16] [--reads 4000] [--mean-length 27000]"""
 import argparse
 import io
 import json
@@ -20,7 +22,6 @@ import os
 import subprocess
 import sys
 import tempfile
-import threading
 import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,146 +51,154 @@ with h5py.File(path, 'w') as f:
 '''
 
 
+def write_with_own_writer(path, n_reads, mean_length, seed):
+    import uuid
+    import numpy as np
+    from deepbinner_amd import hdf5_write
+    rng = np.random.default_rng(seed)
+    reads = []
+    for _ in range(n_reads):
+        n = int(np.clip(rng.lognormal(np.log(mean_length) - 0.32, 0.8), 2000, 400000))
+        levels = rng.normal(450, 80, size=n // 8 + 1)
+        signal = np.clip(np.rint(np.repeat(levels, 8)[:n] + rng.normal(0, 8, size=n)), 0, 2047)
+        reads.append((str(uuid.UUID(bytes=rng.bytes(16), version=4)), signal.astype(np.int16)))
+    with open(path, 'wb') as f:
+        f.write(hdf5_write.multi_read_fast5_bytes(reads))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--files', type=int, default=3)
+    ap.add_argument('--files', type=int, default=16)
     ap.add_argument('--reads', type=int, default=4000)
     ap.add_argument('--mean-length', type=int, default=27000)
+    ap.add_argument('--no-gpu', action='store_true', help='loader measurements only')
     opts = ap.parse_args()
-    if not os.path.exists(CONDA_PYTHON):
-        sys.exit('no interpreter with h5py at {}: cannot write the containers'.format(CONDA_PYTHON))
-    from deepbinner_amd import classify, fast5_native, load_fast5s
-    out = {'files': opts.files, 'reads_per_file': opts.reads, 'host_threads': os.cpu_count()}
+    from deepbinner_amd import classify, fast5_native
+    cpus = os.cpu_count() or 1
+    total = opts.files * opts.reads
+    out = {'files': opts.files, 'reads_per_file': opts.reads, 'host_threads': cpus}
     with tempfile.TemporaryDirectory() as tmp:
-        paths = [os.path.join(tmp, 'batch_%d.fast5' % k) for k in range(opts.files)]
+        paths = [os.path.join(tmp, 'batch_%02d.fast5' % k) for k in range(opts.files)]
         t0 = time.perf_counter()
-        jobs = [subprocess.Popen([CONDA_PYTHON, '-c', WRITER, p, str(opts.reads),
-                                  str(opts.mean_length), str(100 + k)])
-                for k, p in enumerate(paths)]
-        if any(j.wait() != 0 for j in jobs):
-            sys.exit('writing the containers with h5py failed')
-        out['h5py_write_seconds'] = round(time.perf_counter() - t0, 1)
+        if os.path.exists(CONDA_PYTHON):
+            out['containers_written_by'] = 'h5py (libhdf5)'
+            jobs = [subprocess.Popen([CONDA_PYTHON, '-c', WRITER, p, str(opts.reads),
+                                      str(opts.mean_length), str(100 + k)])
+                    for k, p in enumerate(paths)]
+            if any(j.wait() != 0 for j in jobs):
+                sys.exit('writing the containers with h5py failed')
+        else:
+            out['containers_written_by'] = 'hdf5_write.multi_read_fast5_bytes'
+            for k, p in enumerate(paths):
+                write_with_own_writer(p, opts.reads, opts.mean_length, 100 + k)
+        out['write_seconds'] = round(time.perf_counter() - t0, 1)
         out['container_MB'] = round(sum(os.path.getsize(p) for p in paths) / 1e6 / opts.files, 1)
+        keep = classify.scanned_end_samples(6144)
 
         ids, samples, offsets, status = fast5_native.load_reads(paths[0], threads=8)
         assert (status == 0).all() and len(ids) == opts.reads
         out['mean_samples_per_read'] = int(offsets[-1] // opts.reads)
-        rates = {}
-        for threads in (1, 8, 16, 32, 64, 128):
-            if threads > (os.cpu_count() or 1):
-                continue
-            t0 = time.perf_counter()
-            for p in paths:
-                fast5_native.load_reads(p, keep=6656, threads=threads)
-            rates['%d threads' % threads] = round(opts.files * opts.reads /
-                                                  (time.perf_counter() - t0))
-        os.environ['DEEPBINNER_FAST5_READER'] = 'python'
-        t0 = time.perf_counter()
-        n = 0
-        for _, _ in load_fast5s.iter_reads(paths[0]):
-            n += 1
-            if n == 500:
-                break
-        rates['python reader (500 reads)'] = round(n / (time.perf_counter() - t0))
-        os.environ['DEEPBINNER_FAST5_READER'] = 'native'
-        out['f5_load_reads, scanned ends'] = {'reads_per_s': rates}
+        del samples
 
+        # ---- 1. the loader alone ----------------------------------------------------------
+        teams = [t for t in (1, 8, 16, 32, 64, 128, 192, 256) if t <= cpus]
+        per_call = {}
+        for threads in teams:
+            if threads > 64 and threads not in (128,):
+                continue
+            subset = paths[:max(2, min(len(paths), threads))]
+            t0 = time.perf_counter()
+            for p in subset:
+                fast5_native.load_reads(p, keep=keep, threads=threads)
+            per_call['%d threads' % threads] = round(len(subset) * opts.reads /
+                                                     (time.perf_counter() - t0))
+        out['loader alone, one f5_load_reads call per container'] = {'reads_per_s': per_call}
+
+        def stream_rate(threads, depth, subset):
+            t0 = time.perf_counter()
+            n = 0
+            for _, ids, samples, _, _ in fast5_native.stream_reads(subset, keep=keep,
+                                                                   threads=threads, depth=depth):
+                n += len(ids)
+            return round(n / (time.perf_counter() - t0))
+
+        streamed = {}
+        for threads in teams:
+            subset = paths[:max(2, min(len(paths), threads // 2))]
+            stream_rate(threads, 4, subset[:2])                     # warm the buffer pool
+            streamed['%d threads' % threads] = stream_rate(threads, 4, subset)
+        out['loader alone, f5_stream (4 containers in flight), pageable buffers'] = {
+            'reads_per_s': streamed}
+        best_team = max(teams, key=lambda t: streamed['%d threads' % t])
+        out['depth sweep at %d threads' % best_team] = {
+            'depth %d' % d: stream_rate(best_team, d, paths) for d in (1, 2, 3, 4, 6, 8)}
+        if opts.no_gpu:
+            print(json.dumps(out, indent=1))
+            return
+
+        # ---- 2./3. with the GPU ---------------------------------------------------------------
+        from deepbinner_amd import hip_backend
         models = os.path.join(REPO, 'deepbinner_amd', 'models')
-        sm, si, em, ei, osz, _ = classify.load_and_check_models(
-            os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
-            os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
         args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144, score_diff=0.5,
                                   require_either=True, require_start=False, require_both=False)
-        threads = min(32, max(1, (os.cpu_count() or 4) // 4))
-
-        def load(path, box):
-            box.append(fast5_native.load_reads(path, keep=6144 + 512, threads=threads))
-
-        calls = {}
-        t0 = time.perf_counter()
-        box = []
-        worker = threading.Thread(target=load, args=(paths[0], box))
-        worker.start()
-        for k in range(opts.files):
-            worker.join()
-            ids, samples, offsets, _ = box.pop()
-            if k + 1 < opts.files:
-                worker = threading.Thread(target=load, args=(paths[k + 1], box))
-                worker.start()
-            signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
-            for lo in range(0, len(ids), args.batch_size):
-                hi = min(lo + args.batch_size, len(ids))
-                chunk = classify.PackedSignals(signals[lo:hi], samples[offsets[lo]:offsets[hi]],
-                                               offsets[lo:hi + 1] - offsets[lo])
-                classify.classify_read_batch(ids[lo:hi], chunk, sm, si, em, ei, osz, args, calls)
-        dt = time.perf_counter() - t0
-        out['load + classify (start and end models, scan 6144, batch 256)'] = {
-            'loader_threads': threads, 'seconds': round(dt, 3),
-            'reads_per_s': round(opts.files * opts.reads / dt), 'distinct_reads': len(calls)}
-        # ---- 3. the dispatcher, per number of device queues -------------------------------
-        from deepbinner_amd import hip_backend
         visible = hip_backend.device_count()
-        loaded = [fast5_native.load_reads(p, keep=6144 + 512, threads=threads) for p in paths]
 
-        def batches_of(container):
-            ids, samples, offsets, _ = container
-            signals = [samples[offsets[i]:offsets[i + 1]] for i in range(len(ids))]
-            for lo in range(0, len(ids), args.batch_size):
-                hi = min(lo + args.batch_size, len(ids))
-                yield ids[lo:hi], classify.PackedSignals(
-                    signals[lo:hi], samples[offsets[lo]:offsets[hi]],
-                    offsets[lo:hi + 1] - offsets[lo])
-
-        def work(batch, start_replica, end_replica):
-            found = {}
-            classify.classify_read_batch(batch[0], batch[1], start_replica, si, end_replica, ei,
-                                         osz, args, found)
-            return len(found)
-
-        t0 = time.perf_counter()
-        for p in paths:
-            fast5_native.load_reads(p, keep=6144 + 512, threads=threads)
-        loader_rate = opts.files * opts.reads / (time.perf_counter() - t0)
-        per_devices = {}
-        for n_queues in (1, 2, 4, 8):
+        def load_models(n_queues):
             ordinals = [d % max(visible, 1) for d in range(n_queues)]
-            if n_queues > 1 and visible == 1 and n_queues > 2:
-                continue                    # more than two queues on one GPU says nothing new
             os.environ['DEEPBINNER_DEVICE_ORDINALS'] = ','.join(map(str, ordinals))
             classify.set_tensorflow_threads(argparse.Namespace(devices=n_queues))
-            sm_n, _, em_n, _, _, _ = classify.load_and_check_models(
+            sm, _, em, _, _, _ = classify.load_and_check_models(
                 os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
                 os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
-            replicas = classify.device_replicas(sm_n, em_n)
-            every = [b for c in loaded for b in batches_of(c)]
-            list(classify.dispatch_batches(iter(every[:8]), replicas, work))          # warm-up
+            return classify.device_replicas(sm, em), ordinals
+
+        def work(batch, start_replica, end_replica):
+            _, ids, samples, offsets, _ = batch
+            return len(classify.classify_packed_numbers(samples, offsets, start_replica,
+                                                        end_replica, args))
+
+        replicas, _ = load_models(1)          # (build_model switches the loader to pinned buffers)
+        pinned = {}
+        for threads in teams:
+            if threads < 16:
+                continue
+            subset = paths[:max(2, min(len(paths), threads // 2))]
+            stream_rate(threads, 4, subset[:4])
+            pinned['%d threads' % threads] = stream_rate(threads, 4, subset)
+        out['loader alone, f5_stream (4 containers in flight), pinned buffers'] = {
+            'reads_per_s': pinned}
+        loader_team = max(teams, key=lambda t: pinned.get('%d threads' % t, 0))
+        loader_rate = pinned['%d threads' % loader_team]
+
+        loaded = list(fast5_native.stream_reads(paths[:8], keep=keep, threads=loader_team, depth=4))
+        out['batches_in_pinned_memory'] = bool(hip_backend.is_pinned(loaded[0][2]))
+        per_queues = {}
+        for n_queues in (1, 2, 4, 8):
+            if n_queues > 2 and visible == 1:
+                continue                    # more than two queues on one GPU says nothing new
+            replicas, ordinals = load_models(n_queues)
+            sum(classify.dispatch_batches(iter(loaded[:2]), replicas, work))          # warm-up
             t0 = time.perf_counter()
-            done = sum(classify.dispatch_batches(iter(every), replicas, work))
+            done = sum(classify.dispatch_batches(iter(loaded * 3), replicas, work))
             gpu_rate = done / (time.perf_counter() - t0)
-
-            def stream():                   # containers loaded one ahead, as realtime does
-                box = []
-                worker = threading.Thread(target=load, args=(paths[0], box))
-                worker.start()
-                for k in range(opts.files):
-                    worker.join()
-                    container = box.pop()
-                    if k + 1 < opts.files:
-                        worker = threading.Thread(target=load, args=(paths[k + 1], box))
-                        worker.start()
-                    yield from batches_of(container)
-
-            t0 = time.perf_counter()
-            done = sum(classify.dispatch_batches(stream(), replicas, work))
-            both = done / (time.perf_counter() - t0)
-            per_devices['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
+            best = 0.0
+            for _ in range(2):
+                t0 = time.perf_counter()
+                stream = fast5_native.stream_reads(paths, keep=keep, threads=loader_team, depth=4)
+                done = sum(classify.dispatch_batches(stream, replicas, work))
+                best = max(best, done / (time.perf_counter() - t0))
+            assert done == total
+            per_queues['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
                 'gpu_side_alone_reads_per_s': round(gpu_rate),
                 'loader_alone_reads_per_s': round(loader_rate),
-                'load_and_classify_reads_per_s': round(both),
-                'bound_by': 'loader' if loader_rate < gpu_rate else 'gpu side (incl. its host work)'}
+                'load_and_classify_reads_per_s': round(best),
+                'bound_by': 'loader' if loader_rate < gpu_rate else 'gpu side'}
         os.environ.pop('DEEPBINNER_DEVICE_ORDINALS', None)
-        out['dispatcher (start + end models, scan 6144, batch 256, %d loader threads)' % threads] = \
-            per_devices
+        out['stream -> dispatcher -> dbh_classify_pair_i16 (start + end models, scan 6144, '
+            '%d loader threads)' % loader_team] = per_queues
+        # the GPU side without the host path: 24 windows per read at the resident kernel rate
+        out['note'] = ('GPU-resident ceiling for this workload: bench.py windows/s / 24 windows '
+                       'per read (two models x 12 scan steps)')
     print(json.dumps(out, indent=1))
 
 
