@@ -35,6 +35,8 @@ import sys
 import threading
 import zlib
 
+from .misc import usable_cpus
+
 UUID = re.compile(rb'[0-9a-fA-F]{8}-[0-9a-fA-F]{4}-[0-9a-fA-F]{4}-[0-9a-fA-F]{4}-[0-9a-fA-F]{12}')
 RECORD = {'fasta': re.compile(rb'([^\n]*\n)[^\n]*\n'),
           'fastq': re.compile(rb'([^\n]*\n)[^\n]*\n[^\n]*\n[^\n]*\n')}
@@ -259,7 +261,7 @@ def write_read_files(reads_filename, classifications, out_filenames, input_type,
     """Deals the records out; returns {class name: reads} (reference bin.py:101-153)."""
     by_id = {read_id.encode(): class_name(call) for read_id, call in classifications.items()}
     counts = collections.defaultdict(int)
-    workers = threads if threads > 0 else max(1, min(32, os.cpu_count() or 1))
+    workers = threads if threads > 0 else max(1, min(32, usable_cpus()))
     total, next_report = 0, 0
     with concurrent.futures.ThreadPoolExecutor(workers) as pool:
         sinks = {name: GzipSink(path + '.gz', pool) for name, path in out_filenames.items()}

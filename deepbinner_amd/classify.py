@@ -21,7 +21,7 @@ from . import hdf5_lite
 from .load_fast5s import (find_all_fast5s, get_read_id_and_signal,
                           determine_single_or_multi_fast5s, LoaderPool, choose_loader_procs,
                           reader_kind)
-from .misc import print_summary_table
+from .misc import print_summary_table, usable_cpus
 from .model_format import ModelWeights
 from .trim_signal import normalise
 
@@ -277,13 +277,13 @@ def load_in_batches(fast5_files, args):
 
 def _native_batches(fast5_files, args):
     """load_in_batches on the native loader (libdeepbinner_fast5.so): every batch is parsed and
-    inflated by the library's own worker threads (``--loader_procs`` of them; 0 = a quarter of
-    the host threads, at most 32), and the next batch is loaded on a background thread - the
+    inflated by the library's own worker threads (``--loader_procs`` of them; 0 = one per hardware
+    thread this process may keep busy - misc.usable_cpus - at most 32), and the next batch is loaded on a background thread - the
     call releases the GIL - while the caller classifies the current one."""
     from concurrent.futures import ThreadPoolExecutor
     from . import fast5_native
     keep = scanned_end_samples(args.scan_size)
-    threads = int(getattr(args, 'loader_procs', 0) or 0) or max(1, min(32, (os.cpu_count() or 4) // 4))
+    threads = int(getattr(args, 'loader_procs', 0) or 0) or max(1, min(32, usable_cpus()))
     batches = list(chunker(fast5_files, args.batch_size))
 
     def load(batch):

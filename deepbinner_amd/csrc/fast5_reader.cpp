@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1262,11 +1263,48 @@ class WorkerPool {
     bool stop_ = false;
 };
 
-// n_threads as the ABI takes it: <= 0 = one per hardware thread, at most 64; an explicit count is
-// honoured up to 256
+// How many hardware threads this process may really keep busy: the online CPUs, cut down to the
+// scheduler's affinity mask and to the cgroup's CPU quota (cpu.max of cgroup v2, cfs_quota_us of
+// v1).  A container that shows 256 CPUs with a quota of 16 runs a 128-thread team SLOWER than a
+// 16-thread one - every thread beyond the quota only adds throttling stalls
+// (profiles/r03_cpu_capacity.txt).
+int usable_cpus() {
+    static const int n = [] {
+        int cpus = (int)std::thread::hardware_concurrency();
+        if (cpus < 1) cpus = 1;
+        cpu_set_t mask;
+        if (sched_getaffinity(0, sizeof(mask), &mask) == 0) {
+            const int allowed = CPU_COUNT(&mask);
+            if (allowed > 0) cpus = std::min(cpus, allowed);
+        }
+        long long quota = -1, period = -1;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char first[32] = {0};
+            if (std::fscanf(f, "%31s %lld", first, &period) == 2 && std::strcmp(first, "max") != 0)
+                quota = std::atoll(first);
+            std::fclose(f);
+        } else {
+            if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(q, "%lld", &quota) != 1) quota = -1;
+                std::fclose(q);
+            }
+            if (FILE* p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(p, "%lld", &period) != 1) period = -1;
+                std::fclose(p);
+            }
+        }
+        if (quota > 0 && period > 0)
+            cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+        return cpus;
+    }();
+    return n;
+}
+
+// n_threads as the ABI takes it: <= 0 = one per usable hardware thread, at most 64; an explicit
+// count is honoured up to 256
 int thread_count(int n_threads) {
     if (n_threads > 0) return std::min(n_threads, 256);
-    return std::max(1, std::min((int)std::thread::hardware_concurrency(), 64));
+    return std::max(1, std::min(usable_cpus(), 64));
 }
 
 WorkerPool& worker_pool() {
@@ -1422,6 +1460,8 @@ struct f5_batch {
 extern "C" {
 
 const char* f5_version(void) { return "deepbinner_fast5 0.1"; }
+
+int f5_usable_cpus(void) { return usable_cpus(); }
 
 const char* f5_status_string(int status) {
     switch (status) {

@@ -23,7 +23,7 @@ F5_READ_ID_MAX = 64
 LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 
 EXPORTED_SYMBOLS = [
-    'f5_version', 'f5_status_string', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
+    'f5_version', 'f5_status_string', 'f5_usable_cpus', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
     'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_size', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
     'f5_batch_read_ids', 'f5_batch_free', 'f5_stream_open', 'f5_stream_next', 'f5_stream_close',
     'f5_set_sample_allocator', 'f5_release_idle_buffers',
@@ -58,6 +58,7 @@ def load_library():
     sigs = {
         'f5_version': (c_char_p, []),
         'f5_status_string': (c_char_p, [c_int]),
+        'f5_usable_cpus': (c_int, []),
         'f5_open': (c_int, [c_char_p, P(c_void_p)]),
         'f5_close': (None, [c_void_p]),
         'f5_layout': (c_int, [c_void_p, P(c_int), P(c_i64)]),
@@ -84,6 +85,11 @@ def load_library():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def usable_cpus():
+    """Hardware threads this process can keep busy (online CPUs, affinity mask, cgroup quota)."""
+    return int(load_library().f5_usable_cpus())
 
 
 def status_string(status):

@@ -161,7 +161,8 @@ def choose_loader_procs(requested, n_files):
         return int(requested)
     if n_files < 512:
         return 1
-    return max(1, min(8, (os.cpu_count() or 2) // 2))
+    from .misc import usable_cpus
+    return max(1, min(8, usable_cpus() // 2))
 
 
 def find_all_fast5s(directory, verbose=False):

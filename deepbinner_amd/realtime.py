@@ -28,7 +28,7 @@ import time
 
 from . import classify
 from .load_fast5s import determine_single_or_multi_fast5s, iter_reads, reader_kind
-from .misc import print_summary_table
+from .misc import print_summary_table, usable_cpus
 
 POLL_SECONDS = 5
 PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
@@ -223,7 +223,7 @@ class Session:
         from concurrent.futures import ThreadPoolExecutor
         from .hdf5_write import write_single_read_fast5
         calls, done, written = {}, 0, 0
-        n_writers = min(16, os.cpu_count() or 4)
+        n_writers = min(16, usable_cpus())
         writers = ThreadPoolExecutor(max_workers=n_writers,
                                      thread_name_prefix='deepbinner-fast5-writer')
         # at most this many reads wait to be written (each holds its signal - and with it the

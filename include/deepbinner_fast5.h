@@ -50,6 +50,9 @@ typedef struct f5_file f5_file;
 
 const char* f5_version(void);
 const char* f5_status_string(int status);
+/* Hardware threads this process can keep busy: online CPUs, affinity mask and cgroup CPU quota
+ * taken together - what "one thread per hardware thread" (n_threads <= 0) means below. */
+int f5_usable_cpus(void);
 
 int f5_open(const char* path, f5_file** out);
 void f5_close(f5_file* file);
@@ -60,8 +63,8 @@ int f5_read_info(f5_file* file, int64_t index, char read_id[F5_READ_ID_MAX], int
 /* Samples [first, first + count) of read `index`; only the chunks that overlap are inflated. */
 int f5_read_signal(f5_file* file, int64_t index, int64_t first, int64_t count, int16_t* out);
 
-/* One-read files -> packed signals, loaded by `n_threads` worker threads (<= 0: one per hardware
- * thread, at most 64; an explicit count is honoured up to 256).  keep > 0: reads longer than
+/* One-read files -> packed signals, loaded by `n_threads` worker threads (<= 0: one per usable
+ * hardware thread, at most 64; an explicit count is honoured up to 256).  keep > 0: reads longer than
  * 2*keep contribute their first and last `keep` samples only (windows are cut from those:
  * reference classify.py:337-349); keep <= 0: whole reads.  Read i occupies
  * samples[offsets[i] .. offsets[i+1]); a file that could not be read has status != F5_OK, an

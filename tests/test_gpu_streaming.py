@@ -39,10 +39,7 @@ def reference_final_calls(gold, mode='require_either'):
     ids = gold['read_ids'] + gold['multi_read_ids']
     starts = gold['calls'][START + '/start']
     ends = gold['calls'][END + '/end']
-    args = argparse.Namespace(require_either=mode == 'require_either',
-                              require_start=mode == 'require_start',
-                              require_both=mode == 'require_both')
-    return {rid: classify_ref.combine_calls(s, e, args) for rid, s, e in zip(ids, starts, ends)}
+    return {rid: classify_ref.combine_calls(s, e, mode) for rid, s, e in zip(ids, starts, ends)}
 
 
 @pytest.mark.parametrize('mode', ['require_either', 'require_start', 'require_both'])
@@ -59,10 +56,7 @@ def test_pair_entry_point_is_the_two_models_and_combine_calls(hip, hip_models, g
     ids = gold['read_ids'] + gold['multi_read_ids']
     s_probs, s_calls = start.classify_packed(samples, offsets, 'start', 6144, 0.5)
     e_probs, e_calls = end.classify_packed(samples, offsets, 'end', 6144, 0.5)
-    combine = argparse.Namespace(require_either=mode == 'require_either',
-                                 require_start=mode == 'require_start',
-                                 require_both=mode == 'require_both')
-    expected = [classify_ref.combine_calls(s, e, combine)
+    expected = [classify_ref.combine_calls(s, e, mode)
                 for s, e in zip(names(s_calls), names(e_calls))]
     assert expected[:37] == [want[rid] for rid in ids]
 
