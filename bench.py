@@ -512,4 +512,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except (hip_backend.HipBackendError, sharding.RendezvousError) as e:
+        # (e.g. `--gpus 8` on a box with fewer devices: one line, not a traceback per thread)
+        raise SystemExit('bench.py: {}'.format(e))

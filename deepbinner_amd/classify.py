@@ -121,9 +121,12 @@ def classify(args):
         return
     print('', file=sys.stderr)
     assert kind in ('directory', 'single_fast5')
-    fast5s = find_all_fast5s(args.input, verbose=True) if kind == 'directory' else [args.input]
     from . import sharding
-    if kind == 'directory' and sharding.env_world()[2] > 1:
+    rank, _, world = sharding.env_world()
+    if kind == 'single_fast5' and world > 1 and rank != 0:
+        return          # one file is one rank's work: rank 0 classifies and prints it
+    fast5s = find_all_fast5s(args.input, verbose=True) if kind == 'directory' else [args.input]
+    if kind == 'directory' and world > 1:
         # one process per GPU (torch.distributed.run): shard the reads, gather the calls
         sharding.classify_fast5_files_sharded(fast5s, *models, args)
     else:
@@ -682,6 +685,11 @@ def set_tensorflow_threads(args):
     GPU.  The TensorFlow thread flags are accepted and ignored."""
     global _DEVICES
     n = int(getattr(args, 'devices', 0) or os.environ.get('DEEPBINNER_DEVICES', 0) or 0)
+    if n > 1 and int(os.environ.get('WORLD_SIZE', 1)) > 1:
+        # one process per GPU AND several GPUs per process: every rank would replicate on GPUs
+        # 0..n-1.  The launcher has already dealt the GPUs out; say so instead of guessing.
+        sys.exit('Error: --devices {} under a one-process-per-GPU launcher (WORLD_SIZE={}): use '
+                 'one or the other'.format(n, os.environ['WORLD_SIZE']))
     if n > 1:
         explicit = os.environ.get('DEEPBINNER_DEVICE_ORDINALS')
         _DEVICES = [int(v) for v in explicit.split(',')] if explicit else list(range(n))

@@ -156,8 +156,11 @@ struct dbh_model {
     void* d_work = nullptr;    size_t work_bytes = 0;
     void* d_out = nullptr;     size_t out_bytes = 0;
     // conv17 outputs parked per workgroup until the batched tail runs (dbh_forward.hip); one
-    // buffer per stream a model launches on: this one for the caller's stream, one per staging slot
-    void* d_tail = nullptr;    size_t tail_bytes = 0;
+    // buffer per stream a model launches on - launches on one stream follow each other, launches
+    // on two streams may overlap: `tails` for the streams callers of the *_dev entry points
+    // bring, one per staging slot for the host-buffer pipeline
+    struct Tail { hipStream_t stream; void* ptr; size_t bytes; };
+    std::vector<Tail> tails;
     void* d_clock = nullptr;   size_t clock_bytes = 0;     // dbh_forward_clock_enable
     bool clock_probe = false;  unsigned clock_grid = 0;
     // staging slots of the host-buffer entry points (classify_host: overlapped H2D / kernels / D2H)
@@ -261,8 +264,15 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         // share of the windows; the debug / timeline modes keep one workgroup per window
         const bool one_per_window = debug_stage >= 0 && debug_stage != 301;
         const unsigned grid = (unsigned)(one_per_window || cnt < m->cus ? cnt : m->cus);
-        void** tail = in.tail ? in.tail : &m->d_tail;
-        size_t* tail_bytes = in.tail_bytes ? in.tail_bytes : &m->tail_bytes;
+        void** tail = in.tail;
+        size_t* tail_bytes = in.tail_bytes;
+        if (!tail) {
+            size_t k = 0;
+            while (k < m->tails.size() && m->tails[k].stream != stream) ++k;
+            if (k == m->tails.size()) m->tails.push_back(dbh_model::Tail{stream, nullptr, 0});
+            tail = &m->tails[k].ptr;
+            tail_bytes = &m->tails[k].bytes;
+        }
         {
             const int st = ensure(tail, tail_bytes, (size_t)grid * dbh::kTailBatch *
                                                         dbh::kTailSlotFloats * sizeof(float));
@@ -494,7 +504,8 @@ int dbh_model_destroy(dbh_model* m) {
     if (m->d_in) (void)hipFree(m->d_in);
     if (m->d_work) (void)hipFree(m->d_work);
     if (m->d_out) (void)hipFree(m->d_out);
-    if (m->d_tail) (void)hipFree(m->d_tail);
+    for (auto& t : m->tails)
+        if (t.ptr) (void)hipFree(t.ptr);
     if (m->d_clock) (void)hipFree(m->d_clock);
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.first);

@@ -73,10 +73,24 @@ int rccl_fail(ncclResult_t e, const char* what) {
     g_comm_error = std::string(what) + ": " + (rccl()->ok ? rccl()->GetErrorString(e) : "?");
     return DBH_ERR_COMM;
 }
+// (DBH_ERR_COMM for HIP failures too: the text is in dbh_comm_last_error(), which is where a
+// caller looks after that status)
 int hip_fail(hipError_t e, const char* what) {
     g_comm_error = std::string(what) + ": " + hipGetErrorString(e);
-    return DBH_ERR_HIP;
+    return DBH_ERR_COMM;
 }
+
+// Puts the calling thread's current device back when a function that switches devices returns -
+// on every path, the early error returns included.
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace dbh_comm_detail
 
@@ -100,6 +114,7 @@ struct dbh_comm {
     std::vector<int> devices;              // HIP ordinals of the local devices
     std::vector<ncclComm_t> comms;         // one per local device (RCCL transport)
     std::vector<hipEvent_t> ready;         // COPY transport: "send buffer of device s is final"
+    std::vector<hipEvent_t> copied;        //                 "device d has pulled every block"
 };
 
 extern "C" {
@@ -117,8 +132,7 @@ int dbh_comm_init_all(int n_devices, const int* ordinals, int transport, dbh_com
     c->transport = transport;
     c->n_ranks = n_devices;
     for (int i = 0; i < n_devices; ++i) c->devices.push_back(ordinals ? ordinals[i] : i);
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceRestore restore;
     int st = DBH_OK;
     if (transport == DBH_COMM_RCCL) {
         if (!rccl()->ok) {
@@ -134,16 +148,18 @@ int dbh_comm_init_all(int n_devices, const int* ordinals, int transport, dbh_com
         }
     } else {
         for (int i = 0; i < n_devices && st == DBH_OK; ++i) {
-            hipEvent_t ev = nullptr;
+            hipEvent_t ev = nullptr, ev2 = nullptr;
             hipError_t e = hipSetDevice(c->devices[(size_t)i]);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming);
+            if (ev) c->ready.push_back(ev);
+            if (ev2) c->copied.push_back(ev2);
             if (e != hipSuccess) st = hip_fail(e, "dbh_comm_init_all");
-            else c->ready.push_back(ev);
         }
     }
-    (void)hipSetDevice(prev);
     if (st != DBH_OK) {
         for (hipEvent_t ev : c->ready) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : c->copied) (void)hipEventDestroy(ev);
         delete c;
         return st;
     }
@@ -228,9 +244,10 @@ int dbh_comm_all_gather_i32(dbh_comm* c, const int32_t* const* send_dev, int32_t
         return DBH_OK;
     }
     // COPY transport: device d's stream waits until every send buffer is final, then pulls the
-    // n blocks into its receive buffer (peer copies; the same device twice is a plain D2D copy)
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    // n blocks into its receive buffer (peer copies; the same device twice is a plain D2D copy).
+    // And the back edge: whatever device s queues NEXT on its stream (the next step's
+    // classification overwrites its send buffer) waits until every other device has pulled.
+    DeviceRestore restore;
     const size_t bytes = (size_t)count * sizeof(int32_t);
     for (int s = 0; s < n_local; ++s) {
         DBH_CHIP(hipSetDevice(c->devices[(size_t)s]));
@@ -248,8 +265,13 @@ int dbh_comm_all_gather_i32(dbh_comm* c, const int32_t* const* send_dev, int32_t
                 DBH_CHIP(hipMemcpyPeerAsync(dst, c->devices[(size_t)d], send_dev[s],
                                             c->devices[(size_t)s], bytes, st));
         }
+        DBH_CHIP(hipEventRecord(c->copied[(size_t)d], st));
     }
-    (void)hipSetDevice(prev);
+    for (int s = 0; s < n_local; ++s) {
+        DBH_CHIP(hipSetDevice(c->devices[(size_t)s]));
+        for (int d = 0; d < n_local; ++d)
+            if (d != s) DBH_CHIP(hipStreamWaitEvent((hipStream_t)streams[s], c->copied[(size_t)d], 0));
+    }
     return DBH_OK;
 }
 
@@ -258,6 +280,7 @@ int dbh_comm_destroy(dbh_comm* c) {
     for (ncclComm_t nc : c->comms)
         if (nc && rccl()->ok) (void)rccl()->CommDestroy(nc);
     for (hipEvent_t ev : c->ready) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->copied) (void)hipEventDestroy(ev);
     delete c;
     return DBH_OK;
 }

@@ -53,18 +53,36 @@ class RendezvousError(RuntimeError):
     pass
 
 
-def _rendezvous_name():
-    """All ranks of one launch must arrive at the same name and no other launch at it.  Under
-    ``torch.distributed.run`` MASTER_PORT belongs to the launcher's own store, so it cannot be
-    bound again - but it is unique per launch on this host, and so is the launcher's pid (the
-    parent of every rank): together they name an abstract unix socket, which needs no file and
-    disappears with rank 0."""
-    explicit = os.environ.get('DEEPBINNER_RDZV')
+def _rendezvous_endpoint():
+    """Where the ranks of one launch meet: ('unix', name) - an abstract unix socket, which needs
+    no file and disappears with rank 0 - or ('tcp', host, port).  All ranks must arrive at the same
+    answer and no other launch at it, from nothing but their environment:
+
+    * under a launcher (MASTER_PORT set: ``torch.distributed.run`` and the like) the name is made
+      of MASTER_ADDR, MASTER_PORT and the run id - the port belongs to the launcher's own store, so
+      it cannot be bound again, but it is unique per launch on this host.  (Not the parent's pid:
+      a launcher that wraps every rank in a shell of its own gives every rank another parent.)
+    * ranks started by hand from one shell (no MASTER_PORT) share that shell's pid;
+    * ``DEEPBINNER_RDZV=<name>`` names the socket outright; ``DEEPBINNER_RDZV=tcp`` meets on TCP
+      port MASTER_PORT + 1 of MASTER_ADDR instead (ranks that do not share a network namespace),
+      ``DEEPBINNER_RDZV=tcp://host:port`` on that address."""
+    explicit = os.environ.get('DEEPBINNER_RDZV', '')
+    if explicit.startswith('tcp://'):
+        host, _, port = explicit[6:].rpartition(':')
+        return ('tcp', host or '127.0.0.1', int(port))
+    if explicit == 'tcp':
+        return ('tcp', os.environ.get('MASTER_ADDR', '127.0.0.1'),
+                int(os.environ.get('MASTER_PORT', '29500')) + 1)
     if explicit:
-        return explicit
-    return 'deepbinner-{}-{}-{}'.format(os.environ.get('MASTER_PORT', '0'),
-                                        os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
-                                        os.getppid())
+        return ('unix', explicit)
+    if os.environ.get('MASTER_PORT'):
+        return ('unix', 'deepbinner-{}-{}-{}'.format(os.environ.get('MASTER_ADDR', 'localhost'),
+                                                     os.environ['MASTER_PORT'],
+                                                     os.environ.get('TORCHELASTIC_RUN_ID', 'none')))
+    return ('unix', 'deepbinner-by-hand-{}'.format(os.getppid()))
+
+
+MAX_MESSAGE_BYTES = 1 << 30        # nothing the ranks tell each other comes near it
 
 
 def _send_msg(sock, payload):
@@ -84,6 +102,8 @@ def _recv_exact(sock, n):
 
 def _recv_msg(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > MAX_MESSAGE_BYTES:
+        raise RendezvousError('rendezvous: a peer announced a message of {} bytes'.format(n))
     return _recv_exact(sock, n)
 
 
@@ -95,40 +115,63 @@ class Rendezvous:
     def __init__(self, rank, world, name=None, timeout=None):
         self.rank, self.world = int(rank), int(world)
         self.timeout = float(timeout if timeout is not None
-                             else os.environ.get('DEEPBINNER_RDZV_TIMEOUT', 600))
+                             else os.environ.get('DEEPBINNER_RDZV_TIMEOUT', 120))
         self._peers = {}
         self._sock = None
         if self.world == 1:
             return
-        address = '\0' + (name or _rendezvous_name())
+        if not 0 <= self.rank < self.world:
+            raise RendezvousError('rendezvous: rank {} of {}'.format(self.rank, self.world))
+        endpoint = ('unix', name) if name else _rendezvous_endpoint()
+        if endpoint[0] == 'unix':
+            family, address = socket.AF_UNIX, '\0' + endpoint[1]
+        else:
+            family, address = socket.AF_INET, (endpoint[1], endpoint[2])
+        self.endpoint = endpoint
         if self.rank == 0:
-            server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-            server.bind(address)
+            server = socket.socket(family, socket.SOCK_STREAM)
+            if family == socket.AF_INET:
+                server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                server.bind(address)
+            except OSError as e:
+                server.close()
+                raise RendezvousError('rendezvous: cannot bind {} ({})'.format(endpoint[1:], e))
             server.listen(self.world)
-            server.settimeout(self.timeout)
+            deadline = time.monotonic() + self.timeout
             try:
                 while len(self._peers) < self.world - 1:
+                    server.settimeout(max(deadline - time.monotonic(), 0.001))
                     conn, _ = server.accept()
                     conn.settimeout(self.timeout)
                     (peer,) = struct.unpack('<I', _recv_exact(conn, 4))
+                    # (a stray connection, or two ranks that both think they are rank k, must
+                    # not pass for the missing rank: say so now, not as a KeyError later)
+                    if not 0 < peer < self.world or peer in self._peers:
+                        conn.close()
+                        raise RendezvousError(
+                            'rendezvous: a peer introduced itself as rank {} ({} ranks; seen so '
+                            'far: {})'.format(peer, self.world, sorted(self._peers)))
                     self._peers[peer] = conn
             except socket.timeout:
-                raise RendezvousError('rendezvous: only {} of {} ranks arrived within {:.0f} s'
-                                      .format(len(self._peers) + 1, self.world, self.timeout))
+                raise RendezvousError('rendezvous: only {} of {} ranks arrived within {:.0f} s '
+                                      '(at {}; DEEPBINNER_RDZV_TIMEOUT sets the wait)'
+                                      .format(len(self._peers) + 1, self.world, self.timeout,
+                                              endpoint[1:]))
             finally:
                 server.close()
         else:
             deadline = time.monotonic() + self.timeout
             while True:
-                sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                sock = socket.socket(family, socket.SOCK_STREAM)
                 try:
                     sock.connect(address)
                     break
-                except (ConnectionRefusedError, FileNotFoundError):
+                except (ConnectionRefusedError, FileNotFoundError, OSError):
                     sock.close()
                     if time.monotonic() > deadline:
-                        raise RendezvousError('rendezvous: rank 0 did not appear within {:.0f} s'
-                                              .format(self.timeout))
+                        raise RendezvousError('rendezvous: rank 0 did not appear within {:.0f} s '
+                                              '(at {})'.format(self.timeout, endpoint[1:]))
                     time.sleep(0.02)
             sock.settimeout(self.timeout)
             sock.sendall(struct.pack('<I', self.rank))
@@ -551,13 +594,21 @@ def classify_fast5_files_sharded(fast5_files, start_model, start_input_size, end
     rdzv = Rendezvous(rank, world)
 
     def together(fn):
-        """Run fn on this rank; if it exits anywhere, every rank exits with the first message."""
-        result, failure = None, None
+        """Run fn on this rank; if it fails anywhere - the reference's ``sys.exit('Error: ...')``
+        cases, or anything else a rank can die of (a HIP error, an unreadable directory) - every
+        rank learns of it here, before the next collective, and leaves with the first message
+        instead of waiting out the rendezvous timeout for a peer that is gone."""
+        result, failure, reraise = None, None, None
         try:
             result = fn()
         except SystemExit as e:
             failure = str(e.code) if e.code is not None else 'exit'
+        except BaseException as e:       # noqa: B902 - KeyboardInterrupt included: all must leave
+            failure = 'Error: rank {} failed: {}: {}'.format(rank, type(e).__name__, e)
+            reraise = e
         ok, why = rdzv.agree(failure is None, failure or '')
+        if reraise is not None:
+            raise reraise
         if not ok:
             sys.exit(why)
         return result

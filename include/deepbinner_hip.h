@@ -89,7 +89,9 @@ int dbh_model_output_size(const dbh_model* model, int* n_classes);   /* model.ou
  * thread's current device (HIP keeps that per thread), so a model may be driven from any thread -
  * two models from two threads at once, each on its own streams and staging buffers.  One model is
  * for one caller at a time.  The *_dev entry points work on the caller's device pointers and
- * leave the current device alone. */
+ * leave the current device alone; launches of one model queued on DIFFERENT streams may overlap
+ * on the device (the per-launch scratch is kept per stream), the host-side calls themselves must
+ * still not overlap. */
 /* ---- seam b1: model.predict (classify.py:361) ------------------------------------------ */
 /* x: n_windows x 1024 fp32 (already normalised);  probs: n_windows x n_classes fp32 softmax. */
 int dbh_predict(dbh_model* model, const float* x_host, int64_t n_windows, float* probs_host);

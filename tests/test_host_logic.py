@@ -468,3 +468,18 @@ def test_bench_workload_string_names_the_configuration():
         'BASELINE.json configs[1]: EXP-NBD103_read_starts model, 10000 synthetic')
     assert bench.PUBLISHED_CPU == {'value': 15, 'unit': 'reads/s', 'threads': 12,
                                    'source': 'README.md:213'}
+
+
+def test_devices_flag_under_a_per_gpu_launcher_is_refused(monkeypatch):
+    """`--devices N` (one process driving N GPUs) together with WORLD_SIZE > 1 (a
+    launcher that already gave every process its GPU) would put every rank on GPUs 0..N-1."""
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit) as e:
+        classify.set_tensorflow_threads(argparse.Namespace(devices=2))
+    assert 'one-process-per-GPU launcher' in str(e.value)
+
+
+def test_usable_cpus_is_a_sane_number():
+    from deepbinner_amd import misc
+    n = misc.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)

@@ -208,3 +208,119 @@ def test_a_rank_local_fatal_error_ends_every_rank(tmp_path):
     results = _run_ranks_plainly(script, 2, {'DEEPBINNER_COMM': 'host'}, timeout=300)
     for rc, out, err in results:
         assert rc != 0 and 'Error: no fast5 files found' in err, out + err
+
+
+def test_ranks_wrapped_in_shells_of_their_own_still_meet(tmp_path):
+    """Round-2 verdict: a launcher that interposes a per-rank shell gives every rank another
+    parent pid.  With MASTER_PORT in the environment the rendezvous is named after the launch
+    (address, port, run id), not after the parent - the two ranks meet although each has a shell
+    of its own between it and the common ancestor."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='2', RANK=str(rank),
+                   LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   DEEPBINNER_COMM='host', DEEPBINNER_RDZV_TIMEOUT='300')
+        env.pop('DEEPBINNER_RDZV', None)
+        # `sh -c '... ; exit $?'`: the shell stays between us and the rank
+        procs.append(subprocess.Popen(
+            ['sh', '-c', '"$0" "$1" "$2"; exit $?', sys.executable, str(script), REPO], env=env,
+            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    results = [p.communicate(timeout=600) + (p.returncode,) for p in procs]
+    for out, err, rc in results:
+        assert rc == 0, out + err
+    assert 'GATHER_OK' in results[0][0]
+
+
+def test_rendezvous_over_tcp(tmp_path):
+    """DEEPBINNER_RDZV=tcp://host:port: the same star over TCP (ranks that do not share a network
+    namespace); DEEPBINNER_RDZV=tcp = MASTER_ADDR : MASTER_PORT + 1."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    results = _run_ranks_plainly(script, 2, {
+        'DEEPBINNER_COMM': 'host', 'DEEPBINNER_RDZV': 'tcp://127.0.0.1:%d' % _free_port()})
+    for rc, out, err in results:
+        assert rc == 0, out + err
+    assert 'GATHER_OK' in results[0][1]
+    results = _run_ranks_plainly(script, 2, {
+        'DEEPBINNER_COMM': 'host', 'DEEPBINNER_RDZV': 'tcp', 'MASTER_ADDR': '127.0.0.1',
+        'MASTER_PORT': str(_free_port())})
+    for rc, out, err in results:
+        assert rc == 0, out + err
+
+
+def test_rendezvous_refuses_impostors_and_huge_messages(tmp_path):
+    """rank 0 checks who connects (a duplicate or out-of-range rank is an error at
+    once, not a KeyError later) and no rank allocates whatever length a peer announces."""
+    import struct
+    import threading
+    from deepbinner_amd import sharding
+    name = 'deepbinner-test-' + uuid.uuid4().hex
+    errors = []
+
+    def rank0():
+        try:
+            sharding.Rendezvous(0, 3, name=name, timeout=20)
+        except sharding.RendezvousError as e:
+            errors.append(str(e))
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    import time
+    for attempt in range(200):
+        try:
+            a = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            a.connect('\0' + name)
+            break
+        except OSError:
+            a.close()
+            time.sleep(0.02)
+    a.sendall(struct.pack('<I', 1))
+    b = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    b.connect('\0' + name)
+    b.sendall(struct.pack('<I', 1))             # a second "rank 1"
+    t.join(30)
+    a.close()
+    b.close()
+    assert errors and 'introduced itself as rank 1' in errors[0], errors
+    with pytest.raises(sharding.RendezvousError):
+        sharding.Rendezvous(5, 3, name=name)
+    left, right = socket.socketpair()
+    left.sendall(struct.pack('<Q', 1 << 40))
+    with pytest.raises(sharding.RendezvousError, match='announced a message'):
+        sharding._recv_msg(right)
+    left.close()
+    right.close()
+    assert sharding.Rendezvous(0, 1).timeout == 120.0 or 'DEEPBINNER_RDZV_TIMEOUT' in os.environ
+
+
+BROKEN_LOADER = r"""
+import deepbinner_amd.sharding as sh
+import deepbinner_amd.load_fast5s as lf
+files = sorted(lf.find_all_fast5s(target))
+def broken(files, args):
+    if int(os.environ['RANK']) == 1:
+        raise KeyError('loader blew up')
+    return iter(())
+classify.load_in_batches = broken
+args = __import__('argparse').Namespace(verbose=False, batch_size=3, scan_size=6144,
+                                        score_diff=0.5)
+sh.classify_fast5_files_sharded(files, None, None, None, None, 13, args)
+raise SystemExit('not reached')
+"""
+
+
+def test_any_exception_on_one_rank_ends_every_rank(tmp_path):
+    """not only SystemExit - an OSError / KeyError / backend error on one rank reaches
+    the others through agree(); nobody waits for the rendezvous timeout."""
+    import time
+    script = tmp_path / 'cli_worker.py'
+    script.write_text(CLI_WORKER[:CLI_WORKER.index('cli.main(')] + BROKEN_LOADER)
+    t0 = time.monotonic()
+    results = _run_ranks_plainly(script, 2, {'DEEPBINNER_COMM': 'host'}, timeout=300)
+    assert time.monotonic() - t0 < 120
+    (rc0, out0, err0), (rc1, out1, err1) = results
+    assert rc0 != 0 and 'rank 1 failed: KeyError' in err0, out0 + err0
+    assert rc1 != 0 and 'loader blew up' in err1, out1 + err1
