@@ -161,6 +161,7 @@ struct dbh_model {
     // bring, one per staging slot for the host-buffer pipeline
     struct Tail { hipStream_t stream; void* ptr; size_t bytes; };
     std::vector<Tail> tails;
+    void* d_tail = nullptr;    size_t tail_bytes = 0;      // the timeline entry points' (null stream)
     void* d_clock = nullptr;   size_t clock_bytes = 0;     // dbh_forward_clock_enable
     bool clock_probe = false;  unsigned clock_grid = 0;
     // staging slots of the host-buffer entry points (classify_host: overlapped H2D / kernels / D2H)
@@ -506,6 +507,7 @@ int dbh_model_destroy(dbh_model* m) {
     if (m->d_out) (void)hipFree(m->d_out);
     for (auto& t : m->tails)
         if (t.ptr) (void)hipFree(t.ptr);
+    if (m->d_tail) (void)hipFree(m->d_tail);
     if (m->d_clock) (void)hipFree(m->d_clock);
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.first);
