@@ -177,6 +177,19 @@ struct dbh_model {
         void* d_work = nullptr; size_t d_work_bytes = 0;
         void* d_tail = nullptr; size_t d_tail_bytes = 0;
     } slot[kSlots];
+    // buffers of dbh_classify_pair_deflated (the start model's, or the only model's, are used)
+    struct Deflated {
+        hipStream_t stream = nullptr;
+        void* h_small = nullptr;  size_t h_small_bytes = 0;     // pinned: records, offsets, results
+        void* h_comp = nullptr;   size_t h_comp_bytes = 0;      // pinned staging for pageable input
+        void* d_comp = nullptr;   size_t d_comp_bytes = 0;
+        void* d_small = nullptr;  size_t d_small_bytes = 0;
+        void* d_samples = nullptr; size_t d_samples_bytes = 0;
+        void* d_tokens = nullptr; size_t d_tokens_bytes = 0;
+        void* d_out = nullptr;    size_t d_out_bytes = 0;
+        void* d_work = nullptr;   size_t d_work_bytes = 0;
+        void* d_tail = nullptr;   size_t d_tail_bytes = 0;
+    } deflated;
     // live timing of the forward kernel (dbh_forward_timing_*)
     int64_t hint_len = 0, hint_cap = 0;   // dbh_model_set_read_length_hint
     int timing = 0;              // 0 = off, n = open an event bracket at every n-th forward launch
@@ -512,6 +525,14 @@ int dbh_model_destroy(dbh_model* m) {
     for (auto& ev : m->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
+    }
+    {
+        dbh_model::Deflated& d = m->deflated;
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.h_small) (void)hipHostFree(d.h_small);
+        if (d.h_comp) (void)hipHostFree(d.h_comp);
+        for (void* p : {d.d_comp, d.d_small, d.d_samples, d.d_tokens, d.d_out, d.d_work, d.d_tail})
+            if (p) (void)hipFree(p);
     }
     for (auto& sl : m->slot) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -985,6 +1006,141 @@ int dbh_classify_pair_i16(dbh_model* start_model, dbh_model* end_model,
             std::memcpy(calls_host, side_calls, (size_t)n_reads * sizeof(int32_t));
     }
     return st;
+}
+
+int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
+                               const uint8_t* comp_host, int64_t comp_bytes,
+                               const dbh_inflate_stream* streams_host, int64_t n_streams,
+                               const int64_t* offsets_host, int64_t n_reads, int scan_size,
+                               double score_diff, int combine_mode, int32_t* calls_host,
+                               int32_t* stream_status_host, int16_t* samples_host,
+                               double* stage_ms) {
+    dbh_model* m = start_model ? start_model : end_model;
+    if (!m || n_reads < 0 || n_streams < 0 || comp_bytes < 0 ||
+        combine_mode < DBH_REQUIRE_EITHER || combine_mode > DBH_REQUIRE_BOTH)
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_reads == 0) return DBH_OK;
+    if (!offsets_host || !calls_host || (n_streams > 0 && (!streams_host || !comp_host)))
+        return DBH_ERR_INVALID_ARGUMENT;
+    const bool both = start_model && end_model;
+    if (both && (start_model->device != end_model->device ||
+                 start_model->n_classes != end_model->n_classes))
+        return DBH_ERR_INVALID_ARGUMENT;
+    const int steps = steps_for(scan_size);
+    if (steps <= 0 || steps * (dbh::kWindow / 2) != scan_size) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t total_samples = offsets_host[n_reads] - offsets_host[0];
+    if (offsets_host[0] != 0 || total_samples < 0) return DBH_ERR_INVALID_ARGUMENT;
+    const int64_t out_bytes = total_samples * 2;
+    for (int64_t i = 0; i < n_streams; ++i) {
+        const dbh_inflate_stream& r = streams_host[i];
+        if (r.comp_offset < 0 || r.comp_bytes < 0 || r.out_offset < 0 || r.out_bytes < 0 ||
+            (r.out_offset & 1) || r.comp_offset + r.comp_bytes > comp_bytes ||
+            r.out_offset + r.out_bytes > out_bytes)
+            return DBH_ERR_INVALID_ARGUMENT;
+    }
+    DBH_HIP(hipSetDevice(m->device));
+    dbh_model::Deflated& d = m->deflated;
+    if (!d.stream) DBH_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    const int C = m->n_classes;
+    // small things travel together: [records | offsets] in, [status | final calls | side calls] out
+    const size_t rec_bytes = ((size_t)n_streams * sizeof(dbh_inflate_stream) + 255) & ~(size_t)255;
+    const size_t off_bytes = ((size_t)(n_reads + 1) * sizeof(int64_t) + 255) & ~(size_t)255;
+    const size_t status_bytes = ((size_t)n_streams * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t calls_bytes = ((size_t)n_reads * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t in_small = rec_bytes + off_bytes;
+    const size_t out_small = status_bytes + 3 * calls_bytes;
+    const size_t probs_bytes = (size_t)n_reads * C * sizeof(float);
+    size_t token_bytes = 0, work = 0;
+    int st = dbh_inflate_workspace_bytes(out_bytes, n_streams, &token_bytes);
+    if (st == DBH_OK) st = dbh_classify_workspace_bytes(m, n_reads, scan_size, &work);
+    if (st == DBH_OK) st = ensure_host(&d.h_small, &d.h_small_bytes, in_small + out_small);
+    if (st == DBH_OK) st = ensure(&d.d_small, &d.d_small_bytes, in_small + out_small);
+    if (st == DBH_OK) st = ensure(&d.d_comp, &d.d_comp_bytes, (size_t)comp_bytes + 64);
+    if (st == DBH_OK) st = ensure(&d.d_samples, &d.d_samples_bytes, (size_t)out_bytes + 256);
+    if (st == DBH_OK) st = ensure(&d.d_tokens, &d.d_tokens_bytes, token_bytes);
+    if (st == DBH_OK) st = ensure(&d.d_out, &d.d_out_bytes, 2 * probs_bytes + 256);
+    if (st == DBH_OK && work) st = ensure(&d.d_work, &d.d_work_bytes, work);
+    if (st != DBH_OK) return st;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (stage_ms)
+        for (hipEvent_t& e : ev) DBH_HIP(hipEventCreate(&e));
+    auto done = [&](int status) -> int {
+        (void)hipStreamSynchronize(d.stream);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        return status;
+    };
+    char* h = (char*)d.h_small;
+    if (n_streams) std::memcpy(h, streams_host, (size_t)n_streams * sizeof(dbh_inflate_stream));
+    std::memcpy(h + rec_bytes, offsets_host, (size_t)(n_reads + 1) * sizeof(int64_t));
+    char* ds = (char*)d.d_small;
+    const dbh_inflate_stream* d_records = (const dbh_inflate_stream*)ds;
+    const int64_t* d_offsets = (const int64_t*)(ds + rec_bytes);
+    int32_t* d_status = (int32_t*)(ds + in_small);
+    int32_t* d_final = (int32_t*)(ds + in_small + status_bytes);
+    int32_t* d_side[2] = {(int32_t*)(ds + in_small + status_bytes + calls_bytes),
+                          (int32_t*)(ds + in_small + status_bytes + 2 * calls_bytes)};
+    if (ev[0]) (void)hipEventRecord(ev[0], d.stream);
+    hipError_t e = hipMemcpyAsync(ds, h, in_small, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess && comp_bytes > 0) {
+        const void* src = comp_host;
+        // the decoder fetches up to 64 bytes beyond the last stream: the loader's buffers carry
+        // them; a pageable buffer is staged (and padded) first
+        if (!is_pinned(comp_host, (size_t)comp_bytes + 64)) {
+            st = ensure_host(&d.h_comp, &d.h_comp_bytes, (size_t)comp_bytes + 64);
+            if (st != DBH_OK) return done(st);
+            staged_copy(d.h_comp, comp_host, (size_t)comp_bytes);
+            std::memset((char*)d.h_comp + comp_bytes, 0, 64);
+            src = d.h_comp;
+        }
+        e = hipMemcpyAsync(d.d_comp, src, (size_t)comp_bytes + 64, hipMemcpyHostToDevice, d.stream);
+    }
+    if (e != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync H2D"));
+    if (ev[1]) (void)hipEventRecord(ev[1], d.stream);
+    // a read without a piece (nothing stored, or nothing readable) must still be zeros
+    if (out_bytes > 0) {
+        e = hipMemsetAsync(d.d_samples, 0, (size_t)out_bytes, d.stream);
+        if (e != hipSuccess) return done(hip_fail(e, "hipMemsetAsync"));
+    }
+    if (n_streams > 0) {
+        st = dbh_inflate_dev((const uint8_t*)d.d_comp, d_records, n_streams, out_bytes,
+                             (uint8_t*)d.d_samples, d.d_tokens, d_status, (dbh_stream)d.stream);
+        if (st != DBH_OK) return done(st);
+    }
+    if (ev[2]) (void)hipEventRecord(ev[2], d.stream);
+    dbh_model* models[2] = {start_model, end_model};
+    for (int j = 0; j < 2; ++j) {
+        if (!models[j]) continue;
+        st = classify_i16_dev(models[j], (const int16_t*)d.d_samples, d_offsets, n_reads,
+                              j == 0 ? DBH_SIDE_START : DBH_SIDE_END, scan_size, score_diff,
+                              (float*)((char*)d.d_out + (size_t)j * probs_bytes), d_side[j],
+                              d.d_work, (dbh_stream)d.stream, 0, 0, 0, &d.d_tail, &d.d_tail_bytes);
+        if (st != DBH_OK) return done(st);
+    }
+    const int32_t* d_calls = both ? d_final : d_side[start_model ? 0 : 1];
+    if (both) {
+        st = dbh_combine_calls_dev(d_side[0], d_side[1], n_reads, combine_mode, d_final,
+                                   (dbh_stream)d.stream);
+        if (st != DBH_OK) return done(st);
+    }
+    if (ev[3]) (void)hipEventRecord(ev[3], d.stream);
+    e = hipMemcpyAsync(h + in_small, ds + in_small, out_small, hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess && samples_host && out_bytes > 0)
+        e = hipMemcpyAsync(samples_host, d.d_samples, (size_t)out_bytes, hipMemcpyDeviceToHost,
+                           d.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    if (e != hipSuccess) return done(hip_fail(e, "dbh_classify_pair_deflated"));
+    std::memcpy(calls_host, h + in_small + ((const char*)d_calls - (const char*)d_status),
+                (size_t)n_reads * sizeof(int32_t));
+    if (stream_status_host && n_streams)
+        std::memcpy(stream_status_host, h + in_small, (size_t)n_streams * sizeof(int32_t));
+    if (stage_ms) {
+        float ms = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            stage_ms[k] = hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess ? ms : -1.0;
+        }
+    }
+    return done(DBH_OK);
 }
 
 void* dbh_host_alloc(size_t bytes, void* user) {

@@ -1,0 +1,375 @@
+// dbh_inflate.hip - inflating the Signal chunks of fast5 files ON THE GPU (C ABI: the
+// "compressed input" section of include/deepbinner_hip.h).
+//
+// The reference inflates on the host: h5py -> libhdf5 -> zlib, one chunk after the other
+// (deepbinner/load_fast5s.py:33-43).  For this package's native loader that is ~100 of the ~118 us
+// a 55 KB read costs a CPU core, and the box hands a process 16 cores: one host stops at ~130 k
+// reads/s while ONE GPU classifies 214 k (profiles/r03_*).  A container of 4,000 reads is 4,000
+// independent zlib streams - latency-bound, branchy, byte-granular work that a CPU runs 16 at a
+// time and a GPU runs thousands at a time.
+//
+// Two kernels (RFC 1950 / 1951; bit-exact with zlib, same accept / reject decisions; the decoder
+// core is dbh_inflate_core.h, which the CPU test harness compiles too):
+//   1. inflate_tokens_kernel  - ONE LANE PER STREAM, 32 streams per workgroup, decode tables in
+//      LDS (4.6 KB per lane).  Each lane walks its stream's Huffman codes and writes a token per
+//      symbol (literal | match {length, distance}) - no output bytes, no window: nothing a lane does
+//      depends on memory it wrote itself.  All lanes of a wave step together; streams deflated with
+//      the same settings reach their block boundaries (every 16,383 symbols with zlib's defaults)
+//      on the same step, so the table builds line up too.
+//   2. inflate_resolve_kernel - ONE WAVE PER STREAM with the 32 KiB window as a ring in LDS.  64
+//      tokens per step: a wave-wide prefix sum of the token lengths gives every token its output
+//      position; literals are stored at once; matches copy from the ring as soon as everything
+//      they read has been written (a match of one step may read what another match of the same
+//      step writes: the lanes go in rounds, the earliest unfinished position deciding who may
+//      go).  The ring is written out in coalesced 256-byte pieces, with the Adler-32 on the way.
+// HBM traffic per read (55 KB of samples, ~22 k tokens): 35 KB compressed in, 88 KB of tokens out
+// and in again, 55 KB of samples out - latency, not bandwidth, is what both kernels wait for.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/deepbinner_hip.h"
+#include "dbh_inflate_core.h"
+
+namespace dbh_inflate_detail {
+
+using dbi::Lane;
+
+constexpr int kLanes = 32;                 // streams per workgroup of kernel 1
+// LDS of kernel 1, every array interleaved by lane ([entry][lane]): consecutive lanes hit
+// consecutive addresses whatever entry each of them wants
+constexpr int kLitOff = 0;                                          // uint16 units
+constexpr int kDistOff = kLitOff + dbi::kLitEntries * kLanes;
+constexpr int kWorkOff = kDistOff + dbi::kDistEntries * kLanes;
+constexpr int kLensOff16 = kWorkOff + dbi::kMaxSyms * kLanes;       // then kMaxLens bytes per lane
+constexpr int kLdsBytes1 = kLensOff16 * 2 + dbi::kMaxLens * kLanes;
+static_assert(kLdsBytes1 <= 160 * 1024, "kernel 1's tables exceed the CU's LDS");
+
+struct LdsMem {
+    uint16_t* lit_;
+    uint16_t* dist_;
+    uint16_t* work_;
+    uint8_t* lens_;
+    __device__ __forceinline__ uint16_t lit(int e) const { return lit_[e * kLanes]; }
+    __device__ __forceinline__ uint16_t dist(int e) const { return dist_[e * kLanes]; }
+    __device__ __forceinline__ void set_lit(int e, uint16_t v) { lit_[e * kLanes] = v; }
+    __device__ __forceinline__ void set_dist(int e, uint16_t v) { dist_[e * kLanes] = v; }
+    __device__ __forceinline__ int len(int i) const { return lens_[i * kLanes]; }
+    __device__ __forceinline__ void set_len(int i, int v) { lens_[i * kLanes] = (uint8_t)v; }
+    __device__ __forceinline__ int work(int i) const { return work_[i * kLanes]; }
+    __device__ __forceinline__ void set_work(int i, int v) { work_[i * kLanes] = (uint16_t)v; }
+};
+
+// what kernel 1 leaves for kernel 2 (and for the caller) per stream
+struct StreamInfo {
+    int32_t status;
+    int32_t ended;
+    uint32_t adler;
+    int32_t n_tokens;
+    int64_t produced;
+};
+
+__global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
+    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
+    uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes1];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * kLanes + lane;
+    uint16_t* lds16 = reinterpret_cast<uint16_t*>(lds);
+    LdsMem mem;
+    mem.lit_ = lds16 + kLitOff + lane;
+    mem.dist_ = lds16 + kDistOff + lane;
+    mem.work_ = lds16 + kWorkOff + lane;
+    mem.lens_ = lds + kLensOff16 * 2 + lane;
+
+    Lane L;
+    L.state = dbi::kDone;
+    L.status = dbi::kOk;
+    L.ended = 0;
+    L.adler = 0;
+    L.out_pos = 0;
+    uint32_t* tok = tokens;
+    int n_tok = 0;
+    uint32_t t0 = 0, t1 = 0, t2 = 0;       // tokens wait here for a 16-byte store
+    bool mine = false;
+    if (i < n_streams) {
+        const dbh_inflate_stream s = streams[i];
+        if (s.mode == DBH_INFLATE_ZLIB) {
+            mine = true;
+            dbi::lane_start(L, comp + s.comp_offset, s.comp_bytes, s.out_bytes);
+            tok = tokens + s.out_offset;          // one token slot per byte of output
+        }
+    }
+    while (__any(L.state != dbi::kDone)) {
+        if (L.state == dbi::kNeedBlock) {
+            dbi::lane_block(L, mem);
+        } else if (L.state != dbi::kDone) {
+            uint32_t token;
+            if (dbi::lane_step(L, mem, &token)) {
+                // (a store per token and lane is 32 partial cache lines per step)
+                const int k = n_tok & 3;
+                if (k == 3) {
+                    uint32_t four[4] = {t0, t1, t2, token};
+                    __builtin_memcpy(tok + (n_tok - 3), four, 16);
+                }
+                t0 = k == 0 ? token : t0;
+                t1 = k == 1 ? token : t1;
+                t2 = k == 2 ? token : t2;
+                ++n_tok;
+            }
+        }
+    }
+    for (int k = 0; k < (n_tok & 3); ++k)      // the tokens still waiting
+        tok[(n_tok & ~3) + k] = k == 0 ? t0 : k == 1 ? t1 : t2;
+    if (i < n_streams) {
+        StreamInfo r;
+        r.status = mine ? L.status : dbi::kOk;
+        r.ended = L.ended;
+        r.adler = L.adler;
+        r.n_tokens = n_tok;
+        r.produced = L.out_pos;
+        info[i] = r;
+    }
+}
+
+constexpr int kRing = 32768;
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int other = __shfl_xor(v, o);
+        v = other < v ? other : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// a compiler barrier that also drains the wave's LDS queue: what other lanes wrote is there
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(256) void inflate_resolve_kernel(
+    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
+    const uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info, uint8_t* __restrict__ out,
+    int32_t* __restrict__ status_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t rings[4 * kRing];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t* ring = rings + wave * kRing;
+    for (int i = blockIdx.x * 4 + wave; i < n_streams; i += gridDim.x * 4) {
+        const dbh_inflate_stream s = streams[i];
+        uint8_t* dst = out + s.out_offset;
+        const int64_t cap = s.out_bytes;
+        if (s.mode != DBH_INFLATE_ZLIB) {
+            // stored as it is (an unfiltered chunk, a contiguous dataset, or bytes the host has
+            // inflated itself): copy, zero-extend
+            const int64_t have = s.comp_bytes < cap ? s.comp_bytes : cap;
+            const uint8_t* src = comp + s.comp_offset;
+            for (int64_t k = lane; k < cap; k += 64) dst[k] = k < have ? src[k] : (uint8_t)0;
+            if (lane == 0) status_out[i] = dbi::kOk;
+            continue;
+        }
+        StreamInfo r = info[i];
+        int status = r.status;
+        const uint32_t* tok = tokens + s.out_offset;
+        const int n_tok = r.n_tokens;
+        int pos = 0, flushed = 0;                    // (a stream's output is far below 2^31 bytes)
+        unsigned s1 = 1, s2 = 0;
+        if (status == dbi::kOk) {
+            for (int t0 = 0; t0 < n_tok; t0 += 64) {
+                const bool valid = t0 + lane < n_tok;
+                const uint32_t t = valid ? tok[t0 + lane] : 0u;
+                const bool is_match = valid && (t & dbi::kMatchFlag);
+                const int len = !valid ? 0 : is_match ? (int)(t & 0x1FFu) : 1;
+                const int dist = (int)((t >> 9) & 0x7FFFu) + 1;
+                int incl = len;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int total = __shfl(incl, 63);
+                const int my = pos + incl - len;
+                if (__any(is_match && dist > my)) {     // reaches before the start of the output
+                    status = dbi::kBadDistance;
+                    break;
+                }
+                if (valid && !is_match) ring[my & (kRing - 1)] = (uint8_t)t;
+                bool pending = is_match;
+                const int src = my - dist;
+                for (;;) {
+                    const int first = wave_min_i32(pending ? my : 0x7FFFFFFF);
+                    if (first == 0x7FFFFFFF) break;
+                    lds_settle();
+                    // everything this match reads that it does not write itself lies before
+                    // the earliest byte still to be written
+                    const int own = src + len < my ? src + len : my;
+                    if (pending && own <= first) {
+                        for (int k = 0; k < len; ++k)
+                            ring[(my + k) & (kRing - 1)] = ring[(src + k) & (kRing - 1)];
+                        pending = false;
+                    }
+                    lds_settle();
+                }
+                pos += total;
+                // whole 256-byte pieces out of the ring, the Adler-32 on the way
+                while (pos - flushed >= 256) {
+                    lds_settle();
+                    const uint32_t w =
+                        *reinterpret_cast<const uint32_t*>(ring + ((flushed + 4 * lane) & (kRing - 1)));
+                    uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + flushed + 4 * lane);
+                    d16[0] = (uint16_t)w;             // (a read starts at an even byte, not
+                    d16[1] = (uint16_t)(w >> 16);     //  necessarily at a multiple of four)
+                    const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u,
+                                   b3 = w >> 24;
+                    const unsigned at = 4u * (unsigned)lane;          // position inside the piece
+                    const unsigned sum = wave_sum_u32(b0 + b1 + b2 + b3);
+                    const unsigned weighted = wave_sum_u32((256u - at) * b0 + (255u - at) * b1 +
+                                                           (254u - at) * b2 + (253u - at) * b3);
+                    s2 = (s2 + 256u * s1 + weighted) % 65521u;
+                    s1 = (s1 + sum) % 65521u;
+                    flushed += 256;
+                }
+            }
+        }
+        if (status == dbi::kOk) {
+            lds_settle();
+            const int rest = pos - flushed;           // < 256
+            unsigned sum = 0, weighted = 0;
+            for (int k = lane; k < rest; k += 64) {
+                const unsigned b = ring[(flushed + k) & (kRing - 1)];
+                dst[flushed + k] = (uint8_t)b;
+                sum += b;
+                weighted += (unsigned)(rest - k) * b;
+            }
+            sum = wave_sum_u32(sum);
+            weighted = wave_sum_u32(weighted);
+            s2 = (s2 + (unsigned)rest * s1 + weighted) % 65521u;
+            s1 = (s1 + sum) % 65521u;
+            if (r.ended && ((s2 << 16) | s1) != r.adler) status = dbi::kBadChecksum;
+            // a stream that ends early (MinKNOW's short final chunk): libhdf5 zero-extends it
+            for (int64_t k = pos + lane; k < cap; k += 64) dst[k] = 0;
+        }
+        if (status != dbi::kOk)                       // nothing of a damaged stream is handed on
+            for (int64_t k = lane; k < cap; k += 64) dst[k] = 0;
+        if (lane == 0) status_out[i] = status;
+    }
+}
+
+thread_local char g_error[256];
+
+int hip_failed(hipError_t e, const char* what) {
+    std::snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(e));
+    return DBH_ERR_HIP;
+}
+#define DBI_HIP(call)                                          \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return hip_failed(e_, #call);    \
+    } while (0)
+
+}  // namespace dbh_inflate_detail
+
+using namespace dbh_inflate_detail;
+
+extern "C" {
+
+const char* dbh_inflate_last_error(void) { return g_error; }
+
+int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size_t* bytes) {
+    if (!bytes || total_out_bytes < 0 || n_streams < 0) return DBH_ERR_INVALID_ARGUMENT;
+    // one token slot per byte of output (a token yields at least one byte), then the per-stream
+    // records of kernel 1
+    *bytes = (size_t)total_out_bytes * sizeof(uint32_t) + 256 +
+             (size_t)n_streams * sizeof(StreamInfo);
+    return DBH_OK;
+}
+
+int dbh_inflate_dev(const uint8_t* comp_dev, const dbh_inflate_stream* streams_dev,
+                    int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
+                    void* workspace_dev, int32_t* status_dev, dbh_stream stream) {
+    if (n_streams < 0 || n_streams > 0x7FFFFFFF || total_out_bytes < 0)
+        return DBH_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return DBH_OK;
+    if (!comp_dev || !streams_dev || !out_dev || !workspace_dev || !status_dev)
+        return DBH_ERR_INVALID_ARGUMENT;
+    uint32_t* tokens = (uint32_t*)workspace_dev;
+    StreamInfo* info = (StreamInfo*)((char*)workspace_dev +
+                                     (((size_t)total_out_bytes * sizeof(uint32_t) + 255) & ~(size_t)255));
+    const int n = (int)n_streams;
+    hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((n + kLanes - 1) / kLanes)),
+                       dim3(kLanes), 0, (hipStream_t)stream, comp_dev, streams_dev, n, tokens, info);
+    DBI_HIP(hipGetLastError());
+    const int blocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
+    hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, comp_dev, streams_dev, n, (const uint32_t*)tokens, info,
+                       out_dev, status_dev);
+    DBI_HIP(hipGetLastError());
+    return DBH_OK;
+}
+
+int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
+                int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,
+                double* kernel_ms) {
+    if (n_streams < 0) return DBH_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return DBH_OK;
+    if (!comp_host || !streams_host || !out_host || !status_host) return DBH_ERR_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < n_streams; ++i) {
+        const dbh_inflate_stream& s = streams_host[i];
+        if (s.comp_offset < 0 || s.comp_bytes < 0 || s.out_offset < 0 || s.out_bytes < 0 ||
+            (size_t)(s.comp_offset + s.comp_bytes) > comp_bytes ||
+            (size_t)(s.out_offset + s.out_bytes) > out_bytes)
+            return DBH_ERR_INVALID_ARGUMENT;
+    }
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    dbh_inflate_stream* d_streams = nullptr;
+    void* d_work = nullptr;
+    int32_t* d_status = nullptr;
+    size_t work = 0;
+    int st = dbh_inflate_workspace_bytes((int64_t)out_bytes, n_streams, &work);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&] {
+        if (d_comp) (void)hipFree(d_comp);
+        if (d_out) (void)hipFree(d_out);
+        if (d_streams) (void)hipFree(d_streams);
+        if (d_work) (void)hipFree(d_work);
+        if (d_status) (void)hipFree(d_status);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    hipError_t e = hipMalloc((void**)&d_comp, comp_bytes + 64);        // (padded: see the header)
+    if (e == hipSuccess) e = hipMemset(d_comp + comp_bytes, 0, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes ? out_bytes : 1);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_streams, (size_t)n_streams * sizeof(dbh_inflate_stream));
+    if (e == hipSuccess) e = hipMalloc(&d_work, work);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_status, (size_t)n_streams * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_streams, streams_host, (size_t)n_streams * sizeof(dbh_inflate_stream),
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    if (e == hipSuccess && st == DBH_OK)
+        st = dbh_inflate_dev(d_comp, d_streams, n_streams, (int64_t)out_bytes, d_out, d_work,
+                             d_status, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, d_out, out_bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(status_host, d_status, (size_t)n_streams * sizeof(int32_t),
+                      hipMemcpyDeviceToHost);
+    if (e == hipSuccess && kernel_ms) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, e0, e1);
+        *kernel_ms = ms;
+    }
+    cleanup();
+    if (e != hipSuccess) return hip_failed(e, "dbh_inflate");
+    return st;
+}
+
+}  // extern "C"

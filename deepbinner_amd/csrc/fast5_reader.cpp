@@ -261,6 +261,136 @@ class Fast5 {
         }
     }
 
+    // ---- the Signal as it is stored (for callers that inflate elsewhere: the GPU) ---------------
+    // What a read's Signal consists of on disk, piece by piece, in sample order.  A piece covers
+    // samples [first, first + count) of the read.
+    struct RawPiece {
+        int kind = 0;              // kZlib / kStored / kHostDecode / kZeros
+        uint64_t file_off = 0;     // where its bytes lie in the file (kZlib, kStored)
+        uint64_t nbytes = 0;       // how many
+        int64_t first = 0, count = 0;
+        uint64_t chunk_addr = 0, chunk_bytes = 0;      // kHostDecode: the chunk, for decode_chunk
+        uint32_t mask = 0;
+        int64_t comp_offset = 0, comp_bytes = 0;       // its place in a batch's byte buffer
+    };
+    enum { kZlib = 0, kStored = 1, kHostDecode = 2, kZeros = 3 };
+
+    // zlib_above: deflate streams longer than this many bytes are left to the host (a lane of the
+    // GPU decoder walks ONE stream: a stream ten times the usual length holds its wave ten times
+    // as long, while a CPU core inflates it in a millisecond); <= 0: no limit.
+    void signal_pieces(const SignalInfo& s, int64_t zlib_above, std::vector<RawPiece>* out) const {
+        out->clear();
+        if (s.n <= 0) return;
+        RawPiece p;
+        p.first = 0;
+        p.count = s.n;
+        if (s.layout == 0) {
+            if ((uint64_t)s.n * 2 > s.compact_size) throw FormatError("compact data too short");
+            need(s.compact_off, s.compact_size);
+            p.kind = kStored;
+            p.file_off = s.compact_off;
+            p.nbytes = (uint64_t)s.n * 2;
+            out->push_back(p);
+            return;
+        }
+        if (s.layout == 1) {
+            if (s.addr == kUndef) {
+                p.kind = kZeros;
+            } else {
+                p.kind = kStored;
+                p.file_off = base_ + s.addr;
+                p.nbytes = (uint64_t)s.n * 2;
+                need(p.file_off, p.nbytes);
+            }
+            out->push_back(p);
+            return;
+        }
+        if (s.chunk_elems <= 0) throw FormatError("bad chunk size");
+        const int64_t n_chunks = (s.n + s.chunk_elems - 1) / s.chunk_elems;
+        if (n_chunks > (1 << 24)) throw FormatError("implausible number of chunks");
+        std::vector<RawPiece> by_chunk((size_t)n_chunks);
+        for (int64_t k = 0; k < n_chunks; ++k) {
+            RawPiece& q = by_chunk[(size_t)k];
+            q.kind = kZeros;                       // a chunk that was never written reads as zeros
+            q.first = k * s.chunk_elems;
+            q.count = std::min<int64_t>(s.chunk_elems, s.n - q.first);
+        }
+        auto found = [&](int64_t k, uint64_t addr, uint64_t nbytes, uint32_t mask) {
+            if (k < 0 || k >= n_chunks) return;
+            RawPiece& q = by_chunk[(size_t)k];
+            const uint64_t start = file_off(addr);
+            need(start, nbytes);
+            q.chunk_addr = addr;
+            q.chunk_bytes = nbytes;
+            q.mask = mask;
+            // the filters that were applied to THIS chunk, in the order they were applied
+            int applied[8], n_applied = 0;
+            bool known = true;
+            for (size_t i = 0; i < s.filters.size(); ++i) {
+                if (mask & (1u << i)) continue;
+                if (n_applied == 8) known = false;
+                else applied[n_applied++] = s.filters[i].id;
+            }
+            q.file_off = start;
+            q.nbytes = nbytes;
+            if (!known) {
+                q.kind = kHostDecode;
+            } else if (n_applied == 0) {
+                q.kind = kStored;
+            } else if (n_applied == 1 && applied[0] == 1) {
+                q.kind = kZlib;
+            } else if (n_applied == 2 && applied[0] == 1 && applied[1] == 3 && nbytes >= 4) {
+                q.kind = kZlib;                    // deflate, then a checksum behind the stream
+                q.nbytes = nbytes - 4;
+            } else if (n_applied == 2 && applied[0] == 3 && applied[1] == 1) {
+                q.kind = kZlib;                    // the checksum lies inside, behind the samples
+            } else if (n_applied == 1 && applied[0] == 3 && nbytes >= 4) {
+                q.kind = kStored;
+                q.nbytes = nbytes - 4;
+            } else {
+                q.kind = kHostDecode;              // shuffle, or an order not seen in the field
+            }
+            if (q.kind == kZlib && zlib_above > 0 && (int64_t)q.nbytes > zlib_above)
+                q.kind = kHostDecode;
+        };
+        if (s.addr != kUndef) {
+            if (s.index == 0) {
+                collect_chunks(s, s.addr, 0, found);
+            } else {
+                for (int64_t k = 0; k < n_chunks; ++k) {
+                    uint64_t addr = kUndef, nbytes = 0;
+                    uint32_t mask = 0;
+                    if (!indexed_chunk(s, (uint64_t)k, &addr, &nbytes, &mask)) continue;
+                    if (s.unfiltered_edge && (k + 1) * s.chunk_elems > s.n) mask = ~0u;
+                    found(k, addr, nbytes, mask);
+                }
+            }
+        }
+        *out = std::move(by_chunk);
+    }
+
+    // bytes [off, off + n) of the file (large files: pread, not the mapping - see decode_chunk)
+    void read_bytes(uint64_t off, uint64_t n, uint8_t* dst) const {
+        need(off, n);
+        if (mapped_ && fd_ >= 0) {
+            uint64_t got = 0;
+            while (got < n) {
+                const ssize_t k = ::pread(fd_, dst + got, (size_t)(n - got), (off_t)(off + got));
+                if (k <= 0) throw FormatError("cannot read chunk");
+                got += (uint64_t)k;
+            }
+        } else {
+            std::memcpy(dst, buf_ + off, (size_t)n);
+        }
+    }
+
+    // a piece the host decodes itself -> its samples' bytes at dst (count * 2 of them)
+    void decode_piece(const SignalInfo& s, const RawPiece& p, uint8_t* dst, ChunkCache* cache) const {
+        decode_chunk(s, p.chunk_addr, p.chunk_bytes, p.mask, cache);
+        cache->owner = nullptr;                    // (not a chunk read_signal may reuse blindly)
+        std::memcpy(dst, cache->data.data(), (size_t)p.count * 2);
+    }
+
   private:
     static constexpr uint64_t kReadWhole = 8u << 20;   // files up to 8 MiB are read, larger mapped
     int fd_ = -1;
@@ -1103,6 +1233,32 @@ class Fast5 {
         }
     }
 
+    // the same walk, reporting every chunk instead of copying from it
+    template <class Found>
+    void collect_chunks(const SignalInfo& s, uint64_t addr, int depth, const Found& found) const {
+        if (depth > kMaxDepth) throw FormatError("chunk B-tree too deep");
+        const uint64_t p = file_off(addr);
+        if (!sig(p, "TREE")) throw FormatError("bad chunk B-tree signature");
+        if (b(p + 4) != 1) throw FormatError("expected a raw-data chunk B-tree");
+        const int level = b(p + 5);
+        const uint64_t used = u(p + 6, 2);
+        const uint64_t key_size = 8 + 8 * 2;
+        const uint64_t q = p + 8 + 2 * kO;
+        for (uint64_t i = 0; i < used; ++i) {
+            const uint64_t k = q + i * (key_size + kO);
+            const uint64_t nbytes = u(k, 4);
+            const uint32_t mask = (uint32_t)u(k + 4, 4);
+            const uint64_t offset = u(k + 8, 8);
+            const uint64_t child = u(k + key_size, kO);
+            if (level > 0) {
+                collect_chunks(s, child, depth + 1, found);
+                continue;
+            }
+            if (offset >= (uint64_t)s.n || offset % (uint64_t)s.chunk_elems) continue;
+            found((int64_t)(offset / (uint64_t)s.chunk_elems), child, nbytes, mask);
+        }
+    }
+
     // ---- which reads the file holds (load_fast5s.py:29-43) ---------------------------------------
     void find_reads() {
         const std::map<std::string, uint64_t> root = group_links(object_header(root_addr_));
@@ -1320,9 +1476,7 @@ struct f5_file {
 // Packed samples of a batch.  Deliberately NOT value-initialised (a std::vector would zero 100+ MB
 // on the calling thread before the workers start), and RECYCLED: a 4,000-read container's scanned
 // ends are 106 MB, and a fresh allocation of that size is an mmap whose 26,000 pages are then
-// faulted in by the worker threads one by one (they queue on the address-space lock: this, not the
-// inflating, was what stopped the loader scaling past 64 threads) and unmapped again when the
-// batch is freed.  Freed buffers wait in a pool (bounded: DEEPBINNER_FAST5_POOL_MB, default 2048)
+// faulted in by the worker threads one by one and unmapped again when the batch is freed.  Freed buffers wait in a pool (bounded: DEEPBINNER_FAST5_POOL_MB, default 2048)
 // for the next batch that fits.  The memory comes from malloc or from an allocator the caller
 // installs (f5_set_sample_allocator) - pinned host memory, so that the GPU's DMA engine reads the
 // batch where the loader threads wrote it.
@@ -1364,7 +1518,7 @@ class SamplePool {
             // best fit among the idle blocks; one that is far too large stays for a larger batch
             size_t best = idle_.size();
             for (size_t i = 0; i < idle_.size(); ++i)
-                if (idle_[i].bytes >= bytes && idle_[i].bytes / 2 <= bytes + (1u << 20) &&
+                if (idle_[i].bytes >= bytes && idle_[i].bytes / 4 <= bytes + (1u << 20) &&
                     (best == idle_.size() || idle_[i].bytes < idle_[best].bytes))
                     best = i;
             if (best != idle_.size()) {
@@ -1376,9 +1530,10 @@ class SamplePool {
             }
             from = allocator_;
         }
-        // a little more than asked for: the next container is about, not exactly, as large
+        // more than asked for: the next container is about, not exactly, as large - and a fresh
+        // buffer costs its page faults (3-4 times the copy that fills it)
         Block b;
-        b.bytes = (bytes + bytes / 8 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+        b.bytes = (bytes + bytes / 4 + (1u << 20)) & ~(size_t)((1u << 20) - 1);
         b.from = from;
         b.ptr = from.alloc ? from.alloc(b.bytes, from.user) : std::malloc(b.bytes);
         if (!b.ptr) throw std::bad_alloc();
@@ -1455,6 +1610,10 @@ struct f5_batch {
     std::vector<int64_t> offsets;
     std::vector<int32_t> status;
     std::vector<char> read_ids;
+    // raw batches (f5_stream_open_raw): the Signal pieces as stored, for a decoder elsewhere
+    SampleBuffer comp;                       // bytes (its count is in int16 units: see comp_bytes)
+    int64_t comp_bytes = 0;
+    std::vector<f5_raw_stream> streams;
 };
 
 extern "C" {
@@ -1719,6 +1878,8 @@ struct f5_stream {
         int64_t count = 0, next = 0, done = 0;
         f5_batch* batch = nullptr;
         std::vector<int64_t> lengths;
+        std::vector<std::vector<Fast5::RawPiece>> pieces;      // raw mode: per read
+        std::chrono::steady_clock::time_point stamp[5];        // DEEPBINNER_FAST5_TIMING
         ~Container() { delete batch; }
     };
     struct Task {
@@ -1730,6 +1891,8 @@ struct f5_stream {
     std::vector<std::string> paths;
     int64_t keep = 0;
     int depth = 3;
+    bool raw = false;                // hand out the Signal pieces as stored (f5_stream_open_raw)
+    int64_t zlib_above = 0;          // ... except deflate streams longer than this: host-inflated
     std::mutex m;
     std::condition_variable work_cv, done_cv;
     std::deque<std::unique_ptr<Container>> inflight;      // in path order
@@ -1782,7 +1945,27 @@ struct f5_stream {
         return false;
     }
 
+    static bool timing() {
+        static const bool on = std::getenv("DEEPBINNER_FAST5_TIMING") != nullptr;
+        return on;
+    }
+    static void mark(Container* c, int k) {
+        if (timing()) c->stamp[k] = std::chrono::steady_clock::now();
+    }
+    static void report(const Container* c) {
+        if (!timing()) return;
+        auto ms = [&](int a, int b) {
+            return std::chrono::duration<double, std::milli>(c->stamp[b] - c->stamp[a]).count();
+        };
+        std::fprintf(stderr,
+                     "f5_stream: container %lld, %lld reads: open+parse %.1f ms, resolve %.1f ms, "
+                     "layout %.1f ms, %s %.1f ms\n",
+                     (long long)c->index, (long long)c->count, ms(0, 1), ms(1, 2), ms(2, 3),
+                     c->pieces.empty() ? "inflate" : "fetch", ms(3, 4));
+    }
+
     void parse(Container* c) {
+        mark(c, 0);
         c->status = guarded([&] {
             c->file.reset(new Fast5(c->path.c_str()));
             c->file->parse();
@@ -1795,10 +1978,12 @@ struct f5_stream {
                 c->batch->status.assign((size_t)c->count, F5_ERR_OPEN);
                 c->batch->read_ids.assign((size_t)c->count * F5_READ_ID_MAX, 0);
                 c->lengths.assign((size_t)c->count, 0);
+                if (raw) c->pieces.resize((size_t)c->count);
             } catch (const std::exception&) {
                 c->status = F5_ERR_FORMAT;
             }
         }
+        mark(c, 1);
     }
 
     void resolve(Container* c, int64_t a, int64_t b) {
@@ -1806,12 +1991,18 @@ struct f5_stream {
             c->batch->status[(size_t)i] = guarded([&] {
                 const ReadEntry& r = c->file->read(i);
                 const int64_t n = r.signal.n;
-                c->lengths[(size_t)i] = (keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                c->lengths[(size_t)i] = (!raw && keep > 0 && n > 2 * keep) ? 2 * keep : n;
+                if (raw) c->file->signal_pieces(r.signal, zlib_above, &c->pieces[(size_t)i]);
                 copy_read_id(r.read_id, &c->batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
             });
     }
 
     void layout(Container* c) {
+        mark(c, 2);
+        struct MarkEnd {
+            Container* c;
+            ~MarkEnd() { mark(c, 3); }
+        } mark_end{c};
         int64_t total = 0;
         for (int64_t i = 0; i < c->count; ++i) {
             c->batch->offsets[(size_t)i] = total;
@@ -1819,9 +2010,81 @@ struct f5_stream {
         }
         c->batch->offsets[(size_t)c->count] = total;
         try {
-            c->batch->samples.resize((size_t)total);
+            if (!raw) {
+                c->batch->samples.resize((size_t)total);
+                return;
+            }
+            // raw: every piece gets its place in the byte buffer (what it occupies there: the
+            // stored bytes, or - decoded by the host - its samples) and its record; the records
+            // go out longest stream first, so that the lanes of a wave of the GPU decoder - which
+            // step together, one stream each - get streams of one length
+            int64_t at = 0;
+            size_t n_pieces = 0;
+            for (int64_t i = 0; i < c->count; ++i)
+                if (c->batch->status[(size_t)i] == F5_OK) n_pieces += c->pieces[(size_t)i].size();
+            c->batch->streams.reserve(n_pieces);
+            for (int64_t i = 0; i < c->count; ++i) {
+                if (c->batch->status[(size_t)i] != F5_OK) continue;
+                for (Fast5::RawPiece& p : c->pieces[(size_t)i]) {
+                    const int64_t wanted = p.count * 2;
+                    p.comp_offset = at;
+                    p.comp_bytes = p.kind == Fast5::kZlib     ? (int64_t)p.nbytes
+                                   : p.kind == Fast5::kStored ? std::min<int64_t>((int64_t)p.nbytes, wanted)
+                                   : p.kind == Fast5::kZeros  ? 0
+                                                              : wanted;
+                    at += p.comp_bytes;
+                    f5_raw_stream rec;
+                    rec.comp_offset = p.comp_offset;
+                    rec.comp_bytes = p.comp_bytes;
+                    rec.out_offset = (c->batch->offsets[(size_t)i] + p.first) * 2;
+                    rec.out_bytes = wanted;
+                    rec.mode = p.kind == Fast5::kZlib ? F5_RAW_ZLIB : F5_RAW_STORED;
+                    rec.reserved = (int32_t)i;         // which read of the batch it belongs to
+                    c->batch->streams.push_back(rec);
+                }
+            }
+            std::stable_sort(c->batch->streams.begin(), c->batch->streams.end(),
+                             [](const f5_raw_stream& x, const f5_raw_stream& y) {
+                                 const int64_t wx = x.mode == F5_RAW_ZLIB ? x.comp_bytes : 0;
+                                 const int64_t wy = y.mode == F5_RAW_ZLIB ? y.comp_bytes : 0;
+                                 return wx > wy;
+                             });
+            c->batch->comp_bytes = at;
+            // (the decoder fetches ahead of itself: 64 readable bytes behind the last stream)
+            c->batch->comp.resize((size_t)(at + 64 + 1) / 2);
+            std::memset(reinterpret_cast<uint8_t*>(c->batch->comp.data()) + at, 0, 64);
         } catch (const std::exception&) {
             c->status = F5_ERR_FORMAT;
+        }
+    }
+
+    // raw mode's pass 2: the pieces of reads [a, b) into the byte buffer
+    void fetch(Container* c, int64_t a, int64_t b) {
+        thread_local ChunkCache cache;
+        uint8_t* comp = reinterpret_cast<uint8_t*>(c->batch->comp.data());
+        for (int64_t i = a; i < b; ++i) {
+            if (c->batch->status[(size_t)i] != F5_OK) continue;
+            const int rc = guarded([&] {
+                const ReadEntry& r = c->file->read(i);
+                for (const Fast5::RawPiece& p : c->pieces[(size_t)i]) {
+                    uint8_t* dst = comp + p.comp_offset;
+                    if (p.kind == Fast5::kZlib || p.kind == Fast5::kStored)
+                        c->file->read_bytes(p.file_off, (uint64_t)p.comp_bytes, dst);
+                    else if (p.kind == Fast5::kHostDecode)
+                        c->file->decode_piece(r.signal, p, dst, &cache);
+                }
+            });
+            if (rc != F5_OK) {
+                // what could not be fetched or decoded reads as nothing: a stored stream of no
+                // bytes is zero-extended by the decoder; the read is marked
+                for (f5_raw_stream& rec : c->batch->streams)
+                    if (rec.reserved == (int32_t)i) {
+                        rec.mode = F5_RAW_STORED;
+                        rec.comp_bytes = 0;
+                    }
+                std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            }
+            c->batch->status[(size_t)i] = rc;
         }
     }
 
@@ -1849,6 +2112,8 @@ struct f5_stream {
     }
 
     void finish(Container* c) {      // no read of it is being worked on any more
+        mark(c, 4);
+        report(c);
         for (int64_t i = 0; i < c->count; ++i)
             if (c->batch->status[(size_t)i] != F5_OK)
                 std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
@@ -1865,6 +2130,7 @@ struct f5_stream {
             lk.unlock();
             if (t.phase == kParsing) parse(c);
             else if (t.phase == kResolve) resolve(c, t.a, t.b);
+            else if (raw) fetch(c, t.a, t.b);
             else inflate(c, t.a, t.b);
             lk.lock();
             if (t.phase == kParsing) {
@@ -1943,6 +2209,53 @@ int f5_stream_open(const char* const* paths, int64_t n_paths, int64_t keep, int 
     }
     *out = s;
     return F5_OK;
+}
+
+int f5_stream_open_raw(const char* const* paths, int64_t n_paths, int n_threads, int depth,
+                       int64_t host_inflate_above, f5_stream** out) {
+    f5_stream* s = nullptr;
+    // (opened without a team first, so that the mode is set before any thread looks at it)
+    const int st = f5_stream_open(paths, 0, 0, 1, depth, &s);
+    if (st != F5_OK) return st;
+    if (!out || n_paths < 0 || (n_paths > 0 && !paths)) {
+        delete s;
+        return F5_ERR_ARGUMENT;
+    }
+    try {
+        for (int64_t i = 0; i < n_paths; ++i) {
+            if (!paths[i]) {
+                delete s;
+                return F5_ERR_ARGUMENT;
+            }
+            s->paths.emplace_back(paths[i]);
+        }
+        {
+            std::lock_guard<std::mutex> g(s->m);
+            s->raw = true;
+            s->zlib_above = host_inflate_above;
+            s->admit_locked();
+        }
+        const int threads = thread_count(n_threads);
+        for (int t = (int)s->workers.size(); t < threads; ++t)
+            s->workers.emplace_back([s] { s->worker(); });
+        s->work_cv.notify_all();
+    } catch (const std::exception&) {
+        delete s;
+        return F5_ERR_OPEN;
+    }
+    *out = s;
+    return F5_OK;
+}
+
+const uint8_t* f5_batch_comp(const f5_batch* batch) {
+    return batch ? reinterpret_cast<const uint8_t*>(batch->comp.data()) : nullptr;
+}
+int64_t f5_batch_comp_bytes(const f5_batch* batch) { return batch ? batch->comp_bytes : 0; }
+const f5_raw_stream* f5_batch_streams(const f5_batch* batch) {
+    return batch && !batch->streams.empty() ? batch->streams.data() : nullptr;
+}
+int64_t f5_batch_n_streams(const f5_batch* batch) {
+    return batch ? (int64_t)batch->streams.size() : 0;
 }
 
 int f5_stream_next(f5_stream* s, int64_t* index, int* container_status, f5_batch** batch) {

@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     'f5_version', 'f5_status_string', 'f5_usable_cpus', 'f5_open', 'f5_close', 'f5_layout', 'f5_read_info',
     'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_size', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
     'f5_batch_read_ids', 'f5_batch_free', 'f5_stream_open', 'f5_stream_next', 'f5_stream_close',
-    'f5_set_sample_allocator', 'f5_release_idle_buffers',
+    'f5_set_sample_allocator', 'f5_release_idle_buffers', 'f5_stream_open_raw', 'f5_batch_comp',
+    'f5_batch_comp_bytes', 'f5_batch_streams', 'f5_batch_n_streams',
 ]
 
 
@@ -76,6 +77,11 @@ def load_library():
         'f5_stream_open': (c_int, [P(c_char_p), c_i64, c_i64, c_int, c_int, P(c_void_p)]),
         'f5_stream_next': (c_int, [c_void_p, P(c_i64), P(c_int), P(c_void_p)]),
         'f5_stream_close': (None, [c_void_p]),
+        'f5_stream_open_raw': (c_int, [P(c_char_p), c_i64, c_int, c_int, c_i64, P(c_void_p)]),
+        'f5_batch_comp': (P(ctypes.c_uint8), [c_void_p]),
+        'f5_batch_comp_bytes': (c_i64, [c_void_p]),
+        'f5_batch_streams': (c_void_p, [c_void_p]),
+        'f5_batch_n_streams': (c_i64, [c_void_p]),
         'f5_set_sample_allocator': (c_int, [c_void_p, c_void_p, c_void_p]),
         'f5_release_idle_buffers': (None, []),
     }
@@ -180,9 +186,10 @@ def iter_reads(fast5_file):
         return
 
 
-def _unpack_batch(lib, handle, n):
+def _unpack_batch(lib, handle, n, keep_alive=None):
     """(read_ids, samples, offsets, status) from a native batch handle (which it frees, at once or
-    when the zero-copy sample array dies)."""
+    when the zero-copy sample array - or ``keep_alive``, the zero-copy byte array of a raw batch -
+    dies)."""
     try:
         offsets = np.ctypeslib.as_array(lib.f5_batch_offsets(handle), shape=(n + 1,)).copy()
         total = int(offsets[n])
@@ -194,7 +201,10 @@ def _unpack_batch(lib, handle, n):
     except Exception:
         lib.f5_batch_free(handle)
         raise
-    if total:
+    if keep_alive is not None:
+        samples = None
+        weakref.finalize(keep_alive, lib.f5_batch_free, handle)
+    elif total:
         # no copy: the array (and every slice of it) keeps the native batch alive
         samples = np.ctypeslib.as_array(lib.f5_batch_samples(handle), shape=(total,))
         weakref.finalize(samples, lib.f5_batch_free, handle)
@@ -271,6 +281,58 @@ def stream_reads(fast5_files, keep=None, threads=0, depth=0):
                 continue
             batch = ctypes.c_void_p(handle.value)
             yield (index.value,) + _unpack_batch(lib, batch, int(lib.f5_batch_size(batch)))
+    finally:
+        lib.f5_stream_close(stream)
+
+
+RAW_ZLIB, RAW_STORED = 0, 1
+# f5_raw_stream (include/deepbinner_fast5.h) = dbh_inflate_stream (include/deepbinner_hip.h)
+RAW_STREAM = np.dtype([('comp_offset', '<i8'), ('comp_bytes', '<i8'), ('out_offset', '<i8'),
+                       ('out_bytes', '<i8'), ('mode', '<i4'), ('read', '<i4')])
+
+
+def stream_raw(fast5_files, threads=0, depth=0, host_inflate_above=0):
+    """Multi-read containers as a stream of RAW batches (``f5_stream_open_raw``): the Signal of
+    every read as it is stored - zlib streams, mostly - for a decoder elsewhere (the GPU:
+    ``hip_backend.classify_pair_deflated``).  Yields, in the order of ``fast5_files``,
+    ``(index, read_ids, offsets, status, comp, streams)``: ``offsets`` (samples) say where each
+    read's signal lies once decoded, ``comp`` is the byte buffer (uint8, zero-copy: it keeps the
+    native batch alive), ``streams`` an array of RAW_STREAM records - or ``(index, None, None,
+    container_status, None, None)`` for a file that could not be opened."""
+    lib = load_library()
+    n = len(fast5_files)
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
+    stream = ctypes.c_void_p()
+    status = lib.f5_stream_open_raw(paths, n, int(threads), int(depth), int(host_inflate_above),
+                                    ctypes.byref(stream))
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+    try:
+        index, container_status = ctypes.c_int64(0), ctypes.c_int(0)
+        handle = ctypes.c_void_p()
+        while lib.f5_stream_next(stream, ctypes.byref(index), ctypes.byref(container_status),
+                                 ctypes.byref(handle)) == F5_OK:
+            if container_status.value != F5_OK:
+                yield index.value, None, None, container_status.value, None, None
+                continue
+            batch = ctypes.c_void_p(handle.value)
+            count = int(lib.f5_batch_size(batch))
+            n_streams = int(lib.f5_batch_n_streams(batch))
+            comp_bytes = int(lib.f5_batch_comp_bytes(batch))
+            try:
+                records = np.empty(n_streams, dtype=RAW_STREAM)
+                if n_streams:
+                    ctypes.memmove(records.ctypes.data, lib.f5_batch_streams(batch),
+                                   n_streams * RAW_STREAM.itemsize)
+                # (64 readable bytes behind the streams: part of the array, so that they travel)
+                comp = np.ctypeslib.as_array(lib.f5_batch_comp(batch), shape=(comp_bytes + 64,)) \
+                    if n_streams else np.zeros(64, dtype=np.uint8)
+            except Exception:
+                lib.f5_batch_free(batch)
+                raise
+            ids, _, offsets, st = _unpack_batch(lib, batch, count, keep_alive=comp if n_streams
+                                                else None)
+            yield index.value, ids, offsets, st, comp, records
     finally:
         lib.f5_stream_close(stream)
 

@@ -106,6 +106,15 @@ def load_library():
         'dbh_host_alloc': (c_void_p, [c_size_t, c_void_p]),
         'dbh_host_release': (None, [c_void_p, c_void_p]),
         'dbh_host_is_pinned': (c_int, [c_void_p, c_size_t, P(c_int)]),
+        'dbh_inflate_last_error': (ctypes.c_char_p, []),
+        'dbh_inflate_workspace_bytes': (c_int, [c_i64, c_i64, P(c_size_t)]),
+        'dbh_inflate_dev': (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+        'dbh_inflate': (c_int, [c_void_p, c_size_t, c_void_p, c_i64, c_void_p, c_size_t, c_void_p,
+                                P(ctypes.c_double)]),
+        'dbh_classify_pair_deflated': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
+                                               c_void_p, c_i64, c_int, ctypes.c_double, c_int,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
         'dbh_classify_workspace_bytes': (c_int, [c_void_p, c_i64, c_int, P(c_size_t)]),
         'dbh_classify_i16_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -159,7 +168,8 @@ EXPORTED_SYMBOLS = [
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_pair_i16',
     'dbh_model_set_host_group', 'dbh_host_alloc', 'dbh_host_release', 'dbh_host_is_pinned',
-    'dbh_classify_workspace_bytes',
+    'dbh_classify_workspace_bytes', 'dbh_inflate_last_error', 'dbh_inflate_workspace_bytes',
+    'dbh_inflate_dev', 'dbh_inflate', 'dbh_classify_pair_deflated',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
@@ -253,6 +263,63 @@ def classify_pair(start_model, end_model, samples, offsets, scan_size, score_dif
     if want_sides or want_probs:
         return calls, tuple(side_calls), tuple(side_probs)
     return calls
+
+
+INFLATE_ZLIB, INFLATE_STORED = 0, 1
+# dbh_inflate_stream (include/deepbinner_hip.h)
+INFLATE_STREAM = np.dtype([('comp_offset', '<i8'), ('comp_bytes', '<i8'), ('out_offset', '<i8'),
+                           ('out_bytes', '<i8'), ('mode', '<i4'), ('reserved', '<i4')])
+
+
+def inflate(comp, streams, out_bytes):
+    """zlib streams inflated on the GPU (``dbh_inflate``: host buffers in and out - tests and
+    tools; the classify path keeps everything on the device).  ``comp``: uint8 array holding the
+    streams, ``streams``: array of INFLATE_STREAM records, ``out_bytes``: size of the output
+    buffer -> (output uint8 array, status int32 per stream, milliseconds the two kernels took)."""
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    streams = np.ascontiguousarray(streams, dtype=INFLATE_STREAM)
+    out = np.zeros(int(out_bytes), dtype=np.uint8)
+    status = np.zeros(len(streams), dtype=np.int32)
+    ms = ctypes.c_double(0)
+    check(load_library().dbh_inflate(comp.ctypes.data, comp.nbytes, streams.ctypes.data,
+                                     len(streams), out.ctypes.data, out.nbytes, status.ctypes.data,
+                                     ctypes.byref(ms)), 'dbh_inflate')
+    return out, status, ms.value
+
+
+def classify_pair_deflated(start_model, end_model, comp, streams, offsets, scan_size, score_diff,
+                           mode='require_either', want_samples=False, want_stages=False):
+    """A raw batch of the native loader (``fast5_native.stream_raw``: the reads' Signal chunks
+    as stored) -> final calls int32 [N] and the decoder's status per stream, in ONE call of the C
+    ABI: upload, inflate on the GPU, both models, ``combine_calls``.  ``comp`` must include its 64
+    bytes of padding (``stream_raw``'s arrays do).  ``want_samples``: also the decoded signals
+    (int16, all reads back to back); ``want_stages``: milliseconds of upload / inflate / classify
+    on the device."""
+    lib = load_library()
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    streams = np.ascontiguousarray(streams)
+    if streams.dtype.itemsize != INFLATE_STREAM.itemsize:
+        raise ValueError('stream records of {} bytes'.format(streams.dtype.itemsize))
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    calls = np.empty(max(n, 0), dtype=np.int32)
+    status = np.zeros(len(streams), dtype=np.int32)
+    samples = np.empty(int(offsets[-1]) if want_samples and n > 0 else 0, dtype=np.int16)
+    stages = (ctypes.c_double * 3)()
+    if n > 0:
+        check(lib.dbh_classify_pair_deflated(
+            start_model.handle if start_model is not None else None,
+            end_model.handle if end_model is not None else None,
+            comp.ctypes.data, max(comp.nbytes - 64, 0), streams.ctypes.data, len(streams),
+            offsets.ctypes.data, n, int(scan_size), float(score_diff), COMBINE_MODES[mode],
+            calls.ctypes.data, status.ctypes.data, samples.ctypes.data if want_samples else None,
+            stages if want_stages else None), 'dbh_classify_pair_deflated')
+    out = [calls, status]
+    if want_samples:
+        out.append(samples)
+    if want_stages:
+        out.append(list(stages))
+    return tuple(out)
 
 
 _PINNED_LOADER = False

@@ -201,6 +201,57 @@ class Session:
         signal = (lambda i: samples[offsets[i]:offsets[i + 1]]) if not self.table_only else None
         return number, path, ids, names, signal
 
+    # The same with the inflating on the GPU (DEEPBINNER_GPU_INFLATE=0 turns it off): the loader
+    # hands over the Signal chunks as stored - zlib streams, 85 % of what loading a read costs a
+    # CPU core is inflating them, and a host has few cores per GPU - and
+    # dbh_classify_pair_deflated does the rest.  Streams above DEEPBINNER_HOST_INFLATE_ABOVE bytes
+    # (default 128 KiB: a lane of the GPU decoder walks ONE stream) stay with the host's threads.
+    def _raw_containers(self, fast5s):
+        from . import fast5_native
+        threads = int(getattr(self.args, 'loader_procs', 0) or 0)
+        above = int(os.environ.get('DEEPBINNER_HOST_INFLATE_ABOVE', 128 << 10))
+        stream = fast5_native.stream_raw(fast5s, threads=threads, host_inflate_above=above,
+                                         depth=int(os.environ.get('DEEPBINNER_LOADER_DEPTH', 0)))
+        for index, ids, offsets, status, comp, records in stream:
+            if ids is None:
+                continue
+            classify.warn_about_filters(status)
+            yield index + 1, fast5s[index], ids, offsets, comp, records
+
+    def _classify_raw_container(self, item, start_replica, end_replica):
+        import numpy as np
+        from . import fast5_native, hip_backend
+        number, path, ids, offsets, comp, records = item
+        result = hip_backend.classify_pair_deflated(
+            start_replica, end_replica, comp, records, offsets, int(self.args.scan_size),
+            self.args.score_diff, classify.combine_mode(self.args) if start_replica is not None and
+            end_replica is not None else 'require_either', want_samples=not self.table_only)
+        numbers, stream_status = result[0], result[1]
+        samples = result[2] if not self.table_only else None
+        redone = {}
+        for i in sorted(set(records['read'][stream_status != 0].tolist())):
+            # a stream the GPU decoder refused (damaged, or beyond it): zlib on the host has the
+            # last word, as it has in the reference (h5py -> libhdf5 -> zlib)
+            try:
+                _, one, one_offsets, one_status = fast5_native.load_reads(path, first=i, count=1,
+                                                                          threads=1)
+            except OSError:
+                one_status = [1]
+            if one_status[0] != 0:
+                ids[i] = None
+                continue
+            numbers[i] = classify.classify_packed_numbers(one, one_offsets, start_replica,
+                                                          end_replica, self.args)[0]
+            redone[i] = np.array(one)
+        keep = [i for i, rid in enumerate(ids) if rid is not None]
+        names = [classify.call_name(int(numbers[i])) for i in keep]
+
+        def signal(k):
+            i = keep[k]
+            return redone[i] if i in redone else samples[offsets[i]:offsets[i + 1]]
+
+        return number, path, [ids[i] for i in keep], names, signal if samples is not None else None
+
     def _read_chunks(self, fast5s):
         """The same units for the Python reader and for models without the packed entry point:
         (container number, path, read ids, signals) per --batch_size reads."""
@@ -244,8 +295,13 @@ class Session:
 
         models = [m for m in (self.start_model, self.end_model) if m is not None]
         packed = reader_kind() == 'native' and all(hasattr(m, 'classify_packed') for m in models)
-        items, work = ((self._packed_containers(fast5s), self._classify_container) if packed
-                       else (self._read_chunks(fast5s), self._classify_chunk))
+        if packed and os.environ.get('DEEPBINNER_GPU_INFLATE', '1') != '0' and \
+                all(hasattr(m, 'handle') for m in models):
+            items, work = self._raw_containers(fast5s), self._classify_raw_container
+        elif packed:
+            items, work = self._packed_containers(fast5s), self._classify_container
+        else:
+            items, work = self._read_chunks(fast5s), self._classify_chunk
         metadata = MetadataSource() if not self.table_only else None
         # the units go round the devices the models are replicated on (one, usually)
         replicas = classify.device_replicas(self.start_model, self.end_model)

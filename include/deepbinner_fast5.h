@@ -95,6 +95,33 @@ int f5_stream_open(const char* const* paths, int64_t n_paths, int64_t keep, int 
 int f5_stream_next(f5_stream* stream, int64_t* index, int* container_status, f5_batch** batch);
 void f5_stream_close(f5_stream* stream);
 
+/* The same stream handing out the Signal AS STORED, for a decoder elsewhere - the GPU
+ * (deepbinner_hip.h: dbh_inflate_dev, dbh_classify_pair_deflated).  Inflating is ~85 % of what
+ * loading a read costs a CPU core; a raw batch costs the host the parsing and one pread per chunk.
+ * A batch then holds no samples (f5_batch_samples is NULL) but
+ *   - offsets (n_reads + 1, in SAMPLES): where each read's signal will lie once decoded;
+ *   - a byte buffer (f5_batch_comp, f5_batch_comp_bytes; readable for 64 bytes beyond its end);
+ *   - one f5_raw_stream per piece of stored Signal (a chunk, or a whole unchunked dataset), longest
+ *     deflate stream first: where its bytes lie in the byte buffer, where its output goes in the
+ *     sample buffer (byte offsets) and how many bytes of it are wanted, and whether it is a zlib
+ *     stream (F5_RAW_ZLIB) or the bytes themselves (F5_RAW_STORED: unfiltered data, chunks with
+ *     filters beyond deflate / fletcher32 - inflated and unshuffled by the host after all - and
+ *     deflate streams longer than host_inflate_above bytes; <= 0: never).  `reserved` = the
+ *     index of the read the piece belongs to.  Layout identical to dbh_inflate_stream. */
+#define F5_RAW_ZLIB 0
+#define F5_RAW_STORED 1
+typedef struct f5_raw_stream {
+    int64_t comp_offset, comp_bytes;
+    int64_t out_offset, out_bytes;
+    int32_t mode, reserved;
+} f5_raw_stream;
+int f5_stream_open_raw(const char* const* paths, int64_t n_paths, int n_threads, int depth,
+                       int64_t host_inflate_above, f5_stream** out);
+const uint8_t* f5_batch_comp(const f5_batch* batch);
+int64_t f5_batch_comp_bytes(const f5_batch* batch);
+const f5_raw_stream* f5_batch_streams(const f5_batch* batch);
+int64_t f5_batch_n_streams(const f5_batch* batch);
+
 /* Where the packed samples of a batch live.  Freed batches leave their sample buffer in a pool
  * (bounded by DEEPBINNER_FAST5_POOL_MB, default 2048) for the next batch that fits, so that a
  * steady stream of containers allocates - and page-faults - nothing.  A caller may supply the

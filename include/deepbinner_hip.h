@@ -174,6 +174,59 @@ int dbh_classify_i16_batched_dev(dbh_model* model, const int16_t* samples_dev,
 int dbh_combine_calls_dev(const int32_t* start_calls_dev, const int32_t* end_calls_dev,
                           int64_t n_reads, int mode, int32_t* out_dev, dbh_stream stream);
 
+/* ---- compressed input: the Signal chunks of fast5 files, inflated on the GPU ---------------- */
+/* The reference reads `Signal[:]` through h5py (load_fast5s.py:33-43): libhdf5 runs zlib's
+ * inflate() over every chunk on the host.  Here the loader may hand over the chunks AS STORED
+ * (zlib streams, RFC 1950/1951: the HDF5 "deflate" filter) and the GPU inflates them - thousands
+ * of streams side by side, bit-exact with zlib, same accept / reject decisions (tests/
+ * test_inflate.py).  A stream is described by where its bytes lie in the compressed buffer and
+ * where its output goes in the output buffer; out_bytes is how much of its output is wanted: a
+ * stream that holds more is cut there (a partial last chunk), one that ends earlier is
+ * zero-extended (MinKNOW's short final chunk, as libhdf5 does it).  DBH_INFLATE_STORED: the
+ * bytes are the data itself (an unfiltered chunk, or what the host inflated for the filters the
+ * GPU does not do) - copied, zero-extended.
+ * status per stream: 0 = ok; anything else = damaged or beyond this decoder (its output is then
+ * all zeros): the caller decodes that stream on the host if it wants the verdict of zlib itself.
+ * The compressed buffer must be readable for 64 bytes beyond its end (the decoder fetches ahead).
+ * Output regions must not overlap; out_offset must be even (samples are int16). */
+#define DBH_INFLATE_ZLIB 0
+#define DBH_INFLATE_STORED 1
+typedef struct dbh_inflate_stream {
+    int64_t comp_offset, comp_bytes;       /* the stream inside the compressed buffer           */
+    int64_t out_offset, out_bytes;         /* its output inside the output buffer (bytes)       */
+    int32_t mode, reserved;
+} dbh_inflate_stream;
+const char* dbh_inflate_last_error(void);
+/* total_out_bytes = size of the output buffer the streams write into */
+int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size_t* bytes);
+int dbh_inflate_dev(const uint8_t* comp_dev, const dbh_inflate_stream* streams_dev,
+                    int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
+                    void* workspace_dev, int32_t* status_dev, dbh_stream stream);
+/* host buffers in, host buffers out (tests, tools); kernel_ms (may be NULL): the two kernels */
+int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
+                int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,
+                double* kernel_ms);
+
+/* The whole of a batch from stored chunks to barcode calls in one call: upload of the compressed
+ * bytes (in place if they are pinned: the native loader's raw batches are), inflate, the start
+ * model over the first and the end model over the last scan_size samples of every read,
+ * combine_calls - dbh_classify_pair_i16 for reads that are still deflated.  offsets_host (n_reads
+ * + 1, in samples, starting at 0): where each read's signal lies once decoded; the streams'
+ * out_offset / out_bytes address the same buffer in bytes.  comp_host must be readable for 64
+ * bytes beyond comp_bytes (a pageable buffer is copied and padded, so it need not be).
+ * stream_status_host (n_streams, may be NULL): the decoder's verdict per stream - a read one of
+ * whose streams failed was classified on zeros; the caller decodes it on the host and asks
+ * again.  samples_host (may be NULL): the decoded signals, all of them (realtime's binning).
+ * stage_ms (may be NULL, else 3 doubles): upload, inflate, classify in milliseconds on the
+ * device (HIP events; tools). */
+int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
+                               const uint8_t* comp_host, int64_t comp_bytes,
+                               const dbh_inflate_stream* streams_host, int64_t n_streams,
+                               const int64_t* offsets_host, int64_t n_reads, int scan_size,
+                               double score_diff, int combine_mode, int32_t* calls_host,
+                               int32_t* stream_status_host, int16_t* samples_host,
+                               double* stage_ms);
+
 /* ---- multi-device: reads shard over the GPUs of one node, calls are all-gathered ---------- */
 /* The reference is single-device (its only knob: set_tensorflow_threads, classify.py:416-423).
  * Reads are independent, so every GPU classifies a contiguous shard with its own model replica

@@ -273,3 +273,87 @@ def test_realtime_bins_multi_read_reads_on_the_gpu(hip, gold, tmp_path, monkeypa
             for sub in ('channel_id', 'tracking_id', 'context_tags'):
                 assert dict(mine[sub].attrs.items()) == dict(theirs[sub].attrs.items())
     assert sum(len(files) for _, _, files in os.walk(str(out_dir))) == 31
+
+
+# ---- inflating on the GPU -----------------------------------------------------------------------
+def every_fixture_file():
+    import glob
+    fast5 = os.path.join(GOLD, 'fast5')
+    return (sorted(glob.glob(os.path.join(fast5, 'multi', '*.fast5'))) +
+            sorted(glob.glob(os.path.join(fast5, 'single', '*.fast5'))) +
+            sorted(glob.glob(os.path.join(fast5, 'h5py_variants', '*.fast5'))))
+
+
+@pytest.mark.parametrize('host_inflate_above', [0, 20000, 1])
+def test_raw_batches_decoded_on_the_gpu_are_the_loaders_samples(hip, hip_models, host_inflate_above):
+    """Every committed fast5 file - the real MinKNOW containers, the one-read files, the 32 h5py
+    variants (both on-disk generations, every layout, storage kind and filter, chunk indexes of
+    every kind, sparse datasets) - as a raw batch through dbh_classify_pair_deflated: the decoded
+    signals are bit for bit what the CPU loader (pinned to h5py and to the reference's own
+    loader) returns, the calls what the CPU-loaded samples give; whichever side inflates (all
+    streams on the GPU; long ones on the host; every stream on the host)."""
+    from deepbinner_amd import fast5_native
+    start, end = hip_models[START], hip_models[END]
+    files = every_fixture_file()
+    assert len(files) >= 40
+    seen_zlib = seen_stored = 0
+    for index, ids, offsets, status, comp, records in fast5_native.stream_raw(
+            files, threads=4, depth=3, host_inflate_above=host_inflate_above):
+        path = files[index]
+        try:
+            want = fast5_native.load_reads(path, threads=2)
+        except OSError:
+            assert ids is None, path
+            continue
+        assert ids == want[0] and np.array_equal(offsets, want[2]) and \
+            np.array_equal(status, want[3]), path
+        calls, stream_status, samples = hip.classify_pair_deflated(
+            start, end, comp, records, offsets, 6144, 0.5, want_samples=True)
+        assert (stream_status == 0).all(), (path, stream_status)
+        assert np.array_equal(samples, want[1]), path
+        want_calls = hip.classify_pair(start, end, want[1], want[2], 6144, 0.5)
+        assert np.array_equal(calls, want_calls), path
+        seen_zlib += int((records['mode'] == 0).sum())
+        seen_stored += int((records['mode'] == 1).sum())
+    assert seen_stored > 0 and (seen_zlib > 40 or host_inflate_above == 1)
+
+
+def test_realtime_with_and_without_gpu_inflate(hip, gold, containers, tmp_path, monkeypatch, capsys):
+    """The 100,000-read stream again, inflated by the GPU (the default) and by the host's threads
+    (DEEPBINNER_GPU_INFLATE=0): the same table, row for row; and a container with a damaged chunk
+    and an unreadable read gives what the CPU path gives (zlib on the host has the last word)."""
+    import time
+    directory, paths, every_id = containers
+    monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '1')
+    t0 = time.perf_counter()
+    on, _ = run_realtime(directory, str(tmp_path / 'gpu'), 1, monkeypatch, capsys)
+    seconds = time.perf_counter() - t0
+    print('realtime, GPU inflate: %d reads in %.1f s = %.0f reads/s' % (len(on), seconds,
+                                                                         len(on) / seconds))
+    monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '0')
+    off, _ = run_realtime(directory, str(tmp_path / 'cpu'), 1, monkeypatch, capsys)
+    assert on == off and len(on) == len(every_id)
+    # damage: one byte in the middle of a deflate stream of one container
+    from deepbinner_amd import fast5_native
+    broken_dir = tmp_path / 'broken'
+    broken_dir.mkdir()
+    victim = str(broken_dir / 'stream_00.fast5')
+    data = bytearray(open(paths[0], 'rb').read())
+    gen = fast5_native.stream_raw([paths[0]], threads=2)
+    _, ids, offsets, status, comp, records = next(gen)
+    gen.close()
+    rec = records[len(records) // 2]
+    chunk = bytes(comp[rec['comp_offset']:rec['comp_offset'] + rec['comp_bytes']])
+    at = bytes(data).find(chunk)
+    assert at > 0
+    data[at + len(chunk) // 2] ^= 0x5A
+    with open(victim, 'wb') as f:
+        f.write(bytes(data))
+    tables = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', flag)
+        tables[flag], _ = run_realtime(str(broken_dir), str(tmp_path / ('broken_out_' + flag)), 1,
+                                       monkeypatch, capsys)
+    assert tables['1'] == tables['0']
+    assert len(tables['1']) in (READS_PER_CONTAINER + 1, READS_PER_CONTAINER + 2) or \
+        len(tables['1']) >= READS_PER_CONTAINER

@@ -29,6 +29,10 @@ def main():
     end_w, _ = ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models',
                                               'EXP-NBD103_read_ends.dbw'))
     end_model = hip_backend.HipModel(end_w, device=0)
+    if len(sys.argv) > 2:              # windows per model and group of the pipeline (A/B knob)
+        model.set_host_group(int(sys.argv[2]))
+        end_model.set_host_group(int(sys.argv[2]))
+        out['host_group_windows'] = int(sys.argv[2])
     for label, length, scan in (('1024-sample reads, scan 512 (1 window/read)', 1024, 512),
                                 ('6656-sample reads, scan 6144 (12 windows/read)', 6656, 6144),
                                 ('13312-sample reads, scan 6144, start + end models + '
