@@ -362,6 +362,23 @@ const char* dbh_last_error(void) { return g_last_error.c_str(); }
 int dbh_device_count(int* count) {
     if (!count) return DBH_ERR_INVALID_ARGUMENT;
     int n = 0;
+    // A host thread that waits for the GPU sleeps instead of spinning: the hosts this runs on
+    // have few cores per GPU (profiles/r03_cpu_capacity.txt) and the loader wants them.  Must be
+    // said before the runtime creates its context; DEEPBINNER_SPIN_WAIT=1 keeps the default.
+    static const bool once = [] {
+        const char* spin = std::getenv("DEEPBINNER_SPIN_WAIT");
+        if (!(spin && spin[0] == '1')) {
+            int devices = 0;
+            if (hipGetDeviceCount(&devices) == hipSuccess)
+                for (int d = 0; d < devices; ++d)
+                    if (hipSetDevice(d) == hipSuccess)
+                        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+            if (devices > 0) (void)hipSetDevice(0);
+            (void)hipGetLastError();
+        }
+        return true;
+    }();
+    (void)once;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
         *count = 0;

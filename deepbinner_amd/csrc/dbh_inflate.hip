@@ -102,22 +102,34 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
             tok = tokens + s.out_offset;          // one token slot per byte of output
         }
     }
+    // (a store per token and lane is 32 partial cache lines per step: four tokens wait in
+    // registers for one 16-byte store)
+    auto emit = [&](uint32_t token) {
+        const int k = n_tok & 3;
+        if (k == 3) {
+            uint32_t four[4] = {t0, t1, t2, token};
+            __builtin_memcpy(tok + (n_tok - 3), four, 16);
+        }
+        t0 = k == 0 ? token : t0;
+        t1 = k == 1 ? token : t1;
+        t2 = k == 2 ? token : t2;
+        ++n_tok;
+    };
     while (__any(L.state != dbi::kDone)) {
+        // the rare states: a block header (with its two table builds), a stored block's bytes
         if (L.state == dbi::kNeedBlock) {
             dbi::lane_block(L, mem);
-        } else if (L.state != dbi::kDone) {
+        } else if (L.state == dbi::kStored) {
             uint32_t token;
-            if (dbi::lane_step(L, mem, &token)) {
-                // (a store per token and lane is 32 partial cache lines per step)
-                const int k = n_tok & 3;
-                if (k == 3) {
-                    uint32_t four[4] = {t0, t1, t2, token};
-                    __builtin_memcpy(tok + (n_tok - 3), four, 16);
-                }
-                t0 = k == 0 ? token : t0;
-                t1 = k == 1 ? token : t1;
-                t2 = k == 2 ? token : t2;
-                ++n_tok;
+            if (dbi::lane_step(L, mem, &token)) emit(token);
+        }
+        // the hot loop: every lane that is inside a Huffman block decodes one token per round
+        // (lanes that have left their block wait for the others - streams deflated alike leave
+        // together)
+        while (__any(L.state == dbi::kDecode)) {
+            if (L.state == dbi::kDecode) {
+                uint32_t token;
+                if (dbi::lane_decode(L, mem, &token)) emit(token);
             }
         }
     }

@@ -30,6 +30,14 @@
 
 namespace dbi {
 
+#if defined(__HIPCC__)
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+#else
+struct U4 {
+    uint32_t x, y, z, w;
+};
+#endif
+
 constexpr int kLitRoot = 10, kDistRoot = 8;
 constexpr int kLitEntries = 1408;        // 1,024 root + sub-tables (more needed: stream refused)
 constexpr int kDistEntries = 448;        // 256 root + sub-tables
@@ -81,82 +89,100 @@ DBI_HD int cl_order(int i) {
 struct BitReader {
     const uint8_t* in;
     uint32_t limit_bits;   // bits of the stream (deflate data + trailer): streams are < 512 MB
-    uint32_t fetch;        // byte offset of the first dword NOT yet moved into the bit buffer
-    uint64_t bb;
-    int nb;
-    // Sixteen bytes in hand (q0 = next) and the sixteen behind them already requested: a lane
-    // needs a new 64-byte line of its stream every ~40 tokens, the 32 lanes of a wave step
-    // together, and a wave waits for its slowest lane - with one dword of look-ahead nearly every
-    // step waited for an HBM round trip of SOME lane (2,500 cycles per token).  Sixteen bytes are
-    // ~10 tokens of slack.
+    uint32_t bp;           // bits consumed so far = position of the next bit
+    uint32_t base;         // position of bit 0 of `lo` (a multiple of 32, <= bp)
+    uint32_t lo, hi;       // the 64 bits from `base` on: everything is 32-bit arithmetic, the
+                           // next 32 bits are ONE v_alignbit_b32 away
+    // Sixteen bytes in hand behind those (q0 = next) and the sixteen after them already
+    // requested: a lane needs a new 64-byte line of its stream every ~40 tokens, the lanes of a
+    // wave step together, and a wave waits for its slowest lane.
     uint32_t q0, q1, q2, q3;
-    uint32_t a0, a1, a2, a3;
-    int left;              // dwords of q still unused (4 .. 1)
+    U4 ahead;              // (kept as ONE 128-bit value until it is needed: taken apart earlier,
+                           // the compiler waits for the load where it is issued)
+    int left;              // dwords of q still unused
+    uint32_t fetch;        // byte offset of the sixteen bytes to request next
 
-    // (no bounds checks and no masking: the buffer is readable for 48 bytes beyond the stream -
+    // (no bounds checks and no masking: the buffer is readable for 64 bytes beyond the stream -
     // the next stream, or the padding - and bits from beyond the stream are never CONSUMED
     // unnoticed: overrun() after every token)
-    DBI_HD void load16(uint32_t at, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) const {
+    DBI_HD U4 load16(uint32_t at) const {
+        U4 v;
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t w[4];
-        __builtin_memcpy(w, in + at, 16);      // (one unaligned 16-byte global load)
-        w0 = w[0];
-        w1 = w[1];
-        w2 = w[2];
-        w3 = w[3];
+        __builtin_memcpy(&v, in + at, 16);     // (one unaligned 16-byte global load)
 #else
-        uint32_t* out[4] = {&w0, &w1, &w2, &w3};
+        uint32_t w[4];
         for (int k = 0; k < 4; ++k) {
             const uint8_t* p = in + at + 4 * k;
-            *out[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) |
-                      ((uint32_t)p[3] << 24);
+            w[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) |
+                   ((uint32_t)p[3] << 24);
         }
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
 #endif
+        return v;
     }
     DBI_HD void start(const uint8_t* data, int64_t n_bytes) {
         in = data;
         limit_bits = (uint32_t)n_bytes * 8u;
-        load16(0, q0, q1, q2, q3);
-        load16(16, a0, a1, a2, a3);
-        bb = (uint64_t)q0;
-        nb = 32;
-        fetch = 4;
+        const U4 first = load16(0);
+        lo = first.x;
+        hi = first.y;
+        q0 = first.z;
+        q1 = first.w;
+        ahead = load16(16);
+        q2 = q3 = 0;
+        left = 2;
+        fetch = 32;
+        bp = base = 0;
+    }
+    // `lo` leaves the window, the next dword enters it
+    DBI_HD void shift() {
+        lo = hi;
+        hi = q0;
         q0 = q1;
         q1 = q2;
         q2 = q3;
-        left = 3;
-    }
-    DBI_HD void refill() {             // afterwards nb >= 33
-        if (nb <= 32) {
-            bb |= (uint64_t)q0 << nb;
-            nb += 32;
-            fetch += 4;
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
-            if (--left == 0) {         // the sixteen bytes asked for a while ago; ask for more
-                q0 = a0;
-                q1 = a1;
-                q2 = a2;
-                q3 = a3;
-                left = 4;
-                load16(fetch + 16, a0, a1, a2, a3);
-            }
+        base += 32;
+        if (--left == 0) {             // the sixteen bytes asked for a while ago; ask for more
+            q0 = ahead.x;
+            q1 = ahead.y;
+            q2 = ahead.z;
+            q3 = ahead.w;
+            left = 4;
+            ahead = load16(fetch);
+            fetch += 16;
         }
     }
-    DBI_HD uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
-    DBI_HD void drop(int n) {
-        bb >>= n;
-        nb -= n;
+    // Normal form: the next bit lies in `lo`.  At most 32 bits may be consumed between two calls
+    // (then one shift restores it); afterwards at least 33 bits are in the window.
+    DBI_HD void refill() {
+        if (bp - base >= 32u) shift();
     }
-    DBI_HD uint32_t take(int n) {      // n <= 16, buffer refilled beforehand
+    // the next 32 bits, in normal form
+    DBI_HD uint32_t window() const {
+        const uint32_t sh = bp & 31u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+    }
+    // the next n <= 16 bits, anywhere in the window (the header code's sequences of small fields)
+    DBI_HD uint32_t peek(int n) const {
+        const uint32_t sh = bp - base;       // 0 .. 63
+        const uint32_t w = sh < 32u ? (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) : hi >> (sh - 32u);
+        return w & ((1u << n) - 1u);
+    }
+    DBI_HD void drop(int n) { bp += (uint32_t)n; }
+    DBI_HD uint32_t take(int n) {
         const uint32_t v = peek(n);
         drop(n);
         return v;
     }
-    // bits consumed so far, and whether that is more than the stream holds
-    DBI_HD uint32_t consumed_bits() const { return fetch * 8u - (uint32_t)nb; }
-    DBI_HD bool overrun() const { return consumed_bits() > limit_bits; }
+    DBI_HD uint32_t consumed_bits() const { return bp; }
+    DBI_HD bool overrun() const { return bp > limit_bits; }
     DBI_HD int64_t limit_bytes() const { return (int64_t)(limit_bits >> 3); }
 };
 
@@ -271,13 +297,15 @@ struct DistTab {
 };
 
 // Decodes one symbol of the code whose table `get(e)` reads: -> symbol, or -1 (no such code).
+// The reader is in normal form (refill() since the last 32 bits were consumed).
 template <class Get>
 DBI_HD int decode_symbol(BitReader& br, int root, const Get& get) {
-    uint16_t e = get((int)br.peek(root));
+    const uint32_t w = br.window();
+    uint16_t e = get((int)(w & ((1u << root) - 1u)));
     int base_bits = 0;
     if (e & 0x8000u) {
         const int sub_bits = e & 15, off = (e >> 4) & 0x7FF;
-        e = get(off + (int)((br.bb >> root) & ((1u << sub_bits) - 1u)));
+        e = get(off + (int)((w >> root) & ((1u << sub_bits) - 1u)));
         base_bits = root;
         if (e & 0x8000u) return -1;
     }
@@ -335,7 +363,7 @@ DBI_HD void lane_block(Lane& L, Mem& mem) {
     const int type = (int)br.take(2);
     if (type == 3) return lane_fail(L, kBadBlock);
     if (type == 0) {
-        br.drop(br.nb & 7);                     // to the byte boundary (nb and position agree mod 8)
+        br.drop((int)((8u - (br.bp & 7u)) & 7u));       // to the byte boundary
         br.refill();
         const uint32_t len = br.take(16);
         br.refill();
@@ -482,6 +510,74 @@ DBI_HD bool lane_step(Lane& L, Mem& mem, uint32_t* token) {
     *token = match_token(length, distance);
     L.out_pos += length;
     return true;
+}
+
+// The hot path: ONE token of a lane that is inside a Huffman block (state kDecode), written to be
+// cheap when 32 lanes run it together - one pass over straight-line code with two conditional
+// regions (a linked sub-table; the distance half of a match) instead of a state machine: the
+// general lane_step costs ~300 instructions per token and wave, this ~120.
+// Returns true with *token set when a token was produced; the lane's state, status, position
+// and reader are updated as lane_step would.
+template <class Mem>
+DBI_HD bool lane_decode(Lane& L, Mem& mem, uint32_t* token) {
+    BitReader& br = L.br;
+    br.refill();
+    const uint32_t w = br.window();
+    uint32_t e = mem.lit((int)(w & ((1u << kLitRoot) - 1u)));
+    uint32_t used = 0;
+    if (e & 0x8000u) {
+        e = mem.lit((int)(((e >> 4) & 0x7FFu) + ((w >> kLitRoot) & ((1u << (e & 15u)) - 1u))));
+        used = kLitRoot;
+    }
+    const uint32_t len = e & 15u, sym = (e >> 4) & 0x1FFu;
+    bool bad = len == 0 || (e & 0x8000u) || sym > 285u;
+    used += len;
+    uint32_t tk = sym;
+    int produced = 1;
+    if (sym > 256u && !bad) {
+        const int c = (int)sym - 257;
+        const int eb = len_extra(c);
+        int length = len_base(c) + (int)((w >> used) & ((1u << eb) - 1u));
+        br.bp += used + (uint32_t)eb;
+        br.refill();
+        const uint32_t w1 = br.window();
+        uint32_t e2 = mem.dist((int)(w1 & ((1u << kDistRoot) - 1u)));
+        uint32_t used2 = 0;
+        if (e2 & 0x8000u) {
+            e2 = mem.dist((int)(((e2 >> 4) & 0x7FFu) +
+                                ((w1 >> kDistRoot) & ((1u << (e2 & 15u)) - 1u))));
+            used2 = kDistRoot;
+        }
+        const uint32_t dlen = e2 & 15u, d = (e2 >> 4) & 0x1FFu;
+        bad = dlen == 0 || (e2 & 0x8000u) || d > 29u;
+        used2 += dlen;
+        const int db = dist_extra((int)d);
+        const int distance = dist_base((int)d) + (int)((w1 >> used2) & ((1u << db) - 1u));
+        br.bp += used2 + (uint32_t)db;
+        if (L.out_pos + length > L.out_cap) {          // more data than wanted: keep what is
+            length = L.out_cap - L.out_pos;
+            L.state = kDone;
+        }
+        tk = match_token(length, distance);
+        produced = length;
+    } else {
+        br.bp += used;
+        if (sym == 256u && !bad) {
+            produced = 0;
+            L.state = kNeedBlock;
+        } else if (L.out_pos >= L.out_cap) {           // a literal beyond what is wanted
+            produced = 0;
+            L.state = kDone;
+        }
+    }
+    if (bad || br.overrun()) {
+        lane_fail(L, bad ? kBadSymbol : kTruncated);
+        return false;
+    }
+    if (sym == 256u && L.final_block) lane_ended(L);
+    L.out_pos += produced;
+    *token = tk;
+    return produced > 0;
 }
 
 }  // namespace dbi

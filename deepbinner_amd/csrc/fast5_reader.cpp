@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <functional>
 #include <map>
 #include <memory>
@@ -1893,6 +1894,7 @@ struct f5_stream {
     int depth = 3;
     bool raw = false;                // hand out the Signal pieces as stored (f5_stream_open_raw)
     int64_t zlib_above = 0;          // ... except deflate streams longer than this: host-inflated
+    int host_share = 0;              // ... and the longest ones holding this share (%) of the bytes
     std::mutex m;
     std::condition_variable work_cv, done_cv;
     std::deque<std::unique_ptr<Container>> inflight;      // in path order
@@ -2013,6 +2015,34 @@ struct f5_stream {
             if (!raw) {
                 c->batch->samples.resize((size_t)total);
                 return;
+            }
+            // A share of the inflating for the host: with host_share > 0 the longest deflate streams
+            // holding that share (per cent) of the container's compressed bytes are left to the
+            // host's threads - long streams are what a CPU core is good at (a stream is one
+            // lane's work on the GPU however long it is) and what is left for the GPU is of even
+            // length.
+            if (host_share > 0) {
+                std::vector<int64_t> sizes;
+                int64_t all = 0;
+                for (int64_t i = 0; i < c->count; ++i)
+                    if (c->batch->status[(size_t)i] == F5_OK)
+                        for (const Fast5::RawPiece& p : c->pieces[(size_t)i])
+                            if (p.kind == Fast5::kZlib) {
+                                sizes.push_back((int64_t)p.nbytes);
+                                all += (int64_t)p.nbytes;
+                            }
+                std::sort(sizes.begin(), sizes.end(), std::greater<int64_t>());
+                int64_t cut = INT64_MAX, taken = 0;
+                for (int64_t v : sizes) {
+                    if (taken * 100 >= all * host_share) break;
+                    taken += v;
+                    cut = v;
+                }
+                for (int64_t i = 0; i < c->count; ++i)
+                    if (c->batch->status[(size_t)i] == F5_OK)
+                        for (Fast5::RawPiece& p : c->pieces[(size_t)i])
+                            if (p.kind == Fast5::kZlib && (int64_t)p.nbytes >= cut)
+                                p.kind = Fast5::kHostDecode;
             }
             // raw: every piece gets its place in the byte buffer (what it occupies there: the
             // stored bytes, or - decoded by the host - its samples) and its record; the records
@@ -2232,7 +2262,10 @@ int f5_stream_open_raw(const char* const* paths, int64_t n_paths, int n_threads,
         {
             std::lock_guard<std::mutex> g(s->m);
             s->raw = true;
-            s->zlib_above = host_inflate_above;
+            // (>= 0: a length in bytes; < 0: minus the host's share of the bytes in per cent)
+            s->zlib_above = host_inflate_above > 0 ? host_inflate_above : 0;
+            s->host_share = host_inflate_above < 0
+                                ? (int)std::min<int64_t>(100, -host_inflate_above) : 0;
             s->admit_locked();
         }
         const int threads = thread_count(n_threads);

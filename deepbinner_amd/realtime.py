@@ -34,6 +34,36 @@ POLL_SECONDS = 5
 PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 
 
+def host_inflate_share(n_gpus):
+    """Per cent of a container's compressed bytes the host's threads inflate themselves (its
+    longest streams); the GPUs inflate the rest.  100 = everything on the host (the CPU-only
+    loader path), 0 = everything on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end,
+    DEEPBINNER_HOST_INFLATE_SHARE=<per cent> any split.
+
+    Left alone, the host does all of it unless it is starved of cores: measured on an MI355X box
+    (profiles/r03_multi_read_rate_gpu_inflate.json; 27 k-sample reads, gzip 1) a core inflates a
+    read in 118 us and fetches it raw in 10, a GPU classifies it (start + end models) in 4.7 us
+    and inflates it in ~8 us at best (three containers in flight) - a whole MI355X inflates like
+    ~50 EPYC cores, and every microsecond of it is taken from the classification.  With 16 cores
+    per GPU (this box) the host alone keeps up with ~60 % of what the GPU can classify and any
+    share given to the GPU lowers the total (the split sweep in that file); below six cores per
+    GPU - eight GPUs on a 16-core host: one host feeding eight GPUs is BASELINE.json configs[4] -
+    the GPUs take the share that loads both sides evenly."""
+    flag = os.environ.get('DEEPBINNER_GPU_INFLATE')
+    if flag == '0':
+        return 100
+    if flag == '1':
+        return 0
+    explicit = os.environ.get('DEEPBINNER_HOST_INFLATE_SHARE')
+    if explicit:
+        return max(0, min(100, int(explicit)))
+    cores, gpus = float(usable_cpus()), float(max(n_gpus, 1))
+    if cores / gpus >= 6.0:
+        return 100
+    r = (128.0 / cores - 4.7 / gpus) / (118.0 / cores + 8.0 / gpus)
+    return int(round(100 * (1.0 - max(0.0, min(1.0, r)))))
+
+
 def bin_name(barcode_call):
     """Directory a call is filed under (reference realtime.py:146-150)."""
     return 'unclassified' if barcode_call == 'none' else 'barcode%02d' % int(barcode_call)
@@ -201,16 +231,15 @@ class Session:
         signal = (lambda i: samples[offsets[i]:offsets[i + 1]]) if not self.table_only else None
         return number, path, ids, names, signal
 
-    # The same with the inflating on the GPU (DEEPBINNER_GPU_INFLATE=0 turns it off): the loader
-    # hands over the Signal chunks as stored - zlib streams, 85 % of what loading a read costs a
-    # CPU core is inflating them, and a host has few cores per GPU - and
-    # dbh_classify_pair_deflated does the rest.  Streams above DEEPBINNER_HOST_INFLATE_ABOVE bytes
-    # (default 128 KiB: a lane of the GPU decoder walks ONE stream) stay with the host's threads.
-    def _raw_containers(self, fast5s):
+    # The same with (part of) the inflating on the GPU: the loader hands over Signal chunks as
+    # stored - zlib streams; 85 % of what loading a read costs a CPU core is inflating them, and a
+    # host has few cores per GPU - and dbh_classify_pair_deflated does the
+    # rest.  The host's threads keep the longest streams of every container (a lane of the GPU
+    # decoder walks ONE stream, however long): `host_inflate_share` of the bytes.
+    def _raw_containers(self, fast5s, host_share):
         from . import fast5_native
         threads = int(getattr(self.args, 'loader_procs', 0) or 0)
-        above = int(os.environ.get('DEEPBINNER_HOST_INFLATE_ABOVE', 128 << 10))
-        stream = fast5_native.stream_raw(fast5s, threads=threads, host_inflate_above=above,
+        stream = fast5_native.stream_raw(fast5s, threads=threads, host_inflate_above=-host_share,
                                          depth=int(os.environ.get('DEEPBINNER_LOADER_DEPTH', 0)))
         for index, ids, offsets, status, comp, records in stream:
             if ids is None:
@@ -295,16 +324,17 @@ class Session:
 
         models = [m for m in (self.start_model, self.end_model) if m is not None]
         packed = reader_kind() == 'native' and all(hasattr(m, 'classify_packed') for m in models)
-        if packed and os.environ.get('DEEPBINNER_GPU_INFLATE', '1') != '0' and \
-                all(hasattr(m, 'handle') for m in models):
-            items, work = self._raw_containers(fast5s), self._classify_raw_container
+        replicas = classify.device_replicas(self.start_model, self.end_model)
+        host_share = host_inflate_share(len({getattr(r[0] or r[1], 'device', 0) for r in replicas}))
+        if packed and host_share < 100 and all(hasattr(m, 'handle') for m in models):
+            items = self._raw_containers(fast5s, host_share)
+            work = self._classify_raw_container
         elif packed:
             items, work = self._packed_containers(fast5s), self._classify_container
         else:
             items, work = self._read_chunks(fast5s), self._classify_chunk
         metadata = MetadataSource() if not self.table_only else None
         # the units go round the devices the models are replicated on (one, usually)
-        replicas = classify.device_replicas(self.start_model, self.end_model)
         with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
             classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
             for number, path, ids, names, signal in classify.dispatch_batches(items, replicas, work):

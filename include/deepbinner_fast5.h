@@ -106,7 +106,9 @@ void f5_stream_close(f5_stream* stream);
  *     sample buffer (byte offsets) and how many bytes of it are wanted, and whether it is a zlib
  *     stream (F5_RAW_ZLIB) or the bytes themselves (F5_RAW_STORED: unfiltered data, chunks with
  *     filters beyond deflate / fletcher32 - inflated and unshuffled by the host after all - and
- *     deflate streams longer than host_inflate_above bytes; <= 0: never).  `reserved` = the
+ *     the deflate streams the host is to keep: those longer than host_inflate_above bytes, or,
+ *     with host_inflate_above = -p (1..100), the longest ones of each container holding p per
+ *     cent of its compressed bytes; 0: none).  `reserved` = the
  *     index of the read the piece belongs to.  Layout identical to dbh_inflate_stream. */
 #define F5_RAW_ZLIB 0
 #define F5_RAW_STORED 1

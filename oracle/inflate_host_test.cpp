@@ -60,7 +60,9 @@ int main(int argc, char** argv) {
                 continue;
             }
             uint32_t token = 0;
-            if (dbi::lane_step(L, mem, &token)) {
+            // (kDecode: the hot path the kernel runs; the rest through the general step)
+            if (L.state == dbi::kDecode ? dbi::lane_decode(L, mem, &token)
+                                        : dbi::lane_step(L, mem, &token)) {
                 tokens.push_back(token);
             }
         }

@@ -13,7 +13,10 @@ without it, by this package's own container writer (hdf5_write.multi_read_fast5_
   2. the GPU side alone: the containers' packed batches already in (pinned) host memory, both
      models + combine_calls per container in one dbh_classify_pair_i16 call;
   3. both together through the dispatcher, per number of device queues (on a one-GPU box the
-     queues beyond the first share GPU 0) - and which of the two bounds the whole.
+     queues beyond the first share GPU 0) - and which of the two bounds the whole;
+  4. the same with the inflating moved to the GPU (f5_stream_open_raw -> dbh_classify_pair_deflated):
+     the host's share per read (CPU seconds of the whole process per read), the raw loader alone,
+     and the device's time per stage (upload / inflate / classify).
 Usage: python tools/multi_read_rate.py [--files 16] [--reads 4000] [--mean-length 27000]"""
 import argparse
 import io
@@ -181,21 +184,105 @@ def main():
             t0 = time.perf_counter()
             done = sum(classify.dispatch_batches(iter(loaded * 3), replicas, work))
             gpu_rate = done / (time.perf_counter() - t0)
-            best = 0.0
+            best, best_cpu = 0.0, 0.0
             for _ in range(2):
-                t0 = time.perf_counter()
+                t0, c0 = time.perf_counter(), time.process_time()
                 stream = fast5_native.stream_reads(paths, keep=keep, threads=loader_team, depth=4)
                 done = sum(classify.dispatch_batches(stream, replicas, work))
-                best = max(best, done / (time.perf_counter() - t0))
+                wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+                if done / wall > best:
+                    best, best_cpu = done / wall, cpu / done
             assert done == total
             per_queues['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
                 'gpu_side_alone_reads_per_s': round(gpu_rate),
                 'loader_alone_reads_per_s': round(loader_rate),
                 'load_and_classify_reads_per_s': round(best),
+                'host_cpu_us_per_read': round(best_cpu * 1e6, 1),
                 'bound_by': 'loader' if loader_rate < gpu_rate else 'gpu side'}
         os.environ.pop('DEEPBINNER_DEVICE_ORDINALS', None)
         out['stream -> dispatcher -> dbh_classify_pair_i16 (start + end models, scan 6144, '
             '%d loader threads)' % loader_team] = per_queues
+        # ---- 4. inflate on the GPU -------------------------------------------------------------
+        from deepbinner_amd import realtime
+        share = realtime.host_inflate_share(1)
+        above = -share
+        out['host_inflate_share_per_cent (realtime.host_inflate_share: %d usable cpus, 1 GPU)'
+            % classify.usable_cpus()] = share
+        raw_rates = {}
+        for threads in (1, 2, 4, 8, 16):
+            if threads > cpus:
+                continue
+            t0, c0 = time.perf_counter(), time.process_time()
+            n = 0
+            for item in fast5_native.stream_raw(paths, threads=threads, depth=4,
+                                                host_inflate_above=0):
+                n += len(item[1])
+            wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+            raw_rates['%d threads' % threads] = {'reads_per_s': round(n / wall),
+                                                 'cpu_us_per_read': round(cpu / n * 1e6, 1)}
+        out['raw loader alone (chunks as stored, nothing inflated)'] = raw_rates
+
+        def raw_work(item, start_replica, end_replica):
+            _, ids, offsets, _, comp, records = item
+            calls, status = hip_backend.classify_pair_deflated(
+                start_replica, end_replica, comp, records, offsets, 6144, 0.5)
+            assert (status == 0).all()
+            return len(calls)
+
+        gpu_inflate = {}
+        team = min(16, classify.usable_cpus())
+        # the split: from everything on the GPU to everything on the host, one device queue
+        sweep = {}
+        replicas, _ = load_models(1)
+        for host_share in (0, 20, 40, 60, 80, 100):
+            best, best_cpu = 0.0, 0.0
+            for _ in range(2):
+                t0, c0 = time.perf_counter(), time.process_time()
+                stream = fast5_native.stream_raw(paths, threads=team, depth=4,
+                                                 host_inflate_above=-host_share)
+                done = sum(classify.dispatch_batches(stream, replicas, raw_work))
+                wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+                if done / wall > best:
+                    best, best_cpu = done / wall, cpu / done
+            sweep['host inflates %d %% of the bytes' % host_share] = {
+                'load_and_classify_reads_per_s': round(best),
+                'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}
+        gpu_inflate['split sweep, 1 queue, %d loader threads' % team] = sweep
+        raw_loaded = list(fast5_native.stream_raw(paths[:4], threads=8, depth=4,
+                                                  host_inflate_above=above))
+        for n_queues in (1, 2, 3):
+            replicas, ordinals = load_models(n_queues)
+            if n_queues == 1:
+                stages = [hip_backend.classify_pair_deflated(
+                    replicas[0][0], replicas[0][1], item[4], item[5], item[2], 6144, 0.5,
+                    want_stages=True)[2] for item in raw_loaded * 2][len(raw_loaded):]
+                gpu_inflate['device_ms_per_container (upload, inflate, classify)'] = [
+                    round(float(sum(s[k] for s in stages) / len(stages)), 2) for k in range(3)]
+                rec = raw_loaded[0][5]
+                gpu_inflate['streams_per_container'] = {
+                    'zlib (GPU)': int((rec['mode'] == 0).sum()),
+                    'stored / host-inflated': int((rec['mode'] == 1).sum())}
+            sum(classify.dispatch_batches(iter(raw_loaded[:2]), replicas, raw_work))       # warm-up
+            t0 = time.perf_counter()
+            done = sum(classify.dispatch_batches(iter(raw_loaded * 4), replicas, raw_work))
+            gpu_rate = done / (time.perf_counter() - t0)
+            best, best_cpu = 0.0, 0.0
+            for _ in range(2):
+                t0, c0 = time.perf_counter(), time.process_time()
+                stream = fast5_native.stream_raw(paths, threads=team, depth=4,
+                                                 host_inflate_above=above)
+                done = sum(classify.dispatch_batches(stream, replicas, raw_work))
+                wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+                if done / wall > best:
+                    best, best_cpu = done / wall, cpu / done
+            assert done == total
+            gpu_inflate['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
+                'gpu_side_alone_reads_per_s': round(gpu_rate),
+                'load_and_classify_reads_per_s': round(best),
+                'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}
+        os.environ.pop('DEEPBINNER_DEVICE_ORDINALS', None)
+        out['inflate shared with the GPU: raw stream -> dispatcher -> dbh_classify_pair_deflated '
+            '(host share %d %% unless stated)' % share] = gpu_inflate
         # the GPU side without the host path: 24 windows per read at the resident kernel rate
         out['note'] = ('GPU-resident ceiling for this workload: bench.py windows/s / 24 windows '
                        'per read (two models x 12 scan steps)')
