@@ -168,6 +168,7 @@ struct dbh_model {
     static constexpr int kSlots = 3;
     static constexpr int64_t kDefaultGroup = 32768;
     int64_t host_group_windows = kDefaultGroup;     // dbh_model_set_host_group
+    bool host_zero_copy = true;      // DEEPBINNER_HOST_ZERO_COPY=0: copy host samples to HBM first
     struct Slot {
         hipStream_t stream = nullptr;
         void* h_in = nullptr;   size_t h_in_bytes = 0;     // pinned
@@ -515,6 +516,8 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
     {
         const char* knob = std::getenv("DEEPBINNER_LAUNCH_PER_BATCH");
         m->launch_per_batch = knob && knob[0] == '1';
+        const char* zc = std::getenv("DEEPBINNER_HOST_ZERO_COPY");
+        m->host_zero_copy = !(zc && zc[0] == '0');
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
     if (e == hipSuccess)
@@ -939,7 +942,20 @@ int classify_host(const HostJob& job, const int16_t* samples_host, const int64_t
             src = (char*)sl.h_in + off_bytes;
         }
         hipError_t e = hipSuccess;
-        if (raw_bytes) e = hipMemcpyAsync(sl.d_in, src, raw_bytes, hipMemcpyHostToDevice, sl.stream);
+        // The samples reach the kernel either by a copy into HBM first, or not at all: the
+        // forward kernel asks for a window's 2 KB ~25,000 cycles before it needs them, which
+        // hides a PCIe round trip as well as an HBM one - so it can read pinned host memory in
+        // place.  (A copy between two launches cannot overlap them here: the persistent kernel
+        // fills every CU's registers and LDS, and the copy of the next group only starts when
+        // it has drained - 1.2 ms of idle GPU per 6 ms group, profiles/r03_host_path_trace.txt.)
+        const int16_t* d_samples = (const int16_t*)sl.d_in;
+        if (raw_bytes && m->host_zero_copy) {
+            void* mapped = nullptr;
+            e = hipHostGetDevicePointer(&mapped, const_cast<void*>(src), 0);
+            d_samples = (const int16_t*)mapped;
+        } else if (raw_bytes) {
+            e = hipMemcpyAsync(sl.d_in, src, raw_bytes, hipMemcpyHostToDevice, sl.stream);
+        }
         if (e == hipSuccess)
             e = hipMemcpyAsync((char*)sl.d_in + sample_bytes, rel, off_bytes, hipMemcpyHostToDevice,
                                sl.stream);
@@ -948,7 +964,7 @@ int classify_host(const HostJob& job, const int16_t* samples_host, const int64_t
         for (int j = 0; j < 2; ++j) {
             if (!job.model[j]) continue;
             d_calls[j] = (int32_t*)((char*)sl.d_out + out_off[2 + j]);
-            st = classify_i16_dev(job.model[j], (const int16_t*)sl.d_in,
+            st = classify_i16_dev(job.model[j], d_samples,
                                   (const int64_t*)((char*)sl.d_in + sample_bytes), cnt, job.side[j],
                                   scan_size, score_diff, (float*)((char*)sl.d_out + out_off[j]),
                                   d_calls[j], sl.d_work, (dbh_stream)sl.stream, 0, uniform, s1 - s0,
