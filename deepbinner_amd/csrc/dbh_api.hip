@@ -1136,7 +1136,7 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
         if (e != hipSuccess) return done(hip_fail(e, "hipMemsetAsync"));
     }
     if (n_streams > 0) {
-        st = dbh_inflate_dev((const uint8_t*)d.d_comp, d_records, n_streams, out_bytes,
+        st = dbh_inflate_dev((const uint8_t*)d.d_comp, (int64_t)comp_bytes, d_records, n_streams, out_bytes,
                              (uint8_t*)d.d_samples, d.d_tokens, d_status, (dbh_stream)d.stream);
         if (st != DBH_OK) return done(st);
     }

@@ -37,29 +37,41 @@ namespace dbh_inflate_detail {
 
 using dbi::Lane;
 
-constexpr int kLanes = 32;                 // streams per workgroup of kernel 1
+constexpr int kLanes = 64;                 // streams per workgroup of kernel 1: one wavefront
 // LDS of kernel 1, every array interleaved by lane ([entry][lane]): consecutive lanes hit
-// consecutive addresses whatever entry each of them wants
-constexpr int kLitOff = 0;                                          // uint16 units
-constexpr int kDistOff = kLitOff + dbi::kLitEntries * kLanes;
-constexpr int kWorkOff = kDistOff + dbi::kDistEntries * kLanes;
-constexpr int kLensOff16 = kWorkOff + dbi::kMaxSyms * kLanes;       // then kMaxLens bytes per lane
-constexpr int kLdsBytes1 = kLensOff16 * 2 + dbi::kMaxLens * kLanes;
-static_assert(kLdsBytes1 <= 160 * 1024, "kernel 1's tables exceed the CU's LDS");
+// consecutive addresses whatever entry each of them wants.  76.5 KB: two workgroups per CU.
+constexpr int kRingOff = 0;                                              // u32 [34][64]
+constexpr int kLitPairOff = kRingOff + dbi::kRingStore * kLanes * 4;     // u32 [16][64]
+constexpr int kDistPairOff = kLitPairOff + 16 * kLanes * 4;              // u32 [16][64]
+constexpr int kLitSymOff = kDistPairOff + 16 * kLanes * 4;               // u16 [288][64]
+constexpr int kCntOff = kLitSymOff + dbi::kLitSyms * kLanes * 2;         // u16 [16][64]
+constexpr int kDistSymOff = kCntOff + 16 * kLanes * 2;                   // u8 [32][64]
+constexpr int kLensOff = kDistSymOff + dbi::kDistSyms * kLanes;          // u8 [320][64]
+constexpr int kLdsBytes1 = kLensOff + dbi::kMaxLens * kLanes;
+static_assert(2 * kLdsBytes1 <= 160 * 1024, "two workgroups of kernel 1 no longer fit a CU");
 
 struct LdsMem {
-    uint16_t* lit_;
-    uint16_t* dist_;
-    uint16_t* work_;
+    uint32_t* ring_;
+    uint32_t* lit_pair_;
+    uint32_t* dist_pair_;
+    uint16_t* lit_sym_;
+    uint16_t* cnt_;
+    uint8_t* dist_sym_;
     uint8_t* lens_;
-    __device__ __forceinline__ uint16_t lit(int e) const { return lit_[e * kLanes]; }
-    __device__ __forceinline__ uint16_t dist(int e) const { return dist_[e * kLanes]; }
-    __device__ __forceinline__ void set_lit(int e, uint16_t v) { lit_[e * kLanes] = v; }
-    __device__ __forceinline__ void set_dist(int e, uint16_t v) { dist_[e * kLanes] = v; }
+    __device__ __forceinline__ uint32_t ring(int r) const { return ring_[r * kLanes]; }
+    __device__ __forceinline__ void set_ring(int r, uint32_t v) { ring_[r * kLanes] = v; }
     __device__ __forceinline__ int len(int i) const { return lens_[i * kLanes]; }
     __device__ __forceinline__ void set_len(int i, int v) { lens_[i * kLanes] = (uint8_t)v; }
-    __device__ __forceinline__ int work(int i) const { return work_[i * kLanes]; }
-    __device__ __forceinline__ void set_work(int i, int v) { work_[i * kLanes] = (uint16_t)v; }
+    __device__ __forceinline__ int cnt(int l) const { return cnt_[l * kLanes]; }
+    __device__ __forceinline__ void set_cnt(int l, int v) { cnt_[l * kLanes] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t lit_pair(int l) const { return lit_pair_[l * kLanes]; }
+    __device__ __forceinline__ void set_lit_pair(int l, uint32_t v) { lit_pair_[l * kLanes] = v; }
+    __device__ __forceinline__ uint32_t dist_pair(int l) const { return dist_pair_[l * kLanes]; }
+    __device__ __forceinline__ void set_dist_pair(int l, uint32_t v) { dist_pair_[l * kLanes] = v; }
+    __device__ __forceinline__ uint32_t lit_sym(int i) const { return lit_sym_[i * kLanes]; }
+    __device__ __forceinline__ void set_lit_sym(int i, uint32_t v) { lit_sym_[i * kLanes] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t dist_sym(int i) const { return dist_sym_[i * kLanes]; }
+    __device__ __forceinline__ void set_dist_sym(int i, uint32_t v) { dist_sym_[i * kLanes] = (uint8_t)v; }
 };
 
 // what kernel 1 leaves for kernel 2 (and for the caller) per stream
@@ -72,17 +84,20 @@ struct StreamInfo {
 };
 
 __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
-    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
-    uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info) {
+    const uint8_t* __restrict__ comp, int64_t comp_total,
+    const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
+    StreamInfo* __restrict__ info) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes1];
     const int lane = threadIdx.x;
     const int i = blockIdx.x * kLanes + lane;
-    uint16_t* lds16 = reinterpret_cast<uint16_t*>(lds);
     LdsMem mem;
-    mem.lit_ = lds16 + kLitOff + lane;
-    mem.dist_ = lds16 + kDistOff + lane;
-    mem.work_ = lds16 + kWorkOff + lane;
-    mem.lens_ = lds + kLensOff16 * 2 + lane;
+    mem.ring_ = reinterpret_cast<uint32_t*>(lds + kRingOff) + lane;
+    mem.lit_pair_ = reinterpret_cast<uint32_t*>(lds + kLitPairOff) + lane;
+    mem.dist_pair_ = reinterpret_cast<uint32_t*>(lds + kDistPairOff) + lane;
+    mem.lit_sym_ = reinterpret_cast<uint16_t*>(lds + kLitSymOff) + lane;
+    mem.cnt_ = reinterpret_cast<uint16_t*>(lds + kCntOff) + lane;
+    mem.dist_sym_ = lds + kDistSymOff + lane;
+    mem.lens_ = lds + kLensOff + lane;
 
     Lane L;
     L.state = dbi::kDone;
@@ -90,51 +105,61 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
     L.ended = 0;
     L.adler = 0;
     L.out_pos = 0;
+    L.out_cap = 0;
+    L.final_block = 0;
+    L.stored_left = 0;
+#pragma unroll
+    for (int l = 0; l < 15; ++l) L.lim_lit[l] = L.lim_dist[l] = 0;
+    L.br.in = comp;
+    L.br.limit_bits = 0;
+    L.br.bp = L.br.wr = 0;
+    L.br.pending = 0;
+    L.br.fetch_cap = 0;
     uint32_t* tok = tokens;
     int n_tok = 0;
-    uint32_t t0 = 0, t1 = 0, t2 = 0;       // tokens wait here for a 16-byte store
     bool mine = false;
     if (i < n_streams) {
         const dbh_inflate_stream s = streams[i];
         if (s.mode == DBH_INFLATE_ZLIB) {
             mine = true;
-            dbi::lane_start(L, comp + s.comp_offset, s.comp_bytes, s.out_bytes);
+            // (the caller's buffer is readable for 64 bytes beyond comp_total)
+            dbi::lane_start(L, mem, comp + s.comp_offset, s.comp_bytes, s.out_bytes,
+                            comp_total + 64 - s.comp_offset);
             tok = tokens + s.out_offset;          // one token slot per byte of output
         }
     }
-    // (a store per token and lane is 32 partial cache lines per step: four tokens wait in
-    // registers for one 16-byte store)
-    auto emit = [&](uint32_t token) {
-        const int k = n_tok & 3;
-        if (k == 3) {
-            uint32_t four[4] = {t0, t1, t2, token};
-            __builtin_memcpy(tok + (n_tok - 3), four, 16);
-        }
-        t0 = k == 0 ? token : t0;
-        t1 = k == 1 ? token : t1;
-        t2 = k == 2 ? token : t2;
-        ++n_tok;
-    };
     while (__any(L.state != dbi::kDone)) {
-        // the rare states: a block header (with its two table builds), a stored block's bytes
+        // the rare states: a block header (with its two code builds), a stored block's bytes
         if (L.state == dbi::kNeedBlock) {
             dbi::lane_block(L, mem);
         } else if (L.state == dbi::kStored) {
             uint32_t token;
-            if (dbi::lane_step(L, mem, &token)) emit(token);
+            if (dbi::lane_stored(L, mem, &token)) tok[n_tok++] = token;
         }
-        // the hot loop: every lane that is inside a Huffman block decodes one token per round
+        // the hot loop: every lane that is inside a Huffman block decodes four tokens per round
         // (lanes that have left their block wait for the others - streams deflated alike leave
-        // together)
+        // together: zlib ends a block after a fixed number of symbols)
         while (__any(L.state == dbi::kDecode)) {
-            if (L.state == dbi::kDecode) {
-                uint32_t token;
-                if (dbi::lane_decode(L, mem, &token)) emit(token);
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            const bool p0 = dbi::lane_decode(L, mem, &t0);
+            const bool p1 = dbi::lane_decode(L, mem, &t1);
+            const bool p2 = dbi::lane_decode(L, mem, &t2);
+            const bool p3 = dbi::lane_decode(L, mem, &t3);
+            // (a store per token and lane would be 64 partial cache lines per step: four tokens
+            // go out as one 16-byte store - all four real in all but a handful of rounds)
+            if (p0 && p1 && p2 && p3) {
+                const uint32_t four[4] = {t0, t1, t2, t3};
+                __builtin_memcpy(tok + n_tok, four, 16);
+                n_tok += 4;
+            } else {
+                if (p0) tok[n_tok++] = t0;
+                if (p1) tok[n_tok++] = t1;
+                if (p2) tok[n_tok++] = t2;
+                if (p3) tok[n_tok++] = t3;
             }
+            L.br.checkpoint(mem);
         }
     }
-    for (int k = 0; k < (n_tok & 3); ++k)      // the tokens still waiting
-        tok[(n_tok & ~3) + k] = k == 0 ? t0 : k == 1 ? t1 : t2;
     if (i < n_streams) {
         StreamInfo r;
         r.status = mine ? L.status : dbi::kOk;
@@ -301,10 +326,10 @@ int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size
     return DBH_OK;
 }
 
-int dbh_inflate_dev(const uint8_t* comp_dev, const dbh_inflate_stream* streams_dev,
-                    int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
+int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
+                    const dbh_inflate_stream* streams_dev, int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
                     void* workspace_dev, int32_t* status_dev, dbh_stream stream) {
-    if (n_streams < 0 || n_streams > 0x7FFFFFFF || total_out_bytes < 0)
+    if (n_streams < 0 || n_streams > 0x7FFFFFFF || total_out_bytes < 0 || comp_bytes < 0)
         return DBH_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return DBH_OK;
     if (!comp_dev || !streams_dev || !out_dev || !workspace_dev || !status_dev)
@@ -314,7 +339,8 @@ int dbh_inflate_dev(const uint8_t* comp_dev, const dbh_inflate_stream* streams_d
                                      (((size_t)total_out_bytes * sizeof(uint32_t) + 255) & ~(size_t)255));
     const int n = (int)n_streams;
     hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((n + kLanes - 1) / kLanes)),
-                       dim3(kLanes), 0, (hipStream_t)stream, comp_dev, streams_dev, n, tokens, info);
+                       dim3(kLanes), 0, (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n,
+                       tokens, info);
     DBI_HIP(hipGetLastError());
     const int blocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
     hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0,
@@ -367,7 +393,8 @@ int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_s
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
     if (e == hipSuccess && st == DBH_OK)
-        st = dbh_inflate_dev(d_comp, d_streams, n_streams, (int64_t)out_bytes, d_out, d_work,
+        st = dbh_inflate_dev(d_comp, (int64_t)comp_bytes, d_streams, n_streams, (int64_t)out_bytes,
+                             d_out, d_work,
                              d_status, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_host, d_out, out_bytes, hipMemcpyDeviceToHost);

@@ -10,15 +10,22 @@
 // is good at.
 //
 // This header is compiled twice: by hipcc into the kernels, and by g++ into the CPU test harness
-// (tests/inflate_host_test.cpp via oracle/Makefile), which runs the SAME decoder lane by lane
-// against zlib on the build box.  All table memory is reached through a `Mem` accessor: LDS,
+// (oracle/inflate_host_test.cpp via oracle/Makefile), which runs the SAME decoder lane by lane
+// against zlib on the build box.  All per-lane memory is reached through a `Mem` accessor: LDS,
 // interleaved by lane, on the device; plain arrays on the host.
 //
-// Decode tables (per lane): zlib's scheme - a root table indexed by the next ROOT bits whose
-// entries either give {symbol, code length} or link to a sub-table for longer codes.
-//   entry (16 bit): bit 15 = 0: bits 0-3 code length in this table (0 = no such code),
-//                                bits 4-12 symbol
-//                   bit 15 = 1: link: bits 0-3 index bits of the sub-table, bits 4-14 its offset
+// How a code is decoded - CANONICALLY, without decode tables: the codes of one length are
+// consecutive numbers, and read as 16-bit numbers with the first bit on top (left-justified) the
+// ranges of lengths 1, 2, .. 15 follow each other in ascending order.  So
+//     length  = 1 + the number of range ENDS that are <= the next 16 bits   (15 compares against
+//               per-lane registers: no memory, no branches)
+//     symbol  = sorted[first index of that length + (bits - first code of that length)]
+// and per lane only the symbols sorted by (length, symbol) live in LDS: 288 + 32 entries and two
+// 16-entry {first code, first index} tables - 1.2 KB per lane against the 4.6 KB of zlib-style
+// root and sub-tables, which is what decides how many streams a CU decodes at a time (LDS is the
+// only thing this kernel runs out of).  The sorted entries of the literal/length code carry the
+// decoded meaning (literal byte | end of block | length base and extra bits), so no
+// per-symbol arithmetic is left in the loop.
 #pragma once
 #include <stdint.h>
 
@@ -38,16 +45,17 @@ struct U4 {
 };
 #endif
 
-constexpr int kLitRoot = 10, kDistRoot = 8;
-constexpr int kLitEntries = 1408;        // 1,024 root + sub-tables (more needed: stream refused)
-constexpr int kDistEntries = 448;        // 256 root + sub-tables
-constexpr int kMaxLens = 352;            // 19 + 13 spare, then up to 286 + 30 lengths as decoded
-constexpr int kMaxSyms = 288;
+constexpr int kMaxLens = 320;            // 288 literal/length + 32 distance code lengths
+constexpr int kLitSyms = 288;
+constexpr int kDistSyms = 32;
+constexpr int kRingRows = 32;            // dwords of input a lane keeps in LDS (+ 2 mirror rows)
+constexpr int kRingStore = kRingRows + 2;
+constexpr int kFetchDwords = 8;          // dwords per request
 
 // token: literal = the byte; match = bit 31 | (distance - 1) << 9 | length
 constexpr uint32_t kMatchFlag = 0x80000000u;
-DBI_HD uint32_t match_token(int length, int distance) {
-    return kMatchFlag | ((uint32_t)(distance - 1) << 9) | (uint32_t)length;
+DBI_HD uint32_t match_token(uint32_t length, uint32_t distance) {
+    return kMatchFlag | ((distance - 1u) << 9) | length;
 }
 
 enum Status : int {
@@ -57,7 +65,7 @@ enum Status : int {
     kBadCodes = 3,         // over-subscribed / incomplete code lengths, bad repeat
     kBadSymbol = 4,        // a code that is not in the table, length/distance symbol out of range
     kTruncated = 5,        // ran out of input
-    kTableSpace = 6,       // needs more sub-table space than this decoder carries (valid stream)
+    kTableSpace = 6,       // (unused since the decoder went canonical: every valid code fits)
     kTokenSpace = 7,       // more tokens than the caller's buffer holds
     kBadDistance = 8,      // (phase 2) distance reaches before the start of the output
     kBadChecksum = 9,      // (phase 2) Adler-32 mismatch
@@ -69,8 +77,6 @@ enum Status : int {
 // c = 28: 258.  Distance symbol d: d < 4: d + 1; else e = d / 2 - 1, base 1 + ((2 + d % 2) << e).
 DBI_HD int len_extra(int c) { return (c < 8 || c == 28) ? 0 : (c - 4) >> 2; }
 DBI_HD int len_base(int c) { return c < 8 ? 3 + c : c == 28 ? 258 : 3 + ((4 + (c & 3)) << len_extra(c)); }
-DBI_HD int dist_extra(int d) { return d < 4 ? 0 : (d >> 1) - 1; }
-DBI_HD int dist_base(int d) { return d < 4 ? d + 1 : 1 + ((2 + (d & 1)) << dist_extra(d)); }
 // the order in which the code lengths of the code-length code are stored (section 3.2.7)
 DBI_HD int cl_order(int i) {
     // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15: five bits each in two words
@@ -81,30 +87,52 @@ DBI_HD int cl_order(int i) {
     return (int)((i < 12 ? lo >> (5 * i) : hi >> (5 * (i - 12))) & 31);
 }
 
-// The input side of a lane: a 64-bit bit buffer refilled 32 bits at a time, the next dword
-// always already requested (the load's latency hides behind the tokens the buffer still holds).
-// The buffer behind a stream is readable (padding, or the next stream): the reader fetches up to
-// 48 bytes beyond the stream's end without looking; a stream that CONSUMES bits from there is
-// truncated and is told so (overrun).
+// what a sorted entry of the literal/length code says (16 bits)
+constexpr uint32_t kEntryLength = 0x8000u;   // bits 0-7 base - 3, bits 8-10 extra bits
+constexpr uint32_t kEntryEnd = 0x4000u;      // end of block
+constexpr uint32_t kEntryBad = 0x2000u;      // symbols 286, 287: in the fixed code, never valid
+DBI_HD uint32_t lit_entry(int s) {
+    if (s < 256) return (uint32_t)s;
+    if (s == 256) return kEntryEnd;
+    if (s > 285) return kEntryBad;
+    return kEntryLength | ((uint32_t)len_extra(s - 257) << 8) | (uint32_t)(len_base(s - 257) - 3);
+}
+
+DBI_HD uint32_t low_bits(uint32_t v, uint32_t n) {      // n <= 16
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, 0u, n);
+#else
+    return v & ((1u << n) - 1u);
+#endif
+}
+// the next 16 bits of the stream as a number with the FIRST bit on top (Huffman codes are packed
+// first bit first, everything else in deflate lowest bit first)
+DBI_HD uint32_t first16(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(w) >> 16;
+#else
+    uint32_t r = 0;
+    for (int k = 0; k < 16; ++k) r |= ((w >> k) & 1u) << (15 - k);
+    return r;
+#endif
+}
+DBI_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// The input side of a lane: a ring of 32 dwords in LDS ([row][lane]: whatever row each lane
+// wants, the lanes of a wave hit 64 different banks), filled eight dwords at a time by a request
+// issued at one checkpoint and written to the ring at the next, so that nobody waits for global
+// memory; rows 32 and 33 mirror rows 0 and 1, so that the 64-bit window at any bit position is
+// three consecutive rows.  Nothing is consumed without being checked: a stream that runs beyond
+// its last byte is told so (overrun), whatever the ring held there.
 struct BitReader {
     const uint8_t* in;
     uint32_t limit_bits;   // bits of the stream (deflate data + trailer): streams are < 512 MB
     uint32_t bp;           // bits consumed so far = position of the next bit
-    uint32_t base;         // position of bit 0 of `lo` (a multiple of 32, <= bp)
-    uint32_t lo, hi;       // the 64 bits from `base` on: everything is 32-bit arithmetic, the
-                           // next 32 bits are ONE v_alignbit_b32 away
-    // Sixteen bytes in hand behind those (q0 = next) and the sixteen after them already
-    // requested: a lane needs a new 64-byte line of its stream every ~40 tokens, the lanes of a
-    // wave step together, and a wave waits for its slowest lane.
-    uint32_t q0, q1, q2, q3;
-    U4 ahead;              // (kept as ONE 128-bit value until it is needed: taken apart earlier,
-                           // the compiler waits for the load where it is issued)
-    int left;              // dwords of q still unused
-    uint32_t fetch;        // byte offset of the sixteen bytes to request next
+    uint32_t wr;           // dwords written to the ring so far (a multiple of 8)
+    uint32_t fetch_cap;    // a request may start no further than this many bytes behind `in`
+    U4 pend0, pend1;       // a request in flight
+    int pending;
 
-    // (no bounds checks and no masking: the buffer is readable for 64 bytes beyond the stream -
-    // the next stream, or the padding - and bits from beyond the stream are never CONSUMED
-    // unnoticed: overrun() after every token)
     DBI_HD U4 load16(uint32_t at) const {
         U4 v;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -123,154 +151,93 @@ struct BitReader {
 #endif
         return v;
     }
-    DBI_HD void start(const uint8_t* data, int64_t n_bytes) {
-        in = data;
-        limit_bits = (uint32_t)n_bytes * 8u;
-        const U4 first = load16(0);
-        lo = first.x;
-        hi = first.y;
-        q0 = first.z;
-        q1 = first.w;
-        ahead = load16(16);
-        q2 = q3 = 0;
-        left = 2;
-        fetch = 32;
-        bp = base = 0;
+    DBI_HD uint32_t level() const { return wr - (bp >> 5); }     // dwords not yet left behind
+    DBI_HD void request() {
+        // (beyond fetch_cap lies the end of the caller's buffer; what a lane reads instead is
+        // never looked at: its stream has ended at least 32 bytes before)
+        const uint32_t at = umin(wr * 4u, fetch_cap);
+        pend0 = load16(at);
+        pend1 = load16(at + 16u);
+        pending = 1;
     }
-    // `lo` leaves the window, the next dword enters it
-    DBI_HD void shift() {
-        lo = hi;
-        hi = q0;
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        base += 32;
-        if (--left == 0) {             // the sixteen bytes asked for a while ago; ask for more
-            q0 = ahead.x;
-            q1 = ahead.y;
-            q2 = ahead.z;
-            q3 = ahead.w;
-            left = 4;
-            ahead = load16(fetch);
-            fetch += 16;
+    template <class Mem>
+    DBI_HD void commit(Mem& mem) {
+        const int row = (int)(wr & (uint32_t)(kRingRows - 1));
+        mem.set_ring(row + 0, pend0.x);
+        mem.set_ring(row + 1, pend0.y);
+        mem.set_ring(row + 2, pend0.z);
+        mem.set_ring(row + 3, pend0.w);
+        mem.set_ring(row + 4, pend1.x);
+        mem.set_ring(row + 5, pend1.y);
+        mem.set_ring(row + 6, pend1.z);
+        mem.set_ring(row + 7, pend1.w);
+        if (row == 0) {
+            mem.set_ring(kRingRows + 0, pend0.x);
+            mem.set_ring(kRingRows + 1, pend0.y);
+        }
+        wr += (uint32_t)kFetchDwords;
+        pending = 0;
+    }
+    // The checkpoint of the hot loop, every four tokens (<= 6 dwords consumed in between): what
+    // was requested last time goes into the ring, and a lane whose level is down to 16 dwords
+    // requests eight more.  Level after a checkpoint >= 11, never above 24 + 8: the ring neither
+    // runs dry nor is overwritten where it is still to be read.
+    template <class Mem>
+    DBI_HD void checkpoint(Mem& mem) {
+        if (pending) commit(mem);
+        if (level() <= 16u) request();
+    }
+    // The rare paths (headers, stored bytes) ask before every field instead: at least `need`
+    // (<= 16) dwords in the ring.
+    template <class Mem>
+    DBI_HD void ensure(Mem& mem, uint32_t need) {
+        while (level() < need) {
+            if (!pending) request();
+            commit(mem);
         }
     }
-    // Normal form: the next bit lies in `lo`.  At most 32 bits may be consumed between two calls
-    // (then one shift restores it); afterwards at least 33 bits are in the window.
-    DBI_HD void refill() {
-        if (bp - base >= 32u) shift();
+    template <class Mem>
+    DBI_HD void start(Mem& mem, const uint8_t* data, int64_t n_bytes, int64_t readable_bytes) {
+        in = data;
+        limit_bits = (uint32_t)n_bytes * 8u;
+        fetch_cap = (uint32_t)(readable_bytes - 32);
+        bp = 0;
+        wr = 0;
+        pending = 0;
+        ensure(mem, 16u);
     }
-    // the next 32 bits, in normal form
-    DBI_HD uint32_t window() const {
+    // the next 64 bits
+    template <class Mem>
+    DBI_HD void window64(const Mem& mem, uint32_t& lo, uint32_t& hi) const {
+        const int row = (int)((bp >> 5) & (uint32_t)(kRingRows - 1));
         const uint32_t sh = bp & 31u;
+        const uint32_t d0 = mem.ring(row), d1 = mem.ring(row + 1), d2 = mem.ring(row + 2);
 #if defined(__HIP_DEVICE_COMPILE__)
-        return __builtin_amdgcn_alignbit(hi, lo, sh);
+        lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+        hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 #else
-        return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+        lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+        hi = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
 #endif
     }
-    // the next n <= 16 bits, anywhere in the window (the header code's sequences of small fields)
-    DBI_HD uint32_t peek(int n) const {
-        const uint32_t sh = bp - base;       // 0 .. 63
-        const uint32_t w = sh < 32u ? (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) : hi >> (sh - 32u);
-        return w & ((1u << n) - 1u);
-    }
-    DBI_HD void drop(int n) { bp += (uint32_t)n; }
-    DBI_HD uint32_t take(int n) {
-        const uint32_t v = peek(n);
-        drop(n);
-        return v;
+    template <class Mem>
+    DBI_HD uint32_t take(Mem& mem, int n) {          // n <= 16; rare paths only
+        ensure(mem, 4u);
+        uint32_t lo, hi;
+        window64(mem, lo, hi);
+        bp += (uint32_t)n;
+        return low_bits(lo, (uint32_t)n);
     }
     DBI_HD uint32_t consumed_bits() const { return bp; }
     DBI_HD bool overrun() const { return bp > limit_bits; }
     DBI_HD int64_t limit_bytes() const { return (int64_t)(limit_bits >> 3); }
 };
 
-// Builds the decode table of one code (zlib's inflate_table, restated): `lens[first .. first+n)`
-// are the code lengths; `Tab` reads and writes table entries; `work` holds n symbols.
-//   -> kOk / kBadCodes / kTableSpace.  An incomplete code is tolerated only where zlib tolerates
-// it: a literal/length or distance code made of a single code of length 1, never the code-length
-// code; no codes at all is accepted (a block of literals only has no distance codes) and leaves a
-// table without codes.
-template <class Mem, class Tab>
-DBI_HD int build_table(Mem& mem, Tab tab, int first, int n, int root, int capacity,
-                       bool may_be_incomplete) {
-    int count[16];
-    for (int l = 0; l < 16; ++l) count[l] = 0;
-    for (int s = 0; s < n; ++s) count[mem.len(first + s)]++;
-    int max = 15;
-    while (max >= 1 && count[max] == 0) --max;
-    for (int e = 0; e < (1 << root); ++e) tab.set(e, 0);      // "no such code" everywhere first
-    if (max == 0) return kOk;                                   // no codes at all
-    int min = 1;
-    while (min < max && count[min] == 0) ++min;
-    int left = 1;
-    for (int l = 1; l <= 15; ++l) {
-        left <<= 1;
-        left -= count[l];
-        if (left < 0) return kBadCodes;                         // over-subscribed
-    }
-    if (left > 0 && (!may_be_incomplete || max != 1)) return kBadCodes;      // incomplete
-    // symbols by (length, symbol)
-    int offs[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
-    for (int s = 0; s < n; ++s) {
-        const int l = mem.len(first + s);
-        if (l != 0) mem.set_work(offs[l]++, s);
-    }
-    unsigned huff = 0, low = ~0u;
-    const unsigned mask = (1u << root) - 1u;
-    int sym = 0, len = min, next = 0, curr = root, drop = 0, used = 1 << root;
-    for (;;) {
-        const int s = mem.work(sym);
-        const uint16_t here = (uint16_t)((s << 4) | (len - drop));
-        const unsigned incr = 1u << (len - drop);
-        unsigned fill = 1u << curr;
-        const unsigned span = fill;
-        do {
-            fill -= incr;
-            tab.set(next + (int)((huff >> drop) + fill), here);
-        } while (fill != 0);
-        // backwards increment of the len-bit code
-        unsigned inc = 1u << (len - 1);
-        while (huff & inc) inc >>= 1;
-        if (inc != 0) {
-            huff &= inc - 1;
-            huff += inc;
-        } else {
-            huff = 0;
-        }
-        ++sym;
-        if (--count[len] == 0) {
-            if (len == max) break;
-            len = mem.len(first + mem.work(sym));
-        }
-        if (len > root && (huff & mask) != low) {              // a new sub-table
-            if (drop == 0) drop = root;
-            next += (int)span;
-            curr = len - drop;
-            int room = 1 << curr;
-            while (curr + drop < max) {
-                room -= count[curr + drop];
-                if (room <= 0) break;
-                ++curr;
-                room <<= 1;
-            }
-            used += 1 << curr;
-            if (used > capacity) return kTableSpace;
-            low = huff & mask;
-            tab.set((int)low, (uint16_t)(0x8000u | ((unsigned)next << 4) | (unsigned)curr));
-        }
-    }
-    // an incomplete code (one code of length 1) leaves one entry without a code: already 0 in
-    // the root; in zlib it is an "invalid code" marker too
-    return kOk;
-}
-
 // One lane's decoder state between iterations of the lockstep loop.
 struct Lane {
     BitReader br;
+    // left-justified ends of the code ranges of lengths 1 .. 15 (65,536 = a complete code's last)
+    uint32_t lim_lit[15], lim_dist[15];
     int out_pos, out_cap;      // bytes produced / wanted (a stream's output is < 2 GB)
     int state;                 // see below
     int status;
@@ -286,38 +253,93 @@ struct Lane {
 enum LaneState : int { kNeedBlock = 0, kDecode = 1, kStored = 2, kDone = 3 };
 
 template <class Mem>
-struct LitTab {
+struct LitCode {
     Mem* m;
-    DBI_HD void set(int e, uint16_t v) const { m->set_lit(e, v); }
+    DBI_HD void set_pair(int l, uint32_t v) const { m->set_lit_pair(l, v); }
+    DBI_HD void set_sym(int at, int s) const { m->set_lit_sym(at, lit_entry(s)); }
 };
 template <class Mem>
-struct DistTab {
+struct DistCode {          // (also the code-length code, before the distance code is built)
     Mem* m;
-    DBI_HD void set(int e, uint16_t v) const { m->set_dist(e, v); }
+    DBI_HD void set_pair(int l, uint32_t v) const { m->set_dist_pair(l, v); }
+    DBI_HD void set_sym(int at, int s) const { m->set_dist_sym(at, (uint32_t)s); }
 };
 
-// Decodes one symbol of the code whose table `get(e)` reads: -> symbol, or -1 (no such code).
-// The reader is in normal form (refill() since the last 32 bits were consumed).
-template <class Get>
-DBI_HD int decode_symbol(BitReader& br, int root, const Get& get) {
-    const uint32_t w = br.window();
-    uint16_t e = get((int)(w & ((1u << root) - 1u)));
-    int base_bits = 0;
-    if (e & 0x8000u) {
-        const int sub_bits = e & 15, off = (e >> 4) & 0x7FF;
-        e = get(off + (int)((w >> root) & ((1u << sub_bits) - 1u)));
-        base_bits = root;
-        if (e & 0x8000u) return -1;
+// Prepares one code for decoding: `lens[first .. first+n)` are the code lengths.  Leaves the
+// range ends in `lim`, {first code, first index} per length and the symbols sorted by (length,
+// symbol) behind `code`.  -> kOk / kBadCodes.  An incomplete code is tolerated only where zlib
+// tolerates it (inftrees.c): a literal/length or distance code made of a single code of length
+// 1, never the code-length code; no codes at all is accepted (a block of literals only has no
+// distance codes) and leaves a code nothing decodes with.
+template <class Mem, class Code>
+DBI_HD int build_code(Mem& mem, Code code, int first, int n, uint32_t (&lim)[15],
+                      bool may_be_incomplete) {
+    for (int l = 0; l < 16; ++l) mem.set_cnt(l, 0);
+    for (int s = 0; s < n; ++s) {
+        const int l = mem.len(first + s);
+        mem.set_cnt(l, mem.cnt(l) + 1);
     }
-    const int len = e & 15;
-    if (len == 0) return -1;
-    br.drop(base_bits + len);
-    return (e >> 4) & 0x1FF;
+    int left = 1, max = 0;
+    uint32_t next_code = 0, index = 0;
+    bool over = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int l = 1; l <= 15; ++l) {
+        const uint32_t c = (uint32_t)mem.cnt(l);
+        left = (left << 1) - (int)c;
+        over = over || left < 0;
+        if (c) max = l;
+        code.set_pair(l, ((next_code << (16 - l)) & 0xFFFFu) | (index << 16));
+        mem.set_cnt(l, (int)index);           // from here on: where the next symbol of length l goes
+        next_code += c;
+        index += c;
+        lim[l - 1] = next_code << (16 - l);
+        next_code <<= 1;
+    }
+    if (over) return kBadCodes;                                            // over-subscribed
+    if (max != 0 && left > 0 && (!may_be_incomplete || max != 1)) return kBadCodes;   // incomplete
+    for (int s = 0; s < n; ++s) {
+        const int l = mem.len(first + s);
+        if (l != 0) {
+            const int at = mem.cnt(l);
+            code.set_sym(at, s);
+            mem.set_cnt(l, at + 1);
+        }
+    }
+    return kOk;
 }
 
-// Zlib header -> lane ready for its first block.
-DBI_HD void lane_start(Lane& L, const uint8_t* data, int64_t n_bytes, int64_t out_cap) {
-    L.br.start(data, n_bytes);
+// The length of the code the 16 bits `c` begin with: 1 .. N, or N + 1 = no such code.
+// (c - end is negative exactly where c lies below the end of a range: the sign bits are shifted
+// into one word and counted - two instructions per length, no condition codes)
+template <int N>
+DBI_HD uint32_t code_length(uint32_t c, const uint32_t (&lim)[15]) {
+    uint32_t below = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int l = 0; l < N; ++l) below = __builtin_amdgcn_alignbit(below, c - lim[l], 31);
+    return (uint32_t)(N + 1) - (uint32_t)__builtin_popcount(below);
+#else
+    for (int l = 0; l < N; ++l) below += (c - lim[l]) >> 31;
+    return (uint32_t)(N + 1) - below;
+#endif
+}
+// index of its symbol among the sorted ones, from the {first code, first index} of its length
+DBI_HD uint32_t sorted_index(uint32_t c, uint32_t len, uint32_t pair) {
+    return (pair >> 16) + ((c - (pair & 0xFFFFu)) >> (16u - len));
+}
+
+DBI_HD void lane_fail(Lane& L, int status) {
+    L.status = status;
+    L.state = kDone;
+}
+
+// Zlib header -> lane ready for its first block.  `readable_bytes`: how far behind `data` the
+// caller's buffer can be read (>= n_bytes + 32).
+template <class Mem>
+DBI_HD void lane_start(Lane& L, Mem& mem, const uint8_t* data, int64_t n_bytes, int64_t out_cap,
+                       int64_t readable_bytes) {
     L.adler = 0;
     L.out_pos = 0;
     L.out_cap = (int)out_cap;
@@ -326,22 +348,18 @@ DBI_HD void lane_start(Lane& L, const uint8_t* data, int64_t n_bytes, int64_t ou
     L.final_block = 0;
     L.stored_left = 0;
     L.ended = 0;
-    if (n_bytes < 6 || n_bytes >= (1 << 29) || out_cap >= (1ll << 31)) {
-        L.status = kTruncated;
-        L.state = kDone;
-        return;
-    }
-    const uint32_t cmf = L.br.take(8), flg = L.br.take(8);
-    if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) {
-        L.status = kBadHeader;
-        L.state = kDone;
-    }
+    for (int l = 0; l < 15; ++l) L.lim_lit[l] = L.lim_dist[l] = 0;
+    L.br.in = data;
+    L.br.limit_bits = 0;
+    L.br.bp = L.br.wr = 0;
+    L.br.pending = 0;
+    L.br.fetch_cap = 0;
+    if (n_bytes < 6 || n_bytes >= (1 << 29) || out_cap >= (1ll << 31)) return lane_fail(L, kTruncated);
+    L.br.start(mem, data, n_bytes, readable_bytes);
+    const uint32_t cmf = L.br.take(mem, 8), flg = L.br.take(mem, 8);
+    if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20))
+        return lane_fail(L, kBadHeader);
     if (out_cap < 0) L.state = kDone;
-}
-
-DBI_HD void lane_fail(Lane& L, int status) {
-    L.status = status;
-    L.state = kDone;
 }
 
 // The deflate data has ended: the Adler-32 of the output follows at the next byte boundary.
@@ -354,20 +372,17 @@ DBI_HD void lane_ended(Lane& L) {
     L.state = kDone;
 }
 
-// Block header (and, for a dynamic block, its code lengths and both tables).
+// Block header (and, for a dynamic block, its code lengths and both codes).
 template <class Mem>
 DBI_HD void lane_block(Lane& L, Mem& mem) {
     BitReader& br = L.br;
-    br.refill();
-    L.final_block = (int)br.take(1);
-    const int type = (int)br.take(2);
+    L.final_block = (int)br.take(mem, 1);
+    const int type = (int)br.take(mem, 2);
     if (type == 3) return lane_fail(L, kBadBlock);
     if (type == 0) {
-        br.drop((int)((8u - (br.bp & 7u)) & 7u));       // to the byte boundary
-        br.refill();
-        const uint32_t len = br.take(16);
-        br.refill();
-        const uint32_t nlen = br.take(16);
+        br.bp += (8u - (br.bp & 7u)) & 7u;              // to the byte boundary
+        const uint32_t len = br.take(mem, 16);
+        const uint32_t nlen = br.take(mem, 16);
         if ((len ^ 0xFFFFu) != nlen) return lane_fail(L, kBadBlock);
         if (br.overrun()) return lane_fail(L, kTruncated);
         L.stored_left = (int)len;
@@ -375,36 +390,36 @@ DBI_HD void lane_block(Lane& L, Mem& mem) {
         if (!len && L.final_block) lane_ended(L);
         return;
     }
-    int hlit = 288, hdist = 30;
+    int hlit = 288, hdist = 32;
     if (type == 1) {
         for (int s = 0; s < 288; ++s) mem.set_len(s, s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
         // (32 five-bit distance codes make the fixed code complete; 30 and 31 never occur in
         // valid data and are refused when decoded)
-        hdist = 32;
         for (int s = 0; s < 32; ++s) mem.set_len(288 + s, 5);
     } else {
-        hlit = (int)br.take(5) + 257;
-        hdist = (int)br.take(5) + 1;
-        const int hclen = (int)br.take(4) + 4;
+        hlit = (int)br.take(mem, 5) + 257;
+        hdist = (int)br.take(mem, 5) + 1;
+        const int hclen = (int)br.take(mem, 4) + 4;
         if (hlit > 286 || hdist > 30) return lane_fail(L, kBadCodes);
         for (int i = 0; i < 19; ++i) mem.set_len(i, 0);
-        for (int i = 0; i < hclen; ++i) {
-            br.refill();
-            mem.set_len(cl_order(i), (int)br.take(3));
-        }
-        // the code-length code: its table in the distance table's place (7-bit root, no links)
-        int st = build_table(mem, DistTab<Mem>{&mem}, 0, 19, 7, 128, false);
+        for (int i = 0; i < hclen; ++i) mem.set_len(cl_order(i), (int)br.take(mem, 3));
+        // the code-length code: sorted symbols and pairs where the distance code's will be
+        uint32_t lim_cl[15];
+        int st = build_code(mem, DistCode<Mem>{&mem}, 0, 19, lim_cl, false);
         if (st != kOk) return lane_fail(L, st);
         int have = 0, prev = 0;
         const int want = hlit + hdist;
         while (have < want) {
-            br.refill();
-            const int s = decode_symbol(br, 7, [&](int e) { return mem.dist(e); });
-            if (s < 0) return lane_fail(L, kBadSymbol);
+            br.ensure(mem, 4u);
+            uint32_t lo, hi;
+            br.window64(mem, lo, hi);
+            const uint32_t c = first16(lo);
+            const uint32_t cl = code_length<7>(c, lim_cl);
+            if (cl > 7u) return lane_fail(L, kBadSymbol);
+            const int s = (int)mem.dist_sym((int)umin(sorted_index(c, cl, mem.dist_pair((int)cl)), 18u));
+            br.bp += cl;
             if (s < 16) {
-                // (the code-length table is read from the distance area; the lengths themselves
-                // go to a second run of the length scratch, behind the 19 already used)
-                mem.set_len(32 + have++, s);
+                mem.set_len(have++, s);
                 prev = s;
                 continue;
             }
@@ -412,172 +427,107 @@ DBI_HD void lane_block(Lane& L, Mem& mem) {
             if (s == 16) {
                 if (have == 0) return lane_fail(L, kBadCodes);
                 val = prev;
-                rep = 3 + (int)br.take(2);
+                rep = 3 + (int)br.take(mem, 2);
             } else if (s == 17) {
-                rep = 3 + (int)br.take(3);
+                rep = 3 + (int)br.take(mem, 3);
             } else {
-                rep = 11 + (int)br.take(7);
+                rep = 11 + (int)br.take(mem, 7);
             }
             if (have + rep > want) return lane_fail(L, kBadCodes);
-            for (int k = 0; k < rep; ++k) mem.set_len(32 + have++, val);
+            for (int k = 0; k < rep; ++k) mem.set_len(have++, val);
             if (s != 16) prev = 0;
         }
         if (br.overrun()) return lane_fail(L, kTruncated);
-        if (mem.len(32 + 256) == 0) return lane_fail(L, kBadCodes);      // no end-of-block code
-        // move to the front: lens[0 .. hlit) literal/length, lens[288 .. 288 + hdist) distance
-        for (int s = 0; s < hlit; ++s) mem.set_len(s, mem.len(32 + s));
-        // (both moves go DOWN in the scratch - 288 + s < 32 + hlit + s as hlit >= 257 - so copying
-        // in ascending order never overwrites what is still to be read)
-        for (int s = 0; s < hdist; ++s) mem.set_len(288 + s, mem.len(32 + hlit + s));
+        if (mem.len(256) == 0) return lane_fail(L, kBadCodes);          // no end-of-block code
     }
-    int st = build_table(mem, LitTab<Mem>{&mem}, 0, hlit, kLitRoot, kLitEntries, true);
-    if (st == kOk)
-        st = build_table(mem, DistTab<Mem>{&mem}, 288, hdist, kDistRoot, kDistEntries, true);
+    // lens[0 .. hlit) literal/length, lens[hlit .. hlit + hdist) distance
+    int st = build_code(mem, LitCode<Mem>{&mem}, 0, hlit, L.lim_lit, true);
+    if (st == kOk) st = build_code(mem, DistCode<Mem>{&mem}, hlit, hdist, L.lim_dist, true);
     if (st != kOk) return lane_fail(L, st);
+    // (the hot loop's checkpoints keep the ring filled only if it is entered well filled)
+    br.ensure(mem, 16u);
     L.state = kDecode;
 }
 
-// One token (or one state transition) of a lane in the lockstep loop.  Returns the token in
-// `*token` with true, or false when this step produced none.
+// One byte of a stored block (rare: a chunk deflate could not shrink).  Returns true with the
+// byte as a literal token in *token.
 template <class Mem>
-DBI_HD bool lane_step(Lane& L, Mem& mem, uint32_t* token) {
+DBI_HD bool lane_stored(Lane& L, Mem& mem, uint32_t* token) {
     BitReader& br = L.br;
-    if (L.state == kStored) {
-        if (L.out_pos >= L.out_cap) {          // more data than wanted
-            L.state = kDone;
-            return false;
-        }
-        br.refill();
-        const uint32_t byte = br.take(8);
-        if (br.overrun()) {
-            lane_fail(L, kTruncated);
-            return false;
-        }
-        *token = byte;
-        L.out_pos += 1;
-        if (--L.stored_left == 0) {
-            L.state = kNeedBlock;
-            if (L.final_block) lane_ended(L);
-        }
-        return true;
-    }
-    // kDecode
-    br.refill();
-    const int s = decode_symbol(br, kLitRoot, [&](int e) { return mem.lit(e); });
-    if (s < 0 || s > 285) {
-        lane_fail(L, kBadSymbol);
+    if (L.out_pos >= L.out_cap) {          // more data than wanted
+        L.state = kDone;
         return false;
     }
-    if (s < 256) {
-        if (br.overrun()) {
-            lane_fail(L, kTruncated);
-            return false;
-        }
-        if (L.out_pos >= L.out_cap) {          // more data than wanted
-            L.state = kDone;
-            return false;
-        }
-        *token = (uint32_t)s;
-        L.out_pos += 1;
-        return true;
-    }
-    if (s == 256) {
-        if (br.overrun()) {
-            lane_fail(L, kTruncated);
-            return false;
-        }
-        L.state = kNeedBlock;
-        if (L.final_block) lane_ended(L);
-        return false;
-    }
-    int length = len_base(s - 257) + (int)br.take(len_extra(s - 257));
-    br.refill();
-    const int d = decode_symbol(br, kDistRoot, [&](int e) { return mem.dist(e); });
-    if (d < 0 || d > 29) {
-        lane_fail(L, kBadSymbol);
-        return false;
-    }
-    const int distance = dist_base(d) + (int)br.take(dist_extra(d));
+    const uint32_t byte = br.take(mem, 8);
     if (br.overrun()) {
         lane_fail(L, kTruncated);
         return false;
     }
-    if (L.out_pos + length > L.out_cap) {      // more data than wanted: keep what is
-        length = L.out_cap - L.out_pos;
-        L.state = kDone;
-        if (length == 0) return false;
+    *token = byte;
+    L.out_pos += 1;
+    if (--L.stored_left == 0) {
+        L.state = kNeedBlock;
+        if (L.final_block) lane_ended(L);
     }
-    *token = match_token(length, distance);
-    L.out_pos += length;
     return true;
 }
 
-// The hot path: ONE token of a lane that is inside a Huffman block (state kDecode), written to be
-// cheap when 32 lanes run it together - one pass over straight-line code with two conditional
-// regions (a linked sub-table; the distance half of a match) instead of a state machine: the
-// general lane_step costs ~300 instructions per token and wave, this ~120.
-// Returns true with *token set when a token was produced; the lane's state, status, position
-// and reader are updated as lane_step would.
+// The hot path: ONE token of a lane that is inside a Huffman block - straight-line code, the
+// same for a literal, a match and an end of block (all lanes of a wave run it together, so a
+// branch would be taken by somebody every time): one 64-bit window (a token is at most 15 + 5 +
+// 15 + 13 bits), both codes decoded from it, the results selected.  A lane in any other state
+// passes through unchanged.  Returns true with *token set when a token was produced.
 template <class Mem>
 DBI_HD bool lane_decode(Lane& L, Mem& mem, uint32_t* token) {
     BitReader& br = L.br;
-    br.refill();
-    const uint32_t w = br.window();
-    uint32_t e = mem.lit((int)(w & ((1u << kLitRoot) - 1u)));
-    uint32_t used = 0;
-    if (e & 0x8000u) {
-        e = mem.lit((int)(((e >> 4) & 0x7FFu) + ((w >> kLitRoot) & ((1u << (e & 15u)) - 1u))));
-        used = kLitRoot;
-    }
-    const uint32_t len = e & 15u, sym = (e >> 4) & 0x1FFu;
-    bool bad = len == 0 || (e & 0x8000u) || sym > 285u;
-    used += len;
-    uint32_t tk = sym;
-    int produced = 1;
-    if (sym > 256u && !bad) {
-        const int c = (int)sym - 257;
-        const int eb = len_extra(c);
-        int length = len_base(c) + (int)((w >> used) & ((1u << eb) - 1u));
-        br.bp += used + (uint32_t)eb;
-        br.refill();
-        const uint32_t w1 = br.window();
-        uint32_t e2 = mem.dist((int)(w1 & ((1u << kDistRoot) - 1u)));
-        uint32_t used2 = 0;
-        if (e2 & 0x8000u) {
-            e2 = mem.dist((int)(((e2 >> 4) & 0x7FFu) +
-                                ((w1 >> kDistRoot) & ((1u << (e2 & 15u)) - 1u))));
-            used2 = kDistRoot;
-        }
-        const uint32_t dlen = e2 & 15u, d = (e2 >> 4) & 0x1FFu;
-        bad = dlen == 0 || (e2 & 0x8000u) || d > 29u;
-        used2 += dlen;
-        const int db = dist_extra((int)d);
-        const int distance = dist_base((int)d) + (int)((w1 >> used2) & ((1u << db) - 1u));
-        br.bp += used2 + (uint32_t)db;
-        if (L.out_pos + length > L.out_cap) {          // more data than wanted: keep what is
-            length = L.out_cap - L.out_pos;
-            L.state = kDone;
-        }
-        tk = match_token(length, distance);
-        produced = length;
-    } else {
-        br.bp += used;
-        if (sym == 256u && !bad) {
-            produced = 0;
-            L.state = kNeedBlock;
-        } else if (L.out_pos >= L.out_cap) {           // a literal beyond what is wanted
-            produced = 0;
-            L.state = kDone;
-        }
-    }
-    if (bad || br.overrun()) {
+    const bool active = L.state == kDecode;
+    uint32_t lo, hi;
+    br.window64(mem, lo, hi);
+    // literal / length
+    const uint32_t c1 = first16(lo);
+    const uint32_t n1 = code_length<15>(c1, L.lim_lit);
+    const uint32_t l1 = umin(n1, 15u);
+    const uint32_t e = mem.lit_sym((int)umin(sorted_index(c1, l1, mem.lit_pair((int)l1)),
+                                             (uint32_t)(kLitSyms - 1)));
+    const bool is_len = (e & kEntryLength) != 0, is_end = (e & kEntryEnd) != 0;
+    bool bad = n1 > 15u || (e & kEntryBad) != 0;
+    const uint32_t eb = is_len ? (e >> 8) & 7u : 0u;
+    uint64_t w = (((uint64_t)hi << 32) | lo) >> l1;
+    uint32_t length = is_len ? 3u + (e & 0xFFu) + low_bits((uint32_t)w, eb) : is_end ? 0u : 1u;
+    w >>= eb;
+    // distance (decoded whatever the symbol was; only looked at behind a length)
+    const uint32_t c2 = first16((uint32_t)w);
+    const uint32_t n2 = code_length<15>(c2, L.lim_dist);
+    const uint32_t l2 = umin(n2, 15u);
+    const uint32_t d = mem.dist_sym((int)umin(sorted_index(c2, l2, mem.dist_pair((int)l2)),
+                                              (uint32_t)(kDistSyms - 1)));
+    const uint32_t half = d >> 1;
+    const uint32_t db = half > 1u ? half - 1u : 0u;
+    const uint32_t dbase = d < 4u ? d + 1u : 1u + ((2u | (d & 1u)) << db);
+    const uint32_t distance = dbase + low_bits((uint32_t)(w >> l2), db);
+    bad = bad || (is_len && (n2 > 15u || d > 29u));
+    const uint32_t used = l1 + (is_len ? eb + l2 + db : 0u);
+    const bool fail = bad || br.bp + used > br.limit_bits;
+    // more data than wanted: a match keeps what is; the lane stops
+    const int room = L.out_cap - L.out_pos;
+    const bool beyond = (int)length > room;
+    if (beyond) length = room > 0 ? (uint32_t)room : 0u;
+    const uint32_t tk = is_len ? match_token(length, distance) : e & 0xFFu;
+    if (!active) return false;
+    br.bp += used;
+    if (fail) {
         lane_fail(L, bad ? kBadSymbol : kTruncated);
         return false;
     }
-    if (sym == 256u && L.final_block) lane_ended(L);
-    L.out_pos += produced;
+    L.out_pos += (int)length;
+    if (beyond) {
+        L.state = kDone;
+    } else if (is_end) {
+        L.state = kNeedBlock;
+        if (L.final_block) lane_ended(L);
+    }
     *token = tk;
-    return produced > 0;
+    return length > 0u;
 }
 
 }  // namespace dbi

@@ -108,8 +108,8 @@ def load_library():
         'dbh_host_is_pinned': (c_int, [c_void_p, c_size_t, P(c_int)]),
         'dbh_inflate_last_error': (ctypes.c_char_p, []),
         'dbh_inflate_workspace_bytes': (c_int, [c_i64, c_i64, P(c_size_t)]),
-        'dbh_inflate_dev': (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
-                                    c_void_p]),
+        'dbh_inflate_dev': (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
         'dbh_inflate': (c_int, [c_void_p, c_size_t, c_void_p, c_i64, c_void_p, c_size_t, c_void_p,
                                 P(ctypes.c_double)]),
         'dbh_classify_pair_deflated': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,

@@ -199,9 +199,11 @@ typedef struct dbh_inflate_stream {
 const char* dbh_inflate_last_error(void);
 /* total_out_bytes = size of the output buffer the streams write into */
 int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size_t* bytes);
-int dbh_inflate_dev(const uint8_t* comp_dev, const dbh_inflate_stream* streams_dev,
-                    int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
-                    void* workspace_dev, int32_t* status_dev, dbh_stream stream);
+/* comp_bytes = size of the compressed buffer (the decoder's read-ahead stops 64 bytes behind it) */
+int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
+                    const dbh_inflate_stream* streams_dev, int64_t n_streams,
+                    int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,
+                    int32_t* status_dev, dbh_stream stream);
 /* host buffers in, host buffers out (tests, tools); kernel_ms (may be NULL): the two kernels */
 int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
                 int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,

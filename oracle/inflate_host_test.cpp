@@ -13,19 +13,26 @@
 #include "../deepbinner_amd/csrc/dbh_inflate_core.h"
 
 struct HostMem {
-    uint16_t lit_[dbi::kLitEntries], dist_[dbi::kDistEntries], work_[dbi::kMaxSyms];
-    uint8_t lens_[dbi::kMaxLens];
-    uint16_t lit(int e) const { return lit_[check(e, dbi::kLitEntries)]; }
-    uint16_t dist(int e) const { return dist_[check(e, dbi::kDistEntries)]; }
-    void set_lit(int e, uint16_t v) { lit_[check(e, dbi::kLitEntries)] = v; }
-    void set_dist(int e, uint16_t v) { dist_[check(e, dbi::kDistEntries)] = v; }
+    uint32_t ring_[dbi::kRingStore], lit_pair_[16], dist_pair_[16];
+    uint16_t lit_sym_[dbi::kLitSyms], cnt_[16];
+    uint8_t dist_sym_[dbi::kDistSyms], lens_[dbi::kMaxLens];
+    uint32_t ring(int r) const { return ring_[check(r, dbi::kRingStore)]; }
+    void set_ring(int r, uint32_t v) { ring_[check(r, dbi::kRingStore)] = v; }
     int len(int i) const { return lens_[check(i, dbi::kMaxLens)]; }
     void set_len(int i, int v) { lens_[check(i, dbi::kMaxLens)] = (uint8_t)v; }
-    int work(int i) const { return work_[check(i, dbi::kMaxSyms)]; }
-    void set_work(int i, int v) { work_[check(i, dbi::kMaxSyms)] = (uint16_t)v; }
+    int cnt(int l) const { return cnt_[check(l, 16)]; }
+    void set_cnt(int l, int v) { cnt_[check(l, 16)] = (uint16_t)v; }
+    uint32_t lit_pair(int l) const { return lit_pair_[check(l, 16)]; }
+    void set_lit_pair(int l, uint32_t v) { lit_pair_[check(l, 16)] = v; }
+    uint32_t dist_pair(int l) const { return dist_pair_[check(l, 16)]; }
+    void set_dist_pair(int l, uint32_t v) { dist_pair_[check(l, 16)] = v; }
+    uint32_t lit_sym(int i) const { return lit_sym_[check(i, dbi::kLitSyms)]; }
+    void set_lit_sym(int i, uint32_t v) { lit_sym_[check(i, dbi::kLitSyms)] = (uint16_t)v; }
+    uint32_t dist_sym(int i) const { return dist_sym_[check(i, dbi::kDistSyms)]; }
+    void set_dist_sym(int i, uint32_t v) { dist_sym_[check(i, dbi::kDistSyms)] = (uint8_t)v; }
     static int check(int i, int n) {
         if (i < 0 || i >= n) {
-            std::fprintf(stderr, "table index %d outside [0, %d)\n", i, n);
+            std::fprintf(stderr, "index %d outside [0, %d)\n", i, n);
             std::abort();
         }
         return i;
@@ -47,7 +54,8 @@ int main(int argc, char** argv) {
         HostMem mem;
         std::memset(&mem, 0, sizeof(mem));
         dbi::Lane L;
-        dbi::lane_start(L, comp.data(), (int64_t)comp_bytes, (int64_t)out_cap);
+        dbi::lane_start(L, mem, comp.data(), (int64_t)comp_bytes, (int64_t)out_cap,
+                        (int64_t)comp.size());
         std::vector<uint32_t> tokens;
         long guard = 0;
         while (L.state != dbi::kDone) {
@@ -60,11 +68,15 @@ int main(int argc, char** argv) {
                 continue;
             }
             uint32_t token = 0;
-            // (kDecode: the hot path the kernel runs; the rest through the general step)
-            if (L.state == dbi::kDecode ? dbi::lane_decode(L, mem, &token)
-                                        : dbi::lane_step(L, mem, &token)) {
-                tokens.push_back(token);
+            if (L.state == dbi::kStored) {
+                if (dbi::lane_stored(L, mem, &token)) tokens.push_back(token);
+                continue;
             }
+            // (kDecode: the hot path as the kernel runs it - four tokens, then the checkpoint
+            // that keeps the input ring filled)
+            for (int k = 0; k < 4; ++k)
+                if (dbi::lane_decode(L, mem, &token)) tokens.push_back(token);
+            L.br.checkpoint(mem);
         }
         // phase 2, sequentially
         std::vector<uint8_t> bytes;

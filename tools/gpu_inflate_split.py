@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""configs[4] with the chunks inflated on the GPU: reads/s of raw loader -> dispatcher ->
+dbh_classify_pair_deflated for ONE setting of (host share of the inflating, device queues) - the
+settings that interact with the process (DEEPBINNER_GRID_CAP: how many CUs the forward kernel
+takes, read when the models are loaded) are set per process by the caller:
+
+    DEEPBINNER_GRID_CAP=224 python tools/gpu_inflate_split.py DIR --share 35 --queues 3
+
+DIR: containers written before with --write (h5py where the box has it, the package's own writer
+otherwise), so that a sweep of processes reads the same files.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('dir')
+    ap.add_argument('--write', type=int, default=0, help='write this many containers and stop')
+    ap.add_argument('--reads', type=int, default=4000)
+    ap.add_argument('--share', type=int, default=35, help='%% of the bytes the host inflates')
+    ap.add_argument('--queues', type=int, default=2)
+    ap.add_argument('--threads', type=int, default=0)
+    ap.add_argument('--repeat', type=int, default=2)
+    opts = ap.parse_args()
+    if opts.write:
+        import subprocess
+        import multi_read_rate
+        os.makedirs(opts.dir, exist_ok=True)
+        paths = [os.path.join(opts.dir, 'batch_%02d.fast5' % k) for k in range(opts.write)]
+        if os.path.exists(multi_read_rate.CONDA_PYTHON):
+            jobs = [subprocess.Popen([multi_read_rate.CONDA_PYTHON, '-c', multi_read_rate.WRITER, p,
+                                      str(opts.reads), '27000', str(100 + k)])
+                    for k, p in enumerate(paths)]
+            if any(j.wait() != 0 for j in jobs):
+                sys.exit('writing the containers with h5py failed')
+        else:
+            for k, p in enumerate(paths):
+                multi_read_rate.write_with_own_writer(p, opts.reads, 27000, 100 + k)
+        return
+    from deepbinner_amd import classify, fast5_native, hip_backend
+    paths = sorted(glob.glob(os.path.join(opts.dir, '*.fast5')))
+    team = opts.threads or min(16, classify.usable_cpus())
+    os.environ['DEEPBINNER_DEVICE_ORDINALS'] = ','.join(['0'] * opts.queues)
+    classify.set_tensorflow_threads(argparse.Namespace(devices=opts.queues))
+    import io
+    models = os.path.join(REPO, 'deepbinner_amd', 'models')
+    sm, _, em, _, _, _ = classify.load_and_check_models(
+        os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
+        os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
+    replicas = classify.device_replicas(sm, em)
+
+    def work(item, start_replica, end_replica):
+        _, ids, offsets, _, comp, records = item
+        calls, status = hip_backend.classify_pair_deflated(
+            start_replica, end_replica, comp, records, offsets, 6144, 0.5)
+        assert (status == 0).all()
+        return len(calls)
+
+    best, best_cpu = 0.0, 0.0
+    for _ in range(opts.repeat + 1):
+        t0, c0 = time.perf_counter(), time.process_time()
+        stream = fast5_native.stream_raw(paths, threads=team, depth=opts.queues + 2,
+                                         host_inflate_above=-opts.share)
+        done = sum(classify.dispatch_batches(stream, replicas, work))
+        wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+        if done / wall > best:
+            best, best_cpu = done / wall, cpu / done
+    print(json.dumps({'host_share_per_cent': opts.share, 'queues': opts.queues,
+                      'grid_cap': os.environ.get('DEEPBINNER_GRID_CAP'), 'loader_threads': team,
+                      'reads_per_s': round(best), 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}))
+
+
+if __name__ == '__main__':
+    main()
