@@ -149,6 +149,9 @@ struct dbh_model {
     int n_classes = 0;
     int device = 0;
     int cus = 256;               // workgroups of a persistent forward launch (one per CU)
+    int cus_total = 256;         // ... before dbh_model_reserve_cus took some away
+    int inflate_streams_per_lane = 0;      // dbh_classify_pair_deflated -> dbh_inflate_dev; 0 = by
+                                           // the lengths of the streams
     bool launch_per_batch = false;   // DEEPBINNER_LAUNCH_PER_BATCH=1: one launch per batch (A/B)
     float* d_packed = nullptr;
     // workspace for the host-pointer entry points, grown on demand
@@ -190,6 +193,7 @@ struct dbh_model {
         void* d_out = nullptr;    size_t d_out_bytes = 0;
         void* d_work = nullptr;   size_t d_work_bytes = 0;
         void* d_tail = nullptr;   size_t d_tail_bytes = 0;
+        std::vector<int32_t> order;                             // the records as they were sent
     } deflated;
     // live timing of the forward kernel (dbh_forward_timing_*)
     int64_t hint_len = 0, hint_cap = 0;   // dbh_model_set_read_length_hint
@@ -512,6 +516,7 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
             const int c = std::atoi(cap);
             if (c > 0 && c < m->cus) m->cus = c;
         }
+        m->cus_total = m->cus;
     }
     {
         const char* knob = std::getenv("DEEPBINNER_LAUNCH_PER_BATCH");
@@ -1104,7 +1109,22 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
         return status;
     };
     char* h = (char*)d.h_small;
-    if (n_streams) std::memcpy(h, streams_host, (size_t)n_streams * sizeof(dbh_inflate_stream));
+    // the records go over longest stream first (a lane of the decoder takes streams off a counter
+    // in this order: what is long starts early, what is short fills the gaps; streams that need no
+    // decoding last); the status comes back in the same order and is put back below
+    std::vector<int32_t>& order = d.order;
+    order.resize((size_t)n_streams);
+    for (int64_t i = 0; i < n_streams; ++i) order[(size_t)i] = (int32_t)i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        const dbh_inflate_stream &x = streams_host[a], &y = streams_host[b];
+        const int64_t kx = x.mode == DBH_INFLATE_ZLIB ? x.comp_bytes : -1;
+        const int64_t ky = y.mode == DBH_INFLATE_ZLIB ? y.comp_bytes : -1;
+        return kx != ky ? kx > ky : a < b;
+    });
+    {
+        dbh_inflate_stream* staged = (dbh_inflate_stream*)h;
+        for (int64_t i = 0; i < n_streams; ++i) staged[i] = streams_host[order[(size_t)i]];
+    }
     std::memcpy(h + rec_bytes, offsets_host, (size_t)(n_reads + 1) * sizeof(int64_t));
     char* ds = (char*)d.d_small;
     const dbh_inflate_stream* d_records = (const dbh_inflate_stream*)ds;
@@ -1136,8 +1156,26 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
         if (e != hipSuccess) return done(hip_fail(e, "hipMemsetAsync"));
     }
     if (n_streams > 0) {
-        st = dbh_inflate_dev((const uint8_t*)d.d_comp, (int64_t)comp_bytes, d_records, n_streams, out_bytes,
-                             (uint8_t*)d.d_samples, d.d_tokens, d_status, (dbh_stream)d.stream);
+        // How wide kernel 1 is launched: it lasts as long as its longest stream whatever the
+        // width, so the lanes may as well take as many streams one after the other as fit into
+        // that time - this call is one of several in flight, and what it leaves free the others
+        // use.  (A lane takes a new stream only at a block boundary, ~1.35 blocks to a mean
+        // read: hence the margin.)
+        int per_lane = m->inflate_streams_per_lane;
+        if (per_lane <= 0) {
+            int64_t sum = 0, count = 0;
+            for (int64_t i = 0; i < n_streams; ++i)
+                if (streams_host[i].mode == DBH_INFLATE_ZLIB) {
+                    sum += streams_host[i].comp_bytes;
+                    ++count;
+                }
+            const int64_t longest = count ? streams_host[order[0]].comp_bytes : 0;
+            per_lane = sum > 0 ? (int)(longest * count * 2 / (sum * 3)) : 1;
+            per_lane = per_lane < 1 ? 1 : per_lane > 8 ? 8 : per_lane;
+        }
+        st = dbh_inflate_dev((const uint8_t*)d.d_comp, (int64_t)comp_bytes, d_records, n_streams,
+                             out_bytes, (uint8_t*)d.d_samples, d.d_tokens, d_status, per_lane,
+                             (dbh_stream)d.stream);
         if (st != DBH_OK) return done(st);
     }
     if (ev[2]) (void)hipEventRecord(ev[2], d.stream);
@@ -1165,8 +1203,11 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
     if (e != hipSuccess) return done(hip_fail(e, "dbh_classify_pair_deflated"));
     std::memcpy(calls_host, h + in_small + ((const char*)d_calls - (const char*)d_status),
                 (size_t)n_reads * sizeof(int32_t));
-    if (stream_status_host && n_streams)
-        std::memcpy(stream_status_host, h + in_small, (size_t)n_streams * sizeof(int32_t));
+    if (stream_status_host && n_streams) {
+        const int32_t* sorted_status = (const int32_t*)(h + in_small);
+        for (int64_t i = 0; i < n_streams; ++i)
+            stream_status_host[order[(size_t)i]] = sorted_status[i];
+    }
     if (stage_ms) {
         float ms = 0.f;
         for (int k = 0; k < 3; ++k) {
@@ -1202,6 +1243,12 @@ int dbh_host_is_pinned(const void* ptr, size_t bytes, int* pinned) {
 int dbh_model_set_host_group(dbh_model* m, int64_t windows_per_group) {
     if (!m || windows_per_group < 0) return DBH_ERR_INVALID_ARGUMENT;
     m->host_group_windows = windows_per_group > 0 ? windows_per_group : dbh_model::kDefaultGroup;
+    return DBH_OK;
+}
+
+int dbh_model_reserve_cus(dbh_model* m, int n_cus) {
+    if (!m || n_cus < 0) return DBH_ERR_INVALID_ARGUMENT;
+    m->cus = m->cus_total - n_cus > 1 ? m->cus_total - n_cus : 1;
     return DBH_OK;
 }
 

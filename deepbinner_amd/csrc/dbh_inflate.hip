@@ -86,10 +86,9 @@ struct StreamInfo {
 __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
     const uint8_t* __restrict__ comp, int64_t comp_total,
     const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
-    StreamInfo* __restrict__ info) {
+    StreamInfo* __restrict__ info, int* __restrict__ next_stream) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes1];
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * kLanes + lane;
     LdsMem mem;
     mem.ring_ = reinterpret_cast<uint32_t*>(lds + kRingOff) + lane;
     mem.lit_pair_ = reinterpret_cast<uint32_t*>(lds + kLitPairOff) + lane;
@@ -117,18 +116,45 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
     L.br.fetch_cap = 0;
     uint32_t* tok = tokens;
     int n_tok = 0;
-    bool mine = false;
-    if (i < n_streams) {
-        const dbh_inflate_stream s = streams[i];
-        if (s.mode == DBH_INFLATE_ZLIB) {
-            mine = true;
-            // (the caller's buffer is readable for 64 bytes beyond comp_total)
-            dbi::lane_start(L, mem, comp + s.comp_offset, s.comp_bytes, s.out_bytes,
-                            comp_total + 64 - s.comp_offset);
-            tok = tokens + s.out_offset;          // one token slot per byte of output
+    int cur = -1;                 // the stream this lane is decoding
+    bool more = true;             // streams may be left to fetch
+    for (;;) {
+        // A lane that has finished its stream takes the next one off the counter - HERE, where
+        // no lane is inside a block: zlib ends a block after a fixed number of symbols, so
+        // streams that start together reach their block headers together (and the hot loop
+        // below ends when the last lane has left its block); a stream taken up in between
+        // would make every lane of the wave wait for its headers, each time, alone.
+        while (L.state == dbi::kDone && more) {
+            if (cur >= 0) {
+                StreamInfo r;
+                r.status = L.status;
+                r.ended = L.ended;
+                r.adler = L.adler;
+                r.n_tokens = n_tok;
+                r.produced = L.out_pos;
+                info[cur] = r;
+            }
+            cur = atomicAdd(next_stream, 1);
+            if (cur >= n_streams) {
+                cur = -1;
+                more = false;
+                break;
+            }
+            const dbh_inflate_stream s = streams[cur];
+            n_tok = 0;
+            if (s.mode == DBH_INFLATE_ZLIB) {
+                // (the caller's buffer is readable for 64 bytes beyond comp_total)
+                dbi::lane_start(L, mem, comp + s.comp_offset, s.comp_bytes, s.out_bytes,
+                                comp_total + 64 - s.comp_offset);
+                tok = tokens + s.out_offset;          // one token slot per byte of output
+            } else {
+                L.status = dbi::kOk;                  // nothing to decode: kernel 2 copies it
+                L.ended = 0;
+                L.adler = 0;
+                L.out_pos = 0;
+            }
         }
-    }
-    while (__any(L.state != dbi::kDone)) {
+        if (!__any(L.state != dbi::kDone)) break;
         // the rare states: a block header (with its two code builds), a stored block's bytes
         if (L.state == dbi::kNeedBlock) {
             dbi::lane_block(L, mem);
@@ -137,8 +163,7 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
             if (dbi::lane_stored(L, mem, &token)) tok[n_tok++] = token;
         }
         // the hot loop: every lane that is inside a Huffman block decodes four tokens per round
-        // (lanes that have left their block wait for the others - streams deflated alike leave
-        // together: zlib ends a block after a fixed number of symbols)
+        // (lanes that have left their block wait for the others)
         while (__any(L.state == dbi::kDecode)) {
             uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             const bool p0 = dbi::lane_decode(L, mem, &t0);
@@ -160,25 +185,20 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
             L.br.checkpoint(mem);
         }
     }
-    if (i < n_streams) {
-        StreamInfo r;
-        r.status = mine ? L.status : dbi::kOk;
-        r.ended = L.ended;
-        r.adler = L.adler;
-        r.n_tokens = n_tok;
-        r.produced = L.out_pos;
-        info[i] = r;
-    }
 }
 
 constexpr int kRing = 32768;
+constexpr int kWaves2 = 5;                 // streams per workgroup of kernel 2: a 32 KiB ring each
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const int other = __shfl_xor(v, o);
-        v = other < v ? other : v;
-    }
+// Wave-wide inclusive prefix sum on the DPP network (no LDS round trips): within rows of 16
+// lanes by shifts, then each row's total handed on to the rows behind it.
+__device__ __forceinline__ int wave_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
@@ -186,18 +206,41 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 // a compiler barrier that also drains the wave's LDS queue: what other lanes wrote is there
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ __launch_bounds__(256) void inflate_resolve_kernel(
+// Adler-32 without a reduction per piece: s1 = 1 + sum of the bytes, s2 = n + sum over the bytes
+// of (n - position) * byte, n = the stream's length (known from kernel 1) - every lane keeps its
+// own two sums, the wave adds them up once per stream.
+struct AdlerLane {
+    unsigned bytes;
+    unsigned long long weighted;
+    __device__ __forceinline__ void add4(unsigned w, unsigned left) {     // `left` = n - position
+        const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
+        const unsigned s = b0 + b1 + b2 + b3;
+        bytes += s;
+        weighted += (unsigned long long)left * s - (b1 + 2u * b2 + 3u * b3);
+    }
+    __device__ __forceinline__ void add1(unsigned b, unsigned left) {
+        bytes += b;
+        weighted += (unsigned long long)left * b;
+    }
+};
+
+__global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
     const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
     const uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info, uint8_t* __restrict__ out,
     int32_t* __restrict__ status_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t rings[4 * kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t rings[kWaves2 * kRing];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t* ring = rings + wave * kRing;
-    for (int i = blockIdx.x * 4 + wave; i < n_streams; i += gridDim.x * 4) {
+    for (int i = blockIdx.x * kWaves2 + wave; i < n_streams; i += gridDim.x * kWaves2) {
         const dbh_inflate_stream s = streams[i];
         uint8_t* dst = out + s.out_offset;
         const int64_t cap = s.out_bytes;
@@ -206,7 +249,13 @@ __global__ __launch_bounds__(256) void inflate_resolve_kernel(
             // inflated itself): copy, zero-extend
             const int64_t have = s.comp_bytes < cap ? s.comp_bytes : cap;
             const uint8_t* src = comp + s.comp_offset;
-            for (int64_t k = lane; k < cap; k += 64) dst[k] = k < have ? src[k] : (uint8_t)0;
+            const int64_t whole = have & ~(int64_t)7;
+            for (int64_t k = 8 * (int64_t)lane; k < whole; k += 512) {
+                uint64_t v;
+                __builtin_memcpy(&v, src + k, 8);
+                __builtin_memcpy(dst + k, &v, 8);
+            }
+            for (int64_t k = whole + lane; k < cap; k += 64) dst[k] = k < have ? src[k] : (uint8_t)0;
             if (lane == 0) status_out[i] = dbi::kOk;
             continue;
         }
@@ -214,80 +263,96 @@ __global__ __launch_bounds__(256) void inflate_resolve_kernel(
         int status = r.status;
         const uint32_t* tok = tokens + s.out_offset;
         const int n_tok = r.n_tokens;
+        const unsigned n_out = (unsigned)r.produced;
         int pos = 0, flushed = 0;                    // (a stream's output is far below 2^31 bytes)
-        unsigned s1 = 1, s2 = 0;
+        AdlerLane adler = {0u, 0ull};
         if (status == dbi::kOk) {
+            uint32_t t_next = lane < n_tok ? tok[lane] : 0u;
             for (int t0 = 0; t0 < n_tok; t0 += 64) {
                 const bool valid = t0 + lane < n_tok;
-                const uint32_t t = valid ? tok[t0 + lane] : 0u;
+                const uint32_t t = t_next;
+                // (the next step's tokens are on their way while this step's are resolved)
+                t_next = t0 + 64 + lane < n_tok ? tok[t0 + 64 + lane] : 0u;
                 const bool is_match = valid && (t & dbi::kMatchFlag);
                 const int len = !valid ? 0 : is_match ? (int)(t & 0x1FFu) : 1;
                 const int dist = (int)((t >> 9) & 0x7FFFu) + 1;
-                int incl = len;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
-                const int total = __shfl(incl, 63);
+                const int incl = wave_scan_i32(len);
+                const int total = __builtin_amdgcn_readlane(incl, 63);
                 const int my = pos + incl - len;
                 if (__any(is_match && dist > my)) {     // reaches before the start of the output
                     status = dbi::kBadDistance;
                     break;
                 }
                 if (valid && !is_match) ring[my & (kRing - 1)] = (uint8_t)t;
-                bool pending = is_match;
+                // A match repeats the `dist` bytes before it: byte k is byte k mod dist of them,
+                // so everything it READS lies before its own start, in [src, src + min(len,
+                // dist)) - it may go as soon as that is written, i.e. lies before the earliest
+                // byte still to be written (the first waiting match's start: the positions ascend
+                // with the lanes).  The first waiting match can always go.
                 const int src = my - dist;
-                for (;;) {
-                    const int first = wave_min_i32(pending ? my : 0x7FFFFFFF);
-                    if (first == 0x7FFFFFFF) break;
+                const int reach = src + (len < dist ? len : dist);
+                bool waiting = is_match;
+                unsigned long long mask = __ballot(waiting);
+                while (mask != 0ull) {
                     lds_settle();
-                    // everything this match reads that it does not write itself lies before
-                    // the earliest byte still to be written
-                    const int own = src + len < my ? src + len : my;
-                    if (pending && own <= first) {
-                        for (int k = 0; k < len; ++k)
-                            ring[(my + k) & (kRing - 1)] = ring[(src + k) & (kRing - 1)];
-                        pending = false;
+                    const int first = __builtin_amdgcn_readlane(my, __ffsll((long long)mask) - 1);
+                    const bool go = waiting && reach <= first;
+                    int k = 0, o = 0;                    // o = k mod dist
+                    while (__any(go && k < len)) {
+                        if (go && k < len) {
+                            // four bytes at a time: the loads leave together, then the stores
+                            int o1 = o + 1;
+                            o1 = o1 == dist ? 0 : o1;
+                            int o2 = o1 + 1;
+                            o2 = o2 == dist ? 0 : o2;
+                            int o3 = o2 + 1;
+                            o3 = o3 == dist ? 0 : o3;
+                            const uint8_t b0 = ring[(src + o) & (kRing - 1)];
+                            const uint8_t b1 = ring[(src + o1) & (kRing - 1)];
+                            const uint8_t b2 = ring[(src + o2) & (kRing - 1)];
+                            const uint8_t b3 = ring[(src + o3) & (kRing - 1)];
+                            ring[(my + k) & (kRing - 1)] = b0;
+                            if (k + 1 < len) ring[(my + k + 1) & (kRing - 1)] = b1;
+                            if (k + 2 < len) ring[(my + k + 2) & (kRing - 1)] = b2;
+                            if (k + 3 < len) ring[(my + k + 3) & (kRing - 1)] = b3;
+                            o = o3 + 1;
+                            o = o == dist ? 0 : o;
+                            k += 4;
+                        }
                     }
-                    lds_settle();
+                    waiting = waiting && !go;
+                    mask = __ballot(waiting);
                 }
                 pos += total;
-                // whole 256-byte pieces out of the ring, the Adler-32 on the way
-                while (pos - flushed >= 256) {
+                // whole 256-byte pieces out of the ring, the Adler-32 sums on the way
+                if (pos - flushed >= 256) {
                     lds_settle();
-                    const uint32_t w =
-                        *reinterpret_cast<const uint32_t*>(ring + ((flushed + 4 * lane) & (kRing - 1)));
-                    uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + flushed + 4 * lane);
-                    d16[0] = (uint16_t)w;             // (a read starts at an even byte, not
-                    d16[1] = (uint16_t)(w >> 16);     //  necessarily at a multiple of four)
-                    const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u,
-                                   b3 = w >> 24;
-                    const unsigned at = 4u * (unsigned)lane;          // position inside the piece
-                    const unsigned sum = wave_sum_u32(b0 + b1 + b2 + b3);
-                    const unsigned weighted = wave_sum_u32((256u - at) * b0 + (255u - at) * b1 +
-                                                           (254u - at) * b2 + (253u - at) * b3);
-                    s2 = (s2 + 256u * s1 + weighted) % 65521u;
-                    s1 = (s1 + sum) % 65521u;
-                    flushed += 256;
+                    do {
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(
+                            ring + ((flushed + 4 * lane) & (kRing - 1)));
+                        uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + flushed + 4 * lane);
+                        d16[0] = (uint16_t)w;             // (a read starts at an even byte, not
+                        d16[1] = (uint16_t)(w >> 16);     //  necessarily at a multiple of four)
+                        adler.add4(w, n_out - (unsigned)(flushed + 4 * lane));
+                        flushed += 256;
+                    } while (pos - flushed >= 256);
                 }
             }
         }
         if (status == dbi::kOk) {
             lds_settle();
             const int rest = pos - flushed;           // < 256
-            unsigned sum = 0, weighted = 0;
             for (int k = lane; k < rest; k += 64) {
                 const unsigned b = ring[(flushed + k) & (kRing - 1)];
                 dst[flushed + k] = (uint8_t)b;
-                sum += b;
-                weighted += (unsigned)(rest - k) * b;
+                adler.add1(b, n_out - (unsigned)(flushed + k));
             }
-            sum = wave_sum_u32(sum);
-            weighted = wave_sum_u32(weighted);
-            s2 = (s2 + (unsigned)rest * s1 + weighted) % 65521u;
-            s1 = (s1 + sum) % 65521u;
-            if (r.ended && ((s2 << 16) | s1) != r.adler) status = dbi::kBadChecksum;
+            if (r.ended) {
+                const unsigned s1 = (1u + wave_sum_u32(adler.bytes)) % 65521u;
+                const unsigned s2 =
+                    (unsigned)(((unsigned long long)n_out + wave_sum_u64(adler.weighted)) % 65521ull);
+                if (((s2 << 16) | s1) != r.adler) status = dbi::kBadChecksum;
+            }
             // a stream that ends early (MinKNOW's short final chunk): libhdf5 zero-extends it
             for (int64_t k = pos + lane; k < cap; k += 64) dst[k] = 0;
         }
@@ -321,29 +386,40 @@ int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size
     if (!bytes || total_out_bytes < 0 || n_streams < 0) return DBH_ERR_INVALID_ARGUMENT;
     // one token slot per byte of output (a token yields at least one byte), then the per-stream
     // records of kernel 1
-    *bytes = (size_t)total_out_bytes * sizeof(uint32_t) + 256 +
+    *bytes = (size_t)total_out_bytes * sizeof(uint32_t) + 512 +
              (size_t)n_streams * sizeof(StreamInfo);
     return DBH_OK;
 }
 
 int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
-                    const dbh_inflate_stream* streams_dev, int64_t n_streams, int64_t total_out_bytes, uint8_t* out_dev,
-                    void* workspace_dev, int32_t* status_dev, dbh_stream stream) {
-    if (n_streams < 0 || n_streams > 0x7FFFFFFF || total_out_bytes < 0 || comp_bytes < 0)
+                    const dbh_inflate_stream* streams_dev, int64_t n_streams,
+                    int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,
+                    int32_t* status_dev, int streams_per_lane, dbh_stream stream) {
+    if (n_streams < 0 || n_streams > 0x7FFFFFFF || total_out_bytes < 0 || comp_bytes < 0 ||
+        streams_per_lane < 0)
         return DBH_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return DBH_OK;
     if (!comp_dev || !streams_dev || !out_dev || !workspace_dev || !status_dev)
         return DBH_ERR_INVALID_ARGUMENT;
     uint32_t* tokens = (uint32_t*)workspace_dev;
-    StreamInfo* info = (StreamInfo*)((char*)workspace_dev +
-                                     (((size_t)total_out_bytes * sizeof(uint32_t) + 255) & ~(size_t)255));
+    char* behind = (char*)workspace_dev +
+                   (((size_t)total_out_bytes * sizeof(uint32_t) + 255) & ~(size_t)255);
+    int* counter = (int*)behind;
+    StreamInfo* info = (StreamInfo*)(behind + 256);
     const int n = (int)n_streams;
-    hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((n + kLanes - 1) / kLanes)),
+    DBI_HIP(hipMemsetAsync(counter, 0, sizeof(int), (hipStream_t)stream));
+    // the lanes take streams off a counter: with one stream per lane (the default) a launch is
+    // as wide as it can be and lasts as long as its longest stream; with several, a fraction of
+    // the CUs does the same work in the time the longest stream needs anyway
+    const int per_lane = streams_per_lane > 0 ? streams_per_lane : 1;
+    const int64_t lanes = (n_streams + per_lane - 1) / per_lane;
+    hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((lanes + kLanes - 1) / kLanes)),
                        dim3(kLanes), 0, (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n,
-                       tokens, info);
+                       tokens, info, counter);
     DBI_HIP(hipGetLastError());
-    const int blocks = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
-    hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0,
+    const int groups = (n + kWaves2 - 1) / kWaves2;
+    const int blocks = groups < 1024 ? groups : 1024;
+    hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(64 * kWaves2), 0,
                        (hipStream_t)stream, comp_dev, streams_dev, n, (const uint32_t*)tokens, info,
                        out_dev, status_dev);
     DBI_HIP(hipGetLastError());
@@ -394,8 +470,7 @@ int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_s
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
     if (e == hipSuccess && st == DBH_OK)
         st = dbh_inflate_dev(d_comp, (int64_t)comp_bytes, d_streams, n_streams, (int64_t)out_bytes,
-                             d_out, d_work,
-                             d_status, nullptr);
+                             d_out, d_work, d_status, 0, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_host, d_out, out_bytes, hipMemcpyDeviceToHost);
     if (e == hipSuccess)

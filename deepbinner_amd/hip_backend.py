@@ -58,6 +58,10 @@ def load_library():
         raise HipBackendError(
             '{} has not been built - run `python -c "import __graft_entry__ as g; g.build()"` '
             '(or `make -C deepbinner_amd/csrc`). There is no CPU fallback.'.format(path))
+    # (the HIP runtime maps a process's streams onto four hardware queues unless told otherwise,
+    # and streams that share one run their kernels one after the other: the streaming path keeps
+    # several containers in flight, each on a stream of its own - realtime.inflate_queues)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:
@@ -103,13 +107,14 @@ def load_library():
                                           ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
         'dbh_model_set_host_group': (c_int, [c_void_p, c_i64]),
+        'dbh_model_reserve_cus': (c_int, [c_void_p, c_int]),
         'dbh_host_alloc': (c_void_p, [c_size_t, c_void_p]),
         'dbh_host_release': (None, [c_void_p, c_void_p]),
         'dbh_host_is_pinned': (c_int, [c_void_p, c_size_t, P(c_int)]),
         'dbh_inflate_last_error': (ctypes.c_char_p, []),
         'dbh_inflate_workspace_bytes': (c_int, [c_i64, c_i64, P(c_size_t)]),
         'dbh_inflate_dev': (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_int, c_void_p]),
         'dbh_inflate': (c_int, [c_void_p, c_size_t, c_void_p, c_i64, c_void_p, c_size_t, c_void_p,
                                 P(ctypes.c_double)]),
         'dbh_classify_pair_deflated': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
@@ -167,7 +172,8 @@ EXPORTED_SYMBOLS = [
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_pair_i16',
-    'dbh_model_set_host_group', 'dbh_host_alloc', 'dbh_host_release', 'dbh_host_is_pinned',
+    'dbh_model_set_host_group', 'dbh_model_reserve_cus', 'dbh_host_alloc', 'dbh_host_release',
+    'dbh_host_is_pinned',
     'dbh_classify_workspace_bytes', 'dbh_inflate_last_error', 'dbh_inflate_workspace_bytes',
     'dbh_inflate_dev', 'dbh_inflate', 'dbh_classify_pair_deflated',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
@@ -600,6 +606,16 @@ class HipModel:
         """Windows per model and group of the host-buffer pipeline (0 = the default 32,768)."""
         check(self._lib.dbh_model_set_host_group(self._handle, int(windows_per_group)),
               'dbh_model_set_host_group')
+
+    def reserve_cus(self, n_cus=0):
+        """Leave ``n_cus`` CUs out of this model's forward launches (0 = take all again): room
+        for the inflate kernels of the containers that follow on other queues."""
+        check(self._lib.dbh_model_reserve_cus(self._handle, int(n_cus)), 'dbh_model_reserve_cus')
+
+    def clone(self):
+        """The same weights as another model on the same GPU: its own streams and buffers - one
+        more queue."""
+        return HipModel(self.weights, device=self.device)
 
     def set_read_length_hint(self, read_length, capacity_samples=0):
         """Tell the ``*_dev`` entry points that every read is ``read_length`` samples long (0

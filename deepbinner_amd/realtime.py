@@ -34,21 +34,30 @@ POLL_SECONDS = 5
 PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 
 
+# The streaming path with the GPU inflating: what it was measured with on an MI355X box (16
+# usable cores, one GPU; profiles/r03_gpu_inflate_split.txt) - three containers in flight per GPU,
+# each on its own queue (model replica), and 32 CUs left out of the forward kernel's persistent
+# launches for the inflate kernels of the containers behind.
+INFLATE_QUEUES = 3          # (six where the GPU inflates nearly everything: a container then
+INFLATE_CUS = 32            #  lasts as long as its longest read, ~10 mean reads)
+
+
 def host_inflate_share(n_gpus):
     """Per cent of a container's compressed bytes the host's threads inflate themselves (its
-    longest streams); the GPUs inflate the rest.  100 = everything on the host (the CPU-only
-    loader path), 0 = everything on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end,
-    DEEPBINNER_HOST_INFLATE_SHARE=<per cent> any split.
+    longest streams: a lane of the GPU's decoder walks ONE stream, however long); the GPUs
+    inflate the rest.  100 = everything on the host (the CPU-only loader path), 0 = everything
+    on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end, DEEPBINNER_HOST_INFLATE_SHARE=
+    <per cent> any split.
 
-    Left alone, the host does all of it unless it is starved of cores: measured on an MI355X box
-    (profiles/r03_multi_read_rate_gpu_inflate.json; 27 k-sample reads, gzip 1) a core inflates a
-    read in 118 us and fetches it raw in 10, a GPU classifies it (start + end models) in 4.7 us
-    and inflates it in ~8 us at best (three containers in flight) - a whole MI355X inflates like
-    ~50 EPYC cores, and every microsecond of it is taken from the classification.  With 16 cores
-    per GPU (this box) the host alone keeps up with ~60 % of what the GPU can classify and any
-    share given to the GPU lowers the total (the split sweep in that file); below six cores per
-    GPU - eight GPUs on a 16-core host: one host feeding eight GPUs is BASELINE.json configs[4] -
-    the GPUs take the share that loads both sides evenly."""
+    Left alone: what the host's cores can do beside their other work while a GPU classifies at
+    the rate it reaches with the inflate kernels running beside the forward kernel.  Measured
+    (profiles/r03_gpu_inflate_split.txt; 27 k-sample reads, gzip 1, 16 loader threads): the host
+    spends ~25 us per read on everything but inflating and ~0.9 us more per per cent of the bytes
+    it inflates; a GPU with three containers in flight settles at ~165 k reads/s for any share
+    between 40 and 70 - so the host takes what four fifths of its cores manage at that rate
+    (16 cores, one GPU: 58 %; 24 cores per GPU and more: everything, and the inflate kernels are
+    not used at all; a 16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing:
+    there the GPUs inflate every stream)."""
     flag = os.environ.get('DEEPBINNER_GPU_INFLATE')
     if flag == '0':
         return 100
@@ -58,10 +67,33 @@ def host_inflate_share(n_gpus):
     if explicit:
         return max(0, min(100, int(explicit)))
     cores, gpus = float(usable_cpus()), float(max(n_gpus, 1))
-    if cores / gpus >= 6.0:
-        return 100
-    r = (128.0 / cores - 4.7 / gpus) / (118.0 / cores + 8.0 / gpus)
-    return int(round(100 * (1.0 - max(0.0, min(1.0, r)))))
+    budget_us = 0.8 * cores / gpus / 165e3 * 1e6           # host time per read at the GPU's rate
+    return int(round(max(0.0, min(100.0, (budget_us - 25.0) / 0.9))))
+
+
+def inflate_queues(replicas, clones, host_share=50):
+    """-> (replicas, models): INFLATE_QUEUES (start, end) pairs per GPU instead of one - more
+    model replicas on the same GPU, each with its own streams and buffers (kept in ``clones`` for
+    the passes to come) - so that one container's chunks are inflated while the one before it is
+    classified; every model's forward launches leave INFLATE_CUS CUs to the inflate kernels
+    (``reserve_cus(0)`` on the models returned gives them back).  DEEPBINNER_INFLATE_QUEUES /
+    DEEPBINNER_INFLATE_CUS."""
+    n_queues = int(os.environ.get('DEEPBINNER_INFLATE_QUEUES', 0) or 0)
+    if n_queues < 1:
+        n_queues = INFLATE_QUEUES if host_share >= 30 else 2 * INFLATE_QUEUES
+    n_cus = max(0, int(os.environ.get('DEEPBINNER_INFLATE_CUS', INFLATE_CUS)))
+    out = []
+    for pair in replicas:
+        more = clones.setdefault(tuple(id(m) for m in pair), [])
+        while len(more) < n_queues - 1:
+            more.append(tuple(m.clone() if m is not None else None for m in pair))
+        out.extend([pair] + more[:n_queues - 1])
+    # queue k of every GPU before queue k + 1 of any: consecutive containers go to different GPUs
+    out = [out[d * n_queues + k] for k in range(n_queues) for d in range(len(replicas))]
+    models = [m for pair in out for m in pair if m is not None]
+    for model in models:
+        model.reserve_cus(n_cus if n_queues > 1 else 0)
+    return out, models
 
 
 def bin_name(barcode_call):
@@ -326,9 +358,13 @@ class Session:
         packed = reader_kind() == 'native' and all(hasattr(m, 'classify_packed') for m in models)
         replicas = classify.device_replicas(self.start_model, self.end_model)
         host_share = host_inflate_share(len({getattr(r[0] or r[1], 'device', 0) for r in replicas}))
+        queues = []
         if packed and host_share < 100 and all(hasattr(m, 'handle') for m in models):
             items = self._raw_containers(fast5s, host_share)
             work = self._classify_raw_container
+            if not hasattr(self, '_queue_clones'):
+                self._queue_clones = {}
+            replicas, queues = inflate_queues(replicas, self._queue_clones, host_share)
         elif packed:
             items, work = self._packed_containers(fast5s), self._classify_container
         else:
@@ -355,6 +391,8 @@ class Session:
         writers.shutdown(wait=True)
         if metadata is not None:
             metadata.close()
+        for model in queues:                # the forward kernel gets every CU back
+            model.reserve_cus(0)
         if failures:
             sys.exit('Error: failed to write {} one-read fast5 file{} into {} ({})'.format(
                 len(failures), '' if len(failures) == 1 else 's', self.out_dir, failures[0]))

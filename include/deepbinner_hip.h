@@ -113,6 +113,12 @@ int dbh_classify_i16(dbh_model* model, const int16_t* samples_host, const int64_
  * slots, so that the upload of one group, the kernels of another and the results of a third
  * overlap. */
 int dbh_model_set_host_group(dbh_model* model, int64_t windows_per_group /* 0 = default */);
+/* The forward kernel is persistent: one workgroup per CU walks the windows of a launch.  A model
+ * whose launches share the GPU with the inflate kernels of the next containers (the streaming
+ * path: dbh_classify_pair_deflated on several queues) leaves them n_cus CUs - otherwise those
+ * kernels find no CU free until the launch ends, and the workgroups they displaced start late.
+ * 0 = all CUs again. */
+int dbh_model_reserve_cus(dbh_model* model, int n_cus);
 
 /* The body of the reference's per-batch loop (classify.py:141-171) for one batch of reads and BOTH
  * models in one call: the samples are uploaded once, the start model scans the first and the end
@@ -199,11 +205,16 @@ typedef struct dbh_inflate_stream {
 const char* dbh_inflate_last_error(void);
 /* total_out_bytes = size of the output buffer the streams write into */
 int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size_t* bytes);
-/* comp_bytes = size of the compressed buffer (the decoder's read-ahead stops 64 bytes behind it) */
+/* comp_bytes = size of the compressed buffer (the decoder's read-ahead stops 64 bytes behind it).
+ * streams_per_lane (0 = 1): the lanes of kernel 1 take streams off a counter, in the order of the
+ * records - with one stream per lane a launch is as wide as the streams are many and lasts as long
+ * as the longest of them; with n, a launch 1/n as wide does the same work, and lasts no longer if
+ * the long streams come first in the records and are long enough (a container of reads: 4) -
+ * room for other kernels on the rest of the GPU. */
 int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
                     const dbh_inflate_stream* streams_dev, int64_t n_streams,
                     int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,
-                    int32_t* status_dev, dbh_stream stream);
+                    int32_t* status_dev, int streams_per_lane, dbh_stream stream);
 /* host buffers in, host buffers out (tests, tools); kernel_ms (may be NULL): the two kernels */
 int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
                 int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,

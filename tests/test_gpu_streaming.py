@@ -168,6 +168,35 @@ def build_containers(directory, gold):
     return paths, every_id
 
 
+def test_a_model_on_fewer_cus_and_its_clone_give_the_same_calls(hip, hip_models, all_signals):
+    """dbh_model_reserve_cus leaves CUs to other kernels (the streaming path's inflate queues),
+    HipModel.clone() is one more queue on the same GPU: neither changes a result."""
+    start, end = hip_models[START], hip_models[END]
+    signals = list(all_signals)
+    want = [m.classify_signals(signals, side, 6144, 0.5)
+            for m, side in ((start, 'start'), (end, 'end'))]
+    try:
+        for reserve in (32, 200, 255, 100000):
+            start.reserve_cus(reserve)
+            end.reserve_cus(reserve)
+            got = [m.classify_signals(signals, side, 6144, 0.5)
+                   for m, side in ((start, 'start'), (end, 'end'))]
+            for (wp, wc), (gp, gc) in zip(want, got):
+                assert np.array_equal(wp, gp) and np.array_equal(wc, gc)
+    finally:
+        start.reserve_cus(0)
+        end.reserve_cus(0)
+    twin = start.clone()
+    try:
+        assert twin.device == start.device and twin.handle.value != start.handle.value
+        gp, gc = twin.classify_signals(signals, 'start', 6144, 0.5)
+        assert np.array_equal(want[0][0], gp) and np.array_equal(want[0][1], gc)
+    finally:
+        twin.close()
+    with pytest.raises(hip.HipBackendError):
+        start.reserve_cus(-1)
+
+
 @pytest.fixture(scope='module')
 def containers(tmp_path_factory, gold):
     directory = str(tmp_path_factory.mktemp('stream'))
@@ -333,6 +362,16 @@ def test_realtime_with_and_without_gpu_inflate(hip, gold, containers, tmp_path, 
     monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '0')
     off, _ = run_realtime(directory, str(tmp_path / 'cpu'), 1, monkeypatch, capsys)
     assert on == off and len(on) == len(every_id)
+    # the split this box gets when nothing is forced (host_inflate_share: the host's threads keep
+    # the longest streams, three queues on the GPU, 32 CUs left to the inflate kernels)
+    monkeypatch.delenv('DEEPBINNER_GPU_INFLATE')
+    import deepbinner_amd.realtime as realtime
+    t0 = time.perf_counter()
+    shared, _ = run_realtime(directory, str(tmp_path / 'shared'), 1, monkeypatch, capsys)
+    seconds = time.perf_counter() - t0
+    print('realtime, host share %d %%: %d reads in %.1f s = %.0f reads/s'
+          % (realtime.host_inflate_share(1), len(shared), seconds, len(shared) / seconds))
+    assert shared == off
     # damage: one byte in the middle of a deflate stream of one container
     from deepbinner_amd import fast5_native
     broken_dir = tmp_path / 'broken'

@@ -483,3 +483,27 @@ def test_usable_cpus_is_a_sane_number():
     from deepbinner_amd import misc
     n = misc.usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_host_inflate_share_follows_the_cores_per_gpu(monkeypatch):
+    """How much of the inflating the host keeps (realtime.host_inflate_share): everything when it
+    has cores to spare, nothing when eight GPUs hang off sixteen cores, in between in between;
+    the environment overrides either way."""
+    import deepbinner_amd.realtime as realtime
+    for name in ('DEEPBINNER_GPU_INFLATE', 'DEEPBINNER_HOST_INFLATE_SHARE'):
+        monkeypatch.delenv(name, raising=False)
+    shares = []
+    for cores in (2, 4, 8, 16, 24, 32, 64, 256):
+        monkeypatch.setattr(realtime, 'usable_cpus', lambda cores=cores: cores)
+        shares.append(realtime.host_inflate_share(1))
+        assert realtime.host_inflate_share(8) <= shares[-1]
+    assert shares == sorted(shares) and shares[0] == 0 and shares[-1] == 100
+    assert 40 <= shares[3] <= 70                     # 16 cores, one GPU: the box it was measured on
+    monkeypatch.setattr(realtime, 'usable_cpus', lambda: 16)
+    assert realtime.host_inflate_share(8) == 0       # BASELINE.json configs[4]: one host, eight GPUs
+    monkeypatch.setenv('DEEPBINNER_HOST_INFLATE_SHARE', '37')
+    assert realtime.host_inflate_share(1) == 37
+    monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '0')
+    assert realtime.host_inflate_share(1) == 100
+    monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '1')
+    assert realtime.host_inflate_share(1) == 0

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """configs[4] with the chunks inflated on the GPU: reads/s of raw loader -> dispatcher ->
-dbh_classify_pair_deflated for ONE setting of (host share of the inflating, device queues) - the
-settings that interact with the process (DEEPBINNER_GRID_CAP: how many CUs the forward kernel
-takes, read when the models are loaded) are set per process by the caller:
+dbh_classify_pair_deflated for ONE setting of (host share of the inflating, device queues, CUs
+left to the inflate kernels) - the pipeline deepbinner_amd/realtime.py runs on multi-read files:
 
-    DEEPBINNER_GRID_CAP=224 python tools/gpu_inflate_split.py DIR --share 35 --queues 3
+    python tools/gpu_inflate_split.py DIR --share 53 --queues 3 --cus 32
 
 DIR: containers written before with --write (h5py where the box has it, the package's own writer
 otherwise), so that a sweep of processes reads the same files.
@@ -27,7 +26,8 @@ def main():
     ap.add_argument('--write', type=int, default=0, help='write this many containers and stop')
     ap.add_argument('--reads', type=int, default=4000)
     ap.add_argument('--share', type=int, default=35, help='%% of the bytes the host inflates')
-    ap.add_argument('--queues', type=int, default=2)
+    ap.add_argument('--queues', type=int, default=0, help='0 = what realtime.py would take')
+    ap.add_argument('--cus', type=int, default=32, help='CUs left out of the forward launches')
     ap.add_argument('--threads', type=int, default=0)
     ap.add_argument('--repeat', type=int, default=2)
     opts = ap.parse_args()
@@ -49,14 +49,16 @@ def main():
     from deepbinner_amd import classify, fast5_native, hip_backend
     paths = sorted(glob.glob(os.path.join(opts.dir, '*.fast5')))
     team = opts.threads or min(16, classify.usable_cpus())
-    os.environ['DEEPBINNER_DEVICE_ORDINALS'] = ','.join(['0'] * opts.queues)
-    classify.set_tensorflow_threads(argparse.Namespace(devices=opts.queues))
     import io
     models = os.path.join(REPO, 'deepbinner_amd', 'models')
     sm, _, em, _, _, _ = classify.load_and_check_models(
         os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
         os.path.join(models, 'EXP-NBD103_read_ends.dbw'), 6144, out_dest=io.StringIO())
-    replicas = classify.device_replicas(sm, em)
+    from deepbinner_amd import realtime
+    if opts.queues:
+        os.environ['DEEPBINNER_INFLATE_QUEUES'] = str(opts.queues)
+    os.environ['DEEPBINNER_INFLATE_CUS'] = str(opts.cus)
+    replicas, _ = realtime.inflate_queues(classify.device_replicas(sm, em), {}, opts.share)
 
     def work(item, start_replica, end_replica):
         _, ids, offsets, _, comp, records = item
@@ -68,14 +70,14 @@ def main():
     best, best_cpu = 0.0, 0.0
     for _ in range(opts.repeat + 1):
         t0, c0 = time.perf_counter(), time.process_time()
-        stream = fast5_native.stream_raw(paths, threads=team, depth=opts.queues + 2,
+        stream = fast5_native.stream_raw(paths, threads=team, depth=len(replicas) + 2,
                                          host_inflate_above=-opts.share)
         done = sum(classify.dispatch_batches(stream, replicas, work))
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0
         if done / wall > best:
             best, best_cpu = done / wall, cpu / done
-    print(json.dumps({'host_share_per_cent': opts.share, 'queues': opts.queues,
-                      'grid_cap': os.environ.get('DEEPBINNER_GRID_CAP'), 'loader_threads': team,
+    print(json.dumps({'host_share_per_cent': opts.share, 'queues': len(replicas),
+                      'cus_left_to_inflate': opts.cus, 'loader_threads': team,
                       'reads_per_s': round(best), 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}))
 
 

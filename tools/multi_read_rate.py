@@ -231,55 +231,68 @@ def main():
 
         gpu_inflate = {}
         team = min(16, classify.usable_cpus())
-        # the split: from everything on the GPU to everything on the host, one device queue
+        # the split: from everything on the GPU to everything on the host, with the queues and
+        # the CUs realtime.py gives the inflate kernels at that split
         sweep = {}
         replicas, _ = load_models(1)
-        for host_share in (0, 20, 40, 60, 80, 100):
+        clones = {}
+        for host_share in (0, 20, 40, 50, 60, 70, 100):
+            queues, models = realtime.inflate_queues(replicas, clones, host_share)
             best, best_cpu = 0.0, 0.0
             for _ in range(2):
                 t0, c0 = time.perf_counter(), time.process_time()
-                stream = fast5_native.stream_raw(paths, threads=team, depth=4,
+                stream = fast5_native.stream_raw(paths, threads=team, depth=len(queues) + 2,
                                                  host_inflate_above=-host_share)
-                done = sum(classify.dispatch_batches(stream, replicas, raw_work))
+                done = sum(classify.dispatch_batches(stream, queues, raw_work))
                 wall, cpu = time.perf_counter() - t0, time.process_time() - c0
                 if done / wall > best:
                     best, best_cpu = done / wall, cpu / done
-            sweep['host inflates %d %% of the bytes' % host_share] = {
+            for model in models:
+                model.reserve_cus(0)
+            sweep['host inflates %d %% of the bytes (%d queues)' % (host_share, len(queues))] = {
                 'load_and_classify_reads_per_s': round(best),
                 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}
-        gpu_inflate['split sweep, 1 queue, %d loader threads' % team] = sweep
+        gpu_inflate['split sweep, %d loader threads' % team] = sweep
         raw_loaded = list(fast5_native.stream_raw(paths[:4], threads=8, depth=4,
                                                   host_inflate_above=above))
-        for n_queues in (1, 2, 3):
-            replicas, ordinals = load_models(n_queues)
-            if n_queues == 1:
-                stages = [hip_backend.classify_pair_deflated(
-                    replicas[0][0], replicas[0][1], item[4], item[5], item[2], 6144, 0.5,
-                    want_stages=True)[2] for item in raw_loaded * 2][len(raw_loaded):]
-                gpu_inflate['device_ms_per_container (upload, inflate, classify)'] = [
-                    round(float(sum(s[k] for s in stages) / len(stages)), 2) for k in range(3)]
-                rec = raw_loaded[0][5]
-                gpu_inflate['streams_per_container'] = {
-                    'zlib (GPU)': int((rec['mode'] == 0).sum()),
-                    'stored / host-inflated': int((rec['mode'] == 1).sum())}
-            sum(classify.dispatch_batches(iter(raw_loaded[:2]), replicas, raw_work))       # warm-up
+        stages = [hip_backend.classify_pair_deflated(
+            replicas[0][0], replicas[0][1], item[4], item[5], item[2], 6144, 0.5,
+            want_stages=True)[2] for item in raw_loaded * 2][len(raw_loaded):]
+        gpu_inflate['device_ms_per_container alone on the GPU (upload, inflate, classify)'] = [
+            round(float(sum(s[k] for s in stages) / len(stages)), 2) for k in range(3)]
+        rec = raw_loaded[0][5]
+        gpu_inflate['streams_per_container'] = {
+            'zlib (GPU)': int((rec['mode'] == 0).sum()),
+            'stored / host-inflated': int((rec['mode'] == 1).sum())}
+        # the pipeline as deepbinner_amd/realtime.py runs it: several containers in flight on the
+        # one GPU (model replicas = queues), CUs left out of the forward launches for the inflate
+        # kernels of the containers behind
+        for n_queues, n_cus in ((1, 0), (2, 32), (3, 0), (3, 32), (4, 32)):
+            os.environ['DEEPBINNER_INFLATE_QUEUES'] = str(n_queues)
+            os.environ['DEEPBINNER_INFLATE_CUS'] = str(n_cus)
+            queues, models = realtime.inflate_queues(replicas, clones, share)
+            sum(classify.dispatch_batches(iter(raw_loaded[:2]), queues, raw_work))       # warm-up
             t0 = time.perf_counter()
-            done = sum(classify.dispatch_batches(iter(raw_loaded * 4), replicas, raw_work))
+            done = sum(classify.dispatch_batches(iter(raw_loaded * 4), queues, raw_work))
             gpu_rate = done / (time.perf_counter() - t0)
             best, best_cpu = 0.0, 0.0
             for _ in range(2):
                 t0, c0 = time.perf_counter(), time.process_time()
-                stream = fast5_native.stream_raw(paths, threads=team, depth=4,
+                stream = fast5_native.stream_raw(paths, threads=team, depth=n_queues + 2,
                                                  host_inflate_above=above)
-                done = sum(classify.dispatch_batches(stream, replicas, raw_work))
+                done = sum(classify.dispatch_batches(stream, queues, raw_work))
                 wall, cpu = time.perf_counter() - t0, time.process_time() - c0
                 if done / wall > best:
                     best, best_cpu = done / wall, cpu / done
             assert done == total
-            gpu_inflate['%d queue(s) on GPU(s) %s' % (n_queues, sorted(set(ordinals)))] = {
+            for model in models:
+                model.reserve_cus(0)
+            gpu_inflate['%d queue(s), %d CUs left to the inflate kernels' % (n_queues, n_cus)] = {
                 'gpu_side_alone_reads_per_s': round(gpu_rate),
                 'load_and_classify_reads_per_s': round(best),
                 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}
+        os.environ.pop('DEEPBINNER_INFLATE_QUEUES', None)
+        os.environ.pop('DEEPBINNER_INFLATE_CUS', None)
         os.environ.pop('DEEPBINNER_DEVICE_ORDINALS', None)
         out['inflate shared with the GPU: raw stream -> dispatcher -> dbh_classify_pair_deflated '
             '(host share %d %% unless stated)' % share] = gpu_inflate
