@@ -10,18 +10,21 @@
 //
 // Two kernels (RFC 1950 / 1951; bit-exact with zlib, same accept / reject decisions; the decoder
 // core is dbh_inflate_core.h, which the CPU test harness compiles too):
-//   1. inflate_tokens_kernel  - ONE LANE PER STREAM, 32 streams per workgroup, decode tables in
-//      LDS (4.6 KB per lane).  Each lane walks its stream's Huffman codes and writes a token per
-//      symbol (literal | match {length, distance}) - no output bytes, no window: nothing a lane does
+//   1. inflate_tokens_kernel  - ONE LANE PER STREAM, 64 streams per workgroup (one wavefront), two
+//      workgroups per CU.  Each lane walks its stream's Huffman codes - decoded canonically from
+//      per-lane registers and 1.2 KB of LDS, see the core - and writes a token per symbol
+//      (literal | match {length, distance}) - no output bytes, no window: nothing a lane does
 //      depends on memory it wrote itself.  All lanes of a wave step together; streams deflated with
 //      the same settings reach their block boundaries (every 16,383 symbols with zlib's defaults)
-//      on the same step, so the table builds line up too.
-//   2. inflate_resolve_kernel - ONE WAVE PER STREAM with the 32 KiB window as a ring in LDS.  64
-//      tokens per step: a wave-wide prefix sum of the token lengths gives every token its output
-//      position; literals are stored at once; matches copy from the ring as soon as everything
-//      they read has been written (a match of one step may read what another match of the same
-//      step writes: the lanes go in rounds, the earliest unfinished position deciding who may
-//      go).  The ring is written out in coalesced 256-byte pieces, with the Adler-32 on the way.
+//      on the same step, so the code builds line up; a lane that is done takes its next stream off
+//      a counter there.
+//   2. inflate_resolve_kernel - ONE WAVE PER STREAM with the 32 KiB window as a ring in LDS, five
+//      per CU.  64 tokens per step: a wave-wide prefix sum of the token lengths gives every token
+//      its output position; literals are stored at once; matches copy from the ring as soon as
+//      everything they read has been written (a match of one step may read what another match of
+//      the same step writes: the lanes go in rounds, the first waiting match deciding who may
+//      go).  The ring is written out in coalesced 256-byte pieces, with the Adler-32 sums on the
+//      way.
 // HBM traffic per read (55 KB of samples, ~22 k tokens): 35 KB compressed in, 88 KB of tokens out
 // and in again, 55 KB of samples out - latency, not bandwidth, is what both kernels wait for.
 #include <hip/hip_runtime.h>
