@@ -150,6 +150,7 @@ struct dbh_model {
     int device = 0;
     int cus = 256;               // workgroups of a persistent forward launch (one per CU)
     int cus_total = 256;         // ... before dbh_model_reserve_cus took some away
+    bool windows_by_counter = true;        // DEEPBINNER_STATIC_WINDOWS=1: fixed shares (A/B)
     int inflate_streams_per_lane = 0;      // dbh_classify_pair_deflated -> dbh_inflate_dev; 0 = by
                                            // the lengths of the streams
     bool launch_per_batch = false;   // DEEPBINNER_LAUNCH_PER_BATCH=1: one launch per batch (A/B)
@@ -292,10 +293,14 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
             tail = &m->tails[k].ptr;
             tail_bytes = &m->tails[k].bytes;
         }
+        // (the first 256 bytes: the counter the launch's workgroups take their windows off -
+        // zero between launches, so zeroed here only when the buffer is new)
         {
-            const int st = ensure(tail, tail_bytes, (size_t)grid * dbh::kTailBatch *
-                                                        dbh::kTailSlotFloats * sizeof(float));
+            void* before = *tail;
+            const int st = ensure(tail, tail_bytes, 256 + (size_t)grid * dbh::kTailBatch *
+                                                              dbh::kTailSlotFloats * sizeof(float));
             if (st != DBH_OK) return st;
+            if (*tail != before) DBH_HIP(hipMemsetAsync(*tail, 0, 256, stream));
         }
         dbh::ForwardArgs a;
         a.packed = m->d_packed;
@@ -306,7 +311,10 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.samples = in.samples;
         a.offsets = in.offsets ? (const long long*)(in.offsets + off / in.steps) : nullptr;
         a.calls = in.calls ? (int*)(in.calls + off / in.steps) : nullptr;
-        a.tail_scratch = (float*)*tail;
+        a.tail_scratch = (float*)((char*)*tail + 256);
+        // production launches hand their windows out by counter; the debug and timeline modes
+        // (which may stop half-way, and index their output by window) keep fixed shares
+        a.win_counter = (debug_stage < 0 && m->windows_by_counter) ? (int*)*tail : nullptr;
         a.clock_out = nullptr;
         if (m->clock_probe && debug_stage < 0) {
             const int st = ensure(&m->d_clock, &m->clock_bytes, (size_t)grid * 4 * sizeof(int64_t));
@@ -523,6 +531,8 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
         m->launch_per_batch = knob && knob[0] == '1';
         const char* zc = std::getenv("DEEPBINNER_HOST_ZERO_COPY");
         m->host_zero_copy = !(zc && zc[0] == '0');
+        const char* sw = std::getenv("DEEPBINNER_STATIC_WINDOWS");
+        m->windows_by_counter = !(sw && sw[0] == '1');
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
     if (e == hipSuccess)
@@ -1327,6 +1337,7 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
                     (size_t)n * dbh::kTailBatch * dbh::kTailSlotFloats * sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;
+        a.win_counter = nullptr;
         hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
                            dim3(dbh::kThreads), 0, 0, a);
     }
@@ -1376,6 +1387,7 @@ int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t 
                                                     sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;
+        a.win_counter = nullptr;
         hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel,
                            dim3((unsigned)(n > m->cus ? m->cus : n)), dim3(dbh::kThreads), 0, 0, a);
     }

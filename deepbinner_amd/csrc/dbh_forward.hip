@@ -1817,6 +1817,9 @@ struct ForwardArgs {
     const long long* offsets;    //          read r = samples[offsets[r] .. offsets[r+1])
     int* calls;                  //          barcode calls (one scan step per read), or null
     float* tail_scratch;         // [grid][kTailBatch][16][48]: conv17 outputs parked per workgroup
+    int* win_counter;            // null: workgroup b walks windows b, b + grid, ...; else every
+                                 // workgroup takes its next window off this counter (0 between
+                                 // launches: the last taker of a launch resets it)
     long long* clock_out;        // [grid][4] or null: shader clock and 100 MHz clock at a
                                  // workgroup's start and end (dbh_forward_clock_read)
     double score_diff;
@@ -1958,7 +1961,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // PERSISTENT GRID: the launch has at most one workgroup per CU (what 160 KiB of LDS allows
     // anyway) and workgroup b walks windows b, b + gridDim.x, ... - no launch per batch, no cold
     // start per window.
-    for (long win = blockIdx.x; win < n_windows; win += gridDim.x) {
+    // WINDOWS OFF A COUNTER (win_counter != null, production launches): the first window of
+    // workgroup b is b, every further one is grid + what atomicAdd returns - a workgroup that
+    // gets its CU late (another kernel sat there: the inflate kernels of the streaming path)
+    // or runs slower (samples read over PCIe) simply takes fewer, instead of finishing its
+    // fixed share late.  Fetched by one lane at the top of a window, known at the end of stage A.
+    long win_after = 0;
+    bool first_window = true;
+    for (long win = blockIdx.x; win < n_windows; win = win_after, first_window = false) {
     // The thread index and the parameter pointer are made opaque once per round: otherwise the
     // loop-invariant-code pass hoists every lane address and constant of the (fully unrolled)
     // body out of the loop and keeps them alive across it - 245 spilled VGPRs instead of none.
@@ -1977,6 +1987,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
     mark(ts, 0);
     mark_realtime(ts, 62);
+    int* const win_counter = glob(args()->win_counter);
+    int taken = 0;
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
     // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
@@ -2001,7 +2013,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         const float(&bw)[3] = bw_a;               // fetched once per workgroup, before the loop
         if (samples == nullptr) {
             // a later window of this workgroup: the window before it may still be read (stage H)
-            if (win != (long)blockIdx.x) full_barrier();  
+            if (!first_window) full_barrier();  
             const float* xw = glob(args()->x) + win * kWindow;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -2054,6 +2066,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             for (int m = 0; m < MT; ++m)
                 a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
         }
+        // (the next window's number: asked for behind the barriers above - they wait for every
+        // outstanding request - and needed behind the one below, a conv1 and its epilogue later)
+        if (win_counter != nullptr && tid == 0) taken = atomicAdd(win_counter, 1);
         f4 acc[MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -2066,6 +2081,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 60);
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, 513, kS48, 48, tid);
+        if (win_counter != nullptr && tid == 0) {
+            reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
+            // n_windows numbers are taken per launch, whatever the grid: this was the last
+            if ((long long)taken == n_windows - 1) *win_counter = 0;
+        }
         full_barrier();  
         mark(ts, 1);
     }
@@ -2076,7 +2096,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         return;
     }
     // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
-    const long next_win = win + gridDim.x;
+    const long next_win = win_counter != nullptr
+                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
+                              : win + (long)gridDim.x;
+    win_after = next_win;
     const bool has_next = args()->samples != nullptr && next_win < n_windows;
     long long next_base = 0, next_len = 0;
     int next_step = 0;
@@ -2328,7 +2351,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // of matrix work.  So conv17's output (3 KB) is parked in a global-memory slot of this
     // workgroup and the rest runs for kTailBatch windows at a time, ONE WAVE PER WINDOW, with no
     // cross-wave step at all (batched_tail below).
-    const bool batch_ends = tail_slot == kTailBatch - 1 || win + (long)gridDim.x >= n_windows;
+    const bool batch_ends = tail_slot == kTailBatch - 1 || next_win >= n_windows;
+    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = (int)win;
     if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
         dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
         dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
@@ -2365,12 +2389,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
     {
         const int n_batch = tail_slot;
-        const long first_win = win - (long)(n_batch - 1) * (long)gridDim.x;
         tail_slot = 0;
         ArgsPtr a = args();
         const int n_classes = a->n_classes;
         const bool mine = wave < n_batch;
-        const long my_win = first_win + (long)wave * (long)gridDim.x;
+        long my_win = 0;         // (read behind the barrier below)
         float* X = lds + kTX + wave * 2 * kTailBuf;
         float* Y = X + kTailBuf;
         // epilogue parameters of the three layers, asked for before anything waits
@@ -2383,6 +2406,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         const float bias20b = packed[bias_offset(19) + 16 + n];
         full_barrier();        // conv17's stores of this window are out; kRed / the concat buffer free
         mark(ts, 45);
+        my_win = (long)reinterpret_cast<const int*>(lds + kTailWins)[mine ? wave : 0];
         if (mine) {
             const float* src = glob(a->tail_scratch) +
                                ((size_t)blockIdx.x * kTailBatch + wave) * kTailSlotFloats;

@@ -245,7 +245,11 @@ constexpr int kStatOut = kStatRed + 32;
 static_assert(kStatRed % 2 == 0, "64-bit words");
 // one counter word per half of each of conv7's four wave pairs (dbh_forward.hip: pair_signal)
 constexpr int kPairSync = kStatOut + 4;
-constexpr int kLdsFloats = kPairSync + 8;
+// which window this workgroup takes next (windows handed out by a counter: dbh_forward.hip) and
+// which windows wait in the slots of the batched tail
+constexpr int kNextWin = kPairSync + 8;
+constexpr int kTailWins = kNextWin + 1;
+constexpr int kLdsFloats = kTailWins + kTailBatch;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])
