@@ -39,7 +39,7 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 # each on its own queue (model replica), and 32 CUs left out of the forward kernel's persistent
 # launches for the inflate kernels of the containers behind.
 INFLATE_QUEUES = 3          # (six where the GPU inflates nearly everything: a container then
-INFLATE_CUS = 32            #  lasts as long as its longest read, ~10 mean reads)
+INFLATE_CUS = 0             #  lasts as long as its longest read, ~10 mean reads)
 
 
 def host_inflate_share(n_gpus):
