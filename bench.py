@@ -156,18 +156,21 @@ class ShardJob:
                 m.set_read_length_hint(1024, n * 1024)
         self.timing_model = self.models[0] if timing_model else None
 
+    calls_out = None      # where the final calls go instead of the shard's device buffer
+
     def step(self):
         s, cfg = self.shard, self.cfg
+        final = ctypes.c_void_p(self.calls_out) if self.calls_out else s.calls.ptr
         if not self.side_calls:
             self.models[0].classify_batched_dev(s.samples.ptr, s.offsets.ptr, self.n, cfg['batch'],
                                                 cfg['sides'][0], SCAN_SIZE, SCORE_DIFF,
-                                                self.probs[0].ptr, s.calls.ptr, s.stream.ptr)
+                                                self.probs[0].ptr, final, s.stream.ptr)
             return
         for m, side, probs, calls in zip(self.models, cfg['sides'], self.probs, self.side_calls):
             m.classify_batched_dev(s.samples.ptr, s.offsets.ptr, self.n, cfg['batch'], side,
                                    SCAN_SIZE, SCORE_DIFF, probs.ptr, calls.ptr, s.stream.ptr)
         hip_backend.combine_calls_dev(self.side_calls[0].ptr, self.side_calls[1].ptr, self.n,
-                                      cfg['combine'], s.calls.ptr, s.stream.ptr)
+                                      cfg['combine'], final, s.stream.ptr)
 
 
 class PinnedCalls:
@@ -179,6 +182,14 @@ class PinnedCalls:
         ptr = ctypes.c_void_p()
         hip_backend.check(self.lib.dbh_malloc_host(ctypes.byref(ptr), max(self.count, 1) * 4))
         self.ptr = ptr.value
+
+    def device_pointer(self):
+        """The address the GPU stores into this buffer at (dbh_host_device_pointer)."""
+        dev = ctypes.c_void_p()
+        hip_backend.check(self.lib.dbh_host_device_pointer(ctypes.c_void_p(self.ptr),
+                                                           ctypes.byref(dev)),
+                          'dbh_host_device_pointer')
+        return dev.value
 
     def fetch(self, dev_ptr, stream):
         hip_backend.check(self.lib.dbh_memcpy_d2h(self.ptr, dev_ptr, self.count * 4, stream),
@@ -284,14 +295,16 @@ def side_rates(weights, reads):
     return out
 
 
-def workload_string(cfg):
+def workload_string(cfg, direct=False):
     """`config.workload` of the JSON line: names the BASELINE.json configuration first."""
     n_models = len(cfg['models'])
     return ('{name}: {models} model{plural}, {reads} synthetic 1024-sample int16 signals {share} '
             'per step, batch {batch}, seam b2 (slice + normalise + CNN + renormalise + call '
             'fused in one kernel, {launches}{combine}), scan_size {scan} => 1 window per read '
-            'and model, inputs resident in HBM, {hint}, gathered calls copied to pinned host '
-            'memory every step').format(
+            'and model, inputs resident in HBM, {hint}, {calls}').format(
+                calls=('calls stored by the kernel straight into pinned host memory every step '
+                       '(one GPU: nothing to gather)' if direct else
+                       'gathered calls copied to pinned host memory every step'),
                 name=cfg['name'], models=' + '.join(cfg['models']),
                 plural='s' if n_models > 1 else '', reads=cfg['reads'],
                 share='in total' if cfg['scaling'] == 'strong' else 'per GPU',
@@ -378,8 +391,19 @@ def main():
     def fetch():
         pinned.fetch(lead.shard.gathered.ptr, lead.shard.stream.ptr)
 
+    # One GPU has nothing to gather: its kernels store the calls straight into the pinned host
+    # buffer (40 KB per 10,000 reads) and a step is nothing but its launches - a copy command
+    # between two launches of a stream costs ~20 us of idle GPU (tools/step_gap.py), 1 % of a step.
+    # DEEPBINNER_BENCH_COPY_CALLS=1 brings the copy back for comparison.
+    direct = (world == 1 and group.comm is None and
+              os.environ.get('DEEPBINNER_BENCH_COPY_CALLS') != '1')
+    if direct:
+        lead.calls_out = pinned.device_pointer()
+
     def step():
         run_all(lambda j: j.step())
+        if direct:
+            return
         group.all_gather()
         if is_lead:       # the gathered calls reach the host inside the timed region
             fetch() if per_rank else group.run_on(0, fetch)
@@ -428,7 +452,7 @@ def main():
         'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': workload_string(cfg),
+            'workload': workload_string(cfg, direct),
             'reads_per_step': reads_per_step, 'reads_per_step_per_gpu': shard_sizes,
             'batch': cfg['batch'], 'windows_per_read': n_models,
             'forward_launches_per_step': (n_models * -(-max(shard_sizes) // cfg['batch'])

@@ -445,6 +445,11 @@ int dbh_free_host(void* host_ptr) {
     if (host_ptr) DBH_HIP(hipHostFree(host_ptr));
     return DBH_OK;
 }
+int dbh_host_device_pointer(void* host_ptr, void** dev_ptr) {
+    if (!host_ptr || !dev_ptr) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipHostGetDevicePointer(dev_ptr, host_ptr, 0));
+    return DBH_OK;
+}
 int dbh_memcpy_h2d(void* dst, const void* src, size_t bytes, dbh_stream stream) {
     DBH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return DBH_OK;

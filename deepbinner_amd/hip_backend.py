@@ -82,6 +82,7 @@ def load_library():
         'dbh_free': (c_int, [c_void_p]),
         'dbh_malloc_host': (c_int, [P(c_void_p), c_size_t]),
         'dbh_free_host': (c_int, [c_void_p]),
+        'dbh_host_device_pointer': (c_int, [c_void_p, P(c_void_p)]),
         'dbh_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
         'dbh_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
         'dbh_memcpy_d2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -172,7 +173,8 @@ EXPORTED_SYMBOLS = [
     'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_pair_i16',
-    'dbh_model_set_host_group', 'dbh_model_reserve_cus', 'dbh_host_alloc', 'dbh_host_release',
+    'dbh_model_set_host_group', 'dbh_model_reserve_cus', 'dbh_host_device_pointer',
+    'dbh_host_alloc', 'dbh_host_release',
     'dbh_host_is_pinned',
     'dbh_classify_workspace_bytes', 'dbh_inflate_last_error', 'dbh_inflate_workspace_bytes',
     'dbh_inflate_dev', 'dbh_inflate', 'dbh_classify_pair_deflated',

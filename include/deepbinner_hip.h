@@ -63,6 +63,11 @@ int dbh_malloc(void** dev_ptr, size_t bytes);
 int dbh_free(void* dev_ptr);
 int dbh_malloc_host(void** host_ptr, size_t bytes);     /* pinned, for overlapped H2D        */
 int dbh_free_host(void* host_ptr);
+/* The address the GPU reaches a pinned host buffer at.  The *_dev entry points take it wherever
+ * they take a device pointer for RESULTS (calls, probabilities): the kernels then store them
+ * straight into host memory - no copy command between two launches of a stream (one GPU's calls
+ * in bench.py; 40 KB per 10,000 reads). */
+int dbh_host_device_pointer(void* host_ptr, void** dev_ptr);
 int dbh_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes, dbh_stream stream);
 int dbh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes, dbh_stream stream);
 int dbh_memcpy_d2d(void* dev_dst, const void* dev_src, size_t bytes, dbh_stream stream);
