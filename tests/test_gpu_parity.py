@@ -499,6 +499,43 @@ def test_long_shares_of_windows_per_workgroup(hip, hip_models, weights, all_sign
         assert np.array_equal(got_c, want_c) and np.array_equal(got_p, want_p), (side, scan)
 
 
+def test_windows_off_the_counter_and_in_fixed_shares_give_the_same(hip, hip_models, weights,
+                                                                   all_signals, monkeypatch):
+    """The workgroups of a production launch take their windows off a counter in global memory,
+    which the launch's last taker puts back to zero for the next launch on that stream;
+    DEEPBINNER_STATIC_WINDOWS=1 keeps round 2's fixed shares (b, b + grid, ...).  Same results
+    either way, launch after launch (a counter left dirty would skip or repeat windows), with
+    more windows than workgroups and with fewer, on several streams of one model."""
+    counted = hip_models['EXP-NBD103_read_starts']
+    monkeypatch.setenv('DEEPBINNER_STATIC_WINDOWS', '1')
+    monkeypatch.setenv('DEEPBINNER_GRID_CAP', '5')
+    fixed = hip.HipModel(weights['EXP-NBD103_read_starts'], device=0)
+    monkeypatch.delenv('DEEPBINNER_STATIC_WINDOWS')
+    few = hip.HipModel(weights['EXP-NBD103_read_starts'], device=0)      # counter, 5 workgroups
+    monkeypatch.delenv('DEEPBINNER_GRID_CAP')
+    rng = np.random.default_rng(11)
+    for n in (700, 3, 61, 700, 1, 257):
+        signals = [all_signals[i % len(all_signals)][:int(rng.integers(0, 4000))] for i in range(n)]
+        want_p, want_c = fixed.classify_signals(signals, 'start', 512, 0.5)
+        for model in (counted, few, few):
+            got_p, got_c = model.classify_signals(signals, 'start', 512, 0.5)
+            assert np.array_equal(got_c, want_c) and np.array_equal(got_p, want_p), n
+    # the host-buffer pipeline: three slots, each with its own stream and counter
+    signals = [all_signals[i % len(all_signals)] for i in range(900)]
+    samples, offsets = pack(signals)
+    want = fixed.classify_packed(samples, offsets, 'end', 2048, 0.5)
+    for model in (counted, few):
+        model.set_host_group(512)
+        try:
+            for _ in range(2):
+                got = model.classify_packed(samples, offsets, 'end', 2048, 0.5)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        finally:
+            model.set_host_group(0)
+    fixed.close()
+    few.close()
+
+
 @pytest.mark.parametrize('side,scan', [('start', 6144), ('end', 6144), ('start', 512), ('end', 512)])
 def test_fused_kernel_equals_three_kernel_path(hip, hip_models, all_signals, side, scan):
     """slice+normalise (and, at one scan step, renormalise+call) fused into the CNN kernel must
