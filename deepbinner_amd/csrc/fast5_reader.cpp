@@ -1524,8 +1524,7 @@ class SamplePool {
                     best = i;
             if (best != idle_.size()) {
                 Block b = idle_[best];
-                idle_[best] = idle_.back();
-                idle_.pop_back();
+                idle_.erase(idle_.begin() + (std::ptrdiff_t)best);     // (the front stays the oldest)
                 idle_bytes_ -= b.bytes;
                 return b;
             }
@@ -1543,14 +1542,26 @@ class SamplePool {
 
     void give(Block b) {
         if (!b.ptr) return;
+        // The block just used is the size the caller needs NOW: it stays, and the blocks that
+        // have waited longest go if the pool is over its limit (a pool full of another
+        // workload's sizes would otherwise never serve a request nor take a block back - every
+        // batch a fresh allocation and a free, and freeing pinned memory waits for the GPU).
+        std::vector<Block> evicted;
         {
             std::lock_guard<std::mutex> g(m_);
-            if (b.from.generation == allocator_.generation && idle_bytes_ + b.bytes <= limit()) {
+            if (b.from.generation == allocator_.generation && b.bytes <= limit()) {
                 idle_.push_back(b);
                 idle_bytes_ += b.bytes;
-                return;
+                b = Block();
+                size_t n = 0;
+                while (idle_bytes_ > limit() && n + 1 < idle_.size()) {
+                    idle_bytes_ -= idle_[n].bytes;
+                    evicted.push_back(idle_[n++]);
+                }
+                idle_.erase(idle_.begin(), idle_.begin() + (std::ptrdiff_t)n);
             }
         }
+        for (Block& old : evicted) free_block(old);
         free_block(b);
     }
 

@@ -380,6 +380,68 @@ def test_sample_buffers_are_recycled_and_can_come_from_the_caller():
     assert np.array_equal(again[1], want[1]) and len(sizes) == 1
 
 
+POOL_EVICTION = r"""
+import ctypes, sys
+import numpy as np
+from deepbinner_amd import fast5_native
+path = sys.argv[1]
+libc = ctypes.CDLL(None)
+libc.malloc.restype = ctypes.c_void_p
+libc.malloc.argtypes = [ctypes.c_size_t]
+libc.free.argtypes = [ctypes.c_void_p]
+sizes, freed = [], []
+ALLOC = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+FREE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
+def alloc(nbytes, user):
+    sizes.append(nbytes)
+    return libc.malloc(nbytes)
+def release(ptr, user):
+    freed.append(ptr)
+    libc.free(ptr)
+a, r = ALLOC(alloc), FREE(release)
+fast5_native.set_sample_allocator(ctypes.cast(a, ctypes.c_void_p).value,
+                                  ctypes.cast(r, ctypes.c_void_p).value)
+small = [fast5_native.load_reads(path, keep=64, threads=1) for _ in range(3)]   # three small batches
+assert len(sizes) == 3 and len(set(sizes)) == 1
+small_block = sizes[0]
+del small                                  # ... now idle in the pool: it is full of them
+whole = fast5_native.load_reads(path, threads=1)
+assert len(sizes) == 4 and sizes[3] > 4 * small_block       # none of them fits: a fresh block
+want = np.array(whole[1])
+del whole                                  # it goes back, the oldest small ones make room
+assert len(freed) >= 1
+for _ in range(5):
+    whole = fast5_native.load_reads(path, threads=1)
+    assert np.array_equal(whole[1], want)
+    del whole
+assert len(sizes) == 4, sizes              # ... and serves every batch of the new size
+fast5_native.set_sample_allocator(None, None)
+print('ok', small_block, sizes[3], len(freed))
+"""
+
+
+def test_the_buffer_pool_makes_room_for_a_new_size(tmp_path):
+    """The pool of idle sample buffers is bounded (DEEPBINNER_FAST5_POOL_MB); full of one
+    workload's sizes it must still take in the blocks of the next workload - the blocks that
+    waited longest go - instead of allocating and freeing (pinned memory: slowly, and waiting
+    for the GPU) for every batch from then on."""
+    import subprocess
+    import sys
+    lengths = [200000] * 12
+    from deepbinner_amd import hdf5_write
+    rng = np.random.default_rng(3)
+    reads = [('read-%02d' % i, rng.integers(0, 2000, n).astype(np.int16))
+             for i, n in enumerate(lengths)]
+    path = tmp_path / 'twelve.fast5'
+    path.write_bytes(hdf5_write.multi_read_fast5_bytes(reads))
+    env = dict(os.environ, DEEPBINNER_FAST5_POOL_MB='8',
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', POOL_EVICTION, str(path)], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith('ok')
+
+
 def test_many_copies_in_parallel(tmp_path):
     """Thread-safety smoke test: 400 files on 16 threads give what one thread gives."""
     files = single_files()
