@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = [
     'f5_read_signal', 'f5_load_batch', 'f5_load_reads', 'f5_batch_size', 'f5_batch_samples', 'f5_batch_offsets', 'f5_batch_status',
     'f5_batch_read_ids', 'f5_batch_free', 'f5_stream_open', 'f5_stream_next', 'f5_stream_close',
     'f5_set_sample_allocator', 'f5_release_idle_buffers', 'f5_stream_open_raw', 'f5_batch_comp',
-    'f5_batch_comp_bytes', 'f5_batch_streams', 'f5_batch_n_streams',
+    'f5_batch_comp_bytes', 'f5_batch_streams', 'f5_batch_n_streams', 'f5_write_single_reads',
+    'f5_single_read_image',
 ]
 
 
@@ -78,6 +79,9 @@ def load_library():
         'f5_stream_next': (c_int, [c_void_p, P(c_i64), P(c_int), P(c_void_p)]),
         'f5_stream_close': (None, [c_void_p]),
         'f5_stream_open_raw': (c_int, [P(c_char_p), c_i64, c_int, c_int, c_i64, P(c_void_p)]),
+        'f5_write_single_reads': (c_int, [c_char_p, c_i64, P(c_i64), P(c_char_p), c_int,
+                                          P(ctypes.c_int32), P(c_i64)]),
+        'f5_single_read_image': (c_int, [c_char_p, c_i64, c_void_p, c_i64, P(c_i64)]),
         'f5_batch_comp': (P(ctypes.c_uint8), [c_void_p]),
         'f5_batch_comp_bytes': (c_i64, [c_void_p]),
         'f5_batch_streams': (c_void_p, [c_void_p]),
@@ -335,6 +339,42 @@ def stream_raw(fast5_files, threads=0, depth=0, host_inflate_above=0):
             yield index.value, ids, offsets, st, comp, records
     finally:
         lib.f5_stream_close(stream)
+
+
+def write_single_reads(container, read_indices, out_paths, threads=0):
+    """Reads ``read_indices`` of the multi-read container ``container`` as one-read fast5 files
+    ``out_paths`` (signal as stored + the read's Raw / channel_id / tracking_id / context_tags
+    attributes: include/deepbinner_fast5.h) on the library's worker threads -> (status per read,
+    bytes written).  Raises Fast5NativeError if the container cannot be opened."""
+    lib = load_library()
+    n = len(out_paths)
+    if len(read_indices) != n:
+        raise ValueError('one path per read')
+    indices = (ctypes.c_int64 * max(n, 1))(*[int(i) for i in read_indices])
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(p) for p in out_paths])
+    status = (ctypes.c_int32 * max(n, 1))()
+    written = ctypes.c_int64(0)
+    rc = lib.f5_write_single_reads(os.fsencode(container), n, indices, paths, int(threads), status,
+                                   ctypes.byref(written))
+    if rc != F5_OK:
+        raise Fast5NativeError('{}: {}'.format(container, status_string(rc)))
+    return np.frombuffer(status, dtype=np.int32, count=n).copy(), written.value
+
+
+def single_read_image(container, read_index):
+    """The bytes ``write_single_reads`` writes for one read (tests)."""
+    lib = load_library()
+    size = ctypes.c_int64(0)
+    rc = lib.f5_single_read_image(os.fsencode(container), int(read_index), None, 0,
+                                  ctypes.byref(size))
+    if rc != F5_OK:
+        raise Fast5NativeError('{}: {}'.format(container, status_string(rc)))
+    buf = ctypes.create_string_buffer(size.value)
+    rc = lib.f5_single_read_image(os.fsencode(container), int(read_index), buf, size.value,
+                                  ctypes.byref(size))
+    if rc != F5_OK:
+        raise Fast5NativeError('{}: {}'.format(container, status_string(rc)))
+    return buf.raw[:size.value]
 
 
 def set_sample_allocator(alloc_address=None, release_address=None, user=None):

@@ -253,16 +253,18 @@ def _finish(image, superblock, root):
     return bytes(image.buf)
 
 
-def single_read_fast5_bytes(read_id, signal, compress=True, read_number=None, metadata=None):
+def single_read_fast5_bytes(read_id, signal, compress=True, read_number=None, metadata=None,
+                            packed_signal=None):
     """The bytes of a one-read fast5 file holding ``signal`` (int16) as read ``read_id``.
     ``metadata``: what else the read's group of a multi-read container held, copied as
     ont_fast5_api's multi_to_single_fast5 does (the tool the reference runs, realtime.py:183-190):
     ``{'read': {attribute: value}, 'Raw': {...}, 'channel_id': {...}, 'tracking_id': {...},
     'context_tags': {...}}`` ('read': the read group's own attributes, e.g. run_id) - basecallers
-    need ``channel_id`` (digitisation, offset, range, sampling_rate)."""
+    need ``channel_id`` (digitisation, offset, range, sampling_rate).  ``packed_signal``: the
+    zlib stream of the signal's bytes where the caller has it already (a chunk as stored)."""
     image = _Image()
     superblock = image.reserve(96)
-    read = _read_group(image, read_id, signal, compress, read_number, metadata)
+    read = _read_group(image, read_id, signal, compress, read_number, metadata, packed_signal)
     root = _group(image, {'read_' + read_id: read}, [string_attribute('file_version', '2.0')])
     return _finish(image, superblock, root)
 

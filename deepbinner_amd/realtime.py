@@ -228,10 +228,23 @@ class Session:
     # models and combine_calls in one call (classify.classify_packed_numbers) on whichever device
     # replica is next (classify.dispatch_batches) - BASELINE.json configs[4]: one host streaming
     # multi-read files into several GPUs.
+    def _native_writer(self):
+        """The one-read files of the bins are written by libdeepbinner_fast5.so itself
+        (f5_write_single_reads: the chunk as stored + the read's metadata, no inflate, no deflate,
+        no Python per read) - unless the Python reader was asked for, or
+        DEEPBINNER_PYTHON_WRITER=1 asks for hdf5_write.py (the writer this one is tested
+        against)."""
+        return (not self.table_only and reader_kind() == 'native' and
+                os.environ.get('DEEPBINNER_PYTHON_WRITER') != '1')
+
+    def _signals_wanted(self):
+        """Whole signals are loaded only for the Python writer to write them out again."""
+        return not self.table_only and not self._native_writer()
+
     def _keep(self):
-        """Samples per read end the loaders keep: only the scanned ends when the reads are merely
-        tabulated (all that call_batch looks at), whole signals when they are binned too."""
-        return classify.scanned_end_samples(self.args.scan_size) if self.table_only else None
+        """Samples per read end the loaders keep: only the scanned ends (all that call_batch
+        looks at) unless the whole signals are needed."""
+        return None if self._signals_wanted() else classify.scanned_end_samples(self.args.scan_size)
 
     def _packed_containers(self, fast5s):
         """(container number, path, read ids, samples, offsets) per readable container, in order;
@@ -246,22 +259,23 @@ class Session:
             if ids is None:
                 continue
             classify.warn_about_filters(status)
+            where = list(range(len(ids)))          # which read of the container each one is
             if any(rid is None for rid in ids):
-                ok = [i for i, rid in enumerate(ids) if rid is not None]
-                parts = [samples[offsets[i]:offsets[i + 1]] for i in ok]
+                where = [i for i, rid in enumerate(ids) if rid is not None]
+                parts = [samples[offsets[i]:offsets[i + 1]] for i in where]
                 lengths = [len(part) for part in parts]
                 samples = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int16)
                 offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-                ids = [ids[i] for i in ok]
-            yield index + 1, fast5s[index], ids, samples, offsets
+                ids = [ids[i] for i in where]
+            yield index + 1, fast5s[index], ids, samples, offsets, where
 
     def _classify_container(self, item, start_replica, end_replica):
-        number, path, ids, samples, offsets = item
+        number, path, ids, samples, offsets, where = item
         numbers = classify.classify_packed_numbers(samples, offsets, start_replica, end_replica,
                                                    self.args)
         names = [classify.call_name(c) for c in numbers.tolist()]
-        signal = (lambda i: samples[offsets[i]:offsets[i + 1]]) if not self.table_only else None
-        return number, path, ids, names, signal
+        signal = (lambda i: samples[offsets[i]:offsets[i + 1]]) if self._signals_wanted() else None
+        return number, path, ids, names, signal, where
 
     # The same with (part of) the inflating on the GPU: the loader hands over Signal chunks as
     # stored - zlib streams; 85 % of what loading a read costs a CPU core is inflating them, and a
@@ -286,9 +300,9 @@ class Session:
         result = hip_backend.classify_pair_deflated(
             start_replica, end_replica, comp, records, offsets, int(self.args.scan_size),
             self.args.score_diff, classify.combine_mode(self.args) if start_replica is not None and
-            end_replica is not None else 'require_either', want_samples=not self.table_only)
+            end_replica is not None else 'require_either', want_samples=self._signals_wanted())
         numbers, stream_status = result[0], result[1]
-        samples = result[2] if not self.table_only else None
+        samples = result[2] if self._signals_wanted() else None
         redone = {}
         for i in sorted(set(records['read'][stream_status != 0].tolist())):
             # a stream the GPU decoder refused (damaged, or beyond it): zlib on the host has the
@@ -311,7 +325,8 @@ class Session:
             i = keep[k]
             return redone[i] if i in redone else samples[offsets[i]:offsets[i + 1]]
 
-        return number, path, [ids[i] for i in keep], names, signal if samples is not None else None
+        return (number, path, [ids[i] for i in keep], names,
+                signal if samples is not None else None, keep)
 
     def _read_chunks(self, fast5s):
         """The same units for the Python reader and for models without the packed entry point:
@@ -329,7 +344,7 @@ class Session:
         found = {}
         classify.classify_read_batch(ids, signals, start_replica, self.start_size, end_replica,
                                      self.end_size, self.n_classes, self.args, found)
-        return number, path, ids, [found[rid] for rid in ids], signals.__getitem__
+        return number, path, ids, [found[rid] for rid in ids], signals.__getitem__, None
 
     def _tabulate_multi_read_files(self, fast5s):
         from concurrent.futures import ThreadPoolExecutor
@@ -369,15 +384,54 @@ class Session:
             items, work = self._packed_containers(fast5s), self._classify_container
         else:
             items, work = self._read_chunks(fast5s), self._classify_chunk
-        metadata = MetadataSource() if not self.table_only else None
+        metadata = MetadataSource() if not self.table_only else None     # (the Python writer's)
+        # The native writer: one call per container on one background thread (the library's own
+        # worker threads do the reads of a container in parallel; the call releases the
+        # interpreter lock), at most two containers waiting, so that writing container k overlaps
+        # loading and classifying the ones behind it.
+        native_jobs = ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-fast5-bins')
+        native_waiting = threading.BoundedSemaphore(2)
+        known_bins = set()
+
+        def bin_container(source, where, targets):
+            from . import fast5_native
+            try:
+                t0 = time.perf_counter()
+                status, _ = fast5_native.write_single_reads(source, where, targets,
+                                                            threads=max(2, usable_cpus() // 2))
+                if os.environ.get('DEEPBINNER_REALTIME_TIMING'):
+                    print('wrote {} reads of {} in {:.1f} ms'.format(
+                        len(targets), os.path.basename(source),
+                        (time.perf_counter() - t0) * 1e3), file=sys.stderr)
+                bad = [t for t, st in zip(targets, status.tolist()) if st != 0]
+                if bad:
+                    failures.append(OSError('{} ({} of {} reads of {})'.format(
+                        bad[0], len(bad), len(targets), source)))
+            except Exception as e:                       # surfaces when the pass ends
+                failures.append(e)
+            finally:
+                native_waiting.release()
+
         # the units go round the devices the models are replicated on (one, usually)
         with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
             classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
-            for number, path, ids, names, signal in classify.dispatch_batches(items, replicas, work):
+            for number, path, ids, names, signal, where in classify.dispatch_batches(items, replicas,
+                                                                                    work):
                 calls.update(zip(ids, names))
                 table.writelines('{}\t{}\t{}\n'.format(rid, name, path)
                                  for rid, name in zip(ids, names))
-                if not self.table_only:      # zlib and file writes release the GIL
+                if not self.table_only and signal is None and where is not None:
+                    targets = []
+                    for rid, name in zip(ids, names):
+                        bin_dir = self.out_dir / bin_name(name)
+                        if name not in known_bins:
+                            os.makedirs(str(bin_dir), exist_ok=True)
+                            known_bins.add(name)
+                        targets.append(str(bin_dir / (self._file_name(rid, name) + '.fast5')))
+                    native_waiting.acquire()
+                    native_jobs.submit(bin_container, path, list(where), targets)
+                    written += len(targets)
+                elif not self.table_only:      # zlib and file writes release the GIL
                     for i, (rid, name) in enumerate(zip(ids, names)):
                         in_flight.acquire()
                         writers.submit(bin_read, self._file_name(rid, name), rid, signal(i), name,
@@ -389,6 +443,7 @@ class Session:
                 classify.print_classification_progress(min(done, total), total, 'reads',
                                                        out_dest=sys.stdout)
         writers.shutdown(wait=True)
+        native_jobs.shutdown(wait=True)
         if metadata is not None:
             metadata.close()
         for model in queues:                # the forward kernel gets every CU back

@@ -124,6 +124,24 @@ int64_t f5_batch_comp_bytes(const f5_batch* batch);
 const f5_raw_stream* f5_batch_streams(const f5_batch* batch);
 int64_t f5_batch_n_streams(const f5_batch* batch);
 
+/* The reads of a multi-read container as one-read fast5 files - what `deepbinner realtime` files
+ * into the directories of their barcodes (the reference runs ont_fast5_api's
+ * multi_to_single_fast5 and moves its output: realtime.py:183-190, :111-150).  Read
+ * read_index[i] of `container` is written to out_paths[i]: /read_<id>/Raw/Signal with the
+ * attributes of the read's group, of Raw, and its channel_id / tracking_id / context_tags groups
+ * (scalar strings, integers, floats; what a basecaller needs), in the layout of
+ * deepbinner_amd/hdf5_write.py (superblock 0, symbol-table groups, one deflated chunk), byte for
+ * byte.  A Signal stored as ONE deflate-compressed chunk - what MinKNOW and ont_fast5_api write -
+ * is carried over as stored: nothing is inflated, nothing deflated again.  status[i] = F5_OK or
+ * why read i could not be written; n_threads as everywhere.  *bytes_written (may be NULL): total
+ * size of the files. */
+int f5_write_single_reads(const char* container, int64_t n, const int64_t* read_index,
+                          const char* const* out_paths, int n_threads, int32_t* status,
+                          int64_t* bytes_written);
+/* the bytes such a file would hold (tests); *size is set even if capacity is too small */
+int f5_single_read_image(const char* container, int64_t read_index, uint8_t* out, int64_t capacity,
+                         int64_t* size);
+
 /* Where the packed samples of a batch live.  Freed batches leave their sample buffer in a pool
  * (bounded by DEEPBINNER_FAST5_POOL_MB, default 2048) for the next batch that fits, so that a
  * steady stream of containers allocates - and page-faults - nothing.  A caller may supply the
