@@ -196,9 +196,16 @@ class Session:
         if kind == 'single':
             calls = self._bin_one_read_files(todo)
         elif shutil.which('multi_to_single_fast5') is None:
-            self.unmovable.update(todo)
-            calls = self._tabulate_multi_read_files(todo)
-            print()
+            # every container that waits, in one stream; reported pass by pass as the reference
+            # would work through them
+            self.unmovable.update(fast5s)
+            for calls, left in self._tabulate_multi_read_files(fast5s, PER_PASS[kind]):
+                print()
+                print_summary_table(calls, output=sys.stdout)
+                if left:
+                    print()
+                    print('Found {:,} fast5 files in {}'.format(left, self.args.in_dir))
+            return
         else:
             self.unmovable.update(todo)
             with tempfile.TemporaryDirectory() as scratch:
@@ -346,10 +353,12 @@ class Session:
                                      self.end_size, self.n_classes, self.args, found)
         return number, path, ids, [found[rid] for rid in ids], signals.__getitem__, None
 
-    def _tabulate_multi_read_files(self, fast5s):
+    def _tabulate_multi_read_files(self, fast5s, per_pass):
+        """Classifies (and bins) the reads of the multi-read containers ``fast5s`` where they are;
+        a generator: after every ``per_pass`` containers -> ({read id: call} of those, how many
+        containers are left)."""
         from concurrent.futures import ThreadPoolExecutor
         from .hdf5_write import write_single_read_fast5
-        calls, done, written = {}, 0, 0
         n_writers = min(16, usable_cpus())
         writers = ThreadPoolExecutor(max_workers=n_writers,
                                      thread_name_prefix='deepbinner-fast5-writer')
@@ -385,12 +394,13 @@ class Session:
         else:
             items, work = self._read_chunks(fast5s), self._classify_chunk
         metadata = MetadataSource() if not self.table_only else None     # (the Python writer's)
-        # The native writer: one call per container on one background thread (the library's own
-        # worker threads do the reads of a container in parallel; the call releases the
-        # interpreter lock), at most two containers waiting, so that writing container k overlaps
-        # loading and classifying the ones behind it.
-        native_jobs = ThreadPoolExecutor(max_workers=1, thread_name_prefix='deepbinner-fast5-bins')
-        native_waiting = threading.BoundedSemaphore(2)
+        # The native writer: one call per container, two containers at a time on background
+        # threads (the library's own worker threads do the reads of a container in parallel - four
+        # are as good as sixteen: the creates in a directory serialise -, the call releases the
+        # interpreter lock), at most three containers waiting, so that writing container k
+        # overlaps loading and classifying the ones behind it.
+        native_jobs = ThreadPoolExecutor(max_workers=2, thread_name_prefix='deepbinner-fast5-bins')
+        native_waiting = threading.BoundedSemaphore(3)
         known_bins = set()
 
         def bin_container(source, where, targets):
@@ -398,7 +408,7 @@ class Session:
             try:
                 t0 = time.perf_counter()
                 status, _ = fast5_native.write_single_reads(source, where, targets,
-                                                            threads=max(2, usable_cpus() // 2))
+                                                            threads=max(2, usable_cpus() // 4))
                 if os.environ.get('DEEPBINNER_REALTIME_TIMING'):
                     print('wrote {} reads of {} in {:.1f} ms'.format(
                         len(targets), os.path.basename(source),
@@ -412,49 +422,71 @@ class Session:
             finally:
                 native_waiting.release()
 
-        # the units go round the devices the models are replicated on (one, usually)
-        with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
-            classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
-            for number, path, ids, names, signal, where in classify.dispatch_batches(items, replicas,
-                                                                                    work):
-                calls.update(zip(ids, names))
-                table.writelines('{}\t{}\t{}\n'.format(rid, name, path)
-                                 for rid, name in zip(ids, names))
-                if not self.table_only and signal is None and where is not None:
-                    targets = []
-                    for rid, name in zip(ids, names):
-                        bin_dir = self.out_dir / bin_name(name)
-                        if name not in known_bins:
-                            os.makedirs(str(bin_dir), exist_ok=True)
-                            known_bins.add(name)
-                        targets.append(str(bin_dir / (self._file_name(rid, name) + '.fast5')))
-                    native_waiting.acquire()
-                    native_jobs.submit(bin_container, path, list(where), targets)
-                    written += len(targets)
-                elif not self.table_only:      # zlib and file writes release the GIL
-                    for i, (rid, name) in enumerate(zip(ids, names)):
-                        in_flight.acquire()
-                        writers.submit(bin_read, self._file_name(rid, name), rid, signal(i), name,
-                                       path, metadata)
-                        written += 1
-                done += len(ids)
-                # the total is known once the last container is open; until then, extrapolate
-                total = max(done * len(fast5s) // number, 1)
-                classify.print_classification_progress(min(done, total), total, 'reads',
-                                                       out_dest=sys.stdout)
-        writers.shutdown(wait=True)
-        native_jobs.shutdown(wait=True)
-        if metadata is not None:
-            metadata.close()
-        for model in queues:                # the forward kernel gets every CU back
-            model.reserve_cus(0)
-        if failures:
-            sys.exit('Error: failed to write {} one-read fast5 file{} into {} ({})'.format(
-                len(failures), '' if len(failures) == 1 else 's', self.out_dir, failures[0]))
-        if written:
-            print()
-            print('Wrote {:,} one-read fast5 files into {}'.format(written, self.out_dir), end='')
-        return calls
+        # The units go round the devices the models are replicated on (one, usually).  ALL the
+        # containers given go through one loader stream and one dispatcher - nothing drains
+        # between two passes - while the output keeps the reference's rhythm: a progress line and
+        # a summary per `per_pass` containers (realtime.py:86-94 takes five multi-read files a pass).
+        def group_of(number):
+            return (number - 1) // per_pass
+
+        def close_group(group, group_calls, group_written, jobs):
+            for job in jobs:                    # this pass's files are on disk before it is
+                job.result()                    # reported
+            if failures:
+                sys.exit('Error: failed to write {} one-read fast5 file{} into {} ({})'.format(
+                    len(failures), '' if len(failures) == 1 else 's', self.out_dir, failures[0]))
+            if group_written:
+                print()
+                print('Wrote {:,} one-read fast5 files into {}'.format(group_written, self.out_dir),
+                      end='')
+            return group_calls, max(len(fast5s) - (group + 1) * per_pass, 0)
+
+        group, calls, done, written, jobs = 0, {}, 0, 0, []
+        try:
+            with open(str(self.out_dir / 'multi_read_classifications.tsv'), 'at') as table:
+                classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
+                for number, path, ids, names, signal, where in classify.dispatch_batches(
+                        items, replicas, work):
+                    while group_of(number) > group:
+                        table.flush()
+                        yield close_group(group, calls, written, jobs)
+                        group, calls, done, written, jobs = group + 1, {}, 0, 0, []
+                        classify.print_classification_progress(0, 1, 'reads', out_dest=sys.stdout)
+                    calls.update(zip(ids, names))
+                    table.writelines('{}\t{}\t{}\n'.format(rid, name, path)
+                                     for rid, name in zip(ids, names))
+                    if not self.table_only and signal is None and where is not None:
+                        targets = []
+                        for rid, name in zip(ids, names):
+                            bin_dir = self.out_dir / bin_name(name)
+                            if name not in known_bins:
+                                os.makedirs(str(bin_dir), exist_ok=True)
+                                known_bins.add(name)
+                            targets.append(str(bin_dir / (self._file_name(rid, name) + '.fast5')))
+                        native_waiting.acquire()
+                        jobs.append(native_jobs.submit(bin_container, path, list(where), targets))
+                        written += len(targets)
+                    elif not self.table_only:      # zlib and file writes release the GIL
+                        for i, (rid, name) in enumerate(zip(ids, names)):
+                            in_flight.acquire()
+                            jobs.append(writers.submit(bin_read, self._file_name(rid, name), rid,
+                                                       signal(i), name, path, metadata))
+                            written += 1
+                    done += len(ids)
+                    # the total is known once the pass's last container is open; until then,
+                    # extrapolate
+                    in_pass = min(per_pass, len(fast5s) - group * per_pass)
+                    total = max(done * in_pass // (number - group * per_pass), 1)
+                    classify.print_classification_progress(min(done, total), total, 'reads',
+                                                           out_dest=sys.stdout)
+            yield close_group(group, calls, written, jobs)
+        finally:
+            writers.shutdown(wait=True)
+            native_jobs.shutdown(wait=True)
+            if metadata is not None:
+                metadata.close()
+            for model in queues:                # the forward kernel gets every CU back
+                model.reserve_cus(0)
 
     def _file_name(self, read_id, call):
         """File name (without .fast5) of a binned read.  The id is an attribute of an untrusted
