@@ -209,6 +209,8 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
 
     def classify_loaded(loaded, start_replica, end_replica):
         """One loaded batch on one device -> (its reads' files, calls, table rows)."""
+        if isinstance(loaded, RawBatch):
+            return _classify_raw_batch(loaded, start_replica, end_replica, args)
         files, read_ids, signals = {}, [], []
         for fast5_file, read_id, signal in loaded:
             if signal is None:
@@ -223,9 +225,17 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
                                     end_replica, end_input_size, output_size, args, calls)
         return files, calls, lines
 
-    for files, calls, lines in dispatch_batches(load_in_batches(fast5_files, args),
-                                                device_replicas(start_model, end_model),
-                                                classify_loaded):
+    replicas = device_replicas(start_model, end_model)
+    host_share = raw_inflate_share(start_model, end_model, args, len(fast5_files), replicas)
+    if host_share is None:
+        batches = load_in_batches(fast5_files, args)
+    else:
+        # Signals as stored, inflated on the GPU beside the classification of the batch before:
+        # several batches in flight per GPU, each on a replica of the models
+        from . import realtime
+        replicas, _ = realtime.inflate_queues(replicas, _QUEUE_CLONES, host_share)
+        batches = _raw_batches(fast5_files, args, host_share, len(replicas))
+    for files, calls, lines in dispatch_batches(batches, replicas, classify_loaded):
         read_id_to_fast5_file.update(files)
         classifications.update(calls)
         if full_output:
@@ -250,6 +260,96 @@ def scanned_end_samples(scan_size, input_size=MODEL_INPUT_SIZE):
     input_size long (reference classify.py:330-349).  The loaders run before any model object is
     in reach, hence the constant - which is also what the device library insists on."""
     return int(scan_size) + input_size // 2
+
+
+RAW_CLASSIFY_MIN_FILES = 8192       # below that the CPU loader is done before a pipeline fills
+RAW_BATCH_FILES = 4096              # one-read files per GPU-inflated batch (a container's worth)
+_QUEUE_CLONES = {}
+
+
+def raw_inflate_share(start_model, end_model, args, n_files, replicas):
+    """Per cent of the inflating the host keeps when ``classify`` hands the Signals of one-read
+    files to the GPU as stored (realtime.host_inflate_share), or None if they go through the
+    CPU loader: verbose output (it prints probabilities, which the deflated entry point does not
+    hand back), another reader or backend, few files, or a host with cores to spare."""
+    models = [m for m in (start_model, end_model) if m is not None]
+    if (reader_kind() != 'native' or getattr(args, 'verbose', False) or
+            n_files < int(os.environ.get('DEEPBINNER_RAW_CLASSIFY_MIN_FILES',
+                                         RAW_CLASSIFY_MIN_FILES)) or
+            not all(hasattr(pick, 'handle') for pair in replicas for pick in pair
+                    if pick is not None) or not models):
+        return None
+    from . import realtime
+    share = realtime.host_inflate_share(len({getattr(r[0] or r[1], 'device', 0)
+                                             for r in replicas}))
+    return share if share < 100 else None
+
+
+class RawBatch:
+    """A batch of one-read files with their Signals as stored (fast5_native.load_batch_raw)."""
+
+    def __init__(self, files, loaded):
+        self.files = list(files)
+        self.read_ids, self.offsets, self.status, self.comp, self.records = loaded
+
+
+def _raw_batches(fast5_files, args, host_share, n_queues):
+    """RawBatch after RawBatch, loaded ahead of the GPU: two loads at a time on background
+    threads (each on half of the loader's threads), as many waiting as there are queues."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    from . import fast5_native
+    threads = int(getattr(args, 'loader_procs', 0) or 0) or max(1, min(32, usable_cpus()))
+    size = max(int(args.batch_size), RAW_BATCH_FILES)
+    chunks = list(chunker(fast5_files, size))
+
+    def load(chunk):
+        return RawBatch(chunk, fast5_native.load_batch_raw(chunk, max(1, threads // 2),
+                                                            -host_share))
+
+    with ThreadPoolExecutor(max_workers=2, thread_name_prefix='deepbinner-raw-loader') as pool:
+        waiting = collections.deque()
+        upcoming = iter(chunks)
+        for chunk in upcoming:
+            waiting.append(pool.submit(load, chunk))
+            if len(waiting) > n_queues:
+                break
+        while waiting:
+            batch = waiting.popleft().result()
+            chunk = next(upcoming, None)
+            if chunk is not None:
+                waiting.append(pool.submit(load, chunk))
+            if (batch.status == fast5_native.F5_ERR_MULTI).any():
+                sys.exit('Error: Deepbinner does not (yet) support multi-read fast5 files')
+            warn_about_filters(batch.status)
+            yield batch
+
+
+def _classify_raw_batch(batch, start_replica, end_replica, args):
+    """One RawBatch on one queue -> (its reads' files, calls, table rows): upload, inflate, both
+    models and combine_calls in one call of the C ABI; a stream the GPU's decoder refuses is
+    inflated again by the host's loader, which has the last word."""
+    from . import fast5_native, hip_backend
+    both = start_replica is not None and end_replica is not None
+    numbers, stream_status = hip_backend.classify_pair_deflated(
+        start_replica, end_replica, batch.comp, batch.records, batch.offsets, int(args.scan_size),
+        args.score_diff, combine_mode(args) if both else 'require_either')
+    read_ids = list(batch.read_ids)
+    for i in sorted(set(batch.records['read'][stream_status != 0].tolist())):
+        ids, samples, offsets, status = fast5_native.load_batch(
+            [batch.files[i]], scanned_end_samples(args.scan_size), 1)
+        if status[0] != 0:
+            read_ids[i] = None
+            continue
+        numbers[i] = classify_packed_numbers(samples, offsets, start_replica, end_replica, args)[0]
+    files, calls, lines = {}, {}, []
+    for read_id, fast5_file, number in zip(read_ids, batch.files, numbers.tolist()):
+        if read_id is None:
+            continue
+        files[read_id] = fast5_file
+        calls[read_id] = _CALL_NAMES[number]
+        lines.append(read_id + '\t' + _CALL_NAMES[number])
+    return files, calls, lines
 
 
 def load_in_batches(fast5_files, args):

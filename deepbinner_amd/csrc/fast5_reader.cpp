@@ -1093,6 +1093,14 @@ class Fast5 {
         return s;
     }
 
+  public:
+    // one zlib stream -> its bytes (libdeflate where the system has it, zlib otherwise)
+    static void inflate_stream(const uint8_t* src, size_t src_len, size_t hint,
+                               std::vector<uint8_t>* out, ChunkCache* cache) {
+        inflate_all(src, src_len, hint, out, cache);
+    }
+
+  private:
     static void inflate_all(const uint8_t* src, size_t src_len, size_t hint,
                             std::vector<uint8_t>* out, ChunkCache* cache) {
         const LibDeflate& fast = libdeflate();
@@ -2123,6 +2131,167 @@ int f5_load_batch(const char* const* paths, int64_t n_files, int64_t keep, int n
         batch->offsets[(size_t)n_files] = total;
         batch->samples.resize((size_t)total);
         run_parallel(pack_one);
+    } catch (const std::exception&) {
+        delete batch;
+        return F5_ERR_OPEN;
+    }
+    *out = batch;
+    return F5_OK;
+}
+
+// One-read files with their Signals AS STORED (the one-read twin of f5_stream_open_raw's
+// batches): pass 1, per file on one worker thread, reads and parses the file and stages its
+// Signal pieces' bytes; then the host's share of the inflating is chosen over the whole batch;
+// pass 2 copies - or, for the host's share, inflates - the staged bytes into the batch's byte
+// buffer.
+int f5_load_batch_raw(const char* const* paths, int64_t n_files, int n_threads,
+                      int64_t host_inflate_above, f5_batch** out) {
+    if (!paths || !out || n_files < 0) return F5_ERR_ARGUMENT;
+    *out = nullptr;
+    f5_batch* batch = nullptr;
+    try {
+        batch = new f5_batch;
+        batch->offsets.assign((size_t)n_files + 1, 0);
+        batch->status.assign((size_t)n_files, F5_ERR_OPEN);
+        batch->read_ids.assign((size_t)n_files * F5_READ_ID_MAX, 0);
+        struct Staged {
+            std::vector<Fast5::RawPiece> pieces;       // file_off = offset into `bytes` from here on
+            std::string bytes;
+            int64_t samples = 0;
+        };
+        std::vector<Staged> staged((size_t)n_files);
+        const int64_t zlib_above = host_inflate_above > 0 ? host_inflate_above : 0;
+
+        auto stage_one = [&](int64_t i) {
+            thread_local std::vector<uint8_t> file_bytes;
+            thread_local ChunkCache cache;
+            cache.addr = ~0ull;
+            bool multi = false;
+            Staged& st = staged[(size_t)i];
+            int rc = paths[i] ? F5_OK : F5_ERR_ARGUMENT;
+            if (rc == F5_OK) rc = guarded([&] {
+                Fast5 file(paths[i], &file_bytes);
+                file.parse();
+                if (file.layout() == F5_LAYOUT_MULTI) {
+                    multi = true;
+                    return;
+                }
+                const ReadEntry& r = file.read(0);
+                st.samples = r.signal.n;
+                file.signal_pieces(r.signal, zlib_above, &st.pieces);
+                for (Fast5::RawPiece& p : st.pieces) {
+                    const uint64_t wanted = (uint64_t)p.count * 2;
+                    const size_t at = st.bytes.size();
+                    if (p.kind == Fast5::kZlib || p.kind == Fast5::kStored) {
+                        const uint64_t take = p.kind == Fast5::kZlib ? p.nbytes
+                                                                     : std::min(p.nbytes, wanted);
+                        st.bytes.resize(at + (size_t)take);
+                        file.read_bytes(p.file_off, take, reinterpret_cast<uint8_t*>(&st.bytes[at]));
+                        p.nbytes = take;
+                    } else if (p.kind == Fast5::kHostDecode) {
+                        st.bytes.resize(at + (size_t)wanted);
+                        file.decode_piece(r.signal, p, reinterpret_cast<uint8_t*>(&st.bytes[at]),
+                                          &cache);
+                        p.kind = Fast5::kStored;
+                        p.nbytes = wanted;
+                    } else {
+                        p.nbytes = 0;
+                    }
+                    p.file_off = at;
+                }
+                copy_read_id(r.read_id, &batch->read_ids[(size_t)i * F5_READ_ID_MAX]);
+            });
+            if (multi) rc = F5_ERR_MULTI;
+            if (rc != F5_OK) {
+                st = Staged();
+                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            }
+            batch->status[(size_t)i] = rc;
+        };
+        int threads = thread_count(n_threads);
+        threads = (int)std::min<int64_t>(threads, std::max<int64_t>(n_files, 1));
+        worker_pool().run(threads, n_files, [&](int64_t i, int) { stage_one(i); });
+
+        // the host's share: the longest streams of the batch holding -host_inflate_above per cent
+        // of its compressed bytes (kHostDecode from here on = "inflate the staged stream")
+        if (host_inflate_above < 0) {
+            std::vector<std::pair<uint64_t, std::pair<int64_t, size_t>>> streams;
+            uint64_t total = 0;
+            for (int64_t i = 0; i < n_files; ++i)
+                for (size_t k = 0; k < staged[(size_t)i].pieces.size(); ++k)
+                    if (staged[(size_t)i].pieces[k].kind == Fast5::kZlib) {
+                        streams.push_back({staged[(size_t)i].pieces[k].nbytes, {i, k}});
+                        total += staged[(size_t)i].pieces[k].nbytes;
+                    }
+            std::sort(streams.begin(), streams.end(),
+                      [](const auto& a, const auto& b) { return a.first > b.first; });
+            const uint64_t share = (uint64_t)std::min<int64_t>(-host_inflate_above, 100);
+            uint64_t taken = 0;
+            for (const auto& e : streams) {
+                if (taken * 100 >= total * share) break;
+                staged[(size_t)e.second.first].pieces[e.second.second].kind = Fast5::kHostDecode;
+                taken += e.first;
+            }
+        }
+        int64_t samples = 0, at = 0;
+        size_t n_pieces = 0;
+        for (int64_t i = 0; i < n_files; ++i) {
+            batch->offsets[(size_t)i] = samples;
+            samples += staged[(size_t)i].samples;
+            n_pieces += staged[(size_t)i].pieces.size();
+        }
+        batch->offsets[(size_t)n_files] = samples;
+        batch->streams.reserve(n_pieces);
+        for (int64_t i = 0; i < n_files; ++i)
+            for (Fast5::RawPiece& p : staged[(size_t)i].pieces) {
+                p.comp_offset = at;
+                p.comp_bytes = p.kind == Fast5::kHostDecode ? p.count * 2 : (int64_t)p.nbytes;
+                at += p.comp_bytes;
+                f5_raw_stream rec;
+                rec.comp_offset = p.comp_offset;
+                rec.comp_bytes = p.comp_bytes;
+                rec.out_offset = (batch->offsets[(size_t)i] + p.first) * 2;
+                rec.out_bytes = p.count * 2;
+                rec.mode = p.kind == Fast5::kZlib ? F5_RAW_ZLIB : F5_RAW_STORED;
+                rec.reserved = (int32_t)i;
+                batch->streams.push_back(rec);
+            }
+        batch->comp_bytes = at;
+        batch->comp.resize((size_t)(at + 64 + 1) / 2);
+        uint8_t* comp = reinterpret_cast<uint8_t*>(batch->comp.data());
+        std::memset(comp + at, 0, 64);
+        std::vector<int32_t> inflate_failed((size_t)n_files, 0);
+        worker_pool().run(threads, n_files, [&](int64_t i, int) {
+            thread_local ChunkCache cache;
+            thread_local std::vector<uint8_t> tmp;
+            const Staged& st = staged[(size_t)i];
+            for (const Fast5::RawPiece& p : st.pieces) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(st.bytes.data()) + p.file_off;
+                uint8_t* dst = comp + p.comp_offset;
+                if (p.kind != Fast5::kHostDecode) {
+                    std::memcpy(dst, src, (size_t)p.comp_bytes);
+                    continue;
+                }
+                const int rc = guarded([&] {
+                    Fast5::inflate_stream(src, (size_t)p.nbytes, (size_t)p.count * 2 + 8, &tmp, &cache);
+                });
+                const size_t have = rc == F5_OK ? std::min(tmp.size(), (size_t)p.count * 2) : 0;
+                if (have) std::memcpy(dst, tmp.data(), have);
+                std::memset(dst + have, 0, (size_t)p.count * 2 - have);
+                if (rc != F5_OK) inflate_failed[(size_t)i] = rc;
+            }
+        });
+        for (int64_t i = 0; i < n_files; ++i)
+            if (inflate_failed[(size_t)i]) {
+                batch->status[(size_t)i] = inflate_failed[(size_t)i];
+                std::memset(&batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            }
+        std::stable_sort(batch->streams.begin(), batch->streams.end(),
+                         [](const f5_raw_stream& x, const f5_raw_stream& y) {
+                             const int64_t wx = x.mode == F5_RAW_ZLIB ? x.comp_bytes : 0;
+                             const int64_t wy = y.mode == F5_RAW_ZLIB ? y.comp_bytes : 0;
+                             return wx > wy;
+                         });
     } catch (const std::exception&) {
         delete batch;
         return F5_ERR_OPEN;

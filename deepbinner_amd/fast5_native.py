@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     'f5_batch_read_ids', 'f5_batch_free', 'f5_stream_open', 'f5_stream_next', 'f5_stream_close',
     'f5_set_sample_allocator', 'f5_release_idle_buffers', 'f5_stream_open_raw', 'f5_batch_comp',
     'f5_batch_comp_bytes', 'f5_batch_streams', 'f5_batch_n_streams', 'f5_write_single_reads',
-    'f5_single_read_image',
+    'f5_single_read_image', 'f5_load_batch_raw',
 ]
 
 
@@ -79,6 +79,7 @@ def load_library():
         'f5_stream_next': (c_int, [c_void_p, P(c_i64), P(c_int), P(c_void_p)]),
         'f5_stream_close': (None, [c_void_p]),
         'f5_stream_open_raw': (c_int, [P(c_char_p), c_i64, c_int, c_int, c_i64, P(c_void_p)]),
+        'f5_load_batch_raw': (c_int, [P(c_char_p), c_i64, c_int, c_i64, P(c_void_p)]),
         'f5_write_single_reads': (c_int, [c_char_p, c_i64, P(c_i64), P(c_char_p), c_int,
                                           P(ctypes.c_int32), P(c_i64)]),
         'f5_single_read_image': (c_int, [c_char_p, c_i64, c_void_p, c_i64, P(c_i64)]),
@@ -231,6 +232,44 @@ def _unpack_batch(lib, handle, n, keep_alive=None):
     return read_ids, samples, offsets, st
 
 
+def _unpack_raw_batch(lib, batch):
+    """(read_ids, offsets, status, comp, records) of a raw batch handle (freed when ``comp``, the
+    zero-copy array of its bytes, dies)."""
+    count = int(lib.f5_batch_size(batch))
+    n_streams = int(lib.f5_batch_n_streams(batch))
+    comp_bytes = int(lib.f5_batch_comp_bytes(batch))
+    try:
+        records = np.empty(n_streams, dtype=RAW_STREAM)
+        if n_streams:
+            ctypes.memmove(records.ctypes.data, lib.f5_batch_streams(batch),
+                           n_streams * RAW_STREAM.itemsize)
+        # (64 readable bytes behind the streams: part of the array, so that they travel)
+        comp = np.ctypeslib.as_array(lib.f5_batch_comp(batch), shape=(comp_bytes + 64,)) \
+            if n_streams else np.zeros(64, dtype=np.uint8)
+    except Exception:
+        lib.f5_batch_free(batch)
+        raise
+    ids, _, offsets, st = _unpack_batch(lib, batch, count, keep_alive=comp if n_streams else None)
+    return ids, offsets, st, comp, records
+
+
+def load_batch_raw(fast5_files, threads=0, host_inflate_above=0):
+    """One-read files with their Signals AS STORED -> (read_ids, offsets, status, comp, records),
+    laid out like a batch of ``stream_raw`` (read i = file i), for
+    ``hip_backend.classify_pair_deflated``.  ``host_inflate_above`` as there: > 0 bytes, or minus
+    the per cent of the batch's compressed bytes (its longest streams) the host's threads inflate
+    themselves."""
+    lib = load_library()
+    n = len(fast5_files)
+    paths = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(p)) for p in fast5_files])
+    handle = ctypes.c_void_p()
+    status = lib.f5_load_batch_raw(paths, n, int(threads), int(host_inflate_above),
+                                   ctypes.byref(handle))
+    if status != F5_OK:
+        raise Fast5NativeError(status_string(status))
+    return _unpack_raw_batch(lib, handle)
+
+
 def load_batch(fast5_files, keep=None, threads=0):
     """One-read files -> (read_ids, samples, offsets, status): read i is
     ``samples[offsets[i]:offsets[i+1]]`` (its first and last ``keep`` samples only when it is
@@ -319,23 +358,7 @@ def stream_raw(fast5_files, threads=0, depth=0, host_inflate_above=0):
             if container_status.value != F5_OK:
                 yield index.value, None, None, container_status.value, None, None
                 continue
-            batch = ctypes.c_void_p(handle.value)
-            count = int(lib.f5_batch_size(batch))
-            n_streams = int(lib.f5_batch_n_streams(batch))
-            comp_bytes = int(lib.f5_batch_comp_bytes(batch))
-            try:
-                records = np.empty(n_streams, dtype=RAW_STREAM)
-                if n_streams:
-                    ctypes.memmove(records.ctypes.data, lib.f5_batch_streams(batch),
-                                   n_streams * RAW_STREAM.itemsize)
-                # (64 readable bytes behind the streams: part of the array, so that they travel)
-                comp = np.ctypeslib.as_array(lib.f5_batch_comp(batch), shape=(comp_bytes + 64,)) \
-                    if n_streams else np.zeros(64, dtype=np.uint8)
-            except Exception:
-                lib.f5_batch_free(batch)
-                raise
-            ids, _, offsets, st = _unpack_batch(lib, batch, count, keep_alive=comp if n_streams
-                                                else None)
+            ids, offsets, st, comp, records = _unpack_raw_batch(lib, ctypes.c_void_p(handle.value))
             yield index.value, ids, offsets, st, comp, records
     finally:
         lib.f5_stream_close(stream)

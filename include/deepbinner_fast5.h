@@ -119,6 +119,9 @@ typedef struct f5_raw_stream {
 } f5_raw_stream;
 int f5_stream_open_raw(const char* const* paths, int64_t n_paths, int n_threads, int depth,
                        int64_t host_inflate_above, f5_stream** out);
+/* the same for a batch of one-read files (f5_load_batch's twin): one batch, read i = file i */
+int f5_load_batch_raw(const char* const* paths, int64_t n_files, int n_threads,
+                      int64_t host_inflate_above, f5_batch** out);
 const uint8_t* f5_batch_comp(const f5_batch* batch);
 int64_t f5_batch_comp_bytes(const f5_batch* batch);
 const f5_raw_stream* f5_batch_streams(const f5_batch* batch);

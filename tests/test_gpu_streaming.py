@@ -396,3 +396,62 @@ def test_realtime_with_and_without_gpu_inflate(hip, gold, containers, tmp_path, 
     assert tables['1'] == tables['0']
     assert len(tables['1']) in (READS_PER_CONTAINER + 1, READS_PER_CONTAINER + 2) or \
         len(tables['1']) >= READS_PER_CONTAINER
+
+
+def test_classify_one_read_files_with_the_gpu_inflating(hip, gold, tmp_path, monkeypatch, capsys):
+    """`deepbinner classify` over a directory of one-read files with their Signals handed to the
+    GPU as stored (classify.raw_inflate_share: on by itself for big directories on hosts with few
+    cores per GPU; forced here) prints the table the CPU loader's path prints - every fixture
+    file (old and new layouts, the 32 h5py variants: chunked, shuffled, checksummed, contiguous
+    ...), copies of them by the hundred, a file that is not HDF5 and one with a damaged chunk
+    (which the host's zlib gets the last word on) - whatever share of the inflating the host
+    keeps."""
+    sources = sorted(os.path.join(GOLD, 'fast5', sub, f)
+                     for sub in ('single', 'h5py_variants')
+                     for f in os.listdir(os.path.join(GOLD, 'fast5', sub)) if f.endswith('.fast5'))
+    from deepbinner_amd import fast5_native
+    sources = [f for f in sources if fast5_native.load_batch([f], None, 1)[3][0] == 0]
+    assert len(sources) >= 25
+    in_dir = tmp_path / 'reads'
+    in_dir.mkdir()
+    for k in range(1500):
+        os.symlink(sources[k % len(sources)], str(in_dir / ('read_%05d.fast5' % k)))
+    (in_dir / 'not_hdf5.fast5').write_bytes(b'definitely not HDF5' * 100)
+    # a damaged deflate stream: flip a byte in the middle of the largest file's biggest chunk
+    victim_source = max(sources, key=os.path.getsize)
+    data = bytearray(open(victim_source, 'rb').read())
+    _, _, _, comp, records = fast5_native.load_batch_raw([victim_source], 1, 0)
+    rec = records[np.argmax(records['comp_bytes'])]
+    chunk = bytes(comp[rec['comp_offset']:rec['comp_offset'] + rec['comp_bytes']])
+    at = bytes(data).find(chunk)
+    assert at > 0 and rec['mode'] == 0
+    data[at + len(chunk) // 2] ^= 0x3C
+    (in_dir / 'damaged.fast5').write_bytes(bytes(data))
+
+    from deepbinner_amd import classify
+    files = sorted(str(p) for p in in_dir.iterdir())
+    models = classify.load_and_check_models(os.path.join(MODEL_DIR, START + '.dbw'),
+                                            os.path.join(MODEL_DIR, END + '.dbw'), 6144)
+    args = argparse.Namespace(verbose=False, batch_size=256, scan_size=6144, score_diff=0.5,
+                              require_either=True, require_start=False, require_both=False,
+                              loader_procs=0)
+
+    def table(env):
+        for name in ('DEEPBINNER_GPU_INFLATE', 'DEEPBINNER_HOST_INFLATE_SHARE',
+                     'DEEPBINNER_RAW_CLASSIFY_MIN_FILES'):
+            monkeypatch.delenv(name, raising=False)
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
+        capsys.readouterr()
+        calls, where = classify.classify_fast5_files(files, *models[:5], args,
+                                                     verified_single_read=True)
+        out = capsys.readouterr().out.splitlines()
+        assert len(calls) == len(where)
+        return out[0], sorted(out[1:])
+
+    want = table({'DEEPBINNER_GPU_INFLATE': '0'})
+    assert len(want[1]) >= 1500 and want[0].split('\t')[:2] == ['read_ID', 'barcode_call']
+    for share in ('0', '40', '99'):
+        got = table({'DEEPBINNER_RAW_CLASSIFY_MIN_FILES': '1',
+                     'DEEPBINNER_HOST_INFLATE_SHARE': share})
+        assert got == want, share
