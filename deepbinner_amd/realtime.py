@@ -107,29 +107,44 @@ class MoveTally:
     def __init__(self, out_dir, total):
         self.out_dir, self.total = pathlib.Path(out_dir), total
         self.moved = self.clashes = self.failures = 0
+        self._bins = {}             # barcode call -> its directory (made once)
+        self._shown = -1
 
     def _bin(self, barcode_call):
-        target = self.out_dir / bin_name(barcode_call)
-        if not target.is_dir():
-            try:
-                target.mkdir(parents=True)
-            except OSError:
-                sys.exit('Error: unable to create output directory {}'.format(target))
+        target = self._bins.get(barcode_call)
+        if target is None:
+            target = self.out_dir / bin_name(barcode_call)
+            if not target.is_dir():
+                try:
+                    target.mkdir(parents=True)
+                except OSError:
+                    sys.exit('Error: unable to create output directory {}'.format(target))
+            target = self._bins[barcode_call] = str(target)
         return target
 
     def file(self, fast5_file, barcode_call, unmovable):
-        target = self._bin(barcode_call)
-        if (target / pathlib.Path(fast5_file).name).is_file():
+        """One file into its bin (reference realtime.py:111-144): never over a file that is
+        there already; a rename where that works (the same file system), a copy where not."""
+        target = os.path.join(self._bin(barcode_call), os.path.basename(fast5_file))
+        if os.path.isfile(target):
             self.clashes += 1
             unmovable.add(fast5_file)          # never look at it again
         else:
             try:
-                shutil.move(fast5_file, str(target))
+                try:
+                    os.rename(fast5_file, target)
+                except OSError:
+                    shutil.move(fast5_file, target)
                 self.moved += 1
             except OSError:
                 self.failures += 1
-        print('\rMoving fast5s:      {} / {} ({:.1f}%)'.format(
-            self.moved, self.total, 100.0 * self.moved / self.total), end='', flush=True)
+        # (the reference redraws the line per file; so does this up to a thousand files a pass,
+        # beyond that a thousand times a pass)
+        if (self.moved - self._shown >= self.total // 1000 or
+                self.moved + self.clashes + self.failures >= self.total):
+            self._shown = self.moved
+            print('\rMoving fast5s:      {} / {} ({:.1f}%)'.format(
+                self.moved, self.total, 100.0 * self.moved / self.total), end='', flush=True)
 
     def report(self):
         print()

@@ -27,6 +27,9 @@ def main():
     ap.add_argument('--files', type=int, default=4)
     ap.add_argument('--reads', type=int, default=4000)
     ap.add_argument('--table-only', action='store_true')
+    ap.add_argument('--single-files', type=int, default=0,
+                    help='instead of containers: this many one-read files (links to 4,000 '
+                         'distinct ones), which realtime classifies and MOVES into their bins')
     opts = ap.parse_args()
     import subprocess
     import multi_read_rate
@@ -37,7 +40,25 @@ def main():
         in_dir, out_dir = os.path.join(tmp, 'in'), os.path.join(tmp, 'out')
         os.makedirs(in_dir)
         paths = [os.path.join(in_dir, 'batch_%02d.fast5' % k) for k in range(opts.files)]
-        if os.path.exists(multi_read_rate.CONDA_PYTHON):
+        if opts.single_files:
+            import numpy as np
+            import uuid
+            from deepbinner_amd import hdf5_write
+            rng = np.random.default_rng(7)
+            originals = []
+            os.makedirs(os.path.join(tmp, 'originals'))
+            for k in range(4000):
+                n = int(np.clip(rng.lognormal(np.log(27000) - 0.32, 0.8), 2000, 400000))
+                levels = rng.normal(450, 80, size=n // 8 + 1)
+                signal = np.clip(np.rint(np.repeat(levels, 8)[:n] + rng.normal(0, 8, size=n)), 0, 2047)
+                path = os.path.join(tmp, 'originals', 'orig_%05d.fast5' % k)
+                hdf5_write.write_single_read_fast5(
+                    path, str(uuid.UUID(bytes=rng.bytes(16), version=4)), signal.astype(np.int16))
+                originals.append(path)
+            for i in range(opts.single_files):
+                os.symlink(originals[i % 4000], os.path.join(in_dir, 'read_%06d.fast5' % i))
+            opts.files, opts.reads = opts.single_files, 1
+        elif os.path.exists(multi_read_rate.CONDA_PYTHON):
             jobs = [subprocess.Popen([multi_read_rate.CONDA_PYTHON, '-c', multi_read_rate.WRITER, p,
                                       str(opts.reads), '27000', str(100 + k)])
                     for k, p in enumerate(paths)]
