@@ -41,22 +41,27 @@ def main():
         os.makedirs(in_dir)
         paths = [os.path.join(in_dir, 'batch_%02d.fast5' % k) for k in range(opts.files)]
         if opts.single_files:
-            import numpy as np
-            import uuid
-            from deepbinner_amd import hdf5_write
-            rng = np.random.default_rng(7)
-            originals = []
-            os.makedirs(os.path.join(tmp, 'originals'))
-            for k in range(4000):
-                n = int(np.clip(rng.lognormal(np.log(27000) - 0.32, 0.8), 2000, 400000))
-                levels = rng.normal(450, 80, size=n // 8 + 1)
-                signal = np.clip(np.rint(np.repeat(levels, 8)[:n] + rng.normal(0, 8, size=n)), 0, 2047)
-                path = os.path.join(tmp, 'originals', 'orig_%05d.fast5' % k)
-                hdf5_write.write_single_read_fast5(
-                    path, str(uuid.UUID(bytes=rng.bytes(16), version=4)), signal.astype(np.int16))
-                originals.append(path)
-            for i in range(opts.single_files):
-                os.symlink(originals[i % 4000], os.path.join(in_dir, 'read_%06d.fast5' % i))
+            # distinct reads: containers first, their reads written out as one-read files by the
+            # native writer
+            from deepbinner_amd import fast5_native
+            n_containers = (opts.single_files + 3999) // 4000
+            scratch = os.path.join(tmp, 'containers')
+            os.makedirs(scratch)
+            left = opts.single_files
+            for k in range(n_containers):
+                container = os.path.join(scratch, 'c%03d.fast5' % k)
+                if os.path.exists(multi_read_rate.CONDA_PYTHON):
+                    subprocess.run([multi_read_rate.CONDA_PYTHON, '-c', multi_read_rate.WRITER,
+                                    container, '4000', '27000', str(100 + k)], check=True)
+                else:
+                    multi_read_rate.write_with_own_writer(container, 4000, 27000, 100 + k)
+                take = min(4000, left)
+                status, _ = fast5_native.write_single_reads(
+                    container, list(range(take)),
+                    [os.path.join(in_dir, 'read_%03d_%04d.fast5' % (k, i)) for i in range(take)])
+                assert (status == 0).all()
+                os.remove(container)
+                left -= take
             opts.files, opts.reads = opts.single_files, 1
         elif os.path.exists(multi_read_rate.CONDA_PYTHON):
             jobs = [subprocess.Popen([multi_read_rate.CONDA_PYTHON, '-c', multi_read_rate.WRITER, p,
