@@ -36,10 +36,12 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 
 # The streaming path with the GPU inflating: what it was measured with on an MI355X box (16
 # usable cores, one GPU; profiles/r03_gpu_inflate_split.txt) - three containers in flight per GPU,
-# each on its own queue (model replica), and 32 CUs left out of the forward kernel's persistent
-# launches for the inflate kernels of the containers behind.
-INFLATE_QUEUES = 3          # (six where the GPU inflates nearly everything: a container then
-INFLATE_CUS = 0             #  lasts as long as its longest read, ~10 mean reads)
+# each on its own queue (model replica); six where the GPU inflates nearly everything (a container
+# then lasts as long as its longest read, ~10 mean reads).  No CUs are left out of the forward
+# kernel's launches for the inflate kernels: its workgroups take their windows off a counter, and
+# one that finds its CU taken simply takes fewer (while they walked fixed shares, 32 were).
+INFLATE_QUEUES = 3
+INFLATE_CUS = 0
 
 
 def host_inflate_share(n_gpus):
