@@ -34,6 +34,11 @@
 
 #include "dbh_layout.h"
 
+// (A/B switches of tools/ab_variants.sh; the defaults are what ships)
+#ifndef DBH_EXP_A_DMA_UNDER_MFMA
+#define DBH_EXP_A_DMA_UNDER_MFMA 1
+#endif
+
 // This file is compiled twice by dbh_api.hip: as namespace dbh with DBH_TIMELINE 0 (the product)
 // and as namespace dbh_timeline with DBH_TIMELINE 1 (cycle stamps for tools/timeline.py).  The
 // stamps are global stores, and on gfx9 a store shares the vmcnt counter with the loads: one
@@ -453,6 +458,16 @@ __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* 
         const int piece = wave + kWaves * i;   // wave-uniform
         if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, lane_bytes);
     }
+}
+
+// The i-th piece of this wave's share of the same copy (i < ceil(pieces / waves)): for callers
+// that spread the requests between their own instructions.
+template <int NFLOATS>
+__device__ __forceinline__ void dma_weights_one(const float* __restrict__ g, float* lds_dst,
+                                                int lane, int wave, int i) {
+    constexpr int kPieces = NFLOATS / 256;
+    const int piece = wave + kWaves * i;
+    if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, (unsigned)lane * 16u);
 }
 
 // The same copy, spread over the NIT steps of the running layer (step IT issues its share).
@@ -2009,6 +2024,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         constexpr int MT = 512 / 16 / kWaves;
         const int m0 = wave * MT;
         float a[MT];
+#if DBH_EXP_A_DMA_UNDER_MFMA
+        bool prefetched_now = false;
+#endif
         const EpiParams<3, true>& ep = ep_a;      // conv1's weights and epilogue parameters:
         const float(&bw)[3] = bw_a;               // fetched once per workgroup, before the loop
         if (samples == nullptr) {
@@ -2046,6 +2064,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                  in_v1, in_raw, in_inside);
             }
             double mean, inv;
+#if DBH_EXP_A_DMA_UNDER_MFMA
+            prefetched_now = prefetched;
+#endif
             if (!prefetched) {
                 window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
                 full_barrier();  
@@ -2056,7 +2077,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 // its conv17 (stage F below); this barrier publishes them - and keeps this
                 // window's activations off the LDS that window's last reads still use
                 full_barrier();  
+                mark(ts, 51);
+#if !DBH_EXP_A_DMA_UNDER_MFMA
                 fetch_conv2_weights();
+#endif
+                mark(ts, 52);
                 const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
                 mean = stats[0];
                 inv = stats[1];
@@ -2065,16 +2090,33 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
+            mark(ts, 54);
         }
         // (the next window's number: asked for behind the barriers above - they wait for every
         // outstanding request - and needed behind the one below, a conv1 and its epilogue later)
         if (win_counter != nullptr && tid == 0) taken = atomicAdd(win_counter, 1);
         f4 acc[MT][3];
+#if DBH_EXP_A_DMA_UNDER_MFMA
+        // conv2's weights are requested BETWEEN conv1's MFMAs (a request costs ~100 cycles of
+        // issue, the matrix pipe 32 per MFMA: seven requests ahead of the MFMAs kept it idle for
+        // ~700 cycles per window) - in the steady state, where nothing else waits for them
+        const bool spread = samples != nullptr && prefetched_now;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
+                if (spread && m * 3 + t < (3 * kWinoHalf / 256 + kWaves - 1) / kWaves)
+                    dma_weights_one<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane,
+                                                   wave, m * 3 + t);
+            }
+#else
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
+#endif
         mark(ts, 59);
         float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
         epilogue<MT, 3, kS48, false, true, false>(acc, out_lane, ep);

@@ -34,6 +34,7 @@ TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 
         49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
 ORDER = list(range(0, 45))
 EXTRA = {25: 'conv7 end', 26: 'conv8 exchange stored', 27: 'conv8 barrier1',
+         51: 'A: first barrier passed', 52: 'A: conv2 weights requested', 54: 'A: window normalised',
          59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 6: 'conv3 U phase done', 7: 'conv3 barrier',
          57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
 
