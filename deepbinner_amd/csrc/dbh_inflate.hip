@@ -431,8 +431,8 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
 
 int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
                 int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,
-                double* kernel_ms) {
-    if (n_streams < 0) return DBH_ERR_INVALID_ARGUMENT;
+                int streams_per_lane, double* kernel_ms) {
+    if (n_streams < 0 || streams_per_lane < 0) return DBH_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return DBH_OK;
     if (!comp_host || !streams_host || !out_host || !status_host) return DBH_ERR_INVALID_ARGUMENT;
     for (int64_t i = 0; i < n_streams; ++i) {
@@ -473,7 +473,7 @@ int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_s
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
     if (e == hipSuccess && st == DBH_OK)
         st = dbh_inflate_dev(d_comp, (int64_t)comp_bytes, d_streams, n_streams, (int64_t)out_bytes,
-                             d_out, d_work, d_status, 0, nullptr);
+                             d_out, d_work, d_status, streams_per_lane, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_host, d_out, out_bytes, hipMemcpyDeviceToHost);
     if (e == hipSuccess)

@@ -117,7 +117,7 @@ def load_library():
         'dbh_inflate_dev': (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p]),
         'dbh_inflate': (c_int, [c_void_p, c_size_t, c_void_p, c_i64, c_void_p, c_size_t, c_void_p,
-                                P(ctypes.c_double)]),
+                                c_int, P(ctypes.c_double)]),
         'dbh_classify_pair_deflated': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
                                                c_void_p, c_i64, c_int, ctypes.c_double, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -279,11 +279,13 @@ INFLATE_STREAM = np.dtype([('comp_offset', '<i8'), ('comp_bytes', '<i8'), ('out_
                            ('out_bytes', '<i8'), ('mode', '<i4'), ('reserved', '<i4')])
 
 
-def inflate(comp, streams, out_bytes):
+def inflate(comp, streams, out_bytes, streams_per_lane=0):
     """zlib streams inflated on the GPU (``dbh_inflate``: host buffers in and out - tests and
     tools; the classify path keeps everything on the device).  ``comp``: uint8 array holding the
     streams, ``streams``: array of INFLATE_STREAM records, ``out_bytes``: size of the output
-    buffer -> (output uint8 array, status int32 per stream, milliseconds the two kernels took)."""
+    buffer, ``streams_per_lane``: how many streams a lane of kernel 1 takes one after the other
+    (0 = 1; the order is the records') -> (output uint8 array, status int32 per stream,
+    milliseconds the two kernels took)."""
     comp = np.ascontiguousarray(comp, dtype=np.uint8)
     streams = np.ascontiguousarray(streams, dtype=INFLATE_STREAM)
     out = np.zeros(int(out_bytes), dtype=np.uint8)
@@ -291,7 +293,7 @@ def inflate(comp, streams, out_bytes):
     ms = ctypes.c_double(0)
     check(load_library().dbh_inflate(comp.ctypes.data, comp.nbytes, streams.ctypes.data,
                                      len(streams), out.ctypes.data, out.nbytes, status.ctypes.data,
-                                     ctypes.byref(ms)), 'dbh_inflate')
+                                     int(streams_per_lane), ctypes.byref(ms)), 'dbh_inflate')
     return out, status, ms.value
 
 

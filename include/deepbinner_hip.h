@@ -223,7 +223,7 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
 /* host buffers in, host buffers out (tests, tools); kernel_ms (may be NULL): the two kernels */
 int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_stream* streams_host,
                 int64_t n_streams, uint8_t* out_host, size_t out_bytes, int32_t* status_host,
-                double* kernel_ms);
+                int streams_per_lane, double* kernel_ms);
 
 /* The whole of a batch from stored chunks to barcode calls in one call: upload of the compressed
  * bytes (in place if they are pinned: the native loader's raw batches are), inflate, the start

@@ -206,12 +206,15 @@ def test_gpu_inflate_matches_zlib(hip):
               (raw, 100, hip.INFLATE_STORED), (b'', 10, hip.INFLATE_STORED)]
     want += [raw, raw + bytes(77), raw[:100], bytes(10)]
     comp, records, out_bytes, places = pack_streams(hip, batch)
-    out, status, ms = hip.inflate(comp, records, out_bytes)
-    assert (status == 0).all(), np.nonzero(status)[0][:10]
-    for k, ((at, cap), w) in enumerate(zip(places, want)):
-        got = out[at:at + cap].tobytes()
-        assert got == w + bytes(cap - len(w)), (k, len(w), cap)          # zero-extended to cap
-    assert ms > 0
+    # one stream per lane, and lanes that take several one after the other (each at the first
+    # block boundary behind the end of its stream - while its neighbours are inside theirs)
+    for per_lane in (0, 3, 8, 1000):
+        out, status, ms = hip.inflate(comp, records, out_bytes, per_lane)
+        assert (status == 0).all(), (per_lane, np.nonzero(status)[0][:10])
+        for k, ((at, cap), w) in enumerate(zip(places, want)):
+            got = out[at:at + cap].tobytes()
+            assert got == w + bytes(cap - len(w)), (per_lane, k, len(w), cap)     # zero-extended
+        assert ms > 0
 
 
 @pytest.mark.gpu
@@ -219,20 +222,21 @@ def test_gpu_inflate_rejects_what_zlib_rejects(hip):
     cases = damaged_cases()
     cap = 100000
     comp, records, out_bytes, places = pack_streams(hip, [(s, cap, hip.INFLATE_ZLIB) for s in cases])
-    out, status, _ = hip.inflate(comp, records, out_bytes)
-    rejected = 0
-    for k, (stream, (at, _)) in enumerate(zip(cases, places)):
-        try:
-            want = zlib.decompress(stream)
-        except zlib.error:
-            want = None
-        got = out[at:at + cap].tobytes()
-        if want is None:
-            assert status[k] != 0 and got == bytes(cap), (k, status[k])
-            rejected += 1
-        else:
-            assert status[k] == 0 and got == want[:cap] + bytes(cap - len(want[:cap])), k
-    assert rejected > 300
+    for per_lane in (0, 5):
+        out, status, _ = hip.inflate(comp, records, out_bytes, per_lane)
+        rejected = 0
+        for k, (stream, (at, _)) in enumerate(zip(cases, places)):
+            try:
+                want = zlib.decompress(stream)
+            except zlib.error:
+                want = None
+            got = out[at:at + cap].tobytes()
+            if want is None:
+                assert status[k] != 0 and got == bytes(cap), (per_lane, k, status[k])
+                rejected += 1
+            else:
+                assert status[k] == 0 and got == want[:cap] + bytes(cap - len(want[:cap])), k
+        assert rejected > 300
 
 
 @pytest.mark.gpu
