@@ -233,7 +233,7 @@ def classify_fast5_files(fast5_files, start_model, start_input_size, end_model, 
         # Signals as stored, inflated on the GPU beside the classification of the batch before:
         # several batches in flight per GPU, each on a replica of the models
         from . import realtime
-        replicas, _ = realtime.inflate_queues(replicas, _QUEUE_CLONES, host_share)
+        replicas, _ = realtime.inflate_queues(replicas, host_share)
         batches = _raw_batches(fast5_files, args, host_share, len(replicas))
     for files, calls, lines in dispatch_batches(batches, replicas, classify_loaded):
         read_id_to_fast5_file.update(files)
@@ -264,7 +264,6 @@ def scanned_end_samples(scan_size, input_size=MODEL_INPUT_SIZE):
 
 RAW_CLASSIFY_MIN_FILES = 8192       # below that the CPU loader is done before a pipeline fills
 RAW_BATCH_FILES = 4096              # one-read files per GPU-inflated batch (a container's worth)
-_QUEUE_CLONES = {}
 
 
 def raw_inflate_share(start_model, end_model, args, n_files, replicas):

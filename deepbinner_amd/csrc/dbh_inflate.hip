@@ -23,8 +23,9 @@
 //      its output position; literals are stored at once; matches copy from the ring as soon as
 //      everything they read has been written (a match of one step may read what another match of
 //      the same step writes: the lanes go in rounds, the first waiting match deciding who may
-//      go).  The ring is written out in coalesced 256-byte pieces, with the Adler-32 sums on the
-//      way.
+//      go; a step in which a far-reaching match could be overtaken by a write that wraps around
+//      the ring goes in token order instead: dbh_inflate_core.h, ring_hazard).  The ring is written
+//      out in coalesced 256-byte pieces, with the Adler-32 sums on the way.
 // HBM traffic per read (55 KB of samples, ~22 k tokens): 35 KB compressed in, 88 KB of tokens out
 // and in again, 55 KB of samples out - latency, not bandwidth, is what both kernels wait for.
 #include <hip/hip_runtime.h>
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
     }
 }
 
-constexpr int kRing = 32768;
+constexpr int kRing = dbi::kWindowRing;
+static_assert(dbi::kStepTokens == 64, "one token per lane and step");
 constexpr int kWaves2 = 5;                 // streams per workgroup of kernel 2: a 32 KiB ring each
 
 // Wave-wide inclusive prefix sum on the DPP network (no LDS round trips): within rows of 16
@@ -286,13 +288,31 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
                     status = dbi::kBadDistance;
                     break;
                 }
+                const int src = my - dist;
+                if (__any(is_match && dbi::ring_hazard(dist, my, pos + total))) {
+                    // A match of this step reaches back so far that a write near the step's end
+                    // would land on bytes it has yet to read (dbh_inflate_core.h: ring_hazard) -
+                    // rare (distances beyond 16 K with long matches behind them): this step goes
+                    // in strict token order, one lane at a time.
+                    for (int l = 0; l < 64; ++l) {
+                        lds_settle();
+                        if (lane == l && valid) {
+                            if (!is_match) {
+                                ring[my & (kRing - 1)] = (uint8_t)t;
+                            } else {
+                                for (int k = 0; k < len; ++k)
+                                    ring[(my + k) & (kRing - 1)] = ring[(src + k) & (kRing - 1)];
+                            }
+                        }
+                    }
+                    lds_settle();
+                } else {
                 if (valid && !is_match) ring[my & (kRing - 1)] = (uint8_t)t;
                 // A match repeats the `dist` bytes before it: byte k is byte k mod dist of them,
                 // so everything it READS lies before its own start, in [src, src + min(len,
                 // dist)) - it may go as soon as that is written, i.e. lies before the earliest
                 // byte still to be written (the first waiting match's start: the positions ascend
                 // with the lanes).  The first waiting match can always go.
-                const int src = my - dist;
                 const int reach = src + (len < dist ? len : dist);
                 bool waiting = is_match;
                 unsigned long long mask = __ballot(waiting);
@@ -325,6 +345,7 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
                     }
                     waiting = waiting && !go;
                     mask = __ballot(waiting);
+                }
                 }
                 pos += total;
                 // whole 256-byte pieces out of the ring, the Adler-32 sums on the way

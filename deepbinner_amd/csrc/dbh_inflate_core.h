@@ -72,6 +72,21 @@ enum Status : int {
     kTooLong = 10,         // (phase 2, whole-stream mode) more output than announced
 };
 
+// Phase 2 keeps a stream's last 32 KiB of output in a ring of exactly that size (the largest
+// distance deflate knows) and resolves kStepTokens tokens at a time, out of token order: all of a
+// step's literals first, then its matches in rounds.  A byte written at position q takes the
+// slot of byte q - kWindowRing; a step spans up to 64 x 258 bytes, so a write near the step's end
+// can land on what a match near the step's start has yet to read - when that match reaches back
+// far enough: its distance plus the bytes from its start to the step's end exceed the ring.  Such
+// a step (zlib produces them: 32,000 random bytes twice in a row are 258-byte matches at distance
+// 32,000 back to back) is resolved in strict token order instead, where every write follows the
+// reads it could disturb.  Shared by the kernel and by the CPU harness's model of it.
+constexpr int kWindowRing = 32768;
+constexpr int kStepTokens = 64;
+DBI_HD bool ring_hazard(int dist, int my, int step_end) {
+    return dist + (step_end - my) > kWindowRing;
+}
+
 // RFC 1951 section 3.2.5, as arithmetic (device code cannot index host-side constant arrays):
 // length symbol 257 + c: c < 8: 3 + c; c < 28: e = (c - 4) / 4 extra bits, base 3 + ((4 + c % 4) << e);
 // c = 28: 258.  Distance symbol d: d < 4: d + 1; else e = d / 2 - 1, base 1 + ((2 + d % 2) << e).

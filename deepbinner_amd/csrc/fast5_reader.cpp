@@ -21,6 +21,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,11 @@ struct FormatError : std::runtime_error {
 // field): reported apart from damage, so that the caller can say what is the matter
 struct UnsupportedFilter : FormatError {
     using FormatError::FormatError;
+};
+
+// the writer found a file under the name it was to create (nothing is ever overwritten)
+struct ExistsError : std::runtime_error {
+    ExistsError() : std::runtime_error("file exists") {}
 };
 
 struct Msg {
@@ -1440,6 +1446,8 @@ int guarded(Fn&& fn) {
         return F5_OK;
     } catch (const UnsupportedFilter&) {
         return F5_ERR_FILTER;
+    } catch (const ExistsError&) {
+        return F5_ERR_EXISTS;
     } catch (const FormatError&) {
         return F5_ERR_FORMAT;
     } catch (const std::out_of_range&) {
@@ -2014,6 +2022,7 @@ const char* f5_status_string(int status) {
         case F5_ERR_MULTI: return "multi-read fast5 file";
         case F5_ERR_ARGUMENT: return "invalid argument";
         case F5_ERR_FILTER: return "Signal compressed with an unsupported filter (VBZ?)";
+        case F5_ERR_EXISTS: return "a file of that name exists already (not overwritten)";
         default: return "unknown status";
     }
 }
@@ -2450,18 +2459,39 @@ int f5_write_single_reads(const char* container, int64_t n, const int64_t* read_
                 }
                 const std::string image =
                     h5w::single_read_file(r.read_id, (uint64_t)samples, packed, meta);
-                const int fd = ::open(out_paths[i], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+                // Never over a file that is there (the reference's move counts a clash and leaves
+                // the earlier file alone, realtime.py:111-144), never through a symlink, and no
+                // half-written file under the final name: the image goes to a fresh temporary
+                // name in the same directory and is linked into place - link() fails if the name
+                // exists, and is atomic.
+                if (::access(out_paths[i], F_OK) == 0) throw ExistsError();
+                const std::string tmp = std::string(out_paths[i]) + ".part." +
+                                        std::to_string((long long)::getpid()) + "." +
+                                        std::to_string((long long)i);
+                const int fd = ::open(tmp.c_str(),
+                                      O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
                 if (fd < 0) throw std::runtime_error("cannot create file");
                 size_t done = 0;
                 while (done < image.size()) {
                     const ssize_t k = ::write(fd, image.data() + done, image.size() - done);
                     if (k <= 0) {
                         ::close(fd);
+                        ::unlink(tmp.c_str());
                         throw std::runtime_error("cannot write file");
                     }
                     done += (size_t)k;
                 }
-                if (::close(fd) != 0) throw std::runtime_error("cannot close file");
+                if (::close(fd) != 0) {
+                    ::unlink(tmp.c_str());
+                    throw std::runtime_error("cannot close file");
+                }
+                const int linked = ::link(tmp.c_str(), out_paths[i]);
+                const int link_errno = errno;
+                ::unlink(tmp.c_str());
+                if (linked != 0) {
+                    if (link_errno == EEXIST) throw ExistsError();
+                    throw std::runtime_error("cannot name file");
+                }
                 written.fetch_add((int64_t)image.size());
             });
         });

@@ -18,7 +18,7 @@ _LIB_NAME = 'libdeepbinner_fast5.so'
 _lib = None
 
 (F5_OK, F5_ERR_OPEN, F5_ERR_FORMAT, F5_ERR_NO_READ, F5_ERR_MULTI, F5_ERR_ARGUMENT,
- F5_ERR_FILTER) = range(7)
+ F5_ERR_FILTER, F5_ERR_EXISTS) = range(8)
 F5_READ_ID_MAX = 64
 LAYOUT_NONE, LAYOUT_SINGLE_OLD, LAYOUT_SINGLE_NEW, LAYOUT_MULTI = range(4)
 
@@ -368,7 +368,7 @@ def write_single_reads(container, read_indices, out_paths, threads=0):
     """Reads ``read_indices`` of the multi-read container ``container`` as one-read fast5 files
     ``out_paths`` (signal as stored + the read's Raw / channel_id / tracking_id / context_tags
     attributes: include/deepbinner_fast5.h) on the library's worker threads -> (status per read,
-    bytes written).  Raises Fast5NativeError if the container cannot be opened."""
+    bytes written).  A path that exists already is left alone (status F5_ERR_EXISTS).  Raises Fast5NativeError if the container cannot be opened."""
     lib = load_library()
     n = len(out_paths)
     if len(read_indices) != n:

@@ -19,7 +19,9 @@ the reference's own ``get_read_id_and_signal`` and with both of this package's r
 (tests/test_hdf5_write.py).
 """
 
+import os
 import struct
+import threading
 import zlib
 
 import numpy as np
@@ -299,5 +301,17 @@ def multi_read_fast5_bytes(reads, compress=True):
 
 def write_single_read_fast5(path, read_id, signal, compress=True, read_number=None,
                             metadata=None):
-    with open(path, 'wb') as f:
-        f.write(single_read_fast5_bytes(read_id, signal, compress, read_number, metadata))
+    """Writes the file under a temporary name beside ``path`` and links it into place: a file
+    that is there already is never overwritten (FileExistsError - the reference's move counts such
+    a clash and leaves the earlier file alone, realtime.py:111-144), and no partial file is ever
+    seen under the final name."""
+    image = single_read_fast5_bytes(read_id, signal, compress, read_number, metadata)
+    if os.path.lexists(path):
+        raise FileExistsError(path)
+    tmp = '{}.part.{}.{}'.format(path, os.getpid(), threading.get_ident())
+    with open(tmp, 'xb') as f:
+        f.write(image)
+    try:
+        os.link(tmp, path)
+    finally:
+        os.unlink(tmp)

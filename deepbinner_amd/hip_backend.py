@@ -488,6 +488,12 @@ class HipModel:
         return self._handle
 
     def close(self):
+        # further queues on the same GPU that realtime.queue_clones made of this model go with it
+        for _pair, more in self.__dict__.pop('_queue_clones', []):
+            for clones in more:
+                for clone in clones:
+                    if clone is not None and clone is not self:
+                        clone.close()
         if self._handle:
             self._lib.dbh_model_destroy(self._handle)
             self._handle = None

@@ -73,11 +73,30 @@ def host_inflate_share(n_gpus):
     return int(round(max(0.0, min(100.0, (budget_us - 25.0) / 0.9))))
 
 
-def inflate_queues(replicas, clones, host_share=50):
+def queue_clones(pair, n_more):
+    """``n_more`` further (start, end) pairs of the same weights on the same GPU.  They are kept
+    ON the pair's first model (``_queue_clones``: partner pair -> clones, matched by identity), so
+    that they live exactly as long as it does and ``HipModel.close()`` releases them with it - a
+    cache keyed by ``id()`` outside the models would hand a new model that happens to get a freed
+    model's id the old model's weights."""
+    holder = next(m for m in pair if m is not None)
+    cache = holder.__dict__.setdefault('_queue_clones', [])
+    for known, more in cache:
+        if len(known) == len(pair) and all(a is b for a, b in zip(known, pair)):
+            break
+    else:
+        more = []
+        cache.append((tuple(pair), more))
+    while len(more) < n_more:
+        more.append(tuple(m.clone() if m is not None else None for m in pair))
+    return more[:n_more]
+
+
+def inflate_queues(replicas, host_share=50):
     """-> (replicas, models): INFLATE_QUEUES (start, end) pairs per GPU instead of one - more
-    model replicas on the same GPU, each with its own streams and buffers (kept in ``clones`` for
-    the passes to come) - so that one container's chunks are inflated while the one before it is
-    classified; every model's forward launches leave INFLATE_CUS CUs to the inflate kernels
+    model replicas on the same GPU, each with its own streams and buffers (kept on the models
+    they copy for the passes to come: queue_clones) - so that one container's chunks are
+    inflated while the one before it is classified; every model's forward launches leave INFLATE_CUS CUs to the inflate kernels
     (``reserve_cus(0)`` on the models returned gives them back).  DEEPBINNER_INFLATE_QUEUES /
     DEEPBINNER_INFLATE_CUS."""
     n_queues = int(os.environ.get('DEEPBINNER_INFLATE_QUEUES', 0) or 0)
@@ -86,10 +105,7 @@ def inflate_queues(replicas, clones, host_share=50):
     n_cus = max(0, int(os.environ.get('DEEPBINNER_INFLATE_CUS', INFLATE_CUS)))
     out = []
     for pair in replicas:
-        more = clones.setdefault(tuple(id(m) for m in pair), [])
-        while len(more) < n_queues - 1:
-            more.append(tuple(m.clone() if m is not None else None for m in pair))
-        out.extend([pair] + more[:n_queues - 1])
+        out.extend([pair] + queue_clones(pair, n_queues - 1))
     # queue k of every GPU before queue k + 1 of any: consecutive containers go to different GPUs
     out = [out[d * n_queues + k] for k in range(n_queues) for d in range(len(replicas))]
     models = [m for pair in out for m in pair if m is not None]
@@ -394,6 +410,8 @@ class Session:
         # container's buffer - in memory)
         in_flight = threading.BoundedSemaphore(64 * n_writers)
         failures = []
+        clashes = []        # files that were there already (an earlier run into the same out_dir):
+                            # left as they are and counted, like the reference's moves (:111-144)
 
         def bin_read(name, read_id, signal, call, source, metadata):
             try:
@@ -401,6 +419,8 @@ class Session:
                 os.makedirs(str(target), exist_ok=True)
                 write_single_read_fast5(str(target / (name + '.fast5')), read_id, signal,
                                         metadata=metadata(source, read_id))
+            except FileExistsError as e:
+                clashes.append(str(e))
             except Exception as e:                       # surfaces when the pass ends
                 failures.append(e)
             finally:
@@ -414,9 +434,7 @@ class Session:
         if packed and host_share < 100 and all(hasattr(m, 'handle') for m in models):
             items = self._raw_containers(fast5s, host_share)
             work = self._classify_raw_container
-            if not hasattr(self, '_queue_clones'):
-                self._queue_clones = {}
-            replicas, queues = inflate_queues(replicas, self._queue_clones, host_share)
+            replicas, queues = inflate_queues(replicas, host_share)
         elif packed:
             items, work = self._packed_containers(fast5s), self._classify_container
         else:
@@ -441,7 +459,10 @@ class Session:
                     print('wrote {} reads of {} in {:.1f} ms'.format(
                         len(targets), os.path.basename(source),
                         (time.perf_counter() - t0) * 1e3), file=sys.stderr)
-                bad = [t for t, st in zip(targets, status.tolist()) if st != 0]
+                clashes.extend(t for t, st in zip(targets, status.tolist())
+                               if st == fast5_native.F5_ERR_EXISTS)
+                bad = [t for t, st in zip(targets, status.tolist())
+                       if st not in (fast5_native.F5_OK, fast5_native.F5_ERR_EXISTS)]
                 if bad:
                     failures.append(OSError('{} ({} of {} reads of {})'.format(
                         bad[0], len(bad), len(targets), source)))
@@ -463,10 +484,18 @@ class Session:
             if failures:
                 sys.exit('Error: failed to write {} one-read fast5 file{} into {} ({})'.format(
                     len(failures), '' if len(failures) == 1 else 's', self.out_dir, failures[0]))
-            if group_written:
+            n_clashes = len(clashes)
+            del clashes[:]
+            if group_written - n_clashes > 0:
                 print()
-                print('Wrote {:,} one-read fast5 files into {}'.format(group_written, self.out_dir),
-                      end='')
+                print('Wrote {:,} one-read fast5 files into {}'.format(group_written - n_clashes,
+                                                                      self.out_dir), end='')
+            if n_clashes:
+                print()
+                print('Error: could not write {:,} one-read fast5 file{} because {} already exist{} '
+                      'in {}'.format(n_clashes, '' if n_clashes == 1 else 's',
+                                     'it' if n_clashes == 1 else 'they',
+                                     's' if n_clashes == 1 else '', self.out_dir), end='')
             return group_calls, max(len(fast5s) - (group + 1) * per_pass, 0)
 
         group, calls, done, written, jobs = 0, {}, 0, 0, []
@@ -542,23 +571,38 @@ class MetadataSource:
 
     GROUPS = ('channel_id', 'tracking_id', 'context_tags')
 
+    class _Slot:
+        """One writer thread's open container (a plain object: ``close()`` runs on another
+        thread, where the thread-local itself would show nothing)."""
+        file = path = None
+
+        def __init__(self):
+            self.shared = {}
+
     def __init__(self):
         self._local = threading.local()
-        self._files = []
+        self._slots = []            # every thread's slot, for close()
         self._lock = threading.Lock()
+
+    def _slot(self):
+        slot = getattr(self._local, 'slot', None)
+        if slot is None:
+            slot = self._local.slot = self._Slot()
+            with self._lock:
+                self._slots.append(slot)
+        return slot
 
     def _container(self, path):
         from . import hdf5_lite
-        if getattr(self._local, 'path', None) != path:
-            if getattr(self._local, 'file', None) is not None:
-                self._local.file.close()
-            self._local.file, self._local.path = None, None
-            self._local.file = hdf5_lite.File(path, 'r')
-            self._local.path = path
-            self._local.shared = {}
-            with self._lock:
-                self._files.append(self._local)
-        return self._local.file
+        slot = self._slot()
+        if slot.path != path:
+            if slot.file is not None:
+                slot.file.close()
+            slot.file = slot.path = None
+            slot.file = hdf5_lite.File(path, 'r')
+            slot.path = path
+            slot.shared = {}
+        return slot.file
 
     def __call__(self, path, read_id):
         try:
@@ -570,23 +614,25 @@ class MetadataSource:
                     child = group[name]
                     # the same channel / run for every read of a container, as a rule
                     key = (name, getattr(child, 'addr', id(child)))
-                    if key not in self._local.shared:
-                        self._local.shared[key] = dict(child.attrs.items())
-                    found[name] = self._local.shared[key]
+                    shared = self._slot().shared
+                    if key not in shared:
+                        shared[key] = dict(child.attrs.items())
+                    found[name] = shared[key]
             return found
         except (OSError, KeyError, ValueError):
             return None             # the signal and the read id are what binning cannot do without
 
     def close(self):
+        """Closes every writer thread's container (call when the writers are idle)."""
         with self._lock:
-            for local in self._files:
+            for slot in self._slots:
                 try:
-                    if local.file is not None:
-                        local.file.close()
+                    if slot.file is not None:
+                        slot.file.close()
                 except Exception:
                     pass
-                local.file = local.path = None
-            self._files = []
+                slot.file = slot.path = None
+                slot.shared = {}
 
 
 def realtime(args):

@@ -37,6 +37,9 @@ extern "C" {
 #define F5_ERR_ARGUMENT 5
 #define F5_ERR_FILTER 6    /* Signal compressed with a filter other than deflate / shuffle /
                               fletcher32 (e.g. ONT's VBZ, HDF5 filter 32020) */
+#define F5_ERR_EXISTS 7    /* f5_write_single_reads: a file of that name is there already - left
+                              as it is (the reference never moves a file over another one,
+                              realtime.py:111-144: such a clash is counted and skipped) */
 
 #define F5_READ_ID_MAX 64  /* bytes per read id slot, NUL terminated (a read id is a 36-char UUID) */
 
@@ -135,8 +138,10 @@ int64_t f5_batch_n_streams(const f5_batch* batch);
  * (scalar strings, integers, floats; what a basecaller needs), in the layout of
  * deepbinner_amd/hdf5_write.py (superblock 0, symbol-table groups, one deflated chunk), byte for
  * byte.  A Signal stored as ONE deflate-compressed chunk - what MinKNOW and ont_fast5_api write -
- * is carried over as stored: nothing is inflated, nothing deflated again.  status[i] = F5_OK or
- * why read i could not be written; n_threads as everywhere.  *bytes_written (may be NULL): total
+ * is carried over as stored: nothing is inflated, nothing deflated again.  A file is written
+ * under a temporary name beside its own and linked into place: an existing file is never
+ * overwritten (status F5_ERR_EXISTS), no symlink followed, no partial file left under the final
+ * name.  status[i] = F5_OK or why read i could not be written; n_threads as everywhere.  *bytes_written (may be NULL): total
  * size of the files. */
 int f5_write_single_reads(const char* container, int64_t n, const int64_t* read_index,
                           const char* const* out_paths, int n_threads, int32_t* status,

@@ -5,6 +5,7 @@
 // without a GPU.  Not part of the product; nothing in deepbinner_amd/ calls it.
 //   cases file: u32 n; per case: u32 comp_bytes, u32 out_cap, bytes
 //   result file: per case: i32 status, i32 ended, i32 adler_ok, u32 n_tokens, u32 out_bytes, bytes
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,83 @@ int main(int argc, char** argv) {
                 } else {
                     bytes.push_back((uint8_t)t);
                 }
+            }
+        }
+        // ... and as the resolve kernel SCHEDULES it (dbh_inflate.hip: inflate_resolve_kernel):
+        // a ring of exactly 32 KiB, 64 tokens per step, all literals of a step first, then the
+        // matches in rounds (whoever reads nothing that is still to be written goes, four bytes
+        // per lockstep turn, the loads of a turn before its stores), steps with a ring hazard in
+        // token order, whole 256-byte pieces flushed after every step.  Must give the same bytes.
+        if (status == dbi::kOk) {
+            std::vector<uint8_t> ring(dbi::kWindowRing, 0), model;
+            auto at = [&](long p) -> uint8_t& { return ring[(size_t)(p & (dbi::kWindowRing - 1))]; };
+            long pos = 0, flushed = 0;
+            const int n_tok = (int)tokens.size();
+            for (int t0 = 0; t0 < n_tok; t0 += dbi::kStepTokens) {
+                const int lanes = std::min(dbi::kStepTokens, n_tok - t0);
+                long my[64];
+                int len[64], dist[64];
+                bool is_match[64];
+                long end = pos;
+                for (int l = 0; l < lanes; ++l) {
+                    const uint32_t t = tokens[t0 + l];
+                    is_match[l] = (t & dbi::kMatchFlag) != 0;
+                    len[l] = is_match[l] ? (int)(t & 0x1FF) : 1;
+                    dist[l] = (int)((t >> 9) & 0x7FFF) + 1;
+                    my[l] = end;
+                    end += len[l];
+                }
+                bool hazard = false;
+                for (int l = 0; l < lanes; ++l)
+                    hazard = hazard || (is_match[l] && dbi::ring_hazard(dist[l], (int)my[l], (int)end));
+                if (hazard) {
+                    for (int l = 0; l < lanes; ++l) {
+                        if (!is_match[l]) at(my[l]) = (uint8_t)tokens[t0 + l];
+                        else for (int k = 0; k < len[l]; ++k) at(my[l] + k) = at(my[l] - dist[l] + k);
+                    }
+                } else {
+                    for (int l = 0; l < lanes; ++l)
+                        if (!is_match[l]) at(my[l]) = (uint8_t)tokens[t0 + l];
+                    bool waiting[64];
+                    for (int l = 0; l < lanes; ++l) waiting[l] = is_match[l];
+                    for (;;) {
+                        int first_lane = -1;
+                        for (int l = 0; l < lanes && first_lane < 0; ++l)
+                            if (waiting[l]) first_lane = l;
+                        if (first_lane < 0) break;
+                        const long first = my[first_lane];
+                        bool go[64];
+                        int longest = 0;
+                        for (int l = 0; l < lanes; ++l) {
+                            const long src = my[l] - dist[l];
+                            go[l] = waiting[l] && src + std::min(len[l], dist[l]) <= first;
+                            if (go[l]) longest = std::max(longest, len[l]);
+                        }
+                        for (int k = 0; k < longest; k += 4) {
+                            uint8_t b[64][4];
+                            for (int l = 0; l < lanes; ++l)
+                                if (go[l] && k < len[l])
+                                    for (int j = 0; j < 4; ++j)
+                                        b[l][j] = at(my[l] - dist[l] + (k + j) % dist[l]);
+                            for (int l = 0; l < lanes; ++l)
+                                if (go[l] && k < len[l])
+                                    for (int j = 0; j < 4 && k + j < len[l]; ++j)
+                                        at(my[l] + k + j) = b[l][j];
+                        }
+                        for (int l = 0; l < lanes; ++l) waiting[l] = waiting[l] && !go[l];
+                    }
+                }
+                pos = end;
+                while (pos - flushed >= 256) {
+                    for (int k = 0; k < 256; ++k) model.push_back(at(flushed + k));
+                    flushed += 256;
+                }
+            }
+            for (long k = flushed; k < pos; ++k) model.push_back(at(k));
+            if (model != bytes) {
+                std::fprintf(stderr, "case %u: the resolve kernel's schedule gives other bytes than "
+                                     "the tokens in order\n", c);
+                return 4;
             }
         }
         int adler_ok = -1;

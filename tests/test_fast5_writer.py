@@ -230,6 +230,41 @@ def test_files_on_disk_and_what_goes_wrong(tmp_path):
     assert len(empty) == 0 and written == 0
 
 
+def test_nothing_is_ever_overwritten(tmp_path):
+    """A second run into the same directory (or a read id seen before) must not replace what an
+    earlier run filed there - the reference never moves a file over another one
+    (realtime.py:111-144: a clash is counted and skipped): a path that exists, as a file or as a
+    symlink (even a dangling one, which an open with O_CREAT would follow), is left alone and
+    reported as F5_ERR_EXISTS; no temporary file stays behind; both writers agree."""
+    path = MULTI[0]
+    ids, samples, offsets, _ = fast5_native.load_reads(path, threads=2)
+    out_dir = tmp_path / 'out'
+    out_dir.mkdir()
+    targets = [str(out_dir / ('r%d.fast5' % k)) for k in range(4)]
+    open(targets[1], 'wb').write(b'filed by an earlier run')
+    outside = tmp_path / 'elsewhere.fast5'
+    os.symlink(str(outside), targets[2])                     # dangling
+    done, written = fast5_native.write_single_reads(path, [0, 1, 2, 3], targets, threads=3)
+    assert done.tolist() == [0, fast5_native.F5_ERR_EXISTS, fast5_native.F5_ERR_EXISTS, 0]
+    assert open(targets[1], 'rb').read() == b'filed by an earlier run'
+    assert not outside.exists() and os.path.islink(targets[2])
+    assert written == os.path.getsize(targets[0]) + os.path.getsize(targets[3])
+    assert sorted(os.listdir(str(out_dir))) == ['r0.fast5', 'r1.fast5', 'r2.fast5', 'r3.fast5']
+    assert fast5_native.status_string(fast5_native.F5_ERR_EXISTS).startswith('a file of that name')
+    again, _ = fast5_native.write_single_reads(path, [0, 3], [targets[0], targets[3]])
+    assert again.tolist() == [fast5_native.F5_ERR_EXISTS] * 2
+    # the Python writer
+    signal = samples[offsets[4]:offsets[5]]
+    fresh = str(out_dir / 'py.fast5')
+    hdf5_write.write_single_read_fast5(fresh, ids[4], signal)
+    before = open(fresh, 'rb').read()
+    for taken in (fresh, targets[1], targets[2]):
+        with pytest.raises(FileExistsError):
+            hdf5_write.write_single_read_fast5(taken, ids[5], samples[offsets[5]:offsets[6]])
+    assert open(fresh, 'rb').read() == before and not outside.exists()
+    assert len(os.listdir(str(out_dir))) == 5
+
+
 def test_damaged_containers_never_crash_the_writer(tmp_path):
     """300 seeded mutations of a real container (byte flips, zeroed runs, truncations): every read
     is either written - and then both readers read the file back - or refused with a status;
@@ -253,6 +288,9 @@ def test_damaged_containers_never_crash_the_writer(tmp_path):
         with open(victim, 'wb') as f:
             f.write(bytes(data))
         targets = [str(tmp_path / ('out_%d.fast5' % i)) for i in range(10)]
+        for target in targets:          # (the writer never writes over a file)
+            if os.path.exists(target):
+                os.unlink(target)
         try:
             status, _ = fast5_native.write_single_reads(victim, list(range(10)), targets, threads=2)
         except OSError:

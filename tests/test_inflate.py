@@ -67,6 +67,14 @@ def valid_cases():
                 bytes(rng.integers(0, 4, 50000, dtype=np.uint8)),              # tiny alphabet
                 b'\x00' * 100000,                                              # RLE, distance 1
                 real[2][:20000] + bytes(33000) + real[2][:20000]]              # distance ~ 32 K
+    # long matches at distances near the window size: a step of the resolve kernel (64 tokens, up
+    # to 16.5 KB) then wraps around its 32 KiB ring onto bytes its own first matches still read
+    # (dbh_inflate_core.h: ring_hazard) - 258-byte matches back to back, and far matches followed
+    # by literals inside one step
+    far = rng.integers(0, 256, 32000, dtype=np.uint8).tobytes()
+    payloads += [far + far, far + far[:774] + b'Q' + far[1000:1600] + b'literal' + far[5000:9000],
+                 far[:32768 - 3] + far[:20000] + far[100:400],
+                 far[:17000] + far[:17000] + far[:17000]]
     for data in payloads:
         for level in (0, 1, 6, 9):
             cases.append((zlib.compress(data, level), len(data), data))
