@@ -74,7 +74,7 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
         p = bias + cout;
         float* dst = packed.data() + weight_offset(i);
         if (i == 0) {
-            // conv1d_1 stays [tap][cout] for the VALU path
+            // conv1d_1 stays [tap][cout]: one value per lane and channel group, read once per workgroup
             for (int tap = 0; tap < 3; ++tap)
                 for (int c = 0; c < cout; ++c) dst[tap * 48 + c] = kernel[(tap * cin) * cout + c];
         } else if (kConv[i].wino) {
@@ -95,7 +95,9 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                     for (int t = 0; t < nt; ++t)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 2; ++e) {
-                                const int ci = 8 * sp + 2 * (lane >> 4) + e;
+                                // (conv1d_2's k-steps walk the channels in the order conv1d_1's
+                                // transposed MFMAs leave them in registers: dbh_layout.h)
+                                const int ci = frag_cin(i, sp, lane >> 4, e);
                                 const int co = 16 * t + (lane & 15);
                                 double v = 0.0;
                                 if (co < cout)
@@ -120,7 +122,7 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                     for (int t = 0; t < nt; ++t)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 2; ++e) {
-                                const int ci = 8 * sp + 2 * (lane >> 4) + e;
+                                const int ci = frag_cin(i, sp, lane >> 4, e);
                                 const int co = 16 * t + (lane & 15);
                                 const float v = co < cout ? kernel[((size_t)tap * cin + ci) * cout + co] : 0.f;
                                 dst[((((size_t)tap * sp_n + sp) * nt + t) * 64 + lane) * 2 + e] = v;

@@ -136,6 +136,9 @@ struct NoSide {
 struct NoBegin {
     __device__ __forceinline__ void operator()() const {}
 };
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
 // Marks side work made of plain global loads to registers: a Winograd step issues those BETWEEN
 // its MFMAs, one after every second MFMA, because a bunch of vector-memory instructions holds
 // the wave (and its in-order MFMAs) ~35 cycles each, a lone one ~9 (tools/microbench/
@@ -1077,14 +1080,221 @@ __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// STAGE A INSIDE conv1d_2's TILE 0.  conv1d_1 (k = 3, stride 2, one input channel) + ReLU + BN1
+// used to be a stage of its own: twelve MFMAs per wave, then 98 KB of outputs through the LDS store
+// path (~85 B/clk), a barrier, and tile 0 of conv1d_2 reading them back - 4.7k cycles per window
+// for 0.8k cycles of matrix work (profiles/r03_v1/timeline_5120_fused.txt).  Here the wave that
+// owns quads j = 16 wave + pm(n) computes the six conv1d_1 rows each of its quads needs
+// (positions 4j - 1 .. 4j + 4) itself, TRANSPOSED: M = 16 output channels, N = 16 quads,
+// K = 3 taps (+ a zero), one MFMA per (row t, channel group g):
+//     A[m][k] = w[k][16g + m]        (lane (m, k): one register per channel group, per workgroup)
+//     B[k][n] = x[8 j(n) - 2 + 2t + k]     (lane (n, k): six samples per window)
+//     D: lane (n, q) gets channels 16g + 4q + r of row t of ITS OWN quad in registers r = 0..3
+// - which is where conv1d_2's input transform wants them: ReLU (clamp), BN1 and the F(4,3)
+// transform run on registers, and the result is conv1d_2's A fragment as it stands, because the
+// packer stores conv1d_2's matrices with k-step 4g + r <-> channels {16g + 4q + r} (dbh_layout.h:
+// frag_cin).  18 MFMAs per wave instead of 12 (every quad's two halo rows are computed twice), no
+// LDS traffic at all, one barrier less.  The rows that are conv1d_2's zero padding (position -1 of
+// quad 0, position 512 of quad 127) are set to zero, not to BN1(ReLU(bias)).
+// ---------------------------------------------------------------------------------------------
+struct ConvAIn {
+    float xs[6];          // x[8j - 2 + 2t + q], t = 0..5: normalised, times kActScale; 0 outside
+    float w[3];           // w[q][16g + n] of conv1d_1 (0 for q = 3)
+    // conv1d_2's 'same' padding: row -1 of quad 0 and row 512 of quad 127 are zeros, not
+    // BN1(ReLU(bias)).  Row 0 of a quad enters the input transform in U0 = 4 d0 - 5 d2 + d4 alone,
+    // row 5 in U5 = 4 d1 - 5 d3 + d5 alone: the first quad's lanes multiply d0 by 0 instead of 4
+    // (the constant of an fma that is there anyway), the last quad's d5 by 0 instead of 1.
+    f2 p4_edge;           // {4, 4}; {0, 0} in the lanes of quad 0
+    f2 one_edge;          // {1, 1}; {0, 0} in the lanes of quad 127
+    float* dump;          // debug_stage 0: where this lane's 4 x 12 outputs go
+    bool dump_on;         // (wave-uniform)
+    bool stop;            // debug_stage 0 / 100: the kernel ends behind tile 0
+};
+
+// ReLU and BN1 of the six rows of one channel pair: x * 1 with the clamp modifier (activations are
+// held times 2^-60: dbh_layout.h), then x * scale + shift - twelve packed instructions in one
+// block.  The inputs are results of MFMAs, and hipcc does not pad the distance between an MFMA
+// and an inline-asm reader of its result (see pk_fma_relu): the callers keep at least twelve
+// MFMAs between a conv1d_1 product and this block.
+__device__ __forceinline__ void relu_bn_rows(f2 (&d)[6], const f2 (&v)[6], f2 sc, f2 sh) {
+    asm volatile(
+        "v_pk_mul_f32 %0, %6, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_mul_f32 %1, %7, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_mul_f32 %2, %8, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_mul_f32 %3, %9, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_mul_f32 %4, %10, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_mul_f32 %5, %11, 1.0 op_sel_hi:[1,0] clamp\n\t"
+        "v_pk_fma_f32 %0, %0, %12, %13\n\t"
+        "v_pk_fma_f32 %1, %1, %12, %13\n\t"
+        "v_pk_fma_f32 %2, %2, %12, %13\n\t"
+        "v_pk_fma_f32 %3, %3, %12, %13\n\t"
+        "v_pk_fma_f32 %4, %4, %12, %13\n\t"
+        "v_pk_fma_f32 %5, %5, %12, %13"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(sc), "v"(sh));
+}
+
+// bias of conv1d_1 for this lane's four channels of group G, BN1 scale / shift pairs of step SP:
+// byte offsets from this lane's place in the LDS parameter table (kParams + 4q)
+constexpr int kTabBn1ScaleBytes = ((kTabBias1 - kTabBias0) + (bn_scale_offset(0) - kTabBn0)) * 4;
+constexpr int kTabBn1ShiftBytes = ((kTabBias1 - kTabBias0) + (bn_shift_offset(0) - kTabBn0)) * 4;
+static_assert(bias_offset(0) == kTabBias0, "conv1d_1's bias opens the parameter table");
+
+template <int SP>
+__device__ __forceinline__ void w43a_load_params(f2 (&par)[2], unsigned p_addr) {
+    constexpr int ch = 16 * (SP >> 1) + 2 * (SP & 1);
+    par[0] = ds_read_f2<kTabBn1ScaleBytes + ch * 4>(p_addr);
+    par[1] = ds_read_f2<kTabBn1ShiftBytes + ch * 4>(p_addr);
+}
+
+// the six conv1d_1 products of channel group G (their accumulators start at the bias)
+template <int G>
+__device__ __forceinline__ void conv_a_group(const ConvAIn& in, f4 bias4, f4 (&a1)[6]) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) a1[t] = mfma4(in.w[G], in.xs[t], bias4);
+}
+
+// Step SP of tile 0: channel pair H = SP & 1 of group G = SP >> 1 - six rows of conv1d_1 outputs
+// become U[.][SP] (24 packed + 4 plain vector instructions in one block), then the step's twelve
+// conv1d_2 MFMAs.  Group 2's conv1d_1 MFMAs ride in front of step 2's.
+template <int SP, class Side>
+__device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3][6], f4 bias4_g2,
+                                          unsigned p_addr, unsigned b_addr, f2 (&pbuf)[2][2],
+                                          f4 (&buf)[2][3], f4 (&acc)[6], float bias,
+                                          const Side& side) {
+    constexpr int G = SP >> 1, H = SP & 1;
+    if constexpr (SP + 1 < 6) {
+        w43a_load_params<SP + 1>(pbuf[(SP + 1) & 1], p_addr);
+        w43_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
+        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[3] = buf[SP & 1];
+    f2(&par)[2] = pbuf[SP & 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    asm volatile("" : "+v"(par[0]), "+v"(par[1]));
+    progress_priority<SP, 6>();
+    __builtin_amdgcn_sched_barrier(0);
+    f2 d[6], v[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+        v[t] = H ? f2{a1[G][t].z, a1[G][t].w} : f2{a1[G][t].x, a1[G][t].y};
+    relu_bn_rows(d, v, par[0], par[1]);
+    if (in.dump_on) {                     // debug_stage 0: the quad's own four rows
+#pragma unroll
+        for (int t = 1; t < 5; ++t) {
+            in.dump[(t - 1) * 48 + 16 * G + 2 * H] = d[t].x * kActUnscale;
+            in.dump[(t - 1) * 48 + 16 * G + 2 * H + 1] = d[t].y * kActUnscale;
+        }
+    }
+    {   // the F(4,3) input transform (w43_transform) with the two padding rows masked
+        const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
+        const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
+        const f2 d5 = d[5] * in.one_edge;
+        const f2 a = __builtin_elementwise_fma(m4, d[2], d[4]), b2 = __builtin_elementwise_fma(m4, d[1], d[3]);
+        const f2 c = d[4] - d[2], g = d[3] - d[1];
+        U.u[0][SP] = __builtin_elementwise_fma(in.p4_edge, d[0], __builtin_elementwise_fma(m5, d[2], d[4]));
+        U.u[1][SP] = a + b2;
+        U.u[2][SP] = a - b2;
+        U.u[3][SP] = __builtin_elementwise_fma(p2, g, c);
+        U.u[4][SP] = __builtin_elementwise_fma(m2, g, c);
+        U.u[5][SP] = __builtin_elementwise_fma(p4, d[1], __builtin_elementwise_fma(m5, d[3], d5));
+#pragma unroll
+        for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(U.u[x][SP]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP == 2) {
+        conv_a_group<2>(in, bias4_g2, a1[2]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) asm volatile("" : "+v"(a1[2][t]));
+    }
+    if constexpr (SP == 0) {
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], zero);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2],
+                                   p == 0 ? f4{bias, bias, bias, bias} : zero);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
+            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
+        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    __builtin_amdgcn_sched_barrier(0);
+    side(IntC<SP>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP + 1 < 6)
+        w43a_step<SP + 1>(U, in, a1, bias4_g2, p_addr, b_addr, pbuf, buf, acc, bias, side);
+}
+
+// Tile 0 of conv1d_2 with conv1d_1 inside.  between(i): the caller's i-th request of the twelve it
+// may place between the first conv1d_1 MFMAs (LDS-DMA pieces for slots 1 and 2: a request costs
+// ~100 cycles of issue, a bunch of them in front of the MFMAs keeps the matrix pipe idle).
+template <class Between>
+__device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* lds, int lane,
+                                           f4 (&acc)[6], float bias, const Between& between) {
+    const int q = lane >> 4;
+    const f4* bias4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);   // + 4 g: group g
+    const f4 b0 = bias4[0], b1 = bias4[4], b2 = bias4[8];
+    f4 a1[3][6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        a1[0][t] = mfma4(in.w[0], in.xs[t], b0);
+        between(t);
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        a1[1][t] = mfma4(in.w[1], in.xs[t], b1);
+        between(6 + t);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) asm volatile("" : "+v"(a1[g][t]));
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned p_addr = lds_addr(lds + kParams + 4 * q);
+    const unsigned b_addr = lds_addr(lds + kSlot0 + lane * 4);
+    f2 pbuf[2][2];
+    f4 buf[2][3];
+    w43a_load_params<0>(pbuf[0], p_addr);
+    w43_load_b<0>(buf[0], b_addr);
+    w43a_step<0>(U, in, a1, b2, p_addr, b_addr, pbuf, buf, acc, bias, NoSide());
+}
+
 // One F(4,3) layer.  On entry the layer's input is complete in LDS (a barrier has passed since
 // the last store) and the layer's three weight thirds are in slots 0..2 or on their way (they land
 // before the barrier below releases).  next_third(t, dst): request third t of the NEXT layer's
 // weights (or whatever takes slot t's place) - called once every wave has left tile t.
-template <int CONV, bool POOL, int BNI, bool END_BARRIER, class NextThird>
+// in_a != null (conv1d_2 only): the layer has no input image - tile 0 computes conv1d_1 itself
+// (w43a_tile0) with between_a(i) placed between its first MFMAs; after_mid(): the caller's work
+// right behind the mid-layer barrier.
+struct NoBetween {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int CONV, bool POOL, int BNI, bool END_BARRIER, class NextThird, class BetweenA = NoBetween,
+          class AfterMid = NoHook, class BeforeMid = NoHook>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
                                           int lane, int wave, long long* ts, int ts_base,
-                                          unsigned& sync_rounds, const NextThird& next_third) {
+                                          unsigned& sync_rounds, const NextThird& next_third,
+                                          const ConvAIn* in_a = nullptr,
+                                          const BetweenA& between_a = BetweenA(),
+                                          const AfterMid& after_mid = AfterMid(),
+                                          const BeforeMid& before_mid = BeforeMid()) {
+    constexpr bool FUSED_A = !std::is_same<BetweenA, NoBetween>::value;
+    static_assert(!FUSED_A || CONV == 1, "only conv1d_2 follows conv1d_1");
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     constexpr int L = 512;
     static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
@@ -1102,11 +1312,23 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     W43U U;
     f4 acc[2][6];
     // tile 0: reads the wave's input rows step by step and builds U on the way
-    w43_tile<true, 0, 6>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
+    if constexpr (FUSED_A)
+        w43a_tile0(U, *in_a, lds, lane, acc[0], ep.b[0], between_a);
+    else
+        w43_tile<true, 0, 6>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
     mark(ts, ts_base);
+    if constexpr (FUSED_A) {
+        if (in_a->stop) return;     // debug_stage 0 / 100: stage A only
+    }
+    before_mid();
     full_barrier();        // every wave has read all its input rows (and has left tile 0): from
     mark(ts, ts_base + 1);   // here on the outputs may be stored in place
+    after_mid();
     if (POOL) zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);   // (row 0 is zero already)
+    if constexpr (FUSED_A) {      // nobody stored an input image: the zero rows around the output
+        zero_row(lds + kActOff, 0, kS48, 48, tid);
+        zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
+    }
     next_third(0, lds + kSlot0);
     // tile 1, with tile 0's epilogue inside its steps 1 and 3
     w43_tile<false, 0, 12>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
@@ -1506,18 +1728,18 @@ struct SmallMRegs {
 
 // TO_GLOBAL: out_region is a dense [16][48] block in global memory (row 0 = position 0) instead
 // of an LDS activation buffer, and the layer ends without a barrier of its own.
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
 // pre_barrier / post_barrier: work of the caller's that rides on the layer's one barrier (every
 // wave calls pre_barrier before it, post_barrier after it).
+// between(tap): a request of the caller's behind the MFMAs of tap `tap` (LDS-DMA pieces: one at a
+// time between MFMAs instead of a bunch in front of them).
 template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false,
-          class PreBarrier = NoHook, class PostBarrier = NoHook>
+          class PreBarrier = NoHook, class PostBarrier = NoHook, class Between = NoBetween>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
                                               const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
                                               int wave, long long* ts, int ts_base,
                                               const PreBarrier& pre_barrier = PreBarrier(),
-                                              const PostBarrier& post_barrier = PostBarrier()) {
+                                              const PostBarrier& post_barrier = PostBarrier(),
+                                              const Between& between = Between()) {
     using R = SmallMRegs<CONV, KS, NTW, BN>;
     constexpr int TAPS = R::TAPS, SP = R::SP;
     const int n = lane & 15, q = lane >> 4;
@@ -1547,6 +1769,7 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
                     acc[0][t] = mfma4(a[sp].x, bw.x, acc[0][t]);
                     odd[t] = mfma4(a[sp].y, bw.y, odd[t]);
                 }
+            between(tap);
         }
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[0][t] += odd[t];
@@ -1594,22 +1817,71 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
 }
 
 // One wave's share of the 1x1 convolutions of the inception block (4 position tiles x 1 N tile).
+// ep: bias (and BN5 scale / shift) of this lane's channel, loaded by the caller ahead of the call
 template <int NTTOT, int S_OUT, bool POOLBN>
 __device__ __forceinline__ void inception_1x1(const float* in_region, const float* w_lds,
                                               float* out_region, int out_ch,
-                                              const float* __restrict__ bias_lane,
-                                              const float* __restrict__ scale_lane,
-                                              const float* __restrict__ shift_lane, int t,
-                                              int lane) {
+                                              const EpiParams<1, POOLBN>& ep, int t, int lane) {
     const int n = lane & 15, q = lane >> 4;
-    EpiParams<1, POOLBN> ep;
-    ep.load(bias_lane, scale_lane, shift_lane);
     f4 acc[4][1];
     bias_acc(acc, ep);
     conv_tiles<1, 6, 6, 4, 1, NTTOT, kS48, 16>(in_region + (n + 1) * kS48 + 2 * q,
                                                w_lds + t * 128 + lane * 2, acc);
     float* out_lane = out_region + (1 + (POOLBN ? 2 * q : 4 * q)) * S_OUT + out_ch + n;
     epilogue<4, 1, S_OUT, POOLBN, POOLBN, false>(acc, out_lane, ep);
+}
+
+// conv10 reads AveragePooling1D(3, stride 1, 'same') of X.  A 1x1 convolution commutes with a
+// pooling along the positions: W . (x[p-1] + x[p] + x[p+1]) / c[p] = (z[p-1] + z[p] + z[p+1]) / c[p]
+// with z = W . x (no bias, z = 0 outside the window; c[p] = the number of taps inside it:
+// TensorFlow's valid-count divisor, oracle/network_ref.py).  So the convolution runs on X itself
+// and the pooling on its OUTPUT, in registers: the wave holds all 64 positions of its 16 channels
+// (lane (n, q), tile m, register r <-> position 16 m + 4 q + r), the neighbours across the lane
+// groups come by ds_bpermute.  No average-pooled copy of X in LDS, no phase of its own (it cost
+// ~1.7k cycles per window with its barrier: profiles/r03_v1/timeline_5120_fused.txt, "E0").
+// Then bias, ReLU, MaxPool2, BN5 as everywhere.
+template <int NTTOT, int S_OUT>
+__device__ __forceinline__ void inception_1x1_of_avgpool(const float* in_region, const float* w_lds,
+                                                         float* out_region, int out_ch,
+                                                         const EpiParams<1, true>& ep, int t,
+                                                         int lane) {
+    const int n = lane & 15, q = lane >> 4;
+    f4 z[4][1];
+    zero_acc(z);
+    conv_tiles<1, 6, 6, 4, 1, NTTOT, kS48, 16>(in_region + (n + 1) * kS48 + 2 * q,
+                                               w_lds + t * 128 + lane * 2, z);
+    // position 4q - 1 lives in register 3 of the lane group before (the tile before, for q = 0),
+    // position 4q + 4 in register 0 of the lane group behind
+    const int from_before = ((lane + 48) & 63) * 4, from_behind = ((lane + 16) & 63) * 4;
+    float before[4], behind[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        // (pinned copies: handed z[m][0].w directly, this hipcc sends register x both times)
+        float last = z[m][0].w, first = z[m][0].x;
+        asm volatile("" : "+v"(last), "+v"(first));
+        before[m] = __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_bpermute(from_before, __builtin_bit_cast(int, last)));
+        behind[m] = __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_bpermute(from_behind, __builtin_bit_cast(int, first)));
+    }
+    const float third = 1.f / 3.f, b = ep.b[0], sc = ep.sc[0], sh = ep.sh[0];
+    float* out_lane = out_region + (1 + 2 * q) * S_OUT + out_ch + n;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float prev = q > 0 ? before[m] : (m > 0 ? before[m > 0 ? m - 1 : 0] : 0.f);
+        const float next = q < 3 ? behind[m] : (m < 3 ? behind[m < 3 ? m + 1 : 3] : 0.f);
+        const f4 v = z[m][0];
+        const float t1 = v.x + v.y, t2 = v.z + v.w;
+        // x (1 / count), not / count: one ulp of the quotient is far inside the tolerance
+        const float inv0 = (m == 0 && q == 0) ? 0.5f : third;
+        const float inv3 = (m == 3 && q == 3) ? 0.5f : third;
+        const float y0 = fmaxf(fmaf(prev + t1, inv0, b), 0.f);
+        const float y1 = fmaxf(fmaf(t1 + v.z, third, b), 0.f);
+        const float y2 = fmaxf(fmaf(v.y + t2, third, b), 0.f);
+        const float y3 = fmaxf(fmaf(t2 + next, inv3, b), 0.f);
+        out_lane[(m * 8 + 0) * S_OUT] = fmaf(fmaxf(y0, y1), sc, sh);
+        out_lane[(m * 8 + 1) * S_OUT] = fmaf(fmaxf(y2, y3), sc, sh);
+    }
 }
 
 // The 16 -> 48, k = 3 convolutions of the inception block (conv13, conv15; L = 64) as Winograd
@@ -1874,32 +2146,33 @@ __device__ __forceinline__ void window_mean_inv(const float* lds, int cnt, doubl
 }
 
 // Seam-b2 input of one window, straight from the read's int16 samples: this lane's two samples
-// for the window statistics (positions tid and tid + 512 of the slice) and its four A-fragment
-// samples for conv1d_1 (position 2*(16*(m0+m)+n) + q of the zero-padded window; q = tap).
+// for the window statistics (positions tid and tid + 512 of the slice) and the six samples its
+// conv1d_1 products take as their B operand (positions 8j - 2 + 2t + q of the zero-padded window,
+// t = 0..5: row t of quad j, tap q).  A position outside the slice (the padding on either side,
+// the fourth "tap") is kOutside - no sample is: they are 16-bit.
+constexpr int kOutside = 0x40000000;
 __device__ __forceinline__ void fetch_window_at(const int16_t* __restrict__ src, int cnt,
-                                                int pad_left, int tid, int m0, int n, int q,
-                                                int& v0, int& v1, int (&raw)[4],
-                                                bool (&inside)[4]) {
+                                                int pad_left, int tid, int j, int q, int& v0,
+                                                int& v1, int (&raw)[6]) {
     // src = first sample of the window's slice (wave-uniform), cnt of them; every index below is
     // a 32-bit lane offset from it
     v0 = tid < cnt ? (int)src[(unsigned)tid] : 0;
     v1 = tid + 512 < cnt ? (int)src[(unsigned)(tid + 512)] : 0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int k = 2 * ((m0 + m) * 16 + n) + q - pad_left;
-        inside[m] = q < 3 && k >= 0 && k < cnt;
-        raw[m] = inside[m] ? (int)src[(unsigned)(inside[m] ? k : 0)] : 0;
+    for (int t = 0; t < 6; ++t) {
+        const int k = 8 * j - 2 + 2 * t + q - pad_left;
+        const bool inside = q < 3 && k >= 0 && k < cnt;
+        raw[t] = inside ? (int)src[(unsigned)(inside ? k : 0)] : kOutside;
     }
 }
 __device__ __forceinline__ void fetch_window(const int16_t* __restrict__ samples, long long base,
-                                             long long len, int step, int side, int tid, int m0,
-                                             int n, int q, int& cnt, int& v0, int& v1,
-                                             int (&raw)[4], bool (&inside)[4]) {
+                                             long long len, int step, int side, int tid, int j,
+                                             int q, int& cnt, int& v0, int& v1, int (&raw)[6]) {
     long long wa, wb;
     window_bounds(len, step, side, &wa, &wb);
     cnt = (int)(wb - wa);
-    fetch_window_at(samples + base + wa, cnt, (side == 0) ? 0 : kWindow - cnt, tid, m0, n, q, v0,
-                    v1, raw, inside);
+    fetch_window_at(samples + base + wa, cnt, (side == 0) ? 0 : kWindow - cnt, tid, j, q, v0, v1,
+                    raw);
 }
 
 // =============================================================================================
@@ -1948,30 +2221,27 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     if (tid_entry < 2) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
     if (tid_entry < 8) reinterpret_cast<unsigned*>(lds + kPairSync)[tid_entry] = 0u;
-    // conv1d_1's three taps (B operand: k = lane >> 4 picks the tap) and its bias / BN1
-    EpiParams<3, true> ep_a;
+    // conv1d_1's weights as the A operand of its transposed MFMAs: lane (m, k) holds w[k][16g + m]
+    // for the three channel groups g (tap k = lane >> 4; the fourth k is a zero column).  Its bias
+    // and BN1 come from the LDS table.
     float bw_a[3];
     {
         const int n_e = tid_entry & 15, q_e = (tid_entry & 63) >> 4;
-        ep_a.load(packed_entry + bias_offset(0) + n_e, packed_entry + bn_scale_offset(0) + n_e,
-                  packed_entry + bn_shift_offset(0) + n_e);
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            bw_a[t] = (q_e < 3) ? packed_entry[weight_offset(0) + q_e * 48 + t * 16 + n_e] : 0.f;
+        for (int g = 0; g < 3; ++g)
+            bw_a[g] = (q_e < 3) ? packed_entry[weight_offset(0) + q_e * 48 + g * 16 + n_e] : 0.f;
     }
     unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
     unsigned pair_rounds = 0;     // exchanges the wave pairs of conv7 have made so far
 
-    // Seam-b2 input of the window in hand: this lane's two samples for the statistics, its
-    // A-fragment samples for conv1d_1 and which of those lie inside the window.  Filled by
-    // fetch(): for a workgroup's first window at the top of stage A, for every later one at the
-    // top of stage E of the window before it (see there), so that only the first fetch of a
-    // launch is exposed.
-    constexpr int kMtA = 512 / 16 / kWaves;
-    int in_cnt = 0, in_v0 = 0, in_v1 = 0, in_raw[kMtA] = {};
-    bool in_inside[kMtA] = {};
+    // Seam-b2 input of the window in hand: this lane's two samples for the statistics and the six
+    // samples its conv1d_1 products take (kOutside = not in the window).  Filled by fetch(): for a
+    // workgroup's first window at the top of stage A, for every later one at the top of stage E of
+    // the window before it (see there), so that only the first fetch of a launch is exposed.
+    int in_cnt = 0, in_v0 = 0, in_v1 = 0, in_raw[6] = {};
     bool prefetched = false;
+    bool thirds_ahead = false;    // slots 1 and 2 of conv2's weights requested under the window before
 
     // PERSISTENT GRID: the launch has at most one workgroup per CU (what 160 KiB of LDS allows
     // anyway) and workgroup b walks windows b, b + gridDim.x, ... - no launch per batch, no cold
@@ -2006,37 +2276,42 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     int taken = 0;
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
-    // Also on the matrix pipe: K = 3 taps padded to 4, A[i][k] = x[2*(16m+i) + k] gathered
-    // straight from global (k = lane>>4 picks the tap), B[k][n] = w[k][n].  One MFMA per
-    // (position tile, N tile); the standard epilogue applies bias, ReLU and BN1.
+    // ... has no phase of its own: the wave that owns a tile of conv1d_2's quads computes the
+    // conv1d_1 rows they need inside conv1d_2's tile 0, in registers (w43a_tile0).  What is left
+    // here: this lane's six samples of the window, normalised.
+    //   Steady state (seam b2, second window of a workgroup onwards): the samples were fetched and
+    // their statistics taken under the window before (stages E, F), and the first third of
+    // conv1d_2's weights has been on its way to slot 0 since that window's stage F - ONE barrier
+    // publishes all of it and keeps this window's stores off the LDS that window still reads; the
+    // other two thirds are requested between conv1d_1's MFMAs and land before the mid-layer barrier.
+    //   Cold (a workgroup's first window; every window of seam b1): everything is asked for here,
+    // behind the barrier of the window statistics, and a second barrier waits for the weights.
+    ConvAIn in_a;
+    bool cold;
     {
-        // conv2's transformed weights: (V1,V2) -> slot 0, (V3,V4) -> slot 1; (V0,V5) follow
-        // during conv2's own first phase
+        // quad of this lane's MFMA column: j = 16 wave + pm(n) (the order of w43_epilogue_half)
+        const int j = wave * 16 + 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
         auto fetch_conv2_weights = [&] {      // all three thirds (slots 0..2 are adjacent)
             dma_weights<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         };
-        // seam b1: at once.  Seam b2: only after the barrier of the window statistics - a barrier
-        // retires every outstanding request of the wave, and waiting there for 36 KB of weights
-        // (~3.5k cycles at the cold start of a launch) would hold up the normalisation for
-        // nothing; issued behind it, they arrive under the normalisation, conv1 and its epilogue.
         const int16_t* __restrict__ samples = glob(args()->samples);
-        if (samples == nullptr) fetch_conv2_weights();
-        constexpr int MT = 512 / 16 / kWaves;
-        const int m0 = wave * MT;
-        float a[MT];
-#if DBH_EXP_A_DMA_UNDER_MFMA
-        bool prefetched_now = false;
-#endif
-        const EpiParams<3, true>& ep = ep_a;      // conv1's weights and epilogue parameters:
-        const float(&bw)[3] = bw_a;               // fetched once per workgroup, before the loop
+        cold = samples == nullptr || !prefetched;
+        // (the registers the samples were prefetched into, looked at once on every path: this is
+        // where hipcc's wait-count pass learns that those loads have landed.  Without it they
+        // are "pending" around the loop, and the first load of the NEXT prefetch - at the top of
+        // stage E, right behind an LDS-DMA request - waits for everything outstanding: one L2
+        // round trip per window.  Here the wait is free: the barriers below wait anyway.)
+        asm volatile("" : "+v"(in_v0), "+v"(in_v1), "+v"(in_raw[0]), "+v"(in_raw[1]),
+                          "+v"(in_raw[2]), "+v"(in_raw[3]), "+v"(in_raw[4]), "+v"(in_raw[5]));
         if (samples == nullptr) {
             // a later window of this workgroup: the window before it may still be read (stage H)
-            if (!first_window) full_barrier();  
+            if (!first_window) full_barrier();
+            fetch_conv2_weights();
             const float* xw = glob(args()->x) + win * kWindow;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int idx = 2 * ((m0 + m) * 16 + n) + q;          // q = tap (3 = zero column)
-                a[m] = (q < 3 && idx < kWindow) ? xw[idx] * kActScale : 0.f;   // idx == 1024: right padding
+            for (int t = 0; t < 6; ++t) {
+                const int idx = 8 * j - 2 + 2 * t + q;            // q = tap (3 = zero column)
+                in_a.xs[t] = (q < 3 && idx >= 0 && idx < kWindow) ? xw[idx] * kActScale : 0.f;
             }
         } else {
             // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
@@ -2055,103 +2330,48 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 const long long guess = (read0 + read) * len_hint;
                 const bool speculate = len_hint > 0 && guess + len_hint <= hint_cap;
                 if (speculate)
-                    fetch_window(samples, guess, len_hint, step, side, tid, m0, n, q, in_cnt,
-                                 in_v0, in_v1, in_raw, in_inside);
+                    fetch_window(samples, guess, len_hint, step, side, tid, j, q, in_cnt, in_v0,
+                                 in_v1, in_raw);
                 const long long base = offsets[read];
                 const long long len = offsets[read + 1] - base;
                 if (!speculate || base != guess || len != len_hint)
-                    fetch_window(samples, base, len, step, side, tid, m0, n, q, in_cnt, in_v0,
-                                 in_v1, in_raw, in_inside);
+                    fetch_window(samples, base, len, step, side, tid, j, q, in_cnt, in_v0, in_v1,
+                                 in_raw);
             }
             double mean, inv;
-#if DBH_EXP_A_DMA_UNDER_MFMA
-            prefetched_now = prefetched;
-#endif
             if (!prefetched) {
                 window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
-                full_barrier();  
+                full_barrier();
                 fetch_conv2_weights();
                 window_mean_inv(lds, in_cnt, &mean, &inv);
             } else {
                 // the sums were taken and turned into mean and 1/std while the window before ran
-                // its conv17 (stage F below); this barrier publishes them - and keeps this
-                // window's activations off the LDS that window's last reads still use
-                full_barrier();  
+                // its conv17 (stage F below); this barrier publishes them, retires slot 0's
+                // weights - and keeps this window off the LDS that window's last reads still use
+                full_barrier();
                 mark(ts, 51);
-#if !DBH_EXP_A_DMA_UNDER_MFMA
-                fetch_conv2_weights();
-#endif
-                mark(ts, 52);
                 const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
                 mean = stats[0];
                 inv = stats[1];
             }
             inv *= (double)kActScale;      // (exact; see kActScale)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                a[m] = in_inside[m] ? (float)(((double)in_raw[m] - mean) * inv) : 0.f;
+            for (int t = 0; t < 6; ++t)
+                in_a.xs[t] = in_raw[t] != kOutside ? (float)(((double)in_raw[t] - mean) * inv) : 0.f;
             mark(ts, 54);
         }
         // (the next window's number: asked for behind the barriers above - they wait for every
-        // outstanding request - and needed behind the one below, a conv1 and its epilogue later)
+        // outstanding request - and needed behind conv1d_2's mid-layer barrier)
         if (win_counter != nullptr && tid == 0) taken = atomicAdd(win_counter, 1);
-        f4 acc[MT][3];
-#if DBH_EXP_A_DMA_UNDER_MFMA
-        // conv2's weights are requested BETWEEN conv1's MFMAs (a request costs ~100 cycles of
-        // issue, the matrix pipe 32 per MFMA: seven requests ahead of the MFMAs kept it idle for
-        // ~700 cycles per window) - in the steady state, where nothing else waits for them
-        const bool spread = samples != nullptr && prefetched_now;
+        if (cold) full_barrier();     // conv1d_2's weights have landed
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
-                if (spread && m * 3 + t < (3 * kWinoHalf / 256 + kWaves - 1) / kWaves)
-                    dma_weights_one<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane,
-                                                   wave, m * 3 + t);
-            }
-#else
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                acc[m][t] = mfma4(a[m], bw[t], f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]});   // + bias
-#endif
-        mark(ts, 59);
-        float* out_lane = lds + kActOff + (1 + m0 * 16 + 4 * q) * kS48 + n;
-        epilogue<MT, 3, kS48, false, true, false>(acc, out_lane, ep);
-        mark(ts, 60);
-        zero_row(lds + kActOff, 0, kS48, 48, tid);
-        zero_row(lds + kActOff, 513, kS48, 48, tid);
-        if (win_counter != nullptr && tid == 0) {
-            reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
-            // n_windows numbers are taken per launch, whatever the grid: this was the last
-            if ((long long)taken == n_windows - 1) *win_counter = 0;
-        }
-        full_barrier();  
+        for (int g = 0; g < 3; ++g) in_a.w[g] = bw_a[g];
+        in_a.p4_edge = j == 0 ? f2{0.f, 0.f} : f2{4.f, 4.f};
+        in_a.one_edge = j == 127 ? f2{0.f, 0.f} : f2{1.f, 1.f};
+        in_a.dump_on = debug_stage == 0;
+        in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
+        in_a.stop = stop_stage == 0;
         mark(ts, 1);
-    }
-    if (stop_stage == 0) {
-        if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 512, 48,
-                       glob(args()->debug_out) + win * kStageFloats[0], tid);
-        return;
-    }
-    // where this workgroup's NEXT window starts: asked for now, needed at the top of stage E
-    const long next_win = win_counter != nullptr
-                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
-                              : win + (long)gridDim.x;
-    win_after = next_win;
-    const bool has_next = args()->samples != nullptr && next_win < n_windows;
-    long long next_base = 0, next_len = 0;
-    int next_step = 0;
-    if (has_next) {
-        ArgsPtr a = args();
-        const long long* __restrict__ offsets = glob(a->offsets);
-        unsigned next_read;
-        split_window((unsigned)next_win, a->steps, &next_read, &next_step);
-        next_base = offsets[next_read];
-        next_len = offsets[next_read + 1] - next_base;
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
@@ -2160,10 +2380,64 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     auto third = [&](int conv, int t, float* dst) {
         dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
     };
-    w43_layer<1, false, -1, true>(lds, packed, tid, lane, wave, ts, 2, sync_rounds,
-                            [&](int t, float* dst) { third(2, t, dst); });
-    w43_layer<2, false, -1, true>(lds, packed, tid, lane, wave, ts, 6, sync_rounds,
-                            [&](int t, float* dst) { third(3, t, dst); });
+    // (kernel arguments the code behind conv2 needs: read from the kernarg segment HERE, so that
+    // their scalar loads are long back when conv3's hand-counted LDS waits begin - lgkmcnt counts
+    // scalar loads too, and the first wait of a tile would sit out their round trip)
+    const bool thirds_here_done = thirds_ahead;      // (requested in the window before: stage F)
+    const long long* __restrict__ offsets_arg = glob(args()->offsets);
+    const int steps_arg = args()->steps;
+    const bool seam_b2 = args()->samples != nullptr;
+    // conv2 with conv1 inside its tile 0.  In the steady state thirds 1 and 2 of its weights are
+    // requested between conv1's first MFMAs, one piece after each (a request costs ~100 cycles of
+    // issue; 36 pieces = 4 or 5 per wave), and land before the mid-layer barrier.
+    w43_layer<1, false, -1, true>(
+        lds, packed, tid, lane, wave, ts, 2, sync_rounds,
+        [&](int t, float* dst) { third(2, t, dst); }, &in_a,
+        [&](int i) {
+            if (!cold && !thirds_here_done && i < (2 * kWinoHalf / 256 + kWaves - 1) / kWaves)
+                dma_weights_one<2 * kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1,
+                                               lane, wave, i);
+        },
+        [&] {
+            if (win_counter != nullptr && tid == 0) {
+                reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
+                // n_windows numbers are taken per launch, whatever the grid: this was the last
+                if ((long long)taken == n_windows - 1) *win_counter = 0;
+            }
+        });
+    if (stop_stage == 0) return;      // (debug_stage 0: tile 0 has written the dump itself)
+    // where this workgroup's NEXT window starts: known behind conv2's end barrier, needed at the
+    // top of stage E
+    const long next_win = win_counter != nullptr
+                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
+                              : win + (long)gridDim.x;
+    win_after = next_win;
+    const bool has_next = seam_b2 && next_win < n_windows;
+    // Its read's place in the sample buffer: two VECTOR loads (the address made per-lane on
+    // purpose) whose results nobody looks at before stage D.  As scalar loads they counted
+    // against lgkmcnt, and the first hand-counted LDS wait of the layer that follows - tile 0 of
+    // conv3 - sat out their whole L2 round trip (~0.9k cycles per window, in conv2's tile 0 when
+    // this stood in front of it: profiles/r03_v1 against r04).
+    long long next_off0 = 0, next_off1 = 0;
+    int next_step = 0;
+    if (has_next) {
+        unsigned next_read;
+        split_window((unsigned)next_win, steps_arg, &next_read, &next_step);
+        unsigned lane_zero = 0;
+        asm volatile("" : "+v"(lane_zero));
+        next_off0 = offsets_arg[next_read + lane_zero];
+        next_off1 = offsets_arg[next_read + lane_zero + 1];
+    }
+    // (before conv3's mid-layer barrier - which waits for everything anyway - the two offset
+    // loads are looked at once: hipcc's wait-count pass then knows they have landed.  Left
+    // "pending" - they are issued under a condition, and the pass merges control flow
+    // pessimistically - the first instruction that reuses one of their registers, in conv8's first
+    // step, waited for all but one of the wave's outstanding requests: the LDS-DMA of conv9's
+    // weights just asked for, a whole L2 round trip per window.)
+    w43_layer<2, false, -1, true>(
+        lds, packed, tid, lane, wave, ts, 6, sync_rounds,
+        [&](int t, float* dst) { third(3, t, dst); }, nullptr, NoBetween(), NoHook(),
+        [&] { asm volatile("" : "+v"(next_off0), "+v"(next_off1)); });
     // conv4 + MaxPool + BN2; conv7's thirds follow conv4's out of the slots, and conv5's and
     // conv6's weights go to the upper buffer once conv4 has read the rows there (tile 0 done)
     w43_layer<3, true, 1, false>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
@@ -2217,6 +2491,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         ArgsPtr a = args();
         long long wa, wb;
         const int nside = a->side;
+        const long long next_base =
+            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
+        const long long next_end =
+            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
+        const long long next_len = next_end - next_base;
         window_bounds(next_len, next_step, nside, &wa, &wb);
         next_cnt = (int)(wb - wa);
         next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
@@ -2235,9 +2516,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             constexpr int IT = decltype(tag)::value;
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
         }));
-    // BN5's scale/shift (384 floats, too many for the parameter table): one per thread, fetched
-    // here, parked in LDS at the top of stage E
-    const float bn5v = tid < 2 * 192 ? packed[bn_scale_offset(4) + tid] : 0.f;
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
     wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
         lds, packed, tid, lane, wave, ts, 30,
@@ -2254,46 +2532,61 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
     {
-        // The next window's samples start their trip from HBM now (stages E-H, ~25k cycles, are
-        // far more than it takes) and are used at the top of the next round's stage A; the
+        // No phase of its own in front of the 1x1 convolutions: the average pooling that conv10
+        // reads happens on conv10's output (inception_1x1_of_avgpool), BN5's parameters come from
+        // L2 in E1 and reach LDS by DMA for E2 and E3, and each zero row is written by a wave
+        // that writes the buffer it belongs to - every store below lands in LDS that nobody
+        // reads before E1's barrier.
+        //   The ORDER of the memory requests matters: vector loads return in order, and the
+        // wait hipcc puts in front of a value's first use counts the requests issued after it -
+        // the ones it knows of (inline-asm LDS-DMA is not among them), pessimistically wherever
+        // control flow has merged.  So: (1) the LDS-DMA piece, (2) the next window's samples -
+        // whose registers the pass believes pending from the round before: asked for behind other
+        // loads, the first of them waited out those loads' L2 round trip -, (3) BN5's parameters
+        // for E1's epilogue, needed an MFMA loop later.  The accumulators of E1-E3 start from
+        // biases in the LDS parameter table: from L2, every phase began with a round trip.
+        // (1) the end of conv16's weights (what did not fit beside conv9's exchange scratch)
+        dma_weights<kEWFloats - kEWEarly>(packed + weight_offset(9) + kEWEarly, lds + kEW + kEWEarly,
+                                          lane, wave);
+        // ... and BN5's scale and shift for E2 and E3 (384 floats - too many for the parameter
+        // table; two pieces, by the two waves the copy above leaves without one; what follows
+        // them in the packed image comes along): landed before E1's closing barrier
+        static_assert((kEWFloats - kEWEarly) / 256 == 6 && bn_scale_offset(4) % 4 == 0 &&
+                      bn_scale_offset(4) + 512 <= kPackedFloats && kEBn5 + 512 <= kArenaFloats, "");
+        if (wave >= 6)
+            dma_piece(packed + bn_scale_offset(4) + (wave - 6) * 256, lds + kEBn5 + (wave - 6) * 256,
+                      (unsigned)lane * 16u);
+        // (2) The next window's samples start their trip from HBM now (stages E-H, ~25k cycles,
+        // are far more than it takes) and are used at the top of the next round's stage A; the
         // registers they land in were last read in this window's stage A.
         prefetched = has_next;
         if (has_next) {
             in_cnt = next_cnt;
-            fetch_window_at(next_src, next_cnt, next_pad, tid, wave * kMtA, n, q, in_v0, in_v1,
-                            in_raw, in_inside);
+            fetch_window_at(next_src, next_cnt, next_pad, tid,
+                            wave * 16 + 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1), q, in_v0, in_v1,
+                            in_raw);
         }
-        // the end of conv16's weights (what did not fit beside conv9's exchange scratch)
-        dma_weights<kEWFloats - kEWEarly>(packed + weight_offset(9) + kEWEarly, lds + kEW + kEWEarly,
-                                          lane, wave);
-        // E0: x1's AveragePooling1D(3, stride 1, 'same'), TF valid-count divisor.
-        const float* X = lds + kEX;
-        // 384 threads, each one channel and eight consecutive positions: ten row reads for eight
-        // outputs (three per output the naive way)
-        if (tid < 8 * 48) {
-            const int g = tid / 48, c = tid - g * 48;
-            float x[10];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) x[i] = X[(8 * g + i) * kS48 + c];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = 8 * g + j;
-                // x (1/count), not / count: an fp32 division is ten instructions, and one ulp of
-                // the quotient is far inside the tolerance
-                const float inv = (p == 0 || p == 63) ? 0.5f : (1.f / 3.f);
-                lds[kEAP + (p + 1) * kS48 + c] = (x[j] + x[j + 1] + x[j + 2]) * inv;
-            }
-        }
-        zero_row(lds + kET3, 0, kS16, 16, tid);
-        zero_row(lds + kET3, 65, kS16, 16, tid);
-        zero_row(lds + kET4a, 0, kS16, 16, tid);
-        zero_row(lds + kET4a, 65, kS16, 16, tid);
-        zero_row(lds + kET4b, 0, kS48, 48, tid);
-        zero_row(lds + kET4b, 65, kS48, 48, tid);
+        // (3) E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
+        // wave 6 conv12, wave 7 conv14
+        static_assert(bias_offset(10) == bias_offset(9) + 48, "conv10's and conv11's biases are adjacent");
+        const float* bias_tab = lds + kParams - kTabBias0 + n;     // + bias_offset(conv): the LDS table
+        EpiParams<1, true> ep_cat;
+        EpiParams<1, false> ep_mid;
+        if (wave < 6)
+            ep_cat.load(bias_tab + bias_offset(9) + wave * 16, packed + bn_scale_offset(4) + wave * 16 + n,
+                        packed + bn_shift_offset(4) + wave * 16 + n);
+        else
+            ep_mid.load(bias_tab + (wave == 6 ? bias_offset(11) : bias_offset(13)), nullptr, nullptr);
         zero_row(lds + kECat, 0, kS192, 192, tid);
         zero_row(lds + kECat, 33, kS192, 192, tid);
-        if (tid < 2 * 192) lds[kEBn5 + tid] = bn5v;
-        lds_barrier();
+        if (wave == 6) {
+            zero_row(lds + kET3, 0, kS16, 16, lane);
+            zero_row(lds + kET3, 65, kS16, 16, lane);
+        }
+        if (wave == 7) {
+            zero_row(lds + kET4a, 0, kS16, 16, lane);
+            zero_row(lds + kET4a, 65, kS16, 16, lane);
+        }
         mark(ts, 34);
 
         constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
@@ -2305,28 +2598,21 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         constexpr int w16 = kEW + weight_offset(15) - weight_offset(9);
         const float* sc5 = lds + kEBn5 + n;
         const float* sh5 = lds + kEBn5 + 192 + n;
-        const float* bias_tab = packed + n;     // + bias_offset(conv): L2 (not in the LDS table)
 
         // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
         if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
-            const int t = wave;
-            inception_1x1<3, kS192, true>(lds + kEAP, lds + w10, lds + kECat, t * 16,
-                                          bias_tab + bias_offset(9) + t * 16, sc5 + t * 16,
-                                          sh5 + t * 16, t, lane);
+            inception_1x1_of_avgpool<3, kS192>(lds + kEX, lds + w10, lds + kECat, wave * 16, ep_cat,
+                                               wave, lane);
         } else if (wave < 6) {     // conv11 -> concat channels 48..95
-            const int t = wave - 3;
-            inception_1x1<3, kS192, true>(lds + kEX, lds + w11, lds + kECat, 48 + t * 16,
-                                          bias_tab + bias_offset(10) + t * 16,
-                                          sc5 + 48 + t * 16, sh5 + 48 + t * 16, t, lane);
+            inception_1x1<3, kS192, true>(lds + kEX, lds + w11, lds + kECat, wave * 16, ep_cat,
+                                          wave - 3, lane);
         } else if (wave == 6) {    // conv12 -> 16-channel bottleneck of branch 3
-            inception_1x1<1, kS16, false>(lds + kEX, lds + w12, lds + kET3, 0,
-                                          bias_tab + bias_offset(11), nullptr, nullptr, 0, lane);
+            inception_1x1<1, kS16, false>(lds + kEX, lds + w12, lds + kET3, 0, ep_mid, 0, lane);
         } else {                   // conv14 -> 16-channel bottleneck of branch 4
-            inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0,
-                                          bias_tab + bias_offset(13), nullptr, nullptr, 0, lane);
+            inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0, ep_mid, 0, lane);
         }
         mark(ts, 35);
-        lds_barrier();
+        full_barrier();      // (also: BN5's parameters, asked for at the top, have landed)
         mark(ts, 36);
 
         // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, and conv13
@@ -2337,6 +2623,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         {
             constexpr int kTile = 2 * 2 * 256;       // floats of one channel tile's weights
             const int m = wave & 1;
+            if (wave == 0) zero_row(lds + kET4b, 0, kS48, 48, lane);     // (conv16's padding rows)
+            if (wave == 1) zero_row(lds + kET4b, 65, kS48, 48, lane);
             if (wave < 2) {
                 inception_k3_wino<2, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, 0,
                                                   bias_tab + bias_offset(14), nullptr, nullptr, m, lane);
@@ -2394,6 +2682,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // workgroup and the rest runs for kTailBatch windows at a time, ONE WAVE PER WINDOW, with no
     // cross-wave step at all (batched_tail below).
     const bool batch_ends = tail_slot == kTailBatch - 1 || next_win >= n_windows;
+    thirds_ahead = prefetched && !batch_ends;
     if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = (int)win;
     if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
         dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
@@ -2421,6 +2710,28 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                         stats[1] = inv;
                     }
                 }
+                // Thirds 1 and 2 of the NEXT window's conv2 weights -> slots 1 and 2, by the
+                // four waves that have nothing else to do while waves 0-2 reduce conv17 (36 pieces,
+                // nine each; the slots overlap the concat buffer, which every wave has finished
+                // reading at the barrier just passed) - unless the batched tail runs between this
+                // window and the next: its buffers lie there.
+                if (thirds_ahead && wave >= 3 && wave < kWaves - 1) {
+                    const unsigned lane_bytes = (unsigned)lane * 16u;
+#pragma unroll
+                    for (int i = 0; i < 2 * kWinoHalf / 256 / 4; ++i) {
+                        const int piece = (wave - 3) + 4 * i;
+                        dma_piece(packed + weight_offset(1) + kWinoHalf + piece * 256,
+                                  lds + kSlot1 + piece * 256, lane_bytes);
+                    }
+                }
+            },
+            // The NEXT window's first third of conv2's weights -> slot 0 (the inception block's
+            // scratch, dead behind E3's barrier; the batched tail keeps clear of it): tile 0 of
+            // conv2 multiplies right behind that window's first barrier, which retires these
+            // requests - 18 pieces, one per wave behind each tap's MFMAs.
+            [&](int tap) {
+                if (prefetched)
+                    dma_weights_one<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave, tap);
             });
     }
     mark_realtime(ts, 63);
@@ -2436,7 +2747,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         const int n_classes = a->n_classes;
         const bool mine = wave < n_batch;
         long my_win = 0;         // (read behind the barrier below)
-        float* X = lds + kTX + wave * 2 * kTailBuf;
+        float* X = lds + tail_x_offset(wave);
         float* Y = X + kTailBuf;
         // epilogue parameters of the three layers, asked for before anything waits
         EpiParams<3, false> ep18;
@@ -2473,7 +2784,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 46);
         if (debug_stage >= 0 && stop_stage == 5) {
             if (debug_stage < 100)
-                dump_stage(lds + kTX, kS48, 16, 48, glob(a->debug_out) + win * kStageFloats[5], tid);
+                dump_stage(lds + tail_x_offset(0), kS48, 16, 48, glob(a->debug_out) + win * kStageFloats[5], tid);
             return;
         }
         if (mine) {
@@ -2500,7 +2811,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (debug_stage >= 0 && stop_stage == 6) {
             full_barrier();  
             if (debug_stage < 100)
-                dump_stage(lds + kTX, kS48, 8, 48, glob(a->debug_out) + win * kStageFloats[6], tid);
+                dump_stage(lds + tail_x_offset(0), kS48, 8, 48, glob(a->debug_out) + win * kStageFloats[6], tid);
             return;
         }
         if (mine) {

@@ -61,6 +61,9 @@ constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 12
 // the same layer is what SURVEY.md's 33,629,952 FLOP per window adds up; the Winograd layers
 // issue 4/6 and 6/12 of it.
 constexpr int conv_mfmas(int i, int n_classes) {
+    // conv1d_1 is computed inside conv1d_2's first tile, transposed (channels x positions) and with
+    // the halo rows of every quad tile recomputed: per wave 6 input rows x 3 channel groups
+    if (i == 0) return 8 * 6 * 3;
     const int units = kConvLout[i] / (kConv[i].wino ? kConv[i].wino : 1);
     const int m_tiles = (units + 15) / 16;
     const int n_tiles = i == kNumConvs - 1 ? (n_classes <= 16 ? 1 : 2) : kConv[i].cout_pad / 16;
@@ -73,7 +76,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 9540, "MFMA count per window (SQ_INSTS_MFMA, profiles/r01_v9)");
+static_assert(forward_mfmas(13) == 9588, "MFMA count per window (SQ_INSTS_MFMA, profiles/r04_*)");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -127,6 +130,17 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // transformed matrices V0..V3).  One ds_read_b64 / global_load_dwordx2 per lane yields
 // the B fragments of two consecutive k-steps; the A side (activations) pairs channels the same
 // way, so the contraction order is a fixed permutation of (tap, c_in).
+
+// conv1d_2 is the exception: its input never exists as an LDS image.  conv1d_1 runs as the
+// TRANSPOSED product (M = 16 output channels, N = 16 positions) inside conv1d_2's first tile, and
+// an MFMA leaves lane l with rows 4*(l>>4) .. +3 of its result = output channels 16g + 4*(l>>4) + r
+// (g = channel group of the MFMA, r = result register).  Those registers, ReLU'd, batch-normalised
+// and Winograd-transformed in place, ARE conv1d_2's A fragments if k-step s = 4g + r of conv1d_2
+// contracts over channels {16g + 4q + r : q = 0..3} - a permutation of the input channels that
+// only the packer needs to know about (dbh_api.hip: pack_weights).
+constexpr int frag_cin(int conv, int sp, int q, int e) {
+    return conv == 1 ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // LDS arena (floats).  Activations are [position][channel] with a padded row stride and one zero
@@ -217,27 +231,39 @@ constexpr int kTW20 = kTW19 + conv_weight_floats(18);
 constexpr int kTWEnd = kTW20 + conv_weight_floats(19);     // 21,504
 static_assert(kTWEnd <= kECat, "tail weights would land on the concat buffer conv17 reads");
 constexpr int kTailBuf = 18 * kS48;                        // 900 floats
-constexpr int kTX = kTWEnd;                                // wave w: X at kTX + w * 2 * kTailBuf
-constexpr int kTLog = kTX + kTailBatch * 2 * kTailBuf;     // 32 logits per wave
-constexpr int kTEnd = kTLog + kTailBatch * 32;
+// The X/Y pairs of waves 0-2 lie where conv17's partial tiles were (dead behind the tail's first
+// barrier), those of waves 3-7 from kSlot1 upwards (the concat buffer, dead too): between them
+// slot 0 stays untouched - the NEXT window's first third of conv1d_2's weights is on its way there
+// since the top of stage F (dbh_forward.hip: the fused stage A needs it right behind its first
+// barrier).
+constexpr int kTXLowWaves = 3;
+constexpr int kTXLow = 0;                                  // wave w < 3: X at kTXLow + w * 2 * kTailBuf
+constexpr int kTLog = kTXLow + kTXLowWaves * 2 * kTailBuf; // 32 logits per wave
+constexpr int kTXHigh = kSlot1;                            // wave w >= 3: X at kTXHigh + (w - 3) * 2 * kTailBuf
+static_assert(kTLog + kTailBatch * 32 <= kTW18, "the tail's low buffers would land on its weights");
+static_assert(kTWEnd <= kSlot0, "the tail's weights would land on slot 0");
+static_assert(kTXHigh + (kTailBatch - kTXLowWaves) * 2 * kTailBuf <= kLdsFloatsAD, "batched tail overflows the arena");
+constexpr int tail_x_offset(int wave) {
+    return wave < kTXLowWaves ? kTXLow + wave * 2 * kTailBuf
+                              : kTXHigh + (wave - kTXLowWaves) * 2 * kTailBuf;
+}
 constexpr int kTailSlotFloats = 16 * 48;                   // conv17 output of one window
 // BN5's scale and shift (2 x 192 floats), parked above stage E's buffers for the inception block
 constexpr int kEBn5 = kLdsFloatsE;
 static_assert(kEBn5 + 2 * 192 <= (kLdsFloatsAD > kLdsFloatsD ? kLdsFloatsAD : kLdsFloatsD), "");
-static_assert(kTEnd <= kLdsFloatsAD, "batched tail overflows the arena");
 constexpr int kArenaFloats =
     (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
         ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
         : kLdsFloatsD;
-// Above the arena, for the whole kernel: a copy of the biases of conv2..conv9 and of BN2..BN4's
-// scale/shift (two contiguous runs of the packed image), so that the epilogue parameters of the
-// in-place layers of stages B-D come from LDS (~100 cycles) instead of L2 (~700 cycles, exposed
+// Above the arena, for the whole kernel: a copy of the biases of conv1..conv16 and of BN1..BN4's
+// scale/shift (two contiguous runs of the packed image), so that the epilogue parameters of
+// stages A-E come from LDS (~100 cycles) instead of L2 (~700 cycles, exposed
 // at the top of every layer); everything else is fetched from global memory well ahead of use.
 // Then one word: the arrival counter of the split barrier (dbh_forward.hip: lds_arrive/lds_wait).
 constexpr int kParams = kArenaFloats;
-constexpr int kTabBias0 = bias_offset(1), kTabBias1 = bias_offset(9);
-constexpr int kTabBn0 = bn_scale_offset(1), kTabBn1 = bn_scale_offset(4);
-constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 352 + 288
+constexpr int kTabBias0 = bias_offset(0), kTabBias1 = bias_offset(16);
+constexpr int kTabBn0 = bn_scale_offset(0), kTabBn1 = bn_scale_offset(4);
+constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 672 + 384
 constexpr int kSync = kParams + kParamFloats;
 // window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
 constexpr int kStatRed = kSync + 2;
