@@ -159,10 +159,59 @@ class ShardJob:
         self.timing_model = self.models[0] if timing_model else None
 
     calls_out = None      # where the final calls go instead of the shard's device buffer
+    side = None           # sharding.SideGather: the exchange on a stream of its own
+    pinned = None         # lead only: where the gathered calls land on the host
+    pending = None        # slot whose exchange was queued since this job's last step
+    timed = None          # lead only: [(Event before the exchange, Event behind the copy)] per step
 
-    def step(self):
+    def enable_side_gather(self, pinned):
+        self.side = sharding.SideGather(self.shard)
+        self.pinned = pinned
+
+    def finish_pending(self):
+        """Behind the exchange of the step before (queued on the side stream by the caller since
+        this job's last step): the copy of the gathered calls to the host (lead), the slot's
+        release - and the end of that step's gather bracket."""
+        if self.side is None or self.pending is None:
+            return
+        slot, self.pending = self.pending, None
+        if self.pinned is not None:
+            self.pinned.fetch(self.side.gathered[slot].ptr, self.side.stream.ptr)
+        if self.timed is not None:
+            self.timed[-1][1].record(self.side.stream.ptr)
+        self.side.release(slot)
+
+    def step(self, slot=0):
         s, cfg = self.shard, self.cfg
-        final = ctypes.c_void_p(self.calls_out) if self.calls_out else s.calls.ptr
+        if self.side is not None:
+            self.finish_pending()
+            self.side.before_classify(slot)
+            final = self.side.calls[slot].ptr
+        else:
+            final = ctypes.c_void_p(self.calls_out) if self.calls_out else s.calls.ptr
+        self._classify(final)
+        if self.side is not None:
+            self.side.after_classify(slot)
+            if self.timed is not None:
+                pair = self.spare.pop() if self.spare else (hip_backend.Event(), hip_backend.Event())
+                pair[0].record(self.side.stream.ptr)
+                self.timed.append(pair)
+            self.pending = slot
+
+    spare = ()
+
+    def time_gathers(self, steps):
+        """From now on every step's exchange + copy is bracketed by two events on the side stream
+        (created here, outside the timed region)."""
+        self.spare = [(hip_backend.Event(), hip_backend.Event()) for _ in range(steps)]
+        self.timed = []
+
+    def gather_ms_per_step(self):
+        done = [a.elapsed_ms(b) for a, b in (self.timed or [])]
+        return sum(done) / len(done) if done else None
+
+    def _classify(self, final):
+        s, cfg = self.shard, self.cfg
         if not self.side_calls:
             self.models[0].classify_batched_dev(s.samples.ptr, s.offsets.ptr, self.n, cfg['batch'],
                                                 cfg['sides'][0], SCAN_SIZE, SCORE_DIFF,
@@ -424,16 +473,57 @@ def main():
     if direct:
         lead.calls_out = pinned.device_pointer()
 
+    # More than one GPU (or a communicator to exercise): the exchange and the copy of the gathered
+    # calls run on a SIDE stream against two sets of call arrays used in turn, so that step k + 1's
+    # launch follows step k's on the classification stream with nothing in between
+    # (sharding.SideGather).  DEEPBINNER_BENCH_GATHER=instream queues them on the classification
+    # stream as rounds 1-3 did, =side forces the side stream; the host transport (no communicator)
+    # always uses the classification stream.
+    #   Measured on one GPU (tools/gather_ab.sh, profiles/r04_gather_ab.txt): device copies on
+    # the side stream overlap the next launch (+0.7 % with two shards, +1.9 % with eight); an RCCL
+    # all-gather there takes 1.2-1.3 ms instead of ~20 us - its kernel does not get to run beside
+    # the persistent forward kernel, CUs left free for it or not - and the step grows by 8 %.  So
+    # the default is the side stream for the copy transport and the classification stream for RCCL.
+    where = os.environ.get('DEEPBINNER_BENCH_GATHER', 'auto')
+    side_gather = (not direct and group.comm is not None and
+                   (where == 'side' or (where == 'auto' and transport == 'copy')))
+    if side_gather:
+        run_all(lambda j: j.enable_side_gather(pinned if (is_lead and j is lead) else None))
+    # (experiment: CUs left out of the forward launches, for a collective's kernel to run beside them)
+    reserve = int(os.environ.get('DEEPBINNER_BENCH_RESERVE_CUS', '0') or 0)
+    if reserve:
+        run_all(lambda j: [m.reserve_cus(reserve) for m in j.models])
+    steps_queued = [0]
+    instream_pairs, instream_spare = None, []      # event brackets around exchange + copy, in stream
+
     def step():
+        slot = steps_queued[0] & 1
+        steps_queued[0] += 1
+        if side_gather:
+            run_all(lambda j: j.step(slot))
+            group.all_gather_side([j.side for j in jobs], slot)
+            return
         run_all(lambda j: j.step())
         if direct:
             return
+        bracket = None
+        if instream_pairs is not None and instream_spare:      # (rank 0, one process per GPU)
+            bracket = instream_spare.pop()
+            bracket[0].record(lead.shard.stream.ptr)
         group.all_gather()
         if is_lead:       # the gathered calls reach the host inside the timed region
             fetch() if per_rank else group.run_on(0, fetch)
+        if bracket is not None:
+            bracket[1].record(lead.shard.stream.ptr)
+            instream_pairs.append(bracket)
 
     def sync():
-        run_all(lambda j: j.shard.synchronize())
+        def drain(j):
+            j.finish_pending()
+            j.shard.synchronize()
+            if j.side is not None:
+                j.side.synchronize()
+        run_all(drain)
 
     def barrier():
         if rdzv is not None:
@@ -444,6 +534,11 @@ def main():
     sync()
     barrier()
     sync()
+    if side_gather and is_lead:
+        run_all(lambda j: j.time_gathers(args.steps) if j is lead else None)
+    elif per_rank and is_lead and not direct and group.comm is not None:
+        instream_spare.extend((hip_backend.Event(), hip_backend.Event()) for _ in range(args.steps))
+        instream_pairs = []
     if lead.timing_model is not None:
         lead.timing_model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
         # two stores per workgroup and launch: the shader clock against the 100 MHz wall clock
@@ -490,6 +585,20 @@ def main():
         'gather': {'transport': transport if (world > 1 or group.comm is not None) else 'none',
                    'fallback_reason': group.fallback_reason},
     }
+    if side_gather or not direct:
+        # where the exchange is queued, and (side stream, rank 0's GPU) how long one step's
+        # exchange + copy of the gathered calls to the host takes from the moment that step's
+        # calls are final - it overlaps the next step's launch
+        result['gather']['queued_on'] = ('side stream, call arrays double-buffered' if side_gather
+                                         else 'classification stream')
+        if side_gather and is_lead:
+            result['gather']['ms_per_step'] = run_all(lambda j: j.gather_ms_per_step()
+                                                      if j is lead else None)[0]
+        elif instream_pairs:
+            result['gather']['ms_per_step'] = (sum(a.elapsed_ms(b) for a, b in instream_pairs) /
+                                               len(instream_pairs))
+        else:
+            result['gather']['ms_per_step'] = None
     if is_lead:
         calls_host = pinned.array()
         gathered = np.concatenate([calls_host[r * block:r * block + shard_sizes[r]]

@@ -498,6 +498,10 @@ int dbh_event_synchronize(dbh_event event) {
     DBH_HIP(hipEventSynchronize((hipEvent_t)event));
     return DBH_OK;
 }
+int dbh_stream_wait_event(dbh_stream stream, dbh_event event) {
+    DBH_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return DBH_OK;
+}
 int dbh_event_elapsed_ms(dbh_event start, dbh_event stop, float* ms) {
     if (!ms) return DBH_ERR_INVALID_ARGUMENT;
     DBH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

@@ -93,6 +93,7 @@ def load_library():
         'dbh_event_destroy': (c_int, [c_void_p]),
         'dbh_event_record': (c_int, [c_void_p, c_void_p]),
         'dbh_event_synchronize': (c_int, [c_void_p]),
+        'dbh_stream_wait_event': (c_int, [c_void_p, c_void_p]),
         'dbh_event_elapsed_ms': (c_int, [c_void_p, c_void_p, P(ctypes.c_float)]),
         'dbh_model_create': (c_int, [_f32(), c_i64, c_int, c_int, P(c_void_p)]),
         'dbh_model_destroy': (c_int, [c_void_p]),
@@ -170,7 +171,8 @@ EXPORTED_SYMBOLS = [
     'dbh_get_device', 'dbh_device_name', 'dbh_device_synchronize', 'dbh_malloc', 'dbh_free',
     'dbh_malloc_host', 'dbh_free_host', 'dbh_memcpy_h2d', 'dbh_memcpy_d2h', 'dbh_memcpy_d2d',
     'dbh_stream_create', 'dbh_stream_destroy', 'dbh_stream_synchronize', 'dbh_event_create',
-    'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_event_elapsed_ms',
+    'dbh_event_destroy', 'dbh_event_record', 'dbh_event_synchronize', 'dbh_stream_wait_event',
+    'dbh_event_elapsed_ms',
     'dbh_model_create', 'dbh_model_destroy', 'dbh_model_set_read_length_hint', 'dbh_model_input_size', 'dbh_model_output_size',
     'dbh_predict', 'dbh_predict_dev', 'dbh_classify_i16', 'dbh_classify_pair_i16',
     'dbh_model_set_host_group', 'dbh_model_reserve_cus', 'dbh_host_device_pointer',
@@ -373,6 +375,10 @@ class Stream:
 
     def synchronize(self):
         check(self._lib.dbh_stream_synchronize(self.ptr), 'dbh_stream_synchronize')
+
+    def wait_event(self, event):
+        """Work queued from now on waits for ``event`` (an ``Event`` recorded on another stream)."""
+        check(self._lib.dbh_stream_wait_event(self.ptr, event.handle), 'dbh_stream_wait_event')
 
     def close(self):
         if self.ptr:

@@ -78,6 +78,10 @@ int dbh_event_create(dbh_event* event);
 int dbh_event_destroy(dbh_event event);
 int dbh_event_record(dbh_event event, dbh_stream stream);
 int dbh_event_synchronize(dbh_event event);
+/* what is queued on `stream` after this call waits until `event` (recorded on another stream of
+ * the device) has happened: the edge between a classification stream and the side stream that
+ * gathers and copies its calls (bench.py, sharding.SideGather) */
+int dbh_stream_wait_event(dbh_stream stream, dbh_event event);
 int dbh_event_elapsed_ms(dbh_event start, dbh_event stop, float* ms);
 
 /* ---- model (replaces keras.models.load_model, classify.py:90) -------------------------- */
