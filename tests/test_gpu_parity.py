@@ -722,6 +722,9 @@ def test_bench_one_process_two_devices(hip):
                         {'DEEPBINNER_DEVICE_ORDINALS': '0,0'})
     assert result['n_gpus'] == 2 and result['value'] > 0 and 'roofline' in result
     assert result['gather']['transport'] == 'copy'
+    # device copies run on a side stream against double-buffered call arrays (sharding.SideGather)
+    assert result['gather']['queued_on'].startswith('side stream')
+    assert result['gather']['ms_per_step'] > 0
     assert result['config']['reads_per_step'] == 20000
     assert result['calls_not_none_rank0'] > 0          # the real-read windows classify
 
@@ -734,7 +737,11 @@ def test_bench_rccl_path_single_rank(hip):
                         {'DEEPBINNER_BENCH_FORCE_RANKS': '1', 'DEEPBINNER_COMM_FORCE': '1'},
                         launcher=1)
     assert result['n_gpus'] == 1 and result['value'] > 0 and 'roofline' in result
-    assert result['gather'] == {'transport': 'rccl', 'fallback_reason': None}
+    assert result['gather']['transport'] == 'rccl' and result['gather']['fallback_reason'] is None
+    # RCCL's collective stays on the classification stream (profiles/r04_gather_ab.txt); rank 0
+    # brackets exchange + copy with events: the line says how long a step's gather took
+    assert result['gather']['queued_on'] == 'classification stream'
+    assert 0 < result['gather']['ms_per_step'] < 5
     assert result['cpu_baseline']['calls_match_gpu'] is True
     assert result['cpu_baseline']['calls_not_none_in_sample'] > 0
     assert result['cpu_baseline']['published']['source'] == 'README.md:213'
@@ -751,8 +758,21 @@ def test_bench_rccl_single_process_form(hip):
     """ncclCommInitAll + grouped ncclAllGather (the `python bench.py --gpus N` form), one device."""
     result = _run_bench(['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
                          '--no-side-rates'], {'DEEPBINNER_COMM_FORCE': '1'})
-    assert result['gather'] == {'transport': 'rccl', 'fallback_reason': None}
+    assert result['gather']['transport'] == 'rccl' and result['gather']['fallback_reason'] is None
     assert result['calls_not_none_rank0'] > 0
+
+
+def test_bench_gather_on_the_side_stream_gives_the_same_calls(hip):
+    """The side-stream form of the exchange forced for RCCL (one rank) over five steps - both
+    sets of call arrays, each reused behind its release event: the calls that reach the host are
+    the CPU port's, and the line says where the exchange was queued and how long it took."""
+    result = _run_bench(['--gpus', '1', '--steps', '5', '--warmup', '2', '--no-side-rates'],
+                        {'DEEPBINNER_COMM_FORCE': '1', 'DEEPBINNER_BENCH_GATHER': 'side'})
+    assert result['gather']['transport'] == 'rccl'
+    assert result['gather']['queued_on'].startswith('side stream')
+    assert result['gather']['ms_per_step'] > 0
+    assert result['calls_not_none_rank0'] > 0
+    assert result['cpu_baseline']['calls_match_gpu'] is True
 
 
 @pytest.mark.parametrize('config', [2, 3])
