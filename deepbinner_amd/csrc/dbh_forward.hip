@@ -639,9 +639,13 @@ __device__ __forceinline__ f2 pk_fma_relu(f2 k, f2 b, f2 c) {
 // it does not look into inline asm: an accumulator read HERE straight after the MFMA chain (the
 // exposed epilogue of a layer's last tile) arrives stale.
 
+// bias: step 0 STARTS the accumulator chains (no moved zeros: vector moves are not free beside
+// fp32 MFMAs) - M0's from +bias (even outputs), M3's from -bias (odd outputs), the others from the
+// MFMA's constant 0.
 template <int MT, int PHASE, int SP_IDX, class Side>
 __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
-                                          f4 (&acc)[4][MT][3], const Side& side) {
+                                          f4 (&acc)[4][MT][3], const float (&bias)[3],
+                                          const Side& side) {
     constexpr int kLoads = 3 * MT + 6;
     if constexpr (SP_IDX + 1 < 6) {
         wino_load<MT, PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
@@ -676,8 +680,16 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, acc[2 * PHASE + x][m][t]);
+            for (int t = 0; t < 3; ++t) {
+                if constexpr (SP_IDX == 0) {
+                    const float b0 = (2 * PHASE + x == 0) ? bias[t] : (2 * PHASE + x == 3) ? -bias[t] : 0.f;
+                    const f4 start = (2 * PHASE + x == 0 || 2 * PHASE + x == 3) ? f4{b0, b0, b0, b0}
+                                                                                : f4{0.f, 0.f, 0.f, 0.f};
+                    acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, start);
+                } else {
+                    acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, acc[2 * PHASE + x][m][t]);
+                }
+            }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -699,16 +711,18 @@ __device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, Wino
 #pragma unroll
             for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][m][t]));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP_IDX + 1 < 6) wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, side);
+    if constexpr (SP_IDX + 1 < 6)
+        wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, bias, side);
 }
 
 template <int MT, int PHASE, class Side = NoSide>
 __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slot_lane,
-                                           f4 (&acc)[4][MT][3], const Side& side = Side()) {
+                                           f4 (&acc)[4][MT][3], const float (&bias)[3],
+                                           const Side& side = Side()) {
     const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
     WinoFrags<MT> buf[2];
     wino_load<MT, PHASE, 0>(buf[0], a_addr, b_addr);
-    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc, side);
+    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc, bias, side);
 }
 
 // One F(2,3) Winograd layer with whole tiles per wave (conv7).  SLOT_A / SLOT_B: LDS homes of
@@ -1587,26 +1601,19 @@ __device__ __forceinline__ void wino_split_layer(float* lds, const float* __rest
     side();
     EpiParams<3, BN> ep;
     load_epi<CONV, BNI>(ep, lds, packed, n);
-    f4 acc[4][1][3];
-    zero_acc(acc[1]);
-    zero_acc(acc[2]);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {     // +bias rides in M0 (even outputs), -bias in M3 (odd)
-        acc[0][0][t] = f4{ep.b[t], ep.b[t], ep.b[t], ep.b[t]};
-        acc[3][0][t] = f4{-ep.b[t], -ep.b[t], -ep.b[t], -ep.b[t]};
-    }
+    f4 acc[4][1][3];      // (+bias rides in M0 - even outputs -, -bias in M3 - odd: wino_step)
     const float* a_lane = lds + kActOff + (m * 32 + 2 * n) * kS48 + 2 * q;
     float* mine = lds + XCHG + (wave & 3) * 6 * 256 + lane * 4;     // slot shared by the pair
     if (ts_base == 26) mark(ts, 48);
     if (!high) {
-        wino_phase<1, 0>(a_lane, lds + SLOT_A + lane * 2, acc, step_side);
+        wino_phase<1, 0>(a_lane, lds + SLOT_A + lane * 2, acc, ep.b, step_side);
         if (ts_base == 26) mark(ts, 50);
         if (!POOL) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(mine + t * 256) = acc[1][0][t];
         }
     } else {
-        wino_phase<1, 1>(a_lane, lds + SLOT_B + lane * 2, acc, step_side);
+        wino_phase<1, 1>(a_lane, lds + SLOT_B + lane * 2, acc, ep.b, step_side);
         if (ts_base == 26) mark(ts, 50);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -2199,6 +2206,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const float* __restrict__ packed_entry = glob(args()->packed);
     const int debug_stage = args()->debug_stage;
     const long long n_windows = args()->n_windows;
+    // (the two pointers every window's first instructions branch on: read once - a scalar load at
+    // the top of a window is ~200 cycles that every wave spends in front of the first barrier)
+    const int16_t* const samples_entry = glob(args()->samples);
+    int* const win_counter_entry = glob(args()->win_counter);
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
 
     const int tid_entry = threadIdx.x;
@@ -2272,7 +2283,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
     mark(ts, 0);
     mark_realtime(ts, 62);
-    int* const win_counter = glob(args()->win_counter);
+    // (opaque once per round like the parameter pointer: see above)
+    const __attribute__((address_space(1))) int* wc_opaque =
+        (const __attribute__((address_space(1))) int*)win_counter_entry;
+    const __attribute__((address_space(1))) int16_t* smp_opaque =
+        (const __attribute__((address_space(1))) int16_t*)samples_entry;
+    asm volatile("" : "+s"(wc_opaque), "+s"(smp_opaque));
+    int* const win_counter = (int*)wc_opaque;
     int taken = 0;
 
     // ---------------- stage A: conv1d_1 (k3, stride 2, pad right) + ReLU + BN1 ---------------
@@ -2294,7 +2311,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         auto fetch_conv2_weights = [&] {      // all three thirds (slots 0..2 are adjacent)
             dma_weights<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         };
-        const int16_t* __restrict__ samples = glob(args()->samples);
+        const int16_t* __restrict__ samples = (const int16_t*)smp_opaque;
         cold = samples == nullptr || !prefetched;
         // (the registers the samples were prefetched into, looked at once on every path: this is
         // where hipcc's wait-count pass learns that those loads have landed.  Without it they
@@ -2369,7 +2386,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         in_a.p4_edge = j == 0 ? f2{0.f, 0.f} : f2{4.f, 4.f};
         in_a.one_edge = j == 127 ? f2{0.f, 0.f} : f2{1.f, 1.f};
         in_a.dump_on = debug_stage == 0;
-        in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
+        in_a.dump = nullptr;
+        if (in_a.dump_on)
+            in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
         in_a.stop = stop_stage == 0;
         mark(ts, 1);
     }
@@ -2386,7 +2405,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const bool thirds_here_done = thirds_ahead;      // (requested in the window before: stage F)
     const long long* __restrict__ offsets_arg = glob(args()->offsets);
     const int steps_arg = args()->steps;
-    const bool seam_b2 = args()->samples != nullptr;
+    const int side_arg = args()->side;
+    const bool seam_b2 = smp_opaque != nullptr;
     // conv2 with conv1 inside its tile 0.  In the steady state thirds 1 and 2 of its weights are
     // requested between conv1's first MFMAs, one piece after each (a request costs ~100 cycles of
     // issue; 36 pieces = 4 or 5 per wave), and land before the mid-layer barrier.
@@ -2488,9 +2508,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const int16_t* next_src = nullptr;
     int next_cnt = 0, next_pad = 0;
     if (has_next) {
-        ArgsPtr a = args();
         long long wa, wb;
-        const int nside = a->side;
+        const int nside = side_arg;
         const long long next_base =
             ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
@@ -2501,7 +2520,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         window_bounds(next_len, next_step, nside, &wa, &wb);
         next_cnt = (int)(wb - wa);
         next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
-        next_src = glob(a->samples) + next_base + wa;
+        next_src = (const int16_t*)smp_opaque + next_base + wa;
     }
     // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
     // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
