@@ -1,8 +1,12 @@
 // dbh_forward.hip — the Deepbinner forward pass as ONE persistent gfx950 kernel: at most one
-// 512-thread workgroup (8 wave64s, 2 per SIMD) per CU, each walking windows b, b + grid, ... and
-// carrying every 1024-sample window through all 20 convolutions with the activations resident in
-// LDS the whole way; HBM sees 2 KiB of int16 in and n_classes floats + a call out per window, the
-// weights stream from L2 by LDS-DMA.
+// 512-thread workgroup (8 wave64s, 2 per SIMD) per CU; workgroup b starts with window b and takes
+// every further window off a counter in global memory, carrying each 1024-sample window through
+// all 20 convolutions with the activations resident in LDS (or in registers) the whole way.  Per
+// window HBM gives 2 KiB of int16 and takes n_classes floats + a call; the weights stream from L2
+// by LDS-DMA; the one round trip through global memory is conv17's 16 x 48 output, parked in a
+// per-workgroup slot until the batched tail runs (3 KB per window, written and read back by the
+// same CU - dirty in L2, so part of it does reach HBM: ~1.2 KB per window of write traffic
+// against 56 B of results, profiles/r04_v1).
 //
 // What it computes: reference deepbinner/network_architecture.py:18-95 as evaluated by
 // model.predict (deepbinner/classify.py:361) — see oracle/network_ref.py for the operator
@@ -15,10 +19,14 @@
 //     matrix pipe (v_mfma_f32_16x16x4_f32: M = 16 positions, N = 16 output channels, K = 4 input
 //     channels).  The pipe is shared with the vector ALU: every other vector instruction costs
 //     matrix time, so the code counts them;
+//   - conv1 (one input channel) has no phase and no LDS image of its own: the wave that owns a
+//     tile of conv2's output quads computes the conv1 rows they need inside conv2's first tile,
+//     TRANSPOSED (M = channels, N = positions), so that the MFMA leaves them where conv2's input
+//     transform wants them - in registers;
 //   - the k = 3 layers with enough positions run as Winograd: F(4,3) for conv2,3,4 (L = 512, one
 //     tile of 16 quads per wave, N tile by N tile with the transformed inputs in registers) and
 //     conv7 (L = 256, a tile per wave PAIR, split by output channels), F(2,3) for conv6, conv8,
-//     conv9, conv13, conv15 - 9,540 MFMAs per window instead of the direct form's 16,452;
+//     conv9, conv13, conv15 - 9,588 MFMAs per window instead of the direct form's 16,452;
 //   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row pitch
 //     50 floats), B fragments (weights): ds_read_b128 / b64 from fragment-ordered copies that
 //     LDS-DMA brought in a phase ahead; both issued from inline asm one step ahead with
@@ -27,8 +35,12 @@
 //     the epilogue of an N tile inside the MFMA steps of the next one;
 //   - activations are held times 2^-60 so that ReLU is the clamp modifier of the instruction that
 //     produces a value (dbh_layout.h: kActScale);
+//   - the average pooling in front of conv10 is applied to conv10's OUTPUT (a 1x1 convolution
+//     commutes with it), in registers;
 //   - the last three layers run for eight windows at a time, one wave per window (batched tail);
-//   - the next window's samples and statistics are fetched under the current one's last stages.
+//   - the next window's samples, statistics and first weights are fetched under the current one's
+//     last stages; memory requests are ordered for the wait counts hipcc derives (it does not see
+//     the inline-asm LDS-DMA requests, and merges control flow pessimistically).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
