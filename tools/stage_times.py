@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Attribute forward-kernel time to network stages on a real MI355X: run the kernel truncated
 after each stage (dbh_forward_truncated_dev) and difference the HIP-event times.
+(Since round 4 conv1 runs inside conv2's first tile: a kernel truncated "after stage A" ends behind
+that tile, so A carries a third of conv2's MFMAs and B lacks them.)
 Usage: python tools/stage_times.py [n_windows] [repeats]"""
 import json
 import os

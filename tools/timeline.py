@@ -14,18 +14,18 @@ sys.path.insert(0, REPO)
 from deepbinner_amd import hip_backend                      # noqa: E402
 from deepbinner_amd.model_format import ModelWeights        # noqa: E402
 
-NAMES = {0: 'start', 1: 'A done'}
+NAMES = {0: 'start', 1: 'A done (samples normalised; conv1 runs inside conv2 tile 0)'}
 # stage B (dbh_forward.hip: w43_layer): per layer U phase done | barrier | tile 2's MFMAs done |
 # end (last epilogue + barrier + DMA request)
 for base, l in ((2, 'conv2'), (6, 'conv3'), (10, 'conv4')):
-    for j, what in enumerate(['U phase done', 'barrier', 'tile 2 done', 'end']):
+    for j, what in enumerate(['tile 0 done', 'barrier', 'tile 2 done', 'end']):
         NAMES[base + j] = '%s %s' % (l, what)
 LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
         NAMES[14 + 4 * i + j] = '%s %s' % (l, what)
 NAMES.update({22: 'conv7 own N tile done', 23: 'conv7 barrier', 24: 'conv7 shared tile done, partials published', 25: 'conv7 end',
-              34: 'E0 avgpool+barrier', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
+              34: 'E top: requests, zero rows (no barrier)', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
               38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
 for j, what in enumerate(['partial done', 'barrier', 'reduce+epilogue (to global)', 'end']):
     NAMES[41 + j] = 'conv17 %s' % what
@@ -34,8 +34,8 @@ TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 
         49: 'tail: conv19 done', 53: 'tail: conv20+softmax+call', 55: 'tail: end barrier'}
 ORDER = list(range(0, 45))
 EXTRA = {25: 'conv7 end', 26: 'conv8 exchange stored', 27: 'conv8 barrier1',
-         51: 'A: first barrier passed', 52: 'A: conv2 weights requested', 54: 'A: window normalised',
-         59: 'A: MFMAs issued', 60: 'A: epilogue stores issued', 6: 'conv3 U phase done', 7: 'conv3 barrier',
+         51: 'A: first barrier passed', 54: 'A: window normalised',
+         6: 'conv3 tile 0 done', 7: 'conv3 barrier',
          57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
 
 
