@@ -1310,6 +1310,9 @@ __device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* ld
 struct NoBetween {
     __device__ __forceinline__ void operator()(int) const {}
 };
+// pieces of a third (18) per wave: waves 0 and 1 take three, the others two
+constexpr int kThirdPieces = (kWinoHalf / 256 + kWaves - 1) / kWaves;
+static_assert(kThirdPieces == 3, "");
 template <int CONV, bool POOL, int BNI, bool END_BARRIER, class NextThird, class BetweenA = NoBetween,
           class AfterMid = NoHook, class BeforeMid = NoHook>
 __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
@@ -1355,24 +1358,29 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
         zero_row(lds + kActOff, 0, kS48, 48, tid);
         zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
     }
-    next_third(0, lds + kSlot0);
-    // tile 1, with tile 0's epilogue inside its steps 1 and 3
+    // tile 1, with tile 0's epilogue inside its steps 1 and 3 - and the requests for the next
+    // layer's third 0, ONE piece behind the MFMAs of each of the first steps: a request in front
+    // of a tile, where both waves of a SIMD issue theirs at the same moment, costs ~90 cycles of
+    // idle matrix pipe (profiles/r04_ablation.txt: the stage-B requests were 1.7 % of the kernel);
+    // behind a step's MFMAs the other wave's MFMAs hide it (tools/microbench/dma_issue.hip)
     w43_tile<false, 0, 12>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
         if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_q);
         if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_q);
+        if constexpr (SP < kThirdPieces) next_third(0, lds + kSlot0, SP);
     });
     lds_arrive(lds, lane, 0);
     sync_rounds += kWaves;
     if (ts_base == 6) mark(ts, 57);
-    // tile 2, with tile 1's epilogue inside
+    // tile 2, with tile 1's epilogue inside; third 1 of the next layer behind its last steps, once
+    // every wave has left tile 1
     w43_tile<false, 6, 12>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
         constexpr int SP = decltype(tag)::value;
         if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_q);
         if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_q);
+        if constexpr (SP == 6 - kThirdPieces) lds_wait(lds, 0, sync_rounds);
+        if constexpr (SP >= 6 - kThirdPieces) next_third(1, lds + kSlot1, SP - (6 - kThirdPieces));
     });
-    lds_wait(lds, 0, sync_rounds);      // every wave has left tile 1
-    next_third(1, lds + kSlot1);
     mark(ts, ts_base + 2);
     w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
     w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
@@ -1380,8 +1388,10 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     // END_BARRIER false: the caller's next layer reads only rows this wave wrote itself (conv5, a
     // 1x1 convolution, after conv4) and takes care of slot 2 behind its own barrier
     if constexpr (END_BARRIER) {
-        full_barrier();        // the layer is stored; every wave has left tile 2
-        next_third(2, lds + kSlot2);
+        // the layer is stored; every wave has left tile 2.  (This wave's third-1 pieces, its
+        // youngest requests, may stay in flight: the next layer's mid-layer barrier retires them)
+        lds_barrier<kThirdPieces>();
+        next_third(2, lds + kSlot2, -1);
     }
     mark(ts, ts_base + 3);
 }
@@ -2408,8 +2418,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
     // Winograd F(4,3) layers (see w43_layer).  Third t of a layer (= what N tile t needs) always
     // lives in slot t; the next layer's third t is requested when every wave has left tile t.
-    auto third = [&](int conv, int t, float* dst) {
-        dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
+    // piece i of this wave's share of a third (i < 0: all of them at once)
+    auto third = [&](int conv, int t, float* dst, int i) {
+        if (i < 0)
+            dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
+        else
+            dma_weights_one<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
     };
     // (kernel arguments the code behind conv2 needs: read from the kernarg segment HERE, so that
     // their scalar loads are long back when conv3's hand-counted LDS waits begin - lgkmcnt counts
@@ -2424,7 +2438,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // issue; 36 pieces = 4 or 5 per wave), and land before the mid-layer barrier.
     w43_layer<1, false, -1, true>(
         lds, packed, tid, lane, wave, ts, 2, sync_rounds,
-        [&](int t, float* dst) { third(2, t, dst); }, &in_a,
+        [&](int t, float* dst, int i) { third(2, t, dst, i); }, &in_a,
         [&](int i) {
             if (!cold && !thirds_here_done && i < (2 * kWinoHalf / 256 + kWaves - 1) / kWaves)
                 dma_weights_one<2 * kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1,
@@ -2468,19 +2482,24 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // weights just asked for, a whole L2 round trip per window.)
     w43_layer<2, false, -1, true>(
         lds, packed, tid, lane, wave, ts, 6, sync_rounds,
-        [&](int t, float* dst) { third(3, t, dst); }, nullptr, NoBetween(), NoHook(),
+        [&](int t, float* dst, int i) { third(3, t, dst, i); }, nullptr, NoBetween(), NoHook(),
         [&] { asm volatile("" : "+v"(next_off0), "+v"(next_off1)); });
     // conv4 + MaxPool + BN2; conv7's thirds follow conv4's out of the slots, and conv5's and
     // conv6's weights go to the upper buffer once conv4 has read the rows there (tile 0 done)
     w43_layer<3, true, 1, false>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
-                          [&](int t, float* dst) {
-                              third(6, t, dst);      // conv7's six F(4,3) matrices, a third a slot
-                              if (t == 0) {
+                          [&](int t, float* dst, int i) {
+                              third(6, t, dst, i);   // conv7's six F(4,3) matrices, a third a slot
+                              // conv5's (3 pieces) and conv6's (9) weights: with the first pieces,
+                              // long before conv4's split barrier vouches for them
+                              if (t == 0 && i == 0) {
                                   dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
                                                                      lds + kW5, lane, wave);
-                                  dma_weights<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                     lds + kW6, lane, wave);
+                                  dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                         lds + kW6, lane, wave, 0);
                               }
+                              if (t == 0 && i == 1)
+                                  dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                         lds + kW6, lane, wave, 1);
                           });
     if (stop_stage == 1) {
         full_barrier();      // (conv4 ends without one)
@@ -2502,7 +2521,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // conv5's barrier - gets conv7's last third then.
     inplace_layer<4, kW5, 256, kS48, kS16, false, -1, 0, kActOff, kMid16>(
         lds, packed, nullptr, nullptr, tid, lane, wave, ts, 14);
-    third(6, 2, lds + kSlot2);
+    third(6, 2, lds + kSlot2, -1);
     w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile
