@@ -1390,7 +1390,12 @@ __device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ 
     if constexpr (END_BARRIER) {
         // the layer is stored; every wave has left tile 2.  (This wave's third-1 pieces, its
         // youngest requests, may stay in flight: the next layer's mid-layer barrier retires them)
-        lds_barrier<kThirdPieces>();
+        // Waves 0 and 1 have asked for three pieces, the others for two: nothing OLDER than those
+        // - the next layer's third 0 among it - may be outstanding behind this barrier.
+        if (wave < kWinoHalf / 256 - (kThirdPieces - 1) * kWaves)
+            lds_barrier<kThirdPieces>();
+        else
+            lds_barrier<kThirdPieces - 1>();
         next_third(2, lds + kSlot2, -1);
     }
     mark(ts, ts_base + 3);
