@@ -65,6 +65,20 @@ def test_predict_matches_oracle(hip_models, model_name, side):
     assert np.abs(got.sum(axis=1) - 1).max() < 1e-5
 
 
+def test_predict_more_windows_than_workgroups(hip_models):
+    """Seam b1 through the persistent loop: 1,500 windows on 256 workgroups (every workgroup walks
+    several, each on the cold path of stage A - the fp32 windows bring no prefetch - and the
+    batched tail runs with full and partial batches): row for row what the same windows give 50 at
+    a time (one workgroup per window)."""
+    x = np.load(os.path.join(GOLD, 'windows_start.npy')).reshape(-1, 1024)
+    rng = np.random.default_rng(5)
+    big = x[rng.integers(0, len(x), 1500)] * rng.uniform(0.5, 1.5, (1500, 1)).astype(np.float32)
+    model = hip_models['EXP-NBD103_read_starts']
+    got = model.predict(big[:, :, None])
+    want = np.concatenate([model.predict(big[a:a + 50, :, None]) for a in range(0, 1500, 50)])
+    assert np.array_equal(got, want)
+
+
 def test_predict_edge_inputs(hip_models, weights):
     model = hip_models['EXP-NBD103_read_starts']
     assert model.predict(np.zeros((0, 1024, 1))).shape == (0, 13)
