@@ -58,7 +58,7 @@ def main():
     if opts.queues:
         os.environ['DEEPBINNER_INFLATE_QUEUES'] = str(opts.queues)
     os.environ['DEEPBINNER_INFLATE_CUS'] = str(opts.cus)
-    replicas, _ = realtime.inflate_queues(classify.device_replicas(sm, em), {}, opts.share)
+    replicas, _ = realtime.inflate_queues(classify.device_replicas(sm, em), opts.share)
 
     def work(item, start_replica, end_replica):
         _, ids, offsets, _, comp, records = item

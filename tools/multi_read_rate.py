@@ -237,7 +237,7 @@ def main():
         replicas, _ = load_models(1)
         clones = {}
         for host_share in (0, 20, 40, 50, 60, 70, 100):
-            queues, models = realtime.inflate_queues(replicas, clones, host_share)
+            queues, models = realtime.inflate_queues(replicas, host_share)
             best, best_cpu = 0.0, 0.0
             for _ in range(2):
                 t0, c0 = time.perf_counter(), time.process_time()
@@ -270,7 +270,7 @@ def main():
         for n_queues, n_cus in ((1, 0), (2, 32), (3, 0), (3, 32), (4, 32)):
             os.environ['DEEPBINNER_INFLATE_QUEUES'] = str(n_queues)
             os.environ['DEEPBINNER_INFLATE_CUS'] = str(n_cus)
-            queues, models = realtime.inflate_queues(replicas, clones, share)
+            queues, models = realtime.inflate_queues(replicas, share)
             sum(classify.dispatch_batches(iter(raw_loaded[:2]), queues, raw_work))       # warm-up
             t0 = time.perf_counter()
             done = sum(classify.dispatch_batches(iter(raw_loaded * 4), queues, raw_work))

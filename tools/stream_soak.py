@@ -48,7 +48,7 @@ def main():
         share = int(rng.choice([0, 5, 20, 40, 58, 75, 99]))
         os.environ['DEEPBINNER_INFLATE_QUEUES'] = str(int(rng.integers(1, 7)))
         os.environ['DEEPBINNER_INFLATE_CUS'] = str(int(rng.choice([0, 0, 16, 32, 200])))
-        queues, held = realtime.inflate_queues(base, clones, share)
+        queues, held = realtime.inflate_queues(base, share)
         stream = fast5_native.stream_raw(paths, threads=int(rng.integers(2, 17)),
                                          depth=len(queues) + 2, host_inflate_above=-share)
         t0 = time.perf_counter()
