@@ -906,27 +906,6 @@ __device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restr
 // always in LDS slot t.  Slot t of the NEXT layer is requested once every wave has left tile t
 // (split barrier below), one tile later, so that the wait is never a wait.
 // ---------------------------------------------------------------------------------------------
-// A workgroup-wide "everybody has passed point P" that is not a barrier: a wave ARRIVES
-// (lds_arrive: one ds_add on a counter word, after everything it asked of memory has landed) and
-// carries on with work that does not depend on the others; where it does depend on them it WAITS
-// for the counter to reach 8 x the number of rounds so far.
-// Two counter words (which = 0, 1), because a count of arrivals only means "all eight" if no wave
-// can arrive twice before another has arrived once: each word is arrived at once per layer.
-__device__ __forceinline__ void lds_arrive(float* lds, int lane, int which) {
-    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync) + which;
-    // release: this wave's LDS reads are done and its LDS-DMA pieces have landed (explicitly: the
-    // compiler does not see the inline-asm DMA requests)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (lane == 0)
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_wait(float* lds, int which, unsigned target) {
-    unsigned* counter = reinterpret_cast<unsigned*>(lds + kSync) + which;
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
-                 target) < 0)
-        __builtin_amdgcn_s_sleep(1);
-}
-
 struct W43U {
     f2 u[6][6];      // [xi][sp]: channels 8 sp + 2 (lane >> 4) + {0, 1} of quad pm(lane & 15)
 };
@@ -990,75 +969,6 @@ __device__ __forceinline__ void w43_load_b(f4 (&b)[3], unsigned b_addr) {
     b[2] = ds_read_f4<((SP * 3 + 2) * 256) * 4>(b_addr);
 }
 
-// Step 0 STARTS the six accumulator chains: five from the constant 0 (an inline operand of the
-// MFMA - no v_mov per register, and VALU work is not free beside fp32 MFMAs), M1's from the bias.
-// TILE0: the step also fetches the input rows of the NEXT channel group and turns this one's
-// into U[.][SP] - tile 0 builds the register-resident U that tiles 1 and 2 reuse.
-template <bool TILE0, int STEP0, int STEPS, int SP, class Side>
-__device__ __forceinline__ void w43_tile_step(W43U& U, unsigned a_addr, unsigned b_addr,
-                                              f2 (&dbuf)[2][6], f4 (&buf)[2][3], f4 (&acc)[6],
-                                              float bias, const Side& side) {
-    if constexpr (SP + 1 < 6) {
-        if constexpr (TILE0) w43_load_rows<SP + 1>(dbuf[(SP + 1) & 1], a_addr);
-        w43_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
-        if constexpr (TILE0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    f4(&b)[3] = buf[SP & 1];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
-    progress_priority<STEP0 + SP, STEPS>();
-    if constexpr (TILE0) {
-        f2(&d)[6] = dbuf[SP & 1];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(d[k]));
-        __builtin_amdgcn_sched_barrier(0);
-        w43_transform<SP>(U, d);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP == 0) {
-        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], zero);
-            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2],
-                                   p == 0 ? f4{bias, bias, bias, bias} : zero);
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
-            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
-        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
-    }
-#pragma unroll
-    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
-    __builtin_amdgcn_sched_barrier(0);
-    side(IntC<SP>{});      // the caller's work for this step (a piece of the tile before's epilogue)
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP + 1 < 6)
-        w43_tile_step<TILE0, STEP0, STEPS, SP + 1>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
-}
-
-// STEP0 of STEPS: where this tile's six steps lie in the stretch between two barriers
-template <bool TILE0, int STEP0, int STEPS, class Side>
-__device__ __forceinline__ void w43_tile(W43U& U, const float* a_lane, const float* slot_lane,
-                                         f4 (&acc)[6], float bias, const Side& side) {
-    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
-    f2 dbuf[2][6];
-    f4 buf[2][3];
-    if constexpr (TILE0) w43_load_rows<0>(dbuf[0], a_addr);
-    w43_load_b<0>(buf[0], b_addr);
-    w43_tile_step<TILE0, STEP0, STEPS, 0>(U, a_addr, b_addr, dbuf, buf, acc, bias, side);
-}
-
 // Half (h = rows 2h, 2h+1 of every accumulator = quads 2q + 8h, 2q + 1 + 8h of the wave's tile)
 // of the epilogue of N tile T: output transform, ReLU (+ MaxPool2 + BatchNorm), stores in place.
 // MFMA row m = 4q'+r' of the wave's tile works on quad pm(m) = 2q' + (r'&1) + 8(r'>>1), so that the
@@ -1104,6 +1014,38 @@ __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, flo
             dst[3 * kS48] = v3;
         }
     }
+}
+
+// The twelve MFMAs of one step of a stage-B tile, TRANSPOSED (round 5): the weight fragments are
+// the A operand (M = 16 output channels), the transformed inputs the B operand (N = the wave's 16
+// quads), so that lane (quad n, q) ends up with output channels 16t + 4q + r of ITS OWN quad in
+// registers r = 0..3 of each of the six accumulators - and everything that follows (output
+// transform, ReLU, the next layer's input transform) is in-lane.  Step 0 starts the chains: five
+// from the MFMA's constant 0, M1's from the bias of the lane's four channels (every output of the
+// transform takes M1 with weight 1).
+template <int SP>
+__device__ __forceinline__ void w43t_mfmas(const W43U& U, const f4 (&b)[3], f4 (&acc)[6], f4 bias4) {
+    if constexpr (SP == 0) {
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(b[p][0], U.u[2 * p][SP].x, zero);
+            acc[2 * p + 1] = mfma4(b[p][2], U.u[2 * p + 1][SP].x, p == 0 ? bias4 : zero);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] = mfma4(b[p][0], U.u[2 * p][SP].x, acc[2 * p]);
+            acc[2 * p + 1] = mfma4(b[p][2], U.u[2 * p + 1][SP].x, acc[2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        acc[2 * p] = mfma4(b[p][1], U.u[2 * p][SP].y, acc[2 * p]);
+        acc[2 * p + 1] = mfma4(b[p][3], U.u[2 * p + 1][SP].y, acc[2 * p + 1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1187,7 +1129,7 @@ __device__ __forceinline__ void conv_a_group(const ConvAIn& in, f4 bias4, f4 (&a
 template <int SP, class Side>
 __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3][6], f4 bias4_g2,
                                           unsigned p_addr, unsigned b_addr, f2 (&pbuf)[2][2],
-                                          f4 (&buf)[2][3], f4 (&acc)[6], float bias,
+                                          f4 (&buf)[2][3], f4 (&acc)[6], f4 bias,
                                           const Side& side) {
     constexpr int G = SP >> 1, H = SP & 1;
     if constexpr (SP + 1 < 6) {
@@ -1202,7 +1144,7 @@ __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
     asm volatile("" : "+v"(par[0]), "+v"(par[1]));
-    progress_priority<SP, 6>();
+    progress_priority<SP, 18>();
     __builtin_amdgcn_sched_barrier(0);
     f2 d[6], v[6];
 #pragma unroll
@@ -1237,28 +1179,7 @@ __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3
 #pragma unroll
         for (int t = 0; t < 6; ++t) asm volatile("" : "+v"(a1[2][t]));
     }
-    if constexpr (SP == 0) {
-        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], zero);
-            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2],
-                                   p == 0 ? f4{bias, bias, bias, bias} : zero);
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            acc[2 * p] = mfma4(U.u[2 * p][SP].x, b[p][0], acc[2 * p]);
-            acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].x, b[p][2], acc[2 * p + 1]);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        acc[2 * p] = mfma4(U.u[2 * p][SP].y, b[p][1], acc[2 * p]);
-        acc[2 * p + 1] = mfma4(U.u[2 * p + 1][SP].y, b[p][3], acc[2 * p + 1]);
-    }
-#pragma unroll
-    for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(acc[x]));
+    w43t_mfmas<SP>(U, b, acc, bias);
     __builtin_amdgcn_sched_barrier(0);
     side(IntC<SP>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -1269,9 +1190,10 @@ __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3
 // Tile 0 of conv1d_2 with conv1d_1 inside.  between(i): the caller's i-th request of the twelve it
 // may place between the first conv1d_1 MFMAs (LDS-DMA pieces for slots 1 and 2: a request costs
 // ~100 cycles of issue, a bunch of them in front of the MFMAs keeps the matrix pipe idle).
-template <class Between>
+template <class Between, class Side>
 __device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* lds, int lane,
-                                           f4 (&acc)[6], float bias, const Between& between) {
+                                           f4 (&acc)[6], f4 bias, const Between& between,
+                                           const Side& side) {
     const int q = lane >> 4;
     const f4* bias4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);   // + 4 g: group g
     const f4 b0 = bias4[0], b1 = bias4[4], b2 = bias4[8];
@@ -1297,110 +1219,376 @@ __device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* ld
     f4 buf[2][3];
     w43a_load_params<0>(pbuf[0], p_addr);
     w43_load_b<0>(buf[0], b_addr);
-    w43a_step<0>(U, in, a1, b2, p_addr, b_addr, pbuf, buf, acc, bias, NoSide());
+    w43a_step<0>(U, in, a1, b2, p_addr, b_addr, pbuf, buf, acc, bias, side);
 }
 
-// One F(4,3) layer.  On entry the layer's input is complete in LDS (a barrier has passed since
-// the last store) and the layer's three weight thirds are in slots 0..2 or on their way (they land
-// before the barrier below releases).  next_third(t, dst): request third t of the NEXT layer's
-// weights (or whatever takes slot t's place) - called once every wave has left tile t.
-// in_a != null (conv1d_2 only): the layer has no input image - tile 0 computes conv1d_1 itself
-// (w43a_tile0) with between_a(i) placed between its first MFMAs; after_mid(): the caller's work
-// right behind the mid-layer barrier.
-struct NoBetween {
-    __device__ __forceinline__ void operator()(int) const {}
-};
+// =============================================================================================
+// STAGE B CHAINED IN REGISTERS (round 5): conv1d_2 -> conv1d_3 -> conv1d_4 without an LDS image
+// of any activation in between.  All three layers run TRANSPOSED (w43t_mfmas): lane (n, q) of wave
+// w owns quad j = 16 w + n and, after the six steps of N tile t, holds output channels 16t + 4q + r
+// of that quad's six Winograd products.  The output transform (in-lane), bias (the start of M1's
+// chain), ReLU (clamp) leave Y[t][h][i] = positions 4j + i, channels 16t + 4q + 2h + {0, 1} - and
+// the next layer's input transform needs exactly those channels in this lane (its k-step 4t + r
+// contracts over channels {16t + 4q + r}: dbh_layout.h: frag_cin) plus ONE halo position each
+// side: position 4j - 1 is lane n - 1's row 3, position 4j + 4 lane n + 1's row 0 - a DPP row
+// shift; at the two ends of a wave's row of 16 quads they come from the neighbouring wave through
+// 2 x 48 floats of LDS per wave and layer, announced on a counter word per wave (halo_post /
+// halo_wait: no workgroup barrier).  What this removes per layer: 98 KB of LDS stores, the 36
+// A-fragment reads per wave that brought them back, both workgroup barriers and the pipeline
+// fill behind each.  Nine tiles of six steps run back to back; the epilogue of tile T (output
+// transform -> Y, edge rows, post) rides inside tile T + 1's steps, U of the next layer is built
+// step by step inside its tile 0 (from Y of channel group g in steps 2g, 2g + 1), conv1d_4's
+// epilogue pools, applies BN2 and stores [position][channel] rows for stage C.
+//   Weights: a ring of six slots - conv2's thirds in slots 0..2 of the weight area, conv3's in the
+// (idle) activation buffer, conv4's in slots 0..2 again as conv2 leaves them, conv7's behind
+// conv4's.  "Every wave has left tile t" / "every wave's pieces have landed" is a count of
+// arrivals on one word per tile index (chain_arrive: after the wave's own requests have landed),
+// polled where the answer is needed, always at least a tile after it became true for a wave in
+// step with the others.
+// =============================================================================================
+typedef __attribute__((address_space(3))) f2 lds_f2;
 // pieces of a third (18) per wave: waves 0 and 1 take three, the others two
 constexpr int kThirdPieces = (kWinoHalf / 256 + kWaves - 1) / kWaves;
 static_assert(kThirdPieces == 3, "");
-template <int CONV, bool POOL, int BNI, bool END_BARRIER, class NextThird, class BetweenA = NoBetween,
-          class AfterMid = NoHook, class BeforeMid = NoHook>
-__device__ __forceinline__ void w43_layer(float* lds, const float* __restrict__ packed, int tid,
-                                          int lane, int wave, long long* ts, int ts_base,
-                                          unsigned& sync_rounds, const NextThird& next_third,
-                                          const ConvAIn* in_a = nullptr,
-                                          const BetweenA& between_a = BetweenA(),
-                                          const AfterMid& after_mid = AfterMid(),
-                                          const BeforeMid& before_mid = BeforeMid()) {
-    constexpr bool FUSED_A = !std::is_same<BetweenA, NoBetween>::value;
-    static_assert(!FUSED_A || CONV == 1, "only conv1d_2 follows conv1d_1");
-    static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
-    constexpr int L = 512;
-    static_assert(L / 64 == kWaves, "one 16-quad tile per wave");
-    constexpr int LOUT = POOL ? L / 2 : L;
-    constexpr bool BN = BNI >= 0;
-    const int n = lane & 15, q = lane >> 4;
 
-    EpiParams<3, BN> ep;
-    load_epi<CONV, BNI>(ep, lds, packed, n);
-    // quad j = wave*16 + pm(n) needs logical rows 4j-1 .. 4j+4 = physical rows 4j .. 4j+5
-    const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
-    const float* a_lane = lds + kActOff + (wave * 64 + 4 * pm_n) * kS48 + 2 * q;
-    // this lane's place in output quad wave*16 + 2q (NV rows per quad after pooling or not)
-    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + (POOL ? 2 : 4) * (wave * 16 + 2 * q)) * kS48);
-    W43U U;
-    f4 acc[2][6];
-    // tile 0: reads the wave's input rows step by step and builds U on the way
-    if constexpr (FUSED_A)
-        w43a_tile0(U, *in_a, lds, lane, acc[0], ep.b[0], between_a);
-    else
-        w43_tile<true, 0, 6>(U, a_lane, lds + kSlot0 + lane * 4, acc[0], ep.b[0], NoSide());
-    mark(ts, ts_base);
-    if constexpr (FUSED_A) {
-        if (in_a->stop) return;     // debug_stage 0 / 100: stage A only
+__device__ __forceinline__ void chain_arrive(float* lds, int lane, int t) {
+    const unsigned addr = lds_addr(lds + kSyncTiles + t);
+    // release: this wave's LDS reads are done and its LDS-DMA pieces have landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void chain_wait(float* lds, int t, unsigned target) {
+    const unsigned addr = lds_addr(lds + kSyncTiles + t);
+    for (;;) {
+        unsigned seen;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(addr) : "memory");
+        if ((int)(__builtin_amdgcn_readfirstlane(seen) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    before_mid();
-    full_barrier();        // every wave has read all its input rows (and has left tile 0): from
-    mark(ts, ts_base + 1);   // here on the outputs may be stored in place
-    after_mid();
-    if (POOL) zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);   // (row 0 is zero already)
-    if constexpr (FUSED_A) {      // nobody stored an input image: the zero rows around the output
-        zero_row(lds + kActOff, 0, kS48, 48, tid);
-        zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
+}
+// (plain LDS instructions: a wave's requests are served in order, so the add lands behind the edge
+// rows stored before it)
+__device__ __forceinline__ void halo_post(float* lds, int wave, int lane) {
+    const unsigned addr = lds_addr(lds + kSyncHalo + wave);
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+// both neighbours of `wave` have posted `target` times (the outer waves have one neighbour)
+__device__ __forceinline__ void halo_wait(float* lds, int wave, unsigned target) {
+    const unsigned lo = lds_addr(lds + kSyncHalo + (wave > 0 ? wave - 1 : wave + 1));
+    const unsigned hi = lds_addr(lds + kSyncHalo + (wave < kWaves - 1 ? wave + 1 : wave - 1));
+    for (;;) {
+        unsigned a, b;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(b)
+                     : "v"(lo), "v"(hi)
+                     : "memory");
+        const int da = (int)(__builtin_amdgcn_readfirstlane(a) - target);
+        const int db = (int)(__builtin_amdgcn_readfirstlane(b) - target);
+        if (da >= 0 && db >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    // tile 1, with tile 0's epilogue inside its steps 1 and 3 - and the requests for the next
-    // layer's third 0, ONE piece behind the MFMAs of each of the first steps: a request in front
-    // of a tile, where both waves of a SIMD issue theirs at the same moment, costs ~90 cycles of
-    // idle matrix pipe (profiles/r04_ablation.txt: the stage-B requests were 1.7 % of the kernel);
-    // behind a step's MFMAs the other wave's MFMAs hide it (tools/microbench/dma_issue.hip)
-    w43_tile<false, 0, 12>(U, a_lane, lds + kSlot1 + lane * 4, acc[1], ep.b[1], [&](auto tag) {
-        constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w43_epilogue_half<0, POOL, BN>(acc[0], 0, ep.sc[0], ep.sh[0], out_q);
-        if constexpr (SP == 3) w43_epilogue_half<0, POOL, BN>(acc[0], 1, ep.sc[0], ep.sh[0], out_q);
-        if constexpr (SP < kThirdPieces) next_third(0, lds + kSlot0, SP);
-    });
-    lds_arrive(lds, lane, 0);
-    sync_rounds += kWaves;
-    if (ts_base == 6) mark(ts, 57);
-    // tile 2, with tile 1's epilogue inside; third 1 of the next layer behind its last steps, once
-    // every wave has left tile 1
-    w43_tile<false, 6, 12>(U, a_lane, lds + kSlot2 + lane * 4, acc[0], ep.b[2], [&](auto tag) {
-        constexpr int SP = decltype(tag)::value;
-        if constexpr (SP == 1) w43_epilogue_half<1, POOL, BN>(acc[1], 0, ep.sc[1], ep.sh[1], out_q);
-        if constexpr (SP == 3) w43_epilogue_half<1, POOL, BN>(acc[1], 1, ep.sc[1], ep.sh[1], out_q);
-        if constexpr (SP == 6 - kThirdPieces) lds_wait(lds, 0, sync_rounds);
-        if constexpr (SP >= 6 - kThirdPieces) next_third(1, lds + kSlot1, SP - (6 - kThirdPieces));
-    });
-    mark(ts, ts_base + 2);
-    w43_epilogue_half<2, POOL, BN>(acc[0], 0, ep.sc[2], ep.sh[2], out_q);
-    w43_epilogue_half<2, POOL, BN>(acc[0], 1, ep.sc[2], ep.sh[2], out_q);
-    if (ts_base == 6) mark(ts, 58);
-    // END_BARRIER false: the caller's next layer reads only rows this wave wrote itself (conv5, a
-    // 1x1 convolution, after conv4) and takes care of slot 2 behind its own barrier
-    if constexpr (END_BARRIER) {
-        // the layer is stored; every wave has left tile 2.  (This wave's third-1 pieces, its
-        // youngest requests, may stay in flight: the next layer's mid-layer barrier retires them)
-        // Waves 0 and 1 have asked for three pieces, the others for two: nothing OLDER than those
-        // - the next layer's third 0 among it - may be outstanding behind this barrier.
-        if (wave < kWinoHalf / 256 - (kThirdPieces - 1) * kWaves)
-            lds_barrier<kThirdPieces>();
-        else
-            lds_barrier<kThirdPieces - 1>();
-        next_third(2, lds + kSlot2, -1);
-    }
-    mark(ts, ts_base + 3);
 }
 
+// lane n <- lane n - 1 / n + 1 of its row of 16; the row's first / last lane keeps `edge`
+__device__ __forceinline__ float row_from_left(float edge, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, v), 0x111,
+                                                                 0xF, 0xF, false));   // row_shr:1
+}
+__device__ __forceinline__ float row_from_right(float edge, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, v), 0x101,
+                                                                 0xF, 0xF, false));   // row_shl:1
+}
+
+// The four outputs of half H (channels 4q + 2H, + 1 of the N tile) of a transposed accumulator
+// set: output transform + ReLU (the clamp of each output's last instruction).
+template <int H>
+__device__ __forceinline__ void w43t_outputs(const f4 (&acc)[6], f2 (&y)[4]) {
+    const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+    const f2 a0 = f2{acc[0][2 * H], acc[0][2 * H + 1]};
+    const f2 a1 = f2{acc[1][2 * H], acc[1][2 * H + 1]};
+    const f2 a2 = f2{acc[2][2 * H], acc[2][2 * H + 1]};
+    const f2 a3 = f2{acc[3][2 * H], acc[3][2 * H + 1]};
+    const f2 a4 = f2{acc[4][2 * H], acc[4][2 * H + 1]};
+    const f2 a5 = f2{acc[5][2 * H], acc[5][2 * H + 1]};
+    const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+    y[0] = pk_add_relu(a0 + s12, s34);
+    y[1] = pk_fma_relu(k2, d34, d12);
+    y[2] = pk_fma_relu(k4, s34, s12);
+    y[3] = pk_fma_relu(k8, d34, d12 + a5);      // (a5 through a visible add: see pk_fma_relu)
+}
+
+// halo rows of step SP (channels 16 g + 4q + 2h, + 1) of the layer output at HOFF
+template <int SP, int HOFF>
+__device__ __forceinline__ void w43t_load_halo(f2 (&hb)[2], unsigned h_addr) {
+    constexpr int c = 16 * (SP >> 1) + 2 * (SP & 1);
+    hb[0] = ds_read_f2<(HOFF + kHaloRows + 48 + c) * 4>(h_addr);     // A3[w][1]: position 4j - 1
+    hb[1] = ds_read_f2<(HOFF + 96 + c) * 4>(h_addr);                 // A0[w + 1][0]: position 4j + 4
+}
+
+// One step of a chained tile.  HOFF >= 0: tile 0 of conv3 / conv4 - the step first turns
+// Y[g][h] (g = SP >> 1, h = SP & 1) and its two halo positions into U[.][SP].  pre(SP) runs in
+// front of the step's LDS requests (polls), side(SP) behind its MFMAs.
+template <int HOFF, int STEP0, int STEPS, int SP, class Pre, class Side>
+__device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
+                                          unsigned b_addr, f2 (&hbuf)[2][2], f4 (&buf)[2][3],
+                                          f4 (&acc)[6], f4 bias4, const Pre& pre, const Side& side) {
+    constexpr bool BUILD = HOFF >= 0;
+    pre(IntC<SP>{});
+    if constexpr (SP + 1 < 6) {
+        if constexpr (BUILD) w43t_load_halo<SP + 1, (BUILD ? HOFF : 0)>(hbuf[(SP + 1) & 1], h_addr);
+        w43_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
+        if constexpr (BUILD) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f4(&b)[3] = buf[SP & 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
+    progress_priority<STEP0 + SP, STEPS>();
+    if constexpr (BUILD) {
+        f2(&hb)[2] = hbuf[SP & 1];
+        asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const f2(&yy)[4] = Y[SP >> 1][SP & 1];
+        const f2 d0 = f2{row_from_left(hb[0].x, yy[3].x), row_from_left(hb[0].y, yy[3].y)};
+        const f2 d5 = f2{row_from_right(hb[1].x, yy[0].x), row_from_right(hb[1].y, yy[0].y)};
+        const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
+        const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
+        const f2 a = __builtin_elementwise_fma(m4, yy[1], yy[3]), b2 = __builtin_elementwise_fma(m4, yy[0], yy[2]);
+        const f2 c = yy[3] - yy[1], g = yy[2] - yy[0];
+        U.u[0][SP] = __builtin_elementwise_fma(p4, d0, __builtin_elementwise_fma(m5, yy[1], yy[3]));
+        U.u[1][SP] = a + b2;
+        U.u[2][SP] = a - b2;
+        U.u[3][SP] = __builtin_elementwise_fma(p2, g, c);
+        U.u[4][SP] = __builtin_elementwise_fma(m2, g, c);
+        U.u[5][SP] = __builtin_elementwise_fma(p4, yy[0], __builtin_elementwise_fma(m5, yy[2], d5));
+#pragma unroll
+        for (int x = 0; x < 6; ++x) asm volatile("" : "+v"(U.u[x][SP]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    w43t_mfmas<SP>(U, b, acc, bias4);
+    __builtin_amdgcn_sched_barrier(0);
+    side(IntC<SP>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP + 1 < 6)
+        w43t_step<HOFF, STEP0, STEPS, SP + 1>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, pre, side);
+}
+
+template <int HOFF, int STEP0, int STEPS, class Pre, class Side>
+__device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
+                                          const float* slot_lane, f4 (&acc)[6], f4 bias4,
+                                          const Pre& pre, const Side& side) {
+    const unsigned b_addr = lds_addr(slot_lane);
+    f2 hbuf[2][2];
+    f4 buf[2][3];
+    if constexpr (HOFF >= 0) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0)>(hbuf[0], h_addr);
+    w43_load_b<0>(buf[0], b_addr);
+    w43t_step<HOFF, STEP0, STEPS, 0>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, pre, side);
+}
+
+struct NoPre {
+    template <int I>
+    __device__ __forceinline__ void operator()(IntC<I>) const {}
+};
+
+// in_a: conv1d_1's operands (w43a_tile0); thirds_here: thirds 1 and 2 of conv2's weights are
+// requested by between_a (between conv1d_1's MFMAs) instead of having landed before the window's
+// first barrier; after_first(): the caller's work behind this wave's first arrival (everything it
+// asked of global memory has landed there).
+template <class BetweenA, class AfterFirst>
+__device__ __forceinline__ void stage_b_chain(float* lds, const float* __restrict__ packed, int tid,
+                                              int lane, int wave, long long* ts,
+                                              unsigned& chain_windows, const ConvAIn& in_a,
+                                              bool thirds_here, const BetweenA& between_a,
+                                              const AfterFirst& after_first) {
+    const int n = lane & 15, q = lane >> 4;
+    const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 6u;
+    chain_windows += 1;
+    const unsigned h_addr = lds_addr(lds + kHalo + wave * 96 + 4 * q);
+    const bool is_edge = n == 0 || n == 15;
+    lds_f2* edge = (lds_f2*)lds_pinned(lds + kHalo + (wave * 2 + (n == 15 ? 1 : 0)) * 48 + 4 * q);
+    lds_f2* out = (lds_f2*)lds_pinned(lds + kActOff + (1 + 2 * (wave * 16 + n)) * kS48 + 4 * q);
+    const f4* tab4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);
+    auto bias4 = [&](int conv, int t) { return tab4[(bias_offset(conv) - kTabBias0) / 4 + 4 * t]; };
+    static_assert((bias_offset(1) - kTabBias0) % 4 == 0 && (bn_scale_offset(1) - kTabBn0) % 4 == 0 &&
+                  (kTabBias1 - kTabBias0) % 4 == 0, "");
+    W43U U;
+    f4 acc[2][6];
+    f2 Y[3][2][4];
+    // half h of the epilogue of tile g of conv2 (L = 0) / conv3 (L = 1): outputs to Y, the wave's
+    // two edge rows to the halo arrays, and the post that announces a finished tile
+    auto finish = [&](auto L_tag, auto g_tag, auto h_tag, const f4(&a)[6]) {
+        constexpr int L = decltype(L_tag)::value, g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        w43t_outputs<h>(a, Y[g][h]);
+        if (is_edge) {
+            edge[(L * 2 * kHaloRows + 16 * g + 2 * h) / 2] = Y[g][h][0];
+            edge[(L * 2 * kHaloRows + kHaloRows + 96 + 16 * g + 2 * h) / 2] = Y[g][h][3];
+        }
+        if constexpr (h == 1) halo_post(lds, wave, lane);
+    };
+    // half h of the epilogue of tile g of conv4: outputs, MaxPool2, BN2, two rows of the image
+    // stage C reads
+    auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
+        constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        f2 y[4];
+        w43t_outputs<h>(a, y);
+        const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
+        const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(1) - kTabBn0)) / 4 + 4 * g];
+        const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
+        const f2 p0 = f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)};
+        const f2 p1 = f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)};
+        out[(16 * g + 2 * h) / 2] = __builtin_elementwise_fma(p0, sc, sh);
+        out[(kS48 + 16 * g + 2 * h) / 2] = __builtin_elementwise_fma(p1, sc, sh);
+    };
+    static_assert((bn_shift_offset(1) - kTabBn0) % 4 == 0 && kS48 % 2 == 0, "");
+    const IntC<0> c0;
+    const IntC<1> c1;
+    const IntC<2> c2;
+    auto third = [&](int conv, int t, float* dst, int i) {
+        dma_weights_one<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
+    };
+
+    // ---- conv2 (its tile 0 computes conv1d_1 itself).  conv3's 54 pieces go to the idle
+    // activation buffer one behind each of the first seven steps.
+    w43a_tile0(U, in_a, lds, lane, acc[0], bias4(1, 0), between_a, [&](auto tag) {
+        dma_weights_one<3 * kWinoHalf>(packed + weight_offset(2), lds + kChainW3, lane, wave,
+                                       decltype(tag)::value);
+    });
+    mark(ts, 2);
+    if (in_a.stop) return;     // debug_stage 0 / 100: stage A only
+    chain_arrive(lds, lane, 0);
+    after_first();
+    mark(ts, 3);
+    if (thirds_here) chain_wait(lds, 0, tiles0 + 8);      // slots 1, 2: every wave's pieces landed
+    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kSlot1 + lane * 4, acc[1], bias4(1, 1), NoPre(),
+                         [&](auto tag) {
+                             constexpr int SP = decltype(tag)::value;
+                             if constexpr (SP == 0)
+                                 dma_weights_one<3 * kWinoHalf>(packed + weight_offset(2),
+                                                                lds + kChainW3, lane, wave, 6);
+                             if constexpr (SP == 1) finish(c0, c0, c0, acc[0]);
+                             if constexpr (SP == 3) finish(c0, c0, c1, acc[0]);
+                         });
+    chain_arrive(lds, lane, 1);
+    w43t_tile<-1, 12, 18>(U, Y, h_addr, lds + kSlot2 + lane * 4, acc[0], bias4(1, 2), NoPre(),
+                          [&](auto tag) {
+                              constexpr int SP = decltype(tag)::value;
+                              if constexpr (SP == 1) finish(c0, c1, c0, acc[1]);
+                              if constexpr (SP == 3) finish(c0, c1, c1, acc[1]);
+                          });
+    chain_arrive(lds, lane, 2);
+    mark(ts, 4);
+    mark(ts, 5);
+
+    // ---- conv3.  Tile 2 of conv2 is finished inside the first two steps (its Y is needed in
+    // steps 4 and 5, its edge rows by the neighbours in theirs); conv4's third t follows conv2's
+    // out of slot t.
+    chain_wait(lds, 1, tiles0 + 8);       // conv3's weights have landed (and slots 0, 1 are free)
+    halo_wait(lds, wave, halos0 + 2);
+    w43t_tile<0, 0, 18>(
+        U, Y, h_addr, lds + kChainW3 + lane * 4, acc[1], bias4(2, 0),
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 3) halo_wait(lds, wave, halos0 + 3);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 0) finish(c0, c2, c0, acc[0]);
+            if constexpr (SP == 1) finish(c0, c2, c1, acc[0]);
+            if constexpr (SP < kThirdPieces) third(3, 0, lds + kSlot0, SP);
+        });
+    chain_arrive(lds, lane, 0);
+    mark(ts, 6);
+    mark(ts, 7);
+    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kChainW3 + kWinoHalf + lane * 4, acc[0], bias4(2, 1),
+                         NoPre(), [&](auto tag) {
+                             constexpr int SP = decltype(tag)::value;
+                             if constexpr (SP == 1) finish(c1, c0, c0, acc[1]);
+                             if constexpr (SP == 3) finish(c1, c0, c1, acc[1]);
+                             if constexpr (SP < kThirdPieces) third(3, 1, lds + kSlot1, SP);
+                         });
+    chain_arrive(lds, lane, 1);
+    mark(ts, 57);
+    w43t_tile<-1, 12, 18>(
+        U, Y, h_addr, lds + kChainW3 + 2 * kWinoHalf + lane * 4, acc[1], bias4(2, 2),
+        [&](auto tag) {      // slot 2: every wave has left conv2's tile 2
+            if constexpr (decltype(tag)::value == 0) chain_wait(lds, 2, tiles0 + 8);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) finish(c1, c1, c0, acc[0]);
+            if constexpr (SP == 3) finish(c1, c1, c1, acc[0]);
+            if constexpr (SP < kThirdPieces) third(3, 2, lds + kSlot2, SP);
+        });
+    chain_arrive(lds, lane, 2);
+    mark(ts, 8);
+    mark(ts, 58);
+    mark(ts, 9);
+
+    // ---- conv4 + MaxPool + BN2 -> rows 1..256 of the activation buffer.  Its first store (and
+    // conv5's / conv6's weights) must find every wave out of conv3, whose weights lie there.
+    chain_wait(lds, 0, tiles0 + 16);      // conv4's first third has landed
+    halo_wait(lds, wave, halos0 + 5);
+    w43t_tile<2 * kHaloRows, 0, 18>(
+        U, Y, h_addr, lds + kSlot0 + lane * 4, acc[0], bias4(3, 0),
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 3) halo_wait(lds, wave, halos0 + 6);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 0) finish(c1, c2, c0, acc[1]);
+            if constexpr (SP == 1) finish(c1, c2, c1, acc[1]);
+        });
+    chain_arrive(lds, lane, 0);
+    mark(ts, 10);
+    mark(ts, 11);
+    chain_wait(lds, 1, tiles0 + 16);
+    chain_wait(lds, 2, tiles0 + 16);      // nobody reads conv3's weights any more
+    zero_row(lds + kActOff, 0, kS48, 48, tid);
+    zero_row(lds + kActOff, 257, kS48, 48, tid);
+    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kSlot1 + lane * 4, acc[1], bias4(3, 1), NoPre(),
+                         [&](auto tag) {
+                             constexpr int SP = decltype(tag)::value;
+                             // conv5's (3 pieces) and conv6's (9) weights, to the upper buffer
+                             if constexpr (SP == 0) {
+                                 dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
+                                                                    lds + kW5, lane, wave);
+                                 dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                        lds + kW6, lane, wave, 0);
+                             }
+                             if constexpr (SP == 2)
+                                 dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
+                                                                        lds + kW6, lane, wave, 1);
+                             if constexpr (SP == 1) store(c0, c0, acc[0]);
+                             if constexpr (SP == 3) store(c0, c1, acc[0]);
+                         });
+    chain_arrive(lds, lane, 1);
+    w43t_tile<-1, 12, 18>(
+        U, Y, h_addr, lds + kSlot2 + lane * 4, acc[0], bias4(3, 2),
+        [&](auto tag) {      // slot 0: every wave has left conv4's tile 0 - conv7's first third
+            if constexpr (decltype(tag)::value == 0) chain_wait(lds, 0, tiles0 + 24);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) store(c1, c0, acc[1]);
+            if constexpr (SP == 3) store(c1, c1, acc[1]);
+            if constexpr (SP < kThirdPieces) third(6, 0, lds + kSlot0, SP);
+        });
+    mark(ts, 12);
+    store(c2, c0, acc[0]);
+    store(c2, c1, acc[0]);
+    chain_arrive(lds, lane, 2);
+    // conv5 (next) multiplies the rows this wave has just written by weights that waves 0-2 asked
+    // for in tile 1: landed once every wave has arrived behind that tile
+    chain_wait(lds, 1, tiles0 + 24);
+    mark(ts, 13);
+}
+
+struct NoBetween {
+    __device__ __forceinline__ void operator()(int) const {}
+};
 
 // ---------------------------------------------------------------------------------------------
 // F(4,3) at L = 256 (conv7 + MaxPool + BN): 64 quads = four tiles of 16 for eight waves, 864 MFMAs
@@ -2257,7 +2445,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                                   : kTabBn0 + (i - (kTabBias1 - kTabBias0));
         lds[kParams + i] = packed_entry[src];
     }
-    if (tid_entry < 2) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
+    if (tid_entry < 16) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
     if (tid_entry < 8) reinterpret_cast<unsigned*>(lds + kPairSync)[tid_entry] = 0u;
     // conv1d_1's weights as the A operand of its transposed MFMAs: lane (m, k) holds w[k][16g + m]
     // for the three channel groups g (tap k = lane >> 4; the fourth k is a zero column).  Its bias
@@ -2269,7 +2457,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         for (int g = 0; g < 3; ++g)
             bw_a[g] = (q_e < 3) ? packed_entry[weight_offset(0) + q_e * 48 + g * 16 + n_e] : 0.f;
     }
-    unsigned sync_rounds = 0;     // arrivals the split barrier has seen so far (8 per round)
+    unsigned chain_windows = 0;   // windows this workgroup has taken through stage B (stage_b_chain)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
     unsigned pair_rounds = 0;     // exchanges the wave pairs of conv7 have made so far
 
@@ -2332,9 +2520,16 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // behind the barrier of the window statistics, and a second barrier waits for the weights.
     ConvAIn in_a;
     bool cold;
+    // the zero rows of stage B's halo arrays ('same' padding at the two ends of the window; the
+    // place is taken by other stages' weights in between): published by the barriers below
+    if (tid < 192) {
+        const int a = tid / 48, c = tid - a * 48;
+        lds[kHalo + (a >> 1) * 2 * kHaloRows + ((a & 1) ? kHaloRows + 48 : 8 * 96) + c] = 0.f;
+    }
     {
-        // quad of this lane's MFMA column: j = 16 wave + pm(n) (the order of w43_epilogue_half)
-        const int j = wave * 16 + 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
+        // quad of this lane's MFMA column: j = 16 wave + n (stage_b_chain: the neighbours of a quad
+        // sit in the neighbouring lanes)
+        const int j = wave * 16 + n;
         auto fetch_conv2_weights = [&] {      // all three thirds (slots 0..2 are adjacent)
             dma_weights<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         };
@@ -2421,35 +2616,28 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
-    // Winograd F(4,3) layers (see w43_layer).  Third t of a layer (= what N tile t needs) always
-    // lives in slot t; the next layer's third t is requested when every wave has left tile t.
-    // piece i of this wave's share of a third (i < 0: all of them at once)
-    auto third = [&](int conv, int t, float* dst, int i) {
-        if (i < 0)
-            dma_weights<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave);
-        else
-            dma_weights_one<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
-    };
-    // (kernel arguments the code behind conv2 needs: read from the kernarg segment HERE, so that
-    // their scalar loads are long back when conv3's hand-counted LDS waits begin - lgkmcnt counts
+    // One chain in registers (stage_b_chain): nine Winograd F(4,3) tiles back to back, no
+    // workgroup barrier, no activation image between the layers.
+    // (kernel arguments the code behind stage B needs: read from the kernarg segment HERE, so that
+    // their scalar loads are long back when the hand-counted LDS waits begin - lgkmcnt counts
     // scalar loads too, and the first wait of a tile would sit out their round trip)
     const bool thirds_here_done = thirds_ahead;      // (requested in the window before: stage F)
     const long long* __restrict__ offsets_arg = glob(args()->offsets);
     const int steps_arg = args()->steps;
     const int side_arg = args()->side;
     const bool seam_b2 = smp_opaque != nullptr;
-    // conv2 with conv1 inside its tile 0.  In the steady state thirds 1 and 2 of its weights are
-    // requested between conv1's first MFMAs, one piece after each (a request costs ~100 cycles of
-    // issue; 36 pieces = 4 or 5 per wave), and land before the mid-layer barrier.
-    w43_layer<1, false, -1, true>(
-        lds, packed, tid, lane, wave, ts, 2, sync_rounds,
-        [&](int t, float* dst, int i) { third(2, t, dst, i); }, &in_a,
+    // In the steady state thirds 1 and 2 of conv2's weights are requested between conv1's first
+    // MFMAs, one piece after each (a request costs ~100 cycles of issue; 36 pieces = 4 or 5 per
+    // wave) - unless the window before has asked for them already.
+    stage_b_chain(
+        lds, packed, tid, lane, wave, ts, chain_windows, in_a, !cold && !thirds_here_done,
         [&](int i) {
             if (!cold && !thirds_here_done && i < (2 * kWinoHalf / 256 + kWaves - 1) / kWaves)
                 dma_weights_one<2 * kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1,
                                                lane, wave, i);
         },
         [&] {
+            // (this wave's arrival has waited for the atomic's answer)
             if (win_counter != nullptr && tid == 0) {
                 reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
                 // n_windows numbers are taken per launch, whatever the grid: this was the last
@@ -2457,55 +2645,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             }
         });
     if (stop_stage == 0) return;      // (debug_stage 0: tile 0 has written the dump itself)
-    // where this workgroup's NEXT window starts: known behind conv2's end barrier, needed at the
-    // top of stage E
-    const long next_win = win_counter != nullptr
-                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
-                              : win + (long)gridDim.x;
-    win_after = next_win;
-    const bool has_next = seam_b2 && next_win < n_windows;
-    // Its read's place in the sample buffer: two VECTOR loads (the address made per-lane on
-    // purpose) whose results nobody looks at before stage D.  As scalar loads they counted
-    // against lgkmcnt, and the first hand-counted LDS wait of the layer that follows - tile 0 of
-    // conv3 - sat out their whole L2 round trip (~0.9k cycles per window, in conv2's tile 0 when
-    // this stood in front of it: profiles/r03_v1 against r04).
-    long long next_off0 = 0, next_off1 = 0;
-    int next_step = 0;
-    if (has_next) {
-        unsigned next_read;
-        split_window((unsigned)next_win, steps_arg, &next_read, &next_step);
-        unsigned lane_zero = 0;
-        asm volatile("" : "+v"(lane_zero));
-        next_off0 = offsets_arg[next_read + lane_zero];
-        next_off1 = offsets_arg[next_read + lane_zero + 1];
-    }
-    // (before conv3's mid-layer barrier - which waits for everything anyway - the two offset
-    // loads are looked at once: hipcc's wait-count pass then knows they have landed.  Left
-    // "pending" - they are issued under a condition, and the pass merges control flow
-    // pessimistically - the first instruction that reuses one of their registers, in conv8's first
-    // step, waited for all but one of the wave's outstanding requests: the LDS-DMA of conv9's
-    // weights just asked for, a whole L2 round trip per window.)
-    w43_layer<2, false, -1, true>(
-        lds, packed, tid, lane, wave, ts, 6, sync_rounds,
-        [&](int t, float* dst, int i) { third(3, t, dst, i); }, nullptr, NoBetween(), NoHook(),
-        [&] { asm volatile("" : "+v"(next_off0), "+v"(next_off1)); });
-    // conv4 + MaxPool + BN2; conv7's thirds follow conv4's out of the slots, and conv5's and
-    // conv6's weights go to the upper buffer once conv4 has read the rows there (tile 0 done)
-    w43_layer<3, true, 1, false>(lds, packed, tid, lane, wave, ts, 10, sync_rounds,
-                          [&](int t, float* dst, int i) {
-                              third(6, t, dst, i);   // conv7's six F(4,3) matrices, a third a slot
-                              // conv5's (3 pieces) and conv6's (9) weights: with the first pieces,
-                              // long before conv4's split barrier vouches for them
-                              if (t == 0 && i == 0) {
-                                  dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
-                                                                     lds + kW5, lane, wave);
-                                  dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                         lds + kW6, lane, wave, 0);
-                              }
-                              if (t == 0 && i == 1)
-                                  dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                         lds + kW6, lane, wave, 1);
-                          });
     if (stop_stage == 1) {
         full_barrier();      // (conv4 ends without one)
         if (debug_stage < 100)
@@ -2526,8 +2665,37 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // conv5's barrier - gets conv7's last third then.
     inplace_layer<4, kW5, 256, kS48, kS16, false, -1, 0, kActOff, kMid16>(
         lds, packed, nullptr, nullptr, tid, lane, wave, ts, 14);
-    third(6, 2, lds + kSlot2, -1);
+    // (behind conv5's barrier every wave has left conv4: slots 1 and 2 take conv7's other thirds)
+    dma_weights<2 * kWinoHalf>(packed + weight_offset(6) + kWinoHalf, lds + kSlot1, lane, wave);
+    // where this workgroup's NEXT window starts: written by thread 0 early in stage B, published
+    // by conv5's barrier, needed at the top of stage E
+    const long next_win = win_counter != nullptr
+                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
+                              : win + (long)gridDim.x;
+    win_after = next_win;
+    const bool has_next = seam_b2 && next_win < n_windows;
+    // Its read's place in the sample buffer: two VECTOR loads (the address made per-lane on
+    // purpose) whose results nobody looks at before stage D.  As scalar loads they counted
+    // against lgkmcnt, and the first hand-counted LDS wait of the layer that follows sat out their
+    // whole L2 round trip.
+    long long next_off0 = 0, next_off1 = 0;
+    int next_step = 0;
+    if (has_next) {
+        unsigned next_read;
+        split_window((unsigned)next_win, steps_arg, &next_read, &next_step);
+        unsigned lane_zero = 0;
+        asm volatile("" : "+v"(lane_zero));
+        next_off0 = offsets_arg[next_read + lane_zero];
+        next_off1 = offsets_arg[next_read + lane_zero + 1];
+    }
     w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
+    // (behind conv6's closing barrier - which has waited for everything - the two offset loads
+    // are looked at once: hipcc's wait-count pass then knows they have landed.  Left "pending" -
+    // they are issued under a condition, and the pass merges control flow pessimistically - the
+    // first instruction that reuses one of their registers, in conv8's first step, waited for all
+    // but one of the wave's outstanding requests: the LDS-DMA of conv9's weights just asked for, a
+    // whole L2 round trip per window.)
+    asm volatile("" : "+v"(next_off0), "+v"(next_off1));
     // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
     // activation buffer meanwhile
     w43_nsplit_pooled_layer<6, 2>(
@@ -2617,9 +2785,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         prefetched = has_next;
         if (has_next) {
             in_cnt = next_cnt;
-            fetch_window_at(next_src, next_cnt, next_pad, tid,
-                            wave * 16 + 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1), q, in_v0, in_v1,
-                            in_raw);
+            fetch_window_at(next_src, next_cnt, next_pad, tid, wave * 16 + n, q, in_v0, in_v1, in_raw);
         }
         // (3) E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
         // wave 6 conv12, wave 7 conv14

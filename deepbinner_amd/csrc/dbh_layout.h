@@ -138,8 +138,13 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // and Winograd-transformed in place, ARE conv1d_2's A fragments if k-step s = 4g + r of conv1d_2
 // contracts over channels {16g + 4q + r : q = 0..3} - a permutation of the input channels that
 // only the packer needs to know about (dbh_api.hip: pack_weights).
+// conv1d_3 and conv1d_4 take the same order (round 5): all of stage B runs in that TRANSPOSED
+// orientation (M = 16 output channels, N = 16 quads), so that a layer's accumulators - lane
+// (quad, q), registers = channels 16t + 4q + r - are, after the output transform, ReLU and the next
+// input transform (all in-lane but for one halo position each side), the next layer's B operand.
+constexpr bool chained(int conv) { return conv >= 1 && conv <= 3; }
 constexpr int frag_cin(int conv, int sp, int q, int e) {
-    return conv == 1 ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
+    return chained(conv) ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,6 +189,20 @@ static_assert(kMid16 + 258 * kS16 <= kW0, "");
 constexpr int kW5 = kMid16 + 258 * kS16;     // 18,060
 constexpr int kW6 = kW5 + 1 * 48 * 16;
 static_assert((kW5 * 4) % 16 == 0 && (kW6 * 4) % 16 == 0 && kW6 + 4 * 16 * 48 <= kW0, "");
+// Stage B chained in registers (dbh_forward.hip: stage_b_chain): the activation buffer is idle from
+// the top of a window until conv1d_4's pooled outputs arrive, so conv1d_3's three thirds wait there
+// (a ring of six slots with the weight area: conv2 in slots 0-2, conv3 here, conv4 in slots 0-2
+// again as conv2 leaves them) ...
+constexpr int kChainW3 = kActOff;
+static_assert((kChainW3 * 4) % 16 == 0 && kChainW3 + 3 * kWinoHalf <= kW5, "");
+// ... and the halo rows the waves hand each other between two layers live above conv6's weights:
+// per layer output (conv2's, conv3's) two arrays [9 rows][2 sides][48 channels] - position 0 of a
+// wave's first quad and position 3 of its last, written by its lanes n = 0 (side 0) and n = 15
+// (side 1); A0 row w = wave w's, A3 row w + 1 = wave w's.  Wave w reads its right halo from
+// A0[w + 1][0] and its left halo from A3[w][1]; A0[8][0] and A3[0][1] stay zero = 'same' padding.
+constexpr int kHaloRows = 9 * 2 * 48;                        // 864 floats per array
+constexpr int kHalo = kW6 + 4 * 16 * 48;                     // 21,900
+static_assert((kHalo * 4) % 16 == 0 && kHalo + 4 * kHaloRows <= kW0, "");
 // conv7's pair exchange: two f4 per lane and wave, in activation rows its pooled output leaves free
 constexpr int kX7 = 130 * kS48;
 static_assert((kX7 * 4) % 16 == 0 && kX7 + 8 * 512 <= 258 * kS48, "");
@@ -265,8 +284,11 @@ constexpr int kTabBias0 = bias_offset(0), kTabBias1 = bias_offset(16);
 constexpr int kTabBn0 = bn_scale_offset(0), kTabBn1 = bn_scale_offset(4);
 constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 672 + 384
 constexpr int kSync = kParams + kParamFloats;
+// 16 words: [0..2] arrivals at the end of tile t of a stage-B layer (dbh_forward.hip: chain_arrive),
+// [4..11] wave w's halo posts (halo_post)
+constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4;
 // window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
-constexpr int kStatRed = kSync + 2;
+constexpr int kStatRed = kSync + 16;
 constexpr int kStatOut = kStatRed + 32;
 static_assert(kStatRed % 2 == 0, "64-bit words");
 // one counter word per half of each of conv7's four wave pairs (dbh_forward.hip: pair_signal)
