@@ -50,6 +50,13 @@
 #ifndef DBH_EXP_A_DMA_UNDER_MFMA
 #define DBH_EXP_A_DMA_UNDER_MFMA 1
 #endif
+// timing-only ablations of stage_b_chain (results wrong on purpose; tools/ab_variants.sh):
+// 1 = no polls, 2 = no edge rows / posts, 4 = no LDS-DMA requests, 8 = no output / input
+// transforms of conv2 -> conv3 -> conv4, 16 = no epilogue of conv4, 32 = no arrivals, 64 = no halo polls,
+// 128 = no tile-word polls
+#ifndef DBH_ABL
+#define DBH_ABL 0
+#endif
 
 // This file is compiled twice by dbh_api.hip: as namespace dbh with DBH_TIMELINE 0 (the product)
 // and as namespace dbh_timeline with DBH_TIMELINE 1 (cycle stamps for tools/timeline.py).  The
@@ -86,25 +93,46 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 //           SP <= SPTOT is how many channel-pairs groups this call walks (split-K).
 // All offsets are compile-time so every access is base + immediate.
 // ---------------------------------------------------------------------------------------------
-// Cycle-stamp for the timeline mode (debug_stage 300): ts is non-null only in lane 0 of each
-// wave and points at that wave's 64 slots.
+// Cycle stamps for the timeline mode (debug_stage 300): ts is non-null in timeline launches and
+// points at ONE register of the wave whose lane `id` takes stamp `id` (v_writelane: no memory
+// traffic - a global store per stamp made every vmcnt(0) of the kernel, the arrivals of stage B
+// among them, wait for it); the register goes out as one coalesced store at the end of the window
+// (flush_marks).  Stamps are the low 32 bits of the counters.
 // The constant 100 MHz clock beside the shader clock of mark(): two of these per window give the
 // shader clock's frequency while the kernel runs (tools/timeline.py) - it is below the 2.4 GHz the
 // peak figures assume.
-__device__ __forceinline__ void mark_realtime(long long* ts, int id) {
+__device__ __forceinline__ void mark_realtime(unsigned* ts, int id) {
 #if DBH_TIMELINE
-    if (ts) ts[id] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (ts) {
+        const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(*ts) : "s"(now), "n"(id));
+    }
 #else
     (void)ts;
     (void)id;
 #endif
 }
-__device__ __forceinline__ void mark(long long* ts, int id) {
+__device__ __forceinline__ void mark(unsigned* ts, int id) {
 #if DBH_TIMELINE
-    if (ts) ts[id] = (long long)__builtin_readcyclecounter();
+    if (ts) {
+        const unsigned now = (unsigned)__builtin_readcyclecounter();
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(*ts) : "s"(now), "n"(id));
+    }
 #else
     (void)ts;
     (void)id;
+#endif
+}
+__device__ __forceinline__ void flush_marks(unsigned* ts, long long* out, int lane) {
+#if DBH_TIMELINE
+    if (ts) {
+        out[lane] = (long long)*ts;
+        *ts = 0u;
+    }
+#else
+    (void)ts;
+    (void)out;
+    (void)lane;
 #endif
 }
 
@@ -187,6 +215,25 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 template <int STEP, int STEPS>
 __device__ __forceinline__ void progress_priority() {
     __builtin_amdgcn_s_setprio(3 - (4 * STEP) / STEPS);
+}
+
+// how many of the eight waves issue stage B's LDS-DMA requests (the low ones: they run ahead of
+// their partners on the same SIMDs anyway, and a request is ~100 cycles of issue during which the
+// partner has the matrix pipe to itself)
+#ifndef DBH_DMA_WAVES
+#define DBH_DMA_WAVES 4
+#endif
+// where in a layer's 18 steps the priority schedule of stage B starts over (the step whose
+// priority is 3 again).  At that wrap the wave in front has priority 3 against the 0 of the one
+// behind and pulls away, so it must not lie at the layer's first steps, where the halo rows of the
+// neighbours are needed: there the schedule should take a normal step DOWN, which lets whoever is
+// behind catch up.
+#ifndef DBH_PRIO_PHASE
+#define DBH_PRIO_PHASE 12
+#endif
+template <int STEP, int STEPS>
+__device__ __forceinline__ void progress_priority_pair(bool) {
+    __builtin_amdgcn_s_setprio(3 - (4 * ((STEP + DBH_PRIO_PHASE) % STEPS)) / STEPS);
 }
 
 template <int MT, int NT>
@@ -455,6 +502,7 @@ __device__ __forceinline__ f2 buffer_load_f2(__amdgpu_buffer_rsrc_t view, unsign
 // nothing else in this kernel uses M0.
 __device__ __forceinline__ void dma_piece(const float* g_piece, const float* lds_piece,
                                           unsigned lane_bytes) {
+    if (DBH_ABL & 4) return;
     const unsigned m0v = lds_addr(lds_piece);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :
@@ -477,12 +525,13 @@ __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* 
 
 // The i-th piece of this wave's share of the same copy (i < ceil(pieces / waves)): for callers
 // that spread the requests between their own instructions.
-template <int NFLOATS>
+template <int NFLOATS, int NW = kWaves>
 __device__ __forceinline__ void dma_weights_one(const float* __restrict__ g, float* lds_dst,
                                                 int lane, int wave, int i) {
     constexpr int kPieces = NFLOATS / 256;
-    const int piece = wave + kWaves * i;
-    if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, (unsigned)lane * 16u);
+    const int piece = wave + NW * i;
+    if (wave < NW && piece < kPieces)
+        dma_piece(g + piece * 256, lds_dst + piece * 256, (unsigned)lane * 16u);
 }
 
 // The same copy, spread over the NIT steps of the running layer (step IT issues its share).
@@ -525,7 +574,7 @@ template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, i
           int IN_OFF = kActOff, int OUT_OFF = kActOff, class Side = NoSide>
 __device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
                                               const float* __restrict__ next_g, float* next_lds,
-                                              int tid, int lane, int wave, long long* ts,
+                                              int tid, int lane, int wave, unsigned* ts,
                                               int ts_base, const Side& side = Side()) {
     constexpr int TAPS = kConv[CONV].taps;
     constexpr int SP = kConv[CONV].cin / 8;
@@ -831,7 +880,7 @@ __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned
 
 template <int CONV, int W_LDS, int IN_OFF, int OUT_OFF>
 __device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restrict__ packed,
-                                                int tid, int lane, int wave, long long* ts,
+                                                int tid, int lane, int wave, unsigned* ts,
                                                 int ts_base) {
     static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV) && kConv[CONV].cin == 16 &&
                   kConv[CONV].cout_pad == 48 && IN_OFF != OUT_OFF, "");
@@ -1078,6 +1127,7 @@ struct ConvAIn {
     float* dump;          // debug_stage 0: where this lane's 4 x 12 outputs go
     bool dump_on;         // (wave-uniform)
     bool stop;            // debug_stage 0 / 100: the kernel ends behind tile 0
+    bool wave_hi;         // wave >= 4 (progress_priority_pair)
 };
 
 // ReLU and BN1 of the six rows of one channel pair: x * 1 with the clamp modifier (activations are
@@ -1144,7 +1194,7 @@ __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
     asm volatile("" : "+v"(par[0]), "+v"(par[1]));
-    progress_priority<SP, 18>();
+    progress_priority_pair<SP, 18>(in.wave_hi);
     __builtin_amdgcn_sched_barrier(0);
     f2 d[6], v[6];
 #pragma unroll
@@ -1251,13 +1301,19 @@ typedef __attribute__((address_space(3))) f2 lds_f2;
 constexpr int kThirdPieces = (kWinoHalf / 256 + kWaves - 1) / kWaves;
 static_assert(kThirdPieces == 3, "");
 
-__device__ __forceinline__ void chain_arrive(float* lds, int lane, int t) {
-    const unsigned addr = lds_addr(lds + kSyncTiles + t);
+// (no lane mask on the adds and edge stores below: changing EXEC right behind a block of MFMAs
+// cost 0.7 % of the kernel - profiles/r05_ablation.txt - so every lane takes part, the lanes that
+// have nothing to say with an address of their own in a 1 KB scratch, kChainDummy)
+// arrive_addr: lane 0 -> word 0 of kSyncTiles, the others -> scratch (chain_addresses)
+__device__ __forceinline__ void chain_arrive(unsigned arrive_addr, int t) {
+    if (DBH_ABL & 32) return;
     // release: this wave's LDS reads are done and its LDS-DMA pieces have landed
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tds_add_u32 %0, %1 offset:%2" ::"v"(arrive_addr), "v"(1u),
+                 "n"(t * 4)
+                 : "memory");
 }
 __device__ __forceinline__ void chain_wait(float* lds, int t, unsigned target) {
+    if (DBH_ABL & (1 | 32 | 128)) return;
     const unsigned addr = lds_addr(lds + kSyncTiles + t);
     for (;;) {
         unsigned seen;
@@ -1266,27 +1322,61 @@ __device__ __forceinline__ void chain_wait(float* lds, int t, unsigned target) {
         __builtin_amdgcn_s_sleep(1);
     }
 }
-// (plain LDS instructions: a wave's requests are served in order, so the add lands behind the edge
-// rows stored before it)
-__device__ __forceinline__ void halo_post(float* lds, int wave, int lane) {
-    const unsigned addr = lds_addr(lds + kSyncHalo + wave);
-    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+// The polls above cost an LDS round trip each with nothing else issued by the wave; where the
+// answer is almost always "yes" the word is PEEKED a step ahead - the read rides in front of a
+// step's fragment requests, whose hand-counted wait retires it - and only looked at here.
+__device__ __forceinline__ unsigned chain_peek(float* lds, int t) {
+    unsigned seen;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + kSyncTiles + t)) : "memory");
+    return seen;
 }
-// both neighbours of `wave` have posted `target` times (the outer waves have one neighbour)
+__device__ __forceinline__ void chain_check(float* lds, int t, unsigned peeked, unsigned target) {
+    if (DBH_ABL & (1 | 32 | 128)) return;
+    asm volatile("" : "+v"(peeked));     // (the use stays behind the wait that retired the read)
+    if ((int)(__builtin_amdgcn_readfirstlane(peeked) - target) >= 0) return;
+    chain_wait(lds, t, target);
+}
+// Halo posts: wave w owns the word pair kSyncHalo + 2w = {posts of wave w - 1, posts of wave w + 1}
+// (an outer wave stands in for its missing neighbour itself), so that one 8-byte read answers
+// "have both my neighbours stored the edge rows of tile g".  post_addr: lane 0 -> the right
+// neighbour's first word, lane 1 -> the left neighbour's second (halo_post_address).
+// (plain LDS instructions: a wave's requests are served in order, so the adds land behind the edge
+// rows stored before them)
+__device__ __forceinline__ unsigned halo_post_address(float* lds, int wave, int lane) {
+    const int right = wave < kWaves - 1 ? 2 * (wave + 1) : 2 * wave + 1;
+    const int left = wave > 0 ? 2 * (wave - 1) + 1 : 0;
+    return lds_addr(lane < 2 ? lds + kSyncHalo + (lane == 0 ? right : left)
+                             : lds + kChainDummy + 176 + lane);
+}
+__device__ __forceinline__ void halo_post(unsigned post_addr) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(post_addr), "v"(1u) : "memory");
+}
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool halo_ready(u2 seen, unsigned target) {
+    const int da = (int)(__builtin_amdgcn_readfirstlane(seen.x) - target);
+    const int db = (int)(__builtin_amdgcn_readfirstlane(seen.y) - target);
+    return da >= 0 && db >= 0;
+}
 __device__ __forceinline__ void halo_wait(float* lds, int wave, unsigned target) {
-    const unsigned lo = lds_addr(lds + kSyncHalo + (wave > 0 ? wave - 1 : wave + 1));
-    const unsigned hi = lds_addr(lds + kSyncHalo + (wave < kWaves - 1 ? wave + 1 : wave - 1));
+    if (DBH_ABL & (1 | 2 | 8 | 64)) return;
+    const unsigned addr = lds_addr(lds + kSyncHalo + 2 * wave);
     for (;;) {
-        unsigned a, b;
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a), "=&v"(b)
-                     : "v"(lo), "v"(hi)
-                     : "memory");
-        const int da = (int)(__builtin_amdgcn_readfirstlane(a) - target);
-        const int db = (int)(__builtin_amdgcn_readfirstlane(b) - target);
-        if (da >= 0 && db >= 0) break;
+        u2 seen;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(addr) : "memory");
+        if (halo_ready(seen, target)) break;
         __builtin_amdgcn_s_sleep(1);
     }
+}
+__device__ __forceinline__ u2 halo_peek(float* lds, int wave) {
+    u2 seen;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + kSyncHalo + 2 * wave)) : "memory");
+    return seen;
+}
+__device__ __forceinline__ void halo_check(float* lds, int wave, u2 peeked, unsigned target) {
+    if (DBH_ABL & (1 | 2 | 8 | 64)) return;
+    asm volatile("" : "+v"(peeked));
+    if (halo_ready(peeked, target)) return;
+    halo_wait(lds, wave, target);
 }
 
 // lane n <- lane n - 1 / n + 1 of its row of 16; the row's first / last lane keeps `edge`
@@ -1333,8 +1423,9 @@ __device__ __forceinline__ void w43t_load_halo(f2 (&hb)[2], unsigned h_addr) {
 template <int HOFF, int STEP0, int STEPS, int SP, class Pre, class Side>
 __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
                                           unsigned b_addr, f2 (&hbuf)[2][2], f4 (&buf)[2][3],
-                                          f4 (&acc)[6], f4 bias4, const Pre& pre, const Side& side) {
-    constexpr bool BUILD = HOFF >= 0;
+                                          f4 (&acc)[6], f4 bias4, bool wave_hi, const Pre& pre,
+                                          const Side& side) {
+    constexpr bool BUILD = HOFF >= 0 && !(DBH_ABL & 8);
     pre(IntC<SP>{});
     if constexpr (SP + 1 < 6) {
         if constexpr (BUILD) w43t_load_halo<SP + 1, (BUILD ? HOFF : 0)>(hbuf[(SP + 1) & 1], h_addr);
@@ -1347,7 +1438,7 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     f4(&b)[3] = buf[SP & 1];
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
-    progress_priority<STEP0 + SP, STEPS>();
+    progress_priority_pair<STEP0 + SP, STEPS>(wave_hi);
     if constexpr (BUILD) {
         f2(&hb)[2] = hbuf[SP & 1];
         asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
@@ -1374,19 +1465,25 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     side(IntC<SP>{});
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP + 1 < 6)
-        w43t_step<HOFF, STEP0, STEPS, SP + 1>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, pre, side);
+        w43t_step<HOFF, STEP0, STEPS, SP + 1>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre,
+                                              side);
 }
 
-template <int HOFF, int STEP0, int STEPS, class Pre, class Side>
+// bias_addr: this lane's place in the LDS parameter table (kParams + 4q); BIAS_OFF: floats from
+// there to the tile's four biases - requested first, so that step 0's hand-counted wait retires it
+// (a load the compiler sees would be waited for with lgkmcnt(0), fragment requests and all)
+template <int HOFF, int STEP0, int STEPS, int BIAS_OFF, class Pre, class Side>
 __device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
-                                          const float* slot_lane, f4 (&acc)[6], f4 bias4,
-                                          const Pre& pre, const Side& side) {
+                                          unsigned bias_addr, const float* slot_lane,
+                                          f4 (&acc)[6], bool wave_hi, const Pre& pre,
+                                          const Side& side) {
     const unsigned b_addr = lds_addr(slot_lane);
     f2 hbuf[2][2];
     f4 buf[2][3];
-    if constexpr (HOFF >= 0) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0)>(hbuf[0], h_addr);
+    const f4 bias4 = ds_read_f4<BIAS_OFF * 4>(bias_addr);
+    if constexpr (HOFF >= 0 && !(DBH_ABL & 8)) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0)>(hbuf[0], h_addr);
     w43_load_b<0>(buf[0], b_addr);
-    w43t_step<HOFF, STEP0, STEPS, 0>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, pre, side);
+    w43t_step<HOFF, STEP0, STEPS, 0>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre, side);
 }
 
 struct NoPre {
@@ -1400,7 +1497,7 @@ struct NoPre {
 // asked of global memory has landed there).
 template <class BetweenA, class AfterFirst>
 __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restrict__ packed, int tid,
-                                              int lane, int wave, long long* ts,
+                                              int lane, int wave, unsigned* ts,
                                               unsigned& chain_windows, const ConvAIn& in_a,
                                               bool thirds_here, const BetweenA& between_a,
                                               const AfterFirst& after_first) {
@@ -1408,13 +1505,31 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 6u;
     chain_windows += 1;
     const unsigned h_addr = lds_addr(lds + kHalo + wave * 96 + 4 * q);
-    const bool is_edge = n == 0 || n == 15;
-    lds_f2* edge = (lds_f2*)lds_pinned(lds + kHalo + (wave * 2 + (n == 15 ? 1 : 0)) * 48 + 4 * q);
+    // where a lane's row 0 (A0) and row 3 (A3) go per layer output: the halo arrays for the lanes
+    // that hold the wave's first and last quad, scratch for the others
+    // (one compare: written as n == 0 || n == 15 hipcc lowers the selects below to a switch over
+    // exec masks - and lost the first of them)
+    const bool is_edge = ((n + 1) & 15) < 2;
+    const unsigned edge_addr = lds_addr(lds + kHalo + (wave * 2 + (n == 15 ? 1 : 0)) * 48 + 4 * q);
+    const unsigned dummy_addr = lds_addr(lds + kChainDummy + 2 * lane);
+    unsigned a0_addr[2], a3_addr[2];
+#pragma unroll
+    for (int L = 0; L < 2; ++L) {
+        a0_addr[L] = is_edge ? edge_addr + L * 2 * kHaloRows * 4 : dummy_addr;
+        a3_addr[L] = is_edge ? edge_addr + (L * 2 * kHaloRows + kHaloRows + 96) * 4 : dummy_addr;
+        asm volatile("" : "+v"(a0_addr[L]), "+v"(a3_addr[L]));
+    }
+    const unsigned post_addr = halo_post_address(lds, wave, lane);
+    const unsigned arrive_addr =
+        lds_addr(lane == 0 ? lds + kSyncTiles : lds + kChainDummy + 176 + 64 + lane);
     lds_f2* out = (lds_f2*)lds_pinned(lds + kActOff + (1 + 2 * (wave * 16 + n)) * kS48 + 4 * q);
     const f4* tab4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);
-    auto bias4 = [&](int conv, int t) { return tab4[(bias_offset(conv) - kTabBias0) / 4 + 4 * t]; };
+    const unsigned bias_addr = lds_addr(lds + kParams + 4 * q);
     static_assert((bias_offset(1) - kTabBias0) % 4 == 0 && (bn_scale_offset(1) - kTabBn0) % 4 == 0 &&
                   (kTabBias1 - kTabBias0) % 4 == 0, "");
+    constexpr int B2 = bias_offset(1) - kTabBias0, B3 = bias_offset(2) - kTabBias0,
+                  B4 = bias_offset(3) - kTabBias0;
+    const bool wave_hi = wave >= 4;
     W43U U;
     f4 acc[2][6];
     f2 Y[3][2][4];
@@ -1422,17 +1537,21 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     // two edge rows to the halo arrays, and the post that announces a finished tile
     auto finish = [&](auto L_tag, auto g_tag, auto h_tag, const f4(&a)[6]) {
         constexpr int L = decltype(L_tag)::value, g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        if (DBH_ABL & 8) return;
         w43t_outputs<h>(a, Y[g][h]);
-        if (is_edge) {
-            edge[(L * 2 * kHaloRows + 16 * g + 2 * h) / 2] = Y[g][h][0];
-            edge[(L * 2 * kHaloRows + kHaloRows + 96 + 16 * g + 2 * h) / 2] = Y[g][h][3];
-        }
-        if constexpr (h == 1) halo_post(lds, wave, lane);
+        if (DBH_ABL & 2) return;
+        asm volatile("ds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %1, %3 offset:%4"
+                     :
+                     : "v"(a0_addr[L]), "v"(a3_addr[L]), "v"(Y[g][h][0]), "v"(Y[g][h][3]),
+                       "n"((16 * g + 2 * h) * 4)
+                     : "memory");
+        if constexpr (h == 1) halo_post(post_addr);
     };
     // half h of the epilogue of tile g of conv4: outputs, MaxPool2, BN2, two rows of the image
     // stage C reads
     auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
         constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        if (DBH_ABL & 16) return;
         f2 y[4];
         w43t_outputs<h>(a, y);
         const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
@@ -1447,142 +1566,197 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     const IntC<0> c0;
     const IntC<1> c1;
     const IntC<2> c2;
+    constexpr int NW = DBH_DMA_WAVES;
+    constexpr int kThirdSteps = (kWinoHalf / 256 + NW - 1) / NW;       // 3 (5 with four waves)
     auto third = [&](int conv, int t, float* dst, int i) {
-        dma_weights_one<kWinoHalf>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
+        dma_weights_one<kWinoHalf, NW>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
     };
+    // conv3's 54 pieces: request i of this wave (7 per wave with eight requesters, 14 with four)
+    auto conv3_piece = [&](int i) {
+        dma_weights_one<3 * kWinoHalf, NW>(packed + weight_offset(2), lds + kChainW3, lane, wave, i);
+    };
+    // words peeked a step ahead of where they are looked at (chain_peek / halo_peek)
+    unsigned pk_a = 0, pk_b = 0;
+    u2 pk_h = u2{0u, 0u};
 
     // ---- conv2 (its tile 0 computes conv1d_1 itself).  conv3's 54 pieces go to the idle
     // activation buffer one behind each of the first seven steps.
-    w43a_tile0(U, in_a, lds, lane, acc[0], bias4(1, 0), between_a, [&](auto tag) {
-        dma_weights_one<3 * kWinoHalf>(packed + weight_offset(2), lds + kChainW3, lane, wave,
-                                       decltype(tag)::value);
-    });
+    {
+        const f4 bias2 = tab4[B2 / 4];
+        w43a_tile0(U, in_a, lds, lane, acc[0], bias2, between_a, [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (NW == 8) {
+                conv3_piece(SP);
+            } else {          // 2, 2, 2, 1, 1, 1
+                if constexpr (SP < 3) {
+                    conv3_piece(2 * SP);
+                    conv3_piece(2 * SP + 1);
+                } else {
+                    conv3_piece(SP + 3);
+                }
+            }
+        });
+    }
     mark(ts, 2);
     if (in_a.stop) return;     // debug_stage 0 / 100: stage A only
-    chain_arrive(lds, lane, 0);
+    chain_arrive(arrive_addr, 0);
     after_first();
-    mark(ts, 3);
     if (thirds_here) chain_wait(lds, 0, tiles0 + 8);      // slots 1, 2: every wave's pieces landed
-    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kSlot1 + lane * 4, acc[1], bias4(1, 1), NoPre(),
-                         [&](auto tag) {
-                             constexpr int SP = decltype(tag)::value;
-                             if constexpr (SP == 0)
-                                 dma_weights_one<3 * kWinoHalf>(packed + weight_offset(2),
-                                                                lds + kChainW3, lane, wave, 6);
-                             if constexpr (SP == 1) finish(c0, c0, c0, acc[0]);
-                             if constexpr (SP == 3) finish(c0, c0, c1, acc[0]);
-                         });
-    chain_arrive(lds, lane, 1);
-    w43t_tile<-1, 12, 18>(U, Y, h_addr, lds + kSlot2 + lane * 4, acc[0], bias4(1, 2), NoPre(),
-                          [&](auto tag) {
-                              constexpr int SP = decltype(tag)::value;
-                              if constexpr (SP == 1) finish(c0, c1, c0, acc[1]);
-                              if constexpr (SP == 3) finish(c0, c1, c1, acc[1]);
-                          });
-    chain_arrive(lds, lane, 2);
+    mark(ts, 3);
+    w43t_tile<-1, 6, 18, B2 + 16>(U, Y, h_addr, bias_addr, lds + kSlot1 + lane * 4, acc[1], wave_hi, NoPre(),
+                                  [&](auto tag) {
+                                      constexpr int SP = decltype(tag)::value;
+                                      if constexpr (NW == 8) {
+                                          if constexpr (SP == 0) conv3_piece(6);
+                                      } else {          // 2, 1, 1, 1
+                                          if constexpr (SP == 0) conv3_piece(9);
+                                          if constexpr (SP < 4) conv3_piece(10 + SP);
+                                      }
+                                      if constexpr (SP == 1) finish(c0, c0, c0, acc[0]);
+                                      if constexpr (SP == 3) finish(c0, c0, c1, acc[0]);
+                                  });
+    chain_arrive(arrive_addr, 1);
     mark(ts, 4);
+    w43t_tile<-1, 12, 18, B2 + 32>(
+        U, Y, h_addr, bias_addr, lds + kSlot2 + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) {
+                pk_a = chain_peek(lds, 1);
+                pk_h = halo_peek(lds, wave);
+            }
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) finish(c0, c1, c0, acc[1]);
+            if constexpr (SP == 3) finish(c0, c1, c1, acc[1]);
+        });
+    chain_arrive(arrive_addr, 2);
     mark(ts, 5);
 
     // ---- conv3.  Tile 2 of conv2 is finished inside the first two steps (its Y is needed in
     // steps 4 and 5, its edge rows by the neighbours in theirs); conv4's third t follows conv2's
     // out of slot t.
-    chain_wait(lds, 1, tiles0 + 8);       // conv3's weights have landed (and slots 0, 1 are free)
-    halo_wait(lds, wave, halos0 + 2);
-    w43t_tile<0, 0, 18>(
-        U, Y, h_addr, lds + kChainW3 + lane * 4, acc[1], bias4(2, 0),
+    chain_check(lds, 1, pk_a, tiles0 + 8);       // conv3's weights have landed (slots 0, 1 are free)
+    halo_check(lds, wave, pk_h, halos0 + 2);
+    mark(ts, 6);
+    w43t_tile<0, 0, 18, B3>(
+        U, Y, h_addr, bias_addr, lds + kChainW3 + lane * 4, acc[1], wave_hi,
         [&](auto tag) {
-            if constexpr (decltype(tag)::value == 3) halo_wait(lds, wave, halos0 + 3);
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 2) pk_h = halo_peek(lds, wave);
+            if constexpr (SP == 3) halo_check(lds, wave, pk_h, halos0 + 3);
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 0) finish(c0, c2, c0, acc[0]);
             if constexpr (SP == 1) finish(c0, c2, c1, acc[0]);
-            if constexpr (SP < kThirdPieces) third(3, 0, lds + kSlot0, SP);
+            if constexpr (SP < kThirdSteps) third(3, 0, lds + kSlot0, SP);
         });
-    chain_arrive(lds, lane, 0);
-    mark(ts, 6);
+    chain_arrive(arrive_addr, 0);
     mark(ts, 7);
-    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kChainW3 + kWinoHalf + lane * 4, acc[0], bias4(2, 1),
-                         NoPre(), [&](auto tag) {
-                             constexpr int SP = decltype(tag)::value;
-                             if constexpr (SP == 1) finish(c1, c0, c0, acc[1]);
-                             if constexpr (SP == 3) finish(c1, c0, c1, acc[1]);
-                             if constexpr (SP < kThirdPieces) third(3, 1, lds + kSlot1, SP);
-                         });
-    chain_arrive(lds, lane, 1);
-    mark(ts, 57);
-    w43t_tile<-1, 12, 18>(
-        U, Y, h_addr, lds + kChainW3 + 2 * kWinoHalf + lane * 4, acc[1], bias4(2, 2),
-        [&](auto tag) {      // slot 2: every wave has left conv2's tile 2
-            if constexpr (decltype(tag)::value == 0) chain_wait(lds, 2, tiles0 + 8);
+    w43t_tile<-1, 6, 18, B3 + 16>(
+        U, Y, h_addr, bias_addr, lds + kChainW3 + kWinoHalf + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) pk_a = chain_peek(lds, 2);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) finish(c1, c0, c0, acc[1]);
+            if constexpr (SP == 3) finish(c1, c0, c1, acc[1]);
+            if constexpr (SP < kThirdSteps) third(3, 1, lds + kSlot1, SP);
+        });
+    chain_arrive(arrive_addr, 1);
+    mark(ts, 8);
+    w43t_tile<-1, 12, 18, B3 + 32>(
+        U, Y, h_addr, bias_addr, lds + kChainW3 + 2 * kWinoHalf + lane * 4, acc[1], wave_hi,
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            // slot 2: every wave has left conv2's tile 2
+            if constexpr (SP == 0) chain_check(lds, 2, pk_a, tiles0 + 8);
+            if constexpr (SP == 5) {
+                pk_a = chain_peek(lds, 0);
+                pk_h = halo_peek(lds, wave);
+            }
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 1) finish(c1, c1, c0, acc[0]);
             if constexpr (SP == 3) finish(c1, c1, c1, acc[0]);
-            if constexpr (SP < kThirdPieces) third(3, 2, lds + kSlot2, SP);
+            if constexpr (SP < kThirdSteps) third(3, 2, lds + kSlot2, SP);
         });
-    chain_arrive(lds, lane, 2);
-    mark(ts, 8);
-    mark(ts, 58);
+    chain_arrive(arrive_addr, 2);
     mark(ts, 9);
 
     // ---- conv4 + MaxPool + BN2 -> rows 1..256 of the activation buffer.  Its first store (and
     // conv5's / conv6's weights) must find every wave out of conv3, whose weights lie there.
-    chain_wait(lds, 0, tiles0 + 16);      // conv4's first third has landed
-    halo_wait(lds, wave, halos0 + 5);
-    w43t_tile<2 * kHaloRows, 0, 18>(
-        U, Y, h_addr, lds + kSlot0 + lane * 4, acc[0], bias4(3, 0),
+    chain_check(lds, 0, pk_a, tiles0 + 16);      // conv4's first third has landed
+    halo_check(lds, wave, pk_h, halos0 + 5);
+    mark(ts, 10);
+    w43t_tile<2 * kHaloRows, 0, 18, B4>(
+        U, Y, h_addr, bias_addr, lds + kSlot0 + lane * 4, acc[0], wave_hi,
         [&](auto tag) {
-            if constexpr (decltype(tag)::value == 3) halo_wait(lds, wave, halos0 + 6);
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 2) pk_h = halo_peek(lds, wave);
+            if constexpr (SP == 3) halo_check(lds, wave, pk_h, halos0 + 6);
+            if constexpr (SP == 5) {
+                pk_a = chain_peek(lds, 1);
+                pk_b = chain_peek(lds, 2);
+            }
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 0) finish(c1, c2, c0, acc[1]);
             if constexpr (SP == 1) finish(c1, c2, c1, acc[1]);
         });
-    chain_arrive(lds, lane, 0);
-    mark(ts, 10);
+    chain_arrive(arrive_addr, 0);
     mark(ts, 11);
-    chain_wait(lds, 1, tiles0 + 16);
-    chain_wait(lds, 2, tiles0 + 16);      // nobody reads conv3's weights any more
+    chain_check(lds, 1, pk_a, tiles0 + 16);
+    chain_check(lds, 2, pk_b, tiles0 + 16);      // nobody reads conv3's weights any more
     zero_row(lds + kActOff, 0, kS48, 48, tid);
     zero_row(lds + kActOff, 257, kS48, 48, tid);
-    w43t_tile<-1, 6, 18>(U, Y, h_addr, lds + kSlot1 + lane * 4, acc[1], bias4(3, 1), NoPre(),
-                         [&](auto tag) {
-                             constexpr int SP = decltype(tag)::value;
-                             // conv5's (3 pieces) and conv6's (9) weights, to the upper buffer
-                             if constexpr (SP == 0) {
-                                 dma_weights<conv_weight_floats(4)>(packed + weight_offset(4),
-                                                                    lds + kW5, lane, wave);
-                                 dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                        lds + kW6, lane, wave, 0);
-                             }
-                             if constexpr (SP == 2)
-                                 dma_weights_one<conv_weight_floats(5)>(packed + weight_offset(5),
-                                                                        lds + kW6, lane, wave, 1);
-                             if constexpr (SP == 1) store(c0, c0, acc[0]);
-                             if constexpr (SP == 3) store(c0, c1, acc[0]);
-                         });
-    chain_arrive(lds, lane, 1);
-    w43t_tile<-1, 12, 18>(
-        U, Y, h_addr, lds + kSlot2 + lane * 4, acc[0], bias4(3, 2),
-        [&](auto tag) {      // slot 0: every wave has left conv4's tile 0 - conv7's first third
-            if constexpr (decltype(tag)::value == 0) chain_wait(lds, 0, tiles0 + 24);
+    mark(ts, 57);
+    w43t_tile<-1, 6, 18, B4 + 16>(
+        U, Y, h_addr, bias_addr, lds + kSlot1 + lane * 4, acc[1], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) pk_a = chain_peek(lds, 0);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            // conv5's (3 pieces) and conv6's (9) weights, to the upper buffer
+            if constexpr (SP == 0) {
+                dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW5, lane, wave);
+                dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 0);
+            }
+            if constexpr (SP == 2)
+                dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 1);
+            if constexpr (SP == 4 && NW < 8)
+                dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 2);
+            if constexpr (SP == 1) store(c0, c0, acc[0]);
+            if constexpr (SP == 3) store(c0, c1, acc[0]);
+        });
+    chain_arrive(arrive_addr, 1);
+    mark(ts, 12);
+    w43t_tile<-1, 12, 18, B4 + 32>(
+        U, Y, h_addr, bias_addr, lds + kSlot2 + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            // slot 0: every wave has left conv4's tile 0 - conv7's first third
+            if constexpr (SP == 0) chain_check(lds, 0, pk_a, tiles0 + 24);
+            if constexpr (SP == 5) pk_a = chain_peek(lds, 1);
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 1) store(c1, c0, acc[1]);
             if constexpr (SP == 3) store(c1, c1, acc[1]);
-            if constexpr (SP < kThirdPieces) third(6, 0, lds + kSlot0, SP);
+            if constexpr (SP < kThirdSteps) third(6, 0, lds + kSlot0, SP);
         });
-    mark(ts, 12);
+    mark(ts, 58);
     store(c2, c0, acc[0]);
     store(c2, c1, acc[0]);
-    chain_arrive(lds, lane, 2);
+    chain_arrive(arrive_addr, 2);
     // conv5 (next) multiplies the rows this wave has just written by weights that waves 0-2 asked
     // for in tile 1: landed once every wave has arrived behind that tile
-    chain_wait(lds, 1, tiles0 + 24);
+    chain_check(lds, 1, pk_a, tiles0 + 24);
     mark(ts, 13);
 }
 
@@ -1711,7 +1885,7 @@ __device__ __forceinline__ void w43_partial_outputs(const f4 (&acc)[6], int h, f
 // One wave's half (HIGH = wave >= 4) of conv7.  begin(): the layer's one-off LDS-DMA requests.
 template <int CONV, int BNI, bool HIGH, class Begin>
 __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restrict__ packed,
-                                                int tid, int lane, int wave, long long* ts,
+                                                int tid, int lane, int wave, unsigned* ts,
                                                 int ts_base, unsigned& pair_rounds,
                                                 const Begin& begin) {
     constexpr int TOWN = HIGH ? 2 : 0, SP0 = HIGH ? 3 : 0;
@@ -1777,7 +1951,7 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
 
 template <int CONV, int BNI, class Begin>
 __device__ __forceinline__ void w43_nsplit_pooled_layer(float* lds, const float* __restrict__ packed,
-                                                        int tid, int lane, int wave, long long* ts,
+                                                        int tid, int lane, int wave, unsigned* ts,
                                                         int ts_base, unsigned& pair_rounds,
                                                         const Begin& begin) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
@@ -1802,7 +1976,7 @@ __device__ __forceinline__ void w43_nsplit_pooled_layer(float* lds, const float*
 template <int CONV, bool POOL, int BNI, int SLOT_A, int SLOT_B, int XCHG, class Side,
           class StepSide = NoSide>
 __device__ __forceinline__ void wino_split_layer(float* lds, const float* __restrict__ packed,
-                                                 int tid, int lane, int wave, long long* ts,
+                                                 int tid, int lane, int wave, unsigned* ts,
                                                  int ts_base, const Side& side,
                                                  const StepSide& step_side = StepSide()) {
     static_assert(kConv[CONV].wino == 2 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
@@ -1958,7 +2132,7 @@ template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, b
           class PreBarrier = NoHook, class PostBarrier = NoHook, class Between = NoBetween>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
                                               const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
-                                              int wave, long long* ts, int ts_base,
+                                              int wave, unsigned* ts, int ts_base,
                                               const PreBarrier& pre_barrier = PreBarrier(),
                                               const PostBarrier& post_barrier = PostBarrier(),
                                               const Between& between = Between()) {
@@ -2445,7 +2619,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                                                   : kTabBn0 + (i - (kTabBias1 - kTabBias0));
         lds[kParams + i] = packed_entry[src];
     }
-    if (tid_entry < 16) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
+    if (tid_entry < kSyncWords) reinterpret_cast<unsigned*>(lds + kSync)[tid_entry] = 0u;
     if (tid_entry < 8) reinterpret_cast<unsigned*>(lds + kPairSync)[tid_entry] = 0u;
     // conv1d_1's weights as the A operand of its transposed MFMAs: lane (m, k) holds w[k][16g + m]
     // for the three channel groups g (tap k = lane >> 4; the fourth k is a zero column).  Its bias
@@ -2493,9 +2667,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
-    long long* ts = nullptr;
-    if (debug_stage >= 300 && lane == 0)        // 301: the same in a persistent launch
-        ts = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
+    unsigned ts_acc = 0u;
+    unsigned* ts = nullptr;
+    long long* ts_out = nullptr;
+    if (debug_stage >= 300) {                   // 301: the same in a persistent launch
+        ts = &ts_acc;
+        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
+    }
     mark(ts, 0);
     mark_realtime(ts, 62);
     // (opaque once per round like the parameter pointer: see above)
@@ -2612,6 +2790,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (in_a.dump_on)
             in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
         in_a.stop = stop_stage == 0;
+        in_a.wave_hi = wave >= 4;
         mark(ts, 1);
     }
 
@@ -2957,7 +3136,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     mark_realtime(ts, 63);
     ++tail_slot;
-    if (!batch_ends) continue;
+    if (!batch_ends) {
+        flush_marks(ts, ts_out, lane);
+        continue;
+    }
 
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
@@ -3097,6 +3279,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         if (debug_stage == 7) return;
         full_barrier();        // the next window's stage A writes over all of this
         mark(ts, 55);
+        flush_marks(ts, ts_out, lane);
     }
     }   // persistent loop over this workgroup's windows
     if (args()->clock_out != nullptr && tid_entry == 0) {

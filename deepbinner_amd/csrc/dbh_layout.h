@@ -202,7 +202,10 @@ static_assert((kChainW3 * 4) % 16 == 0 && kChainW3 + 3 * kWinoHalf <= kW5, "");
 // A0[w + 1][0] and its left halo from A3[w][1]; A0[8][0] and A3[0][1] stay zero = 'same' padding.
 constexpr int kHaloRows = 9 * 2 * 48;                        // 864 floats per array
 constexpr int kHalo = kW6 + 4 * 16 * 48;                     // 21,900
-static_assert((kHalo * 4) % 16 == 0 && kHalo + 4 * kHaloRows <= kW0, "");
+// 1 KB of scratch behind them: where the lanes that have nothing to store or to post point their
+// share of an unmasked LDS instruction (floats: [0, 176) stores, [176, 240) posts, [240, 312) arrivals)
+constexpr int kChainDummy = kHalo + 4 * kHaloRows;           // 25,356
+static_assert((kHalo * 4) % 16 == 0 && kChainDummy % 2 == 0 && kChainDummy + 312 <= kW0, "");
 // conv7's pair exchange: two f4 per lane and wave, in activation rows its pooled output leaves free
 constexpr int kX7 = 130 * kS48;
 static_assert((kX7 * 4) % 16 == 0 && kX7 + 8 * 512 <= 258 * kS48, "");
@@ -284,11 +287,11 @@ constexpr int kTabBias0 = bias_offset(0), kTabBias1 = bias_offset(16);
 constexpr int kTabBn0 = bn_scale_offset(0), kTabBn1 = bn_scale_offset(4);
 constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 672 + 384
 constexpr int kSync = kParams + kParamFloats;
-// 16 words: [0..2] arrivals at the end of tile t of a stage-B layer (dbh_forward.hip: chain_arrive),
-// [4..11] wave w's halo posts (halo_post)
-constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4;
+// 20 words: [0..2] arrivals at the end of tile t of a stage-B layer (dbh_forward.hip: chain_arrive),
+// [4..19] per wave the posts of its two neighbours (halo_post)
+constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4, kSyncWords = 20;
 // window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
-constexpr int kStatRed = kSync + 16;
+constexpr int kStatRed = kSync + kSyncWords;
 constexpr int kStatOut = kStatRed + 32;
 static_assert(kStatRed % 2 == 0, "64-bit words");
 // one counter word per half of each of conv7's four wave pairs (dbh_forward.hip: pair_signal)

@@ -15,11 +15,12 @@ from deepbinner_amd import hip_backend                      # noqa: E402
 from deepbinner_amd.model_format import ModelWeights        # noqa: E402
 
 NAMES = {0: 'start', 1: 'A done (samples normalised; conv1 runs inside conv2 tile 0)'}
-# stage B (dbh_forward.hip: w43_layer): per layer U phase done | barrier | tile 2's MFMAs done |
-# end (last epilogue + barrier + DMA request)
-for base, l in ((2, 'conv2'), (6, 'conv3'), (10, 'conv4')):
-    for j, what in enumerate(['tile 0 done', 'barrier', 'tile 2 done', 'end']):
-        NAMES[base + j] = '%s %s' % (l, what)
+# stage B (dbh_forward.hip: stage_b_chain): nine tiles back to back, T = 3 layer + tile
+NAMES.update({2: 'conv2 tile 0 done (conv1 inside)', 3: 'conv2 tile 1 may start', 4: 'conv2 tile 1 done',
+              5: 'conv2 tile 2 done', 6: 'conv3 entry waits passed', 7: 'conv3 tile 0 done',
+              8: 'conv3 tile 1 done', 9: 'conv3 tile 2 done', 10: 'conv4 entry waits passed',
+              11: 'conv4 tile 0 done', 12: 'conv4 tile 1 done',
+              13: 'conv4 end (tile 2, last epilogue, conv5 weights known)'})
 LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
@@ -35,8 +36,7 @@ TAIL = {45: 'tail: barrier (conv17 out)', 46: 'tail: X loaded, weights landed', 
 ORDER = list(range(0, 45))
 EXTRA = {25: 'conv7 end', 26: 'conv8 exchange stored', 27: 'conv8 barrier1',
          51: 'A: first barrier passed', 54: 'A: window normalised',
-         6: 'conv3 tile 0 done', 7: 'conv3 barrier',
-         57: 'conv3 tile 1 done + DMA', 8: 'conv3 tile 2 done + DMA', 58: 'conv3 last epilogue', 9: 'conv3 end'}
+         57: 'conv4 tile 1 waits passed', 58: 'conv4 tile 2 MFMAs done'}
 
 
 def main():
@@ -54,6 +54,13 @@ def main():
     run = model.timeline_i16 if fused else model.timeline
     run(x)                                  # warm-up
     st = run(x)                             # [n, 8 waves, 64]
+    # stamps are the low 32 bits of the counters (0 = not stamped): rebase them on the run's first
+    # stamp modulo 2^32 (+ 1, so that 0 still means "not stamped")
+    st = st.astype(np.int64)
+    for lo, hi in ((0, 62), (62, 64)):
+        blk = st[:, :, lo:hi]
+        base = st[0, 0, lo]
+        blk[...] = np.where(blk != 0, ((blk - base + (1 << 31)) & 0xFFFFFFFF) + 1, 0)
     ids = ORDER
     # shader clock while the kernel runs: stamps 0 / 44 are s_memtime (shader clock), 62 / 63
     # s_memrealtime (constant 100 MHz) at the same two places of every window
