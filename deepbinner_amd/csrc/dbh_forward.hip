@@ -1128,6 +1128,7 @@ struct ConvAIn {
     bool dump_on;         // (wave-uniform)
     bool stop;            // debug_stage 0 / 100: the kernel ends behind tile 0
     bool wave_hi;         // wave >= 4 (progress_priority_pair)
+    bool dump_b;          // debug_stage 1: stage B's output is dumped (from registers)
 };
 
 // ReLU and BN1 of the six rows of one channel pair: x * 1 with the clamp modifier (activations are
@@ -1495,12 +1496,13 @@ struct NoPre {
 // requested by between_a (between conv1d_1's MFMAs) instead of having landed before the window's
 // first barrier; after_first(): the caller's work behind this wave's first arrival (everything it
 // asked of global memory has landed there).
-template <class BetweenA, class AfterFirst>
+template <class BetweenA, class AfterFirst, class DumpBase>
 __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restrict__ packed, int tid,
                                               int lane, int wave, unsigned* ts,
                                               unsigned& chain_windows, const ConvAIn& in_a,
                                               bool thirds_here, const BetweenA& between_a,
-                                              const AfterFirst& after_first) {
+                                              const AfterFirst& after_first,
+                                              const DumpBase& dump_b_base) {
     const int n = lane & 15, q = lane >> 4;
     const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 6u;
     chain_windows += 1;
@@ -1522,7 +1524,6 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     const unsigned post_addr = halo_post_address(lds, wave, lane);
     const unsigned arrive_addr =
         lds_addr(lane == 0 ? lds + kSyncTiles : lds + kChainDummy + 176 + 64 + lane);
-    lds_f2* out = (lds_f2*)lds_pinned(lds + kActOff + (1 + 2 * (wave * 16 + n)) * kS48 + 4 * q);
     const f4* tab4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);
     const unsigned bias_addr = lds_addr(lds + kParams + 4 * q);
     static_assert((bias_offset(1) - kTabBias0) % 4 == 0 && (bn_scale_offset(1) - kTabBn0) % 4 == 0 &&
@@ -1547,8 +1548,9 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
                      : "memory");
         if constexpr (h == 1) halo_post(post_addr);
     };
-    // half h of the epilogue of tile g of conv4: outputs, MaxPool2, BN2, two rows of the image
-    // stage C reads
+    // half h of the epilogue of tile g of conv4: outputs, MaxPool2, BN2 -> X[g][h][p]: channels
+    // 16g + 4q + 2h, + 1 of pooled positions 2j + p - conv5's B operand as it stands
+    f2 X[3][2][2];
     auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
         constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
         if (DBH_ABL & 16) return;
@@ -1559,9 +1561,37 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
         const f2 p0 = f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)};
         const f2 p1 = f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)};
-        out[(16 * g + 2 * h) / 2] = __builtin_elementwise_fma(p0, sc, sh);
-        out[(kS48 + 16 * g + 2 * h) / 2] = __builtin_elementwise_fma(p1, sc, sh);
+        X[g][h][0] = __builtin_elementwise_fma(p0, sc, sh);
+        X[g][h][1] = __builtin_elementwise_fma(p1, sc, sh);
+        if (in_a.dump_b) {          // debug_stage 1 (wave-uniform)
+            float* dst = dump_b_base() + 2 * (wave * 16 + n) * 48 + 4 * q;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                dst[pp * 48 + 16 * g + 2 * h] = X[g][h][pp].x * kActUnscale;
+                dst[pp * 48 + 16 * g + 2 * h + 1] = X[g][h][pp].y * kActUnscale;
+            }
+        }
     };
+    // conv5 (1x1, 48 -> 16) on X, transposed like everything here: A = its weights (M = its 16
+    // output channels), B = X of one pooled position per quad - 24 MFMAs per wave, two chains;
+    // channel group g's eight as soon as X[g] exists (inside conv4's last tile for g = 0, 1)
+    f2 w5[6];
+    f4 acc5[2];
+    auto conv5_group = [&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                if (g == 0 && h == 0)
+                    acc5[pp] = mfma4(w5[0].x, X[0][0][pp].x, tab4[(bias_offset(4) - kTabBias0) / 4]);
+                else
+                    acc5[pp] = mfma4(w5[2 * g + h].x, X[g][h][pp].x, acc5[pp]);
+                acc5[pp] = mfma4(w5[2 * g + h].y, X[g][h][pp].y, acc5[pp]);
+            }
+        asm volatile("" : "+v"(acc5[0]), "+v"(acc5[1]));
+    };
+    static_assert((bias_offset(4) - kTabBias0) % 4 == 0 && kConv[4].taps == 1 && kConv[4].cout_pad == 16, "");
     static_assert((bn_shift_offset(1) - kTabBn0) % 4 == 0 && kS48 % 2 == 0, "");
     const IntC<0> c0;
     const IntC<1> c1;
@@ -1707,13 +1737,14 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 0) finish(c1, c2, c0, acc[1]);
             if constexpr (SP == 1) finish(c1, c2, c1, acc[1]);
+            // conv5's weights (three pieces, waves 0-2): its first MFMAs run in tile 2
+            if constexpr (SP == 2)
+                dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW5, lane, wave);
         });
     chain_arrive(arrive_addr, 0);
     mark(ts, 11);
     chain_check(lds, 1, pk_a, tiles0 + 16);
     chain_check(lds, 2, pk_b, tiles0 + 16);      // nobody reads conv3's weights any more
-    zero_row(lds + kActOff, 0, kS48, 48, tid);
-    zero_row(lds + kActOff, 257, kS48, 48, tid);
     mark(ts, 57);
     w43t_tile<-1, 6, 18, B4 + 16>(
         U, Y, h_addr, bias_addr, lds + kSlot1 + lane * 4, acc[1], wave_hi,
@@ -1722,11 +1753,9 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
-            // conv5's (3 pieces) and conv6's (9) weights, to the upper buffer
-            if constexpr (SP == 0) {
-                dma_weights<conv_weight_floats(4)>(packed + weight_offset(4), lds + kW5, lane, wave);
+            // conv6's weights (9 pieces), to the upper buffer
+            if constexpr (SP == 0)
                 dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 0);
-            }
             if constexpr (SP == 2)
                 dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 1);
             if constexpr (SP == 4 && NW < 8)
@@ -1740,24 +1769,58 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         U, Y, h_addr, bias_addr, lds + kSlot2 + lane * 4, acc[0], wave_hi,
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
-            // slot 0: every wave has left conv4's tile 0 - conv7's first third
-            if constexpr (SP == 0) chain_check(lds, 0, pk_a, tiles0 + 24);
-            if constexpr (SP == 5) pk_a = chain_peek(lds, 1);
+            // slot 0: every wave has left conv4's tile 0 - conv7's first third goes there, and
+            // conv5's weights (asked for in that tile) have landed: its six fragment pairs ride in
+            // front of this step's requests
+            if constexpr (SP == 0) {
+                chain_check(lds, 0, pk_a, tiles0 + 24);
+                const unsigned w5_addr = lds_addr(lds + kW5 + lane * 2);
+                w5[0] = ds_read_f2<0 * 512>(w5_addr);
+                w5[1] = ds_read_f2<1 * 512>(w5_addr);
+                w5[2] = ds_read_f2<2 * 512>(w5_addr);
+                w5[3] = ds_read_f2<3 * 512>(w5_addr);
+                w5[4] = ds_read_f2<4 * 512>(w5_addr);
+                w5[5] = ds_read_f2<5 * 512>(w5_addr);
+            }
         },
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(w5[k]));
+            }
             if constexpr (SP == 1) store(c1, c0, acc[1]);
             if constexpr (SP == 3) store(c1, c1, acc[1]);
+            if constexpr (SP == 2) conv5_group(c0);
+            if constexpr (SP == 5) conv5_group(c1);
             if constexpr (SP < kThirdSteps) third(6, 0, lds + kSlot0, SP);
         });
     mark(ts, 58);
     store(c2, c0, acc[0]);
     store(c2, c1, acc[0]);
+    conv5_group(c2);
     chain_arrive(arrive_addr, 2);
-    // conv5 (next) multiplies the rows this wave has just written by weights that waves 0-2 asked
-    // for in tile 1: landed once every wave has arrived behind that tile
-    chain_check(lds, 1, pk_a, tiles0 + 24);
     mark(ts, 13);
+    if (in_a.dump_b) return;      // debug_stage 1: stage B's output is out
+    // conv5's epilogue: ReLU, then the wave's 2 x 16 rows of the 16-channel image conv6 reads
+    // (lane (n, q): channels 4q .. 4q + 3 of pooled positions 2j, 2j + 1: one 16-byte store each)
+    {
+        typedef __attribute__((address_space(3))) f4 lds_f4;
+        lds_f4* out5 = (lds_f4*)lds_pinned(lds + kMid16 + (1 + 2 * (wave * 16 + n)) * kS16 + 4 * q);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const f4 v = acc5[pp];
+            out5[pp * (kS16 / 4)] = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        }
+        static_assert(kS16 % 4 == 0 && (kMid16 * 4) % 16 == 0, "");
+    }
+    zero_row(lds + kMid16, 0, kS16, 16, tid);
+    zero_row(lds + kMid16, 257, kS16, 16, tid);
+    mark(ts, 14);
+    mark(ts, 15);
+    mark(ts, 16);
+    full_barrier();     // conv6 reads its neighbours' rows; its weights have landed
+    mark(ts, 17);
 }
 
 struct NoBetween {
@@ -2791,6 +2854,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
         in_a.stop = stop_stage == 0;
         in_a.wave_hi = wave >= 4;
+        in_a.dump_b = debug_stage == 1;
         mark(ts, 1);
     }
 
@@ -2822,14 +2886,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 // n_windows numbers are taken per launch, whatever the grid: this was the last
                 if ((long long)taken == n_windows - 1) *win_counter = 0;
             }
-        });
+        },
+        [&] { return glob(args()->debug_out) + win * kStageFloats[1]; });
     if (stop_stage == 0) return;      // (debug_stage 0: tile 0 has written the dump itself)
-    if (stop_stage == 1) {
-        full_barrier();      // (conv4 ends without one)
-        if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 256, 48, glob(args()->debug_out) + win * kStageFloats[1], tid);
-        return;
-    }
+    if (stop_stage == 1) return;      // (debug_stage 1: dumped from registers, conv5 did not run)
 
     // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
     // conv5's and conv6's weights sit side by side in the upper buffer (DMA'd during conv4),
@@ -2842,8 +2902,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // has been passed (every wave's DMA pieces landed before it arrived there): no workgroup
     // barrier between conv4 and conv5.  Slot 2 - every wave has left conv4's tile 2 behind
     // conv5's barrier - gets conv7's last third then.
-    inplace_layer<4, kW5, 256, kS48, kS16, false, -1, 0, kActOff, kMid16>(
-        lds, packed, nullptr, nullptr, tid, lane, wave, ts, 14);
+    // (conv5 has run at the end of stage B's chain, on registers: stage_b_chain)
     // (behind conv5's barrier every wave has left conv4: slots 1 and 2 take conv7's other thirds)
     dma_weights<2 * kWinoHalf>(packed + weight_offset(6) + kWinoHalf, lds + kSlot1, lane, wave);
     // where this workgroup's NEXT window starts: written by thread 0 early in stage B, published
