@@ -689,6 +689,11 @@ __device__ __forceinline__ f2 pk_add_relu(f2 a, f2 b) {
     asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ f2 pk_sub_relu(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // (k: a constant pair, from scalar registers)
 __device__ __forceinline__ f2 pk_fma_relu(f2 k, f2 b, f2 c) {
     f2 r;
@@ -1504,7 +1509,7 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
                                               const AfterFirst& after_first,
                                               const DumpBase& dump_b_base) {
     const int n = lane & 15, q = lane >> 4;
-    const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 6u;
+    const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 7u;
     chain_windows += 1;
     const unsigned h_addr = lds_addr(lds + kHalo + wave * 96 + 4 * q);
     // where a lane's row 0 (A0) and row 3 (A3) go per layer output: the halo arrays for the lanes
@@ -1802,25 +1807,133 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     chain_arrive(arrive_addr, 2);
     mark(ts, 13);
     if (in_a.dump_b) return;      // debug_stage 1: stage B's output is out
-    // conv5's epilogue: ReLU, then the wave's 2 x 16 rows of the 16-channel image conv6 reads
-    // (lane (n, q): channels 4q .. 4q + 3 of pooled positions 2j, 2j + 1: one 16-byte store each)
+    // ---- conv6 (F(2,3), 16 -> 48 channels, L = 256, ReLU) on conv5's output, which never leaves
+    // the registers either: lane (n, q) holds channels 4q + r of pooled positions 2j, 2j + 1 =
+    // pair j's own two inputs d1, d2; d0 and d3 are the neighbouring lanes' (the neighbouring
+    // waves' at the ends: one more halo exchange).  U1 = d1 + d2 and U2 = d2 - d1 need no halo:
+    // their 24 MFMAs run while the neighbours' rows arrive, then U0 = d0 - d2, U3 = d1 - d3 and
+    // the other 24.  The weights (by N tile: [t][sp][matrix pair][lane][matrix][e], k-step
+    // 2 sp + e <-> channels {4q + 2 sp + e}) are read once, twelve 16-byte fragments.
+    chain_check(lds, 1, pk_a, tiles0 + 24);    // conv6's weights have landed; every wave has left slot 1
+    f4 wf[3][2][2];
     {
-        typedef __attribute__((address_space(3))) f4 lds_f4;
-        lds_f4* out5 = (lds_f4*)lds_pinned(lds + kMid16 + (1 + 2 * (wave * 16 + n)) * kS16 + 4 * q);
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const f4 v = acc5[pp];
-            out5[pp * (kS16 / 4)] = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-        }
-        static_assert(kS16 % 4 == 0 && (kMid16 * 4) % 16 == 0, "");
+        const unsigned w6_addr = lds_addr(lds + kW6 + lane * 4);
+        wf[0][0][0] = ds_read_f4<0 * 1024>(w6_addr);
+        wf[0][0][1] = ds_read_f4<1 * 1024>(w6_addr);
+        wf[0][1][0] = ds_read_f4<2 * 1024>(w6_addr);
+        wf[0][1][1] = ds_read_f4<3 * 1024>(w6_addr);
+        wf[1][0][0] = ds_read_f4<4 * 1024>(w6_addr);
+        wf[1][0][1] = ds_read_f4<5 * 1024>(w6_addr);
+        wf[1][1][0] = ds_read_f4<6 * 1024>(w6_addr);
+        wf[1][1][1] = ds_read_f4<7 * 1024>(w6_addr);
+        wf[2][0][0] = ds_read_f4<8 * 1024>(w6_addr);
+        wf[2][0][1] = ds_read_f4<9 * 1024>(w6_addr);
+        wf[2][1][0] = ds_read_f4<10 * 1024>(w6_addr);
+        wf[2][1][1] = ds_read_f4<11 * 1024>(w6_addr);
     }
-    zero_row(lds + kMid16, 0, kS16, 16, tid);
-    zero_row(lds + kMid16, 257, kS16, 16, tid);
+    static_assert(wino2_by_tile(5) && kConv[5].cin == 16 && kConv[5].cout_pad == 48, "");
+    // conv7's second third follows conv4's out of slot 1
+    dma_weights<kWinoHalf>(packed + weight_offset(6) + kWinoHalf, lds + kSlot1, lane, wave);
+    f4 Z[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const f4 v = acc5[pp];
+        Z[pp] = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    }
+    {   // the wave's first and last position to its neighbours (conv2's halo arrays, long dead)
+        const f2 z0l = f2{Z[0].x, Z[0].y}, z0h = f2{Z[0].z, Z[0].w};
+        const f2 z1l = f2{Z[1].x, Z[1].y}, z1h = f2{Z[1].z, Z[1].w};
+        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:8\n\t"
+                     "ds_write_b64 %1, %4\n\tds_write_b64 %1, %5 offset:8"
+                     :
+                     : "v"(a0_addr[0]), "v"(a3_addr[0]), "v"(z0l), "v"(z0h), "v"(z1l), "v"(z1h)
+                     : "memory");
+        halo_post(post_addr);
+    }
+    pk_b = chain_peek(lds, 2);
     mark(ts, 14);
+    const f4 U1 = Z[0] + Z[1], U2 = Z[1] - Z[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) asm volatile("" : "+v"(wf[t][sp][0]), "+v"(wf[t][sp][1]));
+    f4 M[3][4];
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    f4 hl, hr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            M[t][1] = mfma4(wf[t][k >> 1][0][2 + (k & 1)], U1[k], k == 0 ? zero4 : M[t][1]);
+            M[t][2] = mfma4(wf[t][k >> 1][1][k & 1], U2[k], k == 0 ? zero4 : M[t][2]);
+        }
+        if (k == 1) {
+            // half-way: have the neighbours posted?  Their rows are asked for in the same breath -
+            // if the answer (the older of the two) is yes, what comes back is what they stored
+            __builtin_amdgcn_sched_barrier(0);
+            pk_h = halo_peek(lds, wave);
+            hl = ds_read_f4<(kHaloRows + 48) * 4>(h_addr);     // A3[w][1]: position 2j - 1
+            hr = ds_read_f4<96 * 4>(h_addr);                   // A0[w + 1][0]: position 2j + 2
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(M[t][1]), "+v"(M[t][2]));
     mark(ts, 15);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(hl), "+v"(hr), "+v"(pk_h));
+    if (!(DBH_ABL & (1 | 2 | 8 | 64)) && !halo_ready(pk_h, halos0 + 7)) {
+        halo_wait(lds, wave, halos0 + 7);
+        hl = ds_read_f4<(kHaloRows + 48) * 4>(h_addr);
+        hr = ds_read_f4<96 * 4>(h_addr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(hl), "+v"(hr));
+    }
     mark(ts, 16);
-    full_barrier();     // conv6 reads its neighbours' rows; its weights have landed
+    f4 U0, U3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        U0[k] = row_from_left(hl[k], Z[1][k]) - Z[1][k];
+        U3[k] = Z[0][k] - row_from_right(hr[k], Z[0][k]);
+    }
+    // conv7's last third follows conv4's out of slot 2, once every wave has left its tile 2
+    chain_check(lds, 2, pk_b, tiles0 + 24);
+    dma_weights<kWinoHalf>(packed + weight_offset(6) + 2 * kWinoHalf, lds + kSlot2, lane, wave);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f4 b6 = tab4[(bias_offset(5) - kTabBias0) / 4 + 4 * t];
+            M[t][0] = mfma4(wf[t][k >> 1][0][k & 1], U0[k], k == 0 ? b6 : M[t][0]);
+            M[t][3] = mfma4(wf[t][k >> 1][1][2 + (k & 1)], U3[k], k == 0 ? -b6 : M[t][3]);
+        }
+    static_assert((bias_offset(5) - kTabBias0) % 4 == 0, "");
     mark(ts, 17);
+    mark(ts, 18);
+    // even = M0 + M1 + M2, odd = M1 - M2 - M3 (M0 started at the bias, M3 at minus the bias), ReLU,
+    // rows 2j and 2j + 1 of the image conv7 reads
+    {
+        lds_f2* out6 = (lds_f2*)lds_pinned(lds + kActOff + (1 + 2 * (wave * 16 + n)) * kS48 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {       // (packed; ReLU = the clamp of the last instruction)
+                const f2 m0 = f2{M[t][0][2 * h], M[t][0][2 * h + 1]}, m1 = f2{M[t][1][2 * h], M[t][1][2 * h + 1]};
+                const f2 m2 = f2{M[t][2][2 * h], M[t][2][2 * h + 1]}, m3 = f2{M[t][3][2 * h], M[t][3][2 * h + 1]};
+                // (the two sums the compiler can see read the youngest accumulators, M0 and M3: it
+                // pads the distance to their MFMAs; it would not for an inline-asm reader)
+                const f2 s01 = m0 + m1, s23 = m2 + m3;
+                out6[(16 * t) / 2 + h] = pk_add_relu(s01, m2);
+                out6[(kS48 + 16 * t) / 2 + h] = pk_sub_relu(m1, s23);
+            }
+    }
+    zero_row(lds + kActOff, 0, kS48, 48, tid);
+    zero_row(lds + kActOff, 257, kS48, 48, tid);
+    mark(ts, 19);
+    mark(ts, 20);
+    full_barrier();     // conv7 reads everybody's rows; its weights have landed
+    mark(ts, 21);
 }
 
 struct NoBetween {
@@ -2902,11 +3015,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // has been passed (every wave's DMA pieces landed before it arrived there): no workgroup
     // barrier between conv4 and conv5.  Slot 2 - every wave has left conv4's tile 2 behind
     // conv5's barrier - gets conv7's last third then.
-    // (conv5 has run at the end of stage B's chain, on registers: stage_b_chain)
-    // (behind conv5's barrier every wave has left conv4: slots 1 and 2 take conv7's other thirds)
-    dma_weights<2 * kWinoHalf>(packed + weight_offset(6) + kWinoHalf, lds + kSlot1, lane, wave);
+    // (conv5 and conv6 have run at the end of stage B's chain, on registers: stage_b_chain; its
+    // closing barrier has published conv6's rows and conv7's weights)
     // where this workgroup's NEXT window starts: written by thread 0 early in stage B, published
-    // by conv5's barrier, needed at the top of stage E
+    // by that barrier, needed at the top of stage E
     const long next_win = win_counter != nullptr
                               ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
                               : win + (long)gridDim.x;
@@ -2926,19 +3038,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         next_off0 = offsets_arg[next_read + lane_zero];
         next_off1 = offsets_arg[next_read + lane_zero + 1];
     }
-    w23_cin16_layer<5, kW6, kMid16, kActOff>(lds, packed, tid, lane, wave, ts, 18);
-    // (behind conv6's closing barrier - which has waited for everything - the two offset loads
+    // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
+    // activation buffer meanwhile
+    w43_nsplit_pooled_layer<6, 2>(
+        lds, packed, tid, lane, wave, ts, 22, pair_rounds,
+        [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); });
+    // (behind conv7's closing barrier - which has waited for everything - the two offset loads
     // are looked at once: hipcc's wait-count pass then knows they have landed.  Left "pending" -
     // they are issued under a condition, and the pass merges control flow pessimistically - the
     // first instruction that reuses one of their registers, in conv8's first step, waited for all
     // but one of the wave's outstanding requests: the LDS-DMA of conv9's weights just asked for, a
     // whole L2 round trip per window.)
     asm volatile("" : "+v"(next_off0), "+v"(next_off1));
-    // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
-    // activation buffer meanwhile
-    w43_nsplit_pooled_layer<6, 2>(
-        lds, packed, tid, lane, wave, ts, 22, pair_rounds,
-        [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); });
     if (stop_stage == 2) {
         if (debug_stage < 100)
             dump_stage(lds + kActOff, kS48, 128, 48, glob(args()->debug_out) + win * kStageFloats[2], tid);

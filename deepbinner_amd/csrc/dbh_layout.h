@@ -143,7 +143,8 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // (quad, q), registers = channels 16t + 4q + r - are, after the output transform, ReLU and the next
 // input transform (all in-lane but for one halo position each side), the next layer's B operand.
 // (conv1d_5, a 1x1 convolution on conv1d_4's pooled output, is fed from the same registers)
-constexpr bool chained(int conv) { return conv >= 1 && conv <= 4; }
+// ... and conv1d_6 from conv1d_5's accumulators
+constexpr bool chained(int conv) { return conv >= 1 && conv <= 5; }
 constexpr int frag_cin(int conv, int sp, int q, int e) {
     return chained(conv) ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
 }

@@ -25,6 +25,10 @@ LAYERS = ['conv5', 'conv6', 'conv7', 'conv8', 'conv9']
 for i, l in enumerate(LAYERS):
     for j, what in enumerate(['mfma done', 'barrier1', 'epilogue done', 'barrier2']):
         NAMES[14 + 4 * i + j] = '%s %s' % (l, what)
+# conv5 and conv6 run at the end of stage B's chain, in registers
+NAMES.update({14: 'conv6: weights asked for, edge rows posted', 15: 'conv6 first 24 MFMAs (no halo) issued',
+              16: 'conv6 halo rows arrived', 17: 'conv6 all MFMAs issued', 18: '-', 19: 'conv6 rows stored',
+              20: '-', 21: 'conv6 barrier passed'})
 NAMES.update({22: 'conv7 own N tile done', 23: 'conv7 barrier', 24: 'conv7 shared tile done, partials published', 25: 'conv7 end',
               34: 'E top: requests, zero rows (no barrier)', 35: 'E1 compute', 36: 'E1 barrier', 37: 'E2 compute',
               38: 'E2 barrier', 39: 'E3 compute', 40: 'E3 barrier'})
