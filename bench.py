@@ -638,7 +638,7 @@ def main():
         pmc = pmc_constants()
         executed = executed_flop * rate / 1e12
         result['roofline'] = {
-            # `achieved` / `frac`: the FLOP of the MFMAs the kernel really issues (9,540 per window
+            # `achieved` / `frac`: the FLOP of the MFMAs the kernel really issues (9,588 per window
             # x 2,048: the Winograd layers issue fewer than the direct convolutions would) over the
             # fp32 matrix peak = how busy the matrix pipe is.  The direct convolutions' 33.6 MFLOP
             # per window over the same time are the *_algorithmic_equivalent figures (> peak).

@@ -1139,10 +1139,15 @@ struct ConvAIn {
 // ReLU and BN1 of the six rows of one channel pair: x * 1 with the clamp modifier (activations are
 // held times 2^-60: dbh_layout.h), then x * scale + shift - twelve packed instructions in one
 // block.  The inputs are results of MFMAs, and hipcc does not pad the distance between an MFMA
-// and an inline-asm reader of its result (see pk_fma_relu): the callers keep at least twelve
-// MFMAs between a conv1d_1 product and this block.
+// and an inline-asm reader of its result (see pk_fma_relu): the block starts with the wait states
+// itself (the callers also keep twelve MFMAs between a conv1d_1 product and this block).
 __device__ __forceinline__ void relu_bn_rows(f2 (&d)[6], const f2 (&v)[6], f2 sc, f2 sh) {
+    // (s_nop 7, s_nop 2: the eleven wait states between an 8-pass MFMA and a vector instruction
+    // that reads its result, which hipcc would insert itself if it could see into this block -
+    // correctness does not rest on how far away the callers keep the conv1d_1 MFMAs.  66 cycles
+    // per window.)
     asm volatile(
+        "s_nop 7\n\ts_nop 2\n\t"
         "v_pk_mul_f32 %0, %6, 1.0 op_sel_hi:[1,0] clamp\n\t"
         "v_pk_mul_f32 %1, %7, 1.0 op_sel_hi:[1,0] clamp\n\t"
         "v_pk_mul_f32 %2, %8, 1.0 op_sel_hi:[1,0] clamp\n\t"

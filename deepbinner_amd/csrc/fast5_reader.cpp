@@ -56,6 +56,42 @@ struct ExistsError : std::runtime_error {
     ExistsError() : std::runtime_error("file exists") {}
 };
 
+// errno values with which link() says "this filesystem has no hard links" (or not for us)
+static bool no_hard_links(int e) {
+    // (DEEPBINNER_FAST5_NO_LINK=1: every link() failure is treated as this one - the test of the
+    // fallback on filesystems that do have hard links)
+    static const bool forced = [] {
+        const char* v = std::getenv("DEEPBINNER_FAST5_NO_LINK");
+        return v && v[0] == '1';
+    }();
+    if (forced) return true;
+    return e == EPERM || e == ENOTSUP || e == EOPNOTSUPP || e == EMLINK || e == ENOSYS ||
+           e == EXDEV || e == EACCES;
+}
+// The image under a name that must not exist yet (O_EXCL; a symlink there is not followed); a
+// failed write leaves nothing behind.
+static void write_exclusive(const char* path, const std::string& image) {
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
+    if (fd < 0) {
+        if (errno == EEXIST) throw ExistsError();
+        throw std::runtime_error("cannot create file");
+    }
+    size_t done = 0;
+    while (done < image.size()) {
+        const ssize_t k = ::write(fd, image.data() + done, image.size() - done);
+        if (k <= 0) {
+            ::close(fd);
+            ::unlink(path);
+            throw std::runtime_error("cannot write file");
+        }
+        done += (size_t)k;
+    }
+    if (::close(fd) != 0) {
+        ::unlink(path);
+        throw std::runtime_error("cannot close file");
+    }
+}
+
 struct Msg {
     uint32_t type;
     uint64_t off;
@@ -2468,29 +2504,27 @@ int f5_write_single_reads(const char* container, int64_t n, const int64_t* read_
                 const std::string tmp = std::string(out_paths[i]) + ".part." +
                                         std::to_string((long long)::getpid()) + "." +
                                         std::to_string((long long)i);
-                const int fd = ::open(tmp.c_str(),
-                                      O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
-                if (fd < 0) throw std::runtime_error("cannot create file");
-                size_t done = 0;
-                while (done < image.size()) {
-                    const ssize_t k = ::write(fd, image.data() + done, image.size() - done);
-                    if (k <= 0) {
-                        ::close(fd);
-                        ::unlink(tmp.c_str());
-                        throw std::runtime_error("cannot write file");
-                    }
-                    done += (size_t)k;
+                ::unlink(tmp.c_str());      // (a stale one of this very name: a killed run whose
+                                            // pid came round - the O_EXCL below would refuse it)
+                write_exclusive(tmp.c_str(), image);
+                int linked = ::link(tmp.c_str(), out_paths[i]);
+                int link_errno = errno;
+                if (linked == 0 && no_hard_links(0) && ::unlink(out_paths[i]) == 0) {
+                    linked = -1;            // (forced: as if the filesystem had refused)
+                    link_errno = EPERM;
                 }
-                if (::close(fd) != 0) {
+                if (linked != 0 && link_errno != EEXIST && no_hard_links(link_errno)) {
+                    // exFAT / FAT, many SMB and FUSE mounts (sequencing drives) have no link():
+                    // the final name is created exclusively and written directly - still never
+                    // over an existing file, never through a symlink
                     ::unlink(tmp.c_str());
-                    throw std::runtime_error("cannot close file");
-                }
-                const int linked = ::link(tmp.c_str(), out_paths[i]);
-                const int link_errno = errno;
-                ::unlink(tmp.c_str());
-                if (linked != 0) {
-                    if (link_errno == EEXIST) throw ExistsError();
-                    throw std::runtime_error("cannot name file");
+                    write_exclusive(out_paths[i], image);
+                } else {
+                    ::unlink(tmp.c_str());
+                    if (linked != 0) {
+                        if (link_errno == EEXIST) throw ExistsError();
+                        throw std::runtime_error("cannot name file");
+                    }
                 }
                 written.fetch_add((int64_t)image.size());
             });

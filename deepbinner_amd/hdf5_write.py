@@ -19,6 +19,7 @@ the reference's own ``get_read_id_and_signal`` and with both of this package's r
 (tests/test_hdf5_write.py).
 """
 
+import errno
 import os
 import struct
 import threading
@@ -309,9 +310,46 @@ def write_single_read_fast5(path, read_id, signal, compress=True, read_number=No
     if os.path.lexists(path):
         raise FileExistsError(path)
     tmp = '{}.part.{}.{}'.format(path, os.getpid(), threading.get_ident())
-    with open(tmp, 'xb') as f:
-        f.write(image)
     try:
-        os.link(tmp, path)
+        os.unlink(tmp)          # (a stale one of this very name: a killed run whose pid came round)
+    except OSError:
+        pass
+    try:
+        with open(tmp, 'xb') as f:
+            f.write(image)
+        try:
+            os.link(tmp, path)
+        except FileExistsError:
+            raise
+        except OSError as e:
+            # no hard links here (exFAT / FAT, many SMB and FUSE mounts - sequencing drives):
+            # create the final name exclusively and write it directly
+            if e.errno not in _NO_LINK_ERRNOS:
+                raise
+            _write_exclusive(path, image)
     finally:
-        os.unlink(tmp)
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+
+
+_NO_LINK_ERRNOS = frozenset(
+    getattr(errno, name) for name in ('EPERM', 'ENOTSUP', 'EOPNOTSUPP', 'EMLINK', 'ENOSYS', 'EXDEV',
+                                      'EACCES')
+    if hasattr(errno, name))
+
+
+def _write_exclusive(path, image):
+    """``path`` must not exist (O_EXCL) and is not followed if it is a symlink; a failed write
+    leaves nothing behind."""
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o666)
+    try:
+        with os.fdopen(fd, 'wb') as f:
+            f.write(image)
+    except BaseException:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        raise

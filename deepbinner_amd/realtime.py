@@ -18,6 +18,7 @@ pass appends ``read_id<TAB>barcode<TAB>source_file`` rows to
 """
 
 import os
+import weakref
 import pathlib
 import shutil
 import subprocess
@@ -78,15 +79,28 @@ def queue_clones(pair, n_more):
     ON the pair's first model (``_queue_clones``: partner pair -> clones, matched by identity), so
     that they live exactly as long as it does and ``HipModel.close()`` releases them with it - a
     cache keyed by ``id()`` outside the models would hand a new model that happens to get a freed
-    model's id the old model's weights."""
+    model's id the old model's weights.  The pair is remembered through weak references (the
+    holder is part of it: a strong one would be a cycle that only the collector breaks), and an
+    entry whose partner is gone or closed gives its clones back at once."""
     holder = next(m for m in pair if m is not None)
     cache = holder.__dict__.setdefault('_queue_clones', [])
-    for known, more in cache:
-        if len(known) == len(pair) and all(a is b for a, b in zip(known, pair)):
-            break
-    else:
+    more = None
+    for entry in list(cache):
+        known, clones = entry
+        alive = [None if r is None else r() for r in known]
+        if any(r is not None and (m is None or not getattr(m, 'handle', None))
+               for r, m in zip(known, alive)):
+            cache.remove(entry)             # the partner was closed or collected on its own
+            for group in clones:
+                for clone in group:
+                    if clone is not None:
+                        clone.close()
+            continue
+        if len(alive) == len(pair) and all(a is b for a, b in zip(alive, pair)):
+            more = clones
+    if more is None:
         more = []
-        cache.append((tuple(pair), more))
+        cache.append((tuple(None if m is None else weakref.ref(m) for m in pair), more))
     while len(more) < n_more:
         more.append(tuple(m.clone() if m is not None else None for m in pair))
     return more[:n_more]

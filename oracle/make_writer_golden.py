@@ -58,6 +58,8 @@ def main():
         paths, want = [], {}
         for name, read_id, signal, compress in cases():
             path = os.path.join(tmp, name + '.fast5')
+            if os.path.lexists(path):
+                os.unlink(path)          # (the writer never overwrites: a re-run starts clean)
             hdf5_write.write_single_read_fast5(path, read_id, signal, compress=compress)
             paths.append(path)
             want[name + '.fast5'] = {'read_id': read_id, 'length': int(len(signal)),

@@ -265,6 +265,65 @@ def test_nothing_is_ever_overwritten(tmp_path):
     assert len(os.listdir(str(out_dir))) == 5
 
 
+def test_filesystems_without_hard_links(tmp_path, monkeypatch):
+    """exFAT / FAT and many SMB or FUSE mounts refuse link() (EPERM, ENOTSUP ...): both writers
+    then create the final name exclusively and write it directly - same bytes, still nothing
+    overwritten, no temporary file left.  The native library is run in a child
+    process with DEEPBINNER_FAST5_NO_LINK=1 (it reads the switch once)."""
+    import errno
+    import subprocess
+    import sys
+    path = MULTI[0]
+    ids, samples, offsets, _ = fast5_native.load_reads(path, threads=2)
+    out_dir = tmp_path / 'out'
+    out_dir.mkdir()
+
+    def refuse(src, dst, **kw):
+        raise OSError(errno.EPERM, 'Operation not permitted')
+    monkeypatch.setattr(os, 'link', refuse)
+    target = str(out_dir / 'py.fast5')
+    hdf5_write.write_single_read_fast5(target, ids[0], samples[offsets[0]:offsets[1]])
+    assert open(target, 'rb').read() == hdf5_write.single_read_fast5_bytes(
+        ids[0], samples[offsets[0]:offsets[1]])
+    with pytest.raises(FileExistsError):
+        hdf5_write.write_single_read_fast5(target, ids[1], samples[offsets[1]:offsets[2]])
+    dangling = str(out_dir / 'link.fast5')
+    os.symlink(str(tmp_path / 'elsewhere'), dangling)
+    with pytest.raises(FileExistsError):
+        hdf5_write.write_single_read_fast5(dangling, ids[1], samples[offsets[1]:offsets[2]])
+    assert sorted(os.listdir(str(out_dir))) == ['link.fast5', 'py.fast5']
+    # a failing write leaves neither a temporary nor a final file
+    monkeypatch.setattr(hdf5_write, '_write_exclusive',
+                        lambda p, image: (_ for _ in ()).throw(OSError(errno.ENOSPC, 'full')))
+    with pytest.raises(OSError):
+        hdf5_write.write_single_read_fast5(str(out_dir / 'never.fast5'), ids[2],
+                                           samples[offsets[2]:offsets[3]])
+    assert sorted(os.listdir(str(out_dir))) == ['link.fast5', 'py.fast5']
+    monkeypatch.undo()
+
+    native_dir = tmp_path / 'native'
+    native_dir.mkdir()
+    open(str(native_dir / 'r1.fast5'), 'wb').write(b'earlier')
+    code = (
+        'import sys, json\n'
+        'sys.path.insert(0, %r)\n'
+        'from deepbinner_amd import fast5_native\n'
+        'done, written = fast5_native.write_single_reads(%r, [0, 1, 2], [%r + "/r%%d.fast5" %% k for k in range(3)], threads=2)\n'
+        'print(json.dumps([done.tolist(), int(written)]))\n'
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, str(native_dir))
+    env = dict(os.environ, DEEPBINNER_FAST5_NO_LINK='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True)
+    import json
+    done, written = json.loads(out.stdout.strip().splitlines()[-1])
+    assert done == [0, fast5_native.F5_ERR_EXISTS, 0]
+    assert open(str(native_dir / 'r1.fast5'), 'rb').read() == b'earlier'
+    assert sorted(os.listdir(str(native_dir))) == ['r0.fast5', 'r1.fast5', 'r2.fast5']
+    for k in (0, 2):
+        image = open(str(native_dir / ('r%d.fast5' % k)), 'rb').read()
+        assert image == fast5_native.single_read_image(path, k)
+    assert written == sum(os.path.getsize(str(native_dir / ('r%d.fast5' % k))) for k in (0, 2))
+
+
 def test_damaged_containers_never_crash_the_writer(tmp_path):
     """300 seeded mutations of a real container (byte flips, zeroed runs, truncations): every read
     is either written - and then both readers read the file back - or refused with a status;

@@ -507,3 +507,56 @@ def test_host_inflate_share_follows_the_cores_per_gpu(monkeypatch):
     assert realtime.host_inflate_share(1) == 100
     monkeypatch.setenv('DEEPBINNER_GPU_INFLATE', '1')
     assert realtime.host_inflate_share(1) == 0
+
+
+def test_queue_clones_hold_no_cycle_and_follow_their_partner():
+    """realtime.queue_clones keeps further (start, end) replicas on the pair's first model, keyed
+    by weak references to the pair (a strong tuple containing the holder was a
+    cycle; clones of a partner that was closed on its own stayed on the GPU)."""
+    import gc
+    import weakref
+    from deepbinner_amd import realtime
+
+    class Fake:
+        live = 0
+
+        def __init__(self):
+            self.handle = object()
+            Fake.live += 1
+
+        def clone(self):
+            return Fake()
+
+        def close(self):
+            if self.handle is not None:
+                self.handle = None
+                Fake.live -= 1
+            for _pair, more in self.__dict__.pop('_queue_clones', []):
+                for group in more:
+                    for c in group:
+                        if c is not None and c is not self:
+                            c.close()
+
+    start, end = Fake(), Fake()
+    a = realtime.queue_clones((start, end), 2)
+    assert len(a) == 2 and Fake.live == 6
+    assert realtime.queue_clones((start, end), 2) == a and Fake.live == 6      # cached by identity
+    assert realtime.queue_clones((start, end), 1) == a[:1]
+    # another partner: its own clones; the first entry stays
+    other = Fake()
+    b = realtime.queue_clones((start, other), 1)
+    assert b[0][0] is not a[0][0] and Fake.live == 9
+    # the partner closed on its own: its clones go at the next call, the other entry is kept
+    other.close()
+    assert realtime.queue_clones((start, end), 2) == a
+    assert Fake.live == 6
+    # no cycle through the holder: dropping the last reference frees it without the collector
+    gc.disable()
+    try:
+        ref = weakref.ref(start)
+        start.close()
+        del start, a, b
+        assert ref() is None
+    finally:
+        gc.enable()
+    assert Fake.live == 1       # `end` itself

@@ -38,6 +38,8 @@ def main():
             levels = rng.normal(450, 80, size=n // 8 + 1)
             signal = np.clip(np.rint(np.repeat(levels, 8)[:n] + rng.normal(0, 8, size=n)), 0, 2047)
             path = os.path.join(tmp, 'orig_%05d.fast5' % k)
+            if os.path.lexists(path):
+                os.unlink(path)          # (the writer never overwrites: a re-run starts clean)
             hdf5_write.write_single_read_fast5(path, str(uuid.UUID(bytes=rng.bytes(16), version=4)),
                                                signal.astype(np.int16))
             originals.append(path)
