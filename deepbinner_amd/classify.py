@@ -269,10 +269,11 @@ RAW_BATCH_FILES = 4096              # one-read files per GPU-inflated batch (a c
 def raw_inflate_share(start_model, end_model, args, n_files, replicas):
     """Per cent of the inflating the host keeps when ``classify`` hands the Signals of one-read
     files to the GPU as stored (realtime.host_inflate_share), or None if they go through the
-    CPU loader: verbose output (it prints probabilities, which the deflated entry point does not
-    hand back), another reader or backend, few files, or a host with cores to spare."""
+    CPU loader: another reader or backend, few files, or a host with cores to spare.  (The
+    verbose table takes this route too: dbh_classify_pair_deflated_verbose hands the sides' calls
+    and probabilities back.)"""
     models = [m for m in (start_model, end_model) if m is not None]
-    if (reader_kind() != 'native' or getattr(args, 'verbose', False) or
+    if (reader_kind() != 'native' or
             n_files < int(os.environ.get('DEEPBINNER_RAW_CLASSIFY_MIN_FILES',
                                          RAW_CLASSIFY_MIN_FILES)) or
             not all(hasattr(pick, 'handle') for pair in replicas for pick in pair
@@ -330,24 +331,52 @@ def _classify_raw_batch(batch, start_replica, end_replica, args):
     inflated again by the host's loader, which has the last word."""
     from . import fast5_native, hip_backend
     both = start_replica is not None and end_replica is not None
-    numbers, stream_status = hip_backend.classify_pair_deflated(
+    verbose = bool(getattr(args, 'verbose', False))
+    result = hip_backend.classify_pair_deflated(
         start_replica, end_replica, batch.comp, batch.records, batch.offsets, int(args.scan_size),
-        args.score_diff, combine_mode(args) if both else 'require_either')
+        args.score_diff, combine_mode(args) if both else 'require_either', want_sides=verbose)
+    numbers, stream_status = result[0], result[1]
+    sides = result[2] if verbose else None
     read_ids = list(batch.read_ids)
+    redone = {}           # read index -> its verbose row, for reads the host had to decode
     for i in sorted(set(batch.records['read'][stream_status != 0].tolist())):
         ids, samples, offsets, status = fast5_native.load_batch(
             [batch.files[i]], scanned_end_samples(args.scan_size), 1)
         if status[0] != 0:
             read_ids[i] = None
             continue
-        numbers[i] = classify_packed_numbers(samples, offsets, start_replica, end_replica, args)[0]
+        if verbose:
+            model = start_replica if start_replica is not None else end_replica
+            row = classify_read_batch(
+                [read_ids[i]], [samples[offsets[0]:offsets[1]]], start_replica,
+                getattr(start_replica, 'input_size', None), end_replica,
+                getattr(end_replica, 'input_size', None), model.n_classes, args, {})[0]
+            redone[i] = row
+            numbers[i] = _CALL_NAMES.index(row.split('\t')[1])
+        else:
+            numbers[i] = classify_packed_numbers(samples, offsets, start_replica, end_replica,
+                                                 args)[0]
     files, calls, lines = {}, {}, []
-    for read_id, fast5_file, number in zip(read_ids, batch.files, numbers.tolist()):
+    for i, (read_id, fast5_file, number) in enumerate(zip(read_ids, batch.files, numbers.tolist())):
         if read_id is None:
             continue
         files[read_id] = fast5_file
         calls[read_id] = _CALL_NAMES[number]
-        lines.append(read_id + '\t' + _CALL_NAMES[number])
+        if not verbose:
+            lines.append(read_id + '\t' + _CALL_NAMES[number])
+        elif i in redone:
+            lines.append(redone[i])
+        else:
+            # the reference's verbose row (classify.py:157-171): per side the 2-decimal
+            # probabilities, followed - with two models - by that side's own call
+            output = [read_id, _CALL_NAMES[number]]
+            for side, replica in (('start', start_replica), ('end', end_replica)):
+                if replica is None:
+                    continue
+                output += ['%.2f' % x for x in sides[side + '_probs'][i]]
+                if both:
+                    output.append(_CALL_NAMES[int(sides[side + '_calls'][i])])
+            lines.append('\t'.join(output))
     return files, calls, lines
 
 

@@ -1074,6 +1074,22 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
                                double score_diff, int combine_mode, int32_t* calls_host,
                                int32_t* stream_status_host, int16_t* samples_host,
                                double* stage_ms) {
+    return dbh_classify_pair_deflated_verbose(start_model, end_model, comp_host, comp_bytes,
+                                              streams_host, n_streams, offsets_host, n_reads,
+                                              scan_size, score_diff, combine_mode, calls_host,
+                                              stream_status_host, samples_host, stage_ms, nullptr,
+                                              nullptr, nullptr, nullptr);
+}
+
+int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_model,
+                                       const uint8_t* comp_host, int64_t comp_bytes,
+                                       const dbh_inflate_stream* streams_host, int64_t n_streams,
+                                       const int64_t* offsets_host, int64_t n_reads, int scan_size,
+                                       double score_diff, int combine_mode, int32_t* calls_host,
+                                       int32_t* stream_status_host, int16_t* samples_host,
+                                       double* stage_ms, int32_t* start_calls_host,
+                                       int32_t* end_calls_host, float* start_probs_host,
+                                       float* end_probs_host) {
     dbh_model* m = start_model ? start_model : end_model;
     if (!m || n_reads < 0 || n_streams < 0 || comp_bytes < 0 ||
         combine_mode < DBH_REQUIRE_EITHER || combine_mode > DBH_REQUIRE_BOTH)
@@ -1220,10 +1236,23 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
     if (e == hipSuccess && samples_host && out_bytes > 0)
         e = hipMemcpyAsync(samples_host, d.d_samples, (size_t)out_bytes, hipMemcpyDeviceToHost,
                            d.stream);
+    // what --verbose prints beside the final call (classify.py:157-171): the sides' probabilities
+    float* side_probs_host[2] = {start_probs_host, end_probs_host};
+    for (int j = 0; j < 2; ++j)
+        if (e == hipSuccess && side_probs_host[j] && models[j])
+            e = hipMemcpyAsync(side_probs_host[j], (const char*)d.d_out + (size_t)j * probs_bytes,
+                               probs_bytes, hipMemcpyDeviceToHost, d.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
     if (e != hipSuccess) return done(hip_fail(e, "dbh_classify_pair_deflated"));
     std::memcpy(calls_host, h + in_small + ((const char*)d_calls - (const char*)d_status),
                 (size_t)n_reads * sizeof(int32_t));
+    // ... and the sides' own calls
+    int32_t* side_calls_host[2] = {start_calls_host, end_calls_host};
+    for (int j = 0; j < 2; ++j)
+        if (side_calls_host[j] && models[j])
+            std::memcpy(side_calls_host[j],
+                        h + in_small + ((const char*)d_side[j] - (const char*)d_status),
+                        (size_t)n_reads * sizeof(int32_t));
     if (stream_status_host && n_streams) {
         const int32_t* sorted_status = (const int32_t*)(h + in_small);
         for (int64_t i = 0; i < n_streams; ++i)

@@ -122,6 +122,11 @@ def load_library():
         'dbh_classify_pair_deflated': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
                                                c_void_p, c_i64, c_int, ctypes.c_double, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+        'dbh_classify_pair_deflated_verbose': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
+                                                       c_i64, c_void_p, c_i64, c_int,
+                                                       ctypes.c_double, c_int, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p]),
         'dbh_classify_workspace_bytes': (c_int, [c_void_p, c_i64, c_int, P(c_size_t)]),
         'dbh_classify_i16_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -180,6 +185,7 @@ EXPORTED_SYMBOLS = [
     'dbh_host_is_pinned',
     'dbh_classify_workspace_bytes', 'dbh_inflate_last_error', 'dbh_inflate_workspace_bytes',
     'dbh_inflate_dev', 'dbh_inflate', 'dbh_classify_pair_deflated',
+    'dbh_classify_pair_deflated_verbose',
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
@@ -300,13 +306,16 @@ def inflate(comp, streams, out_bytes, streams_per_lane=0):
 
 
 def classify_pair_deflated(start_model, end_model, comp, streams, offsets, scan_size, score_diff,
-                           mode='require_either', want_samples=False, want_stages=False):
+                           mode='require_either', want_samples=False, want_stages=False,
+                           want_sides=False):
     """A raw batch of the native loader (``fast5_native.stream_raw``: the reads' Signal chunks
     as stored) -> final calls int32 [N] and the decoder's status per stream, in ONE call of the C
     ABI: upload, inflate on the GPU, both models, ``combine_calls``.  ``comp`` must include its 64
     bytes of padding (``stream_raw``'s arrays do).  ``want_samples``: also the decoded signals
     (int16, all reads back to back); ``want_stages``: milliseconds of upload / inflate / classify
-    on the device."""
+    on the device; ``want_sides``: also what the verbose table prints - a dict with the sides'
+    own calls (``start_calls`` / ``end_calls``, int32 [N]) and merged probabilities
+    (``start_probs`` / ``end_probs``, float32 [N, classes]); None for a side without a model."""
     lib = load_library()
     comp = np.ascontiguousarray(comp, dtype=np.uint8)
     streams = np.ascontiguousarray(streams)
@@ -318,19 +327,31 @@ def classify_pair_deflated(start_model, end_model, comp, streams, offsets, scan_
     status = np.zeros(len(streams), dtype=np.int32)
     samples = np.empty(int(offsets[-1]) if want_samples and n > 0 else 0, dtype=np.int16)
     stages = (ctypes.c_double * 3)()
+    sides = {'start_calls': None, 'end_calls': None, 'start_probs': None, 'end_probs': None}
+    if want_sides:
+        for side, model in (('start', start_model), ('end', end_model)):
+            if model is not None:
+                sides[side + '_calls'] = np.zeros(max(n, 0), dtype=np.int32)
+                sides[side + '_probs'] = np.zeros((max(n, 0), model.n_classes), dtype=np.float32)
+
+    def ptr(a):
+        return a.ctypes.data if a is not None else None
     if n > 0:
-        check(lib.dbh_classify_pair_deflated(
+        check(lib.dbh_classify_pair_deflated_verbose(
             start_model.handle if start_model is not None else None,
             end_model.handle if end_model is not None else None,
             comp.ctypes.data, max(comp.nbytes - 64, 0), streams.ctypes.data, len(streams),
             offsets.ctypes.data, n, int(scan_size), float(score_diff), COMBINE_MODES[mode],
             calls.ctypes.data, status.ctypes.data, samples.ctypes.data if want_samples else None,
-            stages if want_stages else None), 'dbh_classify_pair_deflated')
+            stages if want_stages else None, ptr(sides['start_calls']), ptr(sides['end_calls']),
+            ptr(sides['start_probs']), ptr(sides['end_probs'])), 'dbh_classify_pair_deflated_verbose')
     out = [calls, status]
     if want_samples:
         out.append(samples)
     if want_stages:
         out.append(list(stages))
+    if want_sides:
+        out.append(sides)
     return tuple(out)
 
 

@@ -248,6 +248,20 @@ int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
                                double score_diff, int combine_mode, int32_t* calls_host,
                                int32_t* stream_status_host, int16_t* samples_host,
                                double* stage_ms);
+/* The same call for the reference's verbose table (classify.py:157-171 prints, beside the final
+ * call, each side's 2-decimal probabilities and - with two models - each side's own call):
+ * optional outputs (NULL = not wanted) as in dbh_classify_pair_i16 - the per-side calls (n_reads
+ * int32 each) and per-side merged probabilities (n_reads x n_classes fp32 each).  A side whose
+ * model is NULL leaves its arrays untouched. */
+int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_model,
+                                       const uint8_t* comp_host, int64_t comp_bytes,
+                                       const dbh_inflate_stream* streams_host, int64_t n_streams,
+                                       const int64_t* offsets_host, int64_t n_reads, int scan_size,
+                                       double score_diff, int combine_mode, int32_t* calls_host,
+                                       int32_t* stream_status_host, int16_t* samples_host,
+                                       double* stage_ms, int32_t* start_calls_host,
+                                       int32_t* end_calls_host, float* start_probs_host,
+                                       float* end_probs_host);
 
 /* ---- multi-device: reads shard over the GPUs of one node, calls are all-gathered ---------- */
 /* The reference is single-device (its only knob: set_tensorflow_threads, classify.py:416-423).

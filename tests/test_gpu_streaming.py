@@ -461,3 +461,20 @@ def test_classify_one_read_files_with_the_gpu_inflating(hip, gold, tmp_path, mon
         got = table({'DEEPBINNER_RAW_CLASSIFY_MIN_FILES': '1',
                      'DEEPBINNER_HOST_INFLATE_SHARE': share})
         assert got == want, share
+    # the verbose table (classify.py:157-171: probabilities and each side's own call beside the
+    # final one) takes the same route - dbh_classify_pair_deflated_verbose hands them back - and
+    # prints what the CPU loader's route prints, row for row, with two models and with one
+    args.verbose = True
+    want_verbose = table({'DEEPBINNER_GPU_INFLATE': '0'})
+    assert len(want_verbose[0].split('\t')) == 2 + 2 * (13 + 1)
+    for share in ('0', '60'):
+        got = table({'DEEPBINNER_RAW_CLASSIFY_MIN_FILES': '1',
+                     'DEEPBINNER_HOST_INFLATE_SHARE': share})
+        assert got == want_verbose, share
+    assert [row.split('\t')[:2] for row in want_verbose[1]] == [row.split('\t') for row in want[1]]
+    one = classify.load_and_check_models(os.path.join(MODEL_DIR, START + '.dbw'), None, 6144)
+    models = one
+    want_one = table({'DEEPBINNER_GPU_INFLATE': '0'})
+    assert len(want_one[0].split('\t')) == 2 + 13
+    assert table({'DEEPBINNER_RAW_CLASSIFY_MIN_FILES': '1',
+                  'DEEPBINNER_HOST_INFLATE_SHARE': '0'}) == want_one
