@@ -199,8 +199,8 @@ def _classify_resident(hip, model, d_samples, d_offsets, n, batch, side, stream=
 def test_config2_at_full_size(hip, hip_models, weights):
     """BASELINE.json configs[2] as stated: 100,000 signals (bench.py's, with real-read windows in
     them) through the EXP-NBD103 start AND end models, batch 512, combine_calls (require_either)
-    on the device.  Parity with the oracle's C port + combine_calls on a 2,000-read subsample
-    spread over the whole set; on all of it: the combined calls follow the oracle's table, a
+    on the device.  Parity with the oracle's C port + combine_calls on every read that gets a
+    barcode from either model plus 2,000 random ones; on all of it: the combined calls follow the oracle's table, a
     different batch size and the reversed read order give the same bits."""
     from bench import config_reads
     from oracle import dbref
@@ -222,8 +222,13 @@ def test_config2_at_full_size(hip, hip_models, weights):
                        for b in range(13)] for a in range(13)], dtype=np.int32)
     assert np.array_equal(final, table[c_s, c_e])
     assert (c_s != 0).sum() > 100 and (final != 0).sum() > 100       # the real windows do classify
-    # the oracle on a subsample spread over the whole set
-    pick = np.linspace(0, n - 1, 2000).astype(np.int64)
+    # the oracle on EVERY read either model gives a barcode (the ones that matter: the rest of the
+    # set is synthetic and calls none) and on 2,000 more spread over the whole set: probabilities
+    # within tolerance and every call identical - no read of these sets sits in the 1e-5 band
+    # around score_diff where fp32 and the port may fall on different sides
+    rng = np.random.default_rng(20260929)
+    pick = np.unique(np.concatenate([np.flatnonzero((c_s != 0) | (c_e != 0)),
+                                     rng.choice(n, 2000, replace=False)]))
     sub = np.ascontiguousarray(reads[pick])
     sub_off = np.arange(len(pick) + 1, dtype=np.int64) * 1024
     for model_name, side, probs, calls in (('EXP-NBD103_read_starts', 'start', p_s, c_s),
@@ -231,9 +236,9 @@ def test_config2_at_full_size(hip, hip_models, weights):
         want_probs, want_calls = dbref.CModel(weights[model_name]).classify(
             sub.reshape(-1), sub_off, side, 512, 0.5)
         assert np.abs(probs[pick] - want_probs).max() < PROB_TOL
-        for i in np.flatnonzero(calls[pick] != want_calls):     # only on the threshold itself
-            top = np.sort(want_probs[i])[::-1]
-            assert abs((top[0] - top[1]) - 0.5) < 1e-5
+        assert np.array_equal(calls[pick], want_calls), \
+            '%d calls differ from the oracle' % (calls[pick] != want_calls).sum()
+        assert (want_calls != 0).sum() > (100 if side == 'start' else 10)
     # invariants on all of it: batch size, read order
     p2, c2 = _classify_resident(hip, start, d_s, d_o, n, 4096, 'start')
     assert np.array_equal(p2, p_s) and np.array_equal(c2, c_s)
@@ -244,7 +249,8 @@ def test_config2_at_full_size(hip, hip_models, weights):
 
 def test_config3_at_full_size(hip, hip_models, weights):
     """BASELINE.json configs[3]: SQK-RBK004_read_starts, batch 256.  One GPU's 125,000-read shard
-    of the 1,000,000 against the oracle's C port (2,000-read subsample); then all 1,000,000 reads
+    of the 1,000,000 against the oracle's C port (every read that gets a barcode + 2,000 random
+    ones: calls identical, none in the threshold band); then all 1,000,000 reads
     on this GPU (what `bench.py --config 3` times at N = 1): probabilities are distributions, the
     first shard's results are unchanged inside the whole, and reversing the order of the reads
     reverses the results bit for bit."""
@@ -258,20 +264,29 @@ def test_config3_at_full_size(hip, hip_models, weights):
     d_o = hip.DeviceBuffer.from_array(offsets)
     d_s = hip.DeviceBuffer.from_array(reads[:shard])
     p_shard, c_shard = _classify_resident(hip, model, d_s, d_o, shard, 256, 'start')
-    pick = np.linspace(0, shard - 1, 2000).astype(np.int64)
-    sub = np.ascontiguousarray(reads[pick])
-    want_probs, want_calls = dbref.CModel(weights['SQK-RBK004_read_starts']).classify(
-        sub.reshape(-1), np.arange(len(pick) + 1, dtype=np.int64) * 1024, 'start', 512, 0.5)
-    assert np.abs(p_shard[pick] - want_probs).max() < PROB_TOL
-    for i in np.flatnonzero(c_shard[pick] != want_calls):
-        top = np.sort(want_probs[i])[::-1]
-        assert abs((top[0] - top[1]) - 0.5) < 1e-5
+    cmodel = dbref.CModel(weights['SQK-RBK004_read_starts'])
+
+    def against_the_oracle(probs, calls, upto, seed):
+        """every read with a barcode + 2,000 random ones of reads[:upto]: same call, |dp| < 1e-4"""
+        rng = np.random.default_rng(seed)
+        pick = np.unique(np.concatenate([np.flatnonzero(calls[:upto] != 0),
+                                         rng.choice(upto, 2000, replace=False)]))
+        sub = np.ascontiguousarray(reads[pick])
+        want_probs, want_calls = cmodel.classify(
+            sub.reshape(-1), np.arange(len(pick) + 1, dtype=np.int64) * 1024, 'start', 512, 0.5)
+        assert np.abs(probs[pick] - want_probs).max() < PROB_TOL
+        assert np.array_equal(calls[pick], want_calls), \
+            '%d calls differ from the oracle' % (calls[pick] != want_calls).sum()
+        return int((want_calls != 0).sum())
+
+    assert against_the_oracle(p_shard, c_shard, shard, 1) > 100
     del d_s
     d_all = hip.DeviceBuffer.from_array(reads)
     p_all, c_all = _classify_resident(hip, model, d_all, d_o, n, 256, 'start')
     assert np.array_equal(p_all[:shard], p_shard) and np.array_equal(c_all[:shard], c_shard)
     assert np.abs(p_all.sum(axis=1) - 1).max() < 1e-5 and p_all.min() >= 0
     assert ((c_all >= 0) & (c_all < 13)).all() and (c_all != 0).sum() > 100
+    against_the_oracle(p_all, c_all, n, 2)      # ... and over the whole million
     del d_all
     d_rev = hip.DeviceBuffer.from_array(np.ascontiguousarray(reads[::-1]))
     p_rev, c_rev = _classify_resident(hip, model, d_rev, d_o, n, 1024, 'start')

@@ -276,6 +276,26 @@ def test_realtime_streams_100k_reads_of_multi_read_containers(hip, gold, contain
             classify.classify_read_batch(ids[lo:lo + 1000], signals[lo:lo + 1000], start, 1024,
                                          end, 1024, 13, args, found)
         assert all(calls[rid] == found[rid] for rid in ids)
+    # ... and against the ORACLE, not only against the GPU's other routes: one
+    # whole container read by the pure-Python HDF5 reader (zlib's inflate), both sides through the
+    # oracle's C port, combine_calls by the oracle's restatement - the table's rows for these
+    # 4,000 reads.  A loader or inflate bug that garbled a read the same way on every GPU route
+    # would show here.
+    from deepbinner_amd import load_fast5s
+    from oracle import dbref
+    from deepbinner_amd.model_format import ModelWeights as MW
+    path = paths[len(paths) // 2]
+    reads = list(load_fast5s._python_iter_reads(path))
+    assert READS_PER_CONTAINER <= len(reads) <= READS_PER_CONTAINER + 30      # (+ fixture reads)
+    o_samples, o_offsets = pack([np.asarray(sig, dtype=np.int16) for _, sig in reads])
+    side_calls = {}
+    for side, name in (('start', START), ('end', END)):
+        weights = MW.load(os.path.join(MODEL_DIR, name + '.dbw'))[0]
+        side_calls[side] = dbref.CModel(weights).classify(o_samples, o_offsets, side, 6144, 0.5)[1]
+    as_name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+    differ = [rid for (rid, _), a, b in zip(reads, side_calls['start'], side_calls['end'])
+              if calls[rid] != classify_ref.combine_calls(as_name(a), as_name(b), 'require_either')]
+    assert not differ, '%d of %d rows differ from the oracle' % (len(differ), len(reads))
 
 
 def test_realtime_bins_multi_read_reads_on_the_gpu(hip, gold, tmp_path, monkeypatch, capsys):
