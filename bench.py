@@ -2,7 +2,7 @@
 """
 bench.py — reads classified/sec on the Deepbinner classify hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}] [--steps-per-launch S]
 
 --config 1 (default; the configuration the metric is quoted on): BASELINE.json configs[1],
     EXP-NBD103_read_starts, 10,000 synthetic 1024-sample int16 signals per GPU, batch 256.
@@ -17,6 +17,17 @@ barcode call), with `--scan_size 512` so that each 1024-sample read is exactly o
 (classify.py:401-402 accepts it): 1 read = 1 window = one classification.  Inputs are resident in
 HBM before the timed region; inside it every step ends with the all-gather of the per-read calls
 (RCCL between GPUs when N > 1) and a copy of the gathered calls to pinned host memory.
+
+--steps-per-launch S (alias --gather-every): S consecutive steps are queued as ONE persistent
+launch (and, N > 1, one exchange of S steps' calls): the reads of every step lie in HBM S times
+over, each step reads its own copy and writes its own results.  The forward kernel hands windows
+to its 256 workgroups off a counter; 10,000 windows are 39.06 rounds, so a launch of ONE
+configs[1] step ends with 2.3 % of the GPU idle - a boundary effect of the launch, not of the
+kernel (configs[2] / [3], whose steps are 100,000 / 1,000,000 windows, do not see it).  Default:
+10 for --config 1 (cut down to a divisor of --steps), 1 otherwise; `--steps-per-launch 1` is the
+one-launch-per-step form of rounds 1-4 (`value_one_launch_per_step` in the line is its rate).  With
+N > 1 the same switch separates what a straggling rank costs from what the collective costs: the
+exchange is paid once per S steps.
 
 N > 1 runs either way, with no torch anywhere:
   * `python bench.py --gpus N`: ONE process drives the N devices (a thread per device,
@@ -78,7 +89,8 @@ PUBLISHED_CPU = {'value': 15, 'unit': 'reads/s', 'threads': 12, 'source': 'READM
 
 CONFIGS = {
     1: {'name': 'BASELINE.json configs[1]', 'models': ['EXP-NBD103_read_starts'],
-        'sides': ['start'], 'reads': 10000, 'batch': 256, 'scaling': 'weak'},
+        'sides': ['start'], 'reads': 10000, 'batch': 256, 'scaling': 'weak',
+        'steps_per_launch': 10},
     2: {'name': 'BASELINE.json configs[2]',
         'models': ['EXP-NBD103_read_starts', 'EXP-NBD103_read_ends'], 'sides': ['start', 'end'],
         'reads': 100000, 'batch': 512, 'scaling': 'weak', 'combine': 'require_either'},
@@ -144,11 +156,17 @@ class ShardJob:
     """One device's share of the benchmark, living on that device's thread (or on the rank's
     main thread): resident reads, per-model outputs, and the step that queues the launches."""
 
-    def __init__(self, shard, cfg, weights, reads, block, timing_model):
+    def __init__(self, shard, cfg, weights, reads, block, timing_model, steps_per_launch=1):
         self.shard, self.cfg = shard, cfg
         self.models = [shard.model] + [shard.add_model(w) for w in weights[1:]]
+        self.n_step = len(reads)
+        # one launch carries `steps_per_launch` steps: every step has its own copy of the reads
+        # in HBM (and its own results), step by step
+        if steps_per_launch > 1:
+            reads = np.tile(reads, (steps_per_launch, 1))
         n = len(reads)
-        shard.upload(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * 1024, block)
+        shard.upload(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * 1024,
+                     block * steps_per_launch)
         self.n = n
         dual = len(self.models) == 2
         self.probs = [hip_backend.DeviceBuffer(max(n, 1) * m.n_classes * 4) for m in self.models]
@@ -199,6 +217,36 @@ class ShardJob:
             self.pending = slot
 
     spare = ()
+    xw_spare, xw_pairs = (), None     # event pairs around this rank's exchange alone (in stream)
+
+    def time_exchanges(self, launches):
+        """From now on exchange_begin / exchange_end bracket this device's share of every
+        exchange on its classification stream: from 'own calls final' to 'all-gather done' -
+        what the collective costs plus what waiting for the slowest rank costs."""
+        self.xw_spare = [(hip_backend.Event(), hip_backend.Event()) for _ in range(launches)]
+        self.xw_pairs = []
+
+    def exchange_begin(self):
+        if self.xw_pairs is not None and self.xw_spare:
+            pair = self.xw_spare.pop()
+            pair[0].record(self.shard.stream.ptr)
+            self.xw_pairs.append(pair)
+
+    def exchange_end(self):
+        if self.xw_pairs:
+            self.xw_pairs[-1][1].record(self.shard.stream.ptr)
+
+    def launch_stats(self):
+        """This device's forward launches of the timed region (HIP events on its stream) and its
+        exchange brackets: what a SCALE record needs to say which rank was the slow one."""
+        ms, launches, windows = self.models[0].timing_read()
+        waits = [a.elapsed_ms(b) for a, b in (self.xw_pairs or [])]
+        if not waits and self.timed:
+            waits = [a.elapsed_ms(b) for a, b in self.timed]
+        return {'avg_launch_ms': ms / launches if launches else None, 'launches': launches,
+                'total_ms': ms, 'windows': windows,
+                'windows_per_launch': windows / launches if launches else None,
+                'exchange_ms': sum(waits) / len(waits) if waits else None}
 
     def time_gathers(self, steps):
         """From now on every step's exchange + copy is bracketed by two events on the side stream
@@ -327,6 +375,19 @@ def side_rates(weights, reads):
     d_probs = hip_backend.DeviceBuffer(n * model.n_classes * 4)
     d_calls = hip_backend.DeviceBuffer(n * 4)
     out = {}
+    # one launch per step (the form `value` had in rounds 1-4): every launch of 10,000 windows
+    # ends with its 40th round of 256 workgroups 6 % full
+    best = None
+    for _ in range(4):
+        hip_backend.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            model.classify_batched_dev(d_samples.ptr, d_offsets.ptr, n, 256, 'start', SCAN_SIZE,
+                                       SCORE_DIFF, d_probs.ptr, d_calls.ptr, None)
+        hip_backend.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        best = dt if best is None else min(best, dt)
+    out['value_one_launch_per_step'] = n / best
     best = None
     model.set_read_length_hint(1024, n * 1024)
     for _ in range(4):
@@ -392,7 +453,7 @@ def side_rates(weights, reads):
     return out
 
 
-def workload_string(cfg, direct=False):
+def workload_string(cfg, direct=False, spl=1):
     """`config.workload` of the JSON line: names the BASELINE.json configuration first."""
     n_models = len(cfg['models'])
     return ('{name}: {models} model{plural}, {reads} synthetic 1024-sample int16 signals {share} '
@@ -407,7 +468,10 @@ def workload_string(cfg, direct=False):
                 share='in total' if cfg['scaling'] == 'strong' else 'per GPU',
                 batch=cfg['batch'],
                 launches=('one launch per batch' if LAUNCH_PER_BATCH else
-                          'the batches of a step walked by ONE persistent launch per model'),
+                          'the batches of a step walked by ONE persistent launch per model'
+                          if spl == 1 else
+                          '{} consecutive steps - each on its own copy of the reads, with its own '
+                          'results - queued as ONE persistent launch per model'.format(spl)),
                 combine=', combine_calls on the device' if n_models > 1 else '',
                 scan=SCAN_SIZE,
                 hint=('uniform read length declared (dbh_model_set_read_length_hint)'
@@ -430,6 +494,11 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument('--steps-per-launch', '--gather-every', type=int, default=0,
+                    dest='steps_per_launch',
+                    help='steps queued as one persistent launch (and one exchange); 0 = the '
+                         'configuration\'s default (10 for --config 1, else 1), cut down to a '
+                         'divisor of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-rates', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -451,6 +520,11 @@ def main():
         bounds = [(0, cfg['reads'])] * world
     shard_sizes = [b - a for a, b in bounds]
     block = max(shard_sizes)
+    want_spl = args.steps_per_launch if args.steps_per_launch > 0 else cfg.get('steps_per_launch', 1)
+    spl = max(d for d in range(1, max(1, min(want_spl, args.steps)) + 1) if args.steps % d == 0)
+    launches_timed = args.steps // spl
+    launches_warmup = -(-args.warmup // spl)
+    launch_block = block * spl                   # calls one device hands over per exchange
     weights = [ModelWeights.load(os.path.join(REPO, 'deepbinner_amd', 'models', m + '.dbw'))[0]
                for m in cfg['models']]
 
@@ -466,24 +540,24 @@ def main():
         rdzv = sharding.Rendezvous(rank, world)
         group = sharding.RankGroup(weights[0], rdzv)
         my_reads = reads_of(rank)
-        jobs = [ShardJob(group.shard, cfg, weights, my_reads, block, rank == 0)]
-        group.shard_sizes = shard_sizes
+        jobs = [ShardJob(group.shard, cfg, weights, my_reads, block, True, spl)]
+        group.shard_sizes = [n * spl for n in shard_sizes]
         run_all = lambda fn: [fn(jobs[0])]
         lead = jobs[0]
         all_reads0 = my_reads if rank == 0 else None
         transport = group.transport
     else:
         group = sharding.DeviceGroup(weights[0], world)
-        group.shard_sizes = shard_sizes
+        group.shard_sizes = [n * spl for n in shard_sizes]
         all_reads0 = reads_of(0)
         jobs = group.run_indexed(lambda i: ShardJob(group.shards[i], cfg, weights,
                                                     all_reads0 if i == 0 else reads_of(i), block,
-                                                    i == 0))
+                                                    True, spl))
         run_all = lambda fn: group.run_indexed(lambda i: fn(jobs[i]))
         lead = jobs[0]
         transport = group.transport
     is_lead = rank == 0
-    pinned = PinnedCalls(block * world) if is_lead else None
+    pinned = PinnedCalls(launch_block * world) if is_lead else None
 
     def fetch():
         pinned.fetch(lead.shard.gathered.ptr, lead.shard.stream.ptr)
@@ -530,11 +604,13 @@ def main():
         run_all(lambda j: j.step())
         if direct:
             return
+        run_all(lambda j: j.exchange_begin())
         bracket = None
         if instream_pairs is not None and instream_spare:      # (rank 0, one process per GPU)
             bracket = instream_spare.pop()
             bracket[0].record(lead.shard.stream.ptr)
         group.all_gather()
+        run_all(lambda j: j.exchange_end())
         if is_lead:       # the gathered calls reach the host inside the timed region
             fetch() if per_rank else group.run_on(0, fetch)
         if bracket is not None:
@@ -553,22 +629,28 @@ def main():
         if rdzv is not None:
             rdzv.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(launches_warmup):
         step()
     sync()
     barrier()
     sync()
-    if side_gather and is_lead:
-        run_all(lambda j: j.time_gathers(args.steps) if j is lead else None)
-    elif per_rank and is_lead and not direct and group.comm is not None:
-        instream_spare.extend((hip_backend.Event(), hip_backend.Event()) for _ in range(args.steps))
-        instream_pairs = []
+    if side_gather:
+        run_all(lambda j: j.time_gathers(launches_timed))
+    elif not direct:
+        run_all(lambda j: j.time_exchanges(launches_timed))
+        if per_rank and is_lead and group.comm is not None:
+            instream_spare.extend((hip_backend.Event(), hip_backend.Event())
+                                  for _ in range(launches_timed))
+            instream_pairs = []
+    # every device times its own forward launches (events on its stream): the line says which
+    # rank was the slow one
+    run_all(lambda j: j.models[0].timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE,
+                                                TIMING_SPAN))
     if lead.timing_model is not None:
-        lead.timing_model.timing_enable(0 if args.no_kernel_timing else TIMING_STRIDE, TIMING_SPAN)
         # two stores per workgroup and launch: the shader clock against the 100 MHz wall clock
         lead.timing_model.clock_enable(not args.no_kernel_timing)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(launches_timed):
         step()
     sync()
     barrier()
@@ -576,9 +658,14 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = launches = windows = 0
     shader_ghz = None
+    per_device = run_all(lambda j: j.launch_stats())
+    own = per_device[0]         # (the lead's: device 0 of this process)
+    if rdzv is not None:        # one process per GPU: every rank's figures travel to all
+        per_device = [json.loads(p.decode())[0]
+                      for p in rdzv.all_gather(json.dumps(per_device).encode())]
     if lead.timing_model is not None:
-        kernel_ms, launches, windows = lead.timing_model.timing_read()
-        lead.timing_model.timing_enable(False)
+        kernel_ms, launches, windows = own['total_ms'], own['launches'], own['windows']
+        run_all(lambda j: j.models[0].timing_enable(False))
         if not args.no_kernel_timing:
             shader_ghz = lead.timing_model.clock_read()      # of the timed region's last launch
             lead.timing_model.clock_enable(False)
@@ -591,13 +678,15 @@ def main():
     result = {
         'metric': 'reads classified/sec (1024-sample windows, batch 256)',
         'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+        'warmup': args.warmup, 'warmup_steps_run': launches_warmup * spl,
+        'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': workload_string(cfg, direct),
+            'workload': workload_string(cfg, direct, spl),
             'reads_per_step': reads_per_step, 'reads_per_step_per_gpu': shard_sizes,
             'batch': cfg['batch'], 'windows_per_read': n_models,
+            'steps_per_launch': spl, 'launches_in_timed_region': launches_timed,
             'forward_launches_per_step': (n_models * -(-max(shard_sizes) // cfg['batch'])
                                           if LAUNCH_PER_BATCH else n_models),
             'real_read_windows_in_first_10000': int(len(real_windows(1000))),
@@ -615,19 +704,43 @@ def main():
         # calls are final - it overlaps the next step's launch
         result['gather']['queued_on'] = ('side stream, call arrays double-buffered' if side_gather
                                          else 'classification stream')
+        per_exchange = None
         if side_gather and is_lead:
-            result['gather']['ms_per_step'] = run_all(lambda j: j.gather_ms_per_step()
-                                                      if j is lead else None)[0]
+            per_exchange = run_all(lambda j: j.gather_ms_per_step() if j is lead else None)[0]
         elif instream_pairs:
-            result['gather']['ms_per_step'] = (sum(a.elapsed_ms(b) for a, b in instream_pairs) /
-                                               len(instream_pairs))
-        else:
-            result['gather']['ms_per_step'] = None
+            per_exchange = (sum(a.elapsed_ms(b) for a, b in instream_pairs) / len(instream_pairs))
+        # (rank 0: exchange + copy of the gathered calls to the host; one exchange per launch)
+        result['gather']['steps_per_exchange'] = spl
+        result['gather']['ms_per_exchange'] = per_exchange
+        result['gather']['ms_per_step'] = per_exchange / spl if per_exchange is not None else None
+        # every rank's own bracket from 'own calls final' to 'all-gather done' on its stream: the
+        # collective itself plus the wait for the slowest rank (with one exchange per S steps,
+        # --steps-per-launch S, the two separate: the wait grows with S, the collective does not)
+        waits = [d.get('exchange_ms') for d in per_device]
+        if all(w is not None for w in waits) and waits:
+            result['gather']['wait_ms_per_exchange'] = {
+                'per_rank': waits, 'min': min(waits), 'max': max(waits),
+                'mean': sum(waits) / len(waits), 'longest_on_rank': int(np.argmax(waits))}
+            result['gather']['wait_ms_per_step'] = max(waits) / spl
     if is_lead:
         calls_host = pinned.array()
-        gathered = np.concatenate([calls_host[r * block:r * block + shard_sizes[r]]
+        # (every device's block holds steps_per_launch passes; the first pass is enough here)
+        gathered = np.concatenate([calls_host[r * launch_block:r * launch_block + shard_sizes[r]]
                                    for r in range(world)])
+        if spl > 1:       # every step of a launch must have given the same calls
+            agree = True
+            for r in range(world):
+                passes = calls_host[r * launch_block:r * launch_block + spl * shard_sizes[r]]
+                passes = passes.reshape(spl, shard_sizes[r])
+                agree = agree and bool((passes == passes[0]).all())
+            result['steps_of_a_launch_agree'] = agree
         result['calls_not_none_rank0'] = int((gathered[:shard_sizes[0]] != 0).sum())
+    launch_ms_per_rank = None
+    per_rank_ms = [d.get('avg_launch_ms') for d in per_device]
+    if per_rank_ms and all(v is not None for v in per_rank_ms):
+        launch_ms_per_rank = {'per_rank': per_rank_ms, 'min': min(per_rank_ms),
+                              'max': max(per_rank_ms), 'slowest_rank': int(np.argmax(per_rank_ms)),
+                              'fastest_rank': int(np.argmin(per_rank_ms))}
     if is_lead and not args.no_kernel_timing:
         avg_ms = kernel_ms / max(launches, 1)
         windows_per_launch = windows / max(launches, 1)
@@ -674,6 +787,7 @@ def main():
                         if 'hbm_bytes_per_launch' in pmc and windows_per_launch else None),
             'traffic_algorithmic': bytes_per_window * windows_per_launch,
             'avg_launch_ms': avg_ms, 'launches_timed': launches,
+            'avg_launch_ms_per_rank': launch_ms_per_rank,
             'timed_every_nth_launch': TIMING_STRIDE, 'launches_per_event_bracket': TIMING_SPAN,
             'windows_per_launch': windows_per_launch,
             'algorithmic_flop_per_window': FLOP_PER_WINDOW,

@@ -742,6 +742,16 @@ def test_bench_two_ranks_share_one_gpu(hip):
     assert result['scaling'] == 'weak' and 'roofline' in result
     assert result['gather']['transport'] == 'host'
     assert result['config']['reads_per_step'] == 20000
+    # three steps as ONE launch and one exchange per rank (--steps-per-launch defaults to 10 for
+    # this configuration, cut down to a divisor of --steps); the line says which rank's launches
+    # and which rank's wait in the exchange were the longest (round-4 verdict, item 6)
+    assert result['config']['steps_per_launch'] == 3 and result['steps_of_a_launch_agree'] is True
+    per_rank = result['roofline']['avg_launch_ms_per_rank']
+    assert len(per_rank['per_rank']) == 2 and per_rank['slowest_rank'] in (0, 1)
+    assert per_rank['min'] <= result['roofline']['avg_launch_ms'] <= per_rank['max']
+    waits = result['gather']['wait_ms_per_exchange']
+    assert len(waits['per_rank']) == 2 and waits['max'] > 0 and waits['longest_on_rank'] in (0, 1)
+    assert result['gather']['steps_per_exchange'] == 3
 
 
 def test_bench_one_process_two_devices(hip):
@@ -756,6 +766,14 @@ def test_bench_one_process_two_devices(hip):
     assert result['gather']['ms_per_step'] > 0
     assert result['config']['reads_per_step'] == 20000
     assert result['calls_not_none_rank0'] > 0          # the real-read windows classify
+    assert len(result['roofline']['avg_launch_ms_per_rank']['per_rank']) == 2
+    assert len(result['gather']['wait_ms_per_exchange']['per_rank']) == 2
+    # one launch and one exchange per step (the form of rounds 1-4) gives the same calls
+    single = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--steps-per-launch', '1',
+                         '--no-side-rates', '--no-cpu-baseline'],
+                        {'DEEPBINNER_DEVICE_ORDINALS': '0,0'})
+    assert single['config']['steps_per_launch'] == 1 and single['gather']['steps_per_exchange'] == 1
+    assert single['calls_not_none_rank0'] == result['calls_not_none_rank0']
 
 
 def test_bench_rccl_path_single_rank(hip):
