@@ -62,6 +62,32 @@ struct LdsMem {
     uint16_t* cnt_;
     uint8_t* dist_sym_;
     uint8_t* lens_;
+    // asynchronous reads for the decode front (dbh_inflate_core.h: issue_*): requested here, waited
+    // for by the caller's lds_landed<>()
+    static __device__ __forceinline__ unsigned addr_of(const void* p) {
+        return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+    }
+    __device__ __forceinline__ void ring3_issue(int r, uint32_t& a, uint32_t& b, uint32_t& c) const {
+        uint64_t ab;
+        asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:512"
+                     : "=&v"(ab), "=&v"(c)
+                     : "v"(addr_of(ring_ + r * kLanes))
+                     : "memory");
+        a = (uint32_t)ab;
+        b = (uint32_t)(ab >> 32);
+    }
+    __device__ __forceinline__ void lit_pair_issue(int l, uint32_t& v) const {
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr_of(lit_pair_ + l * kLanes)) : "memory");
+    }
+    __device__ __forceinline__ void dist_pair_issue(int l, uint32_t& v) const {
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr_of(dist_pair_ + l * kLanes)) : "memory");
+    }
+    __device__ __forceinline__ void lit_sym_issue(int i, uint32_t& v) const {
+        asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(addr_of(lit_sym_ + i * kLanes)) : "memory");
+    }
+    __device__ __forceinline__ void dist_sym_issue(int i, uint32_t& v) const {
+        asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr_of(dist_sym_ + i * kLanes)) : "memory");
+    }
     __device__ __forceinline__ uint32_t ring(int r) const { return ring_[r * kLanes]; }
     __device__ __forceinline__ void set_ring(int r, uint32_t v) { ring_[r * kLanes] = v; }
     __device__ __forceinline__ int len(int i) const { return lens_[i * kLanes]; }
@@ -87,106 +113,159 @@ struct StreamInfo {
     int64_t produced;
 };
 
+// STREAMS PER LANE (round 5; DBI_PER_LANE, default 1).  A token is one dependent chain of ~190
+// vector instructions with five dependent LDS reads in it, and a container's 4,000 streams are 63
+// waves for the GPU's 1,024 SIMDs: a wave decodes alone, nothing fills its latencies.  The obvious
+// answer - every lane carries TWO independent streams, each with its own decoder state and its
+// own 1.2 KB of LDS, the two "fronts" of a round (look at the next token: dbh_inflate_core.h) side
+// by side - was built three ways and measured (profiles/r05_inflate/README.md; 4,000 streams of
+// 54 KB, both kernels): one slot 15.7 ms; two slots, front after front 28.3 ms; as one software
+// pipeline with hand-counted LDS waits (each request in flight behind the other slot's
+// arithmetic) 27.7 ms; in lockstep, the two chains alternating instruction by instruction
+// 28.5 ms.  Twice the tokens per wave cost twice the time whatever the arrangement: a wave alone
+// on its SIMD is bound by instruction ISSUE (~6.3 cycles per instruction, dependent or not), not
+// by the latencies between its instructions.  What is left is the number of instructions per
+// token, i.e. decode tables instead of the canonical compare chains (a third of all
+// instructions) - 2 to 4 KB per lane, half or a quarter of the lanes per wave.  The kernel keeps
+// the general form (the slots of a lane are a compile-time array) with one slot.
+#ifndef DBI_PER_LANE
+#define DBI_PER_LANE 1
+#endif
+constexpr int kPerLane = DBI_PER_LANE;
+static_assert(kPerLane * kLdsBytes1 <= 160 * 1024 && (kPerLane == 1 || kPerLane == 2),
+              "kernel 1's LDS no longer fits a CU");
+
 __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
     const uint8_t* __restrict__ comp, int64_t comp_total,
     const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
     StreamInfo* __restrict__ info, int* __restrict__ next_stream) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes1];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[kPerLane * kLdsBytes1];
     const int lane = threadIdx.x;
-    LdsMem mem;
-    mem.ring_ = reinterpret_cast<uint32_t*>(lds + kRingOff) + lane;
-    mem.lit_pair_ = reinterpret_cast<uint32_t*>(lds + kLitPairOff) + lane;
-    mem.dist_pair_ = reinterpret_cast<uint32_t*>(lds + kDistPairOff) + lane;
-    mem.lit_sym_ = reinterpret_cast<uint16_t*>(lds + kLitSymOff) + lane;
-    mem.cnt_ = reinterpret_cast<uint16_t*>(lds + kCntOff) + lane;
-    mem.dist_sym_ = lds + kDistSymOff + lane;
-    mem.lens_ = lds + kLensOff + lane;
-
-    Lane L;
-    L.state = dbi::kDone;
-    L.status = dbi::kOk;
-    L.ended = 0;
-    L.adler = 0;
-    L.out_pos = 0;
-    L.out_cap = 0;
-    L.final_block = 0;
-    L.stored_left = 0;
+    LdsMem mem[kPerLane];
+    Lane L[kPerLane];
+    uint32_t* tok[kPerLane];
+    int n_tok[kPerLane], cur[kPerLane];
 #pragma unroll
-    for (int l = 0; l < 15; ++l) L.lim_lit[l] = L.lim_dist[l] = 0;
-    L.br.in = comp;
-    L.br.limit_bits = 0;
-    L.br.bp = L.br.wr = 0;
-    L.br.pending = 0;
-    L.br.fetch_cap = 0;
-    uint32_t* tok = tokens;
-    int n_tok = 0;
-    int cur = -1;                 // the stream this lane is decoding
+    for (int s = 0; s < kPerLane; ++s) {
+        uint8_t* lds = lds_all + s * kLdsBytes1;
+        mem[s].ring_ = reinterpret_cast<uint32_t*>(lds + kRingOff) + lane;
+        mem[s].lit_pair_ = reinterpret_cast<uint32_t*>(lds + kLitPairOff) + lane;
+        mem[s].dist_pair_ = reinterpret_cast<uint32_t*>(lds + kDistPairOff) + lane;
+        mem[s].lit_sym_ = reinterpret_cast<uint16_t*>(lds + kLitSymOff) + lane;
+        mem[s].cnt_ = reinterpret_cast<uint16_t*>(lds + kCntOff) + lane;
+        mem[s].dist_sym_ = lds + kDistSymOff + lane;
+        mem[s].lens_ = lds + kLensOff + lane;
+        L[s].state = dbi::kDone;
+        L[s].status = dbi::kOk;
+        L[s].ended = 0;
+        L[s].adler = 0;
+        L[s].out_pos = 0;
+        L[s].out_cap = 0;
+        L[s].final_block = 0;
+        L[s].stored_left = 0;
+#pragma unroll
+        for (int l = 0; l < 15; ++l) L[s].lim_lit[l] = L[s].lim_dist[l] = 0;
+        L[s].br.in = comp;
+        L[s].br.limit_bits = 0;
+        L[s].br.bp = L[s].br.wr = 0;
+        L[s].br.pending = 0;
+        L[s].br.fetch_cap = 0;
+        tok[s] = tokens;
+        n_tok[s] = 0;
+        cur[s] = -1;              // the stream this slot of the lane is decoding
+    }
     bool more = true;             // streams may be left to fetch
     for (;;) {
-        // A lane that has finished its stream takes the next one off the counter - HERE, where
+        // A slot that has finished its stream takes the next one off the counter - HERE, where
         // no lane is inside a block: zlib ends a block after a fixed number of symbols, so
         // streams that start together reach their block headers together (and the hot loop
         // below ends when the last lane has left its block); a stream taken up in between
         // would make every lane of the wave wait for its headers, each time, alone.
-        while (L.state == dbi::kDone && more) {
-            if (cur >= 0) {
+#pragma unroll
+        for (int s = 0; s < kPerLane; ++s) {
+            while (L[s].state == dbi::kDone && more) {
+                if (cur[s] >= 0) {
+                    StreamInfo r;
+                    r.status = L[s].status;
+                    r.ended = L[s].ended;
+                    r.adler = L[s].adler;
+                    r.n_tokens = n_tok[s];
+                    r.produced = L[s].out_pos;
+                    info[cur[s]] = r;
+                }
+                cur[s] = atomicAdd(next_stream, 1);
+                if (cur[s] >= n_streams) {
+                    cur[s] = -1;
+                    more = false;
+                    break;
+                }
+                const dbh_inflate_stream st = streams[cur[s]];
+                n_tok[s] = 0;
+                if (st.mode == DBH_INFLATE_ZLIB) {
+                    // (the caller's buffer is readable for 64 bytes beyond comp_total)
+                    dbi::lane_start(L[s], mem[s], comp + st.comp_offset, st.comp_bytes, st.out_bytes,
+                                    comp_total + 64 - st.comp_offset);
+                    tok[s] = tokens + st.out_offset;          // one token slot per byte of output
+                } else {
+                    L[s].status = dbi::kOk;                  // nothing to decode: kernel 2 copies it
+                    L[s].ended = 0;
+                    L[s].adler = 0;
+                    L[s].out_pos = 0;
+                }
+            }
+            // (a slot left with a finished stream when the counter ran out: its record)
+            if (L[s].state == dbi::kDone && !more && cur[s] >= 0) {
                 StreamInfo r;
-                r.status = L.status;
-                r.ended = L.ended;
-                r.adler = L.adler;
-                r.n_tokens = n_tok;
-                r.produced = L.out_pos;
-                info[cur] = r;
-            }
-            cur = atomicAdd(next_stream, 1);
-            if (cur >= n_streams) {
-                cur = -1;
-                more = false;
-                break;
-            }
-            const dbh_inflate_stream s = streams[cur];
-            n_tok = 0;
-            if (s.mode == DBH_INFLATE_ZLIB) {
-                // (the caller's buffer is readable for 64 bytes beyond comp_total)
-                dbi::lane_start(L, mem, comp + s.comp_offset, s.comp_bytes, s.out_bytes,
-                                comp_total + 64 - s.comp_offset);
-                tok = tokens + s.out_offset;          // one token slot per byte of output
-            } else {
-                L.status = dbi::kOk;                  // nothing to decode: kernel 2 copies it
-                L.ended = 0;
-                L.adler = 0;
-                L.out_pos = 0;
+                r.status = L[s].status;
+                r.ended = L[s].ended;
+                r.adler = L[s].adler;
+                r.n_tokens = n_tok[s];
+                r.produced = L[s].out_pos;
+                info[cur[s]] = r;
+                cur[s] = -1;
             }
         }
-        if (!__any(L.state != dbi::kDone)) break;
+        if (!__any(L[0].state != dbi::kDone || L[kPerLane - 1].state != dbi::kDone)) break;
         // the rare states: a block header (with its two code builds), a stored block's bytes
-        if (L.state == dbi::kNeedBlock) {
-            dbi::lane_block(L, mem);
-        } else if (L.state == dbi::kStored) {
-            uint32_t token;
-            if (dbi::lane_stored(L, mem, &token)) tok[n_tok++] = token;
-        }
-        // the hot loop: every lane that is inside a Huffman block decodes four tokens per round
-        // (lanes that have left their block wait for the others)
-        while (__any(L.state == dbi::kDecode)) {
-            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            const bool p0 = dbi::lane_decode(L, mem, &t0);
-            const bool p1 = dbi::lane_decode(L, mem, &t1);
-            const bool p2 = dbi::lane_decode(L, mem, &t2);
-            const bool p3 = dbi::lane_decode(L, mem, &t3);
-            // (a store per token and lane would be 64 partial cache lines per step: four tokens
-            // go out as one 16-byte store - all four real in all but a handful of rounds)
-            if (p0 && p1 && p2 && p3) {
-                const uint32_t four[4] = {t0, t1, t2, t3};
-                __builtin_memcpy(tok + n_tok, four, 16);
-                n_tok += 4;
-            } else {
-                if (p0) tok[n_tok++] = t0;
-                if (p1) tok[n_tok++] = t1;
-                if (p2) tok[n_tok++] = t2;
-                if (p3) tok[n_tok++] = t3;
+#pragma unroll
+        for (int s = 0; s < kPerLane; ++s) {
+            if (L[s].state == dbi::kNeedBlock) {
+                dbi::lane_block(L[s], mem[s]);
+            } else if (L[s].state == dbi::kStored) {
+                uint32_t token;
+                if (dbi::lane_stored(L[s], mem[s], &token)) tok[s][n_tok[s]++] = token;
             }
-            L.br.checkpoint(mem);
+        }
+        // the hot loop: every slot that is inside a Huffman block decodes four tokens per round
+        // (slots that have left their block wait for the others)
+        while (__any(L[0].state == dbi::kDecode || L[kPerLane - 1].state == dbi::kDecode)) {
+            uint32_t t[kPerLane][4];
+            bool p[kPerLane][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dbi::Decoded dec[kPerLane];
+                dbi::lane_decode_fronts<kPerLane, LdsMem>(L, mem, dec);
+#pragma unroll
+                for (int s = 0; s < kPerLane; ++s) {
+                    t[s][k] = 0;
+                    p[s][k] = dbi::lane_decode_commit(L[s], dec[s], &t[s][k]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kPerLane; ++s) {
+                // (a store per token and lane would be 64 partial cache lines per step: four
+                // tokens go out as one 16-byte store - all four real in all but a handful of rounds)
+                if (p[s][0] && p[s][1] && p[s][2] && p[s][3]) {
+                    const uint32_t four[4] = {t[s][0], t[s][1], t[s][2], t[s][3]};
+                    __builtin_memcpy(tok[s] + n_tok[s], four, 16);
+                    n_tok[s] += 4;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p[s][k]) tok[s][n_tok[s]++] = t[s][k];
+                }
+                L[s].br.checkpoint(mem[s]);
+            }
         }
     }
 }
@@ -435,7 +514,7 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
     // the lanes take streams off a counter: with one stream per lane (the default) a launch is
     // as wide as it can be and lasts as long as its longest stream; with several, a fraction of
     // the CUs does the same work in the time the longest stream needs anyway
-    const int per_lane = streams_per_lane > 0 ? streams_per_lane : 1;
+    const int per_lane = (streams_per_lane > 0 ? streams_per_lane : 1) * kPerLane;
     const int64_t lanes = (n_streams + per_lane - 1) / per_lane;
     hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((lanes + kLanes - 1) / kLanes)),
                        dim3(kLanes), 0, (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n,

@@ -124,6 +124,11 @@ DBI_HD uint32_t low_bits(uint32_t v, uint32_t n) {      // n <= 16
 // first bit first, everything else in deflate lowest bit first)
 DBI_HD uint32_t first16(uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef DBI_NO_SDWA
+    uint32_t r = __builtin_bitreverse32(w) >> 16;
+    asm volatile("" : "+v"(r));      // (a value of its own: not a sub-dword selection in every user)
+    return r;
+#endif
     return __builtin_bitreverse32(w) >> 16;
 #else
     uint32_t r = 0;
@@ -340,6 +345,30 @@ DBI_HD uint32_t code_length(uint32_t c, const uint32_t (&lim)[15]) {
     return (uint32_t)(N + 1) - below;
 #endif
 }
+// The same for N slots at once, the slots' chains interleaved instruction by instruction: a
+// vector instruction that needs the result of the one before it issues later than one that does
+// not, and the chain of one slot is 15 dependent instructions long.
+template <int NL, int N>
+DBI_HD void code_lengths(const uint32_t (&c)[N], const uint32_t* const (&lim)[N], uint32_t (&out)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t below[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) below[s] = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+#pragma unroll
+        for (int s = 0; s < N; ++s) below[s] = __builtin_amdgcn_alignbit(below[s], c[s] - lim[s][l], 31);
+    }
+#pragma unroll
+    for (int s = 0; s < N; ++s) out[s] = (uint32_t)(NL + 1) - (uint32_t)__builtin_popcount(below[s]);
+#else
+    for (int s = 0; s < N; ++s) {
+        uint32_t below = 0;
+        for (int l = 0; l < NL; ++l) below += (c[s] - lim[s][l]) >> 31;
+        out[s] = (uint32_t)(NL + 1) - below;
+    }
+#endif
+}
 // index of its symbol among the sorted ones, from the {first code, first index} of its length
 DBI_HD uint32_t sorted_index(uint32_t c, uint32_t len, uint32_t pair) {
     return (pair >> 16) + ((c - (pair & 0xFFFFu)) >> (16u - len));
@@ -490,59 +519,216 @@ DBI_HD bool lane_stored(Lane& L, Mem& mem, uint32_t* token) {
 // The hot path: ONE token of a lane that is inside a Huffman block - straight-line code, the
 // same for a literal, a match and an end of block (all lanes of a wave run it together, so a
 // branch would be taken by somebody every time): one 64-bit window (a token is at most 15 + 5 +
-// 15 + 13 bits), both codes decoded from it, the results selected.  A lane in any other state
-// passes through unchanged.  Returns true with *token set when a token was produced.
+// 15 + 13 bits), both codes decoded from it, the results selected.
+//   In two halves, because a token is ONE dependent chain - window, code length, two dependent
+// LDS reads, selects, the second code the same again - and a wave that decodes alone on its SIMD
+// (a container is 4,000 streams: 63 waves for 1,024 SIMDs) has nothing to fill the latencies with:
+// lane_decode_front only LOOKS (no state changes), so a kernel whose lanes carry two streams each
+// can run the two fronts side by side in one basic block - the compiler interleaves the two chains
+// - and commit them one after the other (dbh_inflate.hip).
+struct Decoded {
+    uint32_t used, length, token;
+    bool bad, fail, is_end, beyond;
+};
+// all ones if bit `bit` of v is set, else zero (selects below are AND / OR with such masks: a
+// ternary may become a branch, and a branch ends the basic block the two chains share)
+DBI_HD uint32_t bit_mask(uint32_t v, int bit) { return (uint32_t)((int32_t)(v << (31 - bit)) >> 31); }
+DBI_HD uint32_t pick(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// LDS reads whose latency the front hides behind the OTHER slot's arithmetic: on the device they are
+// issued as they are asked for and waited for where their value is needed, with a count of the
+// requests that may still be in flight behind them (LDS answers in order) - the compiler's own
+// wait would be for everything, right behind the request.  On the host they are plain reads.
 template <class Mem>
-DBI_HD bool lane_decode(Lane& L, Mem& mem, uint32_t* token) {
-    BitReader& br = L.br;
-    const bool active = L.state == kDecode;
-    uint32_t lo, hi;
-    br.window64(mem, lo, hi);
-    // literal / length
-    const uint32_t c1 = first16(lo);
-    const uint32_t n1 = code_length<15>(c1, L.lim_lit);
-    const uint32_t l1 = umin(n1, 15u);
-    const uint32_t e = mem.lit_sym((int)umin(sorted_index(c1, l1, mem.lit_pair((int)l1)),
-                                             (uint32_t)(kLitSyms - 1)));
-    const bool is_len = (e & kEntryLength) != 0, is_end = (e & kEntryEnd) != 0;
-    bool bad = n1 > 15u || (e & kEntryBad) != 0;
-    const uint32_t eb = is_len ? (e >> 8) & 7u : 0u;
-    uint64_t w = (((uint64_t)hi << 32) | lo) >> l1;
-    uint32_t length = is_len ? 3u + (e & 0xFFu) + low_bits((uint32_t)w, eb) : is_end ? 0u : 1u;
-    w >>= eb;
+DBI_HD void issue_ring3(const Mem& mem, int row, uint32_t& a, uint32_t& b, uint32_t& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mem.ring3_issue(row, a, b, c);
+#else
+    a = mem.ring(row);
+    b = mem.ring(row + 1);
+    c = mem.ring(row + 2);
+#endif
+}
+template <class Mem>
+DBI_HD void issue_lit_pair(const Mem& mem, int l, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mem.lit_pair_issue(l, v);
+#else
+    v = mem.lit_pair(l);
+#endif
+}
+template <class Mem>
+DBI_HD void issue_dist_pair(const Mem& mem, int l, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mem.dist_pair_issue(l, v);
+#else
+    v = mem.dist_pair(l);
+#endif
+}
+template <class Mem>
+DBI_HD void issue_lit_sym(const Mem& mem, int i, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mem.lit_sym_issue(i, v);
+#else
+    v = mem.lit_sym(i);
+#endif
+}
+template <class Mem>
+DBI_HD void issue_dist_sym(const Mem& mem, int i, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    mem.dist_sym_issue(i, v);
+#else
+    v = mem.dist_sym(i);
+#endif
+}
+// everything but the PENDING youngest LDS requests has landed
+template <int PENDING>
+DBI_HD void lds_landed() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+#endif
+}
+DBI_HD void pin(uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));        // (uses of v stay behind the wait in front of this)
+#else
+    (void)v;
+#endif
+}
+
+// The fronts of N slots (N = 1: the CPU harness and lane_decode; N = 2: the kernel), without a
+// branch and in LOCKSTEP over the slots: every statement is made for all slots before the next
+// one, so that the instruction stream alternates between the slots' (independent) chains - a
+// vector instruction that depends on its predecessor issues later than one that does not - and
+// each stage's LDS reads are in flight together.
+template <int N, class Mem>
+DBI_HD void lane_decode_fronts(const Lane (&L)[N], const Mem (&mem)[N], Decoded (&out)[N]) {
+    uint32_t d0[N], d1[N], d2[N], lo[N], hi[N], sh[N];
+    uint32_t c1[N], n1[N], l1[N], pair1[N], e[N], i1[N];
+    uint32_t is_len[N], eb[N], length[N], c2[N], n2[N], l2[N], pair2[N], d[N], i2[N];
+    uint32_t wl[N], wh[N], not_end[N], ext[N];
+    const uint32_t* lim1[N];
+    const uint32_t* lim2[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DBI_SLOTS _Pragma("unroll") for (int s = 0; s < N; ++s)
+#else
+#define DBI_SLOTS for (int s = 0; s < N; ++s)
+#endif
+    DBI_SLOTS {
+        lim1[s] = L[s].lim_lit;
+        lim2[s] = L[s].lim_dist;
+    }
+    DBI_SLOTS issue_ring3(mem[s], (int)((L[s].br.bp >> 5) & (uint32_t)(kRingRows - 1)), d0[s], d1[s], d2[s]);
+    DBI_SLOTS sh[s] = L[s].br.bp & 31u;
+    lds_landed<0>();
+    DBI_SLOTS {
+        pin(d0[s]);
+        pin(d1[s]);
+        pin(d2[s]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    DBI_SLOTS lo[s] = __builtin_amdgcn_alignbit(d1[s], d0[s], sh[s]);
+    DBI_SLOTS hi[s] = __builtin_amdgcn_alignbit(d2[s], d1[s], sh[s]);
+#else
+    DBI_SLOTS lo[s] = (uint32_t)((((uint64_t)d1[s] << 32) | d0[s]) >> sh[s]);
+    DBI_SLOTS hi[s] = (uint32_t)((((uint64_t)d2[s] << 32) | d1[s]) >> sh[s]);
+#endif
+    // literal / length: the code's length, then {first code, first index} of that length ...
+    DBI_SLOTS c1[s] = first16(lo[s]);
+    code_lengths<15, N>(c1, lim1, n1);
+    DBI_SLOTS l1[s] = umin(n1[s], 15u);
+    DBI_SLOTS issue_lit_pair(mem[s], (int)l1[s], pair1[s]);
+    lds_landed<0>();
+    DBI_SLOTS pin(pair1[s]);
+    // ... its entry among the sorted symbols
+    DBI_SLOTS i1[s] = umin(sorted_index(c1[s], l1[s], pair1[s]), (uint32_t)(kLitSyms - 1));
+    DBI_SLOTS issue_lit_sym(mem[s], (int)i1[s], e[s]);
+    // (the window behind the code, while the entry travels)
+    DBI_SLOTS {
+        const uint64_t w = (((uint64_t)hi[s] << 32) | lo[s]) >> l1[s];
+        wl[s] = (uint32_t)w;
+        wh[s] = (uint32_t)(w >> 32);
+    }
+    lds_landed<0>();
+    DBI_SLOTS pin(e[s]);
+    DBI_SLOTS is_len[s] = bit_mask(e[s], 15);                          // kEntryLength
+    DBI_SLOTS eb[s] = (e[s] >> 8) & 7u & is_len[s];
+    DBI_SLOTS not_end[s] = ((e[s] >> 14) & 1u) ^ 1u;                   // kEntryEnd: length 0, a literal: 1
+    DBI_SLOTS ext[s] = low_bits(wl[s], eb[s]);
+    DBI_SLOTS length[s] = pick(is_len[s], 3u + (e[s] & 0xFFu) + ext[s], not_end[s]);
+    DBI_SLOTS {
+        const uint64_t w = (((uint64_t)wh[s] << 32) | wl[s]) >> eb[s];
+        wl[s] = (uint32_t)w;
+        wh[s] = (uint32_t)(w >> 32);
+    }
     // distance (decoded whatever the symbol was; only looked at behind a length)
-    const uint32_t c2 = first16((uint32_t)w);
-    const uint32_t n2 = code_length<15>(c2, L.lim_dist);
-    const uint32_t l2 = umin(n2, 15u);
-    const uint32_t d = mem.dist_sym((int)umin(sorted_index(c2, l2, mem.dist_pair((int)l2)),
-                                              (uint32_t)(kDistSyms - 1)));
-    const uint32_t half = d >> 1;
-    const uint32_t db = half > 1u ? half - 1u : 0u;
-    const uint32_t dbase = d < 4u ? d + 1u : 1u + ((2u | (d & 1u)) << db);
-    const uint32_t distance = dbase + low_bits((uint32_t)(w >> l2), db);
-    bad = bad || (is_len && (n2 > 15u || d > 29u));
-    const uint32_t used = l1 + (is_len ? eb + l2 + db : 0u);
-    const bool fail = bad || br.bp + used > br.limit_bits;
-    // more data than wanted: a match keeps what is; the lane stops
-    const int room = L.out_cap - L.out_pos;
-    const bool beyond = (int)length > room;
-    if (beyond) length = room > 0 ? (uint32_t)room : 0u;
-    const uint32_t tk = is_len ? match_token(length, distance) : e & 0xFFu;
-    if (!active) return false;
-    br.bp += used;
-    if (fail) {
-        lane_fail(L, bad ? kBadSymbol : kTruncated);
+    DBI_SLOTS c2[s] = first16(wl[s]);
+    code_lengths<15, N>(c2, lim2, n2);
+    DBI_SLOTS l2[s] = umin(n2[s], 15u);
+    DBI_SLOTS issue_dist_pair(mem[s], (int)l2[s], pair2[s]);
+    lds_landed<0>();
+    DBI_SLOTS pin(pair2[s]);
+    DBI_SLOTS i2[s] = umin(sorted_index(c2[s], l2[s], pair2[s]), (uint32_t)(kDistSyms - 1));
+    DBI_SLOTS issue_dist_sym(mem[s], (int)i2[s], d[s]);
+    DBI_SLOTS {
+        const uint64_t w = (((uint64_t)wh[s] << 32) | wl[s]) >> l2[s];
+        wl[s] = (uint32_t)w;             // the distance's extra bits
+    }
+    lds_landed<0>();
+    DBI_SLOTS pin(d[s]);
+    DBI_SLOTS {
+        const uint32_t half = d[s] >> 1;
+        const uint32_t db = (half > 1u ? half : 1u) - 1u;
+        const uint32_t small = (uint32_t)((int32_t)(d[s] - 4u) >> 31);          // d < 4
+        const uint32_t dbase = pick(small, d[s] + 1u, 1u + ((2u | (d[s] & 1u)) << db));
+        const uint32_t distance = dbase + low_bits(wl[s], db);
+        const bool bad = n1[s] > 15u || (e[s] & kEntryBad) != 0 ||
+                         (is_len[s] != 0u && (n2[s] > 15u || d[s] > 29u));
+        Decoded& r = out[s];
+        r.used = l1[s] + eb[s] + ((l2[s] + db) & is_len[s]);
+        r.bad = bad;
+        r.fail = bad || L[s].br.bp + r.used > L[s].br.limit_bits;
+        // more data than wanted: a match keeps what is; the lane stops
+        const int room = L[s].out_cap - L[s].out_pos;
+        r.beyond = (int)length[s] > room;
+        const uint32_t fits = umin(length[s], (uint32_t)(room > 0 ? room : 0));
+        r.length = fits;
+        r.is_end = (e[s] & kEntryEnd) != 0;
+        r.token = pick(is_len[s], match_token(fits, distance), e[s] & 0xFFu);
+    }
+#undef DBI_SLOTS
+}
+template <class Mem>
+DBI_HD Decoded lane_decode_front(const Lane& L, const Mem& mem) {
+    // (one slot: references into one-element arrays)
+    Decoded out[1];
+    lane_decode_fronts<1, Mem>(reinterpret_cast<const Lane(&)[1]>(L),
+                               reinterpret_cast<const Mem(&)[1]>(mem), out);
+    return out[0];
+}
+// A lane in any state but kDecode passes through unchanged.  Returns true with *token set when
+// a token was produced.
+DBI_HD bool lane_decode_commit(Lane& L, const Decoded& r, uint32_t* token) {
+    if (L.state != kDecode) return false;
+    L.br.bp += r.used;
+    if (r.fail) {
+        lane_fail(L, r.bad ? kBadSymbol : kTruncated);
         return false;
     }
-    L.out_pos += (int)length;
-    if (beyond) {
+    L.out_pos += (int)r.length;
+    if (r.beyond) {
         L.state = kDone;
-    } else if (is_end) {
+    } else if (r.is_end) {
         L.state = kNeedBlock;
         if (L.final_block) lane_ended(L);
     }
-    *token = tk;
-    return length > 0u;
+    *token = r.token;
+    return r.length > 0u;
+}
+template <class Mem>
+DBI_HD bool lane_decode(Lane& L, Mem& mem, uint32_t* token) {
+    const Decoded r = lane_decode_front(L, mem);
+    return lane_decode_commit(L, r, token);
 }
 
 }  // namespace dbi
