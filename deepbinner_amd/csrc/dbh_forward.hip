@@ -228,6 +228,9 @@ __device__ __forceinline__ void progress_priority() {
 // behind and pulls away, so it must not lie at the layer's first steps, where the halo rows of the
 // neighbours are needed: there the schedule should take a normal step DOWN, which lets whoever is
 // behind catch up.
+#ifndef DBH_CATCHUP
+#define DBH_CATCHUP 0
+#endif
 #ifndef DBH_PRIO_PHASE
 #define DBH_PRIO_PHASE 12
 #endif
@@ -1431,7 +1434,7 @@ __device__ __forceinline__ void w43t_load_halo(f2 (&hb)[2], unsigned h_addr) {
 // One step of a chained tile.  HOFF >= 0: tile 0 of conv3 / conv4 - the step first turns
 // Y[g][h] (g = SP >> 1, h = SP & 1) and its two halo positions into U[.][SP].  pre(SP) runs in
 // front of the step's LDS requests (polls), side(SP) behind its MFMAs.
-template <int HOFF, int STEP0, int STEPS, int SP, class Pre, class Side>
+template <int HOFF, int STEP0, int STEPS, int SP, int CATCH, class Pre, class Side>
 __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
                                           unsigned b_addr, f2 (&hbuf)[2][2], f4 (&buf)[2][3],
                                           f4 (&acc)[6], f4 bias4, bool wave_hi, const Pre& pre,
@@ -1449,7 +1452,16 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     f4(&b)[3] = buf[SP & 1];
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
-    progress_priority_pair<STEP0 + SP, STEPS>(wave_hi);
+    if constexpr (SP < CATCH) {
+        // the last tile before a workgroup barrier: the younger wave of the SIMD, which runs ~1k
+        // cycles behind its partner through all of stage B (the older one wins every tie), gets
+        // the pipe first for a few steps, so that the two reach the barrier together instead of
+        // the older one waiting there while the younger one finishes alone
+        if (wave_hi) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+    } else {
+        progress_priority_pair<STEP0 + SP, STEPS>(wave_hi);
+    }
     if constexpr (BUILD) {
         f2(&hb)[2] = hbuf[SP & 1];
         asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
@@ -1476,14 +1488,14 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     side(IntC<SP>{});
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP + 1 < 6)
-        w43t_step<HOFF, STEP0, STEPS, SP + 1>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre,
+        w43t_step<HOFF, STEP0, STEPS, SP + 1, CATCH>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre,
                                               side);
 }
 
 // bias_addr: this lane's place in the LDS parameter table (kParams + 4q); BIAS_OFF: floats from
 // there to the tile's four biases - requested first, so that step 0's hand-counted wait retires it
 // (a load the compiler sees would be waited for with lgkmcnt(0), fragment requests and all)
-template <int HOFF, int STEP0, int STEPS, int BIAS_OFF, class Pre, class Side>
+template <int HOFF, int STEP0, int STEPS, int BIAS_OFF, int CATCH = 0, class Pre, class Side>
 __device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
                                           unsigned bias_addr, const float* slot_lane,
                                           f4 (&acc)[6], bool wave_hi, const Pre& pre,
@@ -1494,7 +1506,7 @@ __device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     const f4 bias4 = ds_read_f4<BIAS_OFF * 4>(bias_addr);
     if constexpr (HOFF >= 0 && !(DBH_ABL & 8)) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0)>(hbuf[0], h_addr);
     w43_load_b<0>(buf[0], b_addr);
-    w43t_step<HOFF, STEP0, STEPS, 0>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre, side);
+    w43t_step<HOFF, STEP0, STEPS, 0, CATCH>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre, side);
 }
 
 struct NoPre {
@@ -1775,7 +1787,7 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         });
     chain_arrive(arrive_addr, 1);
     mark(ts, 12);
-    w43t_tile<-1, 12, 18, B4 + 32>(
+    w43t_tile<-1, 12, 18, B4 + 32, DBH_CATCHUP>(
         U, Y, h_addr, bias_addr, lds + kSlot2 + lane * 4, acc[0], wave_hi,
         [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
