@@ -1,7 +1,8 @@
 // dbh_forward.hip — the Deepbinner forward pass as ONE persistent gfx950 kernel: at most one
 // 512-thread workgroup (8 wave64s, 2 per SIMD) per CU; workgroup b starts with window b and takes
 // every further window off a counter in global memory, carrying each 1024-sample window through
-// all 20 convolutions with the activations resident in LDS (or in registers) the whole way.  Per
+// all 20 convolutions with the activations resident in registers (conv1 .. conv6) or in LDS the
+// whole way.  Per
 // window HBM gives 2 KiB of int16 and takes n_classes floats + a call; the weights stream from L2
 // by LDS-DMA; the one round trip through global memory is conv17's 16 x 48 output, parked in a
 // per-workgroup slot until the batched tail runs (3 KB per window, written and read back by the
@@ -19,20 +20,24 @@
 //     matrix pipe (v_mfma_f32_16x16x4_f32: M = 16 positions, N = 16 output channels, K = 4 input
 //     channels).  The pipe is shared with the vector ALU: every other vector instruction costs
 //     matrix time, so the code counts them;
-//   - conv1 (one input channel) has no phase and no LDS image of its own: the wave that owns a
-//     tile of conv2's output quads computes the conv1 rows they need inside conv2's first tile,
-//     TRANSPOSED (M = channels, N = positions), so that the MFMA leaves them where conv2's input
-//     transform wants them - in registers;
+//   - stage B (conv1 .. conv4, 84 % of the work) and conv5, conv6 behind it are ONE CHAIN IN
+//     REGISTERS (stage_b_chain): every layer runs TRANSPOSED (M = output channels = the weights as
+//     the A operand, N = the wave's 16 quads), so that an MFMA leaves each lane with the output
+//     channels of its own quad that the next layer's k-steps want from it; output transform, bias,
+//     ReLU, the next input transform are in-lane but for one halo position each side (a DPP row
+//     shift; at a wave's two ends 2 x 48 floats through LDS and a counter word the neighbours
+//     poll).  No activation image and no workgroup barrier from the top of a window to conv6's
+//     last store; conv1 (one input channel) is computed inside conv2's first tile the same way;
 //   - the k = 3 layers with enough positions run as Winograd: F(4,3) for conv2,3,4 (L = 512, one
 //     tile of 16 quads per wave, N tile by N tile with the transformed inputs in registers) and
 //     conv7 (L = 256, a tile per wave PAIR, split by output channels), F(2,3) for conv6, conv8,
 //     conv9, conv13, conv15 - 9,588 MFMAs per window instead of the direct form's 16,452;
-//   - A fragments (activations): ds_read_b64 from the [position][channel] LDS image (row pitch
-//     50 floats), B fragments (weights): ds_read_b128 / b64 from fragment-ordered copies that
-//     LDS-DMA brought in a phase ahead; both issued from inline asm one step ahead with
+//   - from conv7 on: A fragments (activations): ds_read_b64 from the [position][channel] LDS image
+//     (row pitch 50 floats), B fragments (weights): ds_read_b128 / b64 from fragment-ordered copies
+//     that LDS-DMA brought in a phase ahead; both issued from inline asm one step ahead with
 //     hand-counted waits.  conv17's weights, used once per window, go to registers by buffer loads;
-//   - outputs are stored in place once every wave has read its inputs (one barrier mid-layer),
-//     the epilogue of an N tile inside the MFMA steps of the next one;
+//   - there, outputs are stored in place once every wave has read its inputs (one barrier
+//     mid-layer), the epilogue of an N tile inside the MFMA steps of the next one;
 //   - activations are held times 2^-60 so that ReLU is the clamp modifier of the instruction that
 //     produces a value (dbh_layout.h: kActScale);
 //   - the average pooling in front of conv10 is applied to conv10's OUTPUT (a 1x1 convolution
@@ -565,59 +570,6 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// One convolution of stages B-D, updating the activation buffer at lds+kActOff in place.
-//   CONV    : 0-based layer index; its weights are already in lds + W_CUR
-//   L       : input length;  POOL/BNI: fused MaxPool2 / batch-norm index (-1 = none)
-//   NEXT_N  : floats of the next block of weights, DMA'd from next_g into next_lds meanwhile
-//   IN_OFF / OUT_OFF : where the input and the output rows start in LDS.  Equal = in place: a
-//             barrier between the MFMA loop and the stores (every wave must have read everything
-//             first).  Different buffers: none - a wave stores as soon as it has multiplied.
-// ---------------------------------------------------------------------------------------------
-template <int CONV, int W_CUR, int L, int S_IN, int S_OUT, bool POOL, int BNI, int NEXT_N,
-          int IN_OFF = kActOff, int OUT_OFF = kActOff, class Side = NoSide>
-__device__ __forceinline__ void inplace_layer(float* lds, const float* __restrict__ packed,
-                                              const float* __restrict__ next_g, float* next_lds,
-                                              int tid, int lane, int wave, unsigned* ts,
-                                              int ts_base, const Side& side = Side()) {
-    constexpr int TAPS = kConv[CONV].taps;
-    constexpr int SP = kConv[CONV].cin / 8;
-    constexpr int NT = kConv[CONV].cout_pad / 16;
-    constexpr int MTILES = L / 16;
-    constexpr int MT = MTILES / kWaves;
-    static_assert(MT >= 1 && MT * kWaves == MTILES, "layer does not tile over the waves");
-    constexpr int LOUT = POOL ? L / 2 : L;
-    constexpr bool BN = BNI >= 0;
-    const int n = lane & 15, q = lane >> 4;
-
-    if constexpr (NEXT_N > 0) dma_weights<NEXT_N>(next_g, next_lds, lane, wave);
-    EpiParams<NT, BN> ep;
-    load_epi<CONV, BNI>(ep, lds, packed, n);
-
-    f4 acc[MT][NT];
-    bias_acc(acc, ep);
-    const int m0 = wave * MT;
-    // 'same' k=3: logical row p+tap-1 = physical row p+tap; k=1: physical row p+1.
-    const float* a_lane = lds + IN_OFF + (m0 * 16 + n + (TAPS == 1 ? 1 : 0)) * S_IN + 2 * q;
-    const float* b_lane = lds + W_CUR + lane * 2;
-    conv_tiles<TAPS, SP, SP, MT, NT, NT, S_IN, 16>(a_lane, b_lane, acc, side);
-    mark(ts, ts_base);
-
-    if constexpr (IN_OFF == OUT_OFF)
-        lds_barrier();     // every wave has finished reading the old activations and weights
-    mark(ts, ts_base + 1);
-
-    float* out_lane = lds + OUT_OFF +
-                      (1 + (POOL ? m0 * 8 + 2 * q : m0 * 16 + 4 * q)) * S_OUT + n;
-    epilogue<MT, NT, S_OUT, POOL, BN, false>(acc, out_lane, ep);
-    zero_row(lds + OUT_OFF, 0, S_OUT, NT * 16, tid);
-    zero_row(lds + OUT_OFF, LOUT + 1, S_OUT, NT * 16, tid);
-    mark(ts, ts_base + 2);
-
-    full_barrier();  
-    mark(ts, ts_base + 3);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Winograd F(2,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1), in place.
 //   For the output pair (2j, 2j+1) and d = x[2j-1 .. 2j+2]:
 //     U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3            (input transform, VALU)
@@ -799,8 +751,9 @@ __device__ __forceinline__ void wino_phase(const float* a_lane, const float* slo
 // next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
 // at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
 // ---------------------------------------------------------------------------------------------
-// F(2,3) with 16 input channels (conv6: 16 -> 48, L = 256, no pooling): 384 MFMAs instead of the
-// direct form's 576.  One tile of 16 pairs per wave as in conv7, but with two channel groups a
+// F(2,3) with 16 input channels out of an LDS image (conv13, conv15 of the inception block; conv6,
+// 16 -> 48 at L = 256, ran this way until round 5 and is now part of stage_b_chain): 2/3 of the
+// direct form's MFMAs.  One tile of 16 pairs per wave as in conv7, but with two channel groups a
 // tile is only two steps of eight MFMAs, so the three N tiles run as ONE six-step pipeline: steps
 // 0-1 build U (eight register pairs) and multiply for tile 0, steps 2-3 tile 1 with tile 0's
 // outputs stored inside them, steps 4-5 tile 2 with tile 1's.  Input and output live in different
@@ -885,55 +838,6 @@ __device__ __forceinline__ void w23c16_step(W23U16& U, unsigned a_addr, unsigned
     if constexpr (G + 1 < NSTEPS)
         w23c16_step<G + 1, NSTEPS>(U, a_addr, b_addr, pipe, acc, bias, side);
 }
-
-template <int CONV, int W_LDS, int IN_OFF, int OUT_OFF>
-__device__ __forceinline__ void w23_cin16_layer(float* lds, const float* __restrict__ packed,
-                                                int tid, int lane, int wave, unsigned* ts,
-                                                int ts_base) {
-    static_assert(kConv[CONV].wino == 2 && wino2_by_tile(CONV) && kConv[CONV].cin == 16 &&
-                  kConv[CONV].cout_pad == 48 && IN_OFF != OUT_OFF, "");
-    constexpr int L = 256;
-    const int n = lane & 15, q = lane >> 4;
-    EpiParams<3, false> ep;
-    load_epi<CONV, -1>(ep, lds, packed, n);
-    // pair j = wave*16 + n needs logical rows 2j-1 .. 2j+2 = physical rows 2j .. 2j+3
-    const unsigned a_addr = lds_addr(lds + IN_OFF + (wave * 32 + 2 * n) * kS16 + 2 * q);
-    const unsigned b_addr = lds_addr(lds + W_LDS + lane * 4);
-    // this lane's place in output position 2 (wave*16 + 4q): pairs 4q + r follow 2 rows apart
-    lds_float* out_q = lds_pinned(lds + OUT_OFF + n + (1 + 2 * (wave * 16 + 4 * q)) * kS48);
-    W23U16 U;
-    W23Pipe16 pipe;
-    f4 acc[3][4];
-    // rows 2h, 2h+1 of N tile t's accumulators: output transform, ReLU, stores
-    auto finish_half = [&](auto tile_tag, int h) {
-        constexpr int t = decltype(tile_tag)::value;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = 2 * h + e;
-            const float even = acc[t][0][r] + acc[t][1][r] + acc[t][2][r];
-            const float odd = acc[t][1][r] - acc[t][2][r] - acc[t][3][r];
-            out_q[(2 * r) * kS48 + t * 16] = fmaxf(even, 0.f);
-            out_q[(2 * r + 1) * kS48 + t * 16] = fmaxf(odd, 0.f);
-        }
-    };
-    w23c16_step<0, 6>(U, a_addr, b_addr, pipe, acc, ep.b, [&](auto tag) {
-        constexpr int G = decltype(tag)::value;
-        if constexpr (G == 2) finish_half(IntC<0>{}, 0);
-        if constexpr (G == 3) finish_half(IntC<0>{}, 1);
-        if constexpr (G == 4) finish_half(IntC<1>{}, 0);
-        if constexpr (G == 5) finish_half(IntC<1>{}, 1);
-    });
-    mark(ts, ts_base);
-    mark(ts, ts_base + 1);
-    finish_half(IntC<2>{}, 0);
-    finish_half(IntC<2>{}, 1);
-    zero_row(lds + OUT_OFF, 0, kS48, 48, tid);
-    zero_row(lds + OUT_OFF, L + 1, kS48, 48, tid);
-    mark(ts, ts_base + 2);
-    full_barrier();
-    mark(ts, ts_base + 3);
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Winograd F(4,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1) at L = 512, in place.

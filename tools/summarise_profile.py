@@ -13,7 +13,20 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, 'gpurun_out')
 KERNEL = 'dbh_forward_kernel'
-WINDOWS_PER_LAUNCH = 10000      # bench.py --config 1: one persistent launch per step
+def windows_per_launch():
+    """Windows one forward launch of the PMC passes carried: from the bench line those passes
+    printed (roofline.windows_per_launch; bench.py queues --steps-per-launch steps as one launch)."""
+    for log in sorted(glob.glob(os.path.join(SRC, 'prof_pmc_*.log'))):
+        for line in open(log, errors='replace'):
+            if line.startswith('{'):
+                try:
+                    return int(round(json.loads(line)['roofline']['windows_per_launch']))
+                except (ValueError, KeyError):
+                    pass
+    return 10000
+
+
+WINDOWS_PER_LAUNCH = windows_per_launch()
 CLOCK_GHZ = 2.4
 
 
@@ -78,7 +91,7 @@ def main():
             'algorithmic_bytes_per_launch': WINDOWS_PER_LAUNCH * (2048 + 52 + 4),
             'source': os.path.relpath(dst, REPO) + '/pmc_summary.json',
             'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes '
-                    '(tools/profile_gpu.sh), averaged over the persistent 10,000-window launches of '
+                    '(tools/profile_gpu.sh), averaged over the persistent launches (windows_per_launch each) of '
                     'bench.py --config 1; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 '
                     'counts 128-B requests as 64 B); algorithmic bytes per window = 2048 B int16 '
                     'in + 52 B probs + 4 B call in fused seam-b2 mode',
