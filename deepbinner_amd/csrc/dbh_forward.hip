@@ -57,7 +57,7 @@
 #endif
 // timing-only ablations of stage_b_chain (results wrong on purpose; tools/ab_variants.sh):
 // 1 = no polls, 2 = no edge rows / posts, 4 = no LDS-DMA requests, 8 = no output / input
-// transforms of conv2 -> conv3 -> conv4, 16 = no epilogue of conv4, 32 = no arrivals, 64 = no halo polls,
+// transforms of conv2 -> conv3 -> conv4, 16 = no epilogue of conv4, 32 = no arrivals, 64 = no halo polls, 256 = no DPP row shifts (adds instead),
 // 128 = no tile-word polls
 #ifndef DBH_ABL
 #define DBH_ABL 0
@@ -1371,8 +1371,10 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
         asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
         __builtin_amdgcn_sched_barrier(0);
         const f2(&yy)[4] = Y[SP >> 1][SP & 1];
-        const f2 d0 = f2{row_from_left(hb[0].x, yy[3].x), row_from_left(hb[0].y, yy[3].y)};
-        const f2 d5 = f2{row_from_right(hb[1].x, yy[0].x), row_from_right(hb[1].y, yy[0].y)};
+        const f2 d0 = (DBH_ABL & 256) ? hb[0] + yy[3]
+                                      : f2{row_from_left(hb[0].x, yy[3].x), row_from_left(hb[0].y, yy[3].y)};
+        const f2 d5 = (DBH_ABL & 256) ? hb[1] + yy[0]
+                                      : f2{row_from_right(hb[1].x, yy[0].x), row_from_right(hb[1].y, yy[0].y)};
         const f2 m4 = f2{-4.f, -4.f}, p2 = f2{2.f, 2.f}, m2 = f2{-2.f, -2.f};
         const f2 p4 = f2{4.f, 4.f}, m5 = f2{-5.f, -5.f};
         const f2 a = __builtin_elementwise_fma(m4, yy[1], yy[3]), b2 = __builtin_elementwise_fma(m4, yy[0], yy[2]);
@@ -3055,7 +3057,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         prefetched = has_next;
         if (has_next) {
             in_cnt = next_cnt;
-            fetch_window_at(next_src, next_cnt, next_pad, tid, wave * 16 + n, q, in_v0, in_v1, in_raw);
+            if (!(DBH_ABL & 1024))
+                fetch_window_at(next_src, next_cnt, next_pad, tid, wave * 16 + n, q, in_v0, in_v1, in_raw);
         }
         // (3) E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
         // wave 6 conv12, wave 7 conv14
