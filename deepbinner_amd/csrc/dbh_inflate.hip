@@ -41,18 +41,28 @@ namespace dbh_inflate_detail {
 
 using dbi::Lane;
 
-constexpr int kLanes = 64;                 // streams per workgroup of kernel 1: one wavefront
+// streams per workgroup of kernel 1 = the active lanes of its one wavefront.  A token costs a wave
+// the same time whether 64 or 16 of its lanes decode; fewer lanes per wave buy LDS per lane - room
+// for the first-level decode tables of dbh_inflate_core.h (-DDBI_LANES=16 -DDBI_LIT_BITS=11: an
+// experiment of round 5, 15 % faster on four times the waves; what ships is 64 lanes, no tables).
+#ifndef DBI_LANES
+#define DBI_LANES 64
+#endif
+constexpr int kLanes = DBI_LANES;
+static_assert(kLanes == 16 || kLanes == 32 || kLanes == 64, "");
 // LDS of kernel 1, every array interleaved by lane ([entry][lane]): consecutive lanes hit
-// consecutive addresses whatever entry each of them wants.  76.5 KB: two workgroups per CU.
-constexpr int kRingOff = 0;                                              // u32 [34][64]
-constexpr int kLitPairOff = kRingOff + dbi::kRingStore * kLanes * 4;     // u32 [16][64]
-constexpr int kDistPairOff = kLitPairOff + 16 * kLanes * 4;              // u32 [16][64]
-constexpr int kLitSymOff = kDistPairOff + 16 * kLanes * 4;               // u16 [288][64]
-constexpr int kCntOff = kLitSymOff + dbi::kLitSyms * kLanes * 2;         // u16 [16][64]
-constexpr int kDistSymOff = kCntOff + 16 * kLanes * 2;                   // u8 [32][64]
-constexpr int kLensOff = kDistSymOff + dbi::kDistSyms * kLanes;          // u8 [320][64]
+// consecutive addresses whatever entry each of them wants.
+constexpr int kRingOff = 0;                                              // u32 [34][lanes]
+constexpr int kLitPairOff = kRingOff + dbi::kRingStore * kLanes * 4;     // u32 [16][lanes]
+constexpr int kDistPairOff = kLitPairOff + 16 * kLanes * 4;              // u32 [16][lanes]
+constexpr int kLitSymOff = kDistPairOff + 16 * kLanes * 4;               // u16 [288][lanes]
+constexpr int kCntOff = kLitSymOff + dbi::kLitSyms * kLanes * 2;         // u16 [16][lanes]
+constexpr int kLitTabOff = kCntOff + 16 * kLanes * 2;                    // u16 [2^kLitBits][lanes]
+constexpr int kDistTabOff = kLitTabOff + (dbi::kTables ? (1 << dbi::kLitBits) * kLanes * 2 : 0);
+constexpr int kDistSymOff = kDistTabOff + (dbi::kTables ? (1 << dbi::kDistBits) * kLanes * 2 : 0);  // u8 [32][lanes]
+constexpr int kLensOff = kDistSymOff + dbi::kDistSyms * kLanes;          // u8 [320][lanes]
 constexpr int kLdsBytes1 = kLensOff + dbi::kMaxLens * kLanes;
-static_assert(2 * kLdsBytes1 <= 160 * 1024, "two workgroups of kernel 1 no longer fit a CU");
+static_assert(kLdsBytes1 <= 160 * 1024, "kernel 1's LDS no longer fits a CU");
 
 struct LdsMem {
     uint32_t* ring_;
@@ -60,6 +70,8 @@ struct LdsMem {
     uint32_t* dist_pair_;
     uint16_t* lit_sym_;
     uint16_t* cnt_;
+    uint16_t* lit_tab_;
+    uint16_t* dist_tab_;
     uint8_t* dist_sym_;
     uint8_t* lens_;
     // asynchronous reads for the decode front (dbh_inflate_core.h: issue_*): requested here, waited
@@ -69,9 +81,9 @@ struct LdsMem {
     }
     __device__ __forceinline__ void ring3_issue(int r, uint32_t& a, uint32_t& b, uint32_t& c) const {
         uint64_t ab;
-        asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:512"
+        asm volatile("ds_read2_b32 %0, %2 offset1:%3\n\tds_read_b32 %1, %2 offset:%4"
                      : "=&v"(ab), "=&v"(c)
-                     : "v"(addr_of(ring_ + r * kLanes))
+                     : "v"(addr_of(ring_ + r * kLanes)), "n"(kLanes), "n"(kLanes * 8)
                      : "memory");
         a = (uint32_t)ab;
         b = (uint32_t)(ab >> 32);
@@ -88,6 +100,10 @@ struct LdsMem {
     __device__ __forceinline__ void dist_sym_issue(int i, uint32_t& v) const {
         asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr_of(dist_sym_ + i * kLanes)) : "memory");
     }
+    __device__ __forceinline__ uint32_t lit_tab(int i) const { return lit_tab_[i * kLanes]; }
+    __device__ __forceinline__ void set_lit_tab(int i, uint32_t v) { lit_tab_[i * kLanes] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t dist_tab(int i) const { return dist_tab_[i * kLanes]; }
+    __device__ __forceinline__ void set_dist_tab(int i, uint32_t v) { dist_tab_[i * kLanes] = (uint16_t)v; }
     __device__ __forceinline__ uint32_t ring(int r) const { return ring_[r * kLanes]; }
     __device__ __forceinline__ void set_ring(int r, uint32_t v) { ring_[r * kLanes] = v; }
     __device__ __forceinline__ int len(int i) const { return lens_[i * kLanes]; }
@@ -153,6 +169,8 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
         mem[s].dist_pair_ = reinterpret_cast<uint32_t*>(lds + kDistPairOff) + lane;
         mem[s].lit_sym_ = reinterpret_cast<uint16_t*>(lds + kLitSymOff) + lane;
         mem[s].cnt_ = reinterpret_cast<uint16_t*>(lds + kCntOff) + lane;
+        mem[s].lit_tab_ = reinterpret_cast<uint16_t*>(lds + kLitTabOff) + lane;
+        mem[s].dist_tab_ = reinterpret_cast<uint16_t*>(lds + kDistTabOff) + lane;
         mem[s].dist_sym_ = lds + kDistSymOff + lane;
         mem[s].lens_ = lds + kLensOff + lane;
         L[s].state = dbi::kDone;
@@ -244,7 +262,19 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dbi::Decoded dec[kPerLane];
-                dbi::lane_decode_fronts<kPerLane, LdsMem>(L, mem, dec);
+                if constexpr (kPerLane == 1 && dbi::kTables) {
+                    // through the first-level tables; a code longer than their index (no entry)
+                    // sends the whole wave the canonical way for this token
+                    const bool fast = dbi::lane_decode_fast(L[0], mem[0], dec[0]);
+#ifndef DBI_ABL_NO_FALLBACK
+                    if (__any(!fast && L[0].state == dbi::kDecode))
+#else
+                    if (false)
+#endif
+                        dec[0] = dbi::lane_decode_front(L[0], mem[0]);
+                } else {
+                    dbi::lane_decode_fronts<kPerLane, LdsMem>(L, mem, dec);
+                }
 #pragma unroll
                 for (int s = 0; s < kPerLane; ++s) {
                     t[s][k] = 0;

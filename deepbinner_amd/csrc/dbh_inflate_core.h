@@ -51,7 +51,25 @@ constexpr int kDistSyms = 32;
 constexpr int kRingRows = 32;            // dwords of input a lane keeps in LDS (+ 2 mirror rows)
 constexpr int kRingStore = kRingRows + 2;
 constexpr int kFetchDwords = 8;          // dwords per request
-
+// First-level decode tables (round 5): index = the next kLitBits / kDistBits bits of the stream
+// (first bit lowest), entry = the code's length and what it means - one LDS read and a handful of
+// instructions where the canonical method walks a 15-step compare chain and two dependent reads.
+// A code longer than the index has no entry (length 0) and goes the canonical way (lockstep: the
+// whole wave does, whenever one of its lanes meets one).
+// Built, bit-exact and measured in round 5 - and NOT what ships (DBI_LIT_BITS 0 = no tables):
+// with 16 lanes per wave and an 11-bit index (5 % of the rounds still go the canonical way) kernel
+// 1 takes 11.1 ms instead of 13.0 for 4,000 streams, on four times the waves; with 32 lanes and 10
+// bits (39 % of the rounds) 12.8 ms (profiles/r05_inflate/README.md).  The CPU harness compiles
+// them in (oracle/inflate_host_test.cpp) and holds every answer against the canonical method.
+#ifndef DBI_LIT_BITS
+#define DBI_LIT_BITS 0
+#endif
+#ifndef DBI_DIST_BITS
+#define DBI_DIST_BITS 8
+#endif
+constexpr bool kTables = DBI_LIT_BITS > 0;
+constexpr int kLitBits = kTables ? DBI_LIT_BITS : 1, kDistBits = kTables ? DBI_DIST_BITS : 1;
+static_assert(kLitBits >= 1 && kLitBits <= 15 && kDistBits >= 1 && kDistBits <= 15, "");
 // token: literal = the byte; match = bit 31 | (distance - 1) << 9 | length
 constexpr uint32_t kMatchFlag = 0x80000000u;
 DBI_HD uint32_t match_token(uint32_t length, uint32_t distance) {
@@ -112,6 +130,20 @@ DBI_HD uint32_t lit_entry(int s) {
     if (s > 285) return kEntryBad;
     return kEntryLength | ((uint32_t)len_extra(s - 257) << 8) | (uint32_t)(len_base(s - 257) - 3);
 }
+
+// literal/length entry (16 bits): bits 0-3 code length (0 = no entry), 4-6 extra bits of a length
+// symbol (6 = symbols 286 / 287: never valid, 7 = end of block), 7-14 the literal byte or the
+// length's base - 3, bit 15 = not a literal
+DBI_HD uint32_t lit_tab_entry(int s, int len) {
+    uint32_t e;
+    if (s < 256) e = (uint32_t)s << 7;
+    else if (s == 256) e = 0x8000u | (7u << 4);
+    else if (s > 285) e = 0x8000u | (6u << 4);
+    else e = 0x8000u | ((uint32_t)len_extra(s - 257) << 4) | ((uint32_t)(len_base(s - 257) - 3) << 7);
+    return e | (uint32_t)len;
+}
+// distance entry: bits 0-3 code length (0 = no entry), 4-8 the distance symbol
+DBI_HD uint32_t dist_tab_entry(int s, int len) { return ((uint32_t)s << 4) | (uint32_t)len; }
 
 DBI_HD uint32_t low_bits(uint32_t v, uint32_t n) {      // n <= 16
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -198,14 +230,18 @@ struct BitReader {
         wr += (uint32_t)kFetchDwords;
         pending = 0;
     }
-    // The checkpoint of the hot loop, every four tokens (<= 6 dwords consumed in between): what
-    // was requested last time goes into the ring, and a lane whose level is down to 16 dwords
-    // requests eight more.  Level after a checkpoint >= 11, never above 24 + 8: the ring neither
-    // runs dry nor is overwritten where it is still to be read.
+    // The checkpoint of the hot loop, every four tokens (<= 6 dwords consumed in between).  A
+    // request goes out EARLY (as soon as the ring has room for it: level <= 24) and is written to
+    // the ring LATE (when the level is down to 16 dwords): at ~1.6 dwords per checkpoint it has
+    // some five checkpoints to make its way from HBM - with the round-4 policy (requested at one
+    // checkpoint, committed at the next) a decoder faster than ~600 cycles per token waited for
+    // memory at every fifth checkpoint, and the first-level tables bought nothing (round 5).
+    // Level after a checkpoint >= 11 (17 with a request pending, minus 6), never above 24: the
+    // ring neither runs dry nor is overwritten where it is still to be read.
     template <class Mem>
     DBI_HD void checkpoint(Mem& mem) {
-        if (pending) commit(mem);
-        if (level() <= 16u) request();
+        if (pending && level() <= 16u) commit(mem);
+        if (!pending && level() <= 24u) request();
     }
     // The rare paths (headers, stored bytes) ask before every field instead: at least `need`
     // (<= 16) dwords in the ring.
@@ -272,17 +308,61 @@ struct Lane {
 // was decoded, and phase 2 can check its Adler-32.
 enum LaneState : int { kNeedBlock = 0, kDecode = 1, kStored = 2, kDone = 3 };
 
+// the first-level table of a code: every index whose low `len` bits are the code (read first bit
+// lowest) gets the symbol's entry; a code longer than the index blanks the one index it begins with
+template <int BITS, class Set>
+DBI_HD void fill_table(uint32_t c16, int len, uint32_t entry, const Set& set) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t rev = __builtin_bitreverse32(c16) >> 16;      // the code's first bit lowest
+#else
+    uint32_t rev = 0;
+    for (int k = 0; k < 16; ++k) rev |= ((c16 >> (15 - k)) & 1u) << k;
+#endif
+    if (len > BITS) {
+        set((int)(rev & ((1u << BITS) - 1u)), 0u);
+        return;
+    }
+    for (uint32_t k = rev & ((1u << len) - 1u); k < (1u << BITS); k += 1u << len) set((int)k, entry);
+}
 template <class Mem>
 struct LitCode {
     Mem* m;
+    static constexpr int kTableBits = kTables ? kLitBits : 0;
     DBI_HD void set_pair(int l, uint32_t v) const { m->set_lit_pair(l, v); }
+    DBI_HD uint32_t pair(int l) const { return m->lit_pair(l); }
     DBI_HD void set_sym(int at, int s) const { m->set_lit_sym(at, lit_entry(s)); }
+    DBI_HD void clear_table() const {
+        for (int k = 0; k < (1 << kLitBits); ++k) m->set_lit_tab(k, 0u);
+    }
+    DBI_HD void fill(int s, int len, uint32_t c16) const {
+        Mem* mm = m;
+        fill_table<kLitBits>(c16, len, lit_tab_entry(s, len), [mm](int k, uint32_t v) { mm->set_lit_tab(k, v); });
+    }
 };
 template <class Mem>
-struct DistCode {          // (also the code-length code, before the distance code is built)
+struct DistCode {
     Mem* m;
+    static constexpr int kTableBits = kTables ? kDistBits : 0;
     DBI_HD void set_pair(int l, uint32_t v) const { m->set_dist_pair(l, v); }
+    DBI_HD uint32_t pair(int l) const { return m->dist_pair(l); }
     DBI_HD void set_sym(int at, int s) const { m->set_dist_sym(at, (uint32_t)s); }
+    DBI_HD void clear_table() const {
+        for (int k = 0; k < (1 << kDistBits); ++k) m->set_dist_tab(k, 0u);
+    }
+    DBI_HD void fill(int s, int len, uint32_t c16) const {
+        Mem* mm = m;
+        fill_table<kDistBits>(c16, len, dist_tab_entry(s, len), [mm](int k, uint32_t v) { mm->set_dist_tab(k, v); });
+    }
+};
+template <class Mem>
+struct CodeLengthCode {    // the code-length code of a dynamic block: built where the distance
+    Mem* m;                // code's sorted symbols will be, no first-level table
+    static constexpr int kTableBits = 0;
+    DBI_HD void set_pair(int l, uint32_t v) const { m->set_dist_pair(l, v); }
+    DBI_HD uint32_t pair(int) const { return 0u; }
+    DBI_HD void set_sym(int at, int s) const { m->set_dist_sym(at, (uint32_t)s); }
+    DBI_HD void clear_table() const {}
+    DBI_HD void fill(int, int, uint32_t) const {}
 };
 
 // Prepares one code for decoding: `lens[first .. first+n)` are the code lengths.  Leaves the
@@ -319,12 +399,21 @@ DBI_HD int build_code(Mem& mem, Code code, int first, int n, uint32_t (&lim)[15]
     }
     if (over) return kBadCodes;                                            // over-subscribed
     if (max != 0 && left > 0 && (!may_be_incomplete || max != 1)) return kBadCodes;   // incomplete
+    // (a complete code writes every index of its first-level table; one that is not - a single
+    // code of length 1, or none at all - leaves the rest without an entry)
+    if (Code::kTableBits > 0 && (left > 0 || max == 0)) code.clear_table();
     for (int s = 0; s < n; ++s) {
         const int l = mem.len(first + s);
         if (l != 0) {
             const int at = mem.cnt(l);
             code.set_sym(at, s);
             mem.set_cnt(l, at + 1);
+            if (Code::kTableBits > 0) {
+                // its code, left-justified: the first code of its length + its place among them
+                const uint32_t pair = code.pair(l);
+                const uint32_t c16 = (pair & 0xFFFFu) + (((uint32_t)at - (pair >> 16)) << (16 - l));
+                code.fill(s, l, c16);
+            }
         }
     }
     return kOk;
@@ -449,7 +538,7 @@ DBI_HD void lane_block(Lane& L, Mem& mem) {
         for (int i = 0; i < hclen; ++i) mem.set_len(cl_order(i), (int)br.take(mem, 3));
         // the code-length code: sorted symbols and pairs where the distance code's will be
         uint32_t lim_cl[15];
-        int st = build_code(mem, DistCode<Mem>{&mem}, 0, 19, lim_cl, false);
+        int st = build_code(mem, CodeLengthCode<Mem>{&mem}, 0, 19, lim_cl, false);
         if (st != kOk) return lane_fail(L, st);
         int have = 0, prev = 0;
         const int want = hlit + hdist;
@@ -725,9 +814,62 @@ DBI_HD bool lane_decode_commit(Lane& L, const Decoded& r, uint32_t* token) {
     *token = r.token;
     return r.length > 0u;
 }
+// The front through the first-level tables.  Returns false where the token's literal/length code
+// - or, behind a length, its distance code - has no entry (it is longer than the table's index):
+// `r` is then not to be used and lane_decode_front decides.
+template <class Mem>
+DBI_HD bool lane_decode_fast(const Lane& L, const Mem& mem, Decoded& r) {
+    const BitReader& br = L.br;
+    uint32_t lo, hi;
+    br.window64(mem, lo, hi);
+    const uint32_t e = mem.lit_tab((int)(lo & ((1u << kLitBits) - 1u)));
+    const uint32_t l1 = e & 15u;
+    const uint32_t not_lit = bit_mask(e, 15);
+    const uint32_t ebf = (e >> 4) & 7u;                        // 6: a bad symbol, 7: end of block
+    const uint32_t is_len = not_lit & (uint32_t)((int32_t)(ebf - 6u) >> 31);       // ebf < 6
+    const uint32_t eb = ebf & is_len;
+    const uint32_t val = (e >> 7) & 0xFFu;
+    uint64_t w = (((uint64_t)hi << 32) | lo) >> l1;
+    // a literal: 1; end of block (or a bad symbol, refused below): 0
+    const uint32_t length = pick(is_len, 3u + val + low_bits((uint32_t)w, eb), (~not_lit) & 1u);
+    w >>= eb;
+    const uint32_t e2 = mem.dist_tab((int)((uint32_t)w & ((1u << kDistBits) - 1u)));
+    const uint32_t l2 = e2 & 15u;
+    const uint32_t d = e2 >> 4;
+    const uint32_t half = d >> 1;
+    const uint32_t db = (half > 1u ? half : 1u) - 1u;
+    const uint32_t small = (uint32_t)((int32_t)(d - 4u) >> 31);          // d < 4
+    const uint32_t dbase = pick(small, d + 1u, 1u + ((2u | (d & 1u)) << db));
+    const uint32_t distance = dbase + low_bits((uint32_t)(w >> l2), db);
+    const bool bad = (not_lit != 0u && ebf == 6u) || (is_len != 0u && d > 29u);
+    r.used = l1 + eb + ((l2 + db) & is_len);
+    r.bad = bad;
+    r.fail = bad || br.bp + r.used > br.limit_bits;
+    const int room = L.out_cap - L.out_pos;
+    r.beyond = (int)length > room;
+    const uint32_t fits = umin(length, (uint32_t)(room > 0 ? room : 0));
+    r.length = fits;
+    r.is_end = not_lit != 0u && ebf == 7u;
+    r.token = pick(is_len, match_token(fits, distance), val);
+    return l1 != 0u && (is_len == 0u || l2 != 0u);
+}
 template <class Mem>
 DBI_HD bool lane_decode(Lane& L, Mem& mem, uint32_t* token) {
-    const Decoded r = lane_decode_front(L, mem);
+    Decoded r;
+    const bool fast = kTables && lane_decode_fast(L, mem, r);
+#if defined(DBI_CHECK_TABLES)
+    if (L.state == kDecode) dbi_table_answer(fast);
+    // (CPU harness: whenever the tables answer, they must answer what the canonical method does)
+    if (fast && L.state == kDecode) {
+        const Decoded s = lane_decode_front(L, mem);
+        // (a refused token's other fields are never looked at)
+        if (s.bad != r.bad || s.fail != r.fail ||
+            (!s.fail && (s.used != r.used || s.length != r.length || s.token != r.token ||
+                         s.is_end != r.is_end || s.beyond != r.beyond)))
+            dbi_table_mismatch();
+    }
+#endif
+    if (!fast) r = lane_decode_front(L, mem);
     return lane_decode_commit(L, r, token);
 }
 

@@ -11,12 +11,31 @@
 #include <cstring>
 #include <vector>
 
+// the first-level decode tables (an experiment of round 5 the product does not ship: see
+// dbh_inflate_core.h) are compiled in here and every answer of theirs is held against the
+// canonical method's
+#define DBI_CHECK_TABLES 1
+#ifndef DBI_LIT_BITS
+#define DBI_LIT_BITS 10
+#endif
+static void dbi_table_mismatch();
+static long g_answers[2];
+static void dbi_table_answer(bool fast) { ++g_answers[fast ? 1 : 0]; }
 #include "../deepbinner_amd/csrc/dbh_inflate_core.h"
+static void dbi_table_mismatch() {
+    std::fprintf(stderr, "a first-level table entry disagrees with the canonical decoder\n");
+    std::abort();
+}
 
 struct HostMem {
     uint32_t ring_[dbi::kRingStore], lit_pair_[16], dist_pair_[16];
     uint16_t lit_sym_[dbi::kLitSyms], cnt_[16];
     uint8_t dist_sym_[dbi::kDistSyms], lens_[dbi::kMaxLens];
+    uint16_t lit_tab_[1 << dbi::kLitBits], dist_tab_[1 << dbi::kDistBits];
+    uint32_t lit_tab(int i) const { return lit_tab_[check(i, 1 << dbi::kLitBits)]; }
+    void set_lit_tab(int i, uint32_t v) { lit_tab_[check(i, 1 << dbi::kLitBits)] = (uint16_t)v; }
+    uint32_t dist_tab(int i) const { return dist_tab_[check(i, 1 << dbi::kDistBits)]; }
+    void set_dist_tab(int i, uint32_t v) { dist_tab_[check(i, 1 << dbi::kDistBits)] = (uint16_t)v; }
     uint32_t ring(int r) const { return ring_[check(r, dbi::kRingStore)]; }
     void set_ring(int r, uint32_t v) { ring_[check(r, dbi::kRingStore)] = v; }
     int len(int i) const { return lens_[check(i, dbi::kMaxLens)]; }
@@ -47,6 +66,9 @@ int main(int argc, char** argv) {
     if (!in || !out) return 2;
     uint32_t n_cases = 0;
     if (std::fread(&n_cases, 4, 1, in) != 1) return 2;
+    if (std::getenv("DBI_TABLE_STATS")) std::atexit([] {
+        std::fprintf(stderr, "tokens answered by the tables: %ld, sent the canonical way: %ld\n", g_answers[1], g_answers[0]);
+    });
     for (uint32_t c = 0; c < n_cases; ++c) {
         uint32_t comp_bytes = 0, out_cap = 0;
         if (std::fread(&comp_bytes, 4, 1, in) != 1 || std::fread(&out_cap, 4, 1, in) != 1) return 2;
