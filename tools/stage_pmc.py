@@ -6,7 +6,9 @@ whole (dbh_predict_dev), REPS launches each, in that order, on N windows.  Under
 `rocprofv3 --pmc <counters> --kernel-trace` every launch is one row per counter of the CSV.
 `report <pmc_counter_collection.csv> [...]`: groups the forward kernel's dispatches by that order
 (the first launch of a group is dropped), averages, and differences consecutive groups: what each
-stage adds per window.  tools/stage_pmc.sh drives both.
+stage adds per window.  tools/stage_pmc.sh drives both.  (What a truncated launch contains: "A" =
+the window's top + conv2's tile 0 with conv1 inside; "A+B" ends behind conv6 - conv5 and conv6
+run on the end of stage B's chain since round 5 -, so "C" is conv7 alone.)
 Usage: python tools/stage_pmc.py run [n_windows] | report <csv>..."""
 import csv
 import json

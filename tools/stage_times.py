@@ -2,7 +2,9 @@
 """Attribute forward-kernel time to network stages on a real MI355X: run the kernel truncated
 after each stage (dbh_forward_truncated_dev) and difference the HIP-event times.
 (Since round 4 conv1 runs inside conv2's first tile: a kernel truncated "after stage A" ends behind
-that tile, so A carries a third of conv2's MFMAs and B lacks them.)
+that tile, so A carries a third of conv2's MFMAs and B lacks them.  Since round 5 conv5 and conv6
+run on the end of stage B's chain in registers: a kernel truncated "after stage B" ends behind
+conv6, so B carries their MFMAs and C is conv7 alone.)
 Usage: python tools/stage_times.py [n_windows] [repeats]"""
 import json
 import os
