@@ -66,6 +66,22 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
     packed.assign(kPackedFloats, 0.f);
     CanonConv cc[kNumConvs];
     canon_convs(n_classes, cc);
+    // BN2 (scale s, shift t per channel of conv1d_4's pooled output) is folded into conv1d_5, a 1x1
+    // convolution with no padding to get in the way: W5'[c][o] = W5[c][o] s[c], b5'[o] = b5[o] +
+    // sum_c W5[c][o] t[c] - exact algebra, in fp64 here; the forward kernel feeds conv1d_5 the
+    // pooled values as they are (dbh_forward.hip: stage_b_chain)
+    const float* bn_first = w;
+    for (int i = 0; i < kNumConvs; ++i) bn_first += (size_t)cc[i].k * cc[i].cin * cc[i].cout + cc[i].cout;
+    std::vector<double> fold_scale(48, 1.0), fold_shift(48, 0.0);
+    {
+        const float* q = bn_first + 4 * kBnChannels[0];      // BN2 = the second batch normalisation
+        const float *gamma = q, *beta = q + 48, *mean = q + 96, *var = q + 144;
+        for (int c = 0; c < 48; ++c) {
+            fold_scale[c] = (double)gamma[c] / std::sqrt((double)var[c] + 1e-3);
+            fold_shift[c] = (double)beta[c] - (double)mean[c] * fold_scale[c];
+        }
+    }
+    static_assert(kBnChannels[1] == 48 && kConv[4].cin == 48 && kConv[4].taps == 1, "");
     const float* p = w;
     for (int i = 0; i < kNumConvs; ++i) {
         const int k = cc[i].k, cin = cc[i].cin, cout = cc[i].cout;
@@ -124,12 +140,19 @@ void pack_weights(const float* w, int n_classes, std::vector<float>& packed) {
                             for (int e = 0; e < 2; ++e) {
                                 const int ci = frag_cin(i, sp, lane >> 4, e);
                                 const int co = 16 * t + (lane & 15);
-                                const float v = co < cout ? kernel[((size_t)tap * cin + ci) * cout + co] : 0.f;
+                                float v = co < cout ? kernel[((size_t)tap * cin + ci) * cout + co] : 0.f;
+                                if (i == 4 && DBH_FOLD_BN2) v = (float)((double)v * fold_scale[ci]);   // BN2's scale
                                 dst[((((size_t)tap * sp_n + sp) * nt + t) * 64 + lane) * 2 + e] = v;
                             }
         }
         float* bdst = packed.data() + bias_offset(i);
         for (int c = 0; c < cout; ++c) bdst[c] = bias[c] * kActScale;      // (exact: a power of two)
+        if (i == 4 && DBH_FOLD_BN2)       // ... and BN2's shift, through conv1d_5's weights, in its bias
+            for (int c = 0; c < cout; ++c) {
+                double extra = 0.0;
+                for (int ci = 0; ci < cin; ++ci) extra += (double)kernel[(size_t)ci * cout + c] * fold_shift[ci];
+                bdst[c] = (float)(((double)bias[c] + extra) * (double)kActScale);
+            }
     }
     for (int i = 0; i < kNumBn; ++i) {
         const int c_n = kBnChannels[i];

@@ -1476,27 +1476,35 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
                      : "memory");
         if constexpr (h == 1) halo_post(post_addr);
     };
-    // half h of the epilogue of tile g of conv4: outputs, MaxPool2, BN2 -> X[g][h][p]: channels
-    // 16g + 4q + 2h, + 1 of pooled positions 2j + p - conv5's B operand as it stands
+    // half h of the epilogue of tile g of conv4: outputs, MaxPool2 -> X[g][h][p]: channels 16g +
+    // 4q + 2h, + 1 of pooled positions 2j + p - conv5's B operand as it stands
     f2 X[3][2][2];
     auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
         constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
         if (DBH_ABL & 16) return;
         f2 y[4];
         w43t_outputs<h>(a, y);
-        const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
-        const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(1) - kTabBn0)) / 4 + 4 * g];
-        const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
-        const f2 p0 = f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)};
-        const f2 p1 = f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)};
-        X[g][h][0] = __builtin_elementwise_fma(p0, sc, sh);
-        X[g][h][1] = __builtin_elementwise_fma(p1, sc, sh);
+        // (BN2 is folded into conv5's weights and bias by the packer - dbh_api.hip: pack_weights -
+        // so the pooled values go to conv5 as they are; only the debug dump applies it)
+        X[g][h][0] = f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)};
+        X[g][h][1] = f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)};
+        if (!DBH_FOLD_BN2) {
+            const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
+            const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(1) - kTabBn0)) / 4 + 4 * g];
+            const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
+            X[g][h][0] = __builtin_elementwise_fma(X[g][h][0], sc, sh);
+            X[g][h][1] = __builtin_elementwise_fma(X[g][h][1], sc, sh);
+        }
         if (in_a.dump_b) {          // debug_stage 1 (wave-uniform)
+            const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
+            const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(1) - kTabBn0)) / 4 + 4 * g];
+            const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
             float* dst = dump_b_base() + 2 * (wave * 16 + n) * 48 + 4 * q;
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
-                dst[pp * 48 + 16 * g + 2 * h] = X[g][h][pp].x * kActUnscale;
-                dst[pp * 48 + 16 * g + 2 * h + 1] = X[g][h][pp].y * kActUnscale;
+                const f2 v = DBH_FOLD_BN2 ? __builtin_elementwise_fma(X[g][h][pp], sc, sh) : X[g][h][pp];
+                dst[pp * 48 + 16 * g + 2 * h] = v.x * kActUnscale;
+                dst[pp * 48 + 16 * g + 2 * h + 1] = v.y * kActUnscale;
             }
         }
     };
@@ -1526,8 +1534,20 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     const IntC<2> c2;
     constexpr int NW = DBH_DMA_WAVES;
     constexpr int kThirdSteps = (kWinoHalf / 256 + NW - 1) / NW;       // 3 (5 with four waves)
-    auto third = [&](int conv, int t, float* dst, int i) {
-        dma_weights_one<kWinoHalf, NW>(packed + weight_offset(conv) + t * kWinoHalf, dst, lane, wave, i);
+#ifndef DBH_THIRD_PACK
+#define DBH_THIRD_PACK 1
+#endif
+    // request(s) of step `step` of a third: with four requesting waves a wave has five pieces; one
+    // per step would put the last behind step 4, a step in front of the arrival that waits for it
+    // to land - two per step are through by step 2
+    auto third = [&](int conv, int t, float* dst, int step) {
+        const float* src = packed + weight_offset(conv) + t * kWinoHalf;
+        if (DBH_THIRD_PACK && NW < 8) {
+            if (2 * step < kThirdSteps) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step);
+            if (2 * step + 1 < kThirdSteps) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step + 1);
+        } else {
+            dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, step);
+        }
     };
     // conv3's 54 pieces: request i of this wave (7 per wave with eight requesters, 14 with four)
     auto conv3_piece = [&](int i) {
@@ -1684,9 +1704,9 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
             // conv6's weights (9 pieces), to the upper buffer
             if constexpr (SP == 0)
                 dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 0);
-            if constexpr (SP == 2)
+            if constexpr (SP == (DBH_THIRD_PACK ? 1 : 2))
                 dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 1);
-            if constexpr (SP == 4 && NW < 8)
+            if constexpr (SP == (DBH_THIRD_PACK ? 2 : 4) && NW < 8)
                 dma_weights_one<conv_weight_floats(5), NW>(packed + weight_offset(5), lds + kW6, lane, wave, 2);
             if constexpr (SP == 1) store(c0, c0, acc[0]);
             if constexpr (SP == 3) store(c0, c1, acc[0]);

@@ -6,6 +6,11 @@
 // Shared by the host-side packer (dbh_api.hip) and the device code (dbh_forward.hip).
 #pragma once
 
+// A/B switch (tools/ab_variants.sh): BN2 folded into conv1d_5's weights and bias by the packer
+#ifndef DBH_FOLD_BN2
+#define DBH_FOLD_BN2 1
+#endif
+
 namespace dbh {
 
 constexpr int kWindow = 1024;          // model input size (classify.py:96)
