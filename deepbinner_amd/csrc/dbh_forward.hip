@@ -518,15 +518,22 @@ __device__ __forceinline__ void dma_piece(const float* g_piece, const float* lds
                  : "memory");
 }
 
+// (DBH_DMA_ALL_WAVES: how many waves share a block copy - A/B knob; stage B's own requests have
+// theirs, DBH_DMA_WAVES)
+#ifndef DBH_DMA_ALL_WAVES
+#define DBH_DMA_ALL_WAVES 4
+#endif
 template <int NFLOATS>
 __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* lds_dst, int lane,
                                             int wave) {
     static_assert(NFLOATS % 256 == 0, "weight blocks are whole 1 KiB pieces");
     constexpr int kPieces = NFLOATS / 256;
+    constexpr int NW = DBH_DMA_ALL_WAVES;
     const unsigned lane_bytes = (unsigned)lane * 16u;
+    if (wave >= NW) return;
 #pragma unroll
-    for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
-        const int piece = wave + kWaves * i;   // wave-uniform
+    for (int i = 0; i < (kPieces + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i;   // wave-uniform
         if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, lane_bytes);
     }
 }
@@ -547,11 +554,13 @@ template <int NFLOATS, int IT, int NIT>
 __device__ __forceinline__ void dma_weights_slice(const float* __restrict__ g, float* lds_dst,
                                                   int lane, int wave) {
     constexpr int kPieces = NFLOATS / 256;
-    constexpr int kPerWave = (kPieces + kWaves - 1) / kWaves;
+    constexpr int NW = DBH_DMA_ALL_WAVES;
+    constexpr int kPerWave = (kPieces + NW - 1) / NW;
     const unsigned lane_bytes = (unsigned)lane * 16u;
+    if (wave >= NW) return;
 #pragma unroll
     for (int i = IT * kPerWave / NIT; i < (IT + 1) * kPerWave / NIT; ++i) {
-        const int piece = wave + kWaves * i;
+        const int piece = wave + NW * i;
         if (piece < kPieces) dma_piece(g + piece * 256, lds_dst + piece * 256, lane_bytes);
     }
 }
@@ -1917,7 +1926,13 @@ struct W43nsPipe {
     f4 b[2][3];      // [step parity][matrix pair]
 };
 
-// Step G of a wave's nine: G < 6 = channel group G of its own N tile (TOWN) and of U; G >= 6 =
+// How the six channel groups of conv7's shared N tile are split between the two waves of a SIMD:
+// the older one (w < 4) takes the first DBH_CONV7_LOW, the younger one the rest.  (3 / 3 until
+// round 5; the older wave wins every tie for the matrix pipe and reached the exchange first.)
+#ifndef DBH_CONV7_LOW
+#define DBH_CONV7_LOW 3
+#endif
+// Step G of a wave's 6 + n: G < 6 = channel group G of its own N tile (TOWN) and of U; G >= 6 =
 // channel group SP0 + G - 6 of the shared N tile 1.  One software pipeline.
 template <int TOWN, int SP0, bool WITH_BIAS, int G, class Side>
 __device__ __forceinline__ void w43ns_step(W43U& U, unsigned a_addr, unsigned b_addr,
@@ -1931,8 +1946,9 @@ __device__ __forceinline__ void w43ns_step(W43U& U, unsigned a_addr, unsigned b_
         pipe.b[N & 1][1] = ds_read_f4<(T * kWinoHalf + (SP * 3 + 1) * 256) * 4>(b_addr);
         pipe.b[N & 1][2] = ds_read_f4<(T * kWinoHalf + (SP * 3 + 2) * 256) * 4>(b_addr);
     };
+    constexpr int GEND = 6 + (SP0 == 0 ? DBH_CONV7_LOW : 6 - DBH_CONV7_LOW);
     if constexpr (G == 0) loads(IntC<0>{});
-    if constexpr (G + 1 < 9) {
+    if constexpr (G + 1 < GEND) {
         loads(IntC<G + 1>{});
         if constexpr (G + 1 < 6) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
@@ -1943,7 +1959,7 @@ __device__ __forceinline__ void w43ns_step(W43U& U, unsigned a_addr, unsigned b_
 #pragma unroll
     for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[p]));
     if constexpr (G < 6) progress_priority<G, 6>();
-    else progress_priority<G - 6, 3>();
+    else progress_priority<G - 6, GEND - 6>();
     constexpr int SP = G < 6 ? G : SP0 + G - 6;      // which channel group of U this step uses
     if constexpr (G < 6) {
         f2(&d)[6] = pipe.rows[G & 1];
@@ -1983,7 +1999,7 @@ __device__ __forceinline__ void w43ns_step(W43U& U, unsigned a_addr, unsigned b_
     __builtin_amdgcn_sched_barrier(0);
     side(IntC<G>{});
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G != 5 && G + 1 < 9)
+    if constexpr (G != 5 && G + 1 < GEND)
         w43ns_step<TOWN, SP0, WITH_BIAS, G + 1>(U, a_addr, b_addr, pipe, own, shared, bias_own,
                                                 bias_shared, side);
 }
@@ -2007,7 +2023,7 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
                                                 int tid, int lane, int wave, unsigned* ts,
                                                 int ts_base, unsigned& pair_rounds,
                                                 const Begin& begin) {
-    constexpr int TOWN = HIGH ? 2 : 0, SP0 = HIGH ? 3 : 0;
+    constexpr int TOWN = HIGH ? 2 : 0, SP0 = HIGH ? DBH_CONV7_LOW : 0;
     const int n = lane & 15, q = lane >> 4;
     const int m = wave & 3;
     EpiParams<3, true> ep;
