@@ -786,6 +786,9 @@ def main():
             'traffic': (pmc['hbm_bytes_per_launch'] * windows_per_launch / pmc['windows_per_launch']
                         if 'hbm_bytes_per_launch' in pmc and windows_per_launch else None),
             'traffic_algorithmic': bytes_per_window * windows_per_launch,
+            # (a launch carries steps_per_launch steps: avg_launch_ms / steps_per_launch is the
+            # kernel time of ONE step, to hold against ms_per_step)
+            'steps_per_launch': spl, 'avg_launch_ms_per_step': avg_ms / spl,
             'avg_launch_ms': avg_ms, 'launches_timed': launches,
             'avg_launch_ms_per_rank': launch_ms_per_rank,
             'timed_every_nth_launch': TIMING_STRIDE, 'launches_per_event_bracket': TIMING_SPAN,
