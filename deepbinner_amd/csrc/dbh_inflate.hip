@@ -9,15 +9,21 @@
 // time and a GPU runs thousands at a time.
 //
 // Two kernels (RFC 1950 / 1951; bit-exact with zlib, same accept / reject decisions; the decoder
-// core is dbh_inflate_core.h, which the CPU test harness compiles too):
-//   1. inflate_tokens_kernel  - ONE LANE PER STREAM, 64 streams per workgroup (one wavefront), two
-//      workgroups per CU.  Each lane walks its stream's Huffman codes - decoded canonically from
-//      per-lane registers and 1.2 KB of LDS, see the core - and writes a token per symbol
-//      (literal | match {length, distance}) - no output bytes, no window: nothing a lane does
-//      depends on memory it wrote itself.  All lanes of a wave step together; streams deflated with
-//      the same settings reach their block boundaries (every 16,383 symbols with zlib's defaults)
-//      on the same step, so the code builds line up; a lane that is done takes its next stream off
-//      a counter there.
+// core is dbh_inflate_core.h + dbh_inflate_wave.h, which the CPU test harness compiles too):
+//   1. Huffman codes -> tokens (literal | match {length, distance}): no output bytes, no window -
+//      nothing here depends on memory the kernel wrote itself.  Two forms, same tokens:
+//      inflate_tokens_wave_kernel (what runs) - ONE WAVEFRONT PER STREAM: the 64 lanes decode 64
+//      consecutive pieces of the same Huffman block at once, each from a guessed first bit, and
+//      re-decode until every piece begins where the one before it ended (prefix codes
+//      re-synchronise: ~2.7 rounds; dbh_inflate_wave.h); 4,000 streams are 4,000 waves, a dozen
+//      per CU, and a launch lasts 2.4 ms instead of 12.9 (84 -> 14 ms both kernels when the
+//      reads' lengths are log-normal: a long read is no longer one lane's work);
+//      inflate_tokens_kernel (DEEPBINNER_INFLATE_KERNEL=lane) - ONE LANE PER STREAM, 64 streams
+//      per wavefront: rounds 3 and 4's kernel, the same work in 30 % less CU time but 63 waves
+//      for as long as the longest stream lasts.  All lanes of a wave step together; streams
+//      deflated with the same settings reach their block boundaries (every 16,383 symbols with
+//      zlib's defaults) on the same step, so the code builds line up; a lane that is done takes
+//      its next stream off a counter there.
 //   2. inflate_resolve_kernel - ONE WAVE PER STREAM with the 32 KiB window as a ring in LDS, five
 //      per CU.  64 tokens per step: a wave-wide prefix sum of the token lengths gives every token
 //      its output position; literals are stored at once; matches copy from the ring as soon as
@@ -31,11 +37,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/deepbinner_hip.h"
 #include "dbh_inflate_core.h"
+#include "dbh_inflate_wave.h"
 
 namespace dbh_inflate_detail {
 
@@ -146,6 +154,9 @@ struct StreamInfo {
 // the general form (the slots of a lane are a compile-time array) with one slot.
 #ifndef DBI_PER_LANE
 #define DBI_PER_LANE 1
+#endif
+#ifndef DBI_DEFAULT_WAVE
+#define DBI_DEFAULT_WAVE 1
 #endif
 constexpr int kPerLane = DBI_PER_LANE;
 static_assert(kPerLane * kLdsBytes1 <= 160 * 1024 && (kPerLane == 1 || kPerLane == 2),
@@ -297,6 +308,179 @@ __global__ __launch_bounds__(kLanes) void inflate_tokens_kernel(
                 L[s].br.checkpoint(mem[s]);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1, second form: ONE WAVE PER STREAM (dbh_inflate_wave.h - the rounds, why they end, what
+// they cost).  One wavefront per workgroup, one stream per workgroup, in the caller's order (the
+// longest first, if the caller has sorted them).  LDS: the staged chunk (4.4 KB) and ONE set of
+// canonical code tables (1.3 KB) - a dozen and more waves per CU, which is what hides the LDS
+// round trips of a token's dependent chain here.
+// ---------------------------------------------------------------------------------------------
+struct WaveLds {
+    uint32_t stage[dbi::kStageDwords];
+    uint32_t ring[dbi::kRingStore], lit_pair[16], dist_pair[16];
+    uint16_t lit_sym[dbi::kLitSyms], cnt[16];
+    uint8_t dist_sym[dbi::kDistSyms], lens[dbi::kMaxLens];
+};
+struct WaveMem {
+    WaveLds* m;
+    __device__ __forceinline__ uint32_t stage(int i) const { return m->stage[i]; }
+    __device__ __forceinline__ uint32_t lit_tab(int) const { return 0u; }      // (no decode tables)
+    __device__ __forceinline__ void set_lit_tab(int, uint32_t) {}
+    __device__ __forceinline__ uint32_t dist_tab(int) const { return 0u; }
+    __device__ __forceinline__ void set_dist_tab(int, uint32_t) {}
+    __device__ __forceinline__ uint32_t ring(int r) const { return m->ring[r]; }
+    __device__ __forceinline__ void set_ring(int r, uint32_t v) { m->ring[r] = v; }
+    __device__ __forceinline__ int len(int i) const { return m->lens[i]; }
+    __device__ __forceinline__ void set_len(int i, int v) { m->lens[i] = (uint8_t)v; }
+    __device__ __forceinline__ int cnt(int l) const { return m->cnt[l]; }
+    __device__ __forceinline__ void set_cnt(int l, int v) { m->cnt[l] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t lit_pair(int l) const { return m->lit_pair[l]; }
+    __device__ __forceinline__ void set_lit_pair(int l, uint32_t v) { m->lit_pair[l] = v; }
+    __device__ __forceinline__ uint32_t dist_pair(int l) const { return m->dist_pair[l]; }
+    __device__ __forceinline__ void set_dist_pair(int l, uint32_t v) { m->dist_pair[l] = v; }
+    __device__ __forceinline__ uint32_t lit_sym(int i) const { return m->lit_sym[i]; }
+    __device__ __forceinline__ void set_lit_sym(int i, uint32_t v) { m->lit_sym[i] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t dist_sym(int i) const { return m->dist_sym[i]; }
+    __device__ __forceinline__ void set_dist_sym(int i, uint32_t v) { m->dist_sym[i] = (uint8_t)v; }
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ int wave_scan_i32(int v);
+// a value of the lane before (lane 0: its own)
+__device__ __forceinline__ uint32_t from_lane_before(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1); }
+
+__global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
+    const uint8_t* __restrict__ comp, int64_t comp_total,
+    const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
+    StreamInfo* __restrict__ info) {
+    using namespace dbi;
+    __shared__ __attribute__((aligned(16))) WaveLds lds;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= n_streams) return;
+    const dbh_inflate_stream st = streams[i];
+    if (st.mode != DBH_INFLATE_ZLIB) {                   // nothing to decode: kernel 2 copies it
+        if (lane == 0) info[i] = StreamInfo{kOk, 0, 0u, 0, 0};
+        return;
+    }
+    WaveMem mem{&lds};
+    // Lane 0's copy of L is the stream's state; the serial code (header, block headers with their
+    // code builds, stored bytes) runs on lane 0 alone, and what the whole wave needs of it is
+    // handed round afterwards.
+    Lane L;
+    uint32_t* const tok = tokens + st.out_offset;        // one token slot per byte of output
+    int n_tok = 0;
+    // (the caller's buffer is readable for 64 bytes beyond comp_total)
+    lane_start(L, mem, comp + st.comp_offset, st.comp_bytes, st.out_bytes,
+               comp_total + 64 - st.comp_offset);        // (every lane the same: uniform so far)
+    WaveBlock B;
+    while (uni(L.state) != kDone) {
+        const int state = uni(L.state);
+        if (state == kNeedBlock) {
+            if (lane == 0) lane_block(L, mem);
+#pragma unroll
+            for (int l = 0; l < 15; ++l) {
+                B.lim_lit[l] = uni(L.lim_lit[l]);
+                B.lim_dist[l] = uni(L.lim_dist[l]);
+            }
+            __syncthreads();                             // (the tables lane 0 wrote: for all lanes)
+            continue;
+        }
+        if (state == kStored) {
+            // the bytes of a stored block: literal tokens, 64 at a time
+            L.stored_left = uni(L.stored_left);
+            L.out_pos = uni(L.out_pos);
+            L.br.bp = uni(L.br.bp);
+            L.final_block = uni(L.final_block);
+            const int n = stored_run(L);
+            const uint8_t* src = comp + st.comp_offset + (L.br.bp >> 3);
+            for (int k = lane; k < n; k += kWaveLanes) tok[n_tok + k] = src[k];
+            n_tok += n;
+            if (stored_advance(L, n) && lane == 0) L.br.seek(mem, L.br.bp);
+            continue;
+        }
+        // ---- inside a Huffman block: one chunk of 64 homes ----
+        const uint32_t bp = uni(L.br.bp);
+        int out_pos = uni(L.out_pos);
+        const int out_cap = uni(L.out_cap);
+        const uint32_t first_dword = bp >> 5, rel0 = bp & 31u;
+        const uint32_t fetch_cap = uni(L.br.fetch_cap);
+        const uint8_t* in = comp + st.comp_offset;
+        __syncthreads();                                 // (nobody still reads the chunk before)
+        for (int piece = lane; piece < kStageDwords / 4; piece += kWaveLanes) {
+            U4 v;
+            __builtin_memcpy(&v, in + stage_piece_at(first_dword, piece, fetch_cap), 16);
+            *reinterpret_cast<U4*>(&lds.stage[4 * piece]) = v;
+        }
+        __syncthreads();
+        B.limit_rel = uni(L.br.limit_bits) - first_dword * 32u;
+        uint32_t x = sub_start(rel0, lane);
+        const uint32_t stop = sub_start(rel0, lane + 1);
+        SubResult r = sub_decode(B, mem, x, stop);
+        int last;
+        for (;;) {
+            const uint32_t prev_end = from_lane_before(r.end);
+            const int prev_flag = (int)from_lane_before((uint32_t)r.flag);
+            const uint32_t want = lane == 0 ? rel0 : prev_flag != kSubNone ? sub_start(rel0, lane) : prev_end;
+            const bool moved = want != x;
+            const unsigned long long m_moved = __ballot(moved), m_flag = __ballot(r.flag != kSubNone);
+            const int first_moved = m_moved ? __ffsll((long long)m_moved) - 1 : kWaveLanes;
+            const int first_flag = m_flag ? __ffsll((long long)m_flag) - 1 : kWaveLanes;
+            if (first_moved > first_flag || first_moved == kWaveLanes) {
+                last = uni(first_flag < kWaveLanes ? first_flag : kWaveLanes - 1);
+                break;
+            }
+            if (moved) {
+                x = want;
+                r = sub_decode(B, mem, x, stop);
+            }
+        }
+        // where every lane's tokens and bytes go; the lane in which the wanted number of bytes is
+        // exceeded ends the chunk, if that comes first
+        const int cnt_m = lane <= last ? r.count : 0, bytes_m = lane <= last ? r.bytes : 0;
+        const int incl_c = wave_scan_i32(cnt_m), incl_b = wave_scan_i32(bytes_m);
+        const unsigned long long m_over = __ballot(lane <= last && out_pos + incl_b > out_cap);
+        if (m_over) {
+            const int over = __ffsll((long long)m_over) - 1;
+            last = uni(over < last ? over : last);
+        }
+        SubResult e;
+        e.end = 0;
+        e.count = e.bytes = 0;
+        e.flag = kSubNone;
+        if (lane <= last)
+            e = sub_emit(B, mem, x, stop, out_pos + incl_b - bytes_m, out_cap, tok + n_tok + incl_c - cnt_m);
+        const int flag = __builtin_amdgcn_readlane(e.flag, last);
+        n_tok += __builtin_amdgcn_readlane(incl_c - cnt_m, last) + __builtin_amdgcn_readlane(e.count, last);
+        out_pos += __builtin_amdgcn_readlane(incl_b - bytes_m, last) + __builtin_amdgcn_readlane(e.bytes, last);
+        L.out_pos = out_pos;
+        L.br.bp = first_dword * 32u + (uint32_t)__builtin_amdgcn_readlane((int)e.end, last);
+        if (flag == kSubBad) lane_fail(L, kBadSymbol);
+        else if (flag == kSubTrunc) lane_fail(L, kTruncated);
+        else if (flag == kSubBeyond) L.state = kDone;
+        else if (flag == kSubEnd) {
+            L.state = kNeedBlock;
+            if (uni(L.final_block)) {
+                lane_ended(L);                   // (every lane the same)
+            } else if (lane == 0) {
+                L.br.seek(mem, L.br.bp);
+            }
+        }
+    }
+    if (lane == 0) {
+        StreamInfo rec;
+        rec.status = L.status;
+        rec.ended = L.ended;
+        rec.adler = L.adler;
+        rec.n_tokens = n_tok;
+        rec.produced = L.out_pos;
+        info[i] = rec;
     }
 }
 
@@ -497,6 +681,15 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
 
 thread_local char g_error[256];
 
+// which form of kernel 1 runs: DEEPBINNER_INFLATE_KERNEL=wave (one wavefront per stream) | lane (one
+// lane per stream); read at every call, so that a test can hold the two against each other
+bool wave_per_stream() {
+    const char* v = std::getenv("DEEPBINNER_INFLATE_KERNEL");
+    if (v && std::strcmp(v, "lane") == 0) return false;
+    if (v && std::strcmp(v, "wave") == 0) return true;
+    return DBI_DEFAULT_WAVE != 0;
+}
+
 int hip_failed(hipError_t e, const char* what) {
     std::snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(e));
     return DBH_ERR_HIP;
@@ -544,11 +737,16 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
     // the lanes take streams off a counter: with one stream per lane (the default) a launch is
     // as wide as it can be and lasts as long as its longest stream; with several, a fraction of
     // the CUs does the same work in the time the longest stream needs anyway
-    const int per_lane = (streams_per_lane > 0 ? streams_per_lane : 1) * kPerLane;
-    const int64_t lanes = (n_streams + per_lane - 1) / per_lane;
-    hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((lanes + kLanes - 1) / kLanes)),
-                       dim3(kLanes), 0, (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n,
-                       tokens, info, counter);
+    if (wave_per_stream()) {
+        hipLaunchKernelGGL(inflate_tokens_wave_kernel, dim3((unsigned)n), dim3(dbi::kWaveLanes), 0,
+                           (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n, tokens, info);
+    } else {
+        const int per_lane = (streams_per_lane > 0 ? streams_per_lane : 1) * kPerLane;
+        const int64_t lanes = (n_streams + per_lane - 1) / per_lane;
+        hipLaunchKernelGGL(inflate_tokens_kernel, dim3((unsigned)((lanes + kLanes - 1) / kLanes)),
+                           dim3(kLanes), 0, (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n,
+                           tokens, info, counter);
+    }
     DBI_HIP(hipGetLastError());
     const int groups = (n + kWaves2 - 1) / kWaves2;
     const int blocks = groups < 1024 ? groups : 1024;

@@ -2,6 +2,8 @@
 // fast5 Signal chunks are stored with), phase 1: Huffman decoding of ONE stream by ONE lane into a
 // stream of tokens (literal byte | match {length, distance}).  Phase 2 (dbh_inflate.hip) resolves
 // the tokens of a stream into bytes with a whole wavefront and the 32 KiB window in LDS.
+// (Since round 5 what runs by default gives a stream a whole WAVEFRONT in phase 1 too:
+// dbh_inflate_wave.h - the headers, code builds and per-token arithmetic are this header's.)
 //
 // What the reference does here: h5py -> libhdf5 -> zlib's inflate() on the host, one chunk after
 // the other (deepbinner/load_fast5s.py:33-43 reads `Signal[:]`).  Inflating is ~85 % of what loading
@@ -260,6 +262,17 @@ struct BitReader {
         bp = 0;
         wr = 0;
         pending = 0;
+        ensure(mem, 16u);
+    }
+    // Go on at another bit of the stream (the one-wave-per-stream decoder - dbh_inflate_wave.h -
+    // reads the Huffman blocks its own way and comes back here for the next block header): the
+    // ring starts over at the block of eight dwords that bit lies in.
+    template <class Mem>
+    DBI_HD void seek(Mem& mem, uint32_t to_bit) {
+        bp = to_bit;
+        wr = (to_bit >> 5) & ~(uint32_t)(kFetchDwords - 1);
+        request();          // (wr <= bp / 32 < wr + 8: level() is meaningful behind this block)
+        commit(mem);
         ensure(mem, 16u);
     }
     // the next 64 bits

@@ -1,0 +1,239 @@
+// dbh_inflate_wave.h - phase 1 of the GPU inflate with ONE WAVEFRONT PER STREAM (round 5): the
+// 64 lanes of a wave decode 64 consecutive pieces ("homes", kSubBits bits each) of the SAME Huffman
+// block at the same time, although only the first of them knows where its first token begins.
+//
+// Why it works: a prefix code re-synchronises.  A decoder started at an arbitrary bit of a block
+// reads garbage for a few tokens and then - almost always within a few dozen bits - lands on a
+// true token boundary, after which it decodes exactly what a decoder started at the right place
+// decodes.  So (after Weissenberger & Schmidt, "Massively parallel Huffman decoding on GPUs", ICPP
+// 2018 - there for a single code; a deflate token is a literal/length code, extra bits, a distance
+// code, extra bits, and re-synchronises the same way):
+//   round 1   every lane decodes from the first bit of its home until it has left the home, and
+//             notes where it ended (= where the next home's first token begins, if the lane
+//             itself began at a true boundary);
+//   round 2.. every lane whose predecessor ended somewhere else than the lane began decodes
+//             again, from there.  Lane 0 always began at a true boundary, so after round k lanes
+//             0 .. k-1 are right; in practice all are after round 2, because their round-1 garbage
+//             had re-synchronised inside its home and their END did not move.  The loop stops as
+//             soon as every lane up to the first one that met the end of the block (or bad data)
+//             began where its predecessor ended;
+//   output    token counts and byte counts are prefix-summed over the lanes, and every lane
+//             decodes its home a last time, writing its tokens where they belong.
+// Three decodes per token instead of one - on 64 lanes instead of one: the one-lane-per-stream
+// kernel (dbh_inflate_core.h) gives a container's 4,000 streams to 63 wavefronts for as long as the
+// LONGEST stream lasts (a 400 k-sample read: ~90 ms); here a stream is a wave's work for 3/64 of
+// that, and 4,000 waves fill the GPU.
+//
+// The block headers and the two code builds are the serial code of the core, run by lane 0 (a
+// fifth of the kernel's instructions, one lane wide: the next thing to spread over the lanes);
+// the bytes of a stored block become literal tokens 64 at a time; the codes are decoded
+// canonically as in the core - but the range ends are wave-uniform now (scalar registers), and
+// the sorted symbols live in LDS once per wave.
+//
+// Compiled twice like the core: by hipcc into inflate_tokens_wave_kernel (dbh_inflate.hip) and by
+// g++ into the CPU harness (oracle/inflate_host_test.cpp), which runs the rounds lane after lane
+// and must produce exactly the tokens of the one-lane decoder.
+#pragma once
+#include "dbh_inflate_core.h"
+
+namespace dbi {
+
+constexpr int kWaveLanes = 64;
+// a lane's home: 17 dwords - an ODD number, so that the lanes' first reads (and, as long as they
+// advance alike, all their reads) fall into different LDS banks
+#ifndef DBI_SUB_DWORDS
+#define DBI_SUB_DWORDS 17
+#endif
+constexpr int kSubDwords = DBI_SUB_DWORDS;
+constexpr uint32_t kSubBits = 32u * kSubDwords;
+constexpr int kChunkDwords = kWaveLanes * kSubDwords;
+// a chunk begins at any bit of its first dword, and a lane's last token may begin at the last bit
+// of the last home: its 64-bit window reaches into the third dword behind the chunk
+constexpr int kStageDwords = (kChunkDwords + 1 + 2 + 3) & ~3;
+
+// how a lane's walk through its home ended
+enum SubFlag : int { kSubNone = 0, kSubEnd = 1, kSubBad = 2, kSubTrunc = 3, kSubBeyond = 4 };
+
+struct Tok {
+    uint32_t used, length, is_len, distance, lit;
+    bool bad, is_end;
+};
+
+// One token from the 64 bits (lo, hi) it begins with: the arithmetic of lane_decode_fronts
+// (dbh_inflate_core.h), without a lane's state.
+template <class Mem>
+DBI_HD Tok token_decode(uint32_t lo, uint32_t hi, const uint32_t (&lim_lit)[15],
+                        const uint32_t (&lim_dist)[15], const Mem& mem) {
+    const uint32_t c1 = first16(lo);
+    const uint32_t n1 = code_length<15>(c1, lim_lit);
+    const uint32_t l1 = umin(n1, 15u);
+    const uint32_t pair1 = mem.lit_pair((int)l1);
+    const uint32_t i1 = umin(sorted_index(c1, l1, pair1), (uint32_t)(kLitSyms - 1));
+    const uint32_t e = mem.lit_sym((int)i1);
+    uint64_t w = (((uint64_t)hi << 32) | lo) >> l1;
+    const uint32_t is_len = bit_mask(e, 15);                       // kEntryLength
+    const uint32_t eb = (e >> 8) & 7u & is_len;
+    const uint32_t not_end = ((e >> 14) & 1u) ^ 1u;                // kEntryEnd: length 0, a literal: 1
+    const uint32_t length = pick(is_len, 3u + (e & 0xFFu) + low_bits((uint32_t)w, eb), not_end);
+    w >>= eb;
+    const uint32_t c2 = first16((uint32_t)w);
+    const uint32_t n2 = code_length<15>(c2, lim_dist);
+    const uint32_t l2 = umin(n2, 15u);
+    const uint32_t pair2 = mem.dist_pair((int)l2);
+    const uint32_t i2 = umin(sorted_index(c2, l2, pair2), (uint32_t)(kDistSyms - 1));
+    const uint32_t d = mem.dist_sym((int)i2);
+    w >>= l2;
+    const uint32_t half = d >> 1;
+    const uint32_t db = (half > 1u ? half : 1u) - 1u;
+    const uint32_t small = (uint32_t)((int32_t)(d - 4u) >> 31);          // d < 4
+    const uint32_t dbase = pick(small, d + 1u, 1u + ((2u | (d & 1u)) << db));
+    Tok t;
+    t.distance = dbase + low_bits((uint32_t)w, db);
+    t.bad = n1 > 15u || (e & kEntryBad) != 0 || (is_len != 0u && (n2 > 15u || d > 29u));
+    t.used = l1 + eb + ((l2 + db) & is_len);
+    t.length = length;
+    t.is_len = is_len;
+    t.lit = e & 0xFFu;
+    t.is_end = (e & kEntryEnd) != 0;
+    return t;
+}
+
+// the 64 bits at bit x of the staged chunk
+template <class Mem>
+DBI_HD void stage_window(const Mem& mem, uint32_t x, uint32_t& lo, uint32_t& hi) {
+    const int at = (int)(x >> 5);
+    const uint32_t sh = x & 31u;
+    const uint32_t d0 = mem.stage(at), d1 = mem.stage(at + 1), d2 = mem.stage(at + 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+#else
+    lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+    hi = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+#endif
+}
+
+// What the whole wave knows about the block it is in.  Bit positions with the suffix _rel count
+// from the first bit of the staged chunk's first dword.
+struct WaveBlock {
+    uint32_t lim_lit[15], lim_dist[15];
+    uint32_t limit_rel;        // the stream's last bit (deflate data + trailer)
+};
+
+struct SubResult {
+    uint32_t end;              // where the walk stopped (behind the last token it took)
+    int count, bytes;          // tokens that yield bytes (all but the end-of-block code), their bytes
+    int flag;                  // SubFlag: why it stopped before leaving the home, if it did
+};
+
+// A lane's walk through its home in rounds 1, 2, ..: from x until the home [.., stop) is left.
+// Nothing is written, and nothing depends on how many bytes are wanted (that is the output
+// pass's business).
+template <class Mem>
+DBI_HD SubResult sub_decode(const WaveBlock& B, const Mem& mem, uint32_t x, uint32_t stop) {
+    SubResult r;
+    r.count = 0;
+    r.bytes = 0;
+    r.flag = kSubNone;
+    while (x < stop) {
+        uint32_t lo, hi;
+        stage_window(mem, x, lo, hi);
+        const Tok t = token_decode(lo, hi, B.lim_lit, B.lim_dist, mem);
+        if (t.bad) {
+            r.flag = kSubBad;
+            break;
+        }
+        if (x + t.used > B.limit_rel) {
+            r.flag = kSubTrunc;
+            break;
+        }
+        x += t.used;
+        if (t.is_end) {
+            r.flag = kSubEnd;
+            break;
+        }
+        r.count += 1;
+        r.bytes += (int)t.length;
+    }
+    r.end = x;
+    return r;
+}
+
+// The output pass of a lane whose start is known to be right: the walk again, token by token
+// what lane_decode_commit (dbh_inflate_core.h) does - the token that goes BEYOND the wanted bytes
+// is cut and ends the stream's decoding, a refused one fails it, the end-of-block code ends the
+// block.  `tok` is where the lane's first token goes, out_pos the bytes in front of it.
+template <class Mem>
+DBI_HD SubResult sub_emit(const WaveBlock& B, const Mem& mem, uint32_t x, uint32_t stop,
+                          int out_pos, int out_cap, uint32_t* tok) {
+    SubResult r;
+    r.count = 0;
+    r.bytes = 0;
+    r.flag = kSubNone;
+    while (x < stop) {
+        uint32_t lo, hi;
+        stage_window(mem, x, lo, hi);
+        const Tok t = token_decode(lo, hi, B.lim_lit, B.lim_dist, mem);
+        if (t.bad) {
+            r.flag = kSubBad;
+            break;
+        }
+        if (x + t.used > B.limit_rel) {
+            r.flag = kSubTrunc;
+            break;
+        }
+        x += t.used;
+        const int room = out_cap - (out_pos + r.bytes);
+        const uint32_t fits = umin(t.length, (uint32_t)(room > 0 ? room : 0));
+        if (fits > 0u) tok[r.count++] = pick(t.is_len, match_token(fits, t.distance), t.lit);
+        r.bytes += (int)fits;
+        if ((int)t.length > room) {
+            r.flag = kSubBeyond;
+            break;
+        }
+        if (t.is_end) {
+            r.flag = kSubEnd;
+            break;
+        }
+    }
+    r.end = x;
+    return r;
+}
+
+// A stored block (rare: bytes deflate could not shrink) is the 64 lanes' work too: the number of
+// its bytes that become literal tokens now - all that are left of it, unless the wanted number
+// of bytes or the end of the stream comes first - and what lane_stored (dbh_inflate_core.h)
+// would have found at the byte behind them.
+DBI_HD int stored_run(const Lane& L) {
+    const int room = L.out_cap > L.out_pos ? L.out_cap - L.out_pos : 0;
+    const int avail = (int)((L.br.limit_bits - L.br.bp) >> 3);      // (bp <= limit_bits: lane_block)
+    const int n = L.stored_left < room ? L.stored_left : room;
+    return n < avail ? n : avail;
+}
+// ... the state behind a run of n bytes (their tokens are written by the caller).  Returns true
+// if the block has ended and the next block header is to be read.
+DBI_HD bool stored_advance(Lane& L, int n) {
+    L.stored_left -= n;
+    L.out_pos += n;
+    L.br.bp += 8u * (uint32_t)n;
+    if (L.stored_left == 0) {
+        L.state = kNeedBlock;
+        if (L.final_block) lane_ended(L);
+        return L.state == kNeedBlock;
+    }
+    if (L.out_pos >= L.out_cap) L.state = kDone;       // more data than wanted
+    else lane_fail(L, kTruncated);                     // the stream ends inside the block
+    return false;
+}
+
+// where lane i of a chunk that begins at bit rel0 (< 32) of the stage begins / stops
+DBI_HD uint32_t sub_start(uint32_t rel0, int lane) { return rel0 + (uint32_t)lane * kSubBits; }
+
+// the byte (from the stream's first) at which the 16-byte piece k of a chunk's stage is read -
+// never beyond fetch_cap (BitReader::request: what lies there instead is behind the stream's end
+// and never looked at)
+DBI_HD uint32_t stage_piece_at(uint32_t first_dword, int piece, uint32_t fetch_cap) {
+    return umin((first_dword + 4u * (uint32_t)piece) * 4u, fetch_cap);
+}
+
+}  // namespace dbi

@@ -47,20 +47,20 @@ INFLATE_CUS = 0
 
 def host_inflate_share(n_gpus):
     """Per cent of a container's compressed bytes the host's threads inflate themselves (its
-    longest streams: a lane of the GPU's decoder walks ONE stream, however long); the GPUs
-    inflate the rest.  100 = everything on the host (the CPU-only loader path), 0 = everything
-    on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end, DEEPBINNER_HOST_INFLATE_SHARE=
-    <per cent> any split.
+    longest streams); the GPUs inflate the rest.  100 = everything on the host (the CPU-only
+    loader path), 0 = everything on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end,
+    DEEPBINNER_HOST_INFLATE_SHARE=<per cent> any split.
 
     Left alone: what the host's cores can do beside their other work while a GPU classifies at
     the rate it reaches with the inflate kernels running beside the forward kernel.  Measured
-    (profiles/r03_gpu_inflate_split.txt; 27 k-sample reads, gzip 1, 16 loader threads): the host
-    spends ~25 us per read on everything but inflating and ~0.9 us more per per cent of the bytes
-    it inflates; a GPU with three containers in flight settles at ~165 k reads/s for any share
-    between 40 and 70 - so the host takes what four fifths of its cores manage at that rate
-    (16 cores, one GPU: 58 %; 24 cores per GPU and more: everything, and the inflate kernels are
-    not used at all; a 16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing:
-    there the GPUs inflate every stream)."""
+    (profiles/r05_multi_read_rate.json; 27 k-sample reads, gzip 1, 16 loader threads, kernel 1
+    one wavefront per stream): the host spends ~21 us per read on everything but inflating and
+    ~1.0 us more per per cent of the bytes it inflates; a GPU with three containers in flight
+    settles at ~180 k reads/s for any share between 40 and 60 (133 k with no help at all) - so
+    the host takes what four fifths of its cores manage at that rate (16 cores, one GPU: 50 %;
+    24 cores per GPU and more: everything, and the inflate kernels are not used at all; a
+    16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing: there the GPUs
+    inflate every stream)."""
     flag = os.environ.get('DEEPBINNER_GPU_INFLATE')
     if flag == '0':
         return 100
@@ -70,8 +70,8 @@ def host_inflate_share(n_gpus):
     if explicit:
         return max(0, min(100, int(explicit)))
     cores, gpus = float(usable_cpus()), float(max(n_gpus, 1))
-    budget_us = 0.8 * cores / gpus / 165e3 * 1e6           # host time per read at the GPU's rate
-    return int(round(max(0.0, min(100.0, (budget_us - 25.0) / 0.9))))
+    budget_us = 0.8 * cores / gpus / 180e3 * 1e6           # host time per read at the GPU's rate
+    return int(round(max(0.0, min(100.0, (budget_us - 21.0) / 1.0))))
 
 
 def queue_clones(pair, n_more):

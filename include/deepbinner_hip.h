@@ -215,11 +215,13 @@ const char* dbh_inflate_last_error(void);
 /* total_out_bytes = size of the output buffer the streams write into */
 int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size_t* bytes);
 /* comp_bytes = size of the compressed buffer (the decoder's read-ahead stops 64 bytes behind it).
- * streams_per_lane (0 = 1): the lanes of kernel 1 take streams off a counter, in the order of the
- * records - with one stream per lane a launch is as wide as the streams are many and lasts as long
- * as the longest of them; with n, a launch 1/n as wide does the same work, and lasts no longer if
- * the long streams come first in the records and are long enough (a container of reads: 4) -
- * room for other kernels on the rest of the GPU. */
+ * Kernel 1 (Huffman codes -> tokens) gives every stream a wavefront of its own, in the order of
+ * the records (the longest first, if the caller can: the launch then ends evenly).
+ * streams_per_lane only matters to the kernel's older form (environment DEEPBINNER_INFLATE_KERNEL=
+ * lane: one LANE per stream; 0 = 1): its lanes take streams off a counter - with one stream per
+ * lane a launch is as wide as the streams are many and lasts as long as the longest of them; with
+ * n, a launch 1/n as wide does the same work, and lasts no longer if the long streams come first
+ * in the records and are long enough. */
 int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
                     const dbh_inflate_stream* streams_dev, int64_t n_streams,
                     int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,

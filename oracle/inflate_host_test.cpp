@@ -22,6 +22,7 @@ static void dbi_table_mismatch();
 static long g_answers[2];
 static void dbi_table_answer(bool fast) { ++g_answers[fast ? 1 : 0]; }
 #include "../deepbinner_amd/csrc/dbh_inflate_core.h"
+#include "../deepbinner_amd/csrc/dbh_inflate_wave.h"
 static void dbi_table_mismatch() {
     std::fprintf(stderr, "a first-level table entry disagrees with the canonical decoder\n");
     std::abort();
@@ -32,6 +33,9 @@ struct HostMem {
     uint16_t lit_sym_[dbi::kLitSyms], cnt_[16];
     uint8_t dist_sym_[dbi::kDistSyms], lens_[dbi::kMaxLens];
     uint16_t lit_tab_[1 << dbi::kLitBits], dist_tab_[1 << dbi::kDistBits];
+    uint32_t stage_[dbi::kStageDwords];      // (the one-wave-per-stream decoder's chunk)
+    uint32_t stage(int i) const { return stage_[check(i, dbi::kStageDwords)]; }
+    void set_stage(int i, uint32_t v) { stage_[check(i, dbi::kStageDwords)] = v; }
     uint32_t lit_tab(int i) const { return lit_tab_[check(i, 1 << dbi::kLitBits)]; }
     void set_lit_tab(int i, uint32_t v) { lit_tab_[check(i, 1 << dbi::kLitBits)] = (uint16_t)v; }
     uint32_t dist_tab(int i) const { return dist_tab_[check(i, 1 << dbi::kDistBits)]; }
@@ -59,6 +63,111 @@ struct HostMem {
     }
 };
 
+// The one-wave-per-stream decoder (dbh_inflate_wave.h) as inflate_tokens_wave_kernel runs it, the
+// 64 lanes one after the other: serial code (headers, code builds, stored blocks) as lane 0 runs
+// it, then chunk after chunk of the Huffman block - round 1 from every home's first bit, further
+// rounds for the lanes whose predecessor ended elsewhere, the output pass.  Must leave the very
+// tokens and the very lane state of the one-lane decoder.
+static long g_wave_chunks, g_wave_rounds, g_wave_walks, g_wave_tokens;
+static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint32_t out_cap,
+                     HostMem& mem, dbi::Lane& L, std::vector<uint32_t>& tokens) {
+    using namespace dbi;
+    lane_start(L, mem, comp.data(), (int64_t)comp_bytes, (int64_t)out_cap, (int64_t)comp.size());
+    long guard = 0;
+    std::vector<uint32_t> lane_tokens[kWaveLanes];
+    while (L.state != kDone) {
+        if (++guard > 100000000L) std::abort();
+        if (L.state == kNeedBlock) {
+            lane_block(L, mem);
+            continue;
+        }
+        if (L.state == kStored) {
+            const int n = stored_run(L);
+            for (int k = 0; k < n; ++k) tokens.push_back(comp[(L.br.bp >> 3) + (size_t)k]);
+            if (stored_advance(L, n)) L.br.seek(mem, L.br.bp);
+            continue;
+        }
+        // kDecode: one chunk
+        const uint32_t first_dword = L.br.bp >> 5, rel0 = L.br.bp & 31u;
+        for (int piece = 0; piece < kStageDwords / 4; ++piece) {
+            const U4 v = L.br.load16(stage_piece_at(first_dword, piece, L.br.fetch_cap));
+            mem.set_stage(4 * piece + 0, v.x);
+            mem.set_stage(4 * piece + 1, v.y);
+            mem.set_stage(4 * piece + 2, v.z);
+            mem.set_stage(4 * piece + 3, v.w);
+        }
+        WaveBlock B;
+        for (int l = 0; l < 15; ++l) {
+            B.lim_lit[l] = L.lim_lit[l];
+            B.lim_dist[l] = L.lim_dist[l];
+        }
+        B.limit_rel = L.br.limit_bits - first_dword * 32u;
+        uint32_t x[kWaveLanes];
+        SubResult r[kWaveLanes];
+        for (int i = 0; i < kWaveLanes; ++i) {
+            x[i] = sub_start(rel0, i);
+            r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1));
+        }
+        ++g_wave_chunks;
+        ++g_wave_rounds;
+        g_wave_walks += kWaveLanes;
+        int last;                       // the lane whose walk ends the chunk
+        for (;;) {
+            uint32_t want[kWaveLanes];
+            int first_moved = kWaveLanes, first_flag = kWaveLanes;
+            for (int i = 0; i < kWaveLanes; ++i) {
+                want[i] = i == 0 ? rel0 : r[i - 1].flag != kSubNone ? sub_start(rel0, i) : r[i - 1].end;
+                if (want[i] != x[i] && first_moved == kWaveLanes) first_moved = i;
+                if (r[i].flag != kSubNone && first_flag == kWaveLanes) first_flag = i;
+            }
+            if (first_moved > first_flag || first_moved == kWaveLanes) {
+                last = first_flag < kWaveLanes ? first_flag : kWaveLanes - 1;
+                break;
+            }
+            ++g_wave_rounds;
+            for (int i = 0; i < kWaveLanes; ++i)
+                if (want[i] != x[i]) {
+                    x[i] = want[i];
+                    r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1));
+                    ++g_wave_walks;
+                }
+        }
+        // the lane in which the wanted number of bytes is exceeded, if that comes first
+        int before = L.out_pos;
+        for (int i = 0; i <= last; ++i) {
+            if (before + r[i].bytes > L.out_cap) {
+                last = i;
+                break;
+            }
+            before += r[i].bytes;
+        }
+        int out_pos = L.out_pos;
+        SubResult e{};
+        for (int i = 0; i <= last; ++i) {
+            lane_tokens[i].assign((size_t)r[i].count + 1, 0u);
+            e = sub_emit(B, mem, x[i], sub_start(rel0, i + 1), out_pos, L.out_cap, lane_tokens[i].data());
+            if (i < last && (e.flag != kSubNone || e.count != r[i].count || e.bytes != r[i].bytes ||
+                             e.end != r[i].end)) {
+                std::fprintf(stderr, "wave model: the output pass disagrees with the rounds\n");
+                std::abort();
+            }
+            tokens.insert(tokens.end(), lane_tokens[i].begin(), lane_tokens[i].begin() + e.count);
+            out_pos += e.bytes;
+            g_wave_tokens += e.count;
+        }
+        L.out_pos = out_pos;
+        L.br.bp = first_dword * 32u + e.end;
+        if (e.flag == kSubBad) lane_fail(L, kBadSymbol);
+        else if (e.flag == kSubTrunc) lane_fail(L, kTruncated);
+        else if (e.flag == kSubBeyond) L.state = kDone;
+        else if (e.flag == kSubEnd) {
+            L.state = kNeedBlock;
+            if (L.final_block) lane_ended(L);
+            else L.br.seek(mem, L.br.bp);
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc != 3) return 2;
     FILE* in = std::fopen(argv[1], "rb");
@@ -68,6 +177,13 @@ int main(int argc, char** argv) {
     if (std::fread(&n_cases, 4, 1, in) != 1) return 2;
     if (std::getenv("DBI_TABLE_STATS")) std::atexit([] {
         std::fprintf(stderr, "tokens answered by the tables: %ld, sent the canonical way: %ld\n", g_answers[1], g_answers[0]);
+    });
+    if (std::getenv("DBI_WAVE_STATS")) std::atexit([] {
+        std::fprintf(stderr, "one wave per stream: %ld chunks, %.3f rounds per chunk, %.3f walks per lane and chunk, "
+                             "%.1f tokens per lane and chunk\n", g_wave_chunks,
+                     (double)g_wave_rounds / (double)std::max(1L, g_wave_chunks),
+                     (double)g_wave_walks / (64.0 * (double)std::max(1L, g_wave_chunks)),
+                     (double)g_wave_tokens / (64.0 * (double)std::max(1L, g_wave_chunks)));
     });
     for (uint32_t c = 0; c < n_cases; ++c) {
         uint32_t comp_bytes = 0, out_cap = 0;
@@ -100,6 +216,22 @@ int main(int argc, char** argv) {
             for (int k = 0; k < 4; ++k)
                 if (dbi::lane_decode(L, mem, &token)) tokens.push_back(token);
             L.br.checkpoint(mem);
+        }
+        // the one-wave-per-stream decoder must leave the same tokens and the same record
+        {
+            HostMem wmem;
+            std::memset(&wmem, 0, sizeof(wmem));
+            dbi::Lane W;
+            std::vector<uint32_t> wave_tokens;
+            run_wave(comp, comp_bytes, out_cap, wmem, W, wave_tokens);
+            if (W.status != L.status || W.ended != L.ended || W.adler != L.adler ||
+                (L.status == dbi::kOk && (W.out_pos != L.out_pos || wave_tokens != tokens))) {
+                std::fprintf(stderr, "case %u: one wave per stream: status %d ended %d bytes %d tokens %zu, "
+                                     "one lane per stream: status %d ended %d bytes %d tokens %zu\n", c,
+                             W.status, W.ended, W.out_pos, wave_tokens.size(), L.status, L.ended,
+                             L.out_pos, tokens.size());
+                return 5;
+            }
         }
         // phase 2, sequentially
         std::vector<uint8_t> bytes;

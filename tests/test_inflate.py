@@ -201,8 +201,16 @@ def pack_streams(hip, cases):
     return np.frombuffer(bytes(comp) if comp else b'\0', dtype=np.uint8), records, out_at, places
 
 
+@pytest.fixture(params=['lane', 'wave'])
+def kernel1(request, monkeypatch):
+    """Both forms of kernel 1 - one lane per stream, one wavefront per stream (dbh_inflate.hip) -
+    whichever of them is the default."""
+    monkeypatch.setenv('DEEPBINNER_INFLATE_KERNEL', request.param)
+    return request.param
+
+
 @pytest.mark.gpu
-def test_gpu_inflate_matches_zlib(hip):
+def test_gpu_inflate_matches_zlib(hip, kernel1):
     """Every valid case of the CPU test, all in one launch (lanes of one wave at different block
     types, lengths and states), plus stored-as-is streams and zero-extension."""
     cases = valid_cases()
@@ -226,7 +234,7 @@ def test_gpu_inflate_matches_zlib(hip):
 
 
 @pytest.mark.gpu
-def test_gpu_inflate_rejects_what_zlib_rejects(hip):
+def test_gpu_inflate_rejects_what_zlib_rejects(hip, kernel1):
     cases = damaged_cases()
     cap = 100000
     comp, records, out_bytes, places = pack_streams(hip, [(s, cap, hip.INFLATE_ZLIB) for s in cases])
@@ -248,7 +256,7 @@ def test_gpu_inflate_rejects_what_zlib_rejects(hip):
 
 
 @pytest.mark.gpu
-def test_gpu_inflate_a_container_of_reads(hip):
+def test_gpu_inflate_a_container_of_reads(hip, kernel1):
     """4,000 squiggles of 2,000-60,000 samples, deflated at level 1 (what MinKNOW and h5py's
     gzip=1 write): every byte as zlib gives it; the rate goes to the log."""
     rng = np.random.default_rng(17)
@@ -261,5 +269,5 @@ def test_gpu_inflate_a_container_of_reads(hip):
     assert (status == 0).all()
     for (at, cap), j in zip(places, picks):
         assert out[at:at + cap].tobytes() == pool[j]
-    print('gpu inflate: 4,000 streams, %.1f MB out, %.2f ms in the kernels = %.0f streams/s, '
-          '%.2f GB/s of output' % (out_bytes / 1e6, ms, 4000 / (ms * 1e-3), out_bytes / ms / 1e6))
+    print('gpu inflate (kernel 1: one %s per stream): 4,000 streams, %.1f MB out, %.2f ms in the kernels = %.0f streams/s, '
+          '%.2f GB/s of output' % (kernel1, out_bytes / 1e6, ms, 4000 / (ms * 1e-3), out_bytes / ms / 1e6))
