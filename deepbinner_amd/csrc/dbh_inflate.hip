@@ -487,6 +487,11 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
 constexpr int kRing = dbi::kWindowRing;
 static_assert(dbi::kStepTokens == 64, "one token per lane and step");
 constexpr int kWaves2 = 5;                 // streams per workgroup of kernel 2: a 32 KiB ring each
+// timing-only ablations of kernel 2 (wrong bytes): 1 no match copies, 2 no flush of the ring, 4 no
+// literal stores
+#ifndef DBI_K2_ABL
+#define DBI_K2_ABL 0
+#endif
 
 // Wave-wide inclusive prefix sum on the DPP network (no LDS round trips): within rows of 16
 // lanes by shifts, then each row's total handed on to the rows behind it.
@@ -600,14 +605,14 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
                     }
                     lds_settle();
                 } else {
-                if (valid && !is_match) ring[my & (kRing - 1)] = (uint8_t)t;
+                if (!(DBI_K2_ABL & 4) && valid && !is_match) ring[my & (kRing - 1)] = (uint8_t)t;
                 // A match repeats the `dist` bytes before it: byte k is byte k mod dist of them,
                 // so everything it READS lies before its own start, in [src, src + min(len,
                 // dist)) - it may go as soon as that is written, i.e. lies before the earliest
                 // byte still to be written (the first waiting match's start: the positions ascend
                 // with the lanes).  The first waiting match can always go.
                 const int reach = src + (len < dist ? len : dist);
-                bool waiting = is_match;
+                bool waiting = is_match && !(DBI_K2_ABL & 1);
                 unsigned long long mask = __ballot(waiting);
                 while (mask != 0ull) {
                     lds_settle();
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
                 }
                 pos += total;
                 // whole 256-byte pieces out of the ring, the Adler-32 sums on the way
-                if (pos - flushed >= 256) {
+                if (!(DBI_K2_ABL & 2) && pos - flushed >= 256) {
                     lds_settle();
                     do {
                         const uint32_t w = *reinterpret_cast<const uint32_t*>(

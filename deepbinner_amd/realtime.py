@@ -36,9 +36,9 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 
 
 # The streaming path with the GPU inflating: what it was measured with on an MI355X box (16
-# usable cores, one GPU; profiles/r03_gpu_inflate_split.txt) - three containers in flight per GPU,
-# each on its own queue (model replica); six where the GPU inflates nearly everything (a container
-# then lasts as long as its longest read, ~10 mean reads).  No CUs are left out of the forward
+# usable cores, one GPU; profiles/r03_gpu_inflate_split.txt, profiles/r05_multi_read_rate.json) -
+# three containers in flight per GPU, each on its own queue (model replica), whatever share of
+# the inflating the GPU takes.  No CUs are left out of the forward
 # kernel's launches for the inflate kernels: its workgroups take their windows off a counter, and
 # one that finds its CU taken simply takes fewer (while they walked fixed shares, 32 were).
 INFLATE_QUEUES = 3
@@ -56,7 +56,7 @@ def host_inflate_share(n_gpus):
     (profiles/r05_multi_read_rate.json; 27 k-sample reads, gzip 1, 16 loader threads, kernel 1
     one wavefront per stream): the host spends ~21 us per read on everything but inflating and
     ~1.0 us more per per cent of the bytes it inflates; a GPU with three containers in flight
-    settles at ~180 k reads/s for any share between 40 and 60 (133 k with no help at all) - so
+    settles at ~180 k reads/s for any share between 40 and 60 (146 k with no help at all) - so
     the host takes what four fifths of its cores manage at that rate (16 cores, one GPU: 50 %;
     24 cores per GPU and more: everything, and the inflate kernels are not used at all; a
     16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing: there the GPUs
@@ -115,7 +115,11 @@ def inflate_queues(replicas, host_share=50):
     DEEPBINNER_INFLATE_CUS."""
     n_queues = int(os.environ.get('DEEPBINNER_INFLATE_QUEUES', 0) or 0)
     if n_queues < 1:
-        n_queues = INFLATE_QUEUES if host_share >= 30 else 2 * INFLATE_QUEUES
+        # (with kernel 1 one lane per stream a container the GPU inflated alone lasted as long as
+        # its longest read, and twice the queues hid that; with one wavefront per stream three
+        # queues are best at any share: 151 k reads/s against 142 k with six, the host inflating
+        # nothing - profiles/r05_wave/README.md)
+        n_queues = INFLATE_QUEUES
     n_cus = max(0, int(os.environ.get('DEEPBINNER_INFLATE_CUS', INFLATE_CUS)))
     out = []
     for pair in replicas:

@@ -69,6 +69,7 @@ struct HostMem {
 // rounds for the lanes whose predecessor ended elsewhere, the output pass.  Must leave the very
 // tokens and the very lane state of the one-lane decoder.
 static long g_wave_chunks, g_wave_rounds, g_wave_walks, g_wave_tokens;
+static long g_k2_steps, g_k2_rounds, g_k2_turns, g_k2_matches, g_k2_match_bytes, g_k2_tokens;
 static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint32_t out_cap,
                      HostMem& mem, dbi::Lane& L, std::vector<uint32_t>& tokens) {
     using namespace dbi;
@@ -185,6 +186,12 @@ int main(int argc, char** argv) {
                      (double)g_wave_walks / (64.0 * (double)std::max(1L, g_wave_chunks)),
                      (double)g_wave_tokens / (64.0 * (double)std::max(1L, g_wave_chunks)));
     });
+    if (std::getenv("DBI_K2_STATS")) std::atexit([] {
+        std::fprintf(stderr, "resolve schedule: %ld steps, %.1f tokens, %.1f matches (%.1f bytes each), %.2f rounds, "
+                             "%.2f four-byte turns per step\n", g_k2_steps, (double)g_k2_tokens / g_k2_steps,
+                     (double)g_k2_matches / g_k2_steps, (double)g_k2_match_bytes / std::max(1L, g_k2_matches),
+                     (double)g_k2_rounds / g_k2_steps, (double)g_k2_turns / g_k2_steps);
+    });
     for (uint32_t c = 0; c < n_cases; ++c) {
         uint32_t comp_bytes = 0, out_cap = 0;
         if (std::fread(&comp_bytes, 4, 1, in) != 1 || std::fread(&out_cap, 4, 1, in) != 1) return 2;
@@ -274,6 +281,13 @@ int main(int argc, char** argv) {
                     my[l] = end;
                     end += len[l];
                 }
+                ++g_k2_steps;
+                g_k2_tokens += lanes;
+                for (int l = 0; l < lanes; ++l)
+                    if (is_match[l]) {
+                        ++g_k2_matches;
+                        g_k2_match_bytes += len[l];
+                    }
                 bool hazard = false;
                 for (int l = 0; l < lanes; ++l)
                     hazard = hazard || (is_match[l] && dbi::ring_hazard(dist[l], (int)my[l], (int)end));
@@ -300,6 +314,8 @@ int main(int argc, char** argv) {
                             go[l] = waiting[l] && src + std::min(len[l], dist[l]) <= first;
                             if (go[l]) longest = std::max(longest, len[l]);
                         }
+                        ++g_k2_rounds;
+                        g_k2_turns += (longest + 3) / 4;
                         for (int k = 0; k < longest; k += 4) {
                             uint8_t b[64][4];
                             for (int l = 0; l < lanes; ++l)
