@@ -523,12 +523,14 @@ __device__ __forceinline__ void dma_piece(const float* g_piece, const float* lds
 #ifndef DBH_DMA_ALL_WAVES
 #define DBH_DMA_ALL_WAVES 4
 #endif
-template <int NFLOATS>
+#ifndef DBH_CONV8_DMA
+#define DBH_CONV8_DMA 1
+#endif
+template <int NFLOATS, int NW = DBH_DMA_ALL_WAVES>
 __device__ __forceinline__ void dma_weights(const float* __restrict__ g, float* lds_dst, int lane,
                                             int wave) {
     static_assert(NFLOATS % 256 == 0, "weight blocks are whole 1 KiB pieces");
     constexpr int kPieces = NFLOATS / 256;
-    constexpr int NW = DBH_DMA_ALL_WAVES;
     const unsigned lane_bytes = (unsigned)lane * 16u;
     if (wave >= NW) return;
 #pragma unroll
@@ -550,11 +552,10 @@ __device__ __forceinline__ void dma_weights_one(const float* __restrict__ g, flo
 }
 
 // The same copy, spread over the NIT steps of the running layer (step IT issues its share).
-template <int NFLOATS, int IT, int NIT>
+template <int NFLOATS, int IT, int NIT, int NW = DBH_DMA_ALL_WAVES>
 __device__ __forceinline__ void dma_weights_slice(const float* __restrict__ g, float* lds_dst,
                                                   int lane, int wave) {
     constexpr int kPieces = NFLOATS / 256;
-    constexpr int NW = DBH_DMA_ALL_WAVES;
     constexpr int kPerWave = (kPieces + NW - 1) / NW;
     const unsigned lane_bytes = (unsigned)lane * 16u;
     if (wave >= NW) return;
@@ -3040,11 +3041,24 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // of the arena by DMA.
     SmallMRegs<16, 8, 3, true> r17;
     r17.prefetch_epilogue(packed, 5, lane, wave);
+    // (DBH_CONV8_DMA - A/B knob: how conv9's weights are asked for during conv8.  0: up front by
+    // waves 0-3; 1, what runs: a slice per MFMA step, waves 0-3 (+0.2 %: 44.31 -> 44.22 us per 256
+    // windows, same box); 2: a slice per step, all eight waves (-0.5 %); 3: up front, all eight
+    // waves (no change))
     wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
         lds, packed, tid, lane, wave, ts, 26,
-        [&] { dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave); },
+        [&] {
+            if (DBH_CONV8_DMA == 0)
+                dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave);
+            if (DBH_CONV8_DMA == 3)
+                dma_weights<conv_weight_floats(8), 8>(packed + weight_offset(8), lds + kW9, lane, wave);
+        },
         interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
             constexpr int IT = decltype(tag)::value;
+            if (DBH_CONV8_DMA == 1)
+                dma_weights_slice<conv_weight_floats(8), IT, 6, 4>(packed + weight_offset(8), lds + kW9, lane, wave);
+            if (DBH_CONV8_DMA == 2)
+                dma_weights_slice<conv_weight_floats(8), IT, 6, 8>(packed + weight_offset(8), lds + kW9, lane, wave);
             r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
         }));
     // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
