@@ -89,6 +89,19 @@ def valid_cases():
                                        ('fixed', b'xyz' * 400), ('stored', b''),
                                        ('dynamic', squiggle(rng, 9000))])
     cases.append((stream, len(data), data))
+    # what the one-wavefront-per-stream decoder meets at its seams: hundreds of short blocks (a
+    # block boundary inside nearly every chunk of 64 homes, dynamic / fixed / stored in turn, empty
+    # stored blocks between them), one-byte blocks, and a read of 1.5 M samples (a long DNA read:
+    # hundreds of chunks, every block full)
+    many = [(('dynamic', 'fixed', 'stored')[k % 3], squiggle(rng, int(rng.integers(1, 400))))
+            for k in range(300)]
+    stream, data = raw_deflate_stream(many)
+    cases.append((stream, len(data), data))
+    stream, data = raw_deflate_stream([('dynamic', b'a'), ('fixed', b'b'), ('stored', b'c')] * 20)
+    cases.append((stream, len(data), data))
+    long_read = squiggle(rng, 1500000)
+    cases.append((zlib.compress(long_read, 1), len(long_read), long_read))
+    cases.append((zlib.compress(long_read, 1), 12288, long_read[:12288]))
     # fewer bytes wanted than the stream holds (a partial last chunk; scanning read starts only),
     # and more (MinKNOW's short final chunk: libhdf5 zero-extends it)
     for data in (payloads[6], payloads[10], real[0][:30000]):
