@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 DEEPBINNER_TIMELINE_FUSED=1 DEEPBINNER_TIMELINE_WAVES=1 python $R/tools/timeline.py 5120 > $OUT/timeline_5120_fused.txt 2>&1
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- \
-    python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-side-rates > $OUT/prof_stats_bench.log 2>&1
+    python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-rates > $OUT/prof_stats_bench.log 2>&1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" \
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" \
