@@ -684,10 +684,258 @@ __global__ __launch_bounds__(64 * kWaves2) void inflate_resolve_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel 2, second form (what runs; DEEPBINNER_INFLATE_RESOLVE=rounds brings the first back).
+// One wave per stream and up to 64 tokens per step as before - another schedule and a smaller
+// ring (dbh_inflate_core.h: "Phase 2's second form").  In the first form every match went through
+// the rounds: a step's ~38 matches of ~3.6 bytes took 3.65 rounds of 4.6 four-byte turns, each a
+// dependent LDS load and store behind a drained queue - ~5 k cycles per step, 60 % of them waiting,
+// with five waves per CU (the 32 KiB rings) and nothing to fill the waits.  Here
+//   * a short match whose source is complete before its step ("pre", 82 %) reads its eight source
+//     bytes at the boundary in front of the step - one unaligned ds_read_b64 from the ring, or one
+//     unaligned global load from the stream's own output where the source lies further back than
+//     the ring reaches - and is two overlapping four-byte stores (or two two-byte ones) at the top
+//     of its step, together with the literals;
+//   * the others ("late": ~3.9 per step) go in rounds by the exact rule (a scalar loop over the
+//     waiting lanes): 1.36 rounds per step, eight bytes in the first turn; a match that overlaps
+//     itself repeats its first dist bytes (k2_pattern8);
+//   * the ring is 8 KiB: twenty streams per CU, one wave per workgroup (a CU's LDS comes back
+//     stream by stream, not when the longest of five has ended).
+// The CPU harness models this schedule byte for byte - which copy of a position (ring slot or
+// flushed output) every read sees - and holds it against the tokens resolved in order.
+constexpr int kRing3 = dbi::kSmallRing;
+__device__ __forceinline__ uint64_t ring_read8(const uint8_t* ring, int p) {
+    const int slot = p & (kRing3 - 1);
+    uint64_t v;
+    if (slot <= kRing3 - 8) {
+        __builtin_memcpy(&v, ring + slot, 8);          // (byte-aligned: hipcc emits ds_read_b64)
+    } else {                                           // over the end of the ring: byte by byte
+        v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v |= (uint64_t)ring[(slot + j) & (kRing3 - 1)] << (8 * j);
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t output_read8(const uint8_t* dst, int p) {
+    uint64_t v;
+    __builtin_memcpy(&v, dst + p, 8);                  // (one unaligned global_load_dwordx2)
+    return v;
+}
+// the first `len` (1..8) bytes of v to positions p, p + 1, ...
+__device__ __forceinline__ void ring_store_short(uint8_t* ring, int p, int len, uint64_t v) {
+    const int slot = p & (kRing3 - 1);
+    if (len >= 3 && slot + len <= kRing3) {
+        if (len >= 4) {                                // two four-byte stores that may overlap
+            const uint32_t a = (uint32_t)v, b = (uint32_t)(v >> (8 * (len - 4)));
+            __builtin_memcpy(ring + slot, &a, 4);
+            __builtin_memcpy(ring + slot + (len - 4), &b, 4);
+        } else {                                       // three bytes: two two-byte stores
+            const uint16_t a = (uint16_t)v, b = (uint16_t)(v >> 8);
+            __builtin_memcpy(ring + slot, &a, 2);
+            __builtin_memcpy(ring + slot + 1, &b, 2);
+        }
+    } else {                                           // a cut match of one or two bytes, or over
+#pragma unroll                                         // the end of the ring
+        for (int j = 0; j < 8; ++j)
+            if (j < len) ring[(slot + j) & (kRing3 - 1)] = (uint8_t)(v >> (8 * j));
+    }
+}
+
+// A step's tokens, decoded and placed: lane l holds token first + l if the step takes it.
+struct StepTokens {
+    uint32_t t;
+    bool valid, is_match;
+    int len, dist, my;
+    int total, count;          // (uniform) bytes and tokens of the step
+};
+// `raw` = tok[first + lane] (0 behind the last token).  The step takes the tokens that together
+// span at most kStepSpan bytes - all 64 unless there are long matches among them.
+__device__ __forceinline__ StepTokens place_step(uint32_t raw, int first, int n_tok, int base, int lane) {
+    StepTokens s;
+    s.t = raw;
+    s.valid = first + lane < n_tok;
+    s.is_match = s.valid && (raw & dbi::kMatchFlag);
+    s.len = !s.valid ? 0 : s.is_match ? (int)(raw & 0x1FFu) : 1;
+    s.dist = (int)((raw >> 9) & 0x7FFFu) + 1;
+    const int incl = wave_scan_i32(s.len);
+    s.total = __builtin_amdgcn_readlane(incl, 63);
+    s.count = n_tok - first < 64 ? n_tok - first : 64;
+    if (s.total > dbi::kStepSpan) {                    // (rare: long matches)
+        const bool keep = s.valid && incl <= dbi::kStepSpan;      // a prefix of the lanes, never empty
+        s.count = __popcll(__ballot(keep));
+        s.total = __builtin_amdgcn_readlane(incl, s.count - 1);
+        s.valid = keep;
+        s.is_match = s.is_match && keep;
+        s.len = keep ? s.len : 0;
+    }
+    s.my = base + incl - s.len;
+    return s;
+}
+
+__global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
+    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
+    const uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info, uint8_t* out,
+    int32_t* __restrict__ status_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing3];
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n_streams; i += gridDim.x) {
+        const dbh_inflate_stream s = streams[i];
+        uint8_t* dst = out + s.out_offset;
+        const int64_t cap = s.out_bytes;
+        if (s.mode != DBH_INFLATE_ZLIB) {
+            const int64_t have = s.comp_bytes < cap ? s.comp_bytes : cap;
+            const uint8_t* src = comp + s.comp_offset;
+            const int64_t whole = have & ~(int64_t)7;
+            for (int64_t k = 8 * (int64_t)lane; k < whole; k += 512) {
+                uint64_t v;
+                __builtin_memcpy(&v, src + k, 8);
+                __builtin_memcpy(dst + k, &v, 8);
+            }
+            for (int64_t k = whole + lane; k < cap; k += 64) dst[k] = k < have ? src[k] : (uint8_t)0;
+            if (lane == 0) status_out[i] = dbi::kOk;
+            continue;
+        }
+        StreamInfo r = info[i];
+        int status = r.status;
+        const uint32_t* tok = tokens + s.out_offset;
+        const int n_tok = r.n_tokens;
+        const unsigned n_out = (unsigned)r.produced;
+        int pos = 0, flushed = 0;
+        AdlerLane adler = {0u, 0ull};
+        if (status == dbi::kOk && n_tok > 0) {
+            int first = 0;                            // this step's first token
+            StepTokens c = place_step(lane < n_tok ? tok[lane] : 0u, 0, n_tok, 0, lane);
+            uint32_t raw_next = 64 + lane < n_tok ? tok[64 + lane] : 0u;      // (if this step takes 64)
+            bool pre = false;                         // (nothing lies before the first step)
+            uint64_t pv = 0ull;
+            for (;;) {
+                const int end = pos + c.total;
+                if (__any(c.is_match && c.dist > c.my)) {   // reaches before the start of the output
+                    status = dbi::kBadDistance;
+                    break;
+                }
+                // the step behind this one is decoded and placed while this one's stores land
+                const int first_n = first + c.count;
+                if (c.count != 64) raw_next = first_n + lane < n_tok ? tok[first_n + lane] : 0u;
+                const uint32_t raw_after = first_n + 64 + lane < n_tok ? tok[first_n + 64 + lane] : 0u;
+                const StepTokens n = place_step(raw_next, first_n, n_tok, end, lane);
+
+                const int src = c.my - c.dist;
+                const int reach = src + (c.len < c.dist ? c.len : c.dist);
+                const int my_end = c.my + c.len;
+                if (!(DBI_K2_ABL & 4) && c.valid && !c.is_match) ring[c.my & (kRing3 - 1)] = (uint8_t)c.t;
+                if (pre) ring_store_short(ring, c.my, c.len, c.dist < c.len ? dbi::k2_pattern8(pv, c.dist) : pv);
+                bool waiting = c.is_match && !pre && !(DBI_K2_ABL & 1);
+                unsigned long long mask = __ballot(waiting);
+                while (mask != 0ull) {
+                    lds_settle();
+                    bool blocked = false;
+                    for (unsigned long long it = mask; it != 0ull; it &= it - 1ull) {
+                        const int w = __ffsll((long long)it) - 1;
+                        blocked = blocked || dbi::k2_blocks(__builtin_amdgcn_readlane(c.my, w),
+                                                            __builtin_amdgcn_readlane(my_end, w), src, reach);
+                    }
+                    const bool go = waiting && !blocked;
+                    if (go) {
+                        uint64_t v = dbi::k2_in_ring(src, end) ? ring_read8(ring, src) : output_read8(dst, src);
+                        if (c.dist < 8 && c.dist < c.len) v = dbi::k2_pattern8(v, c.dist);
+                        ring_store_short(ring, c.my, c.len < 8 ? c.len : 8, v);
+                    }
+                    if (__any(go && c.len > 8)) {
+                        // what is left of a long match: four bytes per turn, byte k = byte k mod
+                        // dist of the dist bytes before the match
+                        int k = 8, o = 8 % c.dist;
+                        while (__any(go && k < c.len)) {
+                            if (go && k < c.len) {
+                                int o1 = o + 1;
+                                o1 = o1 == c.dist ? 0 : o1;
+                                int o2 = o1 + 1;
+                                o2 = o2 == c.dist ? 0 : o2;
+                                int o3 = o2 + 1;
+                                o3 = o3 == c.dist ? 0 : o3;
+                                const bool near = dbi::k2_in_ring(src, end);      // (then all of [src, my) is)
+                                const uint8_t b0 = near ? ring[(src + o) & (kRing3 - 1)] : dst[src + o];
+                                const uint8_t b1 = near ? ring[(src + o1) & (kRing3 - 1)] : dst[src + o1];
+                                const uint8_t b2 = near ? ring[(src + o2) & (kRing3 - 1)] : dst[src + o2];
+                                const uint8_t b3 = near ? ring[(src + o3) & (kRing3 - 1)] : dst[src + o3];
+                                ring[(c.my + k) & (kRing3 - 1)] = b0;
+                                if (k + 1 < c.len) ring[(c.my + k + 1) & (kRing3 - 1)] = b1;
+                                if (k + 2 < c.len) ring[(c.my + k + 2) & (kRing3 - 1)] = b2;
+                                if (k + 3 < c.len) ring[(c.my + k + 3) & (kRing3 - 1)] = b3;
+                                o = o3 + 1;
+                                o = o == c.dist ? 0 : o;
+                                k += 4;
+                            }
+                        }
+                    }
+                    waiting = waiting && !go;
+                    mask = __ballot(waiting);
+                }
+                lds_settle();                          // everything of this step is in the ring
+                pos = end;
+                // the boundary: the next step's short matches whose source is complete read it now -
+                // from the ring, or from the flushed output where the ring no longer holds it
+                const int src_n = n.my - n.dist;
+                const bool pre_n = dbi::k2_pre(n.is_match, n.len,
+                                               src_n + (n.len < n.dist ? n.len : n.dist), pos);
+                uint64_t pv_n = 0ull;
+                if (pre_n && src_n >= 0)
+                    pv_n = dbi::k2_in_ring(src_n, pos) ? ring_read8(ring, src_n) : output_read8(dst, src_n);
+                // whole 256-byte pieces out of the ring, the Adler-32 sums on the way
+                if (!(DBI_K2_ABL & 2) && pos - flushed >= 256) {
+                    do {
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(
+                            ring + ((flushed + 4 * lane) & (kRing3 - 1)));
+                        uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + flushed + 4 * lane);
+                        d16[0] = (uint16_t)w;             // (a read starts at an even byte, not
+                        d16[1] = (uint16_t)(w >> 16);     //  necessarily at a multiple of four)
+                        adler.add4(w, n_out - (unsigned)(flushed + 4 * lane));
+                        flushed += 256;
+                    } while (pos - flushed >= 256);
+                }
+                if (first_n >= n_tok) break;
+                first = first_n;
+                c = n;
+                raw_next = raw_after;
+                pre = pre_n;
+                pv = pv_n;
+            }
+        }
+        if (status == dbi::kOk) {
+            lds_settle();
+            const int rest = pos - flushed;           // < 256
+            for (int k = lane; k < rest; k += 64) {
+                const unsigned b = ring[(flushed + k) & (kRing3 - 1)];
+                dst[flushed + k] = (uint8_t)b;
+                adler.add1(b, n_out - (unsigned)(flushed + k));
+            }
+            if (r.ended) {
+                const unsigned s1 = (1u + wave_sum_u32(adler.bytes)) % 65521u;
+                const unsigned s2 =
+                    (unsigned)(((unsigned long long)n_out + wave_sum_u64(adler.weighted)) % 65521ull);
+                if (((s2 << 16) | s1) != r.adler) status = dbi::kBadChecksum;
+            }
+            // a stream that ends early (MinKNOW's short final chunk): libhdf5 zero-extends it
+            for (int64_t k = pos + lane; k < cap; k += 64) dst[k] = 0;
+        }
+        if (status != dbi::kOk)                       // nothing of a damaged stream is handed on
+            for (int64_t k = lane; k < cap; k += 64) dst[k] = 0;
+        if (lane == 0) status_out[i] = status;
+    }
+}
+
 thread_local char g_error[256];
 
 // which form of kernel 1 runs: DEEPBINNER_INFLATE_KERNEL=wave (one wavefront per stream) | lane (one
 // lane per stream); read at every call, so that a test can hold the two against each other
+// which form of kernel 2 runs: DEEPBINNER_INFLATE_RESOLVE=pre (short matches with a complete source
+// read at the step boundary, the rest by the exact rule) | rounds (every match through the rounds)
+bool resolve_pre() {
+    const char* v = std::getenv("DEEPBINNER_INFLATE_RESOLVE");
+    if (v && std::strcmp(v, "rounds") == 0) return false;
+    return true;
+}
+
 bool wave_per_stream() {
     const char* v = std::getenv("DEEPBINNER_INFLATE_KERNEL");
     if (v && std::strcmp(v, "lane") == 0) return false;
@@ -755,9 +1003,14 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
     DBI_HIP(hipGetLastError());
     const int groups = (n + kWaves2 - 1) / kWaves2;
     const int blocks = groups < 1024 ? groups : 1024;
-    hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(64 * kWaves2), 0,
-                       (hipStream_t)stream, comp_dev, streams_dev, n, (const uint32_t*)tokens, info,
-                       out_dev, status_dev);
+    if (resolve_pre())
+        hipLaunchKernelGGL(inflate_resolve_pre_kernel, dim3((unsigned)(n < 65536 ? n : 65536)), dim3(64), 0,
+                           (hipStream_t)stream, comp_dev, streams_dev, n, (const uint32_t*)tokens,
+                           info, out_dev, status_dev);
+    else
+        hipLaunchKernelGGL(inflate_resolve_kernel, dim3((unsigned)blocks), dim3(64 * kWaves2), 0,
+                           (hipStream_t)stream, comp_dev, streams_dev, n, (const uint32_t*)tokens,
+                           info, out_dev, status_dev);
     DBI_HIP(hipGetLastError());
     return DBH_OK;
 }

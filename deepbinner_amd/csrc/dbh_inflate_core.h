@@ -107,6 +107,49 @@ DBI_HD bool ring_hazard(int dist, int my, int step_end) {
     return dist + (step_end - my) > kWindowRing;
 }
 
+// Phase 2's second form (inflate_resolve_pre_kernel, what runs since the end of round 5).  What
+// the tokens of a read look like (level-1 streams of squiggles, oracle/inflate_host_test with
+// DBI_K2_STATS): distances are spread over the whole window (19 % within 256 bytes, 75 % within
+// 8 K), 99.99 % of the matches are at most kShortMatch bytes long, and only one in ten reads
+// anything its own step writes.  So:
+//  * a SHORT match whose source lies wholly before its step - four fifths of all - is "pre"
+//    (k2_pre): its eight source bytes are read at the boundary in front of the step, behind the
+//    last write of the step before, and stored together with the step's literals;
+//  * what is left ("late": matches that read what their own step writes, ~3.9 of 64 tokens, and
+//    long ones) goes in rounds, by the exact rule: whoever reads nothing that a still-waiting
+//    match writes (k2_blocks) - 1.36 rounds per step;
+//  * the ring in LDS is kSmallRing bytes, not the window's 32 KiB: what lies further back is read
+//    from the stream's OUTPUT in global memory, where the ring's 256-byte pieces go after every
+//    step (a source before pos - kSmallRing was flushed long ago).  Twenty streams per CU instead
+//    of five: the waits of one are the work of the others;
+//  * a step takes as many of its (up to 64) tokens as span at most kStepSpan bytes, so that the
+//    ring always holds a whole step and the unflushed bytes before it: during a step that ends at
+//    `end` position p is in the ring if p >= end - kSmallRing, and in global memory otherwise
+//    (k2_in_ring) - no write of the step can land on a byte that is still to be read from the
+//    ring, and the first form's ring hazard (a step in token order) does not exist.
+constexpr int kSmallRing = 8192;
+constexpr int kStepSpan = 4096;
+static_assert(kSmallRing >= kStepSpan + 256 + 8 + 8, "a step, the unflushed bytes before it, an eight-byte read");
+DBI_HD bool k2_in_ring(int p, int step_end) { return p >= step_end - kSmallRing; }
+constexpr int kShortMatch = 8;
+DBI_HD bool k2_pre(bool is_match, int len, int reach, int step_start) {
+    return is_match && len <= kShortMatch && reach <= step_start;
+}
+// does the waiting match that writes [w_start, w_end) hold up the one that reads [src, reach)?
+DBI_HD bool k2_blocks(int w_start, int w_end, int src, int reach) {
+    return w_start < reach && w_end > src;
+}
+// the first eight bytes of the endless repetition of v's first `dist` bytes, 1 <= dist < 8 (a match
+// that overlaps itself: byte k is byte k mod dist of the dist bytes before it)
+DBI_HD uint64_t k2_pattern8(uint64_t v, int dist) {
+    const int s1 = 8 * dist;
+    v &= (1ull << s1) - 1ull;
+    v |= v << s1;
+    if (dist <= 3) v |= v << (2 * s1);
+    if (dist == 1) v |= v << 32;
+    return v;
+}
+
 // RFC 1951 section 3.2.5, as arithmetic (device code cannot index host-side constant arrays):
 // length symbol 257 + c: c < 8: 3 + c; c < 28: e = (c - 4) / 4 extra bits, base 3 + ((4 + c % 4) << e);
 // c = 28: 258.  Distance symbol d: d < 4: d + 1; else e = d / 2 - 1, base 1 + ((2 + d % 2) << e).

@@ -70,6 +70,7 @@ struct HostMem {
 // tokens and the very lane state of the one-lane decoder.
 static long g_wave_chunks, g_wave_rounds, g_wave_walks, g_wave_tokens;
 static long g_k2_steps, g_k2_rounds, g_k2_turns, g_k2_matches, g_k2_match_bytes, g_k2_tokens;
+static long g_k2p_steps, g_k2p_rounds, g_k2p_late, g_k2p_pre, g_k2p_far, g_k2p_short_steps;
 static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint32_t out_cap,
                      HostMem& mem, dbi::Lane& L, std::vector<uint32_t>& tokens) {
     using namespace dbi;
@@ -191,6 +192,11 @@ int main(int argc, char** argv) {
                              "%.2f four-byte turns per step\n", g_k2_steps, (double)g_k2_tokens / g_k2_steps,
                      (double)g_k2_matches / g_k2_steps, (double)g_k2_match_bytes / std::max(1L, g_k2_matches),
                      (double)g_k2_rounds / g_k2_steps, (double)g_k2_turns / g_k2_steps);
+        std::fprintf(stderr, "second form: %ld steps (%ld cut short by their span), %.1f matches per step read at the "
+                             "boundary (%.1f of them from the flushed output), %.2f late ones in %.2f rounds\n",
+                     g_k2p_steps, g_k2p_short_steps, (double)g_k2p_pre / std::max(1L, g_k2p_steps),
+                     (double)g_k2p_far / std::max(1L, g_k2p_steps), (double)g_k2p_late / std::max(1L, g_k2p_steps),
+                     (double)g_k2p_rounds / std::max(1L, g_k2p_steps));
     });
     for (uint32_t c = 0; c < n_cases; ++c) {
         uint32_t comp_bytes = 0, out_cap = 0;
@@ -340,6 +346,162 @@ int main(int argc, char** argv) {
             if (model != bytes) {
                 std::fprintf(stderr, "case %u: the resolve kernel's schedule gives other bytes than "
                                      "the tokens in order\n", c);
+                return 4;
+            }
+        }
+        // ... and as the SECOND form schedules it (inflate_resolve_pre_kernel, what runs; dbh_inflate_
+        // core.h, "Phase 2's second form"): a ring of kSmallRing bytes and the flushed output behind
+        // it; steps of up to 64 tokens that span at most kStepSpan bytes; a short match whose source
+        // lies wholly before its step reads eight raw bytes at the boundary in front of the step
+        // (ring or flushed output), and is stored with the step's literals; the late matches go in
+        // rounds by the exact rule, eight bytes in the first turn (self-overlapping ones expanded by
+        // k2_pattern8), four per further turn.  The model knows which POSITION every ring slot
+        // holds and how far the output is flushed: a read of anything else is poisoned, so a read
+        // the schedule may not rely on shows up as wrong bytes.
+        if (status == dbi::kOk) {
+            const int R = dbi::kSmallRing;
+            std::vector<uint8_t> ring((size_t)R, 0), model;       // model = the flushed output
+            std::vector<long> holds((size_t)R, -1);
+            auto put = [&](long p, uint8_t v) {
+                ring[(size_t)(p & (R - 1))] = v;
+                holds[(size_t)(p & (R - 1))] = p;
+            };
+            auto ring_byte = [&](long p, int j) -> uint8_t {      // position p as the ring has it
+                return holds[(size_t)(p & (R - 1))] == p ? ring[(size_t)(p & (R - 1))] : (uint8_t)(0xA5 ^ (j * 37));
+            };
+            auto out_byte = [&](long p, int j) -> uint8_t {       // ... as the flushed output has it
+                return p >= 0 && p < (long)model.size() ? model[(size_t)p] : (uint8_t)(0x5A ^ (j * 41));
+            };
+            auto read8 = [&](long p, bool from_ring) {
+                uint64_t v = 0;
+                for (int j = 0; j < 8; ++j)
+                    v |= (uint64_t)(from_ring ? ring_byte(p + j, j) : out_byte(p + j, j)) << (8 * j);
+                return v;
+            };
+            auto store_short = [&](long p, int n, uint64_t v) {
+                for (int j = 0; j < n; ++j) put(p + j, (uint8_t)(v >> (8 * j)));
+            };
+            long pos = 0, flushed = 0;
+            const int n_tok = (int)tokens.size();
+            bool pre[64] = {};
+            uint64_t pv[64] = {};
+            // the tokens a step takes: up to 64, spanning at most kStepSpan bytes
+            auto step_count = [&](int first) {
+                int n = 0;
+                long span = 0;
+                while (n < dbi::kStepTokens && first + n < n_tok) {
+                    const uint32_t t = tokens[(size_t)(first + n)];
+                    const int ln = (t & dbi::kMatchFlag) ? (int)(t & 0x1FF) : 1;
+                    if (n > 0 && span + ln > dbi::kStepSpan) break;
+                    span += ln;
+                    ++n;
+                }
+                return n;
+            };
+            for (int t0 = 0; t0 < n_tok;) {
+                const int lanes = step_count(t0);
+                long my[64];
+                int len[64], dist[64];
+                bool is_match[64];
+                long end = pos;
+                for (int l = 0; l < lanes; ++l) {
+                    const uint32_t t = tokens[t0 + l];
+                    is_match[l] = (t & dbi::kMatchFlag) != 0;
+                    len[l] = is_match[l] ? (int)(t & 0x1FF) : 1;
+                    dist[l] = (int)((t >> 9) & 0x7FFF) + 1;
+                    my[l] = end;
+                    end += len[l];
+                }
+                ++g_k2p_steps;
+                if (lanes < dbi::kStepTokens && t0 + lanes < n_tok) ++g_k2p_short_steps;
+                auto pre_value = [&](int l) { return dist[l] < len[l] ? dbi::k2_pattern8(pv[l], dist[l]) : pv[l]; };
+                for (int l = 0; l < lanes; ++l) {
+                    if (!is_match[l]) put(my[l], (uint8_t)tokens[t0 + l]);
+                    else if (pre[l]) store_short(my[l], len[l], pre_value(l));
+                }
+                bool waiting[64];
+                for (int l = 0; l < lanes; ++l) {
+                    waiting[l] = is_match[l] && !pre[l];
+                    if (waiting[l]) ++g_k2p_late;
+                }
+                for (;;) {
+                    bool any = false;
+                    for (int l = 0; l < lanes; ++l) any = any || waiting[l];
+                    if (!any) break;
+                    ++g_k2p_rounds;
+                    bool go[64];
+                    int longest = 0;
+                    for (int l = 0; l < lanes; ++l) {
+                        const long src = my[l] - dist[l], reach = src + std::min(len[l], dist[l]);
+                        bool blocked = false;
+                        for (int w = 0; w < lanes; ++w)
+                            blocked = blocked || (waiting[w] && dbi::k2_blocks((int)my[w], (int)my[w] + len[w],
+                                                                                (int)src, (int)reach));
+                        go[l] = waiting[l] && !blocked;
+                        if (go[l]) longest = std::max(longest, len[l]);
+                    }
+                    if (longest == 0) {
+                        std::fprintf(stderr, "case %u: a round of the second form lets nobody go\n", c);
+                        return 4;
+                    }
+                    // first turn: every lane's read, then every lane's stores
+                    uint64_t v[64];
+                    for (int l = 0; l < lanes; ++l)
+                        if (go[l]) {
+                            const long src = my[l] - dist[l];
+                            v[l] = read8(src, dbi::k2_in_ring((int)src, (int)end));
+                            if (dist[l] < 8 && dist[l] < len[l]) v[l] = dbi::k2_pattern8(v[l], dist[l]);
+                        }
+                    for (int l = 0; l < lanes; ++l)
+                        if (go[l]) store_short(my[l], std::min(len[l], 8), v[l]);
+                    for (int k = 8; k < longest; k += 4) {
+                        uint8_t b[64][4];
+                        for (int l = 0; l < lanes; ++l)
+                            if (go[l] && k < len[l]) {
+                                const long src = my[l] - dist[l];
+                                const bool near = dbi::k2_in_ring((int)src, (int)end);
+                                for (int j = 0; j < 4; ++j) {
+                                    const long q = src + (k + j) % dist[l];
+                                    b[l][j] = near ? ring_byte(q, j) : out_byte(q, j);
+                                }
+                            }
+                        for (int l = 0; l < lanes; ++l)
+                            if (go[l] && k < len[l])
+                                for (int j = 0; j < 4 && k + j < len[l]; ++j) put(my[l] + k + j, b[l][j]);
+                    }
+                    for (int l = 0; l < lanes; ++l) waiting[l] = waiting[l] && !go[l];
+                }
+                pos = end;
+                t0 += lanes;
+                // the boundary: the next step's pre matches read their source, then the ring's
+                // whole 256-byte pieces leave
+                {
+                    const int lanes_n = step_count(t0);
+                    long my_n = pos;
+                    for (int l = 0; l < 64; ++l) pre[l] = false;
+                    for (int l = 0; l < lanes_n; ++l) {
+                        const uint32_t t = tokens[t0 + l];
+                        const bool m = (t & dbi::kMatchFlag) != 0;
+                        const int ln = m ? (int)(t & 0x1FF) : 1, d = (int)((t >> 9) & 0x7FFF) + 1;
+                        const long src = my_n - d;
+                        pre[l] = dbi::k2_pre(m, ln, (int)(src + std::min(ln, d)), (int)pos);
+                        if (pre[l]) {
+                            pv[l] = read8(src, dbi::k2_in_ring((int)src, (int)pos));
+                            ++g_k2p_pre;
+                            if (!dbi::k2_in_ring((int)src, (int)pos)) ++g_k2p_far;
+                        }
+                        my_n += ln;
+                    }
+                }
+                while (pos - flushed >= 256) {
+                    for (int k = 0; k < 256; ++k) model.push_back(ring_byte(flushed + k, k));
+                    flushed += 256;
+                }
+            }
+            for (long k = flushed; k < pos; ++k) model.push_back(ring_byte(k, 0));
+            if (model != bytes) {
+                std::fprintf(stderr, "case %u: the second resolve kernel's schedule gives other bytes "
+                                     "than the tokens in order\n", c);
                 return 4;
             }
         }
