@@ -175,6 +175,17 @@ def test_decoder_core_matches_zlib_on_valid_streams(tmp_path):
 
 
 @needs_harness
+def test_resolve_schedules_on_patchwork_streams(tmp_path):
+    """The harness's models of both forms of kernel 2 (which copy of a byte every read sees) on
+    streams built for them: the tokens resolved as the kernels schedule them give zlib's bytes."""
+    cases = patchwork_cases()
+    results = run_harness([(stream, cap) for stream, cap, _ in cases], tmp_path)
+    for k, ((stream, cap, want), (status, ended, adler_ok, n_tokens, got)) in enumerate(zip(cases, results)):
+        assert status == 0, (k, status)
+        assert got == want, k
+
+
+@needs_harness
 def test_decoder_core_rejects_what_zlib_rejects(tmp_path):
     """Damaged streams: where zlib reports an error (bad header, bad block, bad codes, truncation,
     checksum) the decoder reports one too and hands out nothing; where zlib still decodes - a
@@ -199,6 +210,50 @@ def test_decoder_core_rejects_what_zlib_rejects(tmp_path):
     assert rejected > 300 and accepted >= 1
 
 
+def patchwork_cases(n=120, seed=23):
+    """Streams made to exercise kernel 2's second form (dbh_inflate_core.h, "Phase 2's second
+    form"): random bytes, copies of earlier stretches from 1 byte to the whole window back (short
+    and long, so that sources lie in the step itself, in the 8 KiB ring, or in the flushed output),
+    runs with periods 1-7 (matches that overlap themselves), zeros; at several levels, strategies
+    and window sizes, some cut short by `wanted`."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        size = int(rng.integers(200, 120000))
+        data = bytearray()
+        while len(data) < size:
+            kind = int(rng.integers(0, 6))
+            if kind == 0 or not data:
+                data += rng.integers(0, 256, int(rng.integers(1, 60)), dtype=np.uint8).tobytes()
+            elif kind == 1:                                    # a copy from anywhere in the window
+                d = int(rng.integers(1, min(len(data), 32768) + 1))
+                ln = int(rng.integers(3, 12)) if rng.random() < 0.8 else int(rng.integers(12, 1200))
+                for _ in range(ln):
+                    data.append(data[-d])
+            elif kind == 2:                                    # a near copy (inside a step)
+                d = int(rng.integers(1, min(len(data), 300) + 1))
+                for _ in range(int(rng.integers(3, 9))):
+                    data.append(data[-d])
+            elif kind == 3:                                    # a short period, repeated
+                period = rng.integers(0, 256, int(rng.integers(1, 8)), dtype=np.uint8).tobytes()
+                data += period * int(rng.integers(2, 80))
+            elif kind == 4:
+                data += bytes(int(rng.integers(1, 700)))
+            else:                                              # squiggle-like: high byte repeats
+                m = int(rng.integers(4, 400))
+                data += squiggle(rng, m)
+        data = bytes(data[:size])
+        level = (1, 1, 6, 9)[k % 4]
+        strategy = (zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE,
+                    zlib.Z_FIXED)[k % 5]
+        wbits = (15, 15, 15, 13, 9)[(k // 3) % 5]
+        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+        stream = c.compress(data) + c.flush()
+        cap = len(data) if k % 7 else int(rng.integers(1, len(data) + 1))
+        cases.append((stream, cap, data[:cap]))
+    return cases
+
+
 # ---- the kernels themselves ---------------------------------------------------------------------
 def pack_streams(hip, cases):
     """[(stream bytes, wanted bytes, mode)] -> (comp buffer, stream records, output size, where
@@ -214,11 +269,14 @@ def pack_streams(hip, cases):
     return np.frombuffer(bytes(comp) if comp else b'\0', dtype=np.uint8), records, out_at, places
 
 
-@pytest.fixture(params=['lane', 'wave'])
+@pytest.fixture(params=['lane+pre', 'wave+pre', 'wave+rounds'])
 def kernel1(request, monkeypatch):
-    """Both forms of kernel 1 - one lane per stream, one wavefront per stream (dbh_inflate.hip) -
-    whichever of them is the default."""
-    monkeypatch.setenv('DEEPBINNER_INFLATE_KERNEL', request.param)
+    """Both forms of kernel 1 - one lane per stream, one wavefront per stream - and both forms of
+    kernel 2 - short matches read at the step boundary, every match through the rounds
+    (dbh_inflate.hip) - whichever of them are the defaults."""
+    one, two = request.param.split('+')
+    monkeypatch.setenv('DEEPBINNER_INFLATE_KERNEL', one)
+    monkeypatch.setenv('DEEPBINNER_INFLATE_RESOLVE', two)
     return request.param
 
 
@@ -244,6 +302,19 @@ def test_gpu_inflate_matches_zlib(hip, kernel1):
             got = out[at:at + cap].tobytes()
             assert got == w + bytes(cap - len(w)), (per_lane, k, len(w), cap)     # zero-extended
         assert ms > 0
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_patchwork_streams(hip, kernel1):
+    """Streams built for kernel 2's second form (sources in the step, in the ring, in the flushed
+    output; self-overlapping, long and cut matches): every byte as zlib gives it."""
+    cases = patchwork_cases()
+    comp, records, out_bytes, places = pack_streams(
+        hip, [(stream, cap, hip.INFLATE_ZLIB) for stream, cap, _ in cases])
+    out, status, _ = hip.inflate(comp, records, out_bytes)
+    assert (status == 0).all(), np.nonzero(status)[0][:10]
+    for k, ((at, cap), (_, _, want)) in enumerate(zip(places, cases)):
+        assert out[at:at + cap].tobytes() == want, k
 
 
 @pytest.mark.gpu
