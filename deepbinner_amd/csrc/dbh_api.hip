@@ -12,6 +12,7 @@
 #include <string>
 #include <thread>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 #include "../../include/deepbinner_hip.h"
@@ -210,6 +211,7 @@ struct dbh_model {
     // buffers of dbh_classify_pair_deflated (the start model's, or the only model's, are used)
     struct Deflated {
         hipStream_t stream = nullptr;
+        hipEvent_t inflated = nullptr, classified = nullptr;    // hand-over to the forward stream
         void* h_small = nullptr;  size_t h_small_bytes = 0;     // pinned: records, offsets, results
         void* h_comp = nullptr;   size_t h_comp_bytes = 0;      // pinned staging for pageable input
         void* d_comp = nullptr;   size_t d_comp_bytes = 0;
@@ -598,6 +600,8 @@ int dbh_model_destroy(dbh_model* m) {
     {
         dbh_model::Deflated& d = m->deflated;
         if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.inflated) (void)hipEventDestroy(d.inflated);
+        if (d.classified) (void)hipEventDestroy(d.classified);
         if (d.h_small) (void)hipHostFree(d.h_small);
         if (d.h_comp) (void)hipHostFree(d.h_comp);
         for (void* p : {d.d_comp, d.d_small, d.d_samples, d.d_tokens, d.d_out, d.d_work, d.d_tail})
@@ -1090,6 +1094,26 @@ int dbh_classify_pair_i16(dbh_model* start_model, dbh_model* end_model,
     return st;
 }
 
+namespace {
+// THE FORWARD STREAM of a device: every queue's forward launches (and the small kernels between
+// them) go through this one stream, in the order the queues arrive, so that at most one forward
+// kernel is on the GPU at a time.  The forward kernel is persistent - one workgroup per CU for as
+// long as the launch lasts: with every queue launching on its own stream two or three of them
+// share the CUs, each stretched, the small kernels behind them (merge, combine, the next
+// container's fill) wait for whichever ends last, and the queues fall into step: all inflating,
+// then all classifying (profiles/r05_k2/steady_state_trace_share0.txt: 16 of every 68 ms with no
+// forward kernel on the GPU).  One at a time on 256 - n CUs (dbh_model_reserve_cus), the inflate
+// kernels of the containers behind keep the other n CUs busy all the time.
+// DEEPBINNER_FORWARD_STREAM=own: every queue on its own stream again (A/B).
+constexpr int kMaxDevices = 64;
+std::mutex g_forward_mutex[kMaxDevices];
+hipStream_t g_forward_stream[kMaxDevices] = {};
+bool shared_forward_stream() {
+    const char* v = std::getenv("DEEPBINNER_FORWARD_STREAM");
+    return !(v && std::strcmp(v, "own") == 0);
+}
+}  // namespace
+
 int dbh_classify_pair_deflated(dbh_model* start_model, dbh_model* end_model,
                                const uint8_t* comp_host, int64_t comp_bytes,
                                const dbh_inflate_stream* streams_host, int64_t n_streams,
@@ -1240,18 +1264,48 @@ int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_mo
     }
     if (ev[2]) (void)hipEventRecord(ev[2], d.stream);
     dbh_model* models[2] = {start_model, end_model};
-    for (int j = 0; j < 2; ++j) {
-        if (!models[j]) continue;
-        st = classify_i16_dev(models[j], (const int16_t*)d.d_samples, d_offsets, n_reads,
-                              j == 0 ? DBH_SIDE_START : DBH_SIDE_END, scan_size, score_diff,
-                              (float*)((char*)d.d_out + (size_t)j * probs_bytes), d_side[j],
-                              d.d_work, (dbh_stream)d.stream, 0, 0, 0, &d.d_tail, &d.d_tail_bytes);
-        if (st != DBH_OK) return done(st);
-    }
     const int32_t* d_calls = both ? d_final : d_side[start_model ? 0 : 1];
-    if (both) {
-        st = dbh_combine_calls_dev(d_side[0], d_side[1], n_reads, combine_mode, d_final,
-                                   (dbh_stream)d.stream);
+    {
+        // both models' launches and combine_calls: on the device's forward stream, as one block
+        const bool shared = shared_forward_stream() && m->device >= 0 && m->device < kMaxDevices;
+        std::unique_lock<std::mutex> block;
+        hipStream_t on = d.stream;
+        if (shared) {
+            if (!d.inflated) DBH_HIP(hipEventCreateWithFlags(&d.inflated, hipEventDisableTiming));
+            if (!d.classified) DBH_HIP(hipEventCreateWithFlags(&d.classified, hipEventDisableTiming));
+            block = std::unique_lock<std::mutex>(g_forward_mutex[m->device]);
+            hipStream_t& fs = g_forward_stream[m->device];
+            if (!fs) {
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                e = hipStreamCreateWithPriority(&fs, hipStreamNonBlocking, greatest);
+                if (e != hipSuccess) return done(hip_fail(e, "hipStreamCreateWithPriority"));
+            }
+            on = fs;
+            e = hipEventRecord(d.inflated, d.stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(on, d.inflated, 0);
+            if (e != hipSuccess) return done(hip_fail(e, "handing over to the forward stream"));
+        }
+        for (int j = 0; j < 2; ++j) {
+            if (!models[j]) continue;
+            st = classify_i16_dev(models[j], (const int16_t*)d.d_samples, d_offsets, n_reads,
+                                  j == 0 ? DBH_SIDE_START : DBH_SIDE_END, scan_size, score_diff,
+                                  (float*)((char*)d.d_out + (size_t)j * probs_bytes), d_side[j],
+                                  d.d_work, (dbh_stream)on, 0, 0, 0, &d.d_tail, &d.d_tail_bytes);
+            if (st != DBH_OK) break;
+        }
+        if (st == DBH_OK && both)
+            st = dbh_combine_calls_dev(d_side[0], d_side[1], n_reads, combine_mode, d_final,
+                                       (dbh_stream)on);
+        if (shared) {
+            // (whatever was launched must be waited for, also behind an error)
+            e = hipEventRecord(d.classified, on);
+            if (e == hipSuccess) e = hipStreamWaitEvent(d.stream, d.classified, 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(on);
+                return done(hip_fail(e, "taking over from the forward stream"));
+            }
+        }
         if (st != DBH_OK) return done(st);
     }
     if (ev[3]) (void)hipEventRecord(ev[3], d.stream);

@@ -30,6 +30,9 @@ def main():
     ap.add_argument('--cus', type=int, default=32, help='CUs left out of the forward launches')
     ap.add_argument('--threads', type=int, default=0)
     ap.add_argument('--repeat', type=int, default=2)
+    ap.add_argument('--loops', type=int, default=1,
+                    help='stream the containers this many times per pass (filling and draining the '
+                         'pipeline costs ~50 ms a pass: a sixth of a pass of 16 containers)')
     opts = ap.parse_args()
     if opts.write:
         import subprocess
@@ -47,7 +50,7 @@ def main():
                 multi_read_rate.write_with_own_writer(p, opts.reads, 27000, 100 + k)
         return
     from deepbinner_amd import classify, fast5_native, hip_backend
-    paths = sorted(glob.glob(os.path.join(opts.dir, '*.fast5')))
+    paths = sorted(glob.glob(os.path.join(opts.dir, '*.fast5'))) * max(1, opts.loops)
     team = opts.threads or min(16, classify.usable_cpus())
     import io
     models = os.path.join(REPO, 'deepbinner_amd', 'models')
@@ -77,7 +80,8 @@ def main():
         if done / wall > best:
             best, best_cpu = done / wall, cpu / done
     print(json.dumps({'host_share_per_cent': opts.share, 'queues': len(replicas),
-                      'cus_left_to_inflate': opts.cus, 'loader_threads': team,
+                      'cus_left_to_inflate': opts.cus, 'containers_per_pass': len(paths),
+                      'forward_stream': os.environ.get('DEEPBINNER_FORWARD_STREAM', 'shared'), 'loader_threads': team,
                       'reads_per_s': round(best), 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}))
 
 
