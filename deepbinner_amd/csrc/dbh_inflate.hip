@@ -24,16 +24,23 @@
 //      deflated with the same settings reach their block boundaries (every 16,383 symbols with
 //      zlib's defaults) on the same step, so the code builds line up; a lane that is done takes
 //      its next stream off a counter there.
-//   2. inflate_resolve_kernel - ONE WAVE PER STREAM with the 32 KiB window as a ring in LDS, five
-//      per CU.  64 tokens per step: a wave-wide prefix sum of the token lengths gives every token
-//      its output position; literals are stored at once; matches copy from the ring as soon as
-//      everything they read has been written (a match of one step may read what another match of
-//      the same step writes: the lanes go in rounds, the first waiting match deciding who may
-//      go; a step in which a far-reaching match could be overtaken by a write that wraps around
-//      the ring goes in token order instead: dbh_inflate_core.h, ring_hazard).  The ring is written
-//      out in coalesced 256-byte pieces, with the Adler-32 sums on the way.
+//   2. tokens -> bytes, ONE WAVE PER STREAM, up to 64 tokens per step: a wave-wide prefix sum of
+//      the token lengths gives every token its output position.  Two forms, same bytes:
+//      inflate_resolve_pre_kernel (what runs; described in front of it) - an 8 KiB ring in LDS
+//      and the stream's own flushed output behind it, twenty streams per CU; the short matches
+//      whose source is complete before their step (four fifths of all) read it at the step
+//      boundary and are stored with the literals, the others go in rounds by the exact rule:
+//      0.84 ms per 4,000 x 54 KB streams;
+//      inflate_resolve_kernel (DEEPBINNER_INFLATE_RESOLVE=rounds; rounds 3-5) - the whole 32 KiB
+//      window as a ring in LDS, five streams per CU; literals are stored at once, every match
+//      copies from the ring as soon as everything it reads has been written (the lanes go in
+//      rounds, the first waiting match deciding who may go; a step in which a far-reaching match
+//      could be overtaken by a write that wraps around the ring goes in token order instead:
+//      dbh_inflate_core.h, ring_hazard): 3.04 ms.
+//      The ring is written out in coalesced 256-byte pieces, with the Adler-32 sums on the way.
 // HBM traffic per read (55 KB of samples, ~22 k tokens): 35 KB compressed in, 88 KB of tokens out
-// and in again, 55 KB of samples out - latency, not bandwidth, is what both kernels wait for.
+// and in again, 55 KB of samples out - latency and instruction issue, not bandwidth, are what
+// both kernels are bound by.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

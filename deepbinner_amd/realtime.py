@@ -38,7 +38,9 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 # The streaming path with the GPU inflating: what it was measured with on an MI355X box (16
 # usable cores, one GPU; profiles/r03_gpu_inflate_split.txt, profiles/r05_multi_read_rate.json) -
 # three containers in flight per GPU, each on its own queue (model replica), whatever share of
-# the inflating the GPU takes.  No CUs are left out of the forward
+# the inflating the GPU takes (two leave the GPU idle while a container is uploaded, four and more
+# only add inflate kernels that compete with the one forward kernel the device runs at a time:
+# dbh_api.hip, "THE FORWARD STREAM"; profiles/r05_k2/forward_stream_sweep_16_containers.txt).  No CUs are left out of the forward
 # kernel's launches for the inflate kernels: its workgroups take their windows off a counter, and
 # one that finds its CU taken simply takes fewer (while they walked fixed shares, 32 were).
 INFLATE_QUEUES = 3

@@ -221,7 +221,11 @@ int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size
  * lane: one LANE per stream; 0 = 1): its lanes take streams off a counter - with one stream per
  * lane a launch is as wide as the streams are many and lasts as long as the longest of them; with
  * n, a launch 1/n as wide does the same work, and lasts no longer if the long streams come first
- * in the records and are long enough. */
+ * in the records and are long enough.
+ * Kernel 2 (tokens -> bytes) reads the output buffer it writes (a match whose source lies more
+ * than 8 KiB back is copied from the stream's own flushed output): out_dev must not be mapped
+ * write-combined or read-protected.  DEEPBINNER_INFLATE_RESOLVE=rounds selects its older form
+ * (the whole 32 KiB window in LDS). */
 int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
                     const dbh_inflate_stream* streams_dev, int64_t n_streams,
                     int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,
@@ -238,6 +242,11 @@ int dbh_inflate(const uint8_t* comp_host, size_t comp_bytes, const dbh_inflate_s
  * + 1, in samples, starting at 0): where each read's signal lies once decoded; the streams'
  * out_offset / out_bytes address the same buffer in bytes.  comp_host must be readable for 64
  * bytes beyond comp_bytes (a pageable buffer is copied and padded, so it need not be).
+ * Calls from several threads (one model pair each: the queues of the streaming path) share the
+ * device: the inflating of one runs beside the classification of another, but the forward
+ * launches of all of them go through ONE stream per device, one launch at a time - the forward
+ * kernel is persistent, and two of them on one GPU only stretch each other and everything queued
+ * behind them (DEEPBINNER_FORWARD_STREAM=own: each call on its own stream, for comparison).
  * stream_status_host (n_streams, may be NULL): the decoder's verdict per stream - a read one of
  * whose streams failed was classified on zeros; the caller decodes it on the host and asks
  * again.  samples_host (may be NULL): the decoded signals, all of them (realtime's binning).
