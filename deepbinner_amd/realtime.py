@@ -40,8 +40,8 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 # three containers in flight per GPU, each on its own queue (model replica), whatever share of
 # the inflating the GPU takes (two leave the GPU idle while a container is uploaded, four and more
 # only add inflate kernels that compete with the one forward kernel the device runs at a time:
-# dbh_api.hip, "THE FORWARD STREAM"; profiles/r05_k2/forward_stream_sweep_16_containers.txt).  No CUs are left out of the forward
-# kernel's launches for the inflate kernels: its workgroups take their windows off a counter, and
+# dbh_api.hip, "THE FORWARD STREAM"; profiles/r05_k2/forward_stream_sweep_16_containers.txt).
+# No CUs are left out of the forward kernel's launches for the inflate kernels: its workgroups take their windows off a counter, and
 # one that finds its CU taken simply takes fewer (while they walked fixed shares, 32 were).
 INFLATE_QUEUES = 3
 INFLATE_CUS = 0
@@ -55,12 +55,12 @@ def host_inflate_share(n_gpus):
 
     Left alone: what the host's cores can do beside their other work while a GPU classifies at
     the rate it reaches with the inflate kernels running beside the forward kernel.  Measured
-    (profiles/r05_multi_read_rate.json; 27 k-sample reads, gzip 1, 16 loader threads, kernel 1
-    one wavefront per stream): the host spends ~21 us per read on everything but inflating and
-    ~1.0 us more per per cent of the bytes it inflates; a GPU with three containers in flight
-    settles at ~180 k reads/s for any share between 40 and 60 (146 k with no help at all) - so
-    the host takes what four fifths of its cores manage at that rate (16 cores, one GPU: 50 %;
-    24 cores per GPU and more: everything, and the inflate kernels are not used at all; a
+    (profiles/r05_k2/forward_stream_sweep_64_containers.txt; 27 k-sample reads, gzip 1, 16 loader
+    threads, three containers in flight, one forward launch at a time): the host spends ~18 us per
+    read on everything but inflating and ~1.0 us more per per cent of the bytes it inflates; a GPU
+    settles at 203-207 k reads/s for any share between 20 and 50, and at 195 k with no help at all
+    - so the host takes what four fifths of its cores manage at 200 k reads/s (16 cores, one GPU:
+    46 %; 30 cores per GPU and more: everything, and the inflate kernels are not used at all; a
     16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing: there the GPUs
     inflate every stream)."""
     flag = os.environ.get('DEEPBINNER_GPU_INFLATE')
@@ -72,8 +72,8 @@ def host_inflate_share(n_gpus):
     if explicit:
         return max(0, min(100, int(explicit)))
     cores, gpus = float(usable_cpus()), float(max(n_gpus, 1))
-    budget_us = 0.8 * cores / gpus / 180e3 * 1e6           # host time per read at the GPU's rate
-    return int(round(max(0.0, min(100.0, (budget_us - 21.0) / 1.0))))
+    budget_us = 0.8 * cores / gpus / 200e3 * 1e6           # host time per read at the GPU's rate
+    return int(round(max(0.0, min(100.0, (budget_us - 18.0) / 1.0))))
 
 
 def queue_clones(pair, n_more):
