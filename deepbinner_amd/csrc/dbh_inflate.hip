@@ -329,6 +329,7 @@ struct WaveLds {
     uint32_t stage[dbi::kStageDwords];
     uint32_t ring[dbi::kRingStore], lit_pair[16], dist_pair[16];
     uint16_t lit_sym[dbi::kLitSyms], cnt[16];
+    uint16_t wave_lit_tab[dbi::kWaveLitEntries], wave_dist_tab[dbi::kWaveDistEntries];
     uint8_t dist_sym[dbi::kDistSyms], lens[dbi::kMaxLens];
 };
 struct WaveMem {
@@ -338,6 +339,8 @@ struct WaveMem {
     __device__ __forceinline__ void set_lit_tab(int, uint32_t) {}
     __device__ __forceinline__ uint32_t dist_tab(int) const { return 0u; }
     __device__ __forceinline__ void set_dist_tab(int, uint32_t) {}
+    __device__ __forceinline__ uint32_t wave_lit_tab(int i) const { return m->wave_lit_tab[i]; }
+    __device__ __forceinline__ uint32_t wave_dist_tab(int i) const { return m->wave_dist_tab[i]; }
     __device__ __forceinline__ uint32_t ring(int r) const { return m->ring[r]; }
     __device__ __forceinline__ void set_ring(int r, uint32_t v) { m->ring[r] = v; }
     __device__ __forceinline__ int len(int i) const { return m->lens[i]; }
@@ -397,6 +400,15 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
                 B.lim_dist[l] = uni(L.lim_dist[l]);
             }
             __syncthreads();                             // (the tables lane 0 wrote: for all lanes)
+            if (kWaveTables && uni(L.state) == kDecode) {
+                // the first-level tables of this block's two codes: every lane its share of the
+                // indices, decoded the canonical way (dbh_inflate_wave.h)
+                for (int k = lane; k < kWaveLitEntries; k += kWaveLanes)
+                    lds.wave_lit_tab[k] = (uint16_t)wave_lit_entry((uint32_t)k, B.lim_lit, mem);
+                for (int k = lane; k < kWaveDistEntries; k += kWaveLanes)
+                    lds.wave_dist_tab[k] = (uint16_t)wave_dist_entry((uint32_t)k, B.lim_dist, mem);
+                __syncthreads();
+            }
             continue;
         }
         if (state == kStored) {

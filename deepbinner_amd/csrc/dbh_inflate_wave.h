@@ -98,6 +98,108 @@ DBI_HD Tok token_decode(uint32_t lo, uint32_t hi, const uint32_t (&lim_lit)[15],
     return t;
 }
 
+// FIRST-LEVEL DECODE TABLES for the one-wavefront-per-stream form (the second session of round 5).
+// The canonical decode above is ~60 vector instructions and two dependent LDS reads per code,
+// twice per token; a table indexed by the next kWaveLitBits / kWaveDistBits bits of the stream
+// answers in one read - {code length, meaning} - whenever the code is no longer than the index.
+// With one LANE per stream the tables did not pay (dbh_inflate_core.h: 64 copies of them fill a
+// CU's LDS, and one lane with a longer code sends its whole wave the canonical way); here a wave
+// has ONE pair of tables, 4.5 KB, and its lanes fill them together behind every block header:
+// lane l decodes indices l, l + 64, .. the canonical way - no serial code at all.  A lane whose
+// code is longer than the index (kWaveLitBits = 11: about one token in 300 of a level-1 squiggle
+// stream) decodes canonically, the others wait for it: the same tokens either way, and the CPU
+// harness holds every table answer against the canonical one.
+#ifndef DBI_WAVE_LIT_BITS
+#define DBI_WAVE_LIT_BITS 11
+#endif
+#ifndef DBI_WAVE_DIST_BITS
+#define DBI_WAVE_DIST_BITS 8
+#endif
+constexpr int kWaveLitBits = DBI_WAVE_LIT_BITS, kWaveDistBits = DBI_WAVE_DIST_BITS;
+constexpr bool kWaveTables = DBI_WAVE_LIT_BITS > 0;
+static_assert(kWaveLitBits <= 15 && kWaveDistBits >= 1 && kWaveDistBits <= 15, "");
+constexpr int kWaveLitEntries = kWaveTables ? 1 << kWaveLitBits : 1;
+constexpr int kWaveDistEntries = kWaveTables ? 1 << kWaveDistBits : 1;
+
+// the entry of the literal/length table for the index k (the stream's next bits, lowest first):
+// lit_tab_entry's format (dbh_inflate_core.h), 0 = the code that begins so is longer than the index
+// (or does not exist: the canonical decoder refuses it)
+template <class Mem>
+DBI_HD uint32_t wave_lit_entry(uint32_t k, const uint32_t (&lim_lit)[15], const Mem& mem) {
+    const uint32_t c1 = first16(k);
+    const uint32_t n1 = code_length<15>(c1, lim_lit);
+    if (n1 > (uint32_t)kWaveLitBits) return 0u;
+    const uint32_t i1 = umin(sorted_index(c1, n1, mem.lit_pair((int)n1)), (uint32_t)(kLitSyms - 1));
+    const uint32_t e = mem.lit_sym((int)i1);
+    uint32_t t;
+    if (e & kEntryLength) t = 0x8000u | (((e >> 8) & 7u) << 4) | ((e & 0xFFu) << 7);
+    else if (e & kEntryEnd) t = 0x8000u | (7u << 4);
+    else if (e & kEntryBad) t = 0x8000u | (6u << 4);
+    else t = (e & 0xFFu) << 7;
+    return t | n1;
+}
+template <class Mem>
+DBI_HD uint32_t wave_dist_entry(uint32_t k, const uint32_t (&lim_dist)[15], const Mem& mem) {
+    const uint32_t c2 = first16(k);
+    const uint32_t n2 = code_length<15>(c2, lim_dist);
+    if (n2 > (uint32_t)kWaveDistBits) return 0u;
+    const uint32_t i2 = umin(sorted_index(c2, n2, mem.dist_pair((int)n2)), (uint32_t)(kDistSyms - 1));
+    return dist_tab_entry((int)mem.dist_sym((int)i2), (int)n2);
+}
+
+// One token through the tables (the arithmetic of lane_decode_fast, without a lane's state).
+// Returns false where a code has no entry: `t` is then not to be used.
+template <class Mem>
+DBI_HD bool token_decode_tables(uint32_t lo, uint32_t hi, const Mem& mem, Tok& t) {
+    const uint32_t e = mem.wave_lit_tab((int)(lo & (uint32_t)(kWaveLitEntries - 1)));
+    const uint32_t l1 = e & 15u;
+    const uint32_t not_lit = bit_mask(e, 15);
+    const uint32_t ebf = (e >> 4) & 7u;                        // 6: a bad symbol, 7: end of block
+    const uint32_t is_len = not_lit & (uint32_t)((int32_t)(ebf - 6u) >> 31);       // ebf < 6
+    const uint32_t eb = ebf & is_len;
+    const uint32_t val = (e >> 7) & 0xFFu;
+    uint64_t w = (((uint64_t)hi << 32) | lo) >> l1;
+    // a literal: 1; end of block (or a bad symbol, refused below): 0
+    t.length = pick(is_len, 3u + val + low_bits((uint32_t)w, eb), (~not_lit) & 1u);
+    w >>= eb;
+    const uint32_t e2 = mem.wave_dist_tab((int)((uint32_t)w & (uint32_t)(kWaveDistEntries - 1)));
+    const uint32_t l2 = e2 & 15u;
+    const uint32_t d = e2 >> 4;
+    const uint32_t half = d >> 1;
+    const uint32_t db = (half > 1u ? half : 1u) - 1u;
+    const uint32_t small = (uint32_t)((int32_t)(d - 4u) >> 31);          // d < 4
+    const uint32_t dbase = pick(small, d + 1u, 1u + ((2u | (d & 1u)) << db));
+    t.distance = dbase + low_bits((uint32_t)(w >> l2), db);
+    t.bad = (not_lit != 0u && ebf == 6u) || (is_len != 0u && d > 29u);
+    t.used = l1 + eb + ((l2 + db) & is_len);
+    t.is_len = is_len;
+    t.lit = val;
+    t.is_end = not_lit != 0u && ebf == 7u;
+    return l1 != 0u && (is_len == 0u || l2 != 0u);
+}
+
+// the token that begins with the 64 bits (lo, hi): through the tables where they answer
+template <class Mem>
+DBI_HD Tok token_of(uint32_t lo, uint32_t hi, const uint32_t (&lim_lit)[15],
+                    const uint32_t (&lim_dist)[15], const Mem& mem) {
+    Tok t;
+    const bool answered = kWaveTables && token_decode_tables(lo, hi, mem, t);
+#if defined(DBI_CHECK_TABLES)
+    dbi_wave_table_answer(answered);
+    if (answered) {      // (CPU harness: a table answer must be the canonical one)
+        const Tok c = token_decode(lo, hi, lim_lit, lim_dist, mem);
+        // (a refused token's other fields are never looked at; a literal's distance neither)
+        if (c.bad != t.bad || (!c.bad && (c.used != t.used || c.length != t.length ||
+                                          (c.is_len != 0u) != (t.is_len != 0u) || c.is_end != t.is_end ||
+                                          (c.is_len != 0u && c.distance != t.distance) ||
+                                          (c.is_len == 0u && !c.is_end && c.lit != t.lit))))
+            dbi_table_mismatch();
+    }
+#endif
+    if (!answered) t = token_decode(lo, hi, lim_lit, lim_dist, mem);
+    return t;
+}
+
 // the 64 bits at bit x of the staged chunk
 template <class Mem>
 DBI_HD void stage_window(const Mem& mem, uint32_t x, uint32_t& lo, uint32_t& hi) {
@@ -138,7 +240,7 @@ DBI_HD SubResult sub_decode(const WaveBlock& B, const Mem& mem, uint32_t x, uint
     while (x < stop) {
         uint32_t lo, hi;
         stage_window(mem, x, lo, hi);
-        const Tok t = token_decode(lo, hi, B.lim_lit, B.lim_dist, mem);
+        const Tok t = token_of(lo, hi, B.lim_lit, B.lim_dist, mem);
         if (t.bad) {
             r.flag = kSubBad;
             break;
@@ -173,7 +275,7 @@ DBI_HD SubResult sub_emit(const WaveBlock& B, const Mem& mem, uint32_t x, uint32
     while (x < stop) {
         uint32_t lo, hi;
         stage_window(mem, x, lo, hi);
-        const Tok t = token_decode(lo, hi, B.lim_lit, B.lim_dist, mem);
+        const Tok t = token_of(lo, hi, B.lim_lit, B.lim_dist, mem);
         if (t.bad) {
             r.flag = kSubBad;
             break;

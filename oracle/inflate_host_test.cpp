@@ -21,6 +21,8 @@
 static void dbi_table_mismatch();
 static long g_answers[2];
 static void dbi_table_answer(bool fast) { ++g_answers[fast ? 1 : 0]; }
+static long g_wave_answers[2];
+static void dbi_wave_table_answer(bool fast) { ++g_wave_answers[fast ? 1 : 0]; }
 #include "../deepbinner_amd/csrc/dbh_inflate_core.h"
 #include "../deepbinner_amd/csrc/dbh_inflate_wave.h"
 static void dbi_table_mismatch() {
@@ -34,6 +36,9 @@ struct HostMem {
     uint8_t dist_sym_[dbi::kDistSyms], lens_[dbi::kMaxLens];
     uint16_t lit_tab_[1 << dbi::kLitBits], dist_tab_[1 << dbi::kDistBits];
     uint32_t stage_[dbi::kStageDwords];      // (the one-wave-per-stream decoder's chunk)
+    uint16_t wave_lit_tab_[dbi::kWaveLitEntries], wave_dist_tab_[dbi::kWaveDistEntries];   // (its tables)
+    uint32_t wave_lit_tab(int i) const { return wave_lit_tab_[check(i, dbi::kWaveLitEntries)]; }
+    uint32_t wave_dist_tab(int i) const { return wave_dist_tab_[check(i, dbi::kWaveDistEntries)]; }
     uint32_t stage(int i) const { return stage_[check(i, dbi::kStageDwords)]; }
     void set_stage(int i, uint32_t v) { stage_[check(i, dbi::kStageDwords)] = v; }
     uint32_t lit_tab(int i) const { return lit_tab_[check(i, 1 << dbi::kLitBits)]; }
@@ -81,6 +86,13 @@ static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint
         if (++guard > 100000000L) std::abort();
         if (L.state == kNeedBlock) {
             lane_block(L, mem);
+            if (kWaveTables && L.state == kDecode) {
+                // the first-level tables, as the wave's lanes fill them behind a block header
+                for (int k = 0; k < kWaveLitEntries; ++k)
+                    mem.wave_lit_tab_[k] = (uint16_t)wave_lit_entry((uint32_t)k, L.lim_lit, mem);
+                for (int k = 0; k < kWaveDistEntries; ++k)
+                    mem.wave_dist_tab_[k] = (uint16_t)wave_dist_entry((uint32_t)k, L.lim_dist, mem);
+            }
             continue;
         }
         if (L.state == kStored) {
@@ -181,6 +193,8 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "tokens answered by the tables: %ld, sent the canonical way: %ld\n", g_answers[1], g_answers[0]);
     });
     if (std::getenv("DBI_WAVE_STATS")) std::atexit([] {
+        std::fprintf(stderr, "one wave per stream: tokens answered by the tables: %ld, sent the canonical way: %ld\n",
+                     g_wave_answers[1], g_wave_answers[0]);
         std::fprintf(stderr, "one wave per stream: %ld chunks, %.3f rounds per chunk, %.3f walks per lane and chunk, "
                              "%.1f tokens per lane and chunk\n", g_wave_chunks,
                      (double)g_wave_rounds / (double)std::max(1L, g_wave_chunks),

@@ -373,6 +373,45 @@ def test_raw_batches_decoded_on_the_gpu_are_the_loaders_samples(hip, hip_models,
     assert seen_stored > 0 and (seen_zlib > 40 or host_inflate_above == 1)
 
 
+@pytest.mark.parametrize('forward_stream', ['shared', 'own'])
+def test_queues_in_parallel_give_what_one_queue_gives(hip, hip_models, forward_stream, monkeypatch):
+    """Three queues (model replicas) on one GPU, a thread each, the same raw batches through
+    dbh_classify_pair_deflated at the same time - with every queue's forward launches going
+    through the device's ONE forward stream (what ships: dbh_api.hip) and with every queue on a
+    stream of its own: the calls of every batch are what one queue alone gives."""
+    import threading
+    from deepbinner_amd import fast5_native, realtime
+    monkeypatch.setenv('DEEPBINNER_FORWARD_STREAM', forward_stream)
+    start, end = hip_models[START], hip_models[END]
+    files = every_fixture_file()
+    batches = [b for b in fast5_native.stream_raw(files, threads=4, depth=3, host_inflate_above=0)
+               if b[1] is not None]
+    assert batches
+    alone = [hip.classify_pair_deflated(start, end, b[4], b[5], b[2], 6144, 0.5)[0] for b in batches]
+    queues = [(start, end)] + realtime.queue_clones((start, end), 2)
+    got = [[None] * len(batches) for _ in queues]
+    failed = []
+
+    def run(k):
+        try:
+            for _ in range(3):
+                for j, b in enumerate(batches):
+                    got[k][j] = hip.classify_pair_deflated(queues[k][0], queues[k][1], b[4], b[5], b[2],
+                                                           6144, 0.5)[0]
+        except Exception as e:          # noqa: BLE001 - reported below
+            failed.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(queues))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failed, failed
+    for k in range(len(queues)):
+        for j in range(len(batches)):
+            assert np.array_equal(got[k][j], alone[j]), (forward_stream, k, j)
+
+
 def test_realtime_with_and_without_gpu_inflate(hip, gold, containers, tmp_path, monkeypatch, capsys):
     """The 100,000-read stream again, inflated by the GPU (the default) and by the host's threads
     (DEEPBINNER_GPU_INFLATE=0): the same table, row for row; and a container with a damaged chunk
