@@ -25,6 +25,7 @@ def main():
     ap.add_argument('dir')
     ap.add_argument('--write', type=int, default=0, help='write this many containers and stop')
     ap.add_argument('--reads', type=int, default=4000)
+    ap.add_argument('--mean-length', type=int, default=27000, help='samples per read (log-normal, 2,000 .. 400,000)')
     ap.add_argument('--share', type=int, default=35, help='%% of the bytes the host inflates')
     ap.add_argument('--queues', type=int, default=0, help='0 = what realtime.py would take')
     ap.add_argument('--cus', type=int, default=32, help='CUs left out of the forward launches')
@@ -41,13 +42,13 @@ def main():
         paths = [os.path.join(opts.dir, 'batch_%02d.fast5' % k) for k in range(opts.write)]
         if os.path.exists(multi_read_rate.CONDA_PYTHON):
             jobs = [subprocess.Popen([multi_read_rate.CONDA_PYTHON, '-c', multi_read_rate.WRITER, p,
-                                      str(opts.reads), '27000', str(100 + k)])
+                                      str(opts.reads), str(opts.mean_length), str(100 + k)])
                     for k, p in enumerate(paths)]
             if any(j.wait() != 0 for j in jobs):
                 sys.exit('writing the containers with h5py failed')
         else:
             for k, p in enumerate(paths):
-                multi_read_rate.write_with_own_writer(p, opts.reads, 27000, 100 + k)
+                multi_read_rate.write_with_own_writer(p, opts.reads, opts.mean_length, 100 + k)
         return
     from deepbinner_amd import classify, fast5_native, hip_backend
     paths = sorted(glob.glob(os.path.join(opts.dir, '*.fast5'))) * max(1, opts.loops)
