@@ -1271,8 +1271,11 @@ int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_mo
         std::unique_lock<std::mutex> block;
         hipStream_t on = d.stream;
         if (shared) {
-            if (!d.inflated) DBH_HIP(hipEventCreateWithFlags(&d.inflated, hipEventDisableTiming));
-            if (!d.classified) DBH_HIP(hipEventCreateWithFlags(&d.classified, hipEventDisableTiming));
+            e = hipSuccess;
+            if (!d.inflated) e = hipEventCreateWithFlags(&d.inflated, hipEventDisableTiming);
+            if (e == hipSuccess && !d.classified)
+                e = hipEventCreateWithFlags(&d.classified, hipEventDisableTiming);
+            if (e != hipSuccess) return done(hip_fail(e, "hipEventCreateWithFlags"));
             block = std::unique_lock<std::mutex>(g_forward_mutex[m->device]);
             hipStream_t& fs = g_forward_stream[m->device];
             if (!fs) {
