@@ -127,8 +127,11 @@ DBI_HD bool ring_hazard(int dist, int my, int step_end) {
 //    `end` position p is in the ring if p >= end - kSmallRing, and in global memory otherwise
 //    (k2_in_ring) - no write of the step can land on a byte that is still to be read from the
 //    ring, and the first form's ring hazard (a step in token order) does not exist.
-constexpr int kSmallRing = 8192;
-constexpr int kStepSpan = 4096;
+#ifndef DBI_SMALL_RING
+#define DBI_SMALL_RING 8192
+#endif
+constexpr int kSmallRing = DBI_SMALL_RING;
+constexpr int kStepSpan = DBI_SMALL_RING / 2;
 static_assert(kSmallRing >= kStepSpan + 256 + 8 + 8, "a step, the unflushed bytes before it, an eight-byte read");
 DBI_HD bool k2_in_ring(int p, int step_end) { return p >= step_end - kSmallRing; }
 constexpr int kShortMatch = 8;
