@@ -365,20 +365,26 @@ __device__ __forceinline__ int wave_scan_i32(int v);
 // a value of the lane before (lane 0: its own)
 __device__ __forceinline__ uint32_t from_lane_before(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1); }
 
-__global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
-    const uint8_t* __restrict__ comp, int64_t comp_total,
-    const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
-    StreamInfo* __restrict__ info) {
+// a compiler barrier that also drains the wave's LDS queue: what other lanes wrote is there (a
+// wave's LDS operations execute in order; this is all the synchronisation ONE wave needs)
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct NoProgress {
+    __device__ __forceinline__ void tokens(int) const {}
+};
+
+// One stream through kernel 1's one-wavefront-per-stream form: the tokens to `tokens` + the
+// stream's out_offset, its record returned (lane 0's copy is the stream's state).  `lds` is this
+// wave's own, the wave synchronises with nobody (inflate_tokens_wave_kernel: one wave per
+// workgroup; inflate_pair_kernel: beside the wave that resolves the same stream's tokens, which
+// `progress.tokens(n)` tells how many are there - behind every chunk and every stored run).
+template <class Progress>
+__device__ __forceinline__ StreamInfo tokens_wave_stream(
+    WaveLds& lds, const uint8_t* __restrict__ comp, int64_t comp_total, const dbh_inflate_stream& st,
+    uint32_t* tokens, int lane, const Progress& progress) {
     using namespace dbi;
-    __shared__ __attribute__((aligned(16))) WaveLds lds;
-    const int lane = threadIdx.x;
-    const int i = blockIdx.x;
-    if (i >= n_streams) return;
-    const dbh_inflate_stream st = streams[i];
-    if (st.mode != DBH_INFLATE_ZLIB) {                   // nothing to decode: kernel 2 copies it
-        if (lane == 0) info[i] = StreamInfo{kOk, 0, 0u, 0, 0};
-        return;
-    }
+    if (st.mode != DBH_INFLATE_ZLIB)                     // nothing to decode: kernel 2 copies it
+        return StreamInfo{kOk, 0, 0u, 0, 0};
     WaveMem mem{&lds};
     // Lane 0's copy of L is the stream's state; the serial code (header, block headers with their
     // code builds, stored bytes) runs on lane 0 alone, and what the whole wave needs of it is
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
                 B.lim_lit[l] = uni(L.lim_lit[l]);
                 B.lim_dist[l] = uni(L.lim_dist[l]);
             }
-            __syncthreads();                             // (the tables lane 0 wrote: for all lanes)
+            lds_settle();                                 // (the tables lane 0 wrote: for all lanes)
             if (kWaveTables && uni(L.state) == kDecode) {
                 // the first-level tables of this block's two codes: every lane its share of the
                 // indices, decoded the canonical way (dbh_inflate_wave.h)
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
                     lds.wave_lit_tab[k] = (uint16_t)wave_lit_entry((uint32_t)k, B.lim_lit, mem);
                 for (int k = lane; k < kWaveDistEntries; k += kWaveLanes)
                     lds.wave_dist_tab[k] = (uint16_t)wave_dist_entry((uint32_t)k, B.lim_dist, mem);
-                __syncthreads();
+                lds_settle();    
             }
             continue;
         }
@@ -421,6 +427,7 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
             const uint8_t* src = comp + st.comp_offset + (L.br.bp >> 3);
             for (int k = lane; k < n; k += kWaveLanes) tok[n_tok + k] = src[k];
             n_tok += n;
+            progress.tokens(n_tok);
             if (stored_advance(L, n) && lane == 0) L.br.seek(mem, L.br.bp);
             continue;
         }
@@ -431,13 +438,13 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
         const uint32_t first_dword = bp >> 5, rel0 = bp & 31u;
         const uint32_t fetch_cap = uni(L.br.fetch_cap);
         const uint8_t* in = comp + st.comp_offset;
-        __syncthreads();                                 // (nobody still reads the chunk before)
+        lds_settle();                                     // (nobody still reads the chunk before)
         for (int piece = lane; piece < kStageDwords / 4; piece += kWaveLanes) {
             U4 v;
             __builtin_memcpy(&v, in + stage_piece_at(first_dword, piece, fetch_cap), 16);
             *reinterpret_cast<U4*>(&lds.stage[4 * piece]) = v;
         }
-        __syncthreads();
+        lds_settle();    
         B.limit_rel = uni(L.br.limit_bits) - first_dword * 32u;
         uint32_t x = sub_start(rel0, lane);
         const uint32_t stop = sub_start(rel0, lane + 1);
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
             e = sub_emit(B, mem, x, stop, out_pos + incl_b - bytes_m, out_cap, tok + n_tok + incl_c - cnt_m);
         const int flag = __builtin_amdgcn_readlane(e.flag, last);
         n_tok += __builtin_amdgcn_readlane(incl_c - cnt_m, last) + __builtin_amdgcn_readlane(e.count, last);
+        progress.tokens(n_tok);
         out_pos += __builtin_amdgcn_readlane(incl_b - bytes_m, last) + __builtin_amdgcn_readlane(e.bytes, last);
         L.out_pos = out_pos;
         L.br.bp = first_dword * 32u + (uint32_t)__builtin_amdgcn_readlane((int)e.end, last);
@@ -492,15 +500,26 @@ __global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
             }
         }
     }
-    if (lane == 0) {
-        StreamInfo rec;
-        rec.status = L.status;
-        rec.ended = L.ended;
-        rec.adler = L.adler;
-        rec.n_tokens = n_tok;
-        rec.produced = L.out_pos;
-        info[i] = rec;
-    }
+    StreamInfo rec;
+    rec.status = L.status;
+    rec.ended = L.ended;
+    rec.adler = L.adler;
+    rec.n_tokens = n_tok;
+    rec.produced = L.out_pos;
+    return rec;
+}
+
+__global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
+    const uint8_t* __restrict__ comp, int64_t comp_total,
+    const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
+    StreamInfo* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) WaveLds lds;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= n_streams) return;
+    const dbh_inflate_stream st = streams[i];
+    const StreamInfo rec = tokens_wave_stream(lds, comp, comp_total, st, tokens, lane, NoProgress());
+    if (lane == 0) info[i] = rec;
 }
 
 constexpr int kRing = dbi::kWindowRing;
@@ -533,8 +552,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-// a compiler barrier that also drains the wave's LDS queue: what other lanes wrote is there
-__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Adler-32 without a reduction per piece: s1 = 1 + sum of the bytes, s2 = n + sum over the bytes
 // of (n - position) * byte, n = the stream's length (known from kernel 1) - every lane keeps its
@@ -791,14 +808,52 @@ __device__ __forceinline__ StepTokens place_step(uint32_t raw, int first, int n_
     return s;
 }
 
-__global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
-    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
-    const uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info, uint8_t* out,
-    int32_t* __restrict__ status_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing3];
-    const int lane = threadIdx.x;
-    for (int i = blockIdx.x; i < n_streams; i += gridDim.x) {
-        const dbh_inflate_stream s = streams[i];
+// Adler-32 from sums that do not need the stream's length while they are taken (the pair kernel
+// resolves a stream whose end kernel 1 has not reached yet): S = sum of the bytes, P = sum of
+// position x byte; s1 = 1 + S, s2 = n + n S - P (mod 65521) once n is known.  Every lane keeps its
+// own two sums, the wave adds them up once per stream.
+struct AdlerSums {
+    unsigned bytes;
+    unsigned long long weighted;
+    __device__ __forceinline__ void add4(unsigned w, unsigned position) {
+        const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
+        const unsigned s = b0 + b1 + b2 + b3;
+        bytes += s;
+        weighted += (unsigned long long)position * s + (b1 + 2u * b2 + 3u * b3);
+    }
+    __device__ __forceinline__ void add1(unsigned b, unsigned position) {
+        bytes += b;
+        weighted += (unsigned long long)position * b;
+    }
+    // (wave-uniform) the stream's Adler-32, n = its length
+    __device__ __forceinline__ unsigned finish(unsigned n) const {
+        const unsigned long long S = wave_sum_u32(bytes) % 65521u, P = wave_sum_u64(weighted) % 65521ull;
+        const unsigned long long nm = n % 65521u;
+        const unsigned s1 = (unsigned)((1ull + S) % 65521ull);
+        const unsigned s2 = (unsigned)((nm + nm * S + 65521ull - P) % 65521ull);
+        return (s2 << 16) | s1;
+    }
+};
+
+// how many of a stream's tokens are there: all of them (kernel 1 has ended: the two launches) ...
+struct AllTokensThere {
+    StreamInfo r;
+    __device__ __forceinline__ void wait(int, int& limit, bool& done) const {
+        limit = r.n_tokens;
+        done = true;
+    }
+    __device__ __forceinline__ StreamInfo record() const { return r; }
+};
+
+// One stream through kernel 2's second form: its bytes to out + the stream's out_offset, the
+// verdict to *status_slot.  `ring` (kSmallRing bytes) is this wave's own.  `there.wait(need, limit,
+// done)` returns once tokens [0, need) are there or kernel 1 is done with the stream; `limit` = the
+// number of tokens if it is done, INT_MAX otherwise.
+template <class Tokens>
+__device__ __forceinline__ void resolve_pre_stream(
+    uint8_t* ring, const uint8_t* __restrict__ comp, const dbh_inflate_stream& s,
+    const uint32_t* tokens, const Tokens& there, uint8_t* out, int32_t* status_slot, int lane) {
+    {
         uint8_t* dst = out + s.out_offset;
         const int64_t cap = s.out_bytes;
         if (s.mode != DBH_INFLATE_ZLIB) {
@@ -811,17 +866,18 @@ __global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
                 __builtin_memcpy(dst + k, &v, 8);
             }
             for (int64_t k = whole + lane; k < cap; k += 64) dst[k] = k < have ? src[k] : (uint8_t)0;
-            if (lane == 0) status_out[i] = dbi::kOk;
-            continue;
+            if (lane == 0) *status_slot = dbi::kOk;
+            return;
         }
-        StreamInfo r = info[i];
-        int status = r.status;
+        int status = dbi::kOk;                       // (kernel 1's verdict joins at the end)
         const uint32_t* tok = tokens + s.out_offset;
-        const int n_tok = r.n_tokens;
-        const unsigned n_out = (unsigned)r.produced;
+        int n_tok;                                    // INT_MAX while kernel 1 is still at the stream
+        bool all_there;
+        // (a step needs its own tokens and the next step's, which are decoded while it runs)
+        there.wait(128, n_tok, all_there);
         int pos = 0, flushed = 0;
-        AdlerLane adler = {0u, 0ull};
-        if (status == dbi::kOk && n_tok > 0) {
+        AdlerSums adler = {0u, 0ull};
+        if (n_tok > 0) {
             int first = 0;                            // this step's first token
             StepTokens c = place_step(lane < n_tok ? tok[lane] : 0u, 0, n_tok, 0, lane);
             uint32_t raw_next = 64 + lane < n_tok ? tok[64 + lane] : 0u;      // (if this step takes 64)
@@ -835,6 +891,8 @@ __global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
                 }
                 // the step behind this one is decoded and placed while this one's stores land
                 const int first_n = first + c.count;
+                // the next step's tokens are in registers; the ones behind them are requested now
+                if (!all_there) there.wait(first_n + 128, n_tok, all_there);
                 if (c.count != 64) raw_next = first_n + lane < n_tok ? tok[first_n + lane] : 0u;
                 const uint32_t raw_after = first_n + 64 + lane < n_tok ? tok[first_n + 64 + lane] : 0u;
                 const StepTokens n = place_step(raw_next, first_n, n_tok, end, lane);
@@ -908,7 +966,7 @@ __global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
                         uint16_t* d16 = reinterpret_cast<uint16_t*>(dst + flushed + 4 * lane);
                         d16[0] = (uint16_t)w;             // (a read starts at an even byte, not
                         d16[1] = (uint16_t)(w >> 16);     //  necessarily at a multiple of four)
-                        adler.add4(w, n_out - (unsigned)(flushed + 4 * lane));
+                        adler.add4(w, (unsigned)(flushed + 4 * lane));
                         flushed += 256;
                     } while (pos - flushed >= 256);
                 }
@@ -920,28 +978,129 @@ __global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
                 pv = pv_n;
             }
         }
+        // (the loop ends when kernel 1 has: its record is there)
+        const StreamInfo r = there.record();
+        if (r.status != dbi::kOk) status = r.status;
         if (status == dbi::kOk) {
             lds_settle();
             const int rest = pos - flushed;           // < 256
             for (int k = lane; k < rest; k += 64) {
                 const unsigned b = ring[(flushed + k) & (kRing3 - 1)];
                 dst[flushed + k] = (uint8_t)b;
-                adler.add1(b, n_out - (unsigned)(flushed + k));
+                adler.add1(b, (unsigned)(flushed + k));
             }
-            if (r.ended) {
-                const unsigned s1 = (1u + wave_sum_u32(adler.bytes)) % 65521u;
-                const unsigned s2 =
-                    (unsigned)(((unsigned long long)n_out + wave_sum_u64(adler.weighted)) % 65521ull);
-                if (((s2 << 16) | s1) != r.adler) status = dbi::kBadChecksum;
-            }
+            if (r.ended && adler.finish((unsigned)r.produced) != r.adler) status = dbi::kBadChecksum;
             // a stream that ends early (MinKNOW's short final chunk): libhdf5 zero-extends it
             for (int64_t k = pos + lane; k < cap; k += 64) dst[k] = 0;
         }
         if (status != dbi::kOk)                       // nothing of a damaged stream is handed on
             for (int64_t k = lane; k < cap; k += 64) dst[k] = 0;
-        if (lane == 0) status_out[i] = status;
+        if (lane == 0) *status_slot = status;
     }
 }
+
+__global__ __launch_bounds__(64) void inflate_resolve_pre_kernel(
+    const uint8_t* __restrict__ comp, const dbh_inflate_stream* __restrict__ streams, int n_streams,
+    const uint32_t* __restrict__ tokens, StreamInfo* __restrict__ info, uint8_t* out,
+    int32_t* __restrict__ status_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing3];
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n_streams; i += gridDim.x) {
+        const dbh_inflate_stream s = streams[i];
+        resolve_pre_stream(ring, comp, s, tokens, AllTokensThere{info[i]}, out, status_out + i, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BOTH KERNELS AS A PAIR OF WAVES PER STREAM (what runs; DEEPBINNER_INFLATE_PAIR=0: two launches).
+// A stream is one wave's sequential work in either kernel, and as two launches a container's
+// inflating lasts as long as its longest stream takes in kernel 1 PLUS as long as it takes in
+// kernel 2 - 4.8 + 3.9 ms for a read of 400 k samples, whatever else the launches hold; for
+// containers of long reads (1,000 of ~100 k samples) that, not the kernels' CU time, set the
+// streaming path's rate (profiles/r05_k2/long_reads_100k_samples.txt).  Here a workgroup is two
+// waves on one stream: wave 0 is kernel 1 and says behind every chunk how many tokens are there
+// (a word in LDS, behind a workgroup-scope release: the two waves share the CU's L1, the tokens
+// need no more than to have left the wave), wave 1 is kernel 2 and resolves them as they come -
+// a step at a time once its tokens, the next step's and the ones prefetched behind them are
+// there, sleeping otherwise.  The same tokens, the same schedule, the same bytes; a stream lasts
+// as long as the slower of its two halves.
+struct PairWords {
+    int committed;             // tokens kernel 1 has stored so far
+    int done;                  // kernel 1 has ended; the record below is its verdict
+    int status, ended, n_tokens, produced;
+    unsigned adler;
+};
+struct PairProgress {
+    PairWords* w;
+    int lane;
+    __device__ __forceinline__ void tokens(int n) const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (the tokens have left the wave)
+        if (lane == 0) __hip_atomic_store(&w->committed, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+struct TokensFromPartner {
+    PairWords* w;
+    __device__ __forceinline__ void wait(int need, int& limit, bool& done) const {
+        for (;;) {
+            const int d = __hip_atomic_load(&w->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int c = __hip_atomic_load(&w->committed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (d != 0 || c >= need) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                done = d != 0;
+                limit = done ? __hip_atomic_load(&w->n_tokens, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                             : 0x7FFFFFFF;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __device__ __forceinline__ StreamInfo record() const {
+        StreamInfo r;
+        r.status = w->status;
+        r.ended = w->ended;
+        r.adler = w->adler;
+        r.n_tokens = w->n_tokens;
+        r.produced = w->produced;
+        return r;
+    }
+};
+
+__global__ __launch_bounds__(128) void inflate_pair_kernel(
+    const uint8_t* __restrict__ comp, int64_t comp_total,
+    const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* tokens,
+    StreamInfo* __restrict__ info, uint8_t* out, int32_t* __restrict__ status_out) {
+    __shared__ __attribute__((aligned(16))) WaveLds decode;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing3];
+    __shared__ PairWords words;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x;
+    if (i >= n_streams) return;
+    if (threadIdx.x == 0) {
+        words.committed = 0;
+        words.done = 0;
+    }
+    __syncthreads();
+    const dbh_inflate_stream st = streams[i];
+    if (wave == 0) {
+        const StreamInfo rec = tokens_wave_stream(decode, comp, comp_total, st, tokens, lane,
+                                                  PairProgress{&words, lane});
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {                                   // (lane 0's copy is the stream's state)
+            info[i] = rec;
+            words.status = rec.status;
+            words.ended = rec.ended;
+            words.adler = rec.adler;
+            words.n_tokens = rec.n_tokens;
+            words.produced = (int)rec.produced;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&words.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        resolve_pre_stream(ring, comp, st, tokens, TokensFromPartner{&words}, out, status_out + i, lane);
+    }
+}
+
 
 thread_local char g_error[256];
 
@@ -953,6 +1112,12 @@ bool resolve_pre() {
     const char* v = std::getenv("DEEPBINNER_INFLATE_RESOLVE");
     if (v && std::strcmp(v, "rounds") == 0) return false;
     return true;
+}
+
+// both kernels as one launch, a pair of waves per stream (DEEPBINNER_INFLATE_PAIR=0: two launches)
+bool pair_of_waves() {
+    const char* v = std::getenv("DEEPBINNER_INFLATE_PAIR");
+    return !(v && std::strcmp(v, "0") == 0);
 }
 
 bool wave_per_stream() {
@@ -1009,6 +1174,12 @@ int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
     // the lanes take streams off a counter: with one stream per lane (the default) a launch is
     // as wide as it can be and lasts as long as its longest stream; with several, a fraction of
     // the CUs does the same work in the time the longest stream needs anyway
+    if (pair_of_waves() && wave_per_stream() && resolve_pre()) {
+        hipLaunchKernelGGL(inflate_pair_kernel, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream,
+                           comp_dev, comp_bytes, streams_dev, n, tokens, info, out_dev, status_dev);
+        DBI_HIP(hipGetLastError());
+        return DBH_OK;
+    }
     if (wave_per_stream()) {
         hipLaunchKernelGGL(inflate_tokens_wave_kernel, dim3((unsigned)n), dim3(dbi::kWaveLanes), 0,
                            (hipStream_t)stream, comp_dev, comp_bytes, streams_dev, n, tokens, info);

@@ -269,14 +269,17 @@ def pack_streams(hip, cases):
     return np.frombuffer(bytes(comp) if comp else b'\0', dtype=np.uint8), records, out_at, places
 
 
-@pytest.fixture(params=['lane+pre', 'wave+pre', 'wave+rounds'])
+@pytest.fixture(params=['lane+pre', 'wave+pre', 'wave+rounds', 'wave+pre+pair'])
 def kernel1(request, monkeypatch):
     """Both forms of kernel 1 - one lane per stream, one wavefront per stream - and both forms of
-    kernel 2 - short matches read at the step boundary, every match through the rounds
-    (dbh_inflate.hip) - whichever of them are the defaults."""
-    one, two = request.param.split('+')
-    monkeypatch.setenv('DEEPBINNER_INFLATE_KERNEL', one)
-    monkeypatch.setenv('DEEPBINNER_INFLATE_RESOLVE', two)
+    kernel 2 - short matches read at the step boundary, every match through the rounds - as two
+    launches, and the default forms as ONE launch of a pair of waves per stream, kernel 2
+    resolving a stream's tokens while kernel 1 still decodes it (dbh_inflate.hip) - whichever of
+    them are the defaults."""
+    parts = request.param.split('+')
+    monkeypatch.setenv('DEEPBINNER_INFLATE_KERNEL', parts[0])
+    monkeypatch.setenv('DEEPBINNER_INFLATE_RESOLVE', parts[1])
+    monkeypatch.setenv('DEEPBINNER_INFLATE_PAIR', '1' if 'pair' in parts else '0')
     return request.param
 
 
