@@ -38,6 +38,10 @@
 //      could be overtaken by a write that wraps around the ring goes in token order instead:
 //      dbh_inflate_core.h, ring_hazard): 3.04 ms.
 //      The ring is written out in coalesced 256-byte pieces, with the Adler-32 sums on the way.
+// What dbh_inflate_dev launches is both of them AT ONCE, a pair of waves per stream
+// (inflate_pair_kernel: wave 0 is kernel 1, wave 1 is kernel 2 resolving the tokens as they come;
+// described in front of it) - a stream then lasts as long as the slower of its halves, not their
+// sum; DEEPBINNER_INFLATE_PAIR=0: the two launches.
 // HBM traffic per read (55 KB of samples, ~22 k tokens): 35 KB compressed in, 88 KB of tokens out
 // and in again, 55 KB of samples out - latency and instruction issue, not bandwidth, are what
 // both kernels are bound by.

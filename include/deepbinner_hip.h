@@ -225,7 +225,9 @@ int dbh_inflate_workspace_bytes(int64_t total_out_bytes, int64_t n_streams, size
  * Kernel 2 (tokens -> bytes) reads the output buffer it writes (a match whose source lies more
  * than 8 KiB back is copied from the stream's own flushed output): out_dev must not be mapped
  * write-combined or read-protected.  DEEPBINNER_INFLATE_RESOLVE=rounds selects its older form
- * (the whole 32 KiB window in LDS). */
+ * (the whole 32 KiB window in LDS).  The two kernels run as ONE launch, a pair of waves per
+ * stream, kernel 2 resolving a stream's tokens while kernel 1 still decodes it
+ * (DEEPBINNER_INFLATE_PAIR=0: two launches). */
 int dbh_inflate_dev(const uint8_t* comp_dev, int64_t comp_bytes,
                     const dbh_inflate_stream* streams_dev, int64_t n_streams,
                     int64_t total_out_bytes, uint8_t* out_dev, void* workspace_dev,
