@@ -452,7 +452,9 @@ __device__ __forceinline__ StreamInfo tokens_wave_stream(
         B.limit_rel = uni(L.br.limit_bits) - first_dword * 32u;
         uint32_t x = sub_start(rel0, lane);
         const uint32_t stop = sub_start(rel0, lane + 1);
-        SubResult r = sub_decode(B, mem, x, stop);
+        // (the walks keep their tokens at the end of the stream's token region, if there is room)
+        const KeepTokens kept{keep_room(n_tok, st.out_bytes) ? tok + (st.out_bytes - kKeepSlots) : nullptr, lane};
+        SubResult r = sub_decode(B, mem, x, stop, kept);
         int last;
         for (;;) {
             const uint32_t prev_end = from_lane_before(r.end);
@@ -468,7 +470,7 @@ __device__ __forceinline__ StreamInfo tokens_wave_stream(
             }
             if (moved) {
                 x = want;
-                r = sub_decode(B, mem, x, stop);
+                r = sub_decode(B, mem, x, stop, kept);
             }
         }
         // where every lane's tokens and bytes go; the lane in which the wanted number of bytes is
@@ -484,8 +486,15 @@ __device__ __forceinline__ StreamInfo tokens_wave_stream(
         e.end = 0;
         e.count = e.bytes = 0;
         e.flag = kSubNone;
-        if (lane <= last)
+        if (kept.keep != nullptr && m_over == 0ull && !__any(lane <= last && r.count > kSubKeep)) {
+            // the output pass as a copy: what the lanes' last walks kept, to where it belongs
+            uint32_t* to = tok + n_tok + incl_c - cnt_m;
+            for (int k = 0; __any(k < cnt_m); ++k)
+                if (k < cnt_m) to[k] = kept.keep[k * kWaveLanes + lane];
+            if (lane <= last) e = r;
+        } else if (lane <= last) {
             e = sub_emit(B, mem, x, stop, out_pos + incl_b - bytes_m, out_cap, tok + n_tok + incl_c - cnt_m);
+        }
         const int flag = __builtin_amdgcn_readlane(e.flag, last);
         n_tok += __builtin_amdgcn_readlane(incl_c - cnt_m, last) + __builtin_amdgcn_readlane(e.count, last);
         progress.tokens(n_tok);

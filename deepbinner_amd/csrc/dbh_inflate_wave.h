@@ -228,11 +228,42 @@ struct SubResult {
     int flag;                  // SubFlag: why it stopped before leaving the home, if it did
 };
 
+// THE TOKENS OF A LANE'S LAST WALK ARE KEPT (second session of round 5).  The output pass used to
+// be a walk of its own - every token decoded once more, a quarter of the kernel's decodes.  Now a
+// walk of the rounds stores its tokens as it goes, token k of lane l at keep[k * 64 + l] (the
+// lanes of a wave store side by side), and once the rounds agree the output pass is a copy to
+// where the prefix sums put them.  What a lane keeps is its LAST walk's - it walks again only from
+// another start, and then from token 0.  The kept tokens are uncut, so a chunk in which the wanted
+// number of bytes is exceeded still takes the walking output pass, and so does one in which a
+// lane has more than kSubKeep tokens (a home is 544 bits).  `keep` is the END of the stream's own
+// token region (one slot per byte of output: far more than a stream's tokens, unless it is nearly
+// all literals or short) - keep_room says whether the chunk's tokens stay clear of it.
+#ifndef DBI_SUB_KEEP
+#define DBI_SUB_KEEP 96
+#endif
+constexpr int kSubKeep = DBI_SUB_KEEP;
+constexpr int kKeepSlots = kSubKeep * kWaveLanes;
+// may the chunk that begins with n_tok tokens stored use the last kKeepSlots of cap_slots?
+DBI_HD bool keep_room(int n_tok, int64_t cap_slots) {
+    return kSubKeep > 0 && (int64_t)n_tok + 2 * kKeepSlots <= cap_slots;
+}
+struct KeepNothing {
+    DBI_HD void put(int, uint32_t) const {}
+};
+struct KeepTokens {
+    uint32_t* keep;            // null: nothing is kept
+    int lane;
+    DBI_HD void put(int k, uint32_t token) const {
+        if (keep != nullptr && k < kSubKeep) keep[k * kWaveLanes + lane] = token;
+    }
+};
+
 // A lane's walk through its home in rounds 1, 2, ..: from x until the home [.., stop) is left.
-// Nothing is written, and nothing depends on how many bytes are wanted (that is the output
-// pass's business).
-template <class Mem>
-DBI_HD SubResult sub_decode(const WaveBlock& B, const Mem& mem, uint32_t x, uint32_t stop) {
+// Nothing of the stream's output is written, and nothing depends on how many bytes are wanted
+// (that is the output pass's business); the tokens go to `kept`.
+template <class Mem, class Keep>
+DBI_HD SubResult sub_decode(const WaveBlock& B, const Mem& mem, uint32_t x, uint32_t stop,
+                            const Keep& kept) {
     SubResult r;
     r.count = 0;
     r.bytes = 0;
@@ -254,6 +285,7 @@ DBI_HD SubResult sub_decode(const WaveBlock& B, const Mem& mem, uint32_t x, uint
             r.flag = kSubEnd;
             break;
         }
+        kept.put(r.count, pick(t.is_len, match_token(t.length, t.distance), t.lit));
         r.count += 1;
         r.bytes += (int)t.length;
     }

@@ -73,7 +73,7 @@ struct HostMem {
 // it, then chunk after chunk of the Huffman block - round 1 from every home's first bit, further
 // rounds for the lanes whose predecessor ended elsewhere, the output pass.  Must leave the very
 // tokens and the very lane state of the one-lane decoder.
-static long g_wave_chunks, g_wave_rounds, g_wave_walks, g_wave_tokens;
+static long g_wave_chunks, g_wave_rounds, g_wave_walks, g_wave_tokens, g_wave_kept_chunks;
 static long g_k2_steps, g_k2_rounds, g_k2_turns, g_k2_matches, g_k2_match_bytes, g_k2_tokens;
 static long g_k2p_steps, g_k2p_rounds, g_k2p_late, g_k2p_pre, g_k2p_far, g_k2p_short_steps;
 static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint32_t out_cap,
@@ -118,9 +118,14 @@ static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint
         B.limit_rel = L.br.limit_bits - first_dword * 32u;
         uint32_t x[kWaveLanes];
         SubResult r[kWaveLanes];
+        // (the walks keep their tokens where the kernel's do: at the end of the stream's token
+        // region, one slot per byte of output - here a buffer of that shape)
+        static std::vector<uint32_t> keep_buffer;
+        keep_buffer.assign((size_t)kKeepSlots + 1, 0xDEADBEEFu);
+        const bool room = keep_room((int)tokens.size(), (int64_t)out_cap);
         for (int i = 0; i < kWaveLanes; ++i) {
             x[i] = sub_start(rel0, i);
-            r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1));
+            r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1), KeepTokens{room ? keep_buffer.data() : nullptr, i});
         }
         ++g_wave_chunks;
         ++g_wave_rounds;
@@ -142,21 +147,36 @@ static void run_wave(const std::vector<uint8_t>& comp, uint32_t comp_bytes, uint
             for (int i = 0; i < kWaveLanes; ++i)
                 if (want[i] != x[i]) {
                     x[i] = want[i];
-                    r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1));
+                    r[i] = sub_decode(B, mem, x[i], sub_start(rel0, i + 1),
+                                      KeepTokens{room ? keep_buffer.data() : nullptr, i});
                     ++g_wave_walks;
                 }
         }
         // the lane in which the wanted number of bytes is exceeded, if that comes first
         int before = L.out_pos;
+        bool over = false;
         for (int i = 0; i <= last; ++i) {
             if (before + r[i].bytes > L.out_cap) {
                 last = i;
+                over = true;
                 break;
             }
             before += r[i].bytes;
         }
+        bool many = false;
+        for (int i = 0; i <= last; ++i) many = many || r[i].count > kSubKeep;
         int out_pos = L.out_pos;
         SubResult e{};
+        if (room && !over && !many) {
+            // the output pass as a copy of what the lanes' last walks kept
+            ++g_wave_kept_chunks;
+            for (int i = 0; i <= last; ++i) {
+                for (int k = 0; k < r[i].count; ++k) tokens.push_back(keep_buffer[(size_t)k * kWaveLanes + i]);
+                out_pos += r[i].bytes;
+                g_wave_tokens += r[i].count;
+            }
+            e = r[last];
+        } else
         for (int i = 0; i <= last; ++i) {
             lane_tokens[i].assign((size_t)r[i].count + 1, 0u);
             e = sub_emit(B, mem, x[i], sub_start(rel0, i + 1), out_pos, L.out_cap, lane_tokens[i].data());
@@ -195,6 +215,8 @@ int main(int argc, char** argv) {
     if (std::getenv("DBI_WAVE_STATS")) std::atexit([] {
         std::fprintf(stderr, "one wave per stream: tokens answered by the tables: %ld, sent the canonical way: %ld\n",
                      g_wave_answers[1], g_wave_answers[0]);
+        std::fprintf(stderr, "one wave per stream: the output pass a copy of kept tokens in %ld of %ld chunks\n",
+                     g_wave_kept_chunks, g_wave_chunks);
         std::fprintf(stderr, "one wave per stream: %ld chunks, %.3f rounds per chunk, %.3f walks per lane and chunk, "
                              "%.1f tokens per lane and chunk\n", g_wave_chunks,
                      (double)g_wave_rounds / (double)std::max(1L, g_wave_chunks),
