@@ -84,6 +84,9 @@ constexpr int kLdsBytes1 = kLensOff + dbi::kMaxLens * kLanes;
 static_assert(kLdsBytes1 <= 160 * 1024, "kernel 1's LDS no longer fits a CU");
 
 struct LdsMem {
+    static constexpr int kClTableBits = 0;             // (no table for the code-length code: 64 per wave)
+    __device__ __forceinline__ uint32_t cl_tab(int) const { return 0u; }
+    __device__ __forceinline__ void set_cl_tab(int, uint32_t) {}
     uint32_t* ring_;
     uint32_t* lit_pair_;
     uint32_t* dist_pair_;
@@ -336,8 +339,22 @@ struct WaveLds {
     uint16_t wave_lit_tab[dbi::kWaveLitEntries], wave_dist_tab[dbi::kWaveDistEntries];
     uint8_t dist_sym[dbi::kDistSyms], lens[dbi::kMaxLens];
 };
+// (the code-length code's table - 128 bytes, lane 0's, needed only while a block header is read -
+// lies in the chunk's stage: no chunk is staged then.  128 bytes more would make a CU's LDS hold
+// 15 of these instead of 16.)
+static_assert(sizeof(((WaveLds*)nullptr)->stage) >= 128, "");
 struct WaveMem {
     WaveLds* m;
+#ifndef DBI_WAVE_CL_TABLE
+#define DBI_WAVE_CL_TABLE 7
+#endif
+    static constexpr int kClTableBits = DBI_WAVE_CL_TABLE;      // (7, or 0 = without the table)
+    __device__ __forceinline__ uint32_t cl_tab(int i) const {
+        return reinterpret_cast<const uint8_t*>(m->stage)[i];
+    }
+    __device__ __forceinline__ void set_cl_tab(int i, uint32_t v) {
+        reinterpret_cast<uint8_t*>(m->stage)[i] = (uint8_t)v;
+    }
     __device__ __forceinline__ uint32_t stage(int i) const { return m->stage[i]; }
     __device__ __forceinline__ uint32_t lit_tab(int) const { return 0u; }      // (no decode tables)
     __device__ __forceinline__ void set_lit_tab(int, uint32_t) {}
@@ -522,7 +539,7 @@ __device__ __forceinline__ StreamInfo tokens_wave_stream(
     return rec;
 }
 
-__global__ __launch_bounds__(dbi::kWaveLanes) void inflate_tokens_wave_kernel(
+__global__ __launch_bounds__(dbi::kWaveLanes) __attribute__((amdgpu_waves_per_eu(4, 8))) void inflate_tokens_wave_kernel(
     const uint8_t* __restrict__ comp, int64_t comp_total,
     const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* __restrict__ tokens,
     StreamInfo* __restrict__ info) {
@@ -1078,7 +1095,7 @@ struct TokensFromPartner {
     }
 };
 
-__global__ __launch_bounds__(128) void inflate_pair_kernel(
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) void inflate_pair_kernel(
     const uint8_t* __restrict__ comp, int64_t comp_total,
     const dbh_inflate_stream* __restrict__ streams, int n_streams, uint32_t* tokens,
     StreamInfo* __restrict__ info, uint8_t* out, int32_t* __restrict__ status_out) {

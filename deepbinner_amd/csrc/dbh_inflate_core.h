@@ -413,15 +413,26 @@ struct DistCode {
         fill_table<kDistBits>(c16, len, dist_tab_entry(s, len), [mm](int k, uint32_t v) { mm->set_dist_tab(k, v); });
     }
 };
+// The code-length code of a dynamic block: built where the distance code's sorted symbols will
+// be.  Its codes are at most 7 bits long, so a table of 128 bytes {symbol << 3 | code length}
+// answers every one of them - where the decoder's memory has room for it (Mem::kClTableBits = 7:
+// the one-wavefront-per-stream form, whose block headers - ~300 code lengths each, decoded by
+// lane 0 alone, one after the other - are a third of its instructions; 0: one lane per stream,
+// 64 tables per wave).
 template <class Mem>
-struct CodeLengthCode {    // the code-length code of a dynamic block: built where the distance
-    Mem* m;                // code's sorted symbols will be, no first-level table
-    static constexpr int kTableBits = 0;
+struct CodeLengthCode {
+    Mem* m;
+    static constexpr int kTableBits = Mem::kClTableBits;
     DBI_HD void set_pair(int l, uint32_t v) const { m->set_dist_pair(l, v); }
-    DBI_HD uint32_t pair(int) const { return 0u; }
+    DBI_HD uint32_t pair(int l) const { return m->dist_pair(l); }
     DBI_HD void set_sym(int at, int s) const { m->set_dist_sym(at, (uint32_t)s); }
-    DBI_HD void clear_table() const {}
-    DBI_HD void fill(int, int, uint32_t) const {}
+    DBI_HD void clear_table() const {
+        for (int k = 0; k < 128; ++k) m->set_cl_tab(k, 0u);
+    }
+    DBI_HD void fill(int s, int len, uint32_t c16) const {
+        Mem* mm = m;
+        fill_table<7>(c16, len, ((uint32_t)s << 3) | (uint32_t)len, [mm](int k, uint32_t v) { mm->set_cl_tab(k, v); });
+    }
 };
 
 // Prepares one code for decoding: `lens[first .. first+n)` are the code lengths.  Leaves the
@@ -602,32 +613,53 @@ DBI_HD void lane_block(Lane& L, Mem& mem) {
         int have = 0, prev = 0;
         const int want = hlit + hdist;
         while (have < want) {
+            // one 64-bit window of the stream serves as many code lengths as fit: a code and its
+            // extra bits are at most 7 + 7
             br.ensure(mem, 4u);
             uint32_t lo, hi;
             br.window64(mem, lo, hi);
-            const uint32_t c = first16(lo);
-            const uint32_t cl = code_length<7>(c, lim_cl);
-            if (cl > 7u) return lane_fail(L, kBadSymbol);
-            const int s = (int)mem.dist_sym((int)umin(sorted_index(c, cl, mem.dist_pair((int)cl)), 18u));
-            br.bp += cl;
-            if (s < 16) {
-                mem.set_len(have++, s);
-                prev = s;
-                continue;
+            const uint64_t w = ((uint64_t)hi << 32) | lo;
+            uint32_t used = 0;
+            while (have < want && used <= 50u) {
+                const uint32_t v = (uint32_t)(w >> used);
+                uint32_t cl;
+                int s;
+                if (Mem::kClTableBits > 0) {
+                    const uint32_t e = mem.cl_tab((int)(v & 127u));
+                    cl = e & 7u;
+                    s = (int)(e >> 3);
+                    if (cl == 0u) return lane_fail(L, kBadSymbol);
+                } else {
+                    const uint32_t c = first16(v);
+                    cl = code_length<7>(c, lim_cl);
+                    if (cl > 7u) return lane_fail(L, kBadSymbol);
+                    s = (int)mem.dist_sym((int)umin(sorted_index(c, cl, mem.dist_pair((int)cl)), 18u));
+                }
+                used += cl;
+                if (s < 16) {
+                    mem.set_len(have++, s);
+                    prev = s;
+                    continue;
+                }
+                const uint32_t x = (uint32_t)(w >> used);
+                int rep, val = 0;
+                if (s == 16) {
+                    if (have == 0) return lane_fail(L, kBadCodes);
+                    val = prev;
+                    rep = 3 + (int)(x & 3u);
+                    used += 2u;
+                } else if (s == 17) {
+                    rep = 3 + (int)(x & 7u);
+                    used += 3u;
+                } else {
+                    rep = 11 + (int)(x & 127u);
+                    used += 7u;
+                }
+                if (have + rep > want) return lane_fail(L, kBadCodes);
+                for (int k = 0; k < rep; ++k) mem.set_len(have++, val);
+                if (s != 16) prev = 0;
             }
-            int rep, val = 0;
-            if (s == 16) {
-                if (have == 0) return lane_fail(L, kBadCodes);
-                val = prev;
-                rep = 3 + (int)br.take(mem, 2);
-            } else if (s == 17) {
-                rep = 3 + (int)br.take(mem, 3);
-            } else {
-                rep = 11 + (int)br.take(mem, 7);
-            }
-            if (have + rep > want) return lane_fail(L, kBadCodes);
-            for (int k = 0; k < rep; ++k) mem.set_len(have++, val);
-            if (s != 16) prev = 0;
+            br.bp += used;
         }
         if (br.overrun()) return lane_fail(L, kTruncated);
         if (mem.len(256) == 0) return lane_fail(L, kBadCodes);          // no end-of-block code

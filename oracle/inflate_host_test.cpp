@@ -31,6 +31,10 @@ static void dbi_table_mismatch() {
 }
 
 struct HostMem {
+    static constexpr int kClTableBits = 7;            // (the code-length code's table: as the wave form has it)
+    uint8_t cl_tab_[128];
+    uint32_t cl_tab(int i) const { return cl_tab_[check(i, 128)]; }
+    void set_cl_tab(int i, uint32_t v) { cl_tab_[check(i, 128)] = (uint8_t)v; }
     uint32_t ring_[dbi::kRingStore], lit_pair_[16], dist_pair_[16];
     uint16_t lit_sym_[dbi::kLitSyms], cnt_[16];
     uint8_t dist_sym_[dbi::kDistSyms], lens_[dbi::kMaxLens];
