@@ -180,6 +180,10 @@ struct dbh_model {
     int inflate_streams_per_lane = 0;      // dbh_classify_pair_deflated -> dbh_inflate_dev; 0 = by
                                            // the lengths of the streams
     bool launch_per_batch = false;   // DEEPBINNER_LAUNCH_PER_BATCH=1: one launch per batch (A/B)
+    // The end of a persistent launch: with fewer than chunk4_rounds x grid windows not yet handed
+    // out a workgroup asks for groups of 2 instead of 4, below chunk2_rounds x grid for single
+    // windows (DEEPBINNER_CHUNK4_ROUNDS / DEEPBINNER_CHUNK2_ROUNDS: A/B)
+    int chunk4_rounds = 8, chunk2_rounds = 3;
     float* d_packed = nullptr;
     // workspace for the host-pointer entry points, grown on demand
     void* d_in = nullptr;      size_t in_bytes = 0;
@@ -309,8 +313,10 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         }
         // production launches are persistent: at most one workgroup per CU, each walking its
         // share of the windows; the debug / timeline modes keep one workgroup per window
-        const bool one_per_window = debug_stage >= 0 && debug_stage != 301;
-        const unsigned grid = (unsigned)(one_per_window || cnt < m->cus ? cnt : m->cus);
+        // (a workgroup takes its windows in groups of dbh::kGroup: dbh_forward.hip)
+        const bool one_per_group = debug_stage >= 0 && debug_stage != 301;
+        const int64_t groups = (cnt + dbh::kGroup - 1) / dbh::kGroup;
+        const unsigned grid = (unsigned)(one_per_group || groups < m->cus ? groups : m->cus);
         void** tail = in.tail;
         size_t* tail_bytes = in.tail_bytes;
         if (!tail) {
@@ -324,8 +330,7 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         // zero between launches, so zeroed here only when the buffer is new)
         {
             void* before = *tail;
-            const int st = ensure(tail, tail_bytes, 256 + (size_t)grid * dbh::kTailBatch *
-                                                              dbh::kTailSlotFloats * sizeof(float));
+            const int st = ensure(tail, tail_bytes, 256 + (size_t)grid * dbh::kWgScratchFloats * sizeof(float));
             if (st != DBH_OK) return st;
             if (*tail != before) DBH_HIP(hipMemsetAsync(*tail, 0, 256, stream));
         }
@@ -358,6 +363,8 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.debug_stage = debug_stage;
         a.steps = in.steps;
         a.side = in.side;
+        a.chunk4_min_left = m->chunk4_rounds * (int)grid;
+        a.chunk2_min_left = m->chunk2_rounds * (int)grid;
         if (debug_stage == 300)
             hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads),
                                0, stream, reinterpret_cast<dbh_timeline::ForwardArgs&>(a));
@@ -569,6 +576,8 @@ int dbh_model_create(const float* weights, int64_t n_floats, int n_classes, int 
         m->host_zero_copy = !(zc && zc[0] == '0');
         const char* sw = std::getenv("DEEPBINNER_STATIC_WINDOWS");
         m->windows_by_counter = !(sw && sw[0] == '1');
+        if (const char* c4 = std::getenv("DEEPBINNER_CHUNK4_ROUNDS")) m->chunk4_rounds = std::atoi(c4);
+        if (const char* c2 = std::getenv("DEEPBINNER_CHUNK2_ROUNDS")) m->chunk2_rounds = std::atoi(c2);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_packed, packed.size() * sizeof(float));
     if (e == hipSuccess)
@@ -1453,13 +1462,12 @@ int dbh_forward_timeline(dbh_model* m, const float* x_host, int64_t n, int64_t* 
         a.n_classes = m->n_classes;
         a.debug_stage = 300;
         a.steps = 1;
-        st = ensure(&m->d_tail, &m->tail_bytes,
-                    (size_t)n * dbh::kTailBatch * dbh::kTailSlotFloats * sizeof(float));
+        const unsigned grid = (unsigned)((n + dbh::kGroup - 1) / dbh::kGroup);
+        st = ensure(&m->d_tail, &m->tail_bytes, (size_t)grid * dbh::kWgScratchFloats * sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;
         a.win_counter = nullptr;
-        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3((unsigned)n),
-                           dim3(dbh::kThreads), 0, 0, a);
+        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads), 0, 0, a);
     }
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));
@@ -1502,14 +1510,13 @@ int dbh_forward_timeline_i16(dbh_model* m, const int16_t* samples_host, int64_t 
         // more windows than CUs: a persistent launch, as in production (stamps per window)
         a.debug_stage = n > m->cus ? 301 : 300;
         a.steps = 1;
-        st = ensure(&m->d_tail, &m->tail_bytes, (size_t)(n > m->cus ? m->cus : n) *
-                                                    dbh::kTailBatch * dbh::kTailSlotFloats *
-                                                    sizeof(float));
+        const int64_t groups = (n + dbh::kGroup - 1) / dbh::kGroup;
+        const unsigned grid = (unsigned)(n > m->cus ? (groups < m->cus ? groups : m->cus) : groups);
+        st = ensure(&m->d_tail, &m->tail_bytes, (size_t)grid * dbh::kWgScratchFloats * sizeof(float));
         if (st != DBH_OK) return st;
         a.tail_scratch = (float*)m->d_tail;
         a.win_counter = nullptr;
-        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel,
-                           dim3((unsigned)(n > m->cus ? m->cus : n)), dim3(dbh::kThreads), 0, 0, a);
+        hipLaunchKernelGGL(dbh_timeline::dbh_forward_kernel, dim3(grid), dim3(dbh::kThreads), 0, 0, a);
     }
     DBH_HIP(hipGetLastError());
     DBH_HIP(hipMemcpyAsync(stamps_host, m->d_work, stamp_bytes, hipMemcpyDeviceToHost, 0));

@@ -131,7 +131,8 @@ __device__ __forceinline__ void mark(unsigned* ts, int id) {
 __device__ __forceinline__ void flush_marks(unsigned* ts, long long* out, int lane) {
 #if DBH_TIMELINE
     if (ts) {
-        out[lane] = (long long)*ts;
+        // (a window's row is written in three goes - stages A-C, D, E-F: only what was stamped)
+        if (*ts != 0u) out[lane] = (long long)*ts;
         *ts = 0u;
     }
 #else
@@ -579,62 +580,6 @@ __device__ __forceinline__ void dump_stage(const float* region, int stride, int 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Winograd F(2,3) convolution (48 -> 48 channels, k = 3, 'same', stride 1), in place.
-//   For the output pair (2j, 2j+1) and d = x[2j-1 .. 2j+2]:
-//     U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3            (input transform, VALU)
-//     M_xi = U_xi . V_xi  over the 48 input channels             (four GEMMs, MFMA)
-//     y[2j] = M0+M1+M2,  y[2j+1] = M1-M2-M3                      (output transform, epilogue)
-//   with V0 = g0, V1 = (g0+g1+g2)/2, V2 = (g0-g1+g2)/2, V3 = g2 pre-computed on the host:
-//   4 products per output pair instead of 6, i.e. 1.5x fewer MFMAs for the same result
-//   (fp32 round-off differs by a few ulp per layer; the parity tests bound the end effect).
-// A wave owns MT tiles of 16 pairs (= 32 positions each).  The four V matrices arrive as two
-// halves (V0,V1 | V2,V3) in rotating LDS slots: phase 1 multiplies by the first half while the
-// second half of the NEXT layer... see the DMA calls at the call sites.
-// ---------------------------------------------------------------------------------------------
-template <int MT>
-struct WinoFrags {
-    f2 d[MT][3];
-    f2 b[2][3];
-};
-
-template <int MT, int PHASE, int SP_IDX>
-__device__ __forceinline__ void wino_load(WinoFrags<MT>& f, unsigned a_addr, unsigned b_addr) {
-    // phase 0 needs d0,d1,d2 (rows +0..+2 from the tile's first physical row), phase 1 d1,d2,d3
-    static_assert(MT <= 2, "extend wino_load");
-    constexpr int R = PHASE;
-    if constexpr (MT > 0) {
-        f.d[0][0] = ds_read_f2<((0 * 32 + R + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
-        f.d[0][1] = ds_read_f2<((0 * 32 + R + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
-        f.d[0][2] = ds_read_f2<((0 * 32 + R + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    }
-    if constexpr (MT > 1) {
-        f.d[1][0] = ds_read_f2<((1 * 32 + R + 0) * kS48 + SP_IDX * 8) * 4>(a_addr);
-        f.d[1][1] = ds_read_f2<((1 * 32 + R + 1) * kS48 + SP_IDX * 8) * 4>(a_addr);
-        f.d[1][2] = ds_read_f2<((1 * 32 + R + 2) * kS48 + SP_IDX * 8) * 4>(a_addr);
-    }
-    // the slot holds [xi' 0..1][sp 0..5][t 0..2] fragments of 128 floats
-    f.b[0][0] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
-    f.b[0][1] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
-    f.b[0][2] = ds_read_f2<(((0 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
-    f.b[1][0] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 0) * 128) * 4>(b_addr);
-    f.b[1][1] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 1) * 128) * 4>(b_addr);
-    f.b[1][2] = ds_read_f2<(((1 * 6 + SP_IDX) * 3 + 2) * 128) * 4>(b_addr);
-}
-
-template <int PENDING, int MT>
-__device__ __forceinline__ void wino_wait(WinoFrags<MT>& f) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(PENDING) : "memory");
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(f.d[m][k]));
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(f.b[x][t]));
-}
-
 // a + b / a - b on both halves of a register pair.  (Written as asm because hipcc splits a plain
 // f2 add into two scalar ones whenever it likes the register allocation better.)
 __device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
@@ -670,96 +615,6 @@ __device__ __forceinline__ f2 pk_fma_relu(f2 k, f2 b, f2 c) {
 // it does not look into inline asm: an accumulator read HERE straight after the MFMA chain (the
 // exposed epilogue of a layer's last tile) arrives stale.
 
-// bias: step 0 STARTS the accumulator chains (no moved zeros: vector moves are not free beside
-// fp32 MFMAs) - M0's from +bias (even outputs), M3's from -bias (odd outputs), the others from the
-// MFMA's constant 0.
-template <int MT, int PHASE, int SP_IDX, class Side>
-__device__ __forceinline__ void wino_step(unsigned a_addr, unsigned b_addr, WinoFrags<MT> (&buf)[2],
-                                          f4 (&acc)[4][MT][3], const float (&bias)[3],
-                                          const Side& side) {
-    constexpr int kLoads = 3 * MT + 6;
-    if constexpr (SP_IDX + 1 < 6) {
-        wino_load<MT, PHASE, SP_IDX + 1>(buf[(SP_IDX + 1) & 1], a_addr, b_addr);
-        if constexpr (!is_interleaved<Side>::value) side(IntC<SP_IDX>{});
-        wino_wait<kLoads>(buf[SP_IDX & 1]);
-    } else {
-        if constexpr (!is_interleaved<Side>::value) side(IntC<SP_IDX>{});
-        wino_wait<0>(buf[SP_IDX & 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    progress_priority<SP_IDX, 6>();
-    const WinoFrags<MT>& f = buf[SP_IDX & 1];
-    f2 u[2][MT];     // both components at once (v_pk_add_f32), in one block ahead of the MFMAs
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if constexpr (PHASE == 0) {
-            u[0][m] = pk_sub(f.d[m][0], f.d[m][2]);     // U0 = d0 - d2
-            u[1][m] = pk_add(f.d[m][1], f.d[m][2]);     // U1 = d1 + d2
-        } else {                                        // loaded rows are d1, d2, d3
-            u[0][m] = pk_sub(f.d[m][1], f.d[m][0]);     // U2 = d2 - d1
-            u[1][m] = pk_sub(f.d[m][0], f.d[m][2]);     // U3 = d1 - d3
-        }
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(u[x][m]));
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (is_interleaved<Side>::value) side(IntC<SP_IDX>{});
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if constexpr (SP_IDX == 0) {
-                    const float b0 = (2 * PHASE + x == 0) ? bias[t] : (2 * PHASE + x == 3) ? -bias[t] : 0.f;
-                    const f4 start = (2 * PHASE + x == 0 || 2 * PHASE + x == 3) ? f4{b0, b0, b0, b0}
-                                                                                : f4{0.f, 0.f, 0.f, 0.f};
-                    acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, start);
-                } else {
-                    acc[2 * PHASE + x][m][t] = mfma4(u[x][m].x, f.b[x][t].x, acc[2 * PHASE + x][m][t]);
-                }
-            }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                acc[2 * PHASE + x][m][t] = mfma4(u[x][m].y, f.b[x][t].y, acc[2 * PHASE + x][m][t]);
-    if constexpr (is_interleaved<Side>::value) {
-#pragma unroll
-        for (int k = 0; k < 6 * MT; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM
-        }
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(acc[2 * PHASE + x][m][t]));
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SP_IDX + 1 < 6)
-        wino_step<MT, PHASE, SP_IDX + 1>(a_addr, b_addr, buf, acc, bias, side);
-}
-
-template <int MT, int PHASE, class Side = NoSide>
-__device__ __forceinline__ void wino_phase(const float* a_lane, const float* slot_lane,
-                                           f4 (&acc)[4][MT][3], const float (&bias)[3],
-                                           const Side& side = Side()) {
-    const unsigned a_addr = lds_addr(a_lane), b_addr = lds_addr(slot_lane);
-    WinoFrags<MT> buf[2];
-    wino_load<MT, PHASE, 0>(buf[0], a_addr, b_addr);
-    wino_step<MT, PHASE, 0>(a_addr, b_addr, buf, acc, bias, side);
-}
-
-// One F(2,3) Winograd layer with whole tiles per wave (conv7).  SLOT_A / SLOT_B: LDS homes of
-// this layer's (V0,V1) / (V2,V3).
-// next1: DMA issued at the top of phase 1 (into the slot nobody uses now); next2: DMA issued
-// at the top of phase 2 (into SLOT_A, which every wave has finished with by then).
 // ---------------------------------------------------------------------------------------------
 // F(2,3) with 16 input channels out of an LDS image (conv13, conv15 of the inception block; conv6,
 // 16 -> 48 at L = 256, ran this way until round 5 and is now part of stage_b_chain): 2/3 of the
@@ -984,6 +839,37 @@ __device__ __forceinline__ void w43_epilogue_half(const f4 (&acc)[6], int h, flo
             dst[2 * kS48] = v2;
             dst[3 * kS48] = v3;
         }
+    }
+}
+
+// The same epilogue (MaxPool2 + BatchNorm) into conv1d_7's PARK in global memory (round 6): the
+// layout stage D's chain loads its operands from - [half of the window][row i of the quad][channel
+// group g][lane (q, n) of the reading wave][r], channels 16g + 4q + r of position 4 (16 half + n) + i
+// (dbh_layout.h: kPark7Floats).  park_lane: this lane's place for pooled row 0 of quad 2q of its
+// tile, channel n of N tile 0 (w43_nsplit_half); pooled row i = 2e + pp of quad offset e + 8h lies
+// i * 768 + h * 16 floats on, N tile T another T * 256.
+template <int T, class Ptr>
+__device__ __forceinline__ void w43_epilogue_half_park(const f4 (&acc)[6], int h, float sc, float sh,
+                                                       Ptr park_lane) {
+    const f2 k2 = f2{2.f, 2.f}, k4 = f2{4.f, 4.f}, k8 = f2{8.f, 8.f};
+    const f2 a0 = f2{acc[0][2 * h], acc[0][2 * h + 1]};
+    const f2 a1 = f2{acc[1][2 * h], acc[1][2 * h + 1]};
+    const f2 a2 = f2{acc[2][2 * h], acc[2][2 * h + 1]};
+    const f2 a3 = f2{acc[3][2 * h], acc[3][2 * h + 1]};
+    const f2 a4 = f2{acc[4][2 * h], acc[4][2 * h + 1]};
+    const f2 a5 = f2{acc[5][2 * h], acc[5][2 * h + 1]};
+    const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+    const f2 y0 = pk_add_relu(a0 + s12, s34);
+    const f2 y1 = pk_fma_relu(k2, d34, d12);
+    const f2 y2 = pk_fma_relu(k4, s34, s12);
+    const f2 y3 = pk_fma_relu(k8, d34, d12 + a5);      // (a5 through a visible add: see pk_fma_relu)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        f2 p = f2{fmaxf(y0[e], y1[e]), fmaxf(y2[e], y3[e])};
+        p = __builtin_elementwise_fma(p, f2{sc, sc}, f2{sh, sh});
+        Ptr dst = park_lane + (2 * e) * 768 + T * 256 + h * 16;
+        dst[0] = p.x;
+        dst[768] = p.y;
     }
 }
 
@@ -1240,9 +1126,10 @@ __device__ __forceinline__ void chain_arrive(unsigned arrive_addr, int t) {
                  "n"(t * 4)
                  : "memory");
 }
+template <int BASE = kSyncTiles>
 __device__ __forceinline__ void chain_wait(float* lds, int t, unsigned target) {
     if (DBH_ABL & (1 | 32 | 128)) return;
-    const unsigned addr = lds_addr(lds + kSyncTiles + t);
+    const unsigned addr = lds_addr(lds + BASE + t);
     for (;;) {
         unsigned seen;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(addr) : "memory");
@@ -1253,16 +1140,18 @@ __device__ __forceinline__ void chain_wait(float* lds, int t, unsigned target) {
 // The polls above cost an LDS round trip each with nothing else issued by the wave; where the
 // answer is almost always "yes" the word is PEEKED a step ahead - the read rides in front of a
 // step's fragment requests, whose hand-counted wait retires it - and only looked at here.
+template <int BASE = kSyncTiles>
 __device__ __forceinline__ unsigned chain_peek(float* lds, int t) {
     unsigned seen;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + kSyncTiles + t)) : "memory");
+    asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + BASE + t)) : "memory");
     return seen;
 }
+template <int BASE = kSyncTiles>
 __device__ __forceinline__ void chain_check(float* lds, int t, unsigned peeked, unsigned target) {
     if (DBH_ABL & (1 | 32 | 128)) return;
     asm volatile("" : "+v"(peeked));     // (the use stays behind the wait that retired the read)
     if ((int)(__builtin_amdgcn_readfirstlane(peeked) - target) >= 0) return;
-    chain_wait(lds, t, target);
+    chain_wait<BASE>(lds, t, target);
 }
 // Halo posts: wave w owns the word pair kSyncHalo + 2w = {posts of wave w - 1, posts of wave w + 1}
 // (an outer wave stands in for its missing neighbour itself), so that one 8-byte read answers
@@ -1285,9 +1174,10 @@ __device__ __forceinline__ bool halo_ready(u2 seen, unsigned target) {
     const int db = (int)(__builtin_amdgcn_readfirstlane(seen.y) - target);
     return da >= 0 && db >= 0;
 }
+template <int BASE = kSyncHalo>
 __device__ __forceinline__ void halo_wait(float* lds, int wave, unsigned target) {
     if (DBH_ABL & (1 | 2 | 8 | 64)) return;
-    const unsigned addr = lds_addr(lds + kSyncHalo + 2 * wave);
+    const unsigned addr = lds_addr(lds + BASE + 2 * wave);
     for (;;) {
         u2 seen;
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(addr) : "memory");
@@ -1295,16 +1185,18 @@ __device__ __forceinline__ void halo_wait(float* lds, int wave, unsigned target)
         __builtin_amdgcn_s_sleep(1);
     }
 }
+template <int BASE = kSyncHalo>
 __device__ __forceinline__ u2 halo_peek(float* lds, int wave) {
     u2 seen;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + kSyncHalo + 2 * wave)) : "memory");
+    asm volatile("ds_read_b64 %0, %1" : "=v"(seen) : "v"(lds_addr(lds + BASE + 2 * wave)) : "memory");
     return seen;
 }
+template <int BASE = kSyncHalo>
 __device__ __forceinline__ void halo_check(float* lds, int wave, u2 peeked, unsigned target) {
     if (DBH_ABL & (1 | 2 | 8 | 64)) return;
     asm volatile("" : "+v"(peeked));
     if (halo_ready(peeked, target)) return;
-    halo_wait(lds, wave, target);
+    halo_wait<BASE>(lds, wave, target);
 }
 
 // lane n <- lane n - 1 / n + 1 of its row of 16; the row's first / last lane keeps `edge`
@@ -1337,18 +1229,25 @@ __device__ __forceinline__ void w43t_outputs(const f4 (&acc)[6], f2 (&y)[4]) {
     y[3] = pk_fma_relu(k8, d34, d12 + a5);      // (a5 through a visible add: see pk_fma_relu)
 }
 
-// halo rows of step SP (channels 16 g + 4q + 2h, + 1) of the layer output at HOFF
-template <int SP, int HOFF>
+// halo rows of step SP (channels 16 g + 4q + 2h, + 1) of the layer output at HOFF.
+// HLAY 0: stage B's arrays (dbh_layout.h: kHalo); 1: stage D's (kDHalo: [wave][side][48], h_addr =
+// the wave's left row)
+template <int SP, int HOFF, int HLAY>
 __device__ __forceinline__ void w43t_load_halo(f2 (&hb)[2], unsigned h_addr) {
     constexpr int c = 16 * (SP >> 1) + 2 * (SP & 1);
-    hb[0] = ds_read_f2<(HOFF + kHaloRows + 48 + c) * 4>(h_addr);     // A3[w][1]: position 4j - 1
-    hb[1] = ds_read_f2<(HOFF + 96 + c) * 4>(h_addr);                 // A0[w + 1][0]: position 4j + 4
+    if constexpr (HLAY == 0) {
+        hb[0] = ds_read_f2<(HOFF + kHaloRows + 48 + c) * 4>(h_addr);     // A3[w][1]: position 4j - 1
+        hb[1] = ds_read_f2<(HOFF + 96 + c) * 4>(h_addr);                 // A0[w + 1][0]: position 4j + 4
+    } else {
+        hb[0] = ds_read_f2<(HOFF + c) * 4>(h_addr);                      // position 4j - 1
+        hb[1] = ds_read_f2<(HOFF + 48 + c) * 4>(h_addr);                 // position 4j + 4
+    }
 }
 
 // One step of a chained tile.  HOFF >= 0: tile 0 of conv3 / conv4 - the step first turns
 // Y[g][h] (g = SP >> 1, h = SP & 1) and its two halo positions into U[.][SP].  pre(SP) runs in
 // front of the step's LDS requests (polls), side(SP) behind its MFMAs.
-template <int HOFF, int STEP0, int STEPS, int SP, int CATCH, class Pre, class Side>
+template <int HOFF, int STEP0, int STEPS, int SP, int CATCH, int HLAY, class Pre, class Side>
 __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
                                           unsigned b_addr, f2 (&hbuf)[2][2], f4 (&buf)[2][3],
                                           f4 (&acc)[6], f4 bias4, bool wave_hi, const Pre& pre,
@@ -1356,7 +1255,7 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     constexpr bool BUILD = HOFF >= 0 && !(DBH_ABL & 8);
     pre(IntC<SP>{});
     if constexpr (SP + 1 < 6) {
-        if constexpr (BUILD) w43t_load_halo<SP + 1, (BUILD ? HOFF : 0)>(hbuf[(SP + 1) & 1], h_addr);
+        if constexpr (BUILD) w43t_load_halo<SP + 1, (BUILD ? HOFF : 0), HLAY>(hbuf[(SP + 1) & 1], h_addr);
         w43_load_b<SP + 1>(buf[(SP + 1) & 1], b_addr);
         if constexpr (BUILD) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
@@ -1404,14 +1303,14 @@ __device__ __forceinline__ void w43t_step(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     side(IntC<SP>{});
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP + 1 < 6)
-        w43t_step<HOFF, STEP0, STEPS, SP + 1, CATCH>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre,
-                                              side);
+        w43t_step<HOFF, STEP0, STEPS, SP + 1, CATCH, HLAY>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi,
+                                                           pre, side);
 }
 
 // bias_addr: this lane's place in the LDS parameter table (kParams + 4q); BIAS_OFF: floats from
 // there to the tile's four biases - requested first, so that step 0's hand-counted wait retires it
 // (a load the compiler sees would be waited for with lgkmcnt(0), fragment requests and all)
-template <int HOFF, int STEP0, int STEPS, int BIAS_OFF, int CATCH = 0, class Pre, class Side>
+template <int HOFF, int STEP0, int STEPS, int BIAS_OFF, int CATCH = 0, int HLAY = 0, class Pre, class Side>
 __device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_addr,
                                           unsigned bias_addr, const float* slot_lane,
                                           f4 (&acc)[6], bool wave_hi, const Pre& pre,
@@ -1420,9 +1319,9 @@ __device__ __forceinline__ void w43t_tile(W43U& U, f2 (&Y)[3][2][4], unsigned h_
     f2 hbuf[2][2];
     f4 buf[2][3];
     const f4 bias4 = ds_read_f4<BIAS_OFF * 4>(bias_addr);
-    if constexpr (HOFF >= 0 && !(DBH_ABL & 8)) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0)>(hbuf[0], h_addr);
+    if constexpr (HOFF >= 0 && !(DBH_ABL & 8)) w43t_load_halo<0, (HOFF >= 0 ? HOFF : 0), HLAY>(hbuf[0], h_addr);
     w43_load_b<0>(buf[0], b_addr);
-    w43t_step<HOFF, STEP0, STEPS, 0, CATCH>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre, side);
+    w43t_step<HOFF, STEP0, STEPS, 0, CATCH, HLAY>(U, Y, h_addr, b_addr, hbuf, buf, acc, bias4, wave_hi, pre, side);
 }
 
 struct NoPre {
@@ -1889,6 +1788,250 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     mark(ts, 21);
 }
 
+// conv1d_7's output of a wave's sixteen quads in stage D's operand order, from a park (global
+// memory, or the LDS image of the group's last window): twelve 16-byte loads per lane, each
+// wave-instruction one contiguous KiB.  src = the window's park + half * 3072 + lane * 4.
+template <class Ptr>
+__device__ __forceinline__ void d_load_y(f2 (&Y)[3][2][4], Ptr src) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const f4 v = *reinterpret_cast<const f4*>(src + (i * 3 + g) * 256);
+            Y[g][0][i] = f2{v.x, v.y};
+            Y[g][1][i] = f2{v.z, v.w};
+        }
+}
+
+// =============================================================================================
+// STAGE D FOR FOUR WINDOWS AT A TIME (round 6): conv1d_8 -> conv1d_9 -> MaxPool -> BN4 as Winograd
+// F(4,3), chained in registers exactly like conv1d_3 -> conv1d_4 above.  One window has 32 quads
+// at L = 128 = two tiles of 16: for ONE window eight waves had to split a tile's matrices between
+// partner waves and exchange partial sums through LDS behind two barriers per layer (F(2,3), 576
+// MFMAs per layer, 67 % of the matrix pipe's time).  A GROUP of kGroup = 4 windows is eight tiles:
+// wave w owns half hf = w & 1 of window k = w >> 1 - lane (n, q) quad 16 hf + n - from conv1d_7's
+// parked output to BN4's, 216 MFMAs per layer and wave (432 per window and layer instead of 576),
+// no workgroup barrier inside.  Halo rows cross between the two waves of a window only (the
+// window's two ends are zero rows the wave writes itself); the tile words count all eight waves,
+// because the weight slots are shared.
+//   conv1d_7's park (global memory, written by w43_epilogue_half_park in operand order) -> Y:
+// twelve 16-byte loads per lane, each wave-instruction one contiguous KiB.
+//   Weights: four slots of a third each.  conv8's thirds 0 and 1 were requested while the group's
+// last conv1d_7 ran, third 2 and conv9's third 0 are requested in tile 0 here; conv9's thirds 1 and
+// 2 follow conv8's out of slots 0 and 1.  The inception block's weights (conv10 .. conv15) arrive
+// in their stage-E homes meanwhile - once per GROUP.
+//   BN4's output X (66 x 50 image with its two zero rows): window 0's straight into LDS, the
+// others' into their parks in global memory (LDS-DMA brings each in while the window before it
+// runs its stage E2 / E3 / F).
+// =============================================================================================
+__device__ __forceinline__ void stage_d_chain(float* lds, const float* __restrict__ packed,
+                                              float* __restrict__ wg_scratch, int lane, int wave,
+                                              unsigned* ts, unsigned& d_groups, f2 (&Y)[3][2][4]) {
+    const int n = lane & 15, q = lane >> 4;
+    const int k = wave >> 1, hf = wave & 1;
+    const unsigned tiles0 = d_groups * 8u, halos0 = d_groups * 4u;
+    d_groups += 1;
+    constexpr int NW = DBH_DMA_WAVES;
+    static_assert(NW == 4, "the request schedule below deals pieces to four waves");
+    // request(s) of step `step` of a copy of NFLOATS: two per step
+    auto copy_step = [&](auto nfloats_tag, const float* src, float* dst, int step) {
+        constexpr int NFLOATS = decltype(nfloats_tag)::value;
+        constexpr int per_wave = (NFLOATS / 256 + NW - 1) / NW;
+        if (2 * step < per_wave) dma_weights_one<NFLOATS, NW>(src, dst, lane, wave, 2 * step);
+        if (2 * step + 1 < per_wave) dma_weights_one<NFLOATS, NW>(src, dst, lane, wave, 2 * step + 1);
+    };
+    const IntC<kWinoHalf> third_floats;
+    // (Y: conv1d_7's output of this wave's sixteen quads - rows i = 0..3, channels 16g + 4q + {0..3} -
+    // loaded by the caller: d_load_y)
+    // this wave's halo rows: kDHalo + L * kDHaloLayer + (wave * 2 + side) * 48; the one at the
+    // window's end (side hf: left of an even wave, right of an odd one) is 'same' padding
+    if (lane < 48) {
+        lds[kDHalo + (wave * 2 + hf) * 48 + lane] = 0.f;
+        lds[kDHalo + kDHaloLayer + (wave * 2 + hf) * 48 + lane] = 0.f;
+    }
+    const unsigned h_addr = lds_addr(lds + kDHalo + wave * 96 + 4 * q);
+    // where a lane's row 0 (an odd wave's first quad: its partner's right halo) and row 3 (an even
+    // wave's last quad: its partner's left halo) go - entry (wave ^ 1, side hf) - scratch for the rest
+    const bool is_edge = n == (hf ? 0 : 15);
+    const unsigned edge_addr = lds_addr(lds + kDHalo + ((wave ^ 1) * 2 + hf) * 48 + 4 * q);
+    const unsigned dummy_addr = lds_addr(lds + kDDummy + 2 * lane);
+    unsigned a0_addr[2], a3_addr[2];
+#pragma unroll
+    for (int L = 0; L < 2; ++L) {
+        a0_addr[L] = (is_edge && hf == 1) ? edge_addr + L * kDHaloLayer * 4 : dummy_addr;
+        a3_addr[L] = (is_edge && hf == 0) ? edge_addr + L * kDHaloLayer * 4 : dummy_addr;
+        asm volatile("" : "+v"(a0_addr[L]), "+v"(a3_addr[L]));
+    }
+    // posts: word pair kSyncDHalo + 2w = {left neighbour's, right neighbour's}; lane 0 -> the
+    // partner's word for this wave, lane 1 -> this wave's own word for the neighbour it has not
+    const unsigned post_addr =
+        lds_addr(lane == 0   ? lds + kSyncDHalo + 2 * (wave ^ 1) + hf
+                 : lane == 1 ? lds + kSyncDHalo + 2 * wave + hf
+                             : lds + kDDummy + 176 + lane);
+    const unsigned arrive_addr =
+        lds_addr(lane == 0 ? lds + kSyncDTiles : lds + kDDummy + 176 + 64 + lane);
+    const f4* tab4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);
+    const unsigned bias_addr = lds_addr(lds + kParams + 4 * q);
+    constexpr int B8 = bias_offset(7) - kTabBias0, B9 = bias_offset(8) - kTabBias0;
+    static_assert(B8 % 4 == 0 && B9 % 4 == 0 && (bn_scale_offset(3) - kTabBn0) % 4 == 0 &&
+                  bn_scale_offset(4) == kTabBn1, "");
+    const bool wave_hi = wave >= 4;
+    // the edge rows of conv1d_7's output to the partner wave (the loads above have landed: the
+    // compiler waits in front of the first use)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            asm volatile("ds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %1, %3 offset:%4"
+                         :
+                         : "v"(a0_addr[0]), "v"(a3_addr[0]), "v"(Y[g][h][0]), "v"(Y[g][h][3]),
+                           "n"((16 * g + 2 * h) * 4)
+                         : "memory");
+    halo_post(post_addr);
+    mark(ts, 26);
+    W43U U;
+    f4 acc[2][6];
+    // half h of the epilogue of tile g of conv8: outputs to Y, the edge rows to the partner, post
+    auto finish = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
+        constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        w43t_outputs<h>(a, Y[g][h]);
+        asm volatile("ds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %1, %3 offset:%4"
+                     :
+                     : "v"(a0_addr[1]), "v"(a3_addr[1]), "v"(Y[g][h][0]), "v"(Y[g][h][3]),
+                       "n"((16 * g + 2 * h) * 4)
+                     : "memory");
+        if constexpr (h == 1) halo_post(post_addr);
+    };
+    // half h of the epilogue of tile g of conv9: outputs, MaxPool2, BN4 -> X rows 1 + 32 hf + 2n + p,
+    // channels 16g + 4q + 2h, + 1: window 0's in LDS, the others' in their parks
+    lds_f2* x_lds = (lds_f2*)lds_pinned(lds + kEX + (1 + 32 * hf + 2 * n) * kS48 + 4 * q);
+    float* x_park = wg_scratch + kWgParkXOff + k * kParkXFloats + (1 + 32 * hf + 2 * n) * kS48 + 4 * q;
+    auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
+        constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
+        f2 y[4];
+        w43t_outputs<h>(a, y);
+        const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(3) - kTabBn0)) / 4 + 4 * g];
+        const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(3) - kTabBn0)) / 4 + 4 * g];
+        const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
+        const f2 x0 = __builtin_elementwise_fma(f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)}, sc, sh);
+        const f2 x1 = __builtin_elementwise_fma(f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)}, sc, sh);
+        if (k == 0) {
+            x_lds[(16 * g + 2 * h) / 2] = x0;
+            x_lds[(kS48 + 16 * g + 2 * h) / 2] = x1;
+        } else {
+            *reinterpret_cast<f2*>(x_park + 16 * g + 2 * h) = x0;
+            *reinterpret_cast<f2*>(x_park + kS48 + 16 * g + 2 * h) = x1;
+        }
+    };
+    const IntC<0> c0;
+    const IntC<1> c1;
+    const IntC<2> c2;
+    unsigned pk_a = 0;
+    u2 pk_h = u2{0u, 0u};
+    const float* w8 = packed + weight_offset(7);
+    const float* w9 = packed + weight_offset(8);
+    const float* we = packed + weight_offset(9);        // conv10 .. conv14, contiguous
+    static_assert(weight_offset(14) - weight_offset(9) == kEWLowEnd - kEW10, "");
+
+    // ---- conv8.  Tile 0 builds U from Y and the partner's edge rows.
+    halo_wait<kSyncDHalo>(lds, wave, halos0 + 1);
+    w43t_tile<0, 0, 18, B8, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS0 + lane * 4, acc[1], wave_hi, NoPre(), [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            // conv8's third 2 -> slot 2, conv9's third 0 -> slot 3 (conv1d_7's N tiles 1 and 2 lay there)
+            if constexpr (SP < 3) copy_step(third_floats, w8 + 2 * kWinoHalf, lds + kDS2, SP);
+            else copy_step(third_floats, w9, lds + kDS3, SP - 3);
+        });
+    chain_arrive(arrive_addr, 0);
+    mark(ts, 27);
+    w43t_tile<-1, 6, 18, B8 + 16, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS1 + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) pk_a = chain_peek<kSyncDTiles>(lds, 0);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) finish(c0, c0, acc[1]);
+            if constexpr (SP == 3) finish(c0, c1, acc[1]);
+        });
+    chain_arrive(arrive_addr, 1);
+    mark(ts, 28);
+    // slots 2 and 3 have landed (requested in tile 0), and every wave has left slot 0
+    chain_check<kSyncDTiles>(lds, 0, pk_a, tiles0 + 8);
+    w43t_tile<-1, 12, 18, B8 + 32, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS2 + lane * 4, acc[1], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) {
+                pk_a = chain_peek<kSyncDTiles>(lds, 1);
+                pk_h = halo_peek<kSyncDHalo>(lds, wave);
+            }
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) finish(c1, c0, acc[0]);
+            if constexpr (SP == 3) finish(c1, c1, acc[0]);
+            // conv9's third 1 follows conv8's third 0 out of slot 0; conv15 (12 pieces) to its home
+            if constexpr (SP < 3) copy_step(third_floats, w9 + kWinoHalf, lds + kDS0, SP);
+            else copy_step(IntC<conv_weight_floats(14)>{}, packed + weight_offset(14), lds + kEW15, SP - 3);
+        });
+    chain_arrive(arrive_addr, 2);
+    mark(ts, 29);
+
+    // ---- conv9 + MaxPool + BN4.  Tile 2 of conv8 is finished inside the first two steps.
+    halo_check<kSyncDHalo>(lds, wave, pk_h, halos0 + 3);
+    w43t_tile<kDHaloLayer, 0, 18, B9, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS3 + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            // slot 1: every wave has left conv8's tile 1
+            if constexpr (SP == 0) chain_check<kSyncDTiles>(lds, 1, pk_a, tiles0 + 8);
+            if constexpr (SP == 2) pk_h = halo_peek<kSyncDHalo>(lds, wave);
+            if constexpr (SP == 3) halo_check<kSyncDHalo>(lds, wave, pk_h, halos0 + 4);
+            if constexpr (SP == 5) pk_a = chain_peek<kSyncDTiles>(lds, 2);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 0) finish(c2, c0, acc[1]);
+            if constexpr (SP == 1) finish(c2, c1, acc[1]);
+            // conv9's third 2 follows conv8's third 1 out of slot 1; then conv10 .. conv14 (36 pieces,
+            // nine per wave) to their stage-E home - where the group's last window had its conv7
+            // output until its two waves read it (before their arrival behind tile 0, which every
+            // wave has seen by now)
+            if constexpr (SP < 3) copy_step(third_floats, w9 + 2 * kWinoHalf, lds + kDS1, SP);
+            else copy_step(IntC<kEWLowEnd - kEW10>{}, we, lds + kEW10, SP - 3);
+        });
+    chain_arrive(arrive_addr, 3);
+    mark(ts, 30);
+    chain_check<kSyncDTiles>(lds, 2, pk_a, tiles0 + 8);      // conv9's third 1 has landed in slot 0
+    w43t_tile<-1, 6, 18, B9 + 16, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS0 + lane * 4, acc[1], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) pk_a = chain_peek<kSyncDTiles>(lds, 3);
+        },
+        [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) store(c0, c0, acc[0]);
+            if constexpr (SP == 3) store(c0, c1, acc[0]);
+            if constexpr (SP < 2) copy_step(IntC<kEWLowEnd - kEW10>{}, we, lds + kEW10, SP + 3);
+        });
+    mark(ts, 31);
+    chain_check<kSyncDTiles>(lds, 3, pk_a, tiles0 + 8);      // conv9's third 2 has landed in slot 1
+    w43t_tile<-1, 12, 18, B9 + 32, 0, 1>(
+        U, Y, h_addr, bias_addr, lds + kDS1 + lane * 4, acc[0], wave_hi, NoPre(), [&](auto tag) {
+            constexpr int SP = decltype(tag)::value;
+            if constexpr (SP == 1) store(c1, c0, acc[1]);
+            if constexpr (SP == 3) store(c1, c1, acc[1]);
+        });
+    store(c2, c0, acc[0]);
+    store(c2, c1, acc[0]);
+    // the two zero rows of window 0's image ('same' padding of the inception block's k = 3 layers)
+    if (k == 0 && lane < kS48) lds[kEX + (hf ? 65 * kS48 : 0) + lane] = 0.f;
+    mark(ts, 32);
+    // X of window 0 is out, the parks' stores are out, conv10 .. conv15 have landed
+    full_barrier();
+    mark(ts, 33);
+}
+
 struct NoBetween {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -2018,12 +2161,24 @@ __device__ __forceinline__ void w43_partial_outputs(const f4 (&acc)[6], int h, f
     y[3] = __builtin_elementwise_fma(k8, d34, d12) + a5;
 }
 
-// One wave's half (HIGH = wave >= 4) of conv7.  begin(): the layer's one-off LDS-DMA requests.
-template <int CONV, int BNI, bool HIGH, class Begin>
+// One wave's half (HIGH = wave >= 4) of conv7.  side(G): the caller's LDS-DMA requests behind the
+// MFMAs of step G (0..5: before the mid-layer barrier; 6..8: behind it, when N tiles 0 and 2 of the
+// layer's own weights - slots 0 and 2 - are free).
+//   LAST = false: park = this window's park in global memory; the layer ends with an LDS-only
+// barrier - its stores, and the caller's requests, are still on their way: the caller retires them
+// (a full barrier) before anything reads what they bring.
+//   LAST = true (the group's last window, which stage D follows at once): the output goes to the
+// same layout in LDS (kPark7Lds: rows of the input image every wave has read by the mid-layer
+// barrier) and the layer ends with a full barrier, which then has nothing slow to wait for.
+//   after(): the caller's requests behind the layer's last MFMAs (U and the pipeline are dead: ~120
+// free registers); returns how many of them - the wave's newest - may still be in flight behind
+// the LAST form's closing barrier.
+template <int CONV, int BNI, bool HIGH, bool LAST, class Side, class After>
 __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restrict__ packed,
-                                                int tid, int lane, int wave, unsigned* ts,
-                                                int ts_base, unsigned& pair_rounds,
-                                                const Begin& begin) {
+                                                float* __restrict__ park, int tid, int lane,
+                                                int wave, unsigned* ts, int ts_base,
+                                                unsigned& pair_rounds, const Side& side,
+                                                const After& after) {
     constexpr int TOWN = HIGH ? 2 : 0, SP0 = HIGH ? DBH_CONV7_LOW : 0;
     const int n = lane & 15, q = lane >> 4;
     const int m = wave & 3;
@@ -2033,27 +2188,32 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
     const int pm_n = 2 * (n >> 2) + (n & 1) + 8 * ((n >> 1) & 1);
     const unsigned a_addr = lds_addr(lds + kActOff + (m * 64 + 4 * pm_n) * kS48 + 2 * q);
     const unsigned b_addr = lds_addr(lds + kSlot0 + lane * 4);
-    // this lane's place in the (pooled) output of quad m*16 + 2q
-    lds_float* out_q = lds_pinned(lds + kActOff + n + (1 + 2 * (m * 16 + 2 * q)) * kS48);
+    // this lane's place in the park: pooled row 0 of quad m*16 + 2q, channel n of N tile 0
+    const int park_off = (m >> 1) * 3072 + ((n >> 2) * 16 + (m & 1) * 8 + q) * 4 + (n & 3);
+    typedef typename std::conditional<LAST, lds_float*, float*>::type ParkPtr;
+    ParkPtr park_lane;
+    if constexpr (LAST) park_lane = lds_pinned(lds + kPark7Lds + park_off);
+    else park_lane = park + park_off;
+    (void)tid;
     float* mine = lds + kX7 + wave * 512 + lane * 4;
     const float* theirs = lds + kX7 + (wave ^ 4) * 512 + lane * 4;
     W43U U;
     W43nsPipe pipe;
     f4 own[6], shared[6];
-    w43ns_step<TOWN, SP0, !HIGH, 0>(U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1],
-                                    [&](auto tag) {
-                                        if constexpr (decltype(tag)::value == 0) begin();
-                                    });
+    w43ns_step<TOWN, SP0, !HIGH, 0>(U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1], side);
     mark(ts, ts_base);
-    lds_barrier();        // every wave has read all its input rows: outputs may go in place
+    // every wave has read all its input rows, and is through with N tiles 0 and 2 of the weights:
+    // the exchange below may use those rows, side(6..8) those slots
+    lds_barrier();
     mark(ts, ts_base + 1);
-    zero_row(lds + kActOff, 129, kS48, 48, tid);       // (row 0 is zero already)
     w43ns_step<TOWN, SP0, !HIGH, 6>(
         U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1], [&](auto tag) {
             constexpr int G = decltype(tag)::value;
-            if constexpr (G == 6) w43_epilogue_half<TOWN, true, true>(own, 0, ep.sc[TOWN], ep.sh[TOWN], out_q);
-            if constexpr (G == 7) w43_epilogue_half<TOWN, true, true>(own, 1, ep.sc[TOWN], ep.sh[TOWN], out_q);
+            side(tag);
+            if constexpr (G == 6) w43_epilogue_half_park<TOWN, ParkPtr>(own, 0, ep.sc[TOWN], ep.sh[TOWN], park_lane);
+            if constexpr (G == 7) w43_epilogue_half_park<TOWN, ParkPtr>(own, 1, ep.sc[TOWN], ep.sh[TOWN], park_lane);
         });
+    const bool in_flight = after();
     // the shared N tile: the partial outputs of this wave's three channel groups
     f2 y[2][4];
     w43_partial_outputs(shared, 0, y[0]);
@@ -2064,7 +2224,7 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
     *reinterpret_cast<f4*>(mine + 256) =
         f4{y[0][kShip + 1].x, y[0][kShip + 1].y, y[1][kShip + 1].x, y[1][kShip + 1].y};
     pair_signal(lds, 2 * m + (HIGH ? 1 : 0), lane);
-    mark(ts, ts_base + 2);
+    if constexpr (!LAST) mark(ts, ts_base + 2);
     pair_wait(lds, 2 * m + (HIGH ? 0 : 1), pair_rounds + 1);
     pair_rounds += 1;
     const f4 t0 = *reinterpret_cast<const f4*>(theirs);
@@ -2078,122 +2238,34 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
             const float yb = y[h][kKeep + 1][e] + t1[2 * h + e];
             float p = fmaxf(fmaxf(ya, yb), 0.f);       // ReLU, then MaxPool over the two positions
             p = fmaf(p, sc, sh);
-            // quad offset e + 8h from the lane's first (pm(4q + 2h + e)); pooled row HIGH ? 1 : 0
-            out_q[(2 * (e + 8 * h) + (HIGH ? 1 : 0)) * kS48 + 16] = p;
+            // quad offset e + 8h from the lane's first (pm(4q + 2h + e)); pooled row 2e + (HIGH ? 1 : 0)
+            park_lane[(2 * e + (HIGH ? 1 : 0)) * 768 + 256 + h * 16] = p;
         }
-    full_barrier();
-    mark(ts, ts_base + 3);
+    if constexpr (LAST) {
+        // (the weights stage D's first tiles read have landed: requested before after()'s twelve
+        // loads, and loads return in order; this form has no stores in flight)
+        if (in_flight) lds_barrier<12>();
+        else full_barrier();
+    } else {
+        lds_barrier();
+    }
+    mark(ts, LAST ? ts_base + 2 : ts_base + 3);      // (the LAST form is stamped 59, 60, 61)
 }
 
-template <int CONV, int BNI, class Begin>
+struct NoAfter {
+    __device__ __forceinline__ bool operator()() const { return false; }
+};
+template <int CONV, int BNI, bool LAST, class Side, class After = NoAfter>
 __device__ __forceinline__ void w43_nsplit_pooled_layer(float* lds, const float* __restrict__ packed,
-                                                        int tid, int lane, int wave, unsigned* ts,
-                                                        int ts_base, unsigned& pair_rounds,
-                                                        const Begin& begin) {
+                                                        float* __restrict__ park, int tid, int lane,
+                                                        int wave, unsigned* ts, int ts_base,
+                                                        unsigned& pair_rounds, const Side& side,
+                                                        const After& after = After()) {
     static_assert(kConv[CONV].wino == 4 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
     if (wave < 4)
-        w43_nsplit_half<CONV, BNI, false>(lds, packed, tid, lane, wave, ts, ts_base, pair_rounds, begin);
+        w43_nsplit_half<CONV, BNI, false, LAST>(lds, packed, park, tid, lane, wave, ts, ts_base, pair_rounds, side, after);
     else
-        w43_nsplit_half<CONV, BNI, true>(lds, packed, tid, lane, wave, ts, ts_base, pair_rounds, begin);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same Winograd layer at L = 128, where there are only four 16-pair tiles for eight waves:
-// wave w takes tile w&3 and ONE half of the transform pair (w < 4: M0,M1 from V0,V1; w >= 4:
-// M2,M3 from V2,V3), 72 MFMAs each, and partner waves (w, w+4) swap what the other needs
-// through XCHG before the fused epilogue:
-//   no pooling: the low wave finishes the even positions (M0+M1+M2), the high wave the odd
-//               ones (M1-M2-M3);
-//   pooling   : max(even, odd) needs both in one lane, so the high wave ships M2 and M2+M3 and
-//               the low wave finishes the tile alone.
-// The exchange write precedes the barrier that also ends the activation reads, so the layer
-// still costs two barriers.
-// ---------------------------------------------------------------------------------------------
-template <int CONV, bool POOL, int BNI, int SLOT_A, int SLOT_B, int XCHG, class Side,
-          class StepSide = NoSide>
-__device__ __forceinline__ void wino_split_layer(float* lds, const float* __restrict__ packed,
-                                                 int tid, int lane, int wave, unsigned* ts,
-                                                 int ts_base, const Side& side,
-                                                 const StepSide& step_side = StepSide()) {
-    static_assert(kConv[CONV].wino == 2 && kConv[CONV].cin == 48 && kConv[CONV].cout_pad == 48, "");
-    constexpr int L = 128;
-    constexpr int LOUT = POOL ? L / 2 : L;
-    constexpr bool BN = BNI >= 0;
-    const int n = lane & 15, q = lane >> 4;
-    const int m = wave & 3;
-    const bool high = wave >= 4;
-
-    side();
-    EpiParams<3, BN> ep;
-    load_epi<CONV, BNI>(ep, lds, packed, n);
-    f4 acc[4][1][3];      // (+bias rides in M0 - even outputs -, -bias in M3 - odd: wino_step)
-    const float* a_lane = lds + kActOff + (m * 32 + 2 * n) * kS48 + 2 * q;
-    float* mine = lds + XCHG + (wave & 3) * 6 * 256 + lane * 4;     // slot shared by the pair
-    if (ts_base == 26) mark(ts, 48);
-    if (!high) {
-        wino_phase<1, 0>(a_lane, lds + SLOT_A + lane * 2, acc, ep.b, step_side);
-        if (ts_base == 26) mark(ts, 50);
-        if (!POOL) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(mine + t * 256) = acc[1][0][t];
-        }
-    } else {
-        wino_phase<1, 1>(a_lane, lds + SLOT_B + lane * 2, acc, ep.b, step_side);
-        if (ts_base == 26) mark(ts, 50);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            *reinterpret_cast<f4*>(mine + (3 + t) * 256) = acc[2][0][t];
-            if (POOL) *reinterpret_cast<f4*>(mine + t * 256) = acc[2][0][t] + acc[3][0][t];
-        }
-    }
-    mark(ts, ts_base);
-
-    lds_barrier();        // activations fully read; exchange tiles visible
-    mark(ts, ts_base + 1);
-
-    float* out = lds + kActOff + n;
-    if (!POOL) {
-        // low wave: even positions from M0+M1 (+M2 from the partner); high wave: odd positions
-        // from -(M2+M3) (+M1 from the partner)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float sc = ep.sc[t], sh = ep.sh[t];
-            f4 y;
-            if (!high)
-                y = acc[0][0][t] + acc[1][0][t] + *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
-            else
-                y = *reinterpret_cast<const f4*>(mine + t * 256) - acc[2][0][t] - acc[3][0][t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(y[r], 0.f);
-                if (BN) v = fmaf(v, sc, sh);
-                const int j = m * 16 + 4 * q + r;
-                out[(1 + 2 * j + (high ? 1 : 0)) * kS48 + t * 16] = v;
-            }
-        }
-    } else if (!high) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float sc = ep.sc[t], sh = ep.sh[t];
-            const f4 m2 = *reinterpret_cast<const f4*>(mine + (3 + t) * 256);
-            const f4 m23 = *reinterpret_cast<const f4*>(mine + t * 256);
-            const f4 even = acc[0][0][t] + acc[1][0][t] + m2;
-            const f4 odd = acc[1][0][t] - m23;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o = fmaxf(fmaxf(even[r], odd[r]), 0.f);
-                if (BN) o = fmaf(o, sc, sh);
-                const int j = m * 16 + 4 * q + r;
-                out[(1 + j) * kS48 + t * 16] = o;
-            }
-        }
-    }
-    zero_row(lds + kActOff, 0, kS48, 48, tid);
-    zero_row(lds + kActOff, LOUT + 1, kS48, 48, tid);
-    mark(ts, ts_base + 2);
-
-    full_barrier();  
-    mark(ts, ts_base + 3);
+        w43_nsplit_half<CONV, BNI, true, LAST>(lds, packed, park, tid, lane, wave, ts, ts_base, pair_rounds, side, after);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2267,7 +2339,7 @@ struct SmallMRegs {
 template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false,
           class PreBarrier = NoHook, class PostBarrier = NoHook, class Between = NoBetween>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
-                                              const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
+                                              float* red, const SmallMRegs<CONV, KS, NTW, BN>& regs, int lane,
                                               int wave, unsigned* ts, int ts_base,
                                               const PreBarrier& pre_barrier = PreBarrier(),
                                               const PostBarrier& post_barrier = PostBarrier(),
@@ -2311,7 +2383,7 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         if (wave < R::ACTIVE) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                *reinterpret_cast<f4*>(lds + kRed + (wave * 3 + t) * 256 + lane * 4) = acc[0][t];
+                *reinterpret_cast<f4*>(red + (wave * 3 + t) * 256 + lane * 4) = acc[0][t];
         }
         pre_barrier();
         mark(ts, ts_base);
@@ -2321,11 +2393,11 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         if (wave < 3) {
             const int t = wave;
             f4 sum[1][1];
-            sum[0][0] = *reinterpret_cast<const f4*>(lds + kRed + t * 256 + lane * 4);
+            sum[0][0] = *reinterpret_cast<const f4*>(red + t * 256 + lane * 4);
 #pragma unroll
             for (int ks = 1; ks < KS; ++ks)
                 sum[0][0] +=
-                    *reinterpret_cast<const f4*>(lds + kRed + (ks * 3 + t) * 256 + lane * 4);
+                    *reinterpret_cast<const f4*>(red + (ks * 3 + t) * 256 + lane * 4);
             if constexpr (TO_GLOBAL) {
                 static_assert(!POOL, "");
                 epilogue<1, 1, 48, false, BN>(sum, out_region + 4 * q * 48 + t * 16 + n, regs.ep);
@@ -2636,15 +2708,19 @@ struct ForwardArgs {
     const long long* offsets;    //          read r = samples[offsets[r] .. offsets[r+1])
     int* calls;                  //          barcode calls (one scan step per read), or null
     float* tail_scratch;         // [grid][kTailBatch][16][48]: conv17 outputs parked per workgroup
-    int* win_counter;            // null: workgroup b walks windows b, b + grid, ...; else every
-                                 // workgroup takes its next window off this counter (0 between
-                                 // launches: the last taker of a launch resets it)
+    int* win_counter;            // null: workgroup b walks groups b, b + grid, ...; else every
+                                 // workgroup takes its next group of windows off this counter;
+                                 // [1] counts the workgroups that have finished (both 0 between
+                                 // launches: the last workgroup of a launch resets them)
     long long* clock_out;        // [grid][4] or null: shader clock and 100 MHz clock at a
                                  // workgroup's start and end (dbh_forward_clock_read)
     double score_diff;
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
     int n_classes, debug_stage, steps, side;
+    // windows not yet handed out below which a workgroup asks for groups of 2 / of 1 instead of
+    // kGroup (the end of a launch: dbh_forward_kernel)
+    int chunk4_min_left, chunk2_min_left;
 };
 
 // Window statistics, step 1: exact integer sums of this lane's two samples, sum(x) and sum(x^2)
@@ -2730,7 +2806,8 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     };
     const float* __restrict__ packed_entry = glob(args()->packed);
     const int debug_stage = args()->debug_stage;
-    const long long n_windows = args()->n_windows;
+    // (window indices fit 32 bits: the host launches at most 2^20 reads at a time)
+    const int n_windows = (int)args()->n_windows;
     // (the two pointers every window's first instructions branch on: read once - a scalar load at
     // the top of a window is ~200 cycles that every wave spends in front of the first barrier)
     const int16_t* const samples_entry = glob(args()->samples);
@@ -2768,28 +2845,52 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             bw_a[g] = (q_e < 3) ? packed_entry[weight_offset(0) + q_e * 48 + g * 16 + n_e] : 0.f;
     }
     unsigned chain_windows = 0;   // windows this workgroup has taken through stage B (stage_b_chain)
+    unsigned d_groups = 0;        // groups it has taken through stage D (stage_d_chain)
     int tail_slot = 0;            // windows of this workgroup waiting for the batched tail
     unsigned pair_rounds = 0;     // exchanges the wave pairs of conv7 have made so far
 
-    // Seam-b2 input of the window in hand: this lane's two samples for the statistics and the six
-    // samples its conv1d_1 products take (kOutside = not in the window).  Filled by fetch(): for a
-    // workgroup's first window at the top of stage A, for every later one at the top of stage E of
-    // the window before it (see there), so that only the first fetch of a launch is exposed.
-    int in_cnt = 0, in_v0 = 0, in_v1 = 0, in_raw[6] = {};
-    bool prefetched = false;
-    bool thirds_ahead = false;    // slots 1 and 2 of conv2's weights requested under the window before
+    // This workgroup's scratch in global memory (dbh_layout.h: kWgScratchFloats): conv17's outputs
+    // waiting for the batched tail, conv7's parks, X's parks - whose zero rows (the 'same' padding of
+    // the inception block's k = 3 layers: rows 0 and 65 of each image) are written once per launch.
+    float* const wg_scratch_entry = glob(args()->tail_scratch) + (size_t)blockIdx.x * kWgScratchFloats;
+    for (int i = tid_entry; i < kGroup * 2 * kS48; i += kThreads) {
+        const int kk = i / (2 * kS48), r = (i / kS48) & 1, c = i % kS48;
+        wg_scratch_entry[kWgParkXOff + kk * kParkXFloats + (r ? 65 * kS48 : 0) + c] = 0.f;
+    }
 
-    // PERSISTENT GRID: the launch has at most one workgroup per CU (what 160 KiB of LDS allows
-    // anyway) and workgroup b walks windows b, b + gridDim.x, ... - no launch per batch, no cold
-    // start per window.
-    // WINDOWS OFF A COUNTER (win_counter != null, production launches): the first window of
-    // workgroup b is b, every further one is grid + what atomicAdd returns - a workgroup that
-    // gets its CU late (another kernel sat there: the inflate kernels of the streaming path)
-    // or runs slower (samples read over PCIe) simply takes fewer, instead of finishing its
-    // fixed share late.  Fetched by one lane at the top of a window, known at the end of stage A.
-    long win_after = 0;
-    bool first_window = true;
-    for (long win = blockIdx.x; win < n_windows; win = win_after, first_window = false) {
+    // PERSISTENT GRID, GROUPS OF WINDOWS: the launch has at most one workgroup per CU (what 160 KiB
+    // of LDS allows anyway).  A workgroup takes kGroup = 4 consecutive windows at a time: stages A,
+    // B, C for each of them (conv7's output parked in global memory), stage D once for the four
+    // together (stage_d_chain), then stages E and F for each, and every second group the batched
+    // tail.  The first group of workgroup b is windows 4b ..; every further one comes off a counter
+    // in global memory (win_counter != null, production launches; asked for by one lane in the
+    // group's first stage A, known behind its stage B) - a workgroup that gets its CU late (another
+    // kernel sat there: the inflate kernels of the streaming path) or runs slower (samples read
+    // over PCIe) simply takes fewer.  Towards the end of a launch the groups shrink (two windows,
+    // then one: chunk4_min_left / chunk2_min_left windows not yet handed out), so that the
+    // workgroups finish within a window's time of each other, not within a group's.
+    int group_start = (int)blockIdx.x * kGroup;
+    int group_n = n_windows - group_start >= kGroup ? kGroup : n_windows - group_start;
+    bool first_group = true;
+    bool staged = false;          // this group's samples and statistics wait in the LDS staging
+    bool thirds_ahead = false;    // slots 1 and 2 of conv2's weights requested under the group before
+    // debug_stage >= 0 (tests, timeline): the batched tail runs behind every group
+    const bool tail_every_group = debug_stage >= 0;
+
+    while (group_n > 0) {
+    // how many windows the NEXT group asks for: by what was left when this one was handed out
+    const int left_now = n_windows - (group_start + group_n);
+    const int chunk_next = win_counter_entry == nullptr             ? kGroup
+                           : left_now >= args()->chunk4_min_left ? kGroup
+                           : left_now >= args()->chunk2_min_left ? 2
+                                                                 : 1;
+    // (fixed shares - debug and timeline launches: groups b, b + grid, ...)
+    int next_start = group_start + kGroup * (int)gridDim.x;
+    int next_n = n_windows - next_start <= 0 ? 0
+                 : n_windows - next_start < kGroup ? n_windows - next_start : kGroup;
+
+    // ================= stages A, B, C: one window of the group after the other ==================
+    for (int k = 0; k < group_n; ++k) {
     // The thread index and the parameter pointer are made opaque once per round: otherwise the
     // loop-invariant-code pass hoists every lane address and constant of the (fully unrolled)
     // body out of the loop and keeps them alive across it - 245 spilled VGPRs instead of none.
@@ -2797,18 +2898,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     asm volatile("" : "+v"(tid));
     const __attribute__((address_space(1))) float* packed_opaque =
         (const __attribute__((address_space(1))) float*)packed_entry;
-    asm volatile("" : "+s"(packed_opaque));
+    __attribute__((address_space(1))) float* scratch_opaque =
+        (__attribute__((address_space(1))) float*)wg_scratch_entry;
+    asm volatile("" : "+s"(packed_opaque), "+s"(scratch_opaque));
     const float* __restrict__ packed = (const float*)packed_opaque;
+    float* const wg_scratch = (float*)scratch_opaque;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
+    const int win = group_start + k;
     // 300: timeline mode - lane 0 of every wave stamps the cycle counter at each phase boundary
     unsigned ts_acc = 0u;
     unsigned* ts = nullptr;
     long long* ts_out = nullptr;
     if (debug_stage >= 300) {                   // 301: the same in a persistent launch
         ts = &ts_acc;
-        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + (win * kWaves + wave) * 64;
+        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + ((long)win * kWaves + wave) * 64;
     }
     mark(ts, 0);
     mark_realtime(ts, 62);
@@ -2825,17 +2930,22 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // ... has no phase of its own: the wave that owns a tile of conv1d_2's quads computes the
     // conv1d_1 rows they need inside conv1d_2's tile 0, in registers (w43a_tile0).  What is left
     // here: this lane's six samples of the window, normalised.
-    //   Steady state (seam b2, second window of a workgroup onwards): the samples were fetched and
-    // their statistics taken under the window before (stages E, F), and the first third of
-    // conv1d_2's weights has been on its way to slot 0 since that window's stage F - ONE barrier
-    // publishes all of it and keeps this window's stores off the LDS that window still reads; the
-    // other two thirds are requested between conv1d_1's MFMAs and land before the mid-layer barrier.
-    //   Cold (a workgroup's first window; every window of seam b1): everything is asked for here,
-    // behind the barrier of the window statistics, and a second barrier waits for the weights.
+    //   Steady state (seam b2, second group of a workgroup onwards): the window's samples and
+    // statistics wait in the LDS staging (fetched under the group before: stages E, F).  For the
+    // group's first window the first third of conv1d_2's weights has been on its way to slot 0 since
+    // that group's last stage F and ONE barrier publishes it and hands the LDS over; for the others
+    // thirds 0 and 2 landed under conv7 of the window before (slots 0 and 2 are free behind its
+    // mid-layer barrier; its closing barrier retired them) and there is NO barrier at all.  What is
+    // missing of the thirds is requested between conv1d_1's MFMAs.
+    //   Cold (a workgroup's first group; every window of seam b1): the samples are asked for here,
+    // behind the barrier of the window statistics, and for the group's first window a second
+    // barrier waits for the weights.
     ConvAIn in_a;
-    bool cold;
+    bool weights_cold = false;
+    int thirds_mode = 0;      // conv2's thirds tile 0 still has to request: 1 = third 1, 2 = thirds 1 and 2
     // the zero rows of stage B's halo arrays ('same' padding at the two ends of the window; the
-    // place is taken by other stages' weights in between): published by the barriers below
+    // place is taken by other stages' weights in between): published by the arrivals of stage B's
+    // first tiles (every wave's, behind its LDS stores), long before conv3 reads them
     if (tid < 192) {
         const int a = tid / 48, c = tid - a * 48;
         lds[kHalo + (a >> 1) * 2 * kHaloRows + ((a & 1) ? kHaloRows + 48 : 8 * 96) + c] = 0.f;
@@ -2848,19 +2958,19 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             dma_weights<3 * kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave);
         };
         const int16_t* __restrict__ samples = (const int16_t*)smp_opaque;
-        cold = samples == nullptr || !prefetched;
-        // (the registers the samples were prefetched into, looked at once on every path: this is
-        // where hipcc's wait-count pass learns that those loads have landed.  Without it they
-        // are "pending" around the loop, and the first load of the NEXT prefetch - at the top of
-        // stage E, right behind an LDS-DMA request - waits for everything outstanding: one L2
-        // round trip per window.  Here the wait is free: the barriers below wait anyway.)
-        asm volatile("" : "+v"(in_v0), "+v"(in_v1), "+v"(in_raw[0]), "+v"(in_raw[1]),
-                          "+v"(in_raw[2]), "+v"(in_raw[3]), "+v"(in_raw[4]), "+v"(in_raw[5]));
+        // (debug_stage 0 / 1 leave stage B half-way, conv7 - under which a group's later windows
+        // get their weights - does not run: every window starts cold)
+        const bool stop_early = stop_stage == 0 || stop_stage == 1;
         if (samples == nullptr) {
-            // a later window of this workgroup: the window before it may still be read (stage H)
-            if (!first_window) full_barrier();
-            fetch_conv2_weights();
-            const float* xw = glob(args()->x) + win * kWindow;
+            if (k == 0 || stop_early) {
+                // a later group of this workgroup: the group before may still be read (stage H)
+                if (!first_group || k > 0) full_barrier();
+                fetch_conv2_weights();
+                weights_cold = true;
+            } else {
+                thirds_mode = 1;
+            }
+            const float* xw = glob(args()->x) + (long)win * kWindow;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int idx = 8 * j - 2 + 2 * t + q;            // q = tap (3 = zero column)
@@ -2868,7 +2978,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             }
         } else {
             // fused slice + normalise (same arithmetic as dbh_normalise_kernel)
-            if (!prefetched) {
+            double mean, inv;
+            int in_raw[6];
+            if (!staged) {
+                int in_cnt = 0, in_v0 = 0, in_v1 = 0;
                 ArgsPtr a = args();
                 const int steps = a->steps, side = a->side;
                 const long long read0 = a->read0, len_hint = a->len_hint, hint_cap = a->hint_cap;
@@ -2890,22 +3003,37 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 if (!speculate || base != guess || len != len_hint)
                     fetch_window(samples, base, len, step, side, tid, j, q, in_cnt, in_v0, in_v1,
                                  in_raw);
-            }
-            double mean, inv;
-            if (!prefetched) {
                 window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
                 full_barrier();
-                fetch_conv2_weights();
+                if (k == 0 || stop_early) {
+                    fetch_conv2_weights();
+                    weights_cold = true;
+                } else {
+                    thirds_mode = 1;
+                }
                 window_mean_inv(lds, in_cnt, &mean, &inv);
             } else {
-                // the sums were taken and turned into mean and 1/std while the window before ran
-                // its conv17 (stage F below); this barrier publishes them, retires slot 0's
-                // weights - and keeps this window off the LDS that window's last reads still use
-                full_barrier();
-                mark(ts, 51);
-                const double* stats = reinterpret_cast<const double*>(lds + kStatOut);
-                mean = stats[0];
-                inv = stats[1];
+                if (k == 0) {
+                    // publishes slot 0's weights (asked for in the last stage F of the group
+                    // before) and keeps this group off the LDS that group's last reads still use
+                    full_barrier();
+                    mark(ts, 51);
+                    thirds_mode = thirds_ahead ? 0 : 2;
+                } else {
+                    thirds_mode = 1;
+                }
+                const float* st = lds + kStageStats + k * 8;
+                mean = reinterpret_cast<const double*>(st)[0];
+                inv = reinterpret_cast<const double*>(st)[1];
+                const int cnt = reinterpret_cast<const int*>(st)[4];
+                const int pad = reinterpret_cast<const int*>(st)[5];
+                const short* smp = reinterpret_cast<const short*>(lds + kStage + k * kStageWin);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int i = 8 * j - 2 + 2 * t + q - pad;
+                    const bool inside = q < 3 && i >= 0 && i < cnt;
+                    in_raw[t] = inside ? (int)smp[inside ? i : 0] : kOutside;
+                }
             }
             inv *= (double)kActScale;      // (exact; see kActScale)
 #pragma unroll
@@ -2913,10 +3041,10 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 in_a.xs[t] = in_raw[t] != kOutside ? (float)(((double)in_raw[t] - mean) * inv) : 0.f;
             mark(ts, 54);
         }
-        // (the next window's number: asked for behind the barriers above - they wait for every
-        // outstanding request - and needed behind conv1d_2's mid-layer barrier)
-        if (win_counter != nullptr && tid == 0) taken = atomicAdd(win_counter, 1);
-        if (cold) full_barrier();     // conv1d_2's weights have landed
+        // (the next group's first window: asked for behind the barriers above - they wait for every
+        // outstanding request - and needed behind stage B's closing barrier)
+        if (win_counter != nullptr && tid == 0 && k == 0) taken = atomicAdd(win_counter, chunk_next);
+        if (weights_cold) full_barrier();     // conv1d_2's weights have landed
 #pragma unroll
         for (int g = 0; g < 3; ++g) in_a.w[g] = bw_a[g];
         in_a.p4_edge = j == 0 ? f2{0.f, 0.f} : f2{4.f, 4.f};
@@ -2924,193 +3052,257 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         in_a.dump_on = debug_stage == 0;
         in_a.dump = nullptr;
         if (in_a.dump_on)
-            in_a.dump = glob(args()->debug_out) + win * kStageFloats[0] + 4 * j * 48 + 4 * q;
+            in_a.dump = glob(args()->debug_out) + (long)win * kStageFloats[0] + 4 * j * 48 + 4 * q;
         in_a.stop = stop_stage == 0;
         in_a.wave_hi = wave >= 4;
         in_a.dump_b = debug_stage == 1;
         mark(ts, 1);
     }
 
-    // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2 ------------------------------
+    // (a group's later windows: conv7 of the window before ended without waiting for its park's
+    // stores or for the weights asked for under it - they had this stage A's time to land)
+    if (k > 0) full_barrier();
+    // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2, conv5, conv6 ----------------
     // One chain in registers (stage_b_chain): nine Winograd F(4,3) tiles back to back, no
-    // workgroup barrier, no activation image between the layers.
-    // (kernel arguments the code behind stage B needs: read from the kernarg segment HERE, so that
-    // their scalar loads are long back when the hand-counted LDS waits begin - lgkmcnt counts
-    // scalar loads too, and the first wait of a tile would sit out their round trip)
-    const bool thirds_here_done = thirds_ahead;      // (requested in the window before: stage F)
-    const long long* __restrict__ offsets_arg = glob(args()->offsets);
-    const int steps_arg = args()->steps;
-    const int side_arg = args()->side;
-    const bool seam_b2 = smp_opaque != nullptr;
-    // In the steady state thirds 1 and 2 of conv2's weights are requested between conv1's first
-    // MFMAs, one piece after each (a request costs ~100 cycles of issue; 36 pieces = 4 or 5 per
-    // wave) - unless the window before has asked for them already.
+    // workgroup barrier, no activation image between the layers; conv5 and conv6 on its end.
     stage_b_chain(
-        lds, packed, tid, lane, wave, ts, chain_windows, in_a, !cold && !thirds_here_done,
+        lds, packed, tid, lane, wave, ts, chain_windows, in_a, thirds_mode != 0,
         [&](int i) {
-            if (!cold && !thirds_here_done && i < (2 * kWinoHalf / 256 + kWaves - 1) / kWaves)
+            // a request costs ~100 cycles of issue: one piece behind each of conv1's first MFMAs
+            if (thirds_mode == 2 && i < (2 * kWinoHalf / 256 + kWaves - 1) / kWaves)
                 dma_weights_one<2 * kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1,
                                                lane, wave, i);
+            if (thirds_mode == 1 && i < (kWinoHalf / 256 + kWaves - 1) / kWaves)
+                dma_weights_one<kWinoHalf>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane,
+                                           wave, i);
         },
         [&] {
             // (this wave's arrival has waited for the atomic's answer)
-            if (win_counter != nullptr && tid == 0) {
+            if (win_counter != nullptr && tid == 0 && k == 0)
                 reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
-                // n_windows numbers are taken per launch, whatever the grid: this was the last
-                if ((long long)taken == n_windows - 1) *win_counter = 0;
-            }
         },
-        [&] { return glob(args()->debug_out) + win * kStageFloats[1]; });
-    if (stop_stage == 0) return;      // (debug_stage 0: tile 0 has written the dump itself)
-    if (stop_stage == 1) return;      // (debug_stage 1: dumped from registers, conv5 did not run)
+        [&] { return glob(args()->debug_out) + (long)win * kStageFloats[1]; });
+    if (stop_stage == 0 || stop_stage == 1) {
+        // (debug_stage 0: tile 0 has written the dump itself; 1: dumped from registers, conv5 did
+        // not run.  The chain was left half-way: its counters start over for the next window.)
+        full_barrier();
+        if (tid < kSyncWords) reinterpret_cast<unsigned*>(lds + kSync)[tid] = 0u;
+        chain_windows = 0;
+        full_barrier();
+        continue;
+    }
+    // where this workgroup's NEXT GROUP starts: written by thread 0 early in stage B of the group's
+    // first window, published by that stage's closing barrier
+    if (k == 0 && win_counter != nullptr) {
+        next_start = kGroup * (int)gridDim.x + reinterpret_cast<const int*>(lds + kNextWin)[0];
+        const int left = n_windows - next_start;
+        next_n = left <= 0 ? 0 : left < chunk_next ? left : chunk_next;
+    }
 
-    // ---------------- stage C: conv5 (1x1 ->16), conv6, conv7 (L=256) + MaxPool + BN3 --------
-    // conv5's and conv6's weights sit side by side in the upper buffer (DMA'd during conv4),
-    // conv7's six Winograd matrices in the three slots.
-    // conv5's 16-channel output goes beside the activation buffer (kMid16: the upper buffer, idle
-    // until conv8's weights arrive during conv7) and conv6 brings it back: neither layer works in
-    // place, so neither needs the barrier between multiplying and storing.
-    // conv5 is a 1x1 convolution over exactly the rows a wave has just written (32 pooled
-    // positions = its two position tiles), its weights are complete once conv4's split barrier
-    // has been passed (every wave's DMA pieces landed before it arrived there): no workgroup
-    // barrier between conv4 and conv5.  Slot 2 - every wave has left conv4's tile 2 behind
-    // conv5's barrier - gets conv7's last third then.
-    // (conv5 and conv6 have run at the end of stage B's chain, on registers: stage_b_chain; its
-    // closing barrier has published conv6's rows and conv7's weights)
-    // where this workgroup's NEXT window starts: written by thread 0 early in stage B, published
-    // by that barrier, needed at the top of stage E
-    const long next_win = win_counter != nullptr
-                              ? (long)gridDim.x + (long)reinterpret_cast<const int*>(lds + kNextWin)[0]
-                              : win + (long)gridDim.x;
-    win_after = next_win;
-    const bool has_next = seam_b2 && next_win < n_windows;
-    // Its read's place in the sample buffer: two VECTOR loads (the address made per-lane on
-    // purpose) whose results nobody looks at before stage D.  As scalar loads they counted
-    // against lgkmcnt, and the first hand-counted LDS wait of the layer that follows sat out their
-    // whole L2 round trip.
+    // ---------------- stage C: conv7 (L=256, F(4,3)) + MaxPool + BN3 -> this window's park -----
+    // Meanwhile, thirds 0 and 2 of conv2's weights for the NEXT window -> slots 0 and 2, behind the
+    // mid-layer barrier (conv7's own N tiles 0 and 2 lay there); five pieces per requesting wave and
+    // third, two per step.  The layer ends with an LDS-only barrier: the park's stores and these
+    // requests are retired by the full barrier in front of the next window's stage B.
+    // (the group's last window: below, outside the loop)
+    if (k == group_n - 1) {
+        flush_marks(ts, ts_out, lane);
+        break;
+    }
+    {
+        auto third_step = [&](const float* src, float* dst, int step) {
+            constexpr int NW = DBH_DMA_WAVES;
+            constexpr int per_wave = (kWinoHalf / 256 + NW - 1) / NW;
+            if (2 * step < per_wave) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step);
+            if (2 * step + 1 < per_wave) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step + 1);
+        };
+        w43_nsplit_pooled_layer<6, 2, false>(
+            lds, packed, wg_scratch + kWgPark7Off + k * kPark7Floats, tid, lane, wave, ts, 22, pair_rounds,
+            [&](auto tag) {
+                constexpr int G = decltype(tag)::value;
+                if constexpr (G >= 6) {
+                    third_step(packed + weight_offset(1), lds + kSlot0, G - 6);
+                    third_step(packed + weight_offset(1) + 2 * kWinoHalf, lds + kSlot2, G - 6);
+                }
+            });
+    }
+    if (stop_stage == 2) {
+        full_barrier();      // (the park's stores are out)
+        if (debug_stage < 100) {
+            // (from the park, in the order stage D reads it)
+            float* out = glob(args()->debug_out) + (long)win * kStageFloats[2];
+            const float* pk = wg_scratch + kWgPark7Off + k * kPark7Floats;
+            for (int idx = tid; idx < 128 * 48; idx += kThreads) {
+                const int p = idx / 48, c = idx - p * 48;
+                const int hf = p >> 6, nn = (p >> 2) & 15, i = p & 3, g = c >> 4, qq = (c >> 2) & 3, r = c & 3;
+                out[idx] = pk[hf * 3072 + (i * 3 + g) * 256 + (qq * 16 + nn) * 4 + r] * kActUnscale;
+            }
+        }
+        continue;
+    }
+    flush_marks(ts, ts_out, lane);
+    }   // stages A, B, C of the group's windows
+
+    if (stop_stage != 0 && stop_stage != 1) {
+    // (opaque once per phase: see the top of the loop above)
+    int tid = tid_entry;
+    asm volatile("" : "+v"(tid));
+    const __attribute__((address_space(1))) float* packed_opaque =
+        (const __attribute__((address_space(1))) float*)packed_entry;
+    __attribute__((address_space(1))) float* scratch_opaque =
+        (__attribute__((address_space(1))) float*)wg_scratch_entry;
+    asm volatile("" : "+s"(packed_opaque), "+s"(scratch_opaque));
+    const float* __restrict__ packed = (const float*)packed_opaque;
+    float* const wg_scratch = (float*)scratch_opaque;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned ts_acc = 0u;
+    unsigned* ts = nullptr;
+    long long* ts_out = nullptr;
+    if (debug_stage >= 300) {
+        ts = &ts_acc;
+        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) +
+                 ((long)(group_start + (wave >> 1 < group_n ? wave >> 1 : 0)) * kWaves + wave) * 64;
+    }
+    const bool seam_b2 = samples_entry != nullptr;
+
+    // ---------------- stage C of the group's LAST window, with stage D's first requests ---------
+    // Stage D's operands of the group's EARLIER windows start their trip from the parks behind this
+    // layer's last MFMAs (waves 2k, 2k + 1 own window k there; twelve 16-byte loads per lane into
+    // registers conv7 has finished with; in front of the layer's exchange, last epilogue and
+    // closing barrier, which does not wait for them) - the parks are MALL / HBM resident (176 KB per
+    // workgroup: more than the L2 holds), a round trip of thousands of cycles.  The last window's own output goes to
+    // LDS (w43_nsplit_half<LAST>) and is read back behind the layer's closing barrier.  conv8's
+    // third 0 -> stage D's slot 0 (the idle upper half of the activation buffer) and, behind the
+    // mid-layer barrier, its third 1 -> slot 1 (conv7's N tile 0 lay there).
+    // (the waves of windows the group does not have run along on whatever their parks hold: the
+    // weight slots and their counters are shared by all eight, and nothing of theirs is looked at)
+    const int k_last = group_n - 1;
+    const bool own_last = (wave >> 1) == k_last;
+    f2 Y[3][2][4];
+    {
+        auto third_step = [&](const float* src, float* dst, int step) {
+            constexpr int NW = DBH_DMA_WAVES;
+            constexpr int per_wave = (kWinoHalf / 256 + NW - 1) / NW;
+            if (2 * step < per_wave) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step);
+            if (2 * step + 1 < per_wave) dma_weights_one<kWinoHalf, NW>(src, dst, lane, wave, 2 * step + 1);
+        };
+        w43_nsplit_pooled_layer<6, 2, true>(
+            lds, packed, nullptr, tid, lane, wave, ts, 59, pair_rounds, [&](auto tag) {
+                constexpr int G = decltype(tag)::value;
+                if constexpr (G < 3) third_step(packed + weight_offset(7), lds + kDS0, G);
+                if constexpr (G >= 6) third_step(packed + weight_offset(7) + kWinoHalf, lds + kDS1, G - 6);
+            },
+            [&]() -> bool {
+                // (every wave: the two that own the last window load what their park holds - stale -
+                // and overwrite it below.  Loaded under a condition the registers would count as
+                // live around the whole persistent loop - on the path that takes neither branch -
+                // and be spilled in stage B.)
+                d_load_y(Y, (const float*)(wg_scratch + kWgPark7Off + (wave >> 1) * kPark7Floats +
+                                           (wave & 1) * 3072 + lane * 4));
+                return true;
+            });
+    }
+    if (stop_stage == 2) {
+        if (debug_stage < 100) {
+            float* out = glob(args()->debug_out) + (long)(group_start + k_last) * kStageFloats[2];
+            const float* pk = lds + kPark7Lds;
+            for (int idx = tid; idx < 128 * 48; idx += kThreads) {
+                const int p = idx / 48, c = idx - p * 48;
+                const int hf = p >> 6, nn = (p >> 2) & 15, i = p & 3, g = c >> 4, qq = (c >> 2) & 3, r = c & 3;
+                out[idx] = pk[hf * 3072 + (i * 3 + g) * 256 + (qq * 16 + nn) * 4 + r] * kActUnscale;
+            }
+        }
+        full_barrier();
+    } else {
+    // (kernel arguments of the sample prefetch: scalar loads, long back when they are needed)
+    const long long* __restrict__ offsets_arg = glob(args()->offsets);
+    const int steps_arg = args()->steps;
+    const int side_arg = args()->side;
+    if (own_last)
+        d_load_y(Y, (const float*)(lds + kPark7Lds + (wave & 1) * 3072 + lane * 4));
+
+    // ================= stage D: conv8, conv9 (L=128) + MaxPool + BN4, the group together ========
+    stage_d_chain(lds, packed, wg_scratch, lane, wave, ts, d_groups, Y);
+    if (stop_stage == 3) {
+        if (debug_stage < 100)
+            for (int kk = 0; kk < group_n; ++kk)
+                dump_stage(kk == 0 ? lds + kEX : wg_scratch + kWgParkXOff + kk * kParkXFloats, kS48, 64, 48,
+                           glob(args()->debug_out) + (long)(group_start + kk) * kStageFloats[3], tid);
+        full_barrier();
+    } else {
+    // Once per group, behind stage D's closing barrier: conv16's weights (stage D's slots 0 and 1
+    // lay on their home) and BN5's scale and shift for E2 and E3 (384 floats - too many for the
+    // parameter table; two pieces; what follows them in the packed image comes along) by LDS-DMA,
+    // used two barriers on; conv17's 110 KB of weights (27 fragments per wave) from L2 to the
+    // registers they stay in through the stage F of every window of the group.
+    //   The ORDER of the memory requests matters: vector loads return in order, and the wait hipcc
+    // puts in front of a value's first use counts the requests issued after it - the ones it
+    // knows of (inline-asm LDS-DMA is not among them), pessimistically wherever control flow has
+    // merged.  So: the LDS-DMA pieces first.
+    static_assert(bn_scale_offset(4) % 4 == 0 && bn_scale_offset(4) + 512 <= kPackedFloats, "");
+    dma_weights<conv_weight_floats(15)>(packed + weight_offset(15), lds + kEW16, lane, wave);
+    if (wave >= 6)
+        dma_piece(packed + bn_scale_offset(4) + (wave - 6) * 256, lds + kEBn5 + (wave - 6) * 256,
+                  (unsigned)lane * 16u);
+    SmallMRegs<16, 8, 3, true> r17;
+    r17.prefetch_epilogue(packed, 5, lane, wave);
+    r17.template prefetch_slice<0, 27>(packed, lane, wave);
+    flush_marks(ts, ts_out, lane);
+    bool run_tail = false, thirds_next = false;
+
+    // ================= stages E, F: one window of the group after the other =====================
+    for (int k = 0; k < group_n; ++k) {
+    int tid = tid_entry;
+    asm volatile("" : "+v"(tid));
+    const __attribute__((address_space(1))) float* packed_opaque =
+        (const __attribute__((address_space(1))) float*)packed_entry;
+    __attribute__((address_space(1))) float* scratch_opaque =
+        (__attribute__((address_space(1))) float*)wg_scratch_entry;
+    const __attribute__((address_space(1))) int16_t* smp_opaque =
+        (const __attribute__((address_space(1))) int16_t*)samples_entry;
+    asm volatile("" : "+s"(packed_opaque), "+s"(scratch_opaque), "+s"(smp_opaque));
+    const float* __restrict__ packed = (const float*)packed_opaque;
+    float* const wg_scratch = (float*)scratch_opaque;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15;
+    const int win = group_start + k;
+    const bool last = k == group_n - 1;
+    unsigned ts_acc = 0u;
+    unsigned* ts = nullptr;
+    long long* ts_out = nullptr;
+    if (debug_stage >= 300) {
+        ts = &ts_acc;
+        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + ((long)win * kWaves + wave) * 64;
+    }
+    // Window k of the NEXT group (seam b2): its read's place in the sample buffer is asked for now
+    // (two VECTOR loads - the address made per-lane on purpose: as scalar loads they would count
+    // against lgkmcnt, which the hand-counted LDS waits of the layers below watch), its samples
+    // behind E1's barrier, its statistics ride on conv17's barrier (stage F), where the samples go
+    // to the LDS staging.
+    const bool stage_next = seam_b2 && k < next_n;
     long long next_off0 = 0, next_off1 = 0;
     int next_step = 0;
-    if (has_next) {
+    if (stage_next) {
         unsigned next_read;
-        split_window((unsigned)next_win, steps_arg, &next_read, &next_step);
+        split_window((unsigned)(next_start + k), steps_arg, &next_read, &next_step);
         unsigned lane_zero = 0;
         asm volatile("" : "+v"(lane_zero));
         next_off0 = offsets_arg[next_read + lane_zero];
         next_off1 = offsets_arg[next_read + lane_zero + 1];
     }
-    // conv7 (Winograd) + MaxPool + BN3; conv8's weights go to the idle upper half of the
-    // activation buffer meanwhile
-    w43_nsplit_pooled_layer<6, 2>(
-        lds, packed, tid, lane, wave, ts, 22, pair_rounds,
-        [&] { dma_weights<conv_weight_floats(7)>(packed + weight_offset(7), lds + kUpper, lane, wave); });
-    // (behind conv7's closing barrier - which has waited for everything - the two offset loads
-    // are looked at once: hipcc's wait-count pass then knows they have landed.  Left "pending" -
-    // they are issued under a condition, and the pass merges control flow pessimistically - the
-    // first instruction that reuses one of their registers, in conv8's first step, waited for all
-    // but one of the wave's outstanding requests: the LDS-DMA of conv9's weights just asked for, a
-    // whole L2 round trip per window.)
-    asm volatile("" : "+v"(next_off0), "+v"(next_off1));
-    if (stop_stage == 2) {
-        if (debug_stage < 100)
-            dump_stage(lds + kActOff, kS48, 128, 48, glob(args()->debug_out) + win * kStageFloats[2], tid);
-        return;
-    }
-
-    // the next window's slice of its read (scalar arithmetic on the offsets asked for after stage
-    // A): by stage E only the loads themselves are left to issue
-    const int16_t* next_src = nullptr;
-    int next_cnt = 0, next_pad = 0;
-    if (has_next) {
-        long long wa, wb;
-        const int nside = side_arg;
-        const long long next_base =
-            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
-        const long long next_end =
-            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
-        const long long next_len = next_end - next_base;
-        window_bounds(next_len, next_step, nside, &wa, &wb);
-        next_cnt = (int)(wb - wa);
-        next_pad = (nside == 0) ? 0 : kWindow - next_cnt;
-        next_src = (const int16_t*)smp_opaque + next_base + wa;
-    }
-    // ---------------- stage D: conv8, conv9 (L=128) + MaxPool + BN4 ---------------------------
-    // conv17's 110 KB of weights (27 fragments per wave) start their trip from L2 to registers
-    // while conv8 runs, long before stage F needs them; conv9's Winograd matrices go to the top
-    // of the arena by DMA.
-    SmallMRegs<16, 8, 3, true> r17;
-    r17.prefetch_epilogue(packed, 5, lane, wave);
-    // (DBH_CONV8_DMA - A/B knob: how conv9's weights are asked for during conv8.  0: up front by
-    // waves 0-3; 1, what runs: a slice per MFMA step, waves 0-3 (+0.2 %: 44.31 -> 44.22 us per 256
-    // windows, same box); 2: a slice per step, all eight waves (-0.5 %); 3: up front, all eight
-    // waves (no change))
-    wino_split_layer<7, false, -1, kUpper, kUpper + kWinoHalf, kX8>(
-        lds, packed, tid, lane, wave, ts, 26,
-        [&] {
-            if (DBH_CONV8_DMA == 0)
-                dma_weights<conv_weight_floats(8)>(packed + weight_offset(8), lds + kW9, lane, wave);
-            if (DBH_CONV8_DMA == 3)
-                dma_weights<conv_weight_floats(8), 8>(packed + weight_offset(8), lds + kW9, lane, wave);
-        },
-        interleaved([&](auto tag) {   // a wave runs 6 MFMA steps here: 27 fragments = 4-5 per step
-            constexpr int IT = decltype(tag)::value;
-            if (DBH_CONV8_DMA == 1)
-                dma_weights_slice<conv_weight_floats(8), IT, 6, 4>(packed + weight_offset(8), lds + kW9, lane, wave);
-            if (DBH_CONV8_DMA == 2)
-                dma_weights_slice<conv_weight_floats(8), IT, 6, 8>(packed + weight_offset(8), lds + kW9, lane, wave);
-            r17.template prefetch_slice<IT * 27 / 6, (IT + 1) * 27 / 6>(packed, lane, wave);
-        }));
-    // conv9 + MaxPool + BN4; ALL inception weights (conv10..16) arrive in their stage-E home
-    wino_split_layer<8, true, 3, kW9, kW9 + kWinoHalf, kX9>(
-        lds, packed, tid, lane, wave, ts, 30,
-        [] {},
-        [&](auto tag) {      // 69 DMA pieces: one or two per wave per MFMA step
-            dma_weights_slice<kEWEarly, decltype(tag)::value, 6>(packed + weight_offset(9),
-                                                                 lds + kEW, lane, wave);
-        });
-    if (stop_stage == 3) {
-        if (debug_stage < 100)
-            dump_stage(lds + kEX, kS48, 64, 48, glob(args()->debug_out) + win * kStageFloats[3], tid);
-        return;
-    }
+    int next_cnt = 0, next_pad = 0, next_v0 = 0, next_v1 = 0;
 
     // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
     {
         // No phase of its own in front of the 1x1 convolutions: the average pooling that conv10
         // reads happens on conv10's output (inception_1x1_of_avgpool), BN5's parameters come from
-        // L2 in E1 and reach LDS by DMA for E2 and E3, and each zero row is written by a wave
-        // that writes the buffer it belongs to - every store below lands in LDS that nobody
-        // reads before E1's barrier.
-        //   The ORDER of the memory requests matters: vector loads return in order, and the
-        // wait hipcc puts in front of a value's first use counts the requests issued after it -
-        // the ones it knows of (inline-asm LDS-DMA is not among them), pessimistically wherever
-        // control flow has merged.  So: (1) the LDS-DMA piece, (2) the next window's samples -
-        // whose registers the pass believes pending from the round before: asked for behind other
-        // loads, the first of them waited out those loads' L2 round trip -, (3) BN5's parameters
-        // for E1's epilogue, needed an MFMA loop later.  The accumulators of E1-E3 start from
-        // biases in the LDS parameter table: from L2, every phase began with a round trip.
-        // (1) the end of conv16's weights (what did not fit beside conv9's exchange scratch)
-        dma_weights<kEWFloats - kEWEarly>(packed + weight_offset(9) + kEWEarly, lds + kEW + kEWEarly,
-                                          lane, wave);
-        // ... and BN5's scale and shift for E2 and E3 (384 floats - too many for the parameter
-        // table; two pieces, by the two waves the copy above leaves without one; what follows
-        // them in the packed image comes along): landed before E1's closing barrier
-        static_assert((kEWFloats - kEWEarly) / 256 == 6 && bn_scale_offset(4) % 4 == 0 &&
-                      bn_scale_offset(4) + 512 <= kPackedFloats && kEBn5 + 512 <= kArenaFloats, "");
-        if (wave >= 6)
-            dma_piece(packed + bn_scale_offset(4) + (wave - 6) * 256, lds + kEBn5 + (wave - 6) * 256,
-                      (unsigned)lane * 16u);
-        // (2) The next window's samples start their trip from HBM now (stages E-H, ~25k cycles,
-        // are far more than it takes) and are used at the top of the next round's stage A; the
-        // registers they land in were last read in this window's stage A.
-        prefetched = has_next;
-        if (has_next) {
-            in_cnt = next_cnt;
-            if (!(DBH_ABL & 1024))
-                fetch_window_at(next_src, next_cnt, next_pad, tid, wave * 16 + n, q, in_v0, in_v1, in_raw);
-        }
-        // (3) E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
+        // L2 in E1 and from LDS in E2 and E3, and each zero row is written by a wave that writes
+        // the buffer it belongs to - every store below lands in LDS that nobody reads before E1's
+        // barrier.  The accumulators of E1-E3 start from biases in the LDS parameter table: from
+        // L2, every phase began with a round trip.
+        // E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
         // wave 6 conv12, wave 7 conv14
         static_assert(bias_offset(10) == bias_offset(9) + 48, "conv10's and conv11's biases are adjacent");
         const float* bias_tab = lds + kParams - kTabBias0 + n;     // + bias_offset(conv): the LDS table
@@ -3132,32 +3324,51 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             zero_row(lds + kET4a, 65, kS16, 16, lane);
         }
         mark(ts, 34);
-
-        constexpr int w10 = kEW + weight_offset(9) - weight_offset(9);
-        constexpr int w11 = kEW + weight_offset(10) - weight_offset(9);
-        constexpr int w12 = kEW + weight_offset(11) - weight_offset(9);
-        constexpr int w13 = kEW + weight_offset(12) - weight_offset(9);
-        constexpr int w14 = kEW + weight_offset(13) - weight_offset(9);
-        constexpr int w15 = kEW + weight_offset(14) - weight_offset(9);
-        constexpr int w16 = kEW + weight_offset(15) - weight_offset(9);
         const float* sc5 = lds + kEBn5 + n;
         const float* sh5 = lds + kEBn5 + 192 + n;
 
         // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
         if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
-            inception_1x1_of_avgpool<3, kS192>(lds + kEX, lds + w10, lds + kECat, wave * 16, ep_cat,
+            inception_1x1_of_avgpool<3, kS192>(lds + kEX, lds + kEW10, lds + kECat, wave * 16, ep_cat,
                                                wave, lane);
         } else if (wave < 6) {     // conv11 -> concat channels 48..95
-            inception_1x1<3, kS192, true>(lds + kEX, lds + w11, lds + kECat, wave * 16, ep_cat,
+            inception_1x1<3, kS192, true>(lds + kEX, lds + kEW11, lds + kECat, wave * 16, ep_cat,
                                           wave - 3, lane);
         } else if (wave == 6) {    // conv12 -> 16-channel bottleneck of branch 3
-            inception_1x1<1, kS16, false>(lds + kEX, lds + w12, lds + kET3, 0, ep_mid, 0, lane);
+            inception_1x1<1, kS16, false>(lds + kEX, lds + kEW12, lds + kET3, 0, ep_mid, 0, lane);
         } else {                   // conv14 -> 16-channel bottleneck of branch 4
-            inception_1x1<1, kS16, false>(lds + kEX, lds + w14, lds + kET4a, 0, ep_mid, 0, lane);
+            inception_1x1<1, kS16, false>(lds + kEX, lds + kEW14, lds + kET4a, 0, ep_mid, 0, lane);
         }
         mark(ts, 35);
-        full_barrier();      // (also: BN5's parameters, asked for at the top, have landed)
+        full_barrier();      // (also: BN5's parameters and conv16's weights, asked for above, have landed)
+        // (the two offset loads, looked at once on EVERY path, where the barrier has just waited for
+        // everything: this is where hipcc's wait-count pass learns that they have landed.  Left
+        // "pending" on the path that does not use them, the loads of the next round - which reuse
+        // their registers - wait for all but one of the wave's outstanding requests: conv17's
+        // stores, a round trip to memory per window.)
+        asm volatile("" : "+v"(next_off0), "+v"(next_off1));
         mark(ts, 36);
+        // X is read: the next window's image comes in from its park (13 pieces; retired by E2's
+        // closing barrier) ...
+        if (!last)
+            dma_weights<kParkXFloats>(wg_scratch + kWgParkXOff + (k + 1) * kParkXFloats, lds + kEX, lane, wave);
+        // ... and the samples of the next group's window k start their trip from HBM (the barrier
+        // has waited for the two offsets)
+        if (stage_next) {
+            long long wa, wb;
+            const long long next_base =
+                ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
+            const long long next_end =
+                ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
+            window_bounds(next_end - next_base, next_step, side_arg, &wa, &wb);
+            next_cnt = (int)(wb - wa);
+            next_pad = (side_arg == 0) ? 0 : kWindow - next_cnt;
+            const int16_t* src = (const int16_t*)smp_opaque + next_base + wa;
+            next_v0 = tid < next_cnt ? (int)src[(unsigned)tid] : 0;
+            next_v1 = tid + 512 < next_cnt ? (int)src[(unsigned)(tid + 512)] : 0;
+        }
 
         // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, and conv13
         // (16->48, k3) -> concat 96..143, both as Winograd F(2,3): per convolution two pair tiles
@@ -3170,24 +3381,26 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             if (wave == 0) zero_row(lds + kET4b, 0, kS48, 48, lane);     // (conv16's padding rows)
             if (wave == 1) zero_row(lds + kET4b, 65, kS48, 48, lane);
             if (wave < 2) {
-                inception_k3_wino<2, kS48, false>(lds + kET4a, lds + w15, lds + kET4b, 0,
+                inception_k3_wino<2, kS48, false>(lds + kET4a, lds + kEW15, lds + kET4b, 0,
                                                   bias_tab + bias_offset(14), nullptr, nullptr, m, lane);
             } else if (wave < 4) {
-                inception_k3_wino<1, kS48, false>(lds + kET4a, lds + w15 + 2 * kTile, lds + kET4b, 32,
+                inception_k3_wino<1, kS48, false>(lds + kET4a, lds + kEW15 + 2 * kTile, lds + kET4b, 32,
                                                   bias_tab + bias_offset(14) + 32, nullptr, nullptr, m,
                                                   lane);
             } else if (wave < 6) {
-                inception_k3_wino<1, kS192, true>(lds + kET3, lds + w13 + 2 * kTile, lds + kECat, 96 + 32,
+                inception_k3_wino<1, kS192, true>(lds + kET3, lds + kEW13 + 2 * kTile, lds + kECat, 96 + 32,
                                                   bias_tab + bias_offset(12) + 32, sc5 + 96 + 32,
                                                   sh5 + 96 + 32, m, lane);
             } else {
-                inception_k3_wino<2, kS192, true>(lds + kET3, lds + w13, lds + kECat, 96,
+                inception_k3_wino<2, kS192, true>(lds + kET3, lds + kEW13, lds + kECat, 96,
                                                   bias_tab + bias_offset(12), sc5 + 96, sh5 + 96, m,
                                                   lane);
             }
         }
         mark(ts, 37);
-        full_barrier();      // (also: the late part of conv16's weights, asked for in E0, has landed)
+        // (LDS only: the next window's X and the next group's samples, asked for at the top of this
+        // short phase, are still on their way - E3's barrier retires them)
+        lds_barrier();
         mark(ts, 38);
 
         // E3: conv16 (48->48, k3) -> concat 144..191: twelve (position tile, channel tile) units
@@ -3196,62 +3409,82 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         //   w4: t1 m2     w5: t1 m3     w6: t2 m2     w7: t2 m3
         if (wave < 4) {
             const int t = wave < 3 ? wave : 0, m0 = wave < 3 ? 0 : 2;
-            inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
+            inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + kEW16, lds + kECat,
                                                      144 + t * 16,
                                                      bias_tab + bias_offset(15) + t * 16,
                                                      sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
                                                      lane);
         } else {
             const int t = 1 + ((wave - 4) >> 1), m0 = 2 + ((wave - 4) & 1);
-            inception_k3<6, 1, 1, kS48, kS192, true>(lds + kET4b, lds + w16, lds + kECat,
+            inception_k3<6, 1, 1, kS48, kS192, true>(lds + kET4b, lds + kEW16, lds + kECat,
                                                      144 + t * 16,
                                                      bias_tab + bias_offset(15) + t * 16,
                                                      sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
                                                      lane);
         }
         mark(ts, 39);
-        lds_barrier();
+        full_barrier();      // (also: the next window's X has landed)
+        // (the same for the two sample registers: without this the round's loads into them, at the
+        // top of E2, were followed by waits for the X image and the samples just asked for)
+        asm volatile("" : "+v"(next_v0), "+v"(next_v1));
         mark(ts, 40);
     }
     if (stop_stage == 4) {
         if (debug_stage < 100)
-            dump_stage(lds + kECat, kS192, 32, 192, glob(args()->debug_out) + win * kStageFloats[4], tid);
-        return;
+            dump_stage(lds + kECat, kS192, 32, 192, glob(args()->debug_out) + (long)win * kStageFloats[4], tid);
+        full_barrier();
+        continue;
     }
 
     // ---------------- stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48 ---------
     // The last layers (conv18-20 on 16 and 8 positions, softmax, call) are too small to fill a
     // workgroup: per window they cost ~9k cycles of barriers and LDS round trips for ~1.7k cycles
     // of matrix work.  So conv17's output (3 KB) is parked in a global-memory slot of this
-    // workgroup and the rest runs for kTailBatch windows at a time, ONE WAVE PER WINDOW, with no
-    // cross-wave step at all (batched_tail below).
-    const bool batch_ends = tail_slot == kTailBatch - 1 || next_win >= n_windows;
-    thirds_ahead = prefetched && !batch_ends;
-    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = (int)win;
+    // workgroup and the rest runs for up to kTailBatch windows at a time, ONE WAVE PER WINDOW, with
+    // no cross-wave step at all (batched tail below), behind the group's last window when the next
+    // group would not fit in the slots any more.
+    const bool batch_ends = last && (tail_every_group || tail_slot + 1 + next_n > kTailBatch || next_n == 0);
+    const bool slot0_next = last && seam_b2 && next_n > 0;     // the next group's first window: conv2's first third
+    const bool thirds_now = slot0_next && !batch_ends;
+    if (last) {
+        run_tail = batch_ends;
+        thirds_next = thirds_now;
+    }
+    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = win;
     if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
         dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
         dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
         dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
     }
     {
-        float* slot = glob(args()->tail_scratch) +
-                      ((size_t)blockIdx.x * kTailBatch + tail_slot) * kTailSlotFloats;
-        // The next window's statistics ride on conv17's barrier: every wave leaves its partial
-        // sums before it; behind it wave 7 (idle while waves 0-2 reduce conv17) turns them into
-        // mean and 1/std, which the barrier at the top of the next stage A publishes.
+        float* slot = wg_scratch + kWgTailOff + tail_slot * kTailSlotFloats;
+        // conv17's partial tiles: over the inception block's scratch images - dead by now - except
+        // for the group's last window, where slots 0..2 (the next window's conv2 weights, on their
+        // way) cover those and the front of the arena (X, conv10..14's weights) is dead instead
+        float* red = lds + (last ? kRedLast : kRedMid);
+        // The statistics of the next group's window k ride on conv17's barrier: every wave leaves
+        // its partial sums - and its two samples in the staging - before it; behind it wave 7 (idle
+        // while waves 0-2 reduce conv17) turns the sums into mean and 1/std.
         small_m_layer<16, kS192, 2, 8, 3, false, true, true>(
-            lds, lds + kECat, slot, r17, lane, wave, ts, 41,
+            lds, lds + kECat, slot, red, r17, lane, wave, ts, 41,
             [&] {
-                if (prefetched) window_partial_sums(lds, in_cnt, in_v0, in_v1, tid, lane, wave);
+                if (stage_next) {
+                    window_partial_sums(lds, next_cnt, next_v0, next_v1, tid, lane, wave);
+                    short* smp = reinterpret_cast<short*>(lds + kStage + k * kStageWin);
+                    smp[tid] = (short)next_v0;
+                    smp[tid + 512] = (short)next_v1;
+                }
             },
             [&] {
-                if (prefetched && wave == kWaves - 1) {
+                if (stage_next && wave == kWaves - 1) {
                     double mean, inv;
-                    window_mean_inv(lds, in_cnt, &mean, &inv);
-                    double* stats = reinterpret_cast<double*>(lds + kStatOut);
+                    window_mean_inv(lds, next_cnt, &mean, &inv);
+                    float* st = lds + kStageStats + k * 8;
                     if (lane == 0) {
-                        stats[0] = mean;
-                        stats[1] = inv;
+                        reinterpret_cast<double*>(st)[0] = mean;
+                        reinterpret_cast<double*>(st)[1] = inv;
+                        reinterpret_cast<int*>(st)[4] = next_cnt;
+                        reinterpret_cast<int*>(st)[5] = next_pad;
                     }
                 }
                 // Thirds 1 and 2 of the NEXT window's conv2 weights -> slots 1 and 2, by the
@@ -3259,7 +3492,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 // nine each; the slots overlap the concat buffer, which every wave has finished
                 // reading at the barrier just passed) - unless the batched tail runs between this
                 // window and the next: its buffers lie there.
-                if (thirds_ahead && wave >= 3 && wave < kWaves - 1) {
+                if (thirds_now && wave >= 3 && wave < kWaves - 1) {
                     const unsigned lane_bytes = (unsigned)lane * 16u;
 #pragma unroll
                     for (int i = 0; i < 2 * kWinoHalf / 256 / 4; ++i) {
@@ -3270,24 +3503,26 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 }
             },
             // The NEXT window's first third of conv2's weights -> slot 0 (the inception block's
-            // scratch, dead behind E3's barrier; the batched tail keeps clear of it): tile 0 of
-            // conv2 multiplies right behind that window's first barrier, which retires these
-            // requests - 18 pieces, one per wave behind each tap's MFMAs.
+            // weights and scratch, dead behind E3's barrier; the batched tail keeps clear of it):
+            // tile 0 of conv2 multiplies right behind that window's first barrier, which retires
+            // these requests - 18 pieces, one per wave behind each tap's MFMAs.
             [&](int tap) {
-                if (prefetched)
+                if (slot0_next)
                     dma_weights_one<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave, tap);
             });
     }
     mark_realtime(ts, 63);
     ++tail_slot;
-    if (!batch_ends) {
-        flush_marks(ts, ts_out, lane);
-        continue;
-    }
+    flush_marks(ts, ts_out, lane);
+    // (the next window's E1 writes the scratch images the partial tiles lie on; LDS only - nobody
+    // waits for conv17's stores before the batched tail)
+    if (!last) lds_barrier();
+    }   // stages E, F of the group's windows
 
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
-    {
+    if (run_tail && tail_slot > 0) {
+        const int n = lane & 15, q = lane >> 4;
         const int n_batch = tail_slot;
         tail_slot = 0;
         ArgsPtr a = args();
@@ -3304,12 +3539,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                   packed + bn_shift_offset(6) + n);
         const float bias20a = packed[bias_offset(19) + n];
         const float bias20b = packed[bias_offset(19) + 16 + n];
-        full_barrier();        // conv17's stores of this window are out; kRed / the concat buffer free
+        full_barrier();        // conv17's stores of the last window are out; its partial tiles / the concat buffer free
         mark(ts, 45);
         my_win = (long)reinterpret_cast<const int*>(lds + kTailWins)[mine ? wave : 0];
         if (mine) {
-            const float* src = glob(a->tail_scratch) +
-                               ((size_t)blockIdx.x * kTailBatch + wave) * kTailSlotFloats;
+            const float* src = wg_scratch + kWgTailOff + wave * kTailSlotFloats;
             f4 v[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f4*>(src + i * 256 + lane * 4);
@@ -3329,12 +3563,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         }
         full_barrier();        // the batch's weights have landed (vmcnt(0) rides on the barrier)
         mark(ts, 46);
+        bool stop_here = false;
         if (debug_stage >= 0 && stop_stage == 5) {
-            if (debug_stage < 100)
-                dump_stage(lds + tail_x_offset(0), kS48, 16, 48, glob(a->debug_out) + win * kStageFloats[5], tid);
-            return;
+            if (debug_stage < 100 && mine)      // (each wave its own window's 16 x 48)
+                for (int idx = lane; idx < 16 * 48; idx += 64)
+                    glob(a->debug_out)[my_win * kStageFloats[5] + idx] =
+                        X[(idx / 48 + 1) * kS48 + idx % 48] * kActUnscale;
+            stop_here = true;
         }
-        if (mine) {
+        if (mine && !stop_here) {
             // conv18: 16 positions x 48 -> 48, k = 3, bias + ReLU -> Y
             {
                 f4 acc[1][3];
@@ -3356,12 +3593,13 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             mark(ts, 49);
         }
         if (debug_stage >= 0 && stop_stage == 6) {
-            full_barrier();  
-            if (debug_stage < 100)
-                dump_stage(lds + tail_x_offset(0), kS48, 8, 48, glob(a->debug_out) + win * kStageFloats[6], tid);
-            return;
+            if (debug_stage < 100 && mine)
+                for (int idx = lane; idx < 8 * 48; idx += 64)
+                    glob(a->debug_out)[my_win * kStageFloats[6] + idx] =
+                        X[(idx / 48 + 1) * kS48 + idx % 48] * kActUnscale;
+            stop_here = true;
         }
-        if (mine) {
+        if (mine && !stop_here) {
             // conv20 (1x1 -> classes, one or two N tiles) + ReLU + global average: the logit of
             // class 16t + n ends up in the q = 0 lanes
             auto conv20_logit = [&](int t, float bias) -> float {
@@ -3404,7 +3642,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             const float rsum = row16_sum(e);
             const float sum = lane_value(rsum, 0) + lane_value(rsum, 16);
             if (debug_stage == 7) {
-                if (lane < 32) glob(a->debug_out)[win * kStageFloats[7] + lane] = valid ? v : 0.f;
+                if (lane < 32) glob(a->debug_out)[my_win * kStageFloats[7] + lane] = valid ? v : 0.f;
             } else {
                 const float p = e / sum;
                 float* __restrict__ probs = glob(a->probs);
@@ -3420,12 +3658,30 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             }
         }
         mark(ts, 53);
-        if (debug_stage == 7) return;
-        full_barrier();        // the next window's stage A writes over all of this
+        full_barrier();        // the next group's stage A writes over all of this
         mark(ts, 55);
-        flush_marks(ts, ts_out, lane);
     }
-    }   // persistent loop over this workgroup's windows
+    flush_marks(ts, ts_out, lane);
+    thirds_ahead = thirds_next;
+    }   // (not stop_stage 3)
+    }   // (not stop_stage 2)
+    }   // (not stop_stage 0, 1)
+
+    first_group = false;
+    staged = samples_entry != nullptr && next_n > 0 && (stop_stage < 0 || stop_stage > 4);
+    if (!staged) thirds_ahead = false;
+    group_start = next_start;
+    group_n = next_n;
+    }   // persistent loop over this workgroup's groups of windows
+    // the launch's last workgroup puts the counter (and the count of finished workgroups beside
+    // it) back to zero for the next launch on this stream
+    if (win_counter_entry != nullptr && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(win_counter_entry + 1, 1) == (int)gridDim.x - 1) {
+            win_counter_entry[0] = 0;
+            win_counter_entry[1] = 0;
+        }
+    }
     if (args()->clock_out != nullptr && tid_entry == 0) {
         long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * 4;
         c[2] = (long long)__builtin_readcyclecounter();

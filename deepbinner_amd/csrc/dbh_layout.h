@@ -37,8 +37,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {1, 48, 16, 1, 0},    // conv1d_5
     {3, 16, 48, 1, 2},        // conv1d_6
     {3, 48, 48, 1, 4},        // conv1d_7
-    {3, 48, 48, 1, 2},        // conv1d_8
-    {3, 48, 48, 1, 2},        // conv1d_9
+    {3, 48, 48, 1, 4},        // conv1d_8   (round 6: F(4,3), four windows at a time - stage_d_chain)
+    {3, 48, 48, 1, 4},        // conv1d_9
     {1, 48, 48, 1, 0},    // conv1d_10
     {1, 48, 48, 1, 0},    // conv1d_11
     {1, 48, 16, 1, 0},    // conv1d_12
@@ -53,8 +53,7 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_13, conv1d_15); conv1d_8 and conv1d_9 are
-// matrix-major.
+// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_13, conv1d_15).
 constexpr bool wino2_by_tile(int i) { return i == 5 || i == 12 || i == 14; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
@@ -81,7 +80,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 9588, "MFMA count per window (SQ_INSTS_MFMA, profiles/r04_*)");
+static_assert(forward_mfmas(13) == 9300, "MFMA count per window (SQ_INSTS_MFMA; 9,588 until conv1d_8/9 became F(4,3))");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -149,7 +148,9 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // input transform (all in-lane but for one halo position each side), the next layer's B operand.
 // (conv1d_5, a 1x1 convolution on conv1d_4's pooled output, is fed from the same registers)
 // ... and conv1d_6 from conv1d_5's accumulators
-constexpr bool chained(int conv) { return conv >= 1 && conv <= 5; }
+// conv1d_8 and conv1d_9 (round 6) run the same way for FOUR windows at a time (stage_d_chain): a
+// wave owns half a window (16 quads of its 128 positions) from conv1d_7's parked output to BN4.
+constexpr bool chained(int conv) { return (conv >= 1 && conv <= 5) || conv == 7 || conv == 8; }
 constexpr int frag_cin(int conv, int sp, int q, int e) {
     return chained(conv) ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
 }
@@ -216,49 +217,94 @@ static_assert((kHalo * 4) % 16 == 0 && kChainDummy % 2 == 0 && kChainDummy + 312
 // conv7's pair exchange: two f4 per lane and wave, in activation rows its pooled output leaves free
 constexpr int kX7 = 130 * kS48;
 static_assert((kX7 * 4) % 16 == 0 && kX7 + 8 * 512 <= 258 * kS48, "");
-// stage D (L = 128, Winograd split over wave pairs): conv8's weights in the upper buffer, its
-// pair-exchange scratch right above the activations; conv9's weights at the top of the arena
-// and its exchange scratch below them, both clear of the stage-E weights arriving meanwhile.
-constexpr int kXchgFloats = 4 * 6 * 256;                   // 4 sender waves x 6 tiles x 256
-constexpr int kX8 = 130 * kS48 + 8;                        // 6,768
-static_assert(kX8 % 4 == 0 && kX8 + kXchgFloats <= kUpper, "conv8 exchange scratch hits its weights");
+// ---------------------------------------------------------------------------------------------
+// GROUPS OF FOUR WINDOWS (round 6).  A workgroup takes kGroup windows at a time:
+//   [stage A, B, C] x kGroup   conv1d_7's pooled + BN3 output (128 x 48) is PARKED in global memory
+//   stage D once               conv1d_8, conv1d_9 as F(4,3) for the four windows together: 32 quads
+//                              per window = two tiles of 16 = one per wave of a wave pair, eight
+//                              tiles for eight waves, a chain in registers like stage B
+//   [stage E, F] x kGroup      BN4's output X of window 0 waits in LDS, the others' in global memory
+//                              (parked as the padded 66 x 50 image the inception block reads, so
+//                              that LDS-DMA brings one in while the window before runs stage F)
+// Per-workgroup scratch in global memory (floats): conv1d_17's outputs for the batched tail, then
+// the two parks.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGroup = 4;
+constexpr int kPark7Floats = 128 * 48;                      // [half][row of quad][channel group][lane][4]
+constexpr int kParkXFloats = 13 * 256;                      // 66 x 50 = 3,300, whole 1 KiB pieces
+static_assert(kParkXFloats >= 66 * kS48, "");
+// the group's LAST window skips the park: stage D follows its conv1d_7 at once, so its output goes
+// to LDS in the same layout - over rows of conv1d_7's input image (all read by its mid-layer barrier),
+// below its pair exchange; the waves that own the window in stage D read it back behind the layer's
+// closing barrier (stage D's weights for stage E land there two tiles later)
+constexpr int kPark7Lds = 0;
+static_assert(kPark7Lds + kPark7Floats <= kX7, "");
 
-// stage E (inception block, L = 64).  The weights of conv10..16 are DMA'd while conv9 runs:
-// their home must avoid conv9's activations ([0, 130*52)) and its weight buffer (kW1).
-constexpr int kEX = 0;                                     // BN4 output, 66 rows x 52
-constexpr int kEAP = kEX + 66 * kS48;                      // avg-pooled copy
-constexpr int kEW = kEAP + 66 * kS48;                      // weights of conv10..16
-constexpr int kEWFloats = weight_offset(16) - weight_offset(9);   // 19,200
-// what of them arrives while conv9 runs (the rest - the end of conv16's - would land on conv9's
-// exchange scratch and comes at the top of stage E instead, long before conv16 needs it)
-constexpr int kEWEarly = 17664;
-static_assert(kEWEarly % 256 == 0 && (kEWFloats - kEWEarly) % 256 == 0 && kEWEarly <= kEWFloats, "");
-constexpr int kET3 = kEW + kEWFloats;                      // conv12 out, 66 x 20
+// Samples of the NEXT group's windows (seam b2), staged while this group runs stages E and F:
+// 1,024 int16 per window + {mean, 1/std (doubles), count, left padding}.  Always live, so it sits
+// in a hole every stage's plan leaves free: above conv1d_3's ring of weights in stages A-C.
+constexpr int kStage = 3 * kWinoHalf;                       // 13,824
+constexpr int kStageWin = kWindow / 2;                      // floats per staged window
+constexpr int kStageStats = kStage + kGroup * kStageWin;    // 8 floats per window
+constexpr int kStageEnd = kStageStats + kGroup * 8;         // 15,904
+static_assert(kChainW3 + 3 * kWinoHalf <= kStage && kStageEnd <= kW5 && kStageStats % 2 == 0, "");
+static_assert(258 * kS48 <= kStage, "conv1d_6's image (conv1d_7's input) must stay below the staging");
+
+// stage D (stage_d_chain): weights in four slots of one third each (conv1d_8's thirds in slots
+// 0-2, conv1d_9's in slot 3 and - as conv1d_8 leaves them - slots 0 and 1), halo rows, scratch.
+// Slot 0 is requested while the group's last conv1d_7 runs (it lies in the idle upper half of the
+// activation buffer), slot 1 behind that layer's mid-layer barrier (conv1d_7's N tile 0 lies there).
+constexpr int kDS0 = kStageEnd + conv_weight_floats(14);     // 18,976: behind conv1d_15's weights
+constexpr int kDS1 = kDS0 + kWinoHalf, kDS2 = kDS1 + kWinoHalf, kDS3 = kDS2 + kWinoHalf;
+// [layer output 0..1][wave][side: 0 = the wave's left halo row, 1 = its right one][48]
+constexpr int kDHaloLayer = 8 * 2 * 48;               // 768
+constexpr int kDHalo = kDS3 + kWinoHalf;                    // 37,408
+constexpr int kDDummy = kDHalo + 2 * kDHaloLayer;           // 38,944 (+ 312: see kChainDummy)
+constexpr int kLdsFloatsD = kDDummy + 312;
+static_assert((kDS0 * 4) % 16 == 0 && kDS0 >= kStageEnd && kDDummy % 2 == 0, "");
+static_assert(kDS0 + kWinoHalf <= kW0, "slot 0 must be clear of conv1d_7's weights");
+static_assert(kDS1 + kWinoHalf <= kSlot1, "slot 1 may only overlap conv1d_7's N tile 0");
+
+// stages E and F (inception block, conv1d_17), per window of the group.  The weights of conv10..16
+// arrive ONCE per group (conv10..15 while stage D runs, conv16 - whose home stage D's slots cover -
+// at the top of the first window's stage E) and stay through all four windows.
+constexpr int kEX = 0;                                     // BN4 output, 66 rows x 50 (one DMA image)
+constexpr int kEW10 = kEX + kParkXFloats;                  // 3,328
+constexpr int kEW11 = kEW10 + conv_weight_floats(9);
+constexpr int kEW12 = kEW11 + conv_weight_floats(10);
+constexpr int kEW13 = kEW12 + conv_weight_floats(11);
+constexpr int kEW14 = kEW13 + conv_weight_floats(12);
+constexpr int kEWLowEnd = kEW14 + conv_weight_floats(13);  // 12,544
+constexpr int kEW15 = kStageEnd;                           // 15,904
+constexpr int kEW16 = kEW15 + conv_weight_floats(14);      // 18,976
+static_assert(kEWLowEnd <= kStage && kEW16 == kDS0 && (kEW10 * 4) % 16 == 0 && (kEW15 * 4) % 16 == 0, "");
+constexpr int kET3 = kEW16 + conv_weight_floats(15);       // conv12 out, 66 x 20      (25,888)
 constexpr int kET4a = kET3 + 66 * kS16;                    // conv14 out, 66 x 20
-constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 52
-constexpr int kECat = kET4b + 66 * kS48;                   // pooled + BN5 concat, 34 x 196
-constexpr int kLdsFloatsE = kECat + 34 * kS192;            // 37,264
-static_assert(kEW >= 130 * kS48, "stage-E weights would land on conv9's activations");
-constexpr int kX9 = (kEW + kEWEarly + 3) / 4 * 4;          // conv9's exchange scratch
-constexpr int kW9 = kX9 + kXchgFloats;                     // conv9's four Winograd matrices
-constexpr int kLdsFloatsD = kW9 + 4 * 48 * 48;
+constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 50
+// conv1d_17's split-K partial tiles (24 x 256 floats): over the three scratch images (dead by
+// stage F) for every window but the group's last; for the last one at the front of the arena (X
+// and the first weights are dead, and the NEXT window's conv1d_2 weights are on their way to slots
+// 0..2, which cover the scratch images)
+constexpr int kRedMid = kET3, kRedLast = 0;
+constexpr int kRedFloats = 24 * 256;
+constexpr int kECat = kRedMid + kRedFloats;                // pooled + BN5 concat, 34 x 196   (32,032)
+static_assert(kET4b + 66 * kS48 <= kECat, "");
+// BN5's scale and shift (2 x 192 floats + what follows them in the packed image: 512 by DMA)
+constexpr int kEBn5 = kECat + 34 * kS192;                  // 38,696
+constexpr int kLdsFloatsE = kEBn5 + 512;
+static_assert((kEBn5 * 4) % 16 == 0, "");
 
-// stage F (conv17, per window): split-K partial tiles at the front of the arena; the concat buffer
-// stays where it is.  conv17's 16 x 48 output goes to a per-workgroup slot in global memory.
-constexpr int kRed = 0;                                    // 24 x 256 partial tiles
-constexpr int kTailEnd = kRed + 24 * 256;
-static_assert(kTailEnd <= kECat, "tail buffers must not overlap the concat buffer");
-// stages G-H (conv18, conv19, conv20, softmax, call) run for kTailBatch windows at a time, ONE
-// WAVE PER WINDOW (dbh_forward.hip: batched tail): the three layers' weights in fragment order
-// (LDS-DMA'd during the batch's last conv17, so they sit clear of kRed and the concat buffer),
-// then two 18 x 50 activation buffers per wave (X: conv17 out, later conv19 out; Y: conv18 out),
-// which may use the concat buffer's place - it is dead by then.
+// stages G-H (conv18, conv19, conv20, softmax, call) run for up to kTailBatch windows at a time,
+// ONE WAVE PER WINDOW (dbh_forward.hip: batched tail), at the end of a group: the three layers'
+// weights in fragment order (LDS-DMA'd during the batch's last conv17: clear of its partial tiles
+// at kRedLast, of the concat buffer and of the staging), then two 18 x 50 activation buffers per
+// wave (X: conv17 out, later conv19 out; Y: conv18 out).
 constexpr int kTailBatch = 8;
-constexpr int kTW18 = kTailEnd;                            // 6,144
-constexpr int kTW19 = kTW18 + conv_weight_floats(17);      // + 6,912
-constexpr int kTW20 = kTW19 + conv_weight_floats(18);
-constexpr int kTWEnd = kTW20 + conv_weight_floats(19);     // 21,504
-static_assert(kTWEnd <= kECat, "tail weights would land on the concat buffer conv17 reads");
+constexpr int kTW18 = kRedLast + kRedFloats;               // 6,144
+constexpr int kTW19 = kStageEnd;                           // 15,904
+constexpr int kTW20 = kTW19 + conv_weight_floats(18);      // 22,816
+constexpr int kTWEnd = kTW20 + conv_weight_floats(19);     // 24,352
+static_assert(kTW18 + conv_weight_floats(17) <= kStage && (kTW19 * 4) % 16 == 0, "");
 constexpr int kTailBuf = 18 * kS48;                        // 900 floats
 // The X/Y pairs of waves 0-2 lie where conv17's partial tiles were (dead behind the tail's first
 // barrier), those of waves 3-7 from kSlot1 upwards (the concat buffer, dead too): between them
@@ -277,9 +323,12 @@ constexpr int tail_x_offset(int wave) {
                               : kTXHigh + (wave - kTXLowWaves) * 2 * kTailBuf;
 }
 constexpr int kTailSlotFloats = 16 * 48;                   // conv17 output of one window
-// BN5's scale and shift (2 x 192 floats), parked above stage E's buffers for the inception block
-constexpr int kEBn5 = kLdsFloatsE;
-static_assert(kEBn5 + 2 * 192 <= (kLdsFloatsAD > kLdsFloatsD ? kLdsFloatsAD : kLdsFloatsD), "");
+// per-workgroup scratch in global memory: [kTailBatch x conv17 output][kGroup x conv7 park][kGroup x X park]
+constexpr int kWgTailOff = 0;
+constexpr int kWgPark7Off = kTailBatch * kTailSlotFloats;
+constexpr int kWgParkXOff = kWgPark7Off + kGroup * kPark7Floats;
+constexpr int kWgScratchFloats = kWgParkXOff + kGroup * kParkXFloats;
+static_assert((kWgScratchFloats * 4) % 16 == 0 && (kWgPark7Off * 4) % 16 == 0 && (kWgParkXOff * 4) % 16 == 0, "");
 constexpr int kArenaFloats =
     (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
         ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
@@ -295,8 +344,10 @@ constexpr int kTabBn0 = bn_scale_offset(0), kTabBn1 = bn_scale_offset(4);
 constexpr int kParamFloats = (kTabBias1 - kTabBias0) + (kTabBn1 - kTabBn0);     // 672 + 384
 constexpr int kSync = kParams + kParamFloats;
 // 20 words: [0..2] arrivals at the end of tile t of a stage-B layer (dbh_forward.hip: chain_arrive),
-// [4..19] per wave the posts of its two neighbours (halo_post)
-constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4, kSyncWords = 20;
+// [4..19] per wave the posts of its two neighbours (halo_post); the same for stage D's chain: six
+// tile words (one per tile of its two layers), then the posts
+constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4;
+constexpr int kSyncDTiles = kSync + 20, kSyncDHalo = kSyncDTiles + 6, kSyncWords = 20 + 6 + 16;
 // window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
 constexpr int kStatRed = kSync + kSyncWords;
 constexpr int kStatOut = kStatRed + 32;
