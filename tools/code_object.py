@@ -95,7 +95,109 @@ def census(insts):
     return dict(c)
 
 
+# ---------------------------------------------------------------------------------------------
+# The hazards the forward kernel keeps BY HAND.  hipcc pads the distance between an MFMA and the first
+# instruction that reads its result - for instructions it sees: not for inline asm (the clamped
+# packed adds / fmas of the Winograd output transforms, the ds_write_b64 of the edge rows), and its
+# own LDS wait counts know nothing of the inline-asm ds_read pipelines.  So the shipped instruction
+# stream is checked itself:
+#   * a v_mfma_f32_16x16x4_f32 followed by a VALU / LDS / VMEM instruction that READS one of its four
+#     result registers needs 10 wait states in between - what hipcc itself pads such a pair to (LLVM's
+#     GCNHazardRecognizer, "XDL write VGPR -> VALU / VMEM / LDS read"; the hand-written blocks
+#     start with s_nop 7, s_nop 2 = 11); every instruction in between counts one, s_nop N counts N + 1.  (An MFMA reading the result as its accumulator is not
+#     subject to this: back-to-back accumulation is what the pipe is for.)
+#   * the histogram of the literal `s_waitcnt lgkmcnt(n)` forms - the hand-counted ones are almost
+#     all of the n > 0 - is compared with the committed one (tests/golden/code_object.json).
+# ---------------------------------------------------------------------------------------------
+_REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def _vregs(text):
+    out = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def mfma_read_hazards(insts, need=10):
+    """-> [(index, instruction, producing mfma, wait states seen)] of readers that come too early"""
+    bad = []
+    pending = []                     # (result registers, wait states since, text)
+    for i, s in enumerate(insts):
+        op = s.split()[0]
+        ops = s[len(op):]
+        parts = [p.strip() for p in ops.split(',')]
+        if op.startswith('v_mfma'):
+            reads = _vregs(','.join(parts[1:3]))          # A and B operands (the accumulator is exempt)
+            writes = _vregs(parts[0])
+        elif op.startswith(('v_', 'ds_', 'global_', 'buffer_', 'flat_', 'scratch_')):
+            if op.startswith('v_') and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
+                reads, writes = _vregs(','.join(parts[1:])), _vregs(parts[0])
+            elif op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
+                reads, writes = _vregs(ops), set()
+            elif ('_load' in op or op.startswith('ds_read')) and not op.startswith('global_load_lds'):
+                # a load: the first operand is where the data will land (no read; and the register
+                # allocator's reuse of an accumulator for it is the compiler's own business)
+                reads, writes = _vregs(','.join(parts[1:])), set()
+            else:                                         # stores, atomics, LDS-DMA: everything named is read
+                reads, writes = _vregs(ops), set()
+        else:
+            reads, writes = set(), set()
+        for regs, since, text in pending:
+            if reads & regs and since < need:
+                bad.append((i, s, text, since))
+        step = 1
+        if op == 's_nop':
+            step = int(parts[0]) + 1 if parts and parts[0].isdigit() else 1
+        pending = [(r, w + step, t) for (r, w, t) in pending if w + step < need and not (writes and writes >= r)]
+        if op.startswith('v_mfma'):
+            pending.append((writes, 0, s))
+    return bad
+
+
+def lgkm_wait_histogram(insts):
+    h = collections.Counter()
+    for s in insts:
+        m = re.match(r'^s_waitcnt lgkmcnt\((\d+)\)$', s.strip())
+        if m:
+            h[int(m.group(1))] += 1
+    return {str(k): h[k] for k in sorted(h)}
+
+
+def summary(lib):
+    """everything tests/test_code_object.py looks at, as one dict"""
+    with tempfile.TemporaryDirectory() as d:
+        co = extract(lib, d)
+        md = kernel_metadata(co)
+        fwd = next(n for n in md if n.startswith('_ZN3dbh18dbh_forward_kernel'))
+        insts = disassemble(co, fwd)
+        c = census(insts)
+        return {
+            'metadata': {k: md[fwd].get(k) for k in ('vgpr_count', 'agpr_count', 'sgpr_count', 'vgpr_spill_count',
+                                                     'sgpr_spill_count', 'private_segment_fixed_size',
+                                                     'group_segment_fixed_size')},
+            'census': c,
+            'lgkm_waits': lgkm_wait_histogram(insts),
+            'mfma_read_hazards': [list(b) for b in mfma_read_hazards(insts)][:20],
+        }
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--bless':
+        # record what the built library carries (tests/golden/code_object.json): run after every
+        # deliberate change of the forward kernel, and read the diff
+        lib = os.path.join(os.path.dirname(__file__), '..', 'deepbinner_amd', 'libdeepbinner_hip.so')
+        s = summary(lib)
+        keep = {'mfma_static': s['census']['mfma'], 'lds_dma': s['census'].get('lds_dma', 0),
+                's_barrier': s['census'].get('s_barrier', 0), 'lgkm_waits': s['lgkm_waits'],
+                'vgpr_count': int(s['metadata']['vgpr_count']), 'sgpr_spill_count': int(s['metadata']['sgpr_spill_count'])}
+        path = os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'code_object.json')
+        json.dump(keep, open(path, 'w'), indent=1, sort_keys=True)
+        print(json.dumps(keep, indent=1, sort_keys=True))
+        return
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), '..', 'deepbinner_amd',
                                                              'libdeepbinner_hip.so')
     with tempfile.TemporaryDirectory() as d:
