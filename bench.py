@@ -658,6 +658,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = launches = windows = 0
     shader_ghz = None
+    phase_cycles, phase_groups = None, 0
     per_device = run_all(lambda j: j.launch_stats())
     own = per_device[0]         # (the lead's: device 0 of this process)
     if rdzv is not None:        # one process per GPU: every rank's figures travel to all
@@ -668,6 +669,10 @@ def main():
         run_all(lambda j: j.models[0].timing_enable(False))
         if not args.no_kernel_timing:
             shader_ghz = lead.timing_model.clock_read()      # of the timed region's last launch
+            try:        # the same launch's phases (groups of four windows: dbh_forward_phases_read)
+                phase_cycles, phase_groups = lead.timing_model.phases_read()
+            except Exception:
+                phase_cycles, phase_groups = None, 0
             lead.timing_model.clock_enable(False)
     if rdzv is not None:
         elapsed = rdzv.max_float(elapsed)
@@ -775,6 +780,14 @@ def main():
             # every workgroup (s_memtime against the 100 MHz s_memrealtime, median).  In CYCLES -
             # which is what "how busy is the pipe" means - the matrix pipe is this busy:
             'shader_clock_ghz': shader_ghz,
+            # shader cycles per GROUP of four windows and phase, steady-state groups of the timed
+            # region's last launch, measured by the shipped kernel itself (one lane's clock reads
+            # behind barriers): stages A-C of its windows, the stage D-E chain, stage F of its windows,
+            # the batched tail (every second group), between two groups
+            'phase_cycles_per_group': (
+                dict(zip(['stages_a_c', 'chain_d_e', 'stage_f', 'tail', 'between', 'f_mfma', 'f_barrier', 'f_reduce', 'f_end_barrier'],
+                         [round(c, 1) for c in phase_cycles]), groups=phase_groups)
+                if phase_groups else None),
             'mfma_pipe_util_at_shader_clock': (
                 pmc['mfma_busy_cycles_per_window'] * rate / (1024 * shader_ghz * 1e9)
                 if shader_ghz and 'mfma_busy_cycles_per_window' in pmc else None),

@@ -349,7 +349,8 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.win_counter = (debug_stage < 0 && m->windows_by_counter) ? (int*)*tail : nullptr;
         a.clock_out = nullptr;
         if (m->clock_probe && debug_stage < 0) {
-            const int st = ensure(&m->d_clock, &m->clock_bytes, (size_t)grid * 4 * sizeof(int64_t));
+            const int st = ensure(&m->d_clock, &m->clock_bytes,
+                                  (size_t)grid * (4 + dbh::kPhaseMarks * dbh::kPhaseGroups) * sizeof(int64_t));
             if (st != DBH_OK) return st;
             a.clock_out = (long long*)m->d_clock;
             m->clock_grid = grid;
@@ -1573,20 +1574,57 @@ int dbh_forward_clock_read(dbh_model* m, double* shader_ghz) {
     if (!m->clock_probe || m->clock_grid == 0 || !m->d_clock) return DBH_ERR_INVALID_ARGUMENT;
     DBH_HIP(hipSetDevice(m->device));
     DBH_HIP(hipDeviceSynchronize());
-    std::vector<int64_t> c((size_t)m->clock_grid * 4);
+    const size_t per_wg = 4 + dbh::kPhaseMarks * dbh::kPhaseGroups;
+    std::vector<int64_t> c((size_t)m->clock_grid * per_wg);
     DBH_HIP(hipMemcpy(c.data(), m->d_clock, c.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
     int wall_khz = 0;      // the rate of s_memrealtime (100 MHz on this hardware)
     DBH_HIP(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, m->device));
     if (wall_khz <= 0) return DBH_ERR_HIP;
     std::vector<double> ratios;
     for (unsigned b = 0; b < m->clock_grid; ++b) {
-        const double shader = (double)(c[b * 4 + 2] - c[b * 4]);
-        const double wall = (double)(c[b * 4 + 3] - c[b * 4 + 1]);
+        const double shader = (double)(c[b * per_wg + 2] - c[b * per_wg]);
+        const double wall = (double)(c[b * per_wg + 3] - c[b * per_wg + 1]);
         if (shader > 0 && wall > 0) ratios.push_back(shader / wall);
     }
     if (ratios.empty()) return DBH_ERR_HIP;
     std::nth_element(ratios.begin(), ratios.begin() + ratios.size() / 2, ratios.end());
     *shader_ghz = ratios[ratios.size() / 2] * (double)wall_khz * 1e-6;
+    return DBH_OK;
+}
+
+int dbh_forward_phases_read(dbh_model* m, double* mean_cycles, int64_t* groups) {
+    if (!m || !mean_cycles || !groups) return DBH_ERR_INVALID_ARGUMENT;
+    if (!m->clock_probe || m->clock_grid == 0 || !m->d_clock) return DBH_ERR_INVALID_ARGUMENT;
+    DBH_HIP(hipSetDevice(m->device));
+    DBH_HIP(hipDeviceSynchronize());
+    const size_t per_wg = 4 + dbh::kPhaseMarks * dbh::kPhaseGroups;
+    std::vector<int64_t> c((size_t)m->clock_grid * per_wg);
+    DBH_HIP(hipMemcpy(c.data(), m->d_clock, c.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    // steady state: not a workgroup's first group (cold), and only groups followed by another one
+    // (the last interval runs to the next group's first stamp)
+    double sum[dbh::kPhaseMarks] = {};
+    int64_t n = 0;
+    for (unsigned b = 0; b < m->clock_grid; ++b) {
+        const int64_t* s = c.data() + b * per_wg + 4;
+        for (int g = 1; g + 1 < dbh::kPhaseGroups; ++g) {
+            const int64_t* a = s + g * dbh::kPhaseMarks;
+            if (a[0] < 0 || a[dbh::kPhaseMarks] < 0 || a[dbh::kPhaseMarks + 1] < 0) break;
+            bool ok = true;
+            double d[dbh::kPhaseMarks];
+            for (int i = 0; i < 5; ++i) {
+                // (the fifth interval runs to the next group's first stamp)
+                const int64_t from = a[i], to = i < 4 ? a[i + 1] : a[dbh::kPhaseMarks];
+                d[i] = (double)(uint32_t)((uint32_t)to - (uint32_t)from);
+                if (d[i] > 4e6) ok = false;                      // (a group that skipped a phase)
+            }
+            for (int i = 5; i < dbh::kPhaseMarks; ++i) d[i] = (double)a[i];      // (sums of intervals)
+            if (!ok) continue;
+            for (int i = 0; i < dbh::kPhaseMarks; ++i) sum[i] += d[i];
+            ++n;
+        }
+    }
+    for (int i = 0; i < dbh::kPhaseMarks; ++i) mean_cycles[i] = n ? sum[i] / (double)n : 0.0;
+    *groups = n;
     return DBH_OK;
 }
 

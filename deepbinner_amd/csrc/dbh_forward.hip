@@ -1826,10 +1826,11 @@ __device__ __forceinline__ void d_load_y(f2 (&Y)[3][2][4], Ptr src) {
 // =============================================================================================
 __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restrict__ packed,
                                               float* __restrict__ wg_scratch, int lane, int wave,
-                                              unsigned* ts, unsigned& d_groups, f2 (&Y)[3][2][4]) {
+                                              unsigned* ts, unsigned& d_groups, f2 (&Y)[3][2][4],
+                                              float* dump3, bool stop3, int cat_base) {
     const int n = lane & 15, q = lane >> 4;
     const int k = wave >> 1, hf = wave & 1;
-    const unsigned tiles0 = d_groups * 8u, halos0 = d_groups * 4u;
+    const unsigned tiles0 = d_groups * 8u, halos0 = d_groups * 7u;
     d_groups += 1;
     constexpr int NW = DBH_DMA_WAVES;
     static_assert(NW == 4, "the request schedule below deals pieces to four waves");
@@ -1902,10 +1903,10 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                      : "memory");
         if constexpr (h == 1) halo_post(post_addr);
     };
-    // half h of the epilogue of tile g of conv9: outputs, MaxPool2, BN4 -> X rows 1 + 32 hf + 2n + p,
-    // channels 16g + 4q + 2h, + 1: window 0's in LDS, the others' in their parks
-    lds_f2* x_lds = (lds_f2*)lds_pinned(lds + kEX + (1 + 32 * hf + 2 * n) * kS48 + 4 * q);
-    float* x_park = wg_scratch + kWgParkXOff + k * kParkXFloats + (1 + 32 * hf + 2 * n) * kS48 + 4 * q;
+    // half h of the epilogue of tile g of conv9: outputs, MaxPool2, BN4 -> X[g][h][p]: channels 16g +
+    // 4q + 2h, + 1 of pooled positions 2j + p (j = 16 hf + n: the lane's PAIR of the window's 64) -
+    // the B operand of the inception block's 1x1 convolutions as it stands
+    f2 X[3][2][2];
     auto store = [&](auto g_tag, auto h_tag, const f4(&a)[6]) {
         constexpr int g = decltype(g_tag)::value, h = decltype(h_tag)::value;
         f2 y[4];
@@ -1913,14 +1914,15 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
         const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(3) - kTabBn0)) / 4 + 4 * g];
         const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(3) - kTabBn0)) / 4 + 4 * g];
         const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
-        const f2 x0 = __builtin_elementwise_fma(f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)}, sc, sh);
-        const f2 x1 = __builtin_elementwise_fma(f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)}, sc, sh);
-        if (k == 0) {
-            x_lds[(16 * g + 2 * h) / 2] = x0;
-            x_lds[(kS48 + 16 * g + 2 * h) / 2] = x1;
-        } else {
-            *reinterpret_cast<f2*>(x_park + 16 * g + 2 * h) = x0;
-            *reinterpret_cast<f2*>(x_park + kS48 + 16 * g + 2 * h) = x1;
+        X[g][h][0] = __builtin_elementwise_fma(f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)}, sc, sh);
+        X[g][h][1] = __builtin_elementwise_fma(f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)}, sc, sh);
+        if (dump3 != nullptr) {        // debug_stage 3 (wave-uniform): dense [64][48]
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                float* dst = dump3 + (32 * hf + 2 * n + pp) * 48 + 16 * g + 4 * q + 2 * h;
+                dst[0] = X[g][h][pp].x * kActUnscale;
+                dst[1] = X[g][h][pp].y * kActUnscale;
+            }
         }
     };
     const IntC<0> c0;
@@ -1930,8 +1932,7 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
     u2 pk_h = u2{0u, 0u};
     const float* w8 = packed + weight_offset(7);
     const float* w9 = packed + weight_offset(8);
-    const float* we = packed + weight_offset(9);        // conv10 .. conv14, contiguous
-    static_assert(weight_offset(14) - weight_offset(9) == kEWLowEnd - kEW10, "");
+    const float* we = packed + weight_offset(9);        // conv10 .. conv15, contiguous: 48 pieces
 
     // ---- conv8.  Tile 0 builds U from Y and the partner's edge rows.
     halo_wait<kSyncDHalo>(lds, wave, halos0 + 1);
@@ -1971,8 +1972,11 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
             if constexpr (SP == 1) finish(c1, c0, acc[0]);
             if constexpr (SP == 3) finish(c1, c1, acc[0]);
             // conv9's third 1 follows conv8's third 0 out of slot 0; conv15 (12 pieces) to its home
+            // ... then the first half of conv10 .. conv15 (48 pieces, twelve per wave) to the front of
+            // the arena - where the group's last window had its conv7 output until its two waves read
+            // it (before their arrival behind tile 0, which every wave has seen by now)
             if constexpr (SP < 3) copy_step(third_floats, w9 + kWinoHalf, lds + kDS0, SP);
-            else copy_step(IntC<conv_weight_floats(14)>{}, packed + weight_offset(14), lds + kEW15, SP - 3);
+            else copy_step(IntC<kEWEnd>{}, we, lds + kEW10, SP - 3);
         });
     chain_arrive(arrive_addr, 2);
     mark(ts, 29);
@@ -1993,12 +1997,9 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 0) finish(c2, c0, acc[1]);
             if constexpr (SP == 1) finish(c2, c1, acc[1]);
-            // conv9's third 2 follows conv8's third 1 out of slot 1; then conv10 .. conv14 (36 pieces,
-            // nine per wave) to their stage-E home - where the group's last window had its conv7
-            // output until its two waves read it (before their arrival behind tile 0, which every
-            // wave has seen by now)
+            // conv9's third 2 follows conv8's third 1 out of slot 1; then the rest of conv10 .. conv15
             if constexpr (SP < 3) copy_step(third_floats, w9 + 2 * kWinoHalf, lds + kDS1, SP);
-            else copy_step(IntC<kEWLowEnd - kEW10>{}, we, lds + kEW10, SP - 3);
+            else copy_step(IntC<kEWEnd>{}, we, lds + kEW10, SP);
         });
     chain_arrive(arrive_addr, 3);
     mark(ts, 30);
@@ -2012,22 +2013,333 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 1) store(c0, c0, acc[0]);
             if constexpr (SP == 3) store(c0, c1, acc[0]);
-            if constexpr (SP < 2) copy_step(IntC<kEWLowEnd - kEW10>{}, we, lds + kEW10, SP + 3);
+            // conv16's first two matrices' worth -> slot 2 (every wave has left conv8's tile 2: the
+            // check in front of this tile), and BN5's parameters
+            if constexpr (SP < 3) copy_step(third_floats, packed + weight_offset(15), lds + kDS2, SP);
+            if constexpr (SP == 3)
+                dma_weights<512, 2>(packed + bn_scale_offset(4), lds + kEBn5, lane, wave);
         });
+    chain_arrive(arrive_addr, 4);
     mark(ts, 31);
     chain_check<kSyncDTiles>(lds, 3, pk_a, tiles0 + 8);      // conv9's third 2 has landed in slot 1
     w43t_tile<-1, 12, 18, B9 + 32, 0, 1>(
-        U, Y, h_addr, bias_addr, lds + kDS1 + lane * 4, acc[0], wave_hi, NoPre(), [&](auto tag) {
+        U, Y, h_addr, bias_addr, lds + kDS1 + lane * 4, acc[0], wave_hi,
+        [&](auto tag) {
+            if constexpr (decltype(tag)::value == 5) pk_a = chain_peek<kSyncDTiles>(lds, 4);
+        },
+        [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (SP == 1) store(c1, c0, acc[1]);
             if constexpr (SP == 3) store(c1, c1, acc[1]);
+            // conv16's other half -> slot 3 (every wave has left conv9's tile 0: the check in front
+            // of this tile)
+            if constexpr (SP < 3)
+                copy_step(third_floats, packed + weight_offset(15) + kWinoHalf, lds + kDS3, SP);
         });
     store(c2, c0, acc[0]);
     store(c2, c1, acc[0]);
-    // the two zero rows of window 0's image ('same' padding of the inception block's k = 3 layers)
-    if (k == 0 && lane < kS48) lds[kEX + (hf ? 65 * kS48 : 0) + lane] = 0.f;
+    chain_arrive(arrive_addr, 5);
     mark(ts, 32);
-    // X of window 0 is out, the parks' stores are out, conv10 .. conv15 have landed
+    if (stop3) {        // debug_stage 3 / 103: stage D only
+        full_barrier();
+        return;
+    }
+
+    // =========================================================================================
+    // STAGE E ON THE SAME REGISTERS: the inception block (network_architecture.py:54-74) for this
+    // lane's pair of positions 2j, 2j + 1 of its window's 64 - transposed like everything in the
+    // chain (M = 16 output channels = the weights as the A operand, N = the wave's 16 pairs):
+    //   conv11 (1x1, 48 -> 48)                          72 MFMAs  -> concat 48..95
+    //   conv10 (1x1 on the 3-tap average of X = the 3-tap average of its products: a 1x1 convolution
+    //           commutes with a pooling along the positions)      72         -> concat 0..47
+    //   conv12 (1x1 -> 16) -> conv13 (k3, F(2,3) as conv6 runs it) 24 + 48   -> concat 96..143
+    //   conv14 (1x1 -> 16) -> conv15 (k3, F(2,3)) -> conv16 (k3, 48 -> 48, F(2,3): 144 instead of
+    //           the direct form's 216)                            24 + 48 + 144 -> concat 144..191
+    // each followed by ReLU, MaxPool2 - the max of the pair's two outputs, in-lane - and BN5.  What
+    // crosses lanes: one position each side for the k = 3 layers and the average - a DPP row shift;
+    // at a wave's end that meets its partner, 16 or 48 floats through LDS (the window's two ends
+    // are zero rows the wave writes itself), announced on the chain's post words.  432 MFMAs per
+    // wave = 864 per window, where the block as three barrier-separated phases out of LDS images
+    // took 1,008 at two thirds of the pipe's rate.
+    //   The output - lane (n, q): pooled position j = 16 hf + n, channels 16t + 4q + r of each branch -
+    // goes to the window's concat image (34 x 196, rows 0 and 33 zero): window 0's in LDS buffer A,
+    // the others' in their parks.
+    // =========================================================================================
+    // BN5's parameters have landed (requested in conv9's tile 1, whose arrival every wave has made)
+    chain_check<kSyncDTiles>(lds, 4, pk_a, tiles0 + 8);
+    const unsigned ehalos0 = halos0 + 4u;
+    // (zero rows at the window's ends: the 16-channel array, written here; the 48-channel ones are
+    // stage D's, whose end rows are zero already)
+    if (lane < 32) lds[kEHaloZ + (wave * 2 + hf) * 32 + lane] = 0.f;
+    const unsigned ez_edge = is_edge ? lds_addr(lds + kEHaloZ + ((wave ^ 1) * 2 + hf) * 32 + 4 * q) : dummy_addr;
+    // (the edge lane's slot of stage D's arrays, or the scratch: exactly one of a0 / a3 is the slot)
+    const unsigned z48_addr = hf ? a0_addr[0] : a3_addr[0];      // array 0: conv10's products
+    const unsigned y48_addr = hf ? a0_addr[1] : a3_addr[1];      // array 1: conv15's output
+    const float third = 1.f / 3.f;
+    const int j = 16 * hf + n;
+    // This lane's 48 outputs - pooled position j, channels 48 b + 16 t + 4q + r of branch b - stay in
+    // registers to the end of the block: the concat images lie where its weights do.
+    f4 OUT[4][3];
+    const f4* bn5 = reinterpret_cast<const f4*>(lds + kEBn5 + 4 * q);        // + ch / 4: scale; + 48: shift
+    auto pooled_out = [&](f4& dst, int ch, f4 a, f4 b) {       // ReLU'd pair -> MaxPool2 -> BN5
+        const f4 sc = bn5[ch / 4], sh = bn5[48 + ch / 4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = fmaf(fmaxf(a[r], b[r]), sc[r], sh[r]);
+        // (pinned: the result is used under a condition at the end of the block, and the compiler
+        // sinks its whole computation there - keeping four raw accumulators alive per quadruple
+        // instead of the quadruple: 87 spilled registers)
+        asm volatile("" : "+v"(dst));
+    };
+    auto relu4 = [](f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; };
+    constexpr int TB = kTabBias0;
+
+    // ---- conv12, conv14 (1x1, 48 -> 16): Z3, Z4 = channels 4q + r of the pair's two positions
+    f4 Z3[2], Z4[2];
+    {
+        f2 w12[6], w14[6];
+#pragma unroll
+        for (int sp = 0; sp < 6; ++sp) {
+            w12[sp] = *reinterpret_cast<const f2*>(lds + kEW12 + sp * 128 + lane * 2);
+            w14[sp] = *reinterpret_cast<const f2*>(lds + kEW14 + sp * 128 + lane * 2);
+        }
+        const f4 b12 = tab4[(bias_offset(11) - TB) / 4], b14 = tab4[(bias_offset(13) - TB) / 4];
+#pragma unroll
+        for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const f2 x = X[sp >> 1][sp & 1][pp];
+                Z3[pp] = mfma4(w12[sp].x, x.x, sp == 0 ? b12 : Z3[pp]);
+                Z4[pp] = mfma4(w14[sp].x, x.x, sp == 0 ? b14 : Z4[pp]);
+                Z3[pp] = mfma4(w12[sp].y, x.y, Z3[pp]);
+                Z4[pp] = mfma4(w14[sp].y, x.y, Z4[pp]);
+            }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            Z3[pp] = relu4(Z3[pp]);
+            Z4[pp] = relu4(Z4[pp]);
+        }
+        // the position that meets the partner wave: an even wave's last (2j + 1 of its lane 15),
+        // an odd wave's first (2j of its lane 0)
+        const f4 s3 = hf ? Z3[0] : Z3[1], s4 = hf ? Z4[0] : Z4[1];
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:64" ::"v"(ez_edge), "v"(s3), "v"(s4)
+                     : "memory");
+        halo_post(post_addr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 34);
+    // ---- conv10's products z = W10 . x for the two positions (no bias yet: the average comes first)
+    f4 z10[3][2];
+    {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f2 w[6];
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+                w[sp] = *reinterpret_cast<const f2*>(lds + kEW10 + (sp * 3 + t) * 128 + lane * 2);
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const f2 x = X[sp >> 1][sp & 1][pp];
+                    z10[t][pp] = mfma4(w[sp].x, x.x, sp == 0 ? f4{0.f, 0.f, 0.f, 0.f} : z10[t][pp]);
+                    z10[t][pp] = mfma4(w[sp].y, x.y, z10[t][pp]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f4 sz = hf ? z10[t][0] : z10[t][1];
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(z48_addr), "v"(sz), "n"(t * 64) : "memory");
+        }
+        halo_post(post_addr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 35);
+    // the F(2,3) layers on a 16-channel pair (conv13 on Z3, conv15 on Z4), as conv6 runs at the end
+    // of stage B's chain: U1 = d1 + d2, U2 = d2 - d1 in-lane, U0 = d0 - d2 and U3 = d1 - d3 with the
+    // neighbours' positions; M0 starts at the bias, M3 at minus the bias; even = M0 + M1 + M2,
+    // odd = M1 - M2 - M3
+    auto wino16 = [&](const float* w_lds, int bias_off, const f4(&Z)[2], int zoff, f4(&even)[3], f4(&odd)[3]) {
+        const f4 hl = *reinterpret_cast<const f4*>(lds + kEHaloZ + (wave * 2 + 0) * 32 + zoff + 4 * q);
+        const f4 hr = *reinterpret_cast<const f4*>(lds + kEHaloZ + (wave * 2 + 1) * 32 + zoff + 4 * q);
+        f4 U0, U3;
+        const f4 U1 = Z[0] + Z[1], U2 = Z[1] - Z[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            U0[c] = row_from_left(hl[c], Z[1][c]) - Z[1][c];
+            U3[c] = Z[0][c] - row_from_right(hr[c], Z[0][c]);
+        }
+        // (one N tile at a time - four fragments, four chains of four MFMAs: all three at once held
+        // 96 registers of fragments and accumulators beside what the block keeps)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f4 wf[2][2];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    wf[sp][pr] = *reinterpret_cast<const f4*>(w_lds + ((t * 2 + sp) * 2 + pr) * 256 + lane * 4);
+            const f4 b = tab4[(bias_off - TB) / 4 + 4 * t];
+            const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+            f4 M0, M1, M2, M3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                M0 = mfma4(wf[c >> 1][0][c & 1], U0[c], c == 0 ? b : M0);
+                M1 = mfma4(wf[c >> 1][0][2 + (c & 1)], U1[c], c == 0 ? zero4 : M1);
+                M2 = mfma4(wf[c >> 1][1][c & 1], U2[c], c == 0 ? zero4 : M2);
+                M3 = mfma4(wf[c >> 1][1][2 + (c & 1)], U3[c], c == 0 ? -b : M3);
+            }
+            even[t] = relu4(M0 + M1 + M2);
+            odd[t] = relu4(M1 - M2 - M3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ---- conv11 (1x1, 48 -> 48) -> concat 48..95
+    {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f2 w[6];
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+                w[sp] = *reinterpret_cast<const f2*>(lds + kEW11 + (sp * 3 + t) * 128 + lane * 2);
+            const f4 b = tab4[(bias_offset(10) - TB) / 4 + 4 * t];
+            f4 a[2];
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const f2 x = X[sp >> 1][sp & 1][pp];
+                    a[pp] = mfma4(w[sp].x, x.x, sp == 0 ? b : a[pp]);
+                    a[pp] = mfma4(w[sp].y, x.y, a[pp]);
+                }
+            pooled_out(OUT[1][t], 48 + 16 * t, relu4(a[0]), relu4(a[1]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 39);
+    // ---- conv13 -> concat 96..143
+    halo_wait<kSyncDHalo>(lds, wave, ehalos0 + 1);
+    {
+        f4 ev[3], od[3];
+        wino16(lds + kEW13, bias_offset(12), Z3, 0, ev, od);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) pooled_out(OUT[2][t], 96 + 16 * t, ev[t], od[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 36);
+    // ---- conv15 -> the pair of conv16's input positions (48 channels: Y16[t][p] = channels 16t + 4q + r)
+    f4 Y16[3][2];
+    {
+        f4 ev[3], od[3];
+        wino16(lds + kEW15, bias_offset(14), Z4, 16, ev, od);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            Y16[t][0] = ev[t];
+            Y16[t][1] = od[t];
+            const f4 sy = hf ? ev[t] : od[t];
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(y48_addr), "v"(sy), "n"(t * 64) : "memory");
+        }
+        halo_post(post_addr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 37);
+    // ---- conv10: the average over positions p - 1, p, p + 1 of its products (TensorFlow's valid-count
+    // divisor: two taps at a window's end), bias, ReLU -> concat 0..47
+    halo_wait<kSyncDHalo>(lds, wave, ehalos0 + 2);
+    {
+        const float inv_first = j == 0 ? 0.5f : third, inv_last = j == 31 ? 0.5f : third;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f4 hl = *reinterpret_cast<const f4*>(lds + kDHalo + (wave * 2 + 0) * 48 + 16 * t + 4 * q);
+            const f4 hr = *reinterpret_cast<const f4*>(lds + kDHalo + (wave * 2 + 1) * 48 + 16 * t + 4 * q);
+            const f4 b = tab4[(bias_offset(9) - TB) / 4 + 4 * t];
+            f4 y0, y1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float prev = row_from_left(hl[c], z10[t][1][c]);       // position 2j - 1
+                const float next = row_from_right(hr[c], z10[t][0][c]);      // position 2j + 2
+                const float mid = z10[t][0][c] + z10[t][1][c];
+                y0[c] = fmaxf(fmaf(prev + mid, inv_first, b[c]), 0.f);
+                y1[c] = fmaxf(fmaf(mid + next, inv_last, b[c]), 0.f);
+            }
+            pooled_out(OUT[0][t], 16 * t, y0, y1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 38);
+    // ---- conv16 (k3, 48 -> 48) as F(2,3) on the pair -> concat 144..191.  Its four matrices lie in
+    // stage D's slots 2 and 3 (requested in its last two tiles; every wave's pieces have landed when
+    // every wave has arrived behind them).
+    chain_wait<kSyncDTiles>(lds, 5, tiles0 + 8);
+    halo_wait<kSyncDHalo>(lds, wave, ehalos0 + 3);
+    {
+        f4 U0[3], U1[3], U2[3], U3[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f4 hl = *reinterpret_cast<const f4*>(lds + kDHalo + kDHaloLayer + (wave * 2 + 0) * 48 + 16 * t + 4 * q);
+            const f4 hr = *reinterpret_cast<const f4*>(lds + kDHalo + kDHaloLayer + (wave * 2 + 1) * 48 + 16 * t + 4 * q);
+            U1[t] = Y16[t][0] + Y16[t][1];
+            U2[t] = Y16[t][1] - Y16[t][0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                U0[t][c] = row_from_left(hl[c], Y16[t][1][c]) - Y16[t][1][c];
+                U3[t][c] = Y16[t][0][c] - row_from_right(hr[c], Y16[t][0][c]);
+            }
+        }
+    #pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f4 b = tab4[(bias_offset(15) - TB) / 4 + 4 * t];
+            const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+            f4 M0, M1, M2, M3;
+            // (the fragments of a third of the contraction at a time: twelve registers' worth less
+            // to hold beside this lane's 48 outputs)
+#pragma unroll
+            for (int third_k = 0; third_k < 3; ++third_k) {
+                f4 wf[2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr)
+                        wf[s2][pr] = *reinterpret_cast<const f4*>(
+                            lds + kEW16 + ((t * 6 + 2 * third_k + s2) * 2 + pr) * 256 + lane * 4);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        // k-step 2 sp + e <-> channels 16 tc + 4q + r, sp = 2 third_k + s2
+                        const int tc = third_k, r = 2 * s2 + e;
+                        const bool first = third_k == 0 && s2 == 0 && e == 0;
+                        M0 = mfma4(wf[s2][0][e], U0[tc][r], first ? b : M0);
+                        M1 = mfma4(wf[s2][0][2 + e], U1[tc][r], first ? zero4 : M1);
+                        M2 = mfma4(wf[s2][1][e], U2[tc][r], first ? zero4 : M2);
+                        M3 = mfma4(wf[s2][1][2 + e], U3[tc][r], first ? -b : M3);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pooled_out(OUT[3][t], 144 + 16 * t, relu4(M0 + M1 + M2), relu4(M1 - M2 - M3));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mark(ts, 40);
+    // every wave is through with the block's weights (and stage D's slots): the concat images go
+    // over them - row 1 + j, channels 48 b + 16 t + 4q + r - with their two zero rows (conv1d_17's
+    // 'same' padding); cat_base < 0: a window the group does not have
+    lds_barrier();
+    if (cat_base >= 0) {
+        lds_float* cat = lds_pinned(lds + cat_base + (1 + j) * kS192 + 4 * q);
+#pragma unroll
+        for (int br = 0; br < 4; ++br)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                *reinterpret_cast<__attribute__((address_space(3))) f4*>(cat + 48 * br + 16 * t) = OUT[br][t];
+        if (lane < 49) {
+            f4* row = reinterpret_cast<f4*>(lds + cat_base + (hf ? 33 * kS192 : 0));
+            row[lane] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // the images are out (and what stage F's first window needs of global memory has landed)
     full_barrier();
     mark(ts, 33);
 }
@@ -2336,6 +2648,9 @@ struct SmallMRegs {
 // wave calls pre_barrier before it, post_barrier after it).
 // between(tap): a request of the caller's behind the MFMAs of tap `tap` (LDS-DMA pieces: one at a
 // time between MFMAs instead of a bunch in front of them).
+// all_waves (TO_GLOBAL only): the partial tiles are summed by ALL eight waves, 24 of the 192 output
+// quadruples each (ep_all: bias / BN of this lane's quadruple: small_m_all_params), instead of by
+// waves 0-2 while the others wait for them at the next barrier.
 template <int CONV, int S_IN, int STRIDE, int KS, int NTW, bool POOL, bool BN, bool TO_GLOBAL = false,
           class PreBarrier = NoHook, class PostBarrier = NoHook, class Between = NoBetween>
 __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region, float* out_region,
@@ -2343,7 +2658,8 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
                                               int wave, unsigned* ts, int ts_base,
                                               const PreBarrier& pre_barrier = PreBarrier(),
                                               const PostBarrier& post_barrier = PostBarrier(),
-                                              const Between& between = Between()) {
+                                              const Between& between = Between(),
+                                              const EpiParams<1, BN>* ep_all = nullptr) {
     using R = SmallMRegs<CONV, KS, NTW, BN>;
     constexpr int TAPS = R::TAPS, SP = R::SP;
     const int n = lane & 15, q = lane >> 4;
@@ -2390,7 +2706,19 @@ __device__ __forceinline__ void small_m_layer(float* lds, const float* in_region
         lds_barrier();
         mark(ts, ts_base + 1);
         post_barrier();
-        if (wave < 3) {
+        if (ep_all != nullptr) {
+            if constexpr (TO_GLOBAL) {
+                if (lane < 24) {
+                    const int e = wave * 24 + lane, t = e >> 6, l2 = e & 63;
+                    f4 sum[1][1];
+                    sum[0][0] = *reinterpret_cast<const f4*>(red + t * 256 + l2 * 4);
+#pragma unroll
+                    for (int ks = 1; ks < KS; ++ks)
+                        sum[0][0] += *reinterpret_cast<const f4*>(red + (ks * 3 + t) * 256 + l2 * 4);
+                    epilogue<1, 1, 48, false, BN>(sum, out_region + 4 * (l2 >> 4) * 48 + t * 16 + (l2 & 15), *ep_all);
+                }
+            }
+        } else if (wave < 3) {
             const int t = wave;
             f4 sum[1][1];
             sum[0][0] = *reinterpret_cast<const f4*>(red + t * 256 + lane * 4);
@@ -2712,8 +3040,9 @@ struct ForwardArgs {
                                  // workgroup takes its next group of windows off this counter;
                                  // [1] counts the workgroups that have finished (both 0 between
                                  // launches: the last workgroup of a launch resets them)
-    long long* clock_out;        // [grid][4] or null: shader clock and 100 MHz clock at a
-                                 // workgroup's start and end (dbh_forward_clock_read)
+    long long* clock_out;        // [grid][4 + kPhaseMarks * kPhaseGroups] or null: shader clock and 100
+                                 // MHz clock at a workgroup's start and end (dbh_forward_clock_read),
+                                 // then the phase stamps of its first groups (dbh_forward_phases_read)
     double score_diff;
     long long read0, len_hint, hint_cap;     // dbh_model_set_read_length_hint
     long long n_windows;
@@ -2817,10 +3146,30 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     const int tid_entry = threadIdx.x;
     // clock probe (off unless asked for): how fast the shader clock really runs under this load
     if (args()->clock_out != nullptr && tid_entry == 0) {
-        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * 4;
+        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * (4 + kPhaseMarks * kPhaseGroups);
         c[0] = (long long)__builtin_readcyclecounter();
         c[1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
+    // PHASE STAMPS (clock probe on): the shader clock at five points of every group - its start, the
+    // end of its stage A-C loop, of the stage D-E chain, of its stage F loop, of the batched tail -
+    // taken by one lane right behind a barrier (nothing in flight that the counter's read could
+    // hold up) and kept in LDS until the workgroup is done: the kernel measured is the kernel that
+    // ships.
+    const bool phases_on = args()->clock_out != nullptr;
+    int phase_group = 0;
+    auto phase_stamp = [&](int mark) {
+        if (phases_on && threadIdx.x == 0 && phase_group < kPhaseGroups)
+            reinterpret_cast<unsigned*>(lds + kPhase)[phase_group * kPhaseMarks + mark] =
+                (unsigned)__builtin_readcyclecounter();
+    };
+    // (an interval of stage F, added to the group's word `mark`; `since` moves on)
+    auto phase_add = [&](int mark, unsigned& since) {
+        if (phases_on && threadIdx.x == 0 && phase_group < kPhaseGroups) {
+            const unsigned now = (unsigned)__builtin_readcyclecounter();
+            reinterpret_cast<unsigned*>(lds + kPhase)[phase_group * kPhaseMarks + mark] += now - since;
+            since = now;
+        }
+    };
     // debug_stage k: dump the activations after stage k and stop; 100+k: just stop (timing).
     const int stop_stage = debug_stage >= 100 ? debug_stage - 100 : debug_stage;
 
@@ -2850,13 +3199,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     unsigned pair_rounds = 0;     // exchanges the wave pairs of conv7 have made so far
 
     // This workgroup's scratch in global memory (dbh_layout.h: kWgScratchFloats): conv17's outputs
-    // waiting for the batched tail, conv7's parks, X's parks - whose zero rows (the 'same' padding of
-    // the inception block's k = 3 layers: rows 0 and 65 of each image) are written once per launch.
+    // waiting for the batched tail, and conv7's parks.
     float* const wg_scratch_entry = glob(args()->tail_scratch) + (size_t)blockIdx.x * kWgScratchFloats;
-    for (int i = tid_entry; i < kGroup * 2 * kS48; i += kThreads) {
-        const int kk = i / (2 * kS48), r = (i / kS48) & 1, c = i % kS48;
-        wg_scratch_entry[kWgParkXOff + kk * kParkXFloats + (r ? 65 * kS48 : 0) + c] = 0.f;
-    }
+
 
     // PERSISTENT GRID, GROUPS OF WINDOWS: the launch has at most one workgroup per CU (what 160 KiB
     // of LDS allows anyway).  A workgroup takes kGroup = 4 consecutive windows at a time: stages A,
@@ -2877,7 +3222,19 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // debug_stage >= 0 (tests, timeline): the batched tail runs behind every group
     const bool tail_every_group = debug_stage >= 0;
 
+    // the first window of the next group, fetched under the group's last stage F: count, left padding
+    // and this lane's two samples
+    int carry_cnt = 0, carry_pad = 0, carry_v0 = 0, carry_v1 = 0;
+
     while (group_n > 0) {
+    // (taken over and cleared at once: defined on every path round the loop, the four do not count as
+    // live across stage B)
+    const int first_cnt = carry_cnt, first_pad = carry_pad;
+    int first_v0 = carry_v0, first_v1 = carry_v1;
+    carry_cnt = 0;
+    carry_pad = 0;
+    carry_v0 = 0;
+    carry_v1 = 0;
     // how many windows the NEXT group asks for: by what was left when this one was handed out
     const int left_now = n_windows - (group_start + group_n);
     const int chunk_next = win_counter_entry == nullptr             ? kGroup
@@ -2889,6 +3246,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     int next_n = n_windows - next_start <= 0 ? 0
                  : n_windows - next_start < kGroup ? n_windows - next_start : kGroup;
 
+    phase_stamp(0);
+    if (phases_on && threadIdx.x == 0 && phase_group < kPhaseGroups)
+        for (int i = 5; i < kPhaseMarks; ++i) reinterpret_cast<unsigned*>(lds + kPhase)[phase_group * kPhaseMarks + i] = 0u;
     // ================= stages A, B, C: one window of the group after the other ==================
     for (int k = 0; k < group_n; ++k) {
     // The thread index and the parameter pointer are made opaque once per round: otherwise the
@@ -3013,20 +3373,30 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 }
                 window_mean_inv(lds, in_cnt, &mean, &inv);
             } else {
+                int cnt, pad;
                 if (k == 0) {
-                    // publishes slot 0's weights (asked for in the last stage F of the group
-                    // before) and keeps this group off the LDS that group's last reads still use
+                    // the group's first window came in registers (fetched under the last stage F of
+                    // the group before): its samples go to the staging and its exact sums ride on
+                    // the barrier that also publishes slot 0's weights (asked for in that stage F)
+                    // and keeps this group off the LDS that group's last reads still use
+                    short* put = reinterpret_cast<short*>(lds + kStage);
+                    put[tid] = (short)first_v0;
+                    put[tid + 512] = (short)first_v1;
+                    window_partial_sums(lds, first_cnt, first_v0, first_v1, tid, lane, wave);
                     full_barrier();
                     mark(ts, 51);
+                    window_mean_inv(lds, first_cnt, &mean, &inv);
+                    cnt = first_cnt;
+                    pad = first_pad;
                     thirds_mode = thirds_ahead ? 0 : 2;
                 } else {
                     thirds_mode = 1;
+                    const float* st = lds + kStageStats + k * 8;
+                    mean = reinterpret_cast<const double*>(st)[0];
+                    inv = reinterpret_cast<const double*>(st)[1];
+                    cnt = reinterpret_cast<const int*>(st)[4];
+                    pad = reinterpret_cast<const int*>(st)[5];
                 }
-                const float* st = lds + kStageStats + k * 8;
-                mean = reinterpret_cast<const double*>(st)[0];
-                inv = reinterpret_cast<const double*>(st)[1];
-                const int cnt = reinterpret_cast<const int*>(st)[4];
-                const int pad = reinterpret_cast<const int*>(st)[5];
                 const short* smp = reinterpret_cast<const short*>(lds + kStage + k * kStageWin);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
@@ -3222,36 +3592,47 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     if (own_last)
         d_load_y(Y, (const float*)(lds + kPark7Lds + (wave & 1) * 3072 + lane * 4));
 
-    // ================= stage D: conv8, conv9 (L=128) + MaxPool + BN4, the group together ========
-    stage_d_chain(lds, packed, wg_scratch, lane, wave, ts, d_groups, Y);
-    if (stop_stage == 3) {
+    phase_stamp(1);
+    // ================= stages D and E: conv8, conv9 (+ MaxPool + BN4) and the inception block (+
+    // MaxPool + BN5), the group together, one chain in registers ==================================
+    {
+        float* dump3 = nullptr;
+        if (debug_stage == 3 && (wave >> 1) < group_n)
+            dump3 = glob(args()->debug_out) + (long)(group_start + (wave >> 1)) * kStageFloats[3];
+        stage_d_chain(lds, packed, wg_scratch, lane, wave, ts, d_groups, Y, dump3, stop_stage == 3,
+                      (wave >> 1) < group_n ? cat_offset(wave >> 1, group_n) : -1);
+    }
+    if (stop_stage == 4) {
         if (debug_stage < 100)
             for (int kk = 0; kk < group_n; ++kk)
-                dump_stage(kk == 0 ? lds + kEX : wg_scratch + kWgParkXOff + kk * kParkXFloats, kS48, 64, 48,
-                           glob(args()->debug_out) + (long)(group_start + kk) * kStageFloats[3], tid);
+                dump_stage(lds + cat_offset(kk, group_n), kS192, 32, 192,
+                           glob(args()->debug_out) + (long)(group_start + kk) * kStageFloats[4], tid);
         full_barrier();
-    } else {
-    // Once per group, behind stage D's closing barrier: conv16's weights (stage D's slots 0 and 1
-    // lay on their home) and BN5's scale and shift for E2 and E3 (384 floats - too many for the
-    // parameter table; two pieces; what follows them in the packed image comes along) by LDS-DMA,
-    // used two barriers on; conv17's 110 KB of weights (27 fragments per wave) from L2 to the
-    // registers they stay in through the stage F of every window of the group.
-    //   The ORDER of the memory requests matters: vector loads return in order, and the wait hipcc
-    // puts in front of a value's first use counts the requests issued after it - the ones it
-    // knows of (inline-asm LDS-DMA is not among them), pessimistically wherever control flow has
-    // merged.  So: the LDS-DMA pieces first.
-    static_assert(bn_scale_offset(4) % 4 == 0 && bn_scale_offset(4) + 512 <= kPackedFloats, "");
-    dma_weights<conv_weight_floats(15)>(packed + weight_offset(15), lds + kEW16, lane, wave);
-    if (wave >= 6)
-        dma_piece(packed + bn_scale_offset(4) + (wave - 6) * 256, lds + kEBn5 + (wave - 6) * 256,
-                  (unsigned)lane * 16u);
+    } else if (stop_stage != 3) {
+    // Once per group, behind the chain's closing barrier: conv17's 110 KB of weights (27 fragments per
+    // wave) from L2 to the registers they stay in through the stage F of every window of the group.
+    phase_stamp(2);
     SmallMRegs<16, 8, 3, true> r17;
-    r17.prefetch_epilogue(packed, 5, lane, wave);
     r17.template prefetch_slice<0, 27>(packed, lane, wave);
+    // conv17's bias and BN6 for the output quadruple this lane finishes (all eight waves take part
+    // in the reduction of its partial tiles: small_m_layer)
+    EpiParams<1, true> ep17;
+    {
+        const int e = wave * 24 + (lane < 24 ? lane : 0), ch = (e >> 6) * 16 + (e & 15);
+        ep17.load(packed + bias_offset(16) + ch, packed + bn_scale_offset(5) + ch, packed + bn_shift_offset(5) + ch);
+    }
     flush_marks(ts, ts_out, lane);
     bool run_tail = false, thirds_next = false;
+    // The NEXT group's samples (seam b2) are fetched while this one runs stage F, a window per
+    // window: stage F of window k asks for the place of the next group's window k + 1 in the sample
+    // buffer (two offsets) at its top and for the samples themselves behind its barrier; they are
+    // looked at a window later - their exact sums ride on conv17's barrier there, wave 7 (idle
+    // while waves 0-2 reduce conv17) turns them into mean and 1/std, and the samples go to the LDS
+    // staging.  The group's LAST stage F fetches the next group's FIRST window, which that group's
+    // stage A takes from the registers (its first barrier carries the sums).
+    int fetched_cnt = 0, fetched_pad = 0, fetched_v0 = 0, fetched_v1 = 0;
 
-    // ================= stages E, F: one window of the group after the other =====================
+    // ================= stage F: one window of the group after the other =========================
     for (int k = 0; k < group_n; ++k) {
     int tid = tid_entry;
     asm volatile("" : "+v"(tid));
@@ -3266,7 +3647,6 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     float* const wg_scratch = (float*)scratch_opaque;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15;
     const int win = group_start + k;
     const bool last = k == group_n - 1;
     unsigned ts_acc = 0u;
@@ -3276,166 +3656,16 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         ts = &ts_acc;
         ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + ((long)win * kWaves + wave) * 64;
     }
-    // Window k of the NEXT group (seam b2): its read's place in the sample buffer is asked for now
-    // (two VECTOR loads - the address made per-lane on purpose: as scalar loads they would count
-    // against lgkmcnt, which the hand-counted LDS waits of the layers below watch), its samples
-    // behind E1's barrier, its statistics ride on conv17's barrier (stage F), where the samples go
-    // to the LDS staging.
-    const bool stage_next = seam_b2 && k < next_n;
+    unsigned f_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
+    // what this round fetches of the next group: window k + 1, or - the last round - window 0
+    const int fetch_k = last ? 0 : k + 1;
+    const bool fetch = seam_b2 && fetch_k < next_n;
+    // what it stages: window k (fetched a round ago), if the next group has one - never window 0
+    const bool stage_now = seam_b2 && k > 0 && k < next_n;
+    const int now_cnt = fetched_cnt, now_pad = fetched_pad;
+    int now_v0 = fetched_v0, now_v1 = fetched_v1;
     long long next_off0 = 0, next_off1 = 0;
     int next_step = 0;
-    if (stage_next) {
-        unsigned next_read;
-        split_window((unsigned)(next_start + k), steps_arg, &next_read, &next_step);
-        unsigned lane_zero = 0;
-        asm volatile("" : "+v"(lane_zero));
-        next_off0 = offsets_arg[next_read + lane_zero];
-        next_off1 = offsets_arg[next_read + lane_zero + 1];
-    }
-    int next_cnt = 0, next_pad = 0, next_v0 = 0, next_v1 = 0;
-
-    // ---------------- stage E: inception block (L=64) + MaxPool + BN5 -> 32 x 192 --------------
-    {
-        // No phase of its own in front of the 1x1 convolutions: the average pooling that conv10
-        // reads happens on conv10's output (inception_1x1_of_avgpool), BN5's parameters come from
-        // L2 in E1 and from LDS in E2 and E3, and each zero row is written by a wave that writes
-        // the buffer it belongs to - every store below lands in LDS that nobody reads before E1's
-        // barrier.  The accumulators of E1-E3 start from biases in the LDS parameter table: from
-        // L2, every phase began with a round trip.
-        // E1: waves 0-2 conv10, 3-5 conv11 (concat channels 16 wave ..., biases contiguous),
-        // wave 6 conv12, wave 7 conv14
-        static_assert(bias_offset(10) == bias_offset(9) + 48, "conv10's and conv11's biases are adjacent");
-        const float* bias_tab = lds + kParams - kTabBias0 + n;     // + bias_offset(conv): the LDS table
-        EpiParams<1, true> ep_cat;
-        EpiParams<1, false> ep_mid;
-        if (wave < 6)
-            ep_cat.load(bias_tab + bias_offset(9) + wave * 16, packed + bn_scale_offset(4) + wave * 16 + n,
-                        packed + bn_shift_offset(4) + wave * 16 + n);
-        else
-            ep_mid.load(bias_tab + (wave == 6 ? bias_offset(11) : bias_offset(13)), nullptr, nullptr);
-        zero_row(lds + kECat, 0, kS192, 192, tid);
-        zero_row(lds + kECat, 33, kS192, 192, tid);
-        if (wave == 6) {
-            zero_row(lds + kET3, 0, kS16, 16, lane);
-            zero_row(lds + kET3, 65, kS16, 16, lane);
-        }
-        if (wave == 7) {
-            zero_row(lds + kET4a, 0, kS16, 16, lane);
-            zero_row(lds + kET4a, 65, kS16, 16, lane);
-        }
-        mark(ts, 34);
-        const float* sc5 = lds + kEBn5 + n;
-        const float* sh5 = lds + kEBn5 + 192 + n;
-
-        // E1: the four 1x1 convolutions reading X / avgpool(X): 8 N tiles <-> 8 waves.
-        if (wave < 3) {            // conv10 on the avg-pooled input -> concat channels 0..47
-            inception_1x1_of_avgpool<3, kS192>(lds + kEX, lds + kEW10, lds + kECat, wave * 16, ep_cat,
-                                               wave, lane);
-        } else if (wave < 6) {     // conv11 -> concat channels 48..95
-            inception_1x1<3, kS192, true>(lds + kEX, lds + kEW11, lds + kECat, wave * 16, ep_cat,
-                                          wave - 3, lane);
-        } else if (wave == 6) {    // conv12 -> 16-channel bottleneck of branch 3
-            inception_1x1<1, kS16, false>(lds + kEX, lds + kEW12, lds + kET3, 0, ep_mid, 0, lane);
-        } else {                   // conv14 -> 16-channel bottleneck of branch 4
-            inception_1x1<1, kS16, false>(lds + kEX, lds + kEW14, lds + kET4a, 0, ep_mid, 0, lane);
-        }
-        mark(ts, 35);
-        full_barrier();      // (also: BN5's parameters and conv16's weights, asked for above, have landed)
-        // (the two offset loads, looked at once on EVERY path, where the barrier has just waited for
-        // everything: this is where hipcc's wait-count pass learns that they have landed.  Left
-        // "pending" on the path that does not use them, the loads of the next round - which reuse
-        // their registers - wait for all but one of the wave's outstanding requests: conv17's
-        // stores, a round trip to memory per window.)
-        asm volatile("" : "+v"(next_off0), "+v"(next_off1));
-        mark(ts, 36);
-        // X is read: the next window's image comes in from its park (13 pieces; retired by E2's
-        // closing barrier) ...
-        if (!last)
-            dma_weights<kParkXFloats>(wg_scratch + kWgParkXOff + (k + 1) * kParkXFloats, lds + kEX, lane, wave);
-        // ... and the samples of the next group's window k start their trip from HBM (the barrier
-        // has waited for the two offsets)
-        if (stage_next) {
-            long long wa, wb;
-            const long long next_base =
-                ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
-            const long long next_end =
-                ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
-                (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
-            window_bounds(next_end - next_base, next_step, side_arg, &wa, &wb);
-            next_cnt = (int)(wb - wa);
-            next_pad = (side_arg == 0) ? 0 : kWindow - next_cnt;
-            const int16_t* src = (const int16_t*)smp_opaque + next_base + wa;
-            next_v0 = tid < next_cnt ? (int)src[(unsigned)tid] : 0;
-            next_v1 = tid + 512 < next_cnt ? (int)src[(unsigned)(tid + 512)] : 0;
-        }
-
-        // E2: conv15 (16->48, k3) -> T4b, the only input of conv16 not ready yet, and conv13
-        // (16->48, k3) -> concat 96..143, both as Winograd F(2,3): per convolution two pair tiles
-        // x three channel tiles = six units of 16 MFMAs, dealt so that every SIMD carries 48:
-        //   conv15: w0: m0 t0,1   w1: m1 t0,1   w2: m0 t2   w3: m1 t2
-        //   conv13: w6: m0 t0,1   w7: m1 t0,1   w4: m0 t2   w5: m1 t2
-        {
-            constexpr int kTile = 2 * 2 * 256;       // floats of one channel tile's weights
-            const int m = wave & 1;
-            if (wave == 0) zero_row(lds + kET4b, 0, kS48, 48, lane);     // (conv16's padding rows)
-            if (wave == 1) zero_row(lds + kET4b, 65, kS48, 48, lane);
-            if (wave < 2) {
-                inception_k3_wino<2, kS48, false>(lds + kET4a, lds + kEW15, lds + kET4b, 0,
-                                                  bias_tab + bias_offset(14), nullptr, nullptr, m, lane);
-            } else if (wave < 4) {
-                inception_k3_wino<1, kS48, false>(lds + kET4a, lds + kEW15 + 2 * kTile, lds + kET4b, 32,
-                                                  bias_tab + bias_offset(14) + 32, nullptr, nullptr, m,
-                                                  lane);
-            } else if (wave < 6) {
-                inception_k3_wino<1, kS192, true>(lds + kET3, lds + kEW13 + 2 * kTile, lds + kECat, 96 + 32,
-                                                  bias_tab + bias_offset(12) + 32, sc5 + 96 + 32,
-                                                  sh5 + 96 + 32, m, lane);
-            } else {
-                inception_k3_wino<2, kS192, true>(lds + kET3, lds + kEW13, lds + kECat, 96,
-                                                  bias_tab + bias_offset(12), sc5 + 96, sh5 + 96, m,
-                                                  lane);
-            }
-        }
-        mark(ts, 37);
-        // (LDS only: the next window's X and the next group's samples, asked for at the top of this
-        // short phase, are still on their way - E3's barrier retires them)
-        lds_barrier();
-        mark(ts, 38);
-
-        // E3: conv16 (48->48, k3) -> concat 144..191: twelve (position tile, channel tile) units
-        // of 36 MFMAs - two on each of waves 0-3, one on each of waves 4-7, 108 MFMAs per SIMD.
-        //   w0: t0 m0,1   w1: t1 m0,1   w2: t2 m0,1   w3: t0 m2,3
-        //   w4: t1 m2     w5: t1 m3     w6: t2 m2     w7: t2 m3
-        if (wave < 4) {
-            const int t = wave < 3 ? wave : 0, m0 = wave < 3 ? 0 : 2;
-            inception_k3<6, 2, 1, kS48, kS192, true>(lds + kET4b, lds + kEW16, lds + kECat,
-                                                     144 + t * 16,
-                                                     bias_tab + bias_offset(15) + t * 16,
-                                                     sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
-                                                     lane);
-        } else {
-            const int t = 1 + ((wave - 4) >> 1), m0 = 2 + ((wave - 4) & 1);
-            inception_k3<6, 1, 1, kS48, kS192, true>(lds + kET4b, lds + kEW16, lds + kECat,
-                                                     144 + t * 16,
-                                                     bias_tab + bias_offset(15) + t * 16,
-                                                     sc5 + 144 + t * 16, sh5 + 144 + t * 16, t, m0,
-                                                     lane);
-        }
-        mark(ts, 39);
-        full_barrier();      // (also: the next window's X has landed)
-        // (the same for the two sample registers: without this the round's loads into them, at the
-        // top of E2, were followed by waits for the X image and the samples just asked for)
-        asm volatile("" : "+v"(next_v0), "+v"(next_v1));
-        mark(ts, 40);
-    }
-    if (stop_stage == 4) {
-        if (debug_stage < 100)
-            dump_stage(lds + kECat, kS192, 32, 192, glob(args()->debug_out) + (long)win * kStageFloats[4], tid);
-        full_barrier();
-        continue;
-    }
-
     // ---------------- stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48 ---------
     // The last layers (conv18-20 on 16 and 8 positions, softmax, call) are too small to fill a
     // workgroup: per window they cost ~9k cycles of barriers and LDS round trips for ~1.7k cycles
@@ -3450,48 +3680,59 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         run_tail = batch_ends;
         thirds_next = thirds_now;
     }
-    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = win;
-    if (batch_ends) {      // the batch's weights: requested now, used behind two barriers
-        dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
-        dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
-        dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
+    // (1) the two offsets (VECTOR loads - the address made per-lane on purpose: as scalar loads
+    // they would count against lgkmcnt)
+    if (fetch) {
+        unsigned next_read;
+        split_window((unsigned)(next_start + fetch_k), steps_arg, &next_read, &next_step);
+        unsigned lane_zero = 0;
+        asm volatile("" : "+v"(lane_zero));
+        next_off0 = offsets_arg[next_read + lane_zero];
+        next_off1 = offsets_arg[next_read + lane_zero + 1];
     }
+    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = win;
     {
         float* slot = wg_scratch + kWgTailOff + tail_slot * kTailSlotFloats;
-        // conv17's partial tiles: over the inception block's scratch images - dead by now - except
-        // for the group's last window, where slots 0..2 (the next window's conv2 weights, on their
-        // way) cover those and the front of the arena (X, conv10..14's weights) is dead instead
-        float* red = lds + (last ? kRedLast : kRedMid);
-        // The statistics of the next group's window k ride on conv17's barrier: every wave leaves
-        // its partial sums - and its two samples in the staging - before it; behind it wave 7 (idle
-        // while waves 0-2 reduce conv17) turns the sums into mean and 1/std.
         small_m_layer<16, kS192, 2, 8, 3, false, true, true>(
-            lds, lds + kECat, slot, red, r17, lane, wave, ts, 41,
+            lds, lds + cat_offset(k, group_n), slot, lds + kRed, r17, lane, wave, ts, 41,
             [&] {
-                if (stage_next) {
-                    window_partial_sums(lds, next_cnt, next_v0, next_v1, tid, lane, wave);
+                phase_add(5, f_since);
+                // (the two sample registers, looked at once on EVERY path, here where they have long
+                // landed: this is where hipcc's wait-count pass learns it.  Left "pending" on the
+                // path that does not stage them, the round's loads into them are preceded by a wait
+                // for everything in flight.)
+                asm volatile("" : "+v"(now_v0), "+v"(now_v1));
+                if (stage_now) {
+                    window_partial_sums(lds, now_cnt, now_v0, now_v1, tid, lane, wave);
                     short* smp = reinterpret_cast<short*>(lds + kStage + k * kStageWin);
-                    smp[tid] = (short)next_v0;
-                    smp[tid + 512] = (short)next_v1;
+                    smp[tid] = (short)now_v0;
+                    smp[tid + 512] = (short)now_v1;
                 }
             },
             [&] {
-                if (stage_next && wave == kWaves - 1) {
+                phase_add(6, f_since);
+                if (stage_now && wave == kWaves - 1) {
                     double mean, inv;
-                    window_mean_inv(lds, next_cnt, &mean, &inv);
+                    window_mean_inv(lds, now_cnt, &mean, &inv);
                     float* st = lds + kStageStats + k * 8;
                     if (lane == 0) {
                         reinterpret_cast<double*>(st)[0] = mean;
                         reinterpret_cast<double*>(st)[1] = inv;
-                        reinterpret_cast<int*>(st)[4] = next_cnt;
-                        reinterpret_cast<int*>(st)[5] = next_pad;
+                        reinterpret_cast<int*>(st)[4] = now_cnt;
+                        reinterpret_cast<int*>(st)[5] = now_pad;
                     }
+                }
+                // the batch's weights (conv18, conv19, conv20): requested now - this window's image
+                // and the front of the arena are dead - used behind two barriers
+                if (batch_ends) {
+                    dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
+                    dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
+                    dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
                 }
                 // Thirds 1 and 2 of the NEXT window's conv2 weights -> slots 1 and 2, by the
                 // four waves that have nothing else to do while waves 0-2 reduce conv17 (36 pieces,
-                // nine each; the slots overlap the concat buffer, which every wave has finished
-                // reading at the barrier just passed) - unless the batched tail runs between this
-                // window and the next: its buffers lie there.
+                // nine each) - unless the batched tail runs between this window and the next: its
+                // buffers lie there.
                 if (thirds_now && wave >= 3 && wave < kWaves - 1) {
                     const unsigned lane_bytes = (unsigned)lane * 16u;
 #pragma unroll
@@ -3502,22 +3743,51 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                     }
                 }
             },
-            // The NEXT window's first third of conv2's weights -> slot 0 (the inception block's
-            // weights and scratch, dead behind E3's barrier; the batched tail keeps clear of it):
-            // tile 0 of conv2 multiplies right behind that window's first barrier, which retires
-            // these requests - 18 pieces, one per wave behind each tap's MFMAs.
+            // The NEXT window's first third of conv2's weights -> slot 0 (above everything stage F
+            // uses; the batched tail keeps clear of it): tile 0 of conv2 multiplies right behind that
+            // window's first barrier, which retires these requests - 18 pieces, one per wave behind
+            // each tap's MFMAs.
             [&](int tap) {
                 if (slot0_next)
                     dma_weights_one<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave, tap);
-            });
+            },
+            &ep17);
+    }
+    // The next window's conv17 writes the partial tiles this one's reduction reads.  LDS only:
+    // nobody waits for conv17's stores before the batched tail.
+    phase_add(7, f_since);
+    if (!last) lds_barrier();
+    phase_add(8, f_since);
+    // (3) the samples of the window whose offsets were asked for at the top - LAST, so that nothing
+    // above waits for their trip from HBM
+    fetched_cnt = 0;
+    fetched_pad = 0;
+    fetched_v0 = 0;
+    fetched_v1 = 0;
+    if (fetch) {
+        long long wa, wb;
+        const long long next_base =
+            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
+        const long long next_end =
+            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
+        window_bounds(next_end - next_base, next_step, side_arg, &wa, &wb);
+        fetched_cnt = (int)(wb - wa);
+        fetched_pad = (side_arg == 0) ? 0 : kWindow - fetched_cnt;
+        const int16_t* src = (const int16_t*)smp_opaque + next_base + wa;
+        fetched_v0 = tid < fetched_cnt ? (int)src[(unsigned)tid] : 0;
+        fetched_v1 = tid + 512 < fetched_cnt ? (int)src[(unsigned)(tid + 512)] : 0;
     }
     mark_realtime(ts, 63);
     ++tail_slot;
     flush_marks(ts, ts_out, lane);
-    // (the next window's E1 writes the scratch images the partial tiles lie on; LDS only - nobody
-    // waits for conv17's stores before the batched tail)
-    if (!last) lds_barrier();
-    }   // stages E, F of the group's windows
+    }   // stage F of the group's windows
+    phase_stamp(3);
+    carry_cnt = fetched_cnt;
+    carry_pad = fetched_pad;
+    carry_v0 = fetched_v0;
+    carry_v1 = fetched_v1;
 
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
@@ -3662,12 +3932,14 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 55);
     }
     flush_marks(ts, ts_out, lane);
+    phase_stamp(4);
     thirds_ahead = thirds_next;
     }   // (not stop_stage 3)
     }   // (not stop_stage 2)
     }   // (not stop_stage 0, 1)
 
     first_group = false;
+    ++phase_group;
     staged = samples_entry != nullptr && next_n > 0 && (stop_stage < 0 || stop_stage > 4);
     if (!staged) thirds_ahead = false;
     group_start = next_start;
@@ -3682,10 +3954,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             win_counter_entry[1] = 0;
         }
     }
-    if (args()->clock_out != nullptr && tid_entry == 0) {
-        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * 4;
-        c[2] = (long long)__builtin_readcyclecounter();
-        c[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (args()->clock_out != nullptr) {
+        long long* c = glob(args()->clock_out) + (size_t)blockIdx.x * (4 + kPhaseMarks * kPhaseGroups);
+        if (threadIdx.x == 0) {
+            c[2] = (long long)__builtin_readcyclecounter();
+            c[3] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kPhaseMarks * kPhaseGroups; i += kThreads)
+            c[4 + i] = i < phase_group * kPhaseMarks ? (long long)reinterpret_cast<const unsigned*>(lds + kPhase)[i] : -1;
     }
 }
 

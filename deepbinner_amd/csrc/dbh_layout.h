@@ -45,7 +45,7 @@ constexpr ConvSpec kConv[kNumConvs] = {
     {3, 16, 48, 1, 2},        // conv1d_13
     {1, 48, 16, 1, 0},    // conv1d_14
     {3, 16, 48, 1, 2},        // conv1d_15
-    {3, 48, 48, 1, 0},    // conv1d_16
+    {3, 48, 48, 1, 2},    // conv1d_16  (round 6: F(2,3) on the chain's position pairs)
     {3, 192, 48, 2, 0},   // conv1d_17
     {3, 48, 48, 1, 0},    // conv1d_18
     {3, 48, 48, 1, 0},    // conv1d_19
@@ -53,8 +53,8 @@ constexpr ConvSpec kConv[kNumConvs] = {
 };
 constexpr int kBnChannels[kNumBn] = {48, 48, 48, 48, 192, 48, 48};
 // F(2,3) layers whose weights are stored by N tile ([t][sp][matrix pair][lane][matrix][e]) for the
-// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_13, conv1d_15).
-constexpr bool wino2_by_tile(int i) { return i == 5 || i == 12 || i == 14; }
+// N-tile-outer loops of dbh_forward.hip (conv1d_6, conv1d_13, conv1d_15, conv1d_16).
+constexpr bool wino2_by_tile(int i) { return i == 5 || i == 12 || i == 14 || i == 15; }
 // positions each convolution produces (after its stride, before any pooling)
 constexpr int kConvLout[kNumConvs] = {512, 512, 512, 512, 256, 256, 256, 128, 128, 64,
                                       64,  64,  64,  64,  64,  64,  16,  16,  16,  8};
@@ -80,7 +80,7 @@ constexpr int forward_mfmas(int n_classes) {
     for (int i = 0; i < kNumConvs; ++i) n += conv_mfmas(i, n_classes);
     return n;
 }
-static_assert(forward_mfmas(13) == 9300, "MFMA count per window (SQ_INSTS_MFMA; 9,588 until conv1d_8/9 became F(4,3))");
+static_assert(forward_mfmas(13) == 9156, "MFMA count per window (SQ_INSTS_MFMA; 9,588 until conv1d_8/9 became F(4,3) and conv1d_16 F(2,3))");
 
 // Number of floats of fragment-ordered weights of conv layer i (0-based); conv1 keeps [3][48].
 constexpr int conv_weight_floats(int i) {
@@ -150,7 +150,8 @@ constexpr int kPackedFloats = bn_scale_offset(kNumBn);
 // ... and conv1d_6 from conv1d_5's accumulators
 // conv1d_8 and conv1d_9 (round 6) run the same way for FOUR windows at a time (stage_d_chain): a
 // wave owns half a window (16 quads of its 128 positions) from conv1d_7's parked output to BN4.
-constexpr bool chained(int conv) { return (conv >= 1 && conv <= 5) || conv == 7 || conv == 8; }
+// ... and the inception block behind them (conv1d_10 .. conv1d_16) on the same lanes' position pairs.
+constexpr bool chained(int conv) { return (conv >= 1 && conv <= 5) || (conv >= 7 && conv <= 15); }
 constexpr int frag_cin(int conv, int sp, int q, int e) {
     return chained(conv) ? 16 * ((2 * sp + e) >> 2) + 4 * q + ((2 * sp + e) & 3) : 8 * sp + 2 * q + e;
 }
@@ -223,16 +224,13 @@ static_assert((kX7 * 4) % 16 == 0 && kX7 + 8 * 512 <= 258 * kS48, "");
 //   stage D once               conv1d_8, conv1d_9 as F(4,3) for the four windows together: 32 quads
 //                              per window = two tiles of 16 = one per wave of a wave pair, eight
 //                              tiles for eight waves, a chain in registers like stage B
-//   [stage E, F] x kGroup      BN4's output X of window 0 waits in LDS, the others' in global memory
-//                              (parked as the padded 66 x 50 image the inception block reads, so
-//                              that LDS-DMA brings one in while the window before runs stage F)
+//                              ... and stage E (the inception block) on its end, on registers
+//   [stage F] x kGroup         the block's outputs (32 x 192 + zero rows each) wait in LDS
 // Per-workgroup scratch in global memory (floats): conv1d_17's outputs for the batched tail, then
 // the two parks.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGroup = 4;
 constexpr int kPark7Floats = 128 * 48;                      // [half][row of quad][channel group][lane][4]
-constexpr int kParkXFloats = 13 * 256;                      // 66 x 50 = 3,300, whole 1 KiB pieces
-static_assert(kParkXFloats >= 66 * kS48, "");
 // the group's LAST window skips the park: stage D follows its conv1d_7 at once, so its output goes
 // to LDS in the same layout - over rows of conv1d_7's input image (all read by its mid-layer barrier),
 // below its pair exchange; the waves that own the window in stage D read it back behind the layer's
@@ -265,42 +263,50 @@ static_assert((kDS0 * 4) % 16 == 0 && kDS0 >= kStageEnd && kDDummy % 2 == 0, "")
 static_assert(kDS0 + kWinoHalf <= kW0, "slot 0 must be clear of conv1d_7's weights");
 static_assert(kDS1 + kWinoHalf <= kSlot1, "slot 1 may only overlap conv1d_7's N tile 0");
 
-// stages E and F (inception block, conv1d_17), per window of the group.  The weights of conv10..16
-// arrive ONCE per group (conv10..15 while stage D runs, conv16 - whose home stage D's slots cover -
-// at the top of the first window's stage E) and stay through all four windows.
-constexpr int kEX = 0;                                     // BN4 output, 66 rows x 50 (one DMA image)
-constexpr int kEW10 = kEX + kParkXFloats;                  // 3,328
+// stage E (inception block) runs on the END of stage D's chain, on the same lanes' registers
+// (dbh_forward.hip: stage_d_chain): BN4's output never leaves them.  Its weights - conv10 .. conv15,
+// one contiguous run of the packed image - land at the front of the arena while stage D runs (from
+// its tile 2 on: the group's last window has its conv7 output there until its two waves have read
+// it), conv16's four F(2,3) matrices in stage D's slots 2 and 3 as it leaves them.
+constexpr int kEW10 = 0;
 constexpr int kEW11 = kEW10 + conv_weight_floats(9);
 constexpr int kEW12 = kEW11 + conv_weight_floats(10);
 constexpr int kEW13 = kEW12 + conv_weight_floats(11);
 constexpr int kEW14 = kEW13 + conv_weight_floats(12);
-constexpr int kEWLowEnd = kEW14 + conv_weight_floats(13);  // 12,544
-constexpr int kEW15 = kStageEnd;                           // 15,904
-constexpr int kEW16 = kEW15 + conv_weight_floats(14);      // 18,976
-static_assert(kEWLowEnd <= kStage && kEW16 == kDS0 && (kEW10 * 4) % 16 == 0 && (kEW15 * 4) % 16 == 0, "");
-constexpr int kET3 = kEW16 + conv_weight_floats(15);       // conv12 out, 66 x 20      (25,888)
-constexpr int kET4a = kET3 + 66 * kS16;                    // conv14 out, 66 x 20
-constexpr int kET4b = kET4a + 66 * kS16;                   // conv15 out, 66 x 50
-// conv1d_17's split-K partial tiles (24 x 256 floats): over the three scratch images (dead by
-// stage F) for every window but the group's last; for the last one at the front of the arena (X
-// and the first weights are dead, and the NEXT window's conv1d_2 weights are on their way to slots
-// 0..2, which cover the scratch images)
-constexpr int kRedMid = kET3, kRedLast = 0;
-constexpr int kRedFloats = 24 * 256;
-constexpr int kECat = kRedMid + kRedFloats;                // pooled + BN5 concat, 34 x 196   (32,032)
-static_assert(kET4b + 66 * kS48 <= kECat, "");
+constexpr int kEW15 = kEW14 + conv_weight_floats(13);
+constexpr int kEWEnd = kEW15 + conv_weight_floats(14);     // 12,288
+constexpr int kEW16 = kDS2;                                // 9,216 floats = slots 2 and 3
+static_assert(conv_weight_floats(15) == 2 * kWinoHalf && kEWEnd == weight_offset(15) - weight_offset(9), "");
+// halo rows of the two 16-channel bottlenecks (conv12's and conv14's outputs: [wave][side][Z3 16 | Z4 16]);
+// the 48-channel ones (conv10's products, conv15's output) reuse stage D's two arrays
+constexpr int kEHaloZ = kEWEnd;                            // 512 floats
 // BN5's scale and shift (2 x 192 floats + what follows them in the packed image: 512 by DMA)
-constexpr int kEBn5 = kECat + 34 * kS192;                  // 38,696
-constexpr int kLdsFloatsE = kEBn5 + 512;
-static_assert((kEBn5 * 4) % 16 == 0, "");
+constexpr int kEBn5 = kEHaloZ + 8 * 2 * 32;                // 12,800
+static_assert(kEBn5 + 512 <= kStage && (kEBn5 * 4) % 16 == 0, "");
+// The block's output - pooled + BN5 concat, 34 rows x 196 with the two zero rows conv1d_17's
+// 'same' padding reads - is what stage F works on, one window after the other.  All four images
+// wait in LDS: the chain keeps a lane's 48 outputs in registers to its end and writes them behind
+// a barrier, over its own dead weights.  The group's LAST window's image lies below the staging
+// (while its conv1d_17 runs, the next window's conv1d_2 weights land in slots 0..2), the others'
+// above it.
+constexpr int kCatFloats = 34 * kS192;                     // 6,664
+constexpr int kCatLast = kStage - kCatFloats - 248;        // 6,912
+constexpr int kCatHigh = kStageEnd;                        // 15,904: + k * kCatFloats for window k
+constexpr int cat_offset(int k, int group_n) { return k == group_n - 1 ? kCatLast : kCatHigh + k * kCatFloats; }
+// conv1d_17's split-K partial tiles (24 x 256 floats)
+constexpr int kRed = 0;
+constexpr int kRedFloats = 24 * 256;
+static_assert(kRed + kRedFloats <= kCatLast && kCatLast + kCatFloats <= kStage && (kCatLast * 4) % 16 == 0, "");
+static_assert(kCatHigh + (kGroup - 1) * kCatFloats <= kDHalo && (kCatFloats * 4) % 16 == 0, "");
+constexpr int kLdsFloatsE = kDDummy + 312;
 
 // stages G-H (conv18, conv19, conv20, softmax, call) run for up to kTailBatch windows at a time,
 // ONE WAVE PER WINDOW (dbh_forward.hip: batched tail), at the end of a group: the three layers'
-// weights in fragment order (LDS-DMA'd during the batch's last conv17: clear of its partial tiles
-// at kRedLast, of the concat buffer and of the staging), then two 18 x 50 activation buffers per
-// wave (X: conv17 out, later conv19 out; Y: conv18 out).
+// weights in fragment order (LDS-DMA'd behind the barrier of the batch's last conv17, when its
+// concat image is dead: clear of its partial tiles at kRed, of slot 0 and of the staging), then two
+// 18 x 50 activation buffers per wave (X: conv17 out, later conv19 out; Y: conv18 out).
 constexpr int kTailBatch = 8;
-constexpr int kTW18 = kRedLast + kRedFloats;               // 6,144
+constexpr int kTW18 = kRed + kRedFloats;                   // 6,144
 constexpr int kTW19 = kStageEnd;                           // 15,904
 constexpr int kTW20 = kTW19 + conv_weight_floats(18);      // 22,816
 constexpr int kTWEnd = kTW20 + conv_weight_floats(19);     // 24,352
@@ -323,12 +329,11 @@ constexpr int tail_x_offset(int wave) {
                               : kTXHigh + (wave - kTXLowWaves) * 2 * kTailBuf;
 }
 constexpr int kTailSlotFloats = 16 * 48;                   // conv17 output of one window
-// per-workgroup scratch in global memory: [kTailBatch x conv17 output][kGroup x conv7 park][kGroup x X park]
+// per-workgroup scratch in global memory: [kTailBatch x conv17 output][kGroup x conv7 park]
 constexpr int kWgTailOff = 0;
 constexpr int kWgPark7Off = kTailBatch * kTailSlotFloats;
-constexpr int kWgParkXOff = kWgPark7Off + kGroup * kPark7Floats;
-constexpr int kWgScratchFloats = kWgParkXOff + kGroup * kParkXFloats;
-static_assert((kWgScratchFloats * 4) % 16 == 0 && (kWgPark7Off * 4) % 16 == 0 && (kWgParkXOff * 4) % 16 == 0, "");
+constexpr int kWgScratchFloats = kWgPark7Off + kGroup * kPark7Floats;
+static_assert((kWgScratchFloats * 4) % 16 == 0 && (kWgPark7Off * 4) % 16 == 0, "");
 constexpr int kArenaFloats =
     (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD) > kLdsFloatsD
         ? (kLdsFloatsE > kLdsFloatsAD ? kLdsFloatsE : kLdsFloatsAD)
@@ -358,7 +363,14 @@ constexpr int kPairSync = kStatOut + 4;
 // which windows wait in the slots of the batched tail
 constexpr int kNextWin = kPairSync + 8;
 constexpr int kTailWins = kNextWin + 1;
-constexpr int kLdsFloats = kTailWins + kTailBatch;
+// phase stamps of the clock probe (dbh_forward.hip: phase_stamp): kPhaseMarks per group for a
+// workgroup's first kPhaseGroups groups, dumped behind the launch's work
+// (marks 5..8: stage F's inner intervals as wave 0 sees them, summed over the group's windows: to the
+// end of conv17's MFMAs, to behind its barrier, to the end of the reduction, to behind the window's
+// last barrier)
+constexpr int kPhaseMarks = 9, kPhaseGroups = 24;
+constexpr int kPhase = kTailWins + kTailBatch;
+constexpr int kLdsFloats = kPhase + kPhaseMarks * kPhaseGroups;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
 
 // floats per window of the debug dump after each stage (dense [L][C])

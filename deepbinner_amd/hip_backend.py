@@ -153,6 +153,7 @@ def load_library():
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
         'dbh_forward_clock_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_clock_read': (c_int, [c_void_p, P(ctypes.c_double)]),
+        'dbh_forward_phases_read': (c_int, [c_void_p, P(ctypes.c_double), P(ctypes.c_int64)]),
         'dbh_comm_available': (c_int, []),
         'dbh_comm_last_error': (ctypes.c_char_p, []),
         'dbh_comm_init_all': (c_int, [c_int, P(c_int), c_int, P(c_void_p)]),
@@ -189,7 +190,7 @@ EXPORTED_SYMBOLS = [
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
-    'dbh_forward_timing_read', 'dbh_forward_clock_enable', 'dbh_forward_clock_read',
+    'dbh_forward_timing_read', 'dbh_forward_clock_enable', 'dbh_forward_clock_read', 'dbh_forward_phases_read',
     'dbh_comm_available', 'dbh_comm_last_error', 'dbh_comm_init_all', 'dbh_comm_unique_id',
     'dbh_comm_init_rank', 'dbh_comm_info', 'dbh_comm_all_gather_i32', 'dbh_comm_destroy',
 ]
@@ -679,6 +680,15 @@ class HipModel:
         clock (see dbh_forward_clock_enable)."""
         check(self._lib.dbh_forward_clock_enable(self._handle, 1 if on else 0),
               'dbh_forward_clock_enable')
+
+    def phases_read(self):
+        """Mean shader cycles of the five phases of a group of windows in this model's latest forward
+        launch (see dbh_forward_phases_read): stages A-C, the stage D-E chain, stage F, the batched
+        tail, what lies between two groups; and the number of groups averaged."""
+        out = (ctypes.c_double * 9)()
+        n = ctypes.c_int64(0)
+        check(self._lib.dbh_forward_phases_read(self._handle, out, ctypes.byref(n)), 'dbh_forward_phases_read')
+        return [float(v) for v in out], int(n.value)
 
     def clock_read(self):
         """Shader clock (GHz) during this model's latest forward launch."""

@@ -21,9 +21,10 @@ AC = [(0, 'A start'), (1, 'A: samples normalised'), (2, 'conv2 tile 0 (conv1 ins
       (9, 'conv3 done'), (13, 'conv4 done (+conv5)'), (21, 'conv6 done, barrier passed'),
       (23, 'conv7 mid barrier'), (25, 'conv7 end (park written, barrier)')]
 D = [(26, 'D: operands loaded, edge rows posted'), (27, 'conv8 tile 0'), (28, 'conv8 tile 1'), (29, 'conv8 tile 2'),
-     (30, 'conv9 tile 0'), (31, 'conv9 tile 1'), (32, 'conv9 tile 2, X stored'), (33, 'D closing barrier')]
-EF = [(34, 'E top'), (36, 'E1 + barrier'), (38, 'E2 + barrier'), (40, 'E3 + barrier'), (42, 'conv17 MFMAs + barrier'),
-      (43, 'conv17 reduce + store')]
+     (30, 'conv9 tile 0'), (31, 'conv9 tile 1'), (32, 'conv9 tile 2 (X in registers)'),
+     (34, 'E: conv12, conv14'), (35, 'E: conv10 products'), (36, 'E: conv13'), (37, 'E: conv15'),
+     (38, 'E: conv10 average, out'), (39, 'E: conv11'), (40, 'E: conv16'), (33, 'D+E closing barrier')]
+EF = [(42, 'F: conv17 MFMAs + barrier'), (43, 'F: conv17 reduce + store')]
 TAIL = [(45, 'tail: first barrier'), (46, 'tail: X loaded, weights landed'), (49, 'tail: conv18, conv19'),
         (53, 'tail: conv20, softmax, call'), (55, 'tail: end barrier')]
 
@@ -89,7 +90,7 @@ def main():
             for ident, name in D:
                 add('D: ' + name, diff(prev, stamps[ident]))
                 prev = stamps[ident]
-            add('D total (group)', diff(d_start, stamps[33]))
+            add('D+E total (group)', diff(d_start, stamps[33]))
             # stages E, F of each window
             prev_end = stamps[33]
             for k in range(4):
@@ -99,7 +100,7 @@ def main():
                     cur = at(win, ident, 'max')
                     add('EF: ' + name, diff(prev, cur))
                     prev = cur
-                add('EF total (window)', diff(prev_end, prev))
+                add('F total (window)', diff(prev_end, prev))
                 prev_end = prev
             # the batched tail (behind every group in this mode)
             prev = prev_end
