@@ -3056,7 +3056,7 @@ struct ForwardArgs {
 // split in 16-bit halves so that every wave-wide partial stays below 2^31, reduced over the wave
 // with DPP and left in the workgroup's kStatRed words.  Step 2 (after a barrier): mean and 1/std.
 __device__ __forceinline__ void window_partial_sums(float* lds, int cnt, int v0, int v1, int tid,
-                                                    int lane, int wave) {
+                                                    int lane, int wave, int slot = 0) {
     const int biased0 = v0 + 32768, biased1 = v1 + 32768;       // 0 .. 65535
     const unsigned sq0 = (unsigned)(v0 * v0), sq1 = (unsigned)(v1 * v1);   // <= 2^30
     const int present = (tid < cnt ? 1 : 0) + (tid + kThreads < cnt ? 1 : 0);
@@ -3064,15 +3064,15 @@ __device__ __forceinline__ void window_partial_sums(float* lds, int cnt, int v0,
     const int w_cnt = wave_sum_i32(present);
     const int w_lo = wave_sum_i32((int)(sq0 & 0xFFFF) + (int)(sq1 & 0xFFFF));
     const int w_hi = wave_sum_i32((int)(sq0 >> 16) + (int)(sq1 >> 16));
-    long long* red = reinterpret_cast<long long*>(lds + kStatRed);
+    long long* red = reinterpret_cast<long long*>(lds + kStatRed + slot * 32);
     if (lane == 0) {
         red[wave] = (long long)w_sum - 32768LL * w_cnt;
         red[kWaves + wave] = ((long long)w_hi << 16) + (long long)w_lo;
     }
 }
 __device__ __forceinline__ void window_mean_inv(const float* lds, int cnt, double* mean,
-                                                double* inv) {
-    const long long* red = reinterpret_cast<const long long*>(lds + kStatRed);
+                                                double* inv, int slot = 0) {
+    const long long* red = reinterpret_cast<const long long*>(lds + kStatRed + slot * 32);
     long long s1 = 0, s2 = 0;
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) {
@@ -3609,185 +3609,225 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                            glob(args()->debug_out) + (long)(group_start + kk) * kStageFloats[4], tid);
         full_barrier();
     } else if (stop_stage != 3) {
-    // Once per group, behind the chain's closing barrier: conv17's 110 KB of weights (27 fragments per
-    // wave) from L2 to the registers they stay in through the stage F of every window of the group.
+    // ================= stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48, the group
+    // together ====================================================================================
+    // The four concat images wait in LDS; conv17's weights (110 KB, each used once per window) skip
+    // LDS: waves 0-3 take windows 0 and 1, waves 4-7 windows 2 and 3, each wave a QUARTER of the
+    // contraction (six groups of eight channels x three taps x three N tiles = 54 fragment pairs in
+    // registers, fetched from L2 once per group and used for both its windows): 216 MFMAs per wave in
+    // one run, six independent accumulator chains.  Then ONE reduction for the group - 48 partial
+    // tiles through LDS, every lane finishing one or two of the 768 output quadruples - where the
+    // window-by-window form paid two barriers, a pipeline fill and a three-wave reduction per
+    // window (8.3 k cycles per window for 3.5 k of matrix work: profiles/r06_*).  conv17's output
+    // (3 KB per window) goes to the workgroup's slots in global memory for the batched tail below.
+    //   The NEXT group's samples (seam b2) are fetched meanwhile: the places of its windows in the
+    // sample buffer (offsets) are asked for at the top and looked at behind the first barrier,
+    // where the samples themselves are asked for; their exact sums ride on the last barrier, and
+    // waves 5-7 turn those of windows 1-3 into mean and 1/std while the samples go to the LDS
+    // staging; window 0 stays in registers for that group's stage A (whose first barrier carries
+    // its sums).
     phase_stamp(2);
-    SmallMRegs<16, 8, 3, true> r17;
-    r17.template prefetch_slice<0, 27>(packed, lane, wave);
-    // conv17's bias and BN6 for the output quadruple this lane finishes (all eight waves take part
-    // in the reduction of its partial tiles: small_m_layer)
-    EpiParams<1, true> ep17;
-    {
-        const int e = wave * 24 + (lane < 24 ? lane : 0), ch = (e >> 6) * 16 + (e & 15);
-        ep17.load(packed + bias_offset(16) + ch, packed + bn_scale_offset(5) + ch, packed + bn_shift_offset(5) + ch);
-    }
-    flush_marks(ts, ts_out, lane);
-    bool run_tail = false, thirds_next = false;
-    // The NEXT group's samples (seam b2) are fetched while this one runs stage F, a window per
-    // window: stage F of window k asks for the place of the next group's window k + 1 in the sample
-    // buffer (two offsets) at its top and for the samples themselves behind its barrier; they are
-    // looked at a window later - their exact sums ride on conv17's barrier there, wave 7 (idle
-    // while waves 0-2 reduce conv17) turns them into mean and 1/std, and the samples go to the LDS
-    // staging.  The group's LAST stage F fetches the next group's FIRST window, which that group's
-    // stage A takes from the registers (its first barrier carries the sums).
-    int fetched_cnt = 0, fetched_pad = 0, fetched_v0 = 0, fetched_v1 = 0;
-
-    // ================= stage F: one window of the group after the other =========================
-    for (int k = 0; k < group_n; ++k) {
-    int tid = tid_entry;
-    asm volatile("" : "+v"(tid));
-    const __attribute__((address_space(1))) float* packed_opaque =
-        (const __attribute__((address_space(1))) float*)packed_entry;
-    __attribute__((address_space(1))) float* scratch_opaque =
-        (__attribute__((address_space(1))) float*)wg_scratch_entry;
-    const __attribute__((address_space(1))) int16_t* smp_opaque =
-        (const __attribute__((address_space(1))) int16_t*)samples_entry;
-    asm volatile("" : "+s"(packed_opaque), "+s"(scratch_opaque), "+s"(smp_opaque));
-    const float* __restrict__ packed = (const float*)packed_opaque;
-    float* const wg_scratch = (float*)scratch_opaque;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int win = group_start + k;
-    const bool last = k == group_n - 1;
-    unsigned ts_acc = 0u;
-    unsigned* ts = nullptr;
-    long long* ts_out = nullptr;
-    if (debug_stage >= 300) {
-        ts = &ts_acc;
-        ts_out = reinterpret_cast<long long*>(glob(args()->debug_out)) + ((long)win * kWaves + wave) * 64;
-    }
-    unsigned f_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
-    // what this round fetches of the next group: window k + 1, or - the last round - window 0
-    const int fetch_k = last ? 0 : k + 1;
-    const bool fetch = seam_b2 && fetch_k < next_n;
-    // what it stages: window k (fetched a round ago), if the next group has one - never window 0
-    const bool stage_now = seam_b2 && k > 0 && k < next_n;
-    const int now_cnt = fetched_cnt, now_pad = fetched_pad;
-    int now_v0 = fetched_v0, now_v1 = fetched_v1;
-    long long next_off0 = 0, next_off1 = 0;
-    int next_step = 0;
-    // ---------------- stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48 ---------
-    // The last layers (conv18-20 on 16 and 8 positions, softmax, call) are too small to fill a
-    // workgroup: per window they cost ~9k cycles of barriers and LDS round trips for ~1.7k cycles
-    // of matrix work.  So conv17's output (3 KB) is parked in a global-memory slot of this
-    // workgroup and the rest runs for up to kTailBatch windows at a time, ONE WAVE PER WINDOW, with
-    // no cross-wave step at all (batched tail below), behind the group's last window when the next
-    // group would not fit in the slots any more.
-    const bool batch_ends = last && (tail_every_group || tail_slot + 1 + next_n > kTailBatch || next_n == 0);
-    const bool slot0_next = last && seam_b2 && next_n > 0;     // the next group's first window: conv2's first third
+    const bool batch_ends = tail_every_group || tail_slot + group_n + next_n > kTailBatch || next_n == 0;
+    const bool slot0_next = seam_b2 && next_n > 0;       // the next group's first window: conv2's weights
     const bool thirds_now = slot0_next && !batch_ends;
-    if (last) {
-        run_tail = batch_ends;
-        thirds_next = thirds_now;
-    }
-    // (1) the two offsets (VECTOR loads - the address made per-lane on purpose: as scalar loads
-    // they would count against lgkmcnt)
-    if (fetch) {
-        unsigned next_read;
-        split_window((unsigned)(next_start + fetch_k), steps_arg, &next_read, &next_step);
-        unsigned lane_zero = 0;
-        asm volatile("" : "+v"(lane_zero));
-        next_off0 = offsets_arg[next_read + lane_zero];
-        next_off1 = offsets_arg[next_read + lane_zero + 1];
-    }
-    if (tid == 0) reinterpret_cast<int*>(lds + kTailWins)[tail_slot] = win;
-    {
-        float* slot = wg_scratch + kWgTailOff + tail_slot * kTailSlotFloats;
-        small_m_layer<16, kS192, 2, 8, 3, false, true, true>(
-            lds, lds + cat_offset(k, group_n), slot, lds + kRed, r17, lane, wave, ts, 41,
-            [&] {
-                phase_add(5, f_since);
-                // (the two sample registers, looked at once on EVERY path, here where they have long
-                // landed: this is where hipcc's wait-count pass learns it.  Left "pending" on the
-                // path that does not stage them, the round's loads into them are preceded by a wait
-                // for everything in flight.)
-                asm volatile("" : "+v"(now_v0), "+v"(now_v1));
-                if (stage_now) {
-                    window_partial_sums(lds, now_cnt, now_v0, now_v1, tid, lane, wave);
-                    short* smp = reinterpret_cast<short*>(lds + kStage + k * kStageWin);
-                    smp[tid] = (short)now_v0;
-                    smp[tid + 512] = (short)now_v1;
-                }
-            },
-            [&] {
-                phase_add(6, f_since);
-                if (stage_now && wave == kWaves - 1) {
-                    double mean, inv;
-                    window_mean_inv(lds, now_cnt, &mean, &inv);
-                    float* st = lds + kStageStats + k * 8;
-                    if (lane == 0) {
-                        reinterpret_cast<double*>(st)[0] = mean;
-                        reinterpret_cast<double*>(st)[1] = inv;
-                        reinterpret_cast<int*>(st)[4] = now_cnt;
-                        reinterpret_cast<int*>(st)[5] = now_pad;
-                    }
-                }
-                // the batch's weights (conv18, conv19, conv20): requested now - this window's image
-                // and the front of the arena are dead - used behind two barriers
-                if (batch_ends) {
-                    dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
-                    dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
-                    dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
-                }
-                // Thirds 1 and 2 of the NEXT window's conv2 weights -> slots 1 and 2, by the
-                // four waves that have nothing else to do while waves 0-2 reduce conv17 (36 pieces,
-                // nine each) - unless the batched tail runs between this window and the next: its
-                // buffers lie there.
-                if (thirds_now && wave >= 3 && wave < kWaves - 1) {
-                    const unsigned lane_bytes = (unsigned)lane * 16u;
+    const bool run_tail = batch_ends;
+    const bool thirds_next = thirds_now;
+    const int pair_w = wave >> 2, kq = wave & 3;
+    const int n = lane & 15, q = lane >> 4;
+    // (1) the two offsets of each of the next group's windows (VECTOR loads - the address made
+    // per-lane on purpose: as scalar loads they would count against lgkmcnt, which the compiler's
+    // LDS waits below watch)
+    long long noff0[kGroup], noff1[kGroup];
+    int nstep[kGroup];
 #pragma unroll
-                    for (int i = 0; i < 2 * kWinoHalf / 256 / 4; ++i) {
-                        const int piece = (wave - 3) + 4 * i;
-                        dma_piece(packed + weight_offset(1) + kWinoHalf + piece * 256,
-                                  lds + kSlot1 + piece * 256, lane_bytes);
-                    }
+    for (int w = 0; w < kGroup; ++w) {
+        noff0[w] = 0;
+        noff1[w] = 0;
+        nstep[w] = 0;
+        if (seam_b2 && w < next_n) {
+            unsigned next_read;
+            split_window((unsigned)(next_start + w), steps_arg, &next_read, &nstep[w]);
+            unsigned lane_zero = 0;
+            asm volatile("" : "+v"(lane_zero));
+            noff0[w] = offsets_arg[next_read + lane_zero];
+            noff1[w] = offsets_arg[next_read + lane_zero + 1];
+        }
+    }
+    // (2) conv17's fragments: buffer loads the compiler does not see (scalar base and fragment
+    // offset, the lane's eight bytes), waited for by hand below
+    f2 w17[54];
+    {
+        const __amdgpu_buffer_rsrc_t view = buffer_view(packed + weight_offset(16));
+        const unsigned lane_bytes = (unsigned)lane * 8u;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned soff = (unsigned)(((tap * 24 + kq * 6 + sp) * 3 + t) * 128) * 4u;
+                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
+                                 : "=v"(w17[(tap * 6 + sp) * 3 + t])
+                                 : "v"(lane_bytes), "s"(view), "s"(soff)
+                                 : "memory");
                 }
-            },
-            // The NEXT window's first third of conv2's weights -> slot 0 (above everything stage F
-            // uses; the batched tail keeps clear of it): tile 0 of conv2 multiplies right behind that
-            // window's first barrier, which retires these requests - 18 pieces, one per wave behind
-            // each tap's MFMAs.
-            [&](int tap) {
-                if (slot0_next)
-                    dma_weights_one<kWinoHalf>(packed + weight_offset(1), lds + kSlot0, lane, wave, tap);
-            },
-            &ep17);
     }
-    // The next window's conv17 writes the partial tiles this one's reduction reads.  LDS only:
-    // nobody waits for conv17's stores before the batched tail.
-    phase_add(7, f_since);
-    if (!last) lds_barrier();
-    phase_add(8, f_since);
-    // (3) the samples of the window whose offsets were asked for at the top - LAST, so that nothing
-    // above waits for their trip from HBM
-    fetched_cnt = 0;
-    fetched_pad = 0;
-    fetched_v0 = 0;
-    fetched_v1 = 0;
-    if (fetch) {
-        long long wa, wb;
-        const long long next_base =
-            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off0 >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off0);
-        const long long next_end =
-            ((long long)__builtin_amdgcn_readfirstlane((int)(next_off1 >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)next_off1);
-        window_bounds(next_end - next_base, next_step, side_arg, &wa, &wb);
-        fetched_cnt = (int)(wb - wa);
-        fetched_pad = (side_arg == 0) ? 0 : kWindow - fetched_cnt;
-        const int16_t* src = (const int16_t*)smp_opaque + next_base + wa;
-        fetched_v0 = tid < fetched_cnt ? (int)src[(unsigned)tid] : 0;
-        fetched_v1 = tid + 512 < fetched_cnt ? (int)src[(unsigned)(tid + 512)] : 0;
+    // bias and BN6 of the output quadruples this lane finishes (tid and, for tid < 256, 512 + tid of
+    // the group's 768: quadruple e = window e / 192, N tile (e % 192) / 64, lane (e % 64))
+    EpiParams<1, true> ep17[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = (r * kThreads + tid) % 192, ch = (e >> 6) * 16 + (e & 15);
+        ep17[r].load(packed + bias_offset(16) + ch, packed + bn_scale_offset(5) + ch, packed + bn_shift_offset(5) + ch);
     }
-    mark_realtime(ts, 63);
-    ++tail_slot;
+    if (tid < group_n) reinterpret_cast<int*>(lds + kTailWins)[tail_slot + tid] = group_start + tid;
     flush_marks(ts, ts_out, lane);
-    }   // stage F of the group's windows
+    unsigned f_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the fragments and the offsets are in
+#pragma unroll
+    for (int k17 = 0; k17 < 54; ++k17) asm volatile("" : "+v"(w17[k17]));
+#pragma unroll
+    for (int w = 0; w < kGroup; ++w) asm volatile("" : "+v"(noff0[w]), "+v"(noff1[w]));
+    // (3) the next group's samples: this lane's two of each window - asked for here, behind the wait
+    // that has just retired the offsets, in front of the layer's 216 MFMAs per wave, which cover their
+    // trip from HBM
+    int ncnt[kGroup], npad[kGroup], nv0[kGroup], nv1[kGroup];
+#pragma unroll
+    for (int w = 0; w < kGroup; ++w) {
+        ncnt[w] = 0;
+        npad[w] = 0;
+        nv0[w] = 0;
+        nv1[w] = 0;
+        if (seam_b2 && w < next_n) {
+            long long wa, wb;
+            const long long next_base =
+                ((long long)__builtin_amdgcn_readfirstlane((int)(noff0[w] >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)noff0[w]);
+            const long long next_end =
+                ((long long)__builtin_amdgcn_readfirstlane((int)(noff1[w] >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)noff1[w]);
+            window_bounds(next_end - next_base, nstep[w], side_arg, &wa, &wb);
+            ncnt[w] = (int)(wb - wa);
+            npad[w] = (side_arg == 0) ? 0 : kWindow - ncnt[w];
+            const int16_t* src = (const int16_t*)samples_entry + next_base + wa;
+            nv0[w] = tid < ncnt[w] ? (int)src[(unsigned)tid] : 0;
+            nv1[w] = tid + 512 < ncnt[w] ? (int)src[(unsigned)(tid + 512)] : 0;
+        }
+    }
+    {
+        // stride-2 'same' pads on the right only: output position n reads rows 2n, 2n + 1, 2n + 2 of
+        // the image's rows 1 .. 32 (+ the zero row 33)
+        const float* a_lane[2];
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            const int win_k = pair_w * 2 + w2;
+            a_lane[w2] = lds + cat_offset(win_k < group_n ? win_k : 0, group_n) + (1 + 2 * n) * kS192 + 2 * q + kq * 48;
+        }
+        f4 acc[2][3];
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[w2][t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            f2 a[2][6];
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                for (int sp = 0; sp < 6; ++sp)
+                    a[w2][sp] = *reinterpret_cast<const f2*>(a_lane[w2] + tap * kS192 + sp * 8);
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            acc[w2][t] = mfma4(a[w2][sp][e], w17[(tap * 6 + sp) * 3 + t][e], acc[w2][t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        phase_add(5, f_since);
+        mark(ts, 41);
+        lds_barrier();         // every wave has read the images: the partial tiles go over them
+        phase_add(6, f_since);
+        // the next window's conv2 weights: slot 0 (tile 0 multiplies right behind that window's
+        // first barrier, which retires these requests) and - unless the batched tail, whose buffers
+        // lie there, runs in between - slots 1 and 2: 54 pieces, seven per wave; the images that lay
+        // there are dead
+        if (slot0_next) {
+            if (thirds_now) dma_weights<3 * kWinoHalf, kWaves>(packed + weight_offset(1), lds + kSlot0, lane, wave);
+            else dma_weights<kWinoHalf, kWaves>(packed + weight_offset(1), lds + kSlot0, lane, wave);
+        }
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                *reinterpret_cast<f4*>(lds + kRed + (((pair_w * 2 + w2) * 4 + kq) * 3 + t) * 256 + lane * 4) = acc[w2][t];
+    }
+    mark(ts, 42);
+    lds_barrier();             // the partial tiles are out
+    // the reduction: quadruple e of the group's 768 = the sum of its window's four partial tiles,
+    // + bias, ReLU, BN6 -> the window's slot (dense [16][48], row 0 = position 0)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = r * kThreads + tid;
+        const int win_k = e / 192, rest = e - win_k * 192, t = rest >> 6, l2 = rest & 63;
+        if (e < kGroup * 192 && win_k < group_n) {
+            const float* p = lds + kRed + ((win_k * 4) * 3 + t) * 256 + l2 * 4;
+            const f4 p0 = *reinterpret_cast<const f4*>(p), p1 = *reinterpret_cast<const f4*>(p + 3 * 256);
+            const f4 p2 = *reinterpret_cast<const f4*>(p + 6 * 256), p3 = *reinterpret_cast<const f4*>(p + 9 * 256);
+            f4 sum[1][1];
+            sum[0][0] = (p0 + p1) + (p2 + p3);
+            float* slot = wg_scratch + kWgTailOff + (tail_slot + win_k) * kTailSlotFloats;
+            epilogue<1, 1, 48, false, true>(sum, slot + 4 * (l2 >> 4) * 48 + t * 16 + (l2 & 15), ep17[r]);
+        }
+    }
+    phase_add(7, f_since);
+    mark(ts, 43);
+    // the next group's windows 1 .. 3: samples to the staging, exact sums for the barrier below
+#pragma unroll
+    for (int w = 1; w < kGroup; ++w) {
+        asm volatile("" : "+v"(nv0[w]), "+v"(nv1[w]));
+        if (seam_b2 && w < next_n) {
+            window_partial_sums(lds, ncnt[w], nv0[w], nv1[w], tid, lane, wave, w);
+            short* smp = reinterpret_cast<short*>(lds + kStage + w * kStageWin);
+            smp[tid] = (short)nv0[w];
+            smp[tid + 512] = (short)nv1[w];
+        }
+    }
+    // the batch's weights (conv18, conv19, conv20): requested now - the partial tiles they land on
+    // are read - and used behind two barriers
+    tail_slot += group_n;
+    lds_barrier();
+    if (batch_ends) {
+        dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
+        dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
+        dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
+    }
+    if (wave >= 5) {
+        const int w = wave - 4;
+        if (seam_b2 && w < next_n) {
+            double mean, inv;
+            window_mean_inv(lds, ncnt[1], &mean, &inv, 1);
+            if (w == 2) window_mean_inv(lds, ncnt[2], &mean, &inv, 2);
+            if (w == 3) window_mean_inv(lds, ncnt[3], &mean, &inv, 3);
+            float* st = lds + kStageStats + w * 8;
+            if (lane == 0) {
+                reinterpret_cast<double*>(st)[0] = mean;
+                reinterpret_cast<double*>(st)[1] = inv;
+                reinterpret_cast<int*>(st)[4] = w == 1 ? ncnt[1] : w == 2 ? ncnt[2] : ncnt[3];
+                reinterpret_cast<int*>(st)[5] = w == 1 ? npad[1] : w == 2 ? npad[2] : npad[3];
+            }
+        }
+    }
+    phase_add(8, f_since);
+    mark_realtime(ts, 63);
     phase_stamp(3);
-    carry_cnt = fetched_cnt;
-    carry_pad = fetched_pad;
-    carry_v0 = fetched_v0;
-    carry_v1 = fetched_v1;
+    carry_cnt = ncnt[0];
+    carry_pad = npad[0];
+    carry_v0 = nv0[0];
+    carry_v1 = nv1[0];
 
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---

@@ -355,7 +355,7 @@ constexpr int kSyncTiles = kSync, kSyncHalo = kSync + 4;
 constexpr int kSyncDTiles = kSync + 20, kSyncDHalo = kSyncDTiles + 6, kSyncWords = 20 + 6 + 16;
 // window statistics: 16 int64 partial sums (two per wave) and the resulting {mean, 1/std} doubles
 constexpr int kStatRed = kSync + kSyncWords;
-constexpr int kStatOut = kStatRed + 32;
+constexpr int kStatOut = kStatRed + kGroup * 32;      // (a slot of 16 int64 per window staged at once)
 static_assert(kStatRed % 2 == 0, "64-bit words");
 // one counter word per half of each of conv7's four wave pairs (dbh_forward.hip: pair_signal)
 constexpr int kPairSync = kStatOut + 4;
@@ -368,7 +368,7 @@ constexpr int kTailWins = kNextWin + 1;
 // (marks 5..8: stage F's inner intervals as wave 0 sees them, summed over the group's windows: to the
 // end of conv17's MFMAs, to behind its barrier, to the end of the reduction, to behind the window's
 // last barrier)
-constexpr int kPhaseMarks = 9, kPhaseGroups = 24;
+constexpr int kPhaseMarks = 9, kPhaseGroups = 12;
 constexpr int kPhase = kTailWins + kTailBatch;
 constexpr int kLdsFloats = kPhase + kPhaseMarks * kPhaseGroups;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");
