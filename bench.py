@@ -453,6 +453,109 @@ def side_rates(weights, reads):
     return out
 
 
+def other_configs():
+    """The other BASELINE.json configurations on this one GPU, inside the default run's budget, so that
+    every configuration has a figure the driver observed (N = 1, --config 1 only):
+      "2", "3": this script again as a child (`--config K --steps 3 --warmup 1`, no CPU leg): reads/s and
+                roofline.frac of its line;
+      "4":     the realtime stream over multi-read containers written on the spot by this package's
+                own writer (4,000 reads each, deflated, 2,000-9,000 samples): `deepbinner realtime`
+                (table only) over 2 and over 26 of them - the difference of the two runs takes the
+                fixed costs (model loading, thread teams) out: reads/s of the 24 containers between."""
+    import shutil
+    import subprocess
+    import tempfile
+    out = {}
+    for k in (2, 3):
+        try:
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', str(k), '--steps', '3',
+                                '--warmup', '1', '--no-cpu-baseline', '--no-side-rates', '--no-other-configs'],
+                               capture_output=True, text=True, timeout=120)
+            line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
+            d = json.loads(line)
+            out[str(k)] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                           'frac': d['roofline']['frac'], 'windows_per_s': d.get('windows_per_s'),
+                           'workload': d['config']['workload'].split(':')[0],
+                           'seconds': round(time.perf_counter() - t0, 1)}
+        except Exception as e:                      # noqa: BLE001
+            out[str(k)] = {'skipped': repr(e)[:200]}
+    directory = tempfile.mkdtemp(prefix='dbh_bench_stream_')
+    try:
+        t0 = time.perf_counter()
+        out['4'] = stream_rate(directory)
+        out['4']['seconds'] = round(time.perf_counter() - t0, 1)
+    except Exception as e:                          # noqa: BLE001
+        out['4'] = {'skipped': repr(e)[:200]}
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
+    return {'other_configs': out}
+
+
+def stream_rate(directory, small=2, large=26, reads_per_container=4000):
+    import contextlib
+    import io
+    import uuid
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from deepbinner_amd import deepbinner as cli
+    from deepbinner_amd import hdf5_write
+    import deepbinner_amd.realtime as realtime
+    rng = np.random.default_rng(20260929)
+    pool = []
+    for _ in range(1000):
+        n = int(rng.integers(2000, 9000))
+        levels = np.repeat(rng.normal(450, 80, n // 8 + 1), 8)[:n]
+        pool.append(np.clip(np.rint(levels + rng.normal(0, 8, n)), 0, 2047).astype(np.int16))
+    with ThreadPoolExecutor(16) as workers:
+        deflated = list(workers.map(lambda sig: zlib.compress(sig.tobytes(), 1), pool))
+
+    def write(job):
+        path, seed = job
+        r = np.random.default_rng(seed)
+        reads = []
+        for _ in range(reads_per_container):
+            j = int(r.integers(0, len(pool)))
+            reads.append((str(uuid.UUID(bytes=r.bytes(16), version=4)), pool[j], None, deflated[j]))
+        with open(path, 'wb') as f:
+            f.write(hdf5_write.multi_read_fast5_bytes(reads))
+
+    dirs = {}
+    jobs = []
+    for name, count in (('small', small), ('large', large)):
+        dirs[name] = os.path.join(directory, name)
+        os.makedirs(dirs[name])
+        jobs += [(os.path.join(dirs[name], 'stream_%02d.fast5' % c), 1000 * count + c) for c in range(count)]
+    with ThreadPoolExecutor(8) as workers:
+        list(workers.map(write, jobs))
+    models = os.path.join(REPO, 'deepbinner_amd', 'models')
+    realtime.POLL_SECONDS = 0
+    os.environ['DEEPBINNER_REALTIME_TABLE_ONLY'] = '1'
+    seconds = {}
+    for name in ('small', 'large', 'small', 'large'):        # (the second pair is the measurement)
+        argv = ['realtime', '--in_dir', dirs[name], '--out_dir', os.path.join(directory, 'out_' + name), '--stop',
+                '-s', os.path.join(models, 'EXP-NBD103_read_starts.dbw'),
+                '-e', os.path.join(models, 'EXP-NBD103_read_ends.dbw')]
+        shutil_out = os.path.join(directory, 'out_' + name)
+        if os.path.isdir(shutil_out):
+            import shutil
+            shutil.rmtree(shutil_out)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            cli.main(argv)
+        seconds[name] = time.perf_counter() - t0
+        with open(os.path.join(shutil_out, 'multi_read_classifications.tsv')) as f:
+            rows = sum(1 for _ in f)
+        if rows != (small if name == 'small' else large) * reads_per_container:
+            raise RuntimeError('%s: %d rows' % (name, rows))
+    reads = (large - small) * reads_per_container
+    return {'reads_per_s': reads / (seconds['large'] - seconds['small']), 'unit': 'reads/s',
+            'reads': reads, 'host_share_percent': realtime.host_inflate_share(1),
+            'workload': 'BASELINE.json configs[4] on one GPU: `deepbinner realtime` (start + end models, table '
+                        'only) over multi-read containers of 4,000 deflated reads of 2,000-9,000 samples; the '
+                        'rate of the %d containers by which two runs differ' % (large - small)}
+
+
 def workload_string(cfg, direct=False, spl=1):
     """`config.workload` of the JSON line: names the BASELINE.json configuration first."""
     n_models = len(cfg['models'])
@@ -501,6 +604,8 @@ def main():
                          'divisor of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-rates', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short runs of configs[2], [3] and [4] beside --config 1 (other_configs)')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='experiment: skip the per-launch HIP events (roofline object omitted)')
     args = ap.parse_args()
@@ -769,12 +874,9 @@ def main():
             'executed_mfma_per_window': mfmas, 'executed_flop_per_window': executed_flop,
             'achieved_executed': executed,
             'frac_executed': executed / PEAK_FP32_TFLOPS,
-            # matrix-pipe busy fraction: rocprofv3's SQ_VALU_MFMA_BUSY_CYCLES per window (a constant
-            # of the build, profiles/pmc_traffic.json) over this run's launch time on 1,024 SIMDs
-            'mfma_pipe_util': (pmc['mfma_busy_cycles_per_window'] * rate / (1024 * 2.4e9)
-                               if 'mfma_busy_cycles_per_window' in pmc else None),
-            'mfma_pipe_util_source': 'static: the committed PMC run {} over this run\'s launch time'
-                                     .format(pmc.get('source')),
+            # (how busy the matrix pipe is = frac_executed: an MFMA of this kind holds a SIMD's pipe for
+            # 32 cycles and does 2,048 FLOP, which is what the peak counts; rounds 2-5 also printed a
+            # figure scaled from a committed PMC run - a constant of the build, not of the run: dropped)
             # The peak above is the data sheet's, at 2.4 GHz.  Under this kernel the shader clock
             # runs lower (power management); measured inside the timed region's last launch by
             # every workgroup (s_memtime against the 100 MHz s_memrealtime, median).  In CYCLES -
@@ -788,9 +890,6 @@ def main():
                 dict(zip(['stages_a_c', 'chain_d_e', 'stage_f', 'tail', 'between', 'f_mfma', 'f_barrier', 'f_reduce', 'f_end_barrier'],
                          [round(c, 1) for c in phase_cycles]), groups=phase_groups)
                 if phase_groups else None),
-            'mfma_pipe_util_at_shader_clock': (
-                pmc['mfma_busy_cycles_per_window'] * rate / (1024 * shader_ghz * 1e9)
-                if shader_ghz and 'mfma_busy_cycles_per_window' in pmc else None),
             'peak_at_shader_clock': PEAK_FP32_TFLOPS * shader_ghz / 2.4 if shader_ghz else None,
             'frac_executed_at_shader_clock': (
                 executed_flop * rate / 1e12 / (PEAK_FP32_TFLOPS * shader_ghz / 2.4)
@@ -814,19 +913,26 @@ def main():
     if is_lead and world == 1:
         if args.config == 1 and not args.no_side_rates:
             result.update(side_rates(weights[0], all_reads0))
+        if args.config == 1 and not args.no_other_configs and not args.no_side_rates:
+            result['_other_configs_pending'] = True
         if not args.no_cpu_baseline:
             n0 = shard_sizes[0]
             gpu_probs = lead.probs[0].download((n0, lead.models[0].n_classes), np.float32)
             result['cpu_baseline'] = cpu_baseline(cfg, weights, all_reads0[:min(n0, 50000)],
                                                   gathered[:n0], gpu_probs)
+    pending = bool(is_lead and result.pop('_other_configs_pending', False))
     if is_lead:
         result['device'] = hip_backend.device_name(lead.shard.device)
-        print(json.dumps(result))
-        sys.stdout.flush()
     barrier()
     group.close()
     if rdzv is not None:
         rdzv.close()
+    if pending:
+        # (behind everything of this configuration's own: its models and buffers are released)
+        result.update(other_configs())
+    if is_lead:
+        print(json.dumps(result))
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':

@@ -183,7 +183,10 @@ struct dbh_model {
     // The end of a persistent launch: with fewer than chunk4_rounds x grid windows not yet handed
     // out a workgroup asks for groups of 2 instead of 4, below chunk2_rounds x grid for single
     // windows (DEEPBINNER_CHUNK4_ROUNDS / DEEPBINNER_CHUNK2_ROUNDS: A/B)
-    int chunk4_rounds = 8, chunk2_rounds = 3;
+    // (measured on configs[1] one launch per step, 10,000 windows: 8 / 3: 5.44 M reads/s, 4 / 2: 5.75 M,
+    // 2 / 1: 5.74 M, 0 / 0 - always four - 5.74 M: a small group pays the whole stage D-E-F chain for
+    // one or two windows, so they are kept to the launch's very end)
+    int chunk4_rounds = 2, chunk2_rounds = 1;
     float* d_packed = nullptr;
     // workspace for the host-pointer entry points, grown on demand
     void* d_in = nullptr;      size_t in_bytes = 0;
@@ -1115,6 +1118,9 @@ namespace {
 // forward kernel on the GPU).  One at a time on 256 - n CUs (dbh_model_reserve_cus), the inflate
 // kernels of the containers behind keep the other n CUs busy all the time.
 // DEEPBINNER_FORWARD_STREAM=own: every queue on its own stream again (A/B).
+// (the streams live as long as the process - the queues of any model may use them - and are left to
+// the runtime's teardown on purpose; a device ordinal of kMaxDevices or more keeps every queue on
+// its own stream, which is correct, only slower)
 constexpr int kMaxDevices = 64;
 std::mutex g_forward_mutex[kMaxDevices];
 hipStream_t g_forward_stream[kMaxDevices] = {};
@@ -1286,6 +1292,24 @@ int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_mo
             if (e == hipSuccess && !d.classified)
                 e = hipEventCreateWithFlags(&d.classified, hipEventDisableTiming);
             if (e != hipSuccess) return done(hip_fail(e, "hipEventCreateWithFlags"));
+            // The forward kernel's per-workgroup scratch is sized BEFORE the device's lock is taken
+            // (ADVICE round 5): growing it means hipFree / hipMalloc, which synchronise the device,
+            // and under the lock that would stall every other queue's launch.  (Its first 256
+            // bytes - the window counter - are zeroed here when it is new, on this queue's stream,
+            // which the forward stream waits for below.)
+            {
+                void* before = d.d_tail;
+                int cus = 0;
+                for (int j = 0; j < 2; ++j)
+                    if (models[j] && models[j]->cus > cus) cus = models[j]->cus;
+                const int stt = ensure(&d.d_tail, &d.d_tail_bytes,
+                                       256 + (size_t)cus * dbh::kWgScratchFloats * sizeof(float));
+                if (stt != DBH_OK) return done(stt);
+                if (d.d_tail != before) {
+                    e = hipMemsetAsync(d.d_tail, 0, 256, d.stream);
+                    if (e != hipSuccess) return done(hip_fail(e, "hipMemsetAsync"));
+                }
+            }
             block = std::unique_lock<std::mutex>(g_forward_mutex[m->device]);
             hipStream_t& fs = g_forward_stream[m->device];
             if (!fs) {
@@ -1315,6 +1339,7 @@ int dbh_classify_pair_deflated_verbose(dbh_model* start_model, dbh_model* end_mo
             e = hipEventRecord(d.classified, on);
             if (e == hipSuccess) e = hipStreamWaitEvent(d.stream, d.classified, 0);
             if (e != hipSuccess) {
+                block.unlock();        // (the wait below must not hold up the other queues' launches)
                 (void)hipStreamSynchronize(on);
                 return done(hip_fail(e, "taking over from the forward stream"));
             }

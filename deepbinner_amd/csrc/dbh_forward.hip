@@ -2144,7 +2144,6 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                     z10[t][pp] = mfma4(w[sp].x, x.x, sp == 0 ? f4{0.f, 0.f, 0.f, 0.f} : z10[t][pp]);
                     z10[t][pp] = mfma4(w[sp].y, x.y, z10[t][pp]);
                 }
-            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -2191,7 +2190,6 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
             }
             even[t] = relu4(M0 + M1 + M2);
             odd[t] = relu4(M1 - M2 - M3);
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // ---- conv11 (1x1, 48 -> 48) -> concat 48..95
@@ -2213,7 +2211,6 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                     a[pp] = mfma4(w[sp].y, x.y, a[pp]);
                 }
             pooled_out(OUT[1][t], 48 + 16 * t, relu4(a[0]), relu4(a[1]));
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2264,7 +2261,6 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                 y1[c] = fmaxf(fmaf(mid + next, inv_last, b[c]), 0.f);
             }
             pooled_out(OUT[0][t], 16 * t, y0, y1);
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2316,8 +2312,7 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                         M2 = mfma4(wf[s2][1][e], U2[tc][r], first ? zero4 : M2);
                         M3 = mfma4(wf[s2][1][2 + e], U3[tc][r], first ? -b : M3);
                     }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
             pooled_out(OUT[3][t], 144 + 16 * t, relu4(M0 + M1 + M2), relu4(M1 - M2 - M3));
         }
     }

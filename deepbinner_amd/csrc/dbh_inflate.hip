@@ -1008,7 +1008,9 @@ __device__ __forceinline__ void resolve_pre_stream(
                 pv = pv_n;
             }
         }
-        // (the loop ends when kernel 1 has: its record is there)
+        // (the loop ends when kernel 1 has - its record is there - or on this wave's own error, with
+        // the partner possibly still decoding: record() waits for its verdict, so that the code
+        // handed back is the one the two-launch path gives)
         const StreamInfo r = there.record();
         if (r.status != dbi::kOk) status = r.status;
         if (status == dbi::kOk) {
@@ -1085,6 +1087,10 @@ struct TokensFromPartner {
         }
     }
     __device__ __forceinline__ StreamInfo record() const {
+        // (the resolver may get here on an error of its own while the decoder still runs: the words
+        // below are written just before `done`)
+        while (__hip_atomic_load(&w->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+            __builtin_amdgcn_s_sleep(16);
         StreamInfo r;
         r.status = w->status;
         r.ended = w->ended;

@@ -13,6 +13,8 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
+#include <linux/fs.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -56,17 +58,20 @@ struct ExistsError : std::runtime_error {
     ExistsError() : std::runtime_error("file exists") {}
 };
 
-// errno values with which link() says "this filesystem has no hard links" (or not for us)
+// errno values with which link() says "this filesystem has no hard links": ENOTSUP / EOPNOTSUPP /
+// ENOSYS, and EPERM, which is what FAT / exFAT and several FUSE and SMB mounts answer.  (Not EACCES,
+// EXDEV or EMLINK: those are errors of this call, not properties of the filesystem, and fall
+// through to "cannot name file".)
 static bool no_hard_links(int e) {
-    // (DEEPBINNER_FAST5_NO_LINK=1: every link() failure is treated as this one - the test of the
-    // fallback on filesystems that do have hard links)
+    return e == EPERM || e == ENOTSUP || e == EOPNOTSUPP || e == ENOSYS;
+}
+// DEEPBINNER_FAST5_NO_LINK=1 (tests): link() is not tried at all, as on such a filesystem
+static bool links_forbidden() {
     static const bool forced = [] {
         const char* v = std::getenv("DEEPBINNER_FAST5_NO_LINK");
         return v && v[0] == '1';
     }();
-    if (forced) return true;
-    return e == EPERM || e == ENOTSUP || e == EOPNOTSUPP || e == EMLINK || e == ENOSYS ||
-           e == EXDEV || e == EACCES;
+    return forced;
 }
 // The image under a name that must not exist yet (O_EXCL; a symlink there is not followed); a
 // failed write leaves nothing behind.
@@ -2507,18 +2512,38 @@ int f5_write_single_reads(const char* container, int64_t n, const int64_t* read_
                 ::unlink(tmp.c_str());      // (a stale one of this very name: a killed run whose
                                             // pid came round - the O_EXCL below would refuse it)
                 write_exclusive(tmp.c_str(), image);
-                int linked = ::link(tmp.c_str(), out_paths[i]);
-                int link_errno = errno;
-                if (linked == 0 && no_hard_links(0) && ::unlink(out_paths[i]) == 0) {
-                    linked = -1;            // (forced: as if the filesystem had refused)
-                    link_errno = EPERM;
+                int linked = -1, link_errno = EPERM;
+                if (!links_forbidden()) {
+                    linked = ::link(tmp.c_str(), out_paths[i]);
+                    link_errno = errno;
                 }
                 if (linked != 0 && link_errno != EEXIST && no_hard_links(link_errno)) {
-                    // exFAT / FAT, many SMB and FUSE mounts (sequencing drives) have no link():
-                    // the final name is created exclusively and written directly - still never
-                    // over an existing file, never through a symlink
-                    ::unlink(tmp.c_str());
-                    write_exclusive(out_paths[i], image);
+                    // exFAT / FAT, many SMB and FUSE mounts (sequencing drives) have no link(): the
+                    // finished temporary file is RENAMED into place - nobody ever sees a partial
+                    // file under the final name, and a killed process leaves only the .part file -
+                    // without replacing (renameat2 RENAME_NOREPLACE); where the filesystem does not
+                    // know that flag, after a look at the name (rename is atomic there too; the
+                    // window between the look and the rename is the one thing link() had closed)
+                    int renamed = -1;
+#ifdef RENAME_NOREPLACE
+                    renamed = (int)::syscall(SYS_renameat2, AT_FDCWD, tmp.c_str(), AT_FDCWD, out_paths[i],
+                                             RENAME_NOREPLACE);
+                    if (renamed != 0 && errno == EEXIST) {
+                        ::unlink(tmp.c_str());
+                        throw ExistsError();
+                    }
+#endif
+                    if (renamed != 0) {
+                        struct stat st_there;
+                        if (::lstat(out_paths[i], &st_there) == 0) {
+                            ::unlink(tmp.c_str());
+                            throw ExistsError();
+                        }
+                        if (::rename(tmp.c_str(), out_paths[i]) != 0) {
+                            ::unlink(tmp.c_str());
+                            throw std::runtime_error("cannot name file");
+                        }
+                    }
                 } else {
                     ::unlink(tmp.c_str());
                     if (linked != 0) {

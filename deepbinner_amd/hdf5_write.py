@@ -322,11 +322,16 @@ def write_single_read_fast5(path, read_id, signal, compress=True, read_number=No
         except FileExistsError:
             raise
         except OSError as e:
-            # no hard links here (exFAT / FAT, many SMB and FUSE mounts - sequencing drives):
-            # create the final name exclusively and write it directly
+            # no hard links here (exFAT / FAT, many SMB and FUSE mounts - sequencing drives): the
+            # finished temporary file is RENAMED into place, after a look at the name - nobody sees
+            # a partial file under the final name, a killed process leaves only the .part file;
+            # rename is atomic there too, the window between the look and the rename is the one
+            # thing link() had closed
             if e.errno not in _NO_LINK_ERRNOS:
                 raise
-            _write_exclusive(path, image)
+            if os.path.lexists(path):
+                raise FileExistsError(path)
+            os.rename(tmp, path)
     finally:
         try:
             os.unlink(tmp)
@@ -334,22 +339,7 @@ def write_single_read_fast5(path, read_id, signal, compress=True, read_number=No
             pass
 
 
+# what link() answers where the FILESYSTEM has no hard links (EPERM: FAT / exFAT, several FUSE and SMB
+# mounts); EACCES, EXDEV, EMLINK are errors of the call and are raised
 _NO_LINK_ERRNOS = frozenset(
-    getattr(errno, name) for name in ('EPERM', 'ENOTSUP', 'EOPNOTSUPP', 'EMLINK', 'ENOSYS', 'EXDEV',
-                                      'EACCES')
-    if hasattr(errno, name))
-
-
-def _write_exclusive(path, image):
-    """``path`` must not exist (O_EXCL) and is not followed if it is a symlink; a failed write
-    leaves nothing behind."""
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o666)
-    try:
-        with os.fdopen(fd, 'wb') as f:
-            f.write(image)
-    except BaseException:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
-        raise
+    getattr(errno, name) for name in ('EPERM', 'ENOTSUP', 'EOPNOTSUPP', 'ENOSYS') if hasattr(errno, name))

@@ -267,8 +267,8 @@ def test_nothing_is_ever_overwritten(tmp_path):
 
 def test_filesystems_without_hard_links(tmp_path, monkeypatch):
     """exFAT / FAT and many SMB or FUSE mounts refuse link() (EPERM, ENOTSUP ...): both writers
-    then create the final name exclusively and write it directly - same bytes, still nothing
-    overwritten, no temporary file left.  The native library is run in a child
+    then rename the finished temporary file into place (without replacing) - same bytes, still nothing
+    overwritten, no temporary file left (ADVICE rounds 4, 5).  EACCES is an error, not "no links".  The native library is run in a child
     process with DEEPBINNER_FAST5_NO_LINK=1 (it reads the switch once)."""
     import errno
     import subprocess
@@ -292,12 +292,20 @@ def test_filesystems_without_hard_links(tmp_path, monkeypatch):
     with pytest.raises(FileExistsError):
         hdf5_write.write_single_read_fast5(dangling, ids[1], samples[offsets[1]:offsets[2]])
     assert sorted(os.listdir(str(out_dir))) == ['link.fast5', 'py.fast5']
-    # a failing write leaves neither a temporary nor a final file
-    monkeypatch.setattr(hdf5_write, '_write_exclusive',
-                        lambda p, image: (_ for _ in ()).throw(OSError(errno.ENOSPC, 'full')))
+    # a failing rename leaves neither a temporary nor a final file (the finished
+    # temporary file is renamed into place, so that no partial file is ever seen under the final name)
+    monkeypatch.setattr(os, 'rename', lambda a, b: (_ for _ in ()).throw(OSError(errno.ENOSPC, 'full')))
     with pytest.raises(OSError):
         hdf5_write.write_single_read_fast5(str(out_dir / 'never.fast5'), ids[2],
                                            samples[offsets[2]:offsets[3]])
+    assert sorted(os.listdir(str(out_dir))) == ['link.fast5', 'py.fast5']
+    monkeypatch.undo()
+
+    def denied(src, dst, **kw):
+        raise OSError(errno.EACCES, 'Permission denied')
+    monkeypatch.setattr(os, 'link', denied)
+    with pytest.raises(PermissionError):
+        hdf5_write.write_single_read_fast5(str(out_dir / 'denied.fast5'), ids[2], samples[offsets[2]:offsets[3]])
     assert sorted(os.listdir(str(out_dir))) == ['link.fast5', 'py.fast5']
     monkeypatch.undo()
 

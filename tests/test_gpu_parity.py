@@ -835,6 +835,9 @@ def test_bench_other_configs_run(hip, config):
     # rate itself is tracked by bench.py / profiles/; DEEPBINNER_PERF_ASSERT=1 holds it to the
     # matrix pipe's busy fraction this kernel reaches on an idle MI355X)
     assert 0 < result['roofline']['frac'] <= 1.0
+    # (a loose floor by default - a forward kernel at less than half its rate is a defect, not a busy
+    # box: ADVICE round 5 -, the kernel's own figure when asked for)
+    assert result['roofline']['frac'] > 0.3
     if os.environ.get('DEEPBINNER_PERF_ASSERT') == '1':
         assert result['roofline']['frac'] > 0.6
     assert result['roofline']['frac'] == result['roofline']['frac_executed']

@@ -134,12 +134,13 @@ READS_PER_CONTAINER = 4000
 N_CONTAINERS = max(1, -(-int(os.environ.get('DEEPBINNER_STREAM_READS', '128000')) // READS_PER_CONTAINER))
 
 
-def build_containers(directory, gold):
+def build_containers(directory, gold, n_containers=None):
     """N_CONTAINERS containers of 4,000 reads (+ the 30 multi-read fixture reads dealt over them), written
     with this package's own container writer: 2,000 distinct seeded squiggles of 2,000-9,000
     samples, deflated once each, under fresh read ids."""
     from concurrent.futures import ThreadPoolExecutor
     from deepbinner_amd import hdf5_write
+    N_CONTAINERS = n_containers or globals()['N_CONTAINERS']
     rng = np.random.default_rng(20260928)
     pool = []
     for _ in range(2000):
@@ -296,6 +297,52 @@ def test_realtime_streams_100k_reads_of_multi_read_containers(hip, gold, contain
     differ = [rid for (rid, _), a, b in zip(reads, side_calls['start'], side_calls['end'])
               if calls[rid] != classify_ref.combine_calls(as_name(a), as_name(b), 'require_either')]
     assert not differ, '%d of %d rows differ from the oracle' % (len(differ), len(reads))
+
+
+@pytest.mark.skipif(os.environ.get('DEEPBINNER_STREAM_FULL', '1') == '0', reason='DEEPBINNER_STREAM_FULL=0')
+def test_config4_streams_its_full_million_reads(hip, gold, tmp_path_factory, tmp_path, monkeypatch, capsys):
+    """BASELINE.json configs[4] at its STATED size on the one GPU the test has: 250 containers of
+    4,000 reads (+ the 30 fixture reads) = 1,000,030 reads through `deepbinner realtime` - loader
+    team -> pinned batches -> both models + combine_calls per container -> table.  Every read is
+    tabulated exactly once, the fixture reads get the reference's calls, and one whole container's
+    4,000 rows are what the ORACLE's C port makes of the samples the pure-Python HDF5 reader (zlib's
+    inflate) finds in the file.  (~7 GB of scratch files; DEEPBINNER_STREAM_FULL=0 skips it.)"""
+    import time
+    from deepbinner_amd import load_fast5s
+    from deepbinner_amd.model_format import ModelWeights as MW
+    from oracle import dbref
+    n_containers = 250
+    directory = str(tmp_path_factory.mktemp('stream_full'))
+    try:
+        t0 = time.perf_counter()
+        paths, every_id = build_containers(directory, gold, n_containers)
+        built = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        table, text = run_realtime(directory, str(tmp_path / 'full'), 1, monkeypatch, capsys)
+        seconds = time.perf_counter() - t0
+        assert len(table) == len(every_id) == n_containers * READS_PER_CONTAINER + 30
+        assert len(set(every_id)) == len(every_id) and sorted(r[0] for r in table) == sorted(every_id)
+        assert {r[2] for r in table} == set(paths)
+        calls = {r[0]: r[1] for r in table}
+        want = reference_final_calls(gold)
+        for rid in gold['multi_read_ids']:
+            assert calls[rid] == want[rid]
+        assert text.count('Barcode     Count') == -(-n_containers // 5)
+        print('configs[4] at full size: %d reads in %.1f s = %.0f reads/s (table only, incl. model loading; '
+              'containers written in %.1f s)' % (len(table), seconds, len(table) / seconds, built))
+        path = paths[len(paths) // 3]
+        reads = list(load_fast5s._python_iter_reads(path))
+        o_samples, o_offsets = pack([np.asarray(sig, dtype=np.int16) for _, sig in reads])
+        side_calls = {}
+        for side, name in (('start', START), ('end', END)):
+            weights = MW.load(os.path.join(MODEL_DIR, name + '.dbw'))[0]
+            side_calls[side] = dbref.CModel(weights).classify(o_samples, o_offsets, side, 6144, 0.5)[1]
+        as_name = lambda c: 'none' if c == 0 else str(int(c))                # noqa: E731
+        differ = [rid for (rid, _), a, b in zip(reads, side_calls['start'], side_calls['end'])
+                  if calls[rid] != classify_ref.combine_calls(as_name(a), as_name(b), 'require_either')]
+        assert not differ, '%d of %d rows differ from the oracle' % (len(differ), len(reads))
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
 
 
 def test_realtime_bins_multi_read_reads_on_the_gpu(hip, gold, tmp_path, monkeypatch, capsys):
