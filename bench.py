@@ -887,7 +887,8 @@ def main():
             # behind barriers): stages A-C of its windows, the stage D-E chain, stage F of its windows,
             # the batched tail (every second group), between two groups
             'phase_cycles_per_group': (
-                dict(zip(['stages_a_c', 'chain_d_e', 'stage_f', 'tail', 'between', 'f_mfma', 'f_barrier', 'f_reduce', 'f_end_barrier'],
+                dict(zip(['stages_a_c', 'chain_d_e', 'stage_f', 'tail', 'between', 'f_mfma', 'f_barrier', 'f_reduce', 'f_end_barrier',
+                          'ac_top', 'ac_chain', 'ac_conv7_first_three', 'conv7_last', 'conv7_last_to_chain'],
                          [round(c, 1) for c in phase_cycles]), groups=phase_groups)
                 if phase_groups else None),
             'peak_at_shader_clock': PEAK_FP32_TFLOPS * shader_ghz / 2.4 if shader_ghz else None,

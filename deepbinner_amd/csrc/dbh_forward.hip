@@ -1055,8 +1055,8 @@ __device__ __forceinline__ void w43a_step(W43U& U, const ConvAIn& in, f4 (&a1)[3
 // may place between the first conv1d_1 MFMAs (LDS-DMA pieces for slots 1 and 2: a request costs
 // ~100 cycles of issue, a bunch of them in front of the MFMAs keeps the matrix pipe idle).
 template <class Between, class Side>
-__device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* lds, int lane,
-                                           f4 (&acc)[6], f4 bias, const Between& between,
+__device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* lds, const float* third0,
+                                           int lane, f4 (&acc)[6], f4 bias, const Between& between,
                                            const Side& side) {
     const int q = lane >> 4;
     const f4* bias4 = reinterpret_cast<const f4*>(lds + kParams + 4 * q);   // + 4 g: group g
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void w43a_tile0(W43U& U, const ConvAIn& in, float* ld
         for (int t = 0; t < 6; ++t) asm volatile("" : "+v"(a1[g][t]));
     __builtin_amdgcn_sched_barrier(0);
     const unsigned p_addr = lds_addr(lds + kParams + 4 * q);
-    const unsigned b_addr = lds_addr(lds + kSlot0 + lane * 4);
+    const unsigned b_addr = lds_addr(third0 + lane * 4);     // (the tile's third of conv2's weights)
     f2 pbuf[2][2];
     f4 buf[2][3];
     w43a_load_params<0>(pbuf[0], p_addr);
@@ -1339,7 +1339,7 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
                                               unsigned& chain_windows, const ConvAIn& in_a,
                                               bool thirds_here, const BetweenA& between_a,
                                               const AfterFirst& after_first,
-                                              const DumpBase& dump_b_base) {
+                                              const DumpBase& dump_b_base, const float* third0) {
     const int n = lane & 15, q = lane >> 4;
     const unsigned tiles0 = chain_windows * 24u, halos0 = chain_windows * 7u;
     chain_windows += 1;
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
     // activation buffer one behind each of the first seven steps.
     {
         const f4 bias2 = tab4[B2 / 4];
-        w43a_tile0(U, in_a, lds, lane, acc[0], bias2, between_a, [&](auto tag) {
+        w43a_tile0(U, in_a, lds, third0, lane, acc[0], bias2, between_a, [&](auto tag) {
             constexpr int SP = decltype(tag)::value;
             if constexpr (NW == 8) {
                 conv3_piece(SP);
@@ -3272,6 +3272,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
     mark(ts, 0);
     mark_realtime(ts, 62);
+    unsigned ac_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
     // (opaque once per round like the parameter pointer: see above)
     const __attribute__((address_space(1))) int* wc_opaque =
         (const __attribute__((address_space(1))) int*)win_counter_entry;
@@ -3427,6 +3428,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // (a group's later windows: conv7 of the window before ended without waiting for its park's
     // stores or for the weights asked for under it - they had this stage A's time to land)
     if (k > 0) full_barrier();
+    phase_add(9, ac_since);
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2, conv5, conv6 ----------------
     // One chain in registers (stage_b_chain): nine Winograd F(4,3) tiles back to back, no
     // workgroup barrier, no activation image between the layers; conv5 and conv6 on its end.
@@ -3446,7 +3448,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             if (win_counter != nullptr && tid == 0 && k == 0)
                 reinterpret_cast<int*>(lds + kNextWin)[0] = taken;
         },
-        [&] { return glob(args()->debug_out) + (long)win * kStageFloats[1]; });
+        [&] { return glob(args()->debug_out) + (long)win * kStageFloats[1]; },
+        // (a group's later windows: the first third waits where conv7 of the window before put it)
+        lds + ((k > 0 && !weights_cold) ? kChainP : kSlot0));
     if (stop_stage == 0 || stop_stage == 1) {
         // (debug_stage 0: tile 0 has written the dump itself; 1: dumped from registers, conv5 did
         // not run.  The chain was left half-way: its counters start over for the next window.)
@@ -3465,10 +3469,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     }
 
     // ---------------- stage C: conv7 (L=256, F(4,3)) + MaxPool + BN3 -> this window's park -----
-    // Meanwhile, thirds 0 and 2 of conv2's weights for the NEXT window -> slots 0 and 2, behind the
-    // mid-layer barrier (conv7's own N tiles 0 and 2 lay there); five pieces per requesting wave and
-    // third, two per step.  The layer ends with an LDS-only barrier: the park's stores and these
-    // requests are retired by the full barrier in front of the next window's stage B.
+    // Meanwhile the NEXT window's conv2 weights: the first third -> kChainP (the idle part of the
+    // activation buffer: slot 0 holds conv7's own N tile 0) in the layer's first steps, the last
+    // third -> slot 2 behind the mid-layer barrier (conv7's N tile 2 lay there); five pieces per
+    // requesting wave and third, two per step.  The layer ends with an LDS-only barrier: the park's
+    // stores and these requests are retired by the full barrier in front of the next window's stage B.
+    phase_add(10, ac_since);
     // (the group's last window: below, outside the loop)
     if (k == group_n - 1) {
         flush_marks(ts, ts_out, lane);
@@ -3485,12 +3491,11 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             lds, packed, wg_scratch + kWgPark7Off + k * kPark7Floats, tid, lane, wave, ts, 22, pair_rounds,
             [&](auto tag) {
                 constexpr int G = decltype(tag)::value;
-                if constexpr (G >= 6) {
-                    third_step(packed + weight_offset(1), lds + kSlot0, G - 6);
-                    third_step(packed + weight_offset(1) + 2 * kWinoHalf, lds + kSlot2, G - 6);
-                }
+                if constexpr (G < 3) third_step(packed + weight_offset(1), lds + kChainP, G);
+                if constexpr (G >= 6) third_step(packed + weight_offset(1) + 2 * kWinoHalf, lds + kSlot2, G - 6);
             });
     }
+    phase_add(11, ac_since);
     if (stop_stage == 2) {
         full_barrier();      // (the park's stores are out)
         if (debug_stage < 100) {
@@ -3538,13 +3543,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // closing barrier, which does not wait for them) - the parks are MALL / HBM resident (176 KB per
     // workgroup: more than the L2 holds), a round trip of thousands of cycles.  The last window's own output goes to
     // LDS (w43_nsplit_half<LAST>) and is read back behind the layer's closing barrier.  conv8's
-    // third 0 -> stage D's slot 0 (the idle upper half of the activation buffer) and, behind the
-    // mid-layer barrier, its third 1 -> slot 1 (conv7's N tile 0 lay there).
+    // thirds 0 and 1 -> stage D's slots 0 and 1 (the idle part of the activation buffer) in the
+    // layer's first half: nothing is requested in its second half, whose closing barrier waits for
+    // what was (measured with them there: 3 k cycles per group longer than the other windows' conv7).
     // (the waves of windows the group does not have run along on whatever their parks hold: the
     // weight slots and their counters are shared by all eight, and nothing of theirs is looked at)
     const int k_last = group_n - 1;
     const bool own_last = (wave >> 1) == k_last;
     f2 Y[3][2][4];
+    unsigned c7_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
     {
         auto third_step = [&](const float* src, float* dst, int step) {
             constexpr int NW = DBH_DMA_WAVES;
@@ -3556,7 +3563,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
             lds, packed, nullptr, tid, lane, wave, ts, 59, pair_rounds, [&](auto tag) {
                 constexpr int G = decltype(tag)::value;
                 if constexpr (G < 3) third_step(packed + weight_offset(7), lds + kDS0, G);
-                if constexpr (G >= 6) third_step(packed + weight_offset(7) + kWinoHalf, lds + kDS1, G - 6);
+                else if constexpr (G < 6) third_step(packed + weight_offset(7) + kWinoHalf, lds + kDS1, G - 3);
             },
             [&]() -> bool {
                 // (every wave: the two that own the last window load what their park holds - stale -
@@ -3568,6 +3575,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 return true;
             });
     }
+    phase_add(12, c7_since);
     if (stop_stage == 2) {
         if (debug_stage < 100) {
             float* out = glob(args()->debug_out) + (long)(group_start + k_last) * kStageFloats[2];
@@ -3587,6 +3595,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     if (own_last)
         d_load_y(Y, (const float*)(lds + kPark7Lds + (wave & 1) * 3072 + lane * 4));
 
+    phase_add(13, c7_since);
     phase_stamp(1);
     // ================= stages D and E: conv8, conv9 (+ MaxPool + BN4) and the inception block (+
     // MaxPool + BN5), the group together, one chain in registers ==================================

@@ -250,9 +250,9 @@ static_assert(258 * kS48 <= kStage, "conv1d_6's image (conv1d_7's input) must st
 
 // stage D (stage_d_chain): weights in four slots of one third each (conv1d_8's thirds in slots
 // 0-2, conv1d_9's in slot 3 and - as conv1d_8 leaves them - slots 0 and 1), halo rows, scratch.
-// Slot 0 is requested while the group's last conv1d_7 runs (it lies in the idle upper half of the
-// activation buffer), slot 1 behind that layer's mid-layer barrier (conv1d_7's N tile 0 lies there).
-constexpr int kDS0 = kStageEnd + conv_weight_floats(14);     // 18,976: behind conv1d_15's weights
+// Slots 0 and 1 are requested while the group's last conv1d_7 runs, before its mid-layer barrier:
+// both lie in the idle part of the activation buffer, between the staging and conv1d_7's weights.
+constexpr int kDS0 = kStageEnd;                              // 15,904
 constexpr int kDS1 = kDS0 + kWinoHalf, kDS2 = kDS1 + kWinoHalf, kDS3 = kDS2 + kWinoHalf;
 // [layer output 0..1][wave][side: 0 = the wave's left halo row, 1 = its right one][48]
 constexpr int kDHaloLayer = 8 * 2 * 48;               // 768
@@ -260,8 +260,13 @@ constexpr int kDHalo = kDS3 + kWinoHalf;                    // 37,408
 constexpr int kDDummy = kDHalo + 2 * kDHaloLayer;           // 38,944 (+ 312: see kChainDummy)
 constexpr int kLdsFloatsD = kDDummy + 312;
 static_assert((kDS0 * 4) % 16 == 0 && kDS0 >= kStageEnd && kDDummy % 2 == 0, "");
-static_assert(kDS0 + kWinoHalf <= kW0, "slot 0 must be clear of conv1d_7's weights");
-static_assert(kDS1 + kWinoHalf <= kSlot1, "slot 1 may only overlap conv1d_7's N tile 0");
+static_assert(kDS1 + kWinoHalf <= kW0, "slots 0 and 1 must be clear of conv1d_7's weights");
+// The same place serves stage B of a group's LATER windows: the first third of conv1d_2's weights
+// (what its tile 0 multiplies by) is requested there under conv1d_7 of the window before - in that
+// layer's first half, when slot 0 itself still holds conv1d_7's own weights.  (Stage B's own use of
+// the region - conv1d_5's and conv1d_6's weights, the halo rows - begins after tile 0.)
+constexpr int kChainP = kStageEnd;
+static_assert(kChainP + kWinoHalf <= kHalo && kChainP >= kStageEnd, "");
 
 // stage E (inception block) runs on the END of stage D's chain, on the same lanes' registers
 // (dbh_forward.hip: stage_d_chain): BN4's output never leaves them.  Its weights - conv10 .. conv15,
@@ -297,7 +302,8 @@ constexpr int cat_offset(int k, int group_n) { return k == group_n - 1 ? kCatLas
 constexpr int kRed = 0;
 constexpr int kRedFloats = 24 * 256;
 static_assert(kRed + kRedFloats <= kCatLast && kCatLast + kCatFloats <= kStage && (kCatLast * 4) % 16 == 0, "");
-static_assert(kCatHigh + (kGroup - 1) * kCatFloats <= kDHalo && (kCatFloats * 4) % 16 == 0, "");
+// (the images are written behind a barrier at the chain's very end: they may lie on anything of its)
+static_assert(kCatHigh + (kGroup - 1) * kCatFloats <= kLdsFloatsAD && (kCatFloats * 4) % 16 == 0, "");
 constexpr int kLdsFloatsE = kDDummy + 312;
 
 // stages G-H (conv18, conv19, conv20, softmax, call) run for up to kTailBatch windows at a time,
@@ -368,7 +374,9 @@ constexpr int kTailWins = kNextWin + 1;
 // (marks 5..8: stage F's inner intervals as wave 0 sees them, summed over the group's windows: to the
 // end of conv17's MFMAs, to behind its barrier, to the end of the reduction, to behind the window's
 // last barrier)
-constexpr int kPhaseMarks = 9, kPhaseGroups = 12;
+// (marks 9..11: stages A-C's inner intervals, summed over the group's windows: a window's top to the
+// start of stage B's chain, the chain, conv1d_7)
+constexpr int kPhaseMarks = 14, kPhaseGroups = 12;      // (12, 13: the group's last conv1d_7; from it to the chain)
 constexpr int kPhase = kTailWins + kTailBatch;
 constexpr int kLdsFloats = kPhase + kPhaseMarks * kPhaseGroups;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS arena exceeds 160 KiB");

@@ -685,7 +685,7 @@ class HipModel:
         """Mean shader cycles of the five phases of a group of windows in this model's latest forward
         launch (see dbh_forward_phases_read): stages A-C, the stage D-E chain, stage F, the batched
         tail, what lies between two groups; and the number of groups averaged."""
-        out = (ctypes.c_double * 9)()
+        out = (ctypes.c_double * 14)()
         n = ctypes.c_int64(0)
         check(self._lib.dbh_forward_phases_read(self._handle, out, ctypes.byref(n)), 'dbh_forward_phases_read')
         return [float(v) for v in out], int(n.value)

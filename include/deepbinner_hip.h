@@ -374,10 +374,12 @@ int dbh_forward_clock_read(dbh_model* model, double* shader_ghz);
  * dbh_forward_phases_read returns the mean cycles of the five intervals (the fifth runs to the next
  * group's start; tail-less groups leave it near zero) over the steady-state groups of the model's
  * latest launch, and how many groups that was.
- * mean_cycles_9[5..8]: stage F's inner intervals as its first wave sees them, summed over the group's
+ * mean_cycles_12[5..8]: stage F's inner intervals as its first wave sees them, summed over the group's
  * windows: to the end of conv1d_17's MFMAs, to behind its barrier, to the end of the reduction, to
- * behind the window's last barrier. */
-int dbh_forward_phases_read(dbh_model* model, double* mean_cycles_9, int64_t* groups);
+ * behind the group's last barrier.  [9..11]: stages A-C's, summed over the group's windows: a window's
+ * top to the start of stage B's chain, the chain, conv1d_7 (of all windows but the group's last);
+ * [12], [13]: the group's last conv1d_7, and from its end to the start of the stage D-E chain. */
+int dbh_forward_phases_read(dbh_model* model, double* mean_cycles_14, int64_t* groups);
 
 #ifdef __cplusplus
 }
