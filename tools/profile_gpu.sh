@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-DEEPBINNER_TIMELINE_FUSED=1 DEEPBINNER_TIMELINE_WAVES=1 python $R/tools/timeline.py 5120 > $OUT/timeline_5120_fused.txt 2>&1
+python $R/tools/timeline6.py 6 > $OUT/timeline6_groups.txt 2>&1
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- \
     python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-rates > $OUT/prof_stats_bench.log 2>&1

@@ -68,7 +68,7 @@ def main():
     stats = os.path.join(SRC, 'prof_stats', 'bench_kernel_stats.csv')
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(dst, 'rocprofv3_kernel_stats.csv'))
-    for name in ('timeline_5120_fused.txt',):
+    for name in ('timeline6_groups.txt',):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     log = os.path.join(SRC, 'prof_stats_bench.log')
