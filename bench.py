@@ -774,10 +774,16 @@ def main():
         run_all(lambda j: j.models[0].timing_enable(False))
         if not args.no_kernel_timing:
             shader_ghz = lead.timing_model.clock_read()      # of the timed region's last launch
-            try:        # the same launch's phases (groups of four windows: dbh_forward_phases_read)
+            try:
+                # the phases of a group of four windows (dbh_forward_phases_read): ONE more launch, behind
+                # the timed region - the stamps cost about 1 % of the kernel's time
+                lead.timing_model.phases_enable(True)
+                step()
+                sync()
                 phase_cycles, phase_groups = lead.timing_model.phases_read()
-            except Exception:
+            except Exception:                                   # noqa: BLE001
                 phase_cycles, phase_groups = None, 0
+            lead.timing_model.phases_enable(False)
             lead.timing_model.clock_enable(False)
     if rdzv is not None:
         elapsed = rdzv.max_float(elapsed)
@@ -882,9 +888,9 @@ def main():
             # every workgroup (s_memtime against the 100 MHz s_memrealtime, median).  In CYCLES -
             # which is what "how busy is the pipe" means - the matrix pipe is this busy:
             'shader_clock_ghz': shader_ghz,
-            # shader cycles per GROUP of four windows and phase, steady-state groups of the timed
-            # region's last launch, measured by the shipped kernel itself (one lane's clock reads
-            # behind barriers): stages A-C of its windows, the stage D-E chain, stage F of its windows,
+            # shader cycles per GROUP of four windows and phase, steady-state groups of one more launch
+            # behind the timed region, measured by the shipped kernel itself (one lane's clock reads
+            # behind barriers; with the stamps on a launch runs ~1 % slower): stages A-C of its windows, the stage D-E chain, stage F of its windows,
             # the batched tail (every second group), between two groups
             'phase_cycles_per_group': (
                 dict(zip(['stages_a_c', 'chain_d_e', 'stage_f', 'tail', 'between', 'f_mfma', 'f_barrier', 'f_reduce', 'f_end_barrier',

@@ -201,6 +201,7 @@ struct dbh_model {
     void* d_tail = nullptr;    size_t tail_bytes = 0;      // the timeline entry points' (null stream)
     void* d_clock = nullptr;   size_t clock_bytes = 0;     // dbh_forward_clock_enable
     bool clock_probe = false;  unsigned clock_grid = 0;
+    bool phase_probe = false;      // dbh_forward_phases_enable
     // staging slots of the host-buffer entry points (classify_host: overlapped H2D / kernels / D2H)
     static constexpr int kSlots = 3;
     static constexpr int64_t kDefaultGroup = 32768;
@@ -367,6 +368,7 @@ int launch_forward(dbh_model* m, const float* x_dev, int64_t n, float* probs_dev
         a.debug_stage = debug_stage;
         a.steps = in.steps;
         a.side = in.side;
+        a.phases = m->phase_probe ? 1 : 0;
         a.chunk4_min_left = m->chunk4_rounds * (int)grid;
         a.chunk2_min_left = m->chunk2_rounds * (int)grid;
         if (debug_stage == 300)
@@ -1617,9 +1619,15 @@ int dbh_forward_clock_read(dbh_model* m, double* shader_ghz) {
     return DBH_OK;
 }
 
+int dbh_forward_phases_enable(dbh_model* m, int enable) {
+    if (!m) return DBH_ERR_INVALID_ARGUMENT;
+    m->phase_probe = enable != 0;
+    return DBH_OK;
+}
+
 int dbh_forward_phases_read(dbh_model* m, double* mean_cycles, int64_t* groups) {
     if (!m || !mean_cycles || !groups) return DBH_ERR_INVALID_ARGUMENT;
-    if (!m->clock_probe || m->clock_grid == 0 || !m->d_clock) return DBH_ERR_INVALID_ARGUMENT;
+    if (!m->clock_probe || !m->phase_probe || m->clock_grid == 0 || !m->d_clock) return DBH_ERR_INVALID_ARGUMENT;
     DBH_HIP(hipSetDevice(m->device));
     DBH_HIP(hipDeviceSynchronize());
     const size_t per_wg = 4 + dbh::kPhaseMarks * dbh::kPhaseGroups;

@@ -2510,8 +2510,12 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
     w43ns_step<TOWN, SP0, !HIGH, 0>(U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1], side);
     mark(ts, ts_base);
     // every wave has read all its input rows, and is through with N tiles 0 and 2 of the weights:
-    // the exchange below may use those rows, side(6..8) those slots
-    lds_barrier();
+    // the exchange below may use those rows, side(6..8) those slots.  The barrier also RETIRES what
+    // side(0..5) asked for (vmcnt(0): this wave has nothing else in flight - its park stores of the
+    // window before were waited for long ago, this window's come behind this barrier - and the
+    // requests are some thousand cycles old): what they bring may be read behind the layer's closing
+    // barrier without another wait.
+    full_barrier();
     mark(ts, ts_base + 1);
     w43ns_step<TOWN, SP0, !HIGH, 6>(
         U, a_addr, b_addr, pipe, own, shared, ep.b[TOWN], ep.b[1], [&](auto tag) {
@@ -2551,8 +2555,8 @@ __device__ __forceinline__ void w43_nsplit_half(float* lds, const float* __restr
     if constexpr (LAST) {
         // (the weights stage D's first tiles read have landed: requested before after()'s twelve
         // loads, and loads return in order; this form has no stores in flight)
-        if (in_flight) lds_barrier<12>();
-        else full_barrier();
+        (void)in_flight;       // (what was asked for before the mid-layer barrier was retired there)
+        lds_barrier();
     } else {
         lds_barrier();
     }
@@ -3045,6 +3049,7 @@ struct ForwardArgs {
     // windows not yet handed out below which a workgroup asks for groups of 2 / of 1 instead of
     // kGroup (the end of a launch: dbh_forward_kernel)
     int chunk4_min_left, chunk2_min_left;
+    int phases;                  // clock probe on: also keep the phase stamps (dbh_forward_phases_enable)
 };
 
 // Window statistics, step 1: exact integer sums of this lane's two samples, sum(x) and sum(x^2)
@@ -3150,7 +3155,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // taken by one lane right behind a barrier (nothing in flight that the counter's read could
     // hold up) and kept in LDS until the workgroup is done: the kernel measured is the kernel that
     // ships.
-    const bool phases_on = args()->clock_out != nullptr;
+    const bool phases_on = args()->clock_out != nullptr && args()->phases != 0;
     int phase_group = 0;
     auto phase_stamp = [&](int mark) {
         if (phases_on && threadIdx.x == 0 && phase_group < kPhaseGroups)
@@ -3425,9 +3430,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         mark(ts, 1);
     }
 
-    // (a group's later windows: conv7 of the window before ended without waiting for its park's
-    // stores or for the weights asked for under it - they had this stage A's time to land)
-    if (k > 0) full_barrier();
+    // (a group's later windows start without a barrier of their own: the first third of conv2's
+    // weights was retired by conv7's mid-layer barrier, the last third - asked for behind it - by
+    // stage B's first arrivals, which tile 1 waits for; the park's stores likewise)
     phase_add(9, ac_since);
     // ---------------- stage B: conv2,3,4 (L=512) + MaxPool + BN2, conv5, conv6 ----------------
     // One chain in registers (stage_b_chain): nine Winograd F(4,3) tiles back to back, no

@@ -153,6 +153,7 @@ def load_library():
         'dbh_forward_timing_read': (c_int, [c_void_p, P(ctypes.c_double), P(c_i64), P(c_i64)]),
         'dbh_forward_clock_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_clock_read': (c_int, [c_void_p, P(ctypes.c_double)]),
+        'dbh_forward_phases_enable': (c_int, [c_void_p, c_int]),
         'dbh_forward_phases_read': (c_int, [c_void_p, P(ctypes.c_double), P(ctypes.c_int64)]),
         'dbh_comm_available': (c_int, []),
         'dbh_comm_last_error': (ctypes.c_char_p, []),
@@ -190,7 +191,7 @@ EXPORTED_SYMBOLS = [
     'dbh_classify_i16_dev', 'dbh_classify_i16_batched_dev', 'dbh_normalise_windows_dev', 'dbh_merge_calls_dev', 'dbh_combine_calls_dev',
     'dbh_stage_floats', 'dbh_debug_forward', 'dbh_forward_kernel_info',
     'dbh_forward_truncated_dev', 'dbh_forward_executed_mfmas', 'dbh_forward_timeline', 'dbh_forward_timeline_i16', 'dbh_forward_timing_enable', 'dbh_forward_timing_enable_span',
-    'dbh_forward_timing_read', 'dbh_forward_clock_enable', 'dbh_forward_clock_read', 'dbh_forward_phases_read',
+    'dbh_forward_timing_read', 'dbh_forward_clock_enable', 'dbh_forward_clock_read', 'dbh_forward_phases_enable', 'dbh_forward_phases_read',
     'dbh_comm_available', 'dbh_comm_last_error', 'dbh_comm_init_all', 'dbh_comm_unique_id',
     'dbh_comm_init_rank', 'dbh_comm_info', 'dbh_comm_all_gather_i32', 'dbh_comm_destroy',
 ]
@@ -680,6 +681,11 @@ class HipModel:
         clock (see dbh_forward_clock_enable)."""
         check(self._lib.dbh_forward_clock_enable(self._handle, 1 if on else 0),
               'dbh_forward_clock_enable')
+
+    def phases_enable(self, on=True):
+        """Have production launches keep the phase stamps as well (on top of clock_enable): about 1 % of
+        the kernel's time, so not for timed runs."""
+        check(self._lib.dbh_forward_phases_enable(self._handle, 1 if on else 0), 'dbh_forward_phases_enable')
 
     def phases_read(self):
         """Mean shader cycles of the five phases of a group of windows in this model's latest forward

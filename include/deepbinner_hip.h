@@ -366,19 +366,22 @@ int dbh_forward_timing_read(dbh_model* model, double* total_ms, int64_t* launche
  * latest launch as a frequency in GHz. */
 int dbh_forward_clock_enable(dbh_model* model, int enable);
 int dbh_forward_clock_read(dbh_model* model, double* shader_ghz);
-/* With the probe on the forward kernel also keeps, in LDS, the shader clock at five points of each
- * of a workgroup's first 24 groups of windows (it takes its windows four at a time): the group's
+/* Phase stamps, asked for on top of the clock probe (dbh_forward_phases_enable; each stamp is a
+ * counter read and an LDS word by one lane - ~25 per group, about 1 % of the kernel's time, so they are
+ * not part of a timed run): the forward kernel keeps, in LDS, the shader clock at five points of each
+ * of a workgroup's first 12 groups of windows (it takes its windows four at a time): the group's
  * start, the end of its stage A-C loop (conv1d_1 .. conv1d_7 of each window), of the stage D-E chain
  * (conv1d_8 .. conv1d_16 of the four together), of its stage F loop (conv1d_17 of each window) and of
  * the batched tail - one lane, right behind a barrier: the kernel measured is the kernel that ships.
  * dbh_forward_phases_read returns the mean cycles of the five intervals (the fifth runs to the next
  * group's start; tail-less groups leave it near zero) over the steady-state groups of the model's
  * latest launch, and how many groups that was.
- * mean_cycles_12[5..8]: stage F's inner intervals as its first wave sees them, summed over the group's
+ * mean_cycles_14[5..8]: stage F's inner intervals as its first wave sees them, summed over the group's
  * windows: to the end of conv1d_17's MFMAs, to behind its barrier, to the end of the reduction, to
  * behind the group's last barrier.  [9..11]: stages A-C's, summed over the group's windows: a window's
  * top to the start of stage B's chain, the chain, conv1d_7 (of all windows but the group's last);
  * [12], [13]: the group's last conv1d_7, and from its end to the start of the stage D-E chain. */
+int dbh_forward_phases_enable(dbh_model* model, int enable);
 int dbh_forward_phases_read(dbh_model* model, double* mean_cycles_14, int64_t* groups);
 
 #ifdef __cplusplus
