@@ -14,6 +14,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
+#include <sys/uio.h>
 #include <linux/fs.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -430,6 +431,77 @@ class Fast5 {
             }
         } else {
             std::memcpy(dst, buf_ + off, (size_t)n);
+        }
+    }
+
+    // MANY byte ranges of the file at once (the stored Signal pieces of a stretch of a multi-read
+    // container, f5_stream's raw batches): sorted by their place in the file, neighbours with small
+    // gaps between them - the object headers and B-tree nodes between two reads' chunks - are read
+    // by ONE preadv (the gaps go to a sink), up to kMaxIov ranges a call, where a pread per range
+    // was a system call per read (half of the raw loader's time).  Ranges are checked against the
+    // file's length first; failed[k] = 1 for every range that could not be read.
+    struct IoItem {
+        uint64_t off, n;
+        uint8_t* dst;
+        int64_t tag;                 // (the caller's: which read it belongs to)
+    };
+    void read_many(std::vector<IoItem>& items, std::vector<char>* failed) const {
+        failed->assign(items.size(), 0);
+        std::vector<size_t> order;
+        order.reserve(items.size());
+        for (size_t k = 0; k < items.size(); ++k) {
+            const IoItem& it = items[k];
+            if (it.off > len_ || it.n > len_ - it.off) (*failed)[k] = 1;
+            else if (it.n > 0) order.push_back(k);
+        }
+        if (!(mapped_ && fd_ >= 0)) {
+            for (size_t k : order) std::memcpy(items[k].dst, buf_ + items[k].off, (size_t)items[k].n);
+            return;
+        }
+        std::sort(order.begin(), order.end(),
+                  [&](size_t x, size_t y) { return items[x].off < items[y].off; });
+        constexpr uint64_t kMaxGap = 32u << 10;
+        constexpr size_t kMaxIov = 512;
+        thread_local std::vector<uint8_t> sink(kMaxGap);
+        thread_local std::vector<struct iovec> iov;
+        auto one_by_one = [&](size_t a, size_t b) {
+            for (size_t j = a; j < b; ++j) {
+                const IoItem& it = items[order[j]];
+                uint64_t got = 0;
+                while (got < it.n) {
+                    const ssize_t k = ::pread(fd_, it.dst + got, (size_t)(it.n - got), (off_t)(it.off + got));
+                    if (k <= 0) {
+                        (*failed)[order[j]] = 1;
+                        break;
+                    }
+                    got += (uint64_t)k;
+                }
+            }
+        };
+        size_t a = 0;
+        while (a < order.size()) {
+            iov.clear();
+            size_t b = a;
+            uint64_t pos = items[order[a]].off;
+            while (b < order.size() && iov.size() + 2 <= kMaxIov) {
+                const IoItem& it = items[order[b]];
+                if (it.off < pos) break;                      // (overlapping ranges: on their own)
+                const uint64_t gap = it.off - pos;
+                if (b > a && gap > kMaxGap) break;
+                if (gap > 0) iov.push_back({sink.data(), (size_t)gap});
+                iov.push_back({it.dst, (size_t)it.n});
+                pos = it.off + it.n;
+                ++b;
+            }
+            if (b == a) {                                      // (an overlap at the run's start)
+                one_by_one(a, a + 1);
+                a += 1;
+                continue;
+            }
+            const uint64_t total = pos - items[order[a]].off;
+            const ssize_t k = b - a > 1 ? ::preadv(fd_, iov.data(), (int)iov.size(), (off_t)items[order[a]].off) : -1;
+            if (k < 0 || (uint64_t)k != total) one_by_one(a, b);       // (short or failed: range by range)
+            a = b;
         }
     }
 
@@ -2625,6 +2697,7 @@ struct f5_stream {
         f5_batch* batch = nullptr;
         std::vector<int64_t> lengths;
         std::vector<std::vector<Fast5::RawPiece>> pieces;      // raw mode: per read
+        std::vector<int64_t> fetch_order;   // raw mode: the reads by where their Signal lies in the file
         std::chrono::steady_clock::time_point stamp[5];        // DEEPBINNER_FAST5_TIMING
         ~Container() { delete batch; }
     };
@@ -2647,7 +2720,7 @@ struct f5_stream {
     bool stop = false;
     std::vector<std::thread> workers;
 
-    static constexpr int64_t kInflateGrain = 8, kResolveGrain = 64;
+    static constexpr int64_t kInflateGrain = 8, kResolveGrain = 64, kFetchGrain = 256;
 
     ~f5_stream() {
         {
@@ -2671,7 +2744,7 @@ struct f5_stream {
         for (auto& up : inflight) {
             Container* c = up.get();
             if ((c->phase == kInflate || c->phase == kResolve) && c->next < c->count) {
-                const int64_t grain = c->phase == kInflate ? kInflateGrain : kResolveGrain;
+                const int64_t grain = c->phase != kInflate ? kResolveGrain : raw ? kFetchGrain : kInflateGrain;
                 t->c = c;
                 t->phase = c->phase;
                 t->a = c->next;
@@ -2825,6 +2898,23 @@ struct f5_stream {
                                  return wx > wy;
                              });
             c->batch->comp_bytes = at;
+            // the fetch pass walks the reads in FILE order (groups are listed by name - random
+            // read ids - but written one after the other): neighbours in a task are neighbours in
+            // the file, and Fast5::read_many reads them together
+            c->fetch_order.resize((size_t)c->count);
+            for (int64_t i = 0; i < c->count; ++i) c->fetch_order[(size_t)i] = i;
+            {
+                std::vector<uint64_t> where((size_t)c->count, ~0ull);
+                for (int64_t i = 0; i < c->count; ++i)
+                    if (c->batch->status[(size_t)i] == F5_OK)
+                        for (const Fast5::RawPiece& p : c->pieces[(size_t)i])
+                            if (p.kind == Fast5::kZlib || p.kind == Fast5::kStored) {
+                                where[(size_t)i] = p.file_off;
+                                break;
+                            }
+                std::sort(c->fetch_order.begin(), c->fetch_order.end(),
+                          [&](int64_t x, int64_t y) { return where[(size_t)x] < where[(size_t)y]; });
+            }
             // (the decoder fetches ahead of itself: 64 readable bytes behind the last stream)
             c->batch->comp.resize((size_t)(at + 64 + 1) / 2);
             std::memset(reinterpret_cast<uint8_t*>(c->batch->comp.data()) + at, 0, 64);
@@ -2833,33 +2923,46 @@ struct f5_stream {
         }
     }
 
-    // raw mode's pass 2: the pieces of reads [a, b) into the byte buffer
+    // raw mode's pass 2: the pieces of the reads at places [a, b) of the container's fetch order
+    // into the byte buffer - the stored ones together (Fast5::read_many), then what the host decodes
     void fetch(Container* c, int64_t a, int64_t b) {
         thread_local ChunkCache cache;
+        thread_local std::vector<Fast5::IoItem> items;
+        thread_local std::vector<char> failed;
         uint8_t* comp = reinterpret_cast<uint8_t*>(c->batch->comp.data());
-        for (int64_t i = a; i < b; ++i) {
+        auto fail = [&](int64_t i, int rc) {
+            // what could not be fetched or decoded reads as nothing: a stored stream of no
+            // bytes is zero-extended by the decoder; the read is marked
+            for (f5_raw_stream& rec : c->batch->streams)
+                if (rec.reserved == (int32_t)i) {
+                    rec.mode = F5_RAW_STORED;
+                    rec.comp_bytes = 0;
+                }
+            std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
+            c->batch->status[(size_t)i] = rc;
+        };
+        items.clear();
+        for (int64_t k = a; k < b; ++k) {
+            const int64_t i = c->fetch_order[(size_t)k];
+            if (c->batch->status[(size_t)i] != F5_OK) continue;
+            for (const Fast5::RawPiece& p : c->pieces[(size_t)i])
+                if (p.kind == Fast5::kZlib || p.kind == Fast5::kStored)
+                    items.push_back({p.file_off, (uint64_t)p.comp_bytes, comp + p.comp_offset, i});
+        }
+        const int rc_all = guarded([&] { c->file->read_many(items, &failed); });
+        for (size_t k = 0; k < items.size(); ++k)
+            if ((rc_all != F5_OK || failed[k]) && c->batch->status[(size_t)items[k].tag] == F5_OK)
+                fail(items[k].tag, rc_all != F5_OK ? rc_all : F5_ERR_FORMAT);
+        for (int64_t k = a; k < b; ++k) {
+            const int64_t i = c->fetch_order[(size_t)k];
             if (c->batch->status[(size_t)i] != F5_OK) continue;
             const int rc = guarded([&] {
                 const ReadEntry& r = c->file->read(i);
-                for (const Fast5::RawPiece& p : c->pieces[(size_t)i]) {
-                    uint8_t* dst = comp + p.comp_offset;
-                    if (p.kind == Fast5::kZlib || p.kind == Fast5::kStored)
-                        c->file->read_bytes(p.file_off, (uint64_t)p.comp_bytes, dst);
-                    else if (p.kind == Fast5::kHostDecode)
-                        c->file->decode_piece(r.signal, p, dst, &cache);
-                }
+                for (const Fast5::RawPiece& p : c->pieces[(size_t)i])
+                    if (p.kind == Fast5::kHostDecode)
+                        c->file->decode_piece(r.signal, p, comp + p.comp_offset, &cache);
             });
-            if (rc != F5_OK) {
-                // what could not be fetched or decoded reads as nothing: a stored stream of no
-                // bytes is zero-extended by the decoder; the read is marked
-                for (f5_raw_stream& rec : c->batch->streams)
-                    if (rec.reserved == (int32_t)i) {
-                        rec.mode = F5_RAW_STORED;
-                        rec.comp_bytes = 0;
-                    }
-                std::memset(&c->batch->read_ids[(size_t)i * F5_READ_ID_MAX], 0, F5_READ_ID_MAX);
-            }
-            c->batch->status[(size_t)i] = rc;
+            if (rc != F5_OK) fail(i, rc);
         }
     }
 

@@ -333,6 +333,62 @@ def test_stream_of_containers(tmp_path):
     stream.close()
 
 
+def decode_raw_batch(offsets, comp, records):
+    """What a decoder makes of a raw batch: every piece inflated (or copied) to its place."""
+    import zlib
+    out = np.zeros(int(offsets[-1]) * 2, dtype=np.uint8)
+    for r in records:
+        data = bytes(comp[int(r['comp_offset']):int(r['comp_offset']) + int(r['comp_bytes'])])
+        if r['mode'] == fast5_native.RAW_ZLIB:
+            data = zlib.decompress(data)
+        want = int(r['out_bytes'])
+        assert len(data) >= want
+        out[int(r['out_offset']):int(r['out_offset']) + want] = np.frombuffer(data, np.uint8, want)
+    return out.view('<i2')
+
+
+def test_raw_stream_of_containers(tmp_path):
+    """f5_stream_open_raw: the Signal as stored, fetched in file order by runs of neighbouring
+    chunks (Fast5::read_many) - decoded on the spot with zlib it is what f5_load_reads gives, for
+    every team size, window depth and host-inflate policy, with unreadable files among the
+    containers and the same container many times over; the pieces of a batch cover every good
+    read's range exactly once, longest deflate stream first."""
+    bad = tmp_path / 'not_hdf5.fast5'
+    bad.write_bytes(b'nothing of the kind' * 100)
+    paths = (multi_files() + [str(bad)] + single_files()[:1] + [str(tmp_path / 'missing.fast5')] +
+             multi_files()[::-1] * 2)
+    want = {}
+    for p in set(paths):
+        try:
+            want[p] = fast5_native.load_reads(p, threads=1)
+        except OSError:
+            want[p] = None
+    for threads, depth, host_above in ((1, 1, 0), (4, 3, 0), (16, 8, 4096), (3, 2, -50), (2, 2, 1)):
+        seen = []
+        for index, ids, offsets, status, comp, records in fast5_native.stream_raw(
+                paths, threads=threads, depth=depth, host_inflate_above=host_above):
+            seen.append(index)
+            w = want[paths[index]]
+            if w is None:
+                assert ids is None and status != 0
+                continue
+            w_ids, w_samples, w_offsets, w_status = w
+            assert ids == w_ids and np.array_equal(offsets, w_offsets)
+            assert np.array_equal(status, w_status)
+            assert np.array_equal(decode_raw_batch(offsets, comp, records), w_samples)
+            covered = np.zeros(len(ids), dtype=np.int64)
+            np.add.at(covered, records['read'], records['out_bytes'])
+            good = np.asarray(status) == 0
+            assert np.array_equal(covered[good], 2 * np.diff(offsets)[good])
+            z = records[records['mode'] == fast5_native.RAW_ZLIB]['comp_bytes']
+            assert (np.diff(z) <= 0).all()
+            if host_above > 0:
+                assert (z <= host_above).all()
+            assert int((records['comp_offset'] + records['comp_bytes']).max(initial=0)) <= len(comp)
+        assert seen == list(range(len(paths)))
+    assert list(fast5_native.stream_raw([])) == []
+
+
 def test_sample_buffers_are_recycled_and_can_come_from_the_caller():
     """The packed samples of a batch come from a pool of recycled buffers, or from an allocator
     the caller installs (pinned host memory on a GPU box; here: counted malloc)."""
@@ -491,6 +547,14 @@ def test_mutated_files_never_crash_and_agree_with_python_reader(tmp_path):
             fast5_native.load_reads(path, keep=1000, threads=3)
         except OSError:
             pass
+        # ... nor the raw stream (coalesced fetch over whatever addresses the damage left): its
+        # pieces stay inside the buffers it hands over
+        for _, ids, offsets, status, comp, records in fast5_native.stream_raw([path], threads=2):
+            if ids is None:
+                continue
+            assert (records['comp_offset'] >= 0).all() and (records['out_offset'] >= 0).all()
+            assert int((records['comp_offset'] + records['comp_bytes']).max(initial=0)) <= len(comp)
+            assert int((records['out_offset'] + records['out_bytes']).max(initial=0)) <= 2 * int(offsets[-1])
         if want is None or not want:
             # the native reader may still have salvaged reads the generator gave up on midway;
             # what matters here is that it returned at all
