@@ -1824,10 +1824,12 @@ __device__ __forceinline__ void d_load_y(f2 (&Y)[3][2][4], Ptr src) {
 // others' into their parks in global memory (LDS-DMA brings each in while the window before it
 // runs its stage E2 / E3 / F).
 // =============================================================================================
+template <class Ahead>
 __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restrict__ packed,
                                               float* __restrict__ wg_scratch, int lane, int wave,
                                               unsigned* ts, unsigned& d_groups, f2 (&Y)[3][2][4],
-                                              float* dump3, bool stop3, int cat_base) {
+                                              float* dump3, bool stop3, int cat_base,
+                                              const Ahead& ahead) {
     const int n = lane & 15, q = lane >> 4;
     const int k = wave >> 1, hf = wave & 1;
     const unsigned tiles0 = d_groups * 8u, halos0 = d_groups * 7u;
@@ -2041,6 +2043,7 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
     chain_arrive(arrive_addr, 5);
     mark(ts, 32);
     if (stop3) {        // debug_stage 3 / 103: stage D only
+        ahead();
         full_barrier();
         return;
     }
@@ -2284,6 +2287,12 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                 U3[t][c] = Y16[t][0][c] - row_from_right(hr[c], Y16[t][0][c]);
             }
         }
+        // the caller's requests for stage F (conv17's fragments, the next group's offsets): this
+        // wave has nothing in flight and waits for nothing of global memory before the closing
+        // barrier, which retires them
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(U0[t]), "+v"(U1[t]), "+v"(U2[t]), "+v"(U3[t]));
+        ahead();
     #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const f4 b = tab4[(bias_offset(15) - TB) / 4 + 4 * t];
@@ -2331,7 +2340,9 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
                 *reinterpret_cast<__attribute__((address_space(3))) f4*>(cat + 48 * br + 16 * t) = OUT[br][t];
         if (lane < 49) {
             f4* row = reinterpret_cast<f4*>(lds + cat_base + (hf ? 33 * kS192 : 0));
-            row[lane] = f4{0.f, 0.f, 0.f, 0.f};
+            float zero = 0.f;
+            asm volatile("" : "+v"(zero));      // (made here: hoisted out of the persistent loop, four registers of zeros were spilled)
+            row[lane] = f4{zero, zero, zero, zero};
         }
     }
     // the images are out (and what stage F's first window needs of global memory has landed)
@@ -2957,7 +2968,15 @@ __device__ __forceinline__ void renormalise_and_call(float merged, int c, int n_
     const double rest =
         reduce32(RedF64{(valid && c > 0) ? p : 0.0},
                  [](const RedF64& a, const RedF64& b) { return RedF64{a.v + b.v}; }).v;
-    const double p0 = __shfl(p, 0, 32);
+    // (class 0 of this lane's half; the source lane made here: as a loop invariant its byte address
+    // was kept in a register around the whole persistent loop - and spilled)
+    int half_first;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(half_first));
+    half_first = (half_first & 32) << 2;
+    const long long p_bits = __builtin_bit_cast(long long, p);
+    const unsigned p0_lo = (unsigned)__builtin_amdgcn_ds_bpermute(half_first, (int)(unsigned)p_bits);
+    const unsigned p0_hi = (unsigned)__builtin_amdgcn_ds_bpermute(half_first, (int)(p_bits >> 32));
+    const double p0 = __builtin_bit_cast(double, ((long long)p0_hi << 32) | (long long)p0_lo);
     const double factor = (1.0 - p0) / rest;
     if (c > 0) p = p * factor;
     if (valid) probs_row[c] = (float)p;
@@ -3545,7 +3564,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // Stage D's operands of the group's EARLIER windows start their trip from the parks behind this
     // layer's last MFMAs (waves 2k, 2k + 1 own window k there; twelve 16-byte loads per lane into
     // registers conv7 has finished with; in front of the layer's exchange, last epilogue and
-    // closing barrier, which does not wait for them) - the parks are MALL / HBM resident (176 KB per
+    // closing barrier, which does not wait for them) - the parks are MALL / HBM resident (120 KB per
     // workgroup: more than the L2 holds), a round trip of thousands of cycles.  The last window's own output goes to
     // LDS (w43_nsplit_half<LAST>) and is read back behind the layer's closing barrier.  conv8's
     // thirds 0 and 1 -> stage D's slots 0 and 1 (the idle part of the activation buffer) in the
@@ -3604,12 +3623,62 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     phase_stamp(1);
     // ================= stages D and E: conv8, conv9 (+ MaxPool + BN4) and the inception block (+
     // MaxPool + BN5), the group together, one chain in registers ==================================
+    // What stage F needs of global memory is asked for INSIDE the chain, in front of conv1d_16's
+    // MFMAs (the chain's closing barrier retires it): conv1d_17's fragments - this wave's EIGHTH of
+    // the contraction, three groups of eight channels x three taps x three N tiles = 27 fragment
+    // pairs, buffer loads the compiler does not see (scalar base and fragment offset, the lane's
+    // eight bytes) - and the two offsets of each of the next group's windows (VECTOR loads - the
+    // address made per-lane on purpose: as scalar loads they would count against lgkmcnt, which the
+    // compiler's LDS waits watch).  The 110 KB of fragments cross the CU's vector memory path once
+    // per group (64 B a cycle: 1.7 k cycles, under conv1d_16) instead of twice in front of stage F's
+    // MFMAs, with every matrix pipe idle (waves 0-3 and 4-7 each fetched all of it for two windows).
+    f2 w17[27];
+    long long noff0[kGroup], noff1[kGroup];
+    int nstep[kGroup];
+    // bias and BN6 of the output quadruples this lane finishes (tid and, for tid < 256, 512 + tid of
+    // the group's 768: quadruple e = window e / 192, N tile (e % 192) / 64, lane (e % 64))
+    EpiParams<1, true> ep17[2];
+    auto fetch_f = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = (r * kThreads + tid) % 192, ch = (e >> 6) * 16 + (e & 15);
+            ep17[r].load(packed + bias_offset(16) + ch, packed + bn_scale_offset(5) + ch, packed + bn_shift_offset(5) + ch);
+        }
+        const __amdgpu_buffer_rsrc_t view = buffer_view(packed + weight_offset(16));
+        const unsigned lane_bytes = (unsigned)lane * 8u;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned soff = (unsigned)(((tap * 24 + wave * 3 + sp) * 3 + t) * 128) * 4u;
+                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
+                                 : "=v"(w17[(tap * 3 + sp) * 3 + t])
+                                 : "v"(lane_bytes), "s"(view), "s"(soff)
+                                 : "memory");
+                }
+#pragma unroll
+        for (int w = 0; w < kGroup; ++w) {
+            noff0[w] = 0;
+            noff1[w] = 0;
+            nstep[w] = 0;
+            if (seam_b2 && w < next_n) {
+                unsigned next_read;
+                split_window((unsigned)(next_start + w), steps_arg, &next_read, &nstep[w]);
+                unsigned lane_zero = 0;
+                asm volatile("" : "+v"(lane_zero));
+                noff0[w] = offsets_arg[next_read + lane_zero];
+                noff1[w] = offsets_arg[next_read + lane_zero + 1];
+            }
+        }
+    };
     {
         float* dump3 = nullptr;
         if (debug_stage == 3 && (wave >> 1) < group_n)
             dump3 = glob(args()->debug_out) + (long)(group_start + (wave >> 1)) * kStageFloats[3];
         stage_d_chain(lds, packed, wg_scratch, lane, wave, ts, d_groups, Y, dump3, stop_stage == 3,
-                      (wave >> 1) < group_n ? cat_offset(wave >> 1, group_n) : -1);
+                      (wave >> 1) < group_n ? cat_offset(wave >> 1, group_n) : -1, fetch_f);
     }
     if (stop_stage == 4) {
         if (debug_stage < 100)
@@ -3621,80 +3690,32 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // ================= stage F: conv17 (192->48, k3, stride 2) + ReLU + BN6 -> 16 x 48, the group
     // together ====================================================================================
     // The four concat images wait in LDS; conv17's weights (110 KB, each used once per window) skip
-    // LDS: waves 0-3 take windows 0 and 1, waves 4-7 windows 2 and 3, each wave a QUARTER of the
-    // contraction (six groups of eight channels x three taps x three N tiles = 54 fragment pairs in
-    // registers, fetched from L2 once per group and used for both its windows): 216 MFMAs per wave in
-    // one run, six independent accumulator chains.  Then ONE reduction for the group - 48 partial
-    // tiles through LDS, every lane finishing one or two of the 768 output quadruples - where the
-    // window-by-window form paid two barriers, a pipeline fill and a three-wave reduction per
-    // window (8.3 k cycles per window for 3.5 k of matrix work: profiles/r06_*).  conv17's output
-    // (3 KB per window) goes to the workgroup's slots in global memory for the batched tail below.
+    // LDS: every wave takes an EIGHTH of the contraction (three groups of eight channels x three taps
+    // x three N tiles = 27 fragment pairs in registers, fetched from L2 once per group - inside the
+    // chain, above) for all four windows: 216 MFMAs per wave in one run, twelve independent
+    // accumulator chains.  Then ONE reduction for the group - 96 partial tiles through LDS, every
+    // lane finishing one or two of the 768 output quadruples - where the window-by-window form paid
+    // two barriers, a pipeline fill and a three-wave reduction per window (8.3 k cycles per window
+    // for 3.5 k of matrix work: profiles/r06_*).  conv17's output (3 KB per window) goes to the
+    // workgroup's slots in global memory for the batched tail below.
     //   The NEXT group's samples (seam b2) are fetched meanwhile: the places of its windows in the
-    // sample buffer (offsets) are asked for at the top and looked at behind the first barrier,
-    // where the samples themselves are asked for; their exact sums ride on the last barrier, and
-    // waves 5-7 turn those of windows 1-3 into mean and 1/std while the samples go to the LDS
-    // staging; window 0 stays in registers for that group's stage A (whose first barrier carries
-    // its sums).
+    // sample buffer (offsets) came with the fragments; the samples themselves are asked for in front
+    // of the MFMAs; their exact sums ride on the last barrier, and waves 5-7 turn those of windows
+    // 1-3 into mean and 1/std while the samples go to the LDS staging; window 0 stays in registers
+    // for that group's stage A (whose first barrier carries its sums).
     phase_stamp(2);
     const bool batch_ends = tail_every_group || tail_slot + group_n + next_n > kTailBatch || next_n == 0;
     const bool slot0_next = seam_b2 && next_n > 0;       // the next group's first window: conv2's weights
     const bool thirds_now = slot0_next && !batch_ends;
     const bool run_tail = batch_ends;
     const bool thirds_next = thirds_now;
-    const int pair_w = wave >> 2, kq = wave & 3;
     const int n = lane & 15, q = lane >> 4;
-    // (1) the two offsets of each of the next group's windows (VECTOR loads - the address made
-    // per-lane on purpose: as scalar loads they would count against lgkmcnt, which the compiler's
-    // LDS waits below watch)
-    long long noff0[kGroup], noff1[kGroup];
-    int nstep[kGroup];
-#pragma unroll
-    for (int w = 0; w < kGroup; ++w) {
-        noff0[w] = 0;
-        noff1[w] = 0;
-        nstep[w] = 0;
-        if (seam_b2 && w < next_n) {
-            unsigned next_read;
-            split_window((unsigned)(next_start + w), steps_arg, &next_read, &nstep[w]);
-            unsigned lane_zero = 0;
-            asm volatile("" : "+v"(lane_zero));
-            noff0[w] = offsets_arg[next_read + lane_zero];
-            noff1[w] = offsets_arg[next_read + lane_zero + 1];
-        }
-    }
-    // (2) conv17's fragments: buffer loads the compiler does not see (scalar base and fragment
-    // offset, the lane's eight bytes), waited for by hand below
-    f2 w17[54];
-    {
-        const __amdgpu_buffer_rsrc_t view = buffer_view(packed + weight_offset(16));
-        const unsigned lane_bytes = (unsigned)lane * 8u;
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-            for (int sp = 0; sp < 6; ++sp)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const unsigned soff = (unsigned)(((tap * 24 + kq * 6 + sp) * 3 + t) * 128) * 4u;
-                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
-                                 : "=v"(w17[(tap * 6 + sp) * 3 + t])
-                                 : "v"(lane_bytes), "s"(view), "s"(soff)
-                                 : "memory");
-                }
-    }
-    // bias and BN6 of the output quadruples this lane finishes (tid and, for tid < 256, 512 + tid of
-    // the group's 768: quadruple e = window e / 192, N tile (e % 192) / 64, lane (e % 64))
-    EpiParams<1, true> ep17[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int e = (r * kThreads + tid) % 192, ch = (e >> 6) * 16 + (e & 15);
-        ep17[r].load(packed + bias_offset(16) + ch, packed + bn_scale_offset(5) + ch, packed + bn_shift_offset(5) + ch);
-    }
     if (tid < group_n) reinterpret_cast<int*>(lds + kTailWins)[tail_slot + tid] = group_start + tid;
     flush_marks(ts, ts_out, lane);
     unsigned f_since = phases_on ? (unsigned)__builtin_readcyclecounter() : 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the fragments and the offsets are in
 #pragma unroll
-    for (int k17 = 0; k17 < 54; ++k17) asm volatile("" : "+v"(w17[k17]));
+    for (int k17 = 0; k17 < 27; ++k17) asm volatile("" : "+v"(w17[k17]));
 #pragma unroll
     for (int w = 0; w < kGroup; ++w) asm volatile("" : "+v"(noff0[w]), "+v"(noff1[w]));
     // (3) the next group's samples: this lane's two of each window - asked for here, behind the wait
@@ -3726,53 +3747,50 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     {
         // stride-2 'same' pads on the right only: output position n reads rows 2n, 2n + 1, 2n + 2 of
         // the image's rows 1 .. 32 (+ the zero row 33)
-        const float* a_lane[2];
+        const float* a_lane[kGroup];
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-            const int win_k = pair_w * 2 + w2;
-            a_lane[w2] = lds + cat_offset(win_k < group_n ? win_k : 0, group_n) + (1 + 2 * n) * kS192 + 2 * q + kq * 48;
-        }
-        f4 acc[2][3];
+        for (int w4 = 0; w4 < kGroup; ++w4)
+            a_lane[w4] = lds + cat_offset(w4 < group_n ? w4 : 0, group_n) + (1 + 2 * n) * kS192 + 2 * q + wave * 24;
+        f4 acc[kGroup][3];
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2)
+        for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[w2][t] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 3; ++t) acc[w4][t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
-            f2 a[2][6];
+            f2 a[kGroup][3];
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2)
+            for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
-                for (int sp = 0; sp < 6; ++sp)
-                    a[w2][sp] = *reinterpret_cast<const f2*>(a_lane[w2] + tap * kS192 + sp * 8);
+                for (int sp = 0; sp < 3; ++sp)
+                    a[w4][sp] = *reinterpret_cast<const f2*>(a_lane[w4] + tap * kS192 + sp * 8);
 #pragma unroll
-            for (int sp = 0; sp < 6; ++sp)
+            for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int w2 = 0; w2 < 2; ++w2)
+                    for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
                         for (int t = 0; t < 3; ++t)
-                            acc[w2][t] = mfma4(a[w2][sp][e], w17[(tap * 6 + sp) * 3 + t][e], acc[w2][t]);
+                            acc[w4][t] = mfma4(a[w4][sp][e], w17[(tap * 3 + sp) * 3 + t][e], acc[w4][t]);
             __builtin_amdgcn_sched_barrier(0);
         }
         phase_add(5, f_since);
         mark(ts, 41);
         lds_barrier();         // every wave has read the images: the partial tiles go over them
         phase_add(6, f_since);
-        // the next window's conv2 weights: slot 0 (tile 0 multiplies right behind that window's
-        // first barrier, which retires these requests) and - unless the batched tail, whose buffers
-        // lie there, runs in between - slots 1 and 2: 54 pieces, seven per wave; the images that lay
-        // there are dead
-        if (slot0_next) {
-            if (thirds_now) dma_weights<3 * kWinoHalf, kWaves>(packed + weight_offset(1), lds + kSlot0, lane, wave);
-            else dma_weights<kWinoHalf, kWaves>(packed + weight_offset(1), lds + kSlot0, lane, wave);
-        }
+        // the next window's first conv2 weights: slot 0 (tile 0 multiplies right behind that window's
+        // first barrier, which retires these requests); the images that lay there are dead
+        if (slot0_next) dma_weights<kWinoHalf, kWaves>(packed + weight_offset(1), lds + kSlot0, lane, wave);
+        // tile (wave, window, N tile): 32 to a run (dbh_layout.h: red_tile_offset)
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2)
+        for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                *reinterpret_cast<f4*>(lds + kRed + (((pair_w * 2 + w2) * 4 + kq) * 3 + t) * 256 + lane * 4) = acc[w2][t];
+            for (int t = 0; t < 3; ++t) {
+                const int tile = wave * 12 + w4 * 3 + t;
+                const int off = (tile < 32 ? kRed : tile < 64 ? kRedB - kRedRun : kRedC - 2 * kRedRun) + tile * 256;
+                *reinterpret_cast<f4*>(lds + off + lane * 4) = acc[w4][t];
+            }
     }
     mark(ts, 42);
     lds_barrier();             // the partial tiles are out
@@ -3783,11 +3801,15 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         const int e = r * kThreads + tid;
         const int win_k = e / 192, rest = e - win_k * 192, t = rest >> 6, l2 = rest & 63;
         if (e < kGroup * 192 && win_k < group_n) {
-            const float* p = lds + kRed + ((win_k * 4) * 3 + t) * 256 + l2 * 4;
-            const f4 p0 = *reinterpret_cast<const f4*>(p), p1 = *reinterpret_cast<const f4*>(p + 3 * 256);
-            const f4 p2 = *reinterpret_cast<const f4*>(p + 6 * 256), p3 = *reinterpret_cast<const f4*>(p + 9 * 256);
+            f4 part[8];
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+                const int tile = w8 * 12 + win_k * 3 + t;
+                const int off = (tile < 32 ? kRed : tile < 64 ? kRedB - kRedRun : kRedC - 2 * kRedRun) + tile * 256;
+                part[w8] = *reinterpret_cast<const f4*>(lds + off + l2 * 4);
+            }
             f4 sum[1][1];
-            sum[0][0] = (p0 + p1) + (p2 + p3);
+            sum[0][0] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
             float* slot = wg_scratch + kWgTailOff + (tail_slot + win_k) * kTailSlotFloats;
             epilogue<1, 1, 48, false, true>(sum, slot + 4 * (l2 >> 4) * 48 + t * 16 + (l2 & 15), ep17[r]);
         }
@@ -3809,6 +3831,9 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     // are read - and used behind two barriers
     tail_slot += group_n;
     lds_barrier();
+    // conv2's other two thirds for the next window (slots 1 and 2: the partial tiles that lay there
+    // are summed) - unless the batched tail, whose buffers lie there, runs in between
+    if (thirds_now) dma_weights<2 * kWinoHalf, kWaves>(packed + weight_offset(1) + kWinoHalf, lds + kSlot1, lane, wave);
     if (batch_ends) {
         dma_weights<conv_weight_floats(17)>(packed + weight_offset(17), lds + kTW18, lane, wave);
         dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);

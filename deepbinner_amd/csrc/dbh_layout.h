@@ -298,10 +298,19 @@ constexpr int kCatFloats = 34 * kS192;                     // 6,664
 constexpr int kCatLast = kStage - kCatFloats - 248;        // 6,912
 constexpr int kCatHigh = kStageEnd;                        // 15,904: + k * kCatFloats for window k
 constexpr int cat_offset(int k, int group_n) { return k == group_n - 1 ? kCatLast : kCatHigh + k * kCatFloats; }
-// conv1d_17's split-K partial tiles (24 x 256 floats)
+// conv1d_17's split-K partial tiles: 96 of 256 floats (eight waves' eighths of the contraction x
+// four windows x three N tiles), over the dead images in three runs of 32 that keep clear of the
+// staging of the next group's samples and of slot 0 (the next window's first weights, on their way
+// in while the tiles are summed): tile i lies at red_tile_offset(i)
 constexpr int kRed = 0;
-constexpr int kRedFloats = 24 * 256;
-static_assert(kRed + kRedFloats <= kCatLast && kCatLast + kCatFloats <= kStage && (kCatLast * 4) % 16 == 0, "");
+constexpr int kRedFloats = 24 * 256;        // (where the batched tail's first weights begin)
+constexpr int kRedRun = 32 * 256;
+constexpr int kRedB = kStageEnd, kRedC = kW0 + kWinoHalf;
+constexpr int red_tile_offset(int i) {
+    return (i < 32 ? kRed : i < 64 ? kRedB - kRedRun : kRedC - 2 * kRedRun) + i * 256;
+}
+static_assert(kRed + kRedRun <= kStage && kRedB + kRedRun <= kW0 && kRedC + kRedRun <= kLdsFloatsAD, "");
+static_assert(kCatLast + kCatFloats <= kStage && (kCatLast * 4) % 16 == 0, "");
 // (the images are written behind a barrier at the chain's very end: they may lie on anything of its)
 static_assert(kCatHigh + (kGroup - 1) * kCatFloats <= kLdsFloatsAD && (kCatFloats * 4) % 16 == 0, "");
 constexpr int kLdsFloatsE = kDDummy + 312;

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 A=$1; B=$2; N=${3:-3}
 for i in $(seq $N); do
   for lib in $A $B; do
-    DEEPBINNER_HIP_LIB=$lib python $R/bench.py --no-cpu-baseline | python -c "
+    DEEPBINNER_HIP_LIB=$lib python $R/bench.py --no-cpu-baseline --no-other-configs --no-side-rates | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['avg_launch_ms']*1000,2), 'us', round(d['value']))"
   done
 done

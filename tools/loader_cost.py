@@ -4,7 +4,8 @@ resolve every read's chunk addresses, fetch the chunks as stored): process CPU t
 containers of 4,000 deflated reads written on the spot (bench.py's configs[4] containers), for a
 few team sizes, with the byte buffers in malloc'd and - where a GPU is there - in pinned memory.
 DEEPBINNER_FAST5_LIB=<another build> measures that build instead (an A/B of the loader alone);
-DEEPBINNER_FAST5_TIMING=1 makes the library print its own parse / resolve / fetch split.
+DEEPBINNER_FAST5_TIMING=1 makes the library print its own parse / resolve / fetch split;
+LOADER_COST_SAMPLES=lo,hi sets the reads' lengths (default 2000,9000: bench.py's containers).
 Usage: python tools/loader_cost.py [containers] [directory]  -> gpurun_out/loader_cost.json"""
 import json
 import os
@@ -24,10 +25,11 @@ from deepbinner_amd import fast5_native, hdf5_write          # noqa: E402
 
 
 def write_containers(directory, count, reads_per_container=4000):
+    lo, hi = (int(v) for v in os.environ.get('LOADER_COST_SAMPLES', '2000,9000').split(','))
     rng = np.random.default_rng(20260929)
     pool = []
     for _ in range(1000):
-        n = int(rng.integers(2000, 9000))
+        n = int(rng.integers(lo, hi))
         levels = np.repeat(rng.normal(450, 80, n // 8 + 1), 8)[:n]
         pool.append(np.clip(np.rint(levels + rng.normal(0, 8, n)), 0, 2047).astype(np.int16))
     with ThreadPoolExecutor(16) as workers:
