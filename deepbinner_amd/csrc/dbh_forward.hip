@@ -75,6 +75,11 @@
 #define DBH_TIMELINE 0
 #endif
 
+// where stage F's requests are made inside the chain: 0 = in front of conv1d_16's MFMAs, 1 = in
+// front of conv1d_15 (an experiment)
+#ifndef DBH_F_AHEAD_EARLY
+#define DBH_F_AHEAD_EARLY 0
+#endif
 namespace DBH_FORWARD_NS {
 using namespace dbh;
 
@@ -2228,6 +2233,10 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
     }
     __builtin_amdgcn_sched_barrier(0);
     mark(ts, 36);
+#if DBH_F_AHEAD_EARLY
+    ahead();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- conv15 -> the pair of conv16's input positions (48 channels: Y16[t][p] = channels 16t + 4q + r)
     f4 Y16[3][2];
     {
@@ -2292,7 +2301,9 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
         // barrier, which retires them
 #pragma unroll
         for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(U0[t]), "+v"(U1[t]), "+v"(U2[t]), "+v"(U3[t]));
+#if !DBH_F_AHEAD_EARLY
         ahead();
+#endif
     #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const f4 b = tab4[(bias_offset(15) - TB) / 4 + 4 * t];
@@ -3756,14 +3767,18 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[w4][t] = f4{0.f, 0.f, 0.f, 0.f};
+        // (all 36 operand pairs asked for at once: 72 registers the wave has to spare here, and no
+        // LDS round trip between the taps)
+        f2 a[3][kGroup][3];
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            f2 a[kGroup][3];
+        for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
             for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp)
-                    a[w4][sp] = *reinterpret_cast<const f2*>(a_lane[w4] + tap * kS192 + sp * 8);
+                    a[tap][w4][sp] = *reinterpret_cast<const f2*>(a_lane[w4] + tap * kS192 + sp * 8);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
@@ -3772,8 +3787,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                     for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
                         for (int t = 0; t < 3; ++t)
-                            acc[w4][t] = mfma4(a[w4][sp][e], w17[(tap * 3 + sp) * 3 + t][e], acc[w4][t]);
-            __builtin_amdgcn_sched_barrier(0);
+                            acc[w4][t] = mfma4(a[tap][w4][sp][e], w17[(tap * 3 + sp) * 3 + t][e], acc[w4][t]);
         }
         phase_add(5, f_since);
         mark(ts, 41);

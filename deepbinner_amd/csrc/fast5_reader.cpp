@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <pthread.h>
 #include <deque>
 #include <cerrno>
 #include <cstdio>
@@ -2999,6 +3000,9 @@ struct f5_stream {
     }
 
     void worker() {
+        // (a name an operator - and tools/gpu_inflate_split.py's CPU accounting - can tell from the
+        // interpreter's and the GPU runtime's threads)
+        pthread_setname_np(pthread_self(), "f5-stream");
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             Task t;

@@ -19,7 +19,7 @@ for i in $(seq $N); do
   for name in "$@"; do
     lib=$V/$name.so
     [ "$name" = base ] && lib=$R/deepbinner_amd/libdeepbinner_hip.so
-    DEEPBINNER_HIP_LIB=$lib timeout 120 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-rates 2>/dev/null | python -c "
+    DEEPBINNER_HIP_LIB=$lib timeout 120 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-rates --no-other-configs 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -64,26 +64,70 @@ def main():
     os.environ['DEEPBINNER_INFLATE_CUS'] = str(opts.cus)
     replicas, _ = realtime.inflate_queues(classify.device_replicas(sm, em), opts.share)
 
+    import threading
+    worker_cpu = [0.0]
+    lock = threading.Lock()
+
     def work(item, start_replica, end_replica):
+        c0 = time.thread_time()
         _, ids, offsets, _, comp, records = item
         calls, status = hip_backend.classify_pair_deflated(
             start_replica, end_replica, comp, records, offsets, 6144, 0.5)
         assert (status == 0).all()
+        with lock:
+            worker_cpu[0] += time.thread_time() - c0
         return len(calls)
 
-    best, best_cpu = 0.0, 0.0
+    # the CPU time of a pass, split: the threads that call the GPU (classify_pair_deflated: record
+    # tables, copies queued, the wait), the consumer thread (the stream's Python side + the
+    # dispatcher), and the rest of the process - the loader's team and the HIP runtime's own threads
+    # (tools/loader_cost.py has the loader's share alone)
+    # ... and by thread name, sampled from /proc while the passes run (a thread's last sample stands
+    # for it once it is gone): f5-stream = the loader's team (fast5_reader.cpp names it)
+    by_name, seen, stop_sampling = {}, {}, threading.Event()
+    ticks = os.sysconf('SC_CLK_TCK')
+
+    def sample():
+        while not stop_sampling.is_set():
+            for tid in os.listdir('/proc/self/task'):
+                try:
+                    with open('/proc/self/task/%s/stat' % tid) as f:
+                        text = f.read()
+                    name = text[text.index('(') + 1:text.rindex(')')]
+                    fields = text[text.rindex(')') + 2:].split()
+                    seen[tid] = (name, (int(fields[11]) + int(fields[12])) / ticks)
+                except (OSError, ValueError):
+                    pass
+            stop_sampling.wait(0.02)
+
+    sampler = threading.Thread(target=sample, daemon=True)
+    sampler.start()
+    total_done = 0
+    best, best_cpu, best_split = 0.0, 0.0, None
     for _ in range(opts.repeat + 1):
-        t0, c0 = time.perf_counter(), time.process_time()
+        worker_cpu[0] = 0.0
+        t0, c0, m0 = time.perf_counter(), time.process_time(), time.thread_time()
         stream = fast5_native.stream_raw(paths, threads=team, depth=len(replicas) + 2,
                                          host_inflate_above=-opts.share)
         done = sum(classify.dispatch_batches(stream, replicas, work))
-        wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+        wall, cpu, main_cpu = time.perf_counter() - t0, time.process_time() - c0, time.thread_time() - m0
+        total_done += done
         if done / wall > best:
             best, best_cpu = done / wall, cpu / done
+            best_split = {'gpu_call_threads': round(worker_cpu[0] / done * 1e6, 2),
+                          'consumer_thread': round(main_cpu / done * 1e6, 2),
+                          'loader_team_and_runtime_threads': round((cpu - worker_cpu[0] - main_cpu) / done * 1e6, 2)}
+    stop_sampling.set()
+    sampler.join()
+    for name, cpu_s in seen.values():
+        by_name[name] = by_name.get(name, 0.0) + cpu_s
+    by_name = {k: round(v / total_done * 1e6, 2) for k, v in sorted(by_name.items()) if v > 0}
+    print(json.dumps({'cpu_us_per_read_by_thread_name_all_passes_and_setup': by_name}), file=sys.stderr)
     print(json.dumps({'host_share_per_cent': opts.share, 'queues': len(replicas),
                       'cus_left_to_inflate': opts.cus, 'containers_per_pass': len(paths),
                       'forward_stream': os.environ.get('DEEPBINNER_FORWARD_STREAM', 'shared'), 'loader_threads': team,
-                      'reads_per_s': round(best), 'host_cpu_us_per_read': round(best_cpu * 1e6, 1)}))
+                      'reads_per_s': round(best), 'host_cpu_us_per_read': round(best_cpu * 1e6, 1),
+                      'host_cpu_us_per_read_split': best_split}))
 
 
 if __name__ == '__main__':
