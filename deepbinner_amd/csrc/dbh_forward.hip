@@ -615,6 +615,15 @@ __device__ __forceinline__ f2 pk_fma_relu(f2 k, f2 b, f2 c) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(k), "v"(b), "v"(c));
     return r;
 }
+// MaxPool of two values the kernel made itself: v_max_f32 as it is.  (fmaxf costs three: hipcc
+// canonicalises both operands first - `v_max_f32 x, x, x` - unless it can prove them quiet.)  Same
+// result for everything but a signalling NaN.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 max_raw2(f2 a, f2 b) { return f2{max_raw(a.x, b.x), max_raw(a.y, b.y)}; }
 // NB: the operands of these must come from instructions the compiler can see.  hipcc pads the
 // distance between an MFMA and the first VALU instruction that reads its result with s_nop, but
 // it does not look into inline asm: an accumulator read HERE straight after the MFMA chain (the
@@ -1400,8 +1409,8 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         w43t_outputs<h>(a, y);
         // (BN2 is folded into conv5's weights and bias by the packer - dbh_api.hip: pack_weights -
         // so the pooled values go to conv5 as they are; only the debug dump applies it)
-        X[g][h][0] = f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)};
-        X[g][h][1] = f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)};
+        X[g][h][0] = max_raw2(y[0], y[1]);
+        X[g][h][1] = max_raw2(y[2], y[3]);
         if (!DBH_FOLD_BN2) {
             const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(1) - kTabBn0)) / 4 + 4 * g];
             const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(1) - kTabBn0)) / 4 + 4 * g];
@@ -1921,8 +1930,8 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
         const f4 sc4 = tab4[((kTabBias1 - kTabBias0) + (bn_scale_offset(3) - kTabBn0)) / 4 + 4 * g];
         const f4 sh4 = tab4[((kTabBias1 - kTabBias0) + (bn_shift_offset(3) - kTabBn0)) / 4 + 4 * g];
         const f2 sc = h ? f2{sc4.z, sc4.w} : f2{sc4.x, sc4.y}, sh = h ? f2{sh4.z, sh4.w} : f2{sh4.x, sh4.y};
-        X[g][h][0] = __builtin_elementwise_fma(f2{fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y)}, sc, sh);
-        X[g][h][1] = __builtin_elementwise_fma(f2{fmaxf(y[2].x, y[3].x), fmaxf(y[2].y, y[3].y)}, sc, sh);
+        X[g][h][0] = __builtin_elementwise_fma(max_raw2(y[0], y[1]), sc, sh);
+        X[g][h][1] = __builtin_elementwise_fma(max_raw2(y[2], y[3]), sc, sh);
         if (dump3 != nullptr) {        // debug_stage 3 (wave-uniform): dense [64][48]
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
@@ -2092,7 +2101,7 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
     auto pooled_out = [&](f4& dst, int ch, f4 a, f4 b) {       // ReLU'd pair -> MaxPool2 -> BN5
         const f4 sc = bn5[ch / 4], sh = bn5[48 + ch / 4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[r] = fmaf(fmaxf(a[r], b[r]), sc[r], sh[r]);
+        for (int r = 0; r < 4; ++r) dst[r] = fmaf(max_raw(a[r], b[r]), sc[r], sh[r]);
         // (pinned: the result is used under a condition at the end of the block, and the compiler
         // sinks its whole computation there - keeping four raw accumulators alive per quadruple
         // instead of the quadruple: 87 spilled registers)
