@@ -77,6 +77,12 @@
 
 // where stage F's requests are made inside the chain: 0 = in front of conv1d_16's MFMAs, 1 = in
 // front of conv1d_15 (an experiment)
+// the next group's FIRST window staged and its statistics made under stage F like the other three
+// (1: +0.4 %), or carried in registers to that group's stage A (0: every wave summing and dividing
+// behind that stage's first barrier)
+#ifndef DBH_STATS0_IN_F
+#define DBH_STATS0_IN_F 1
+#endif
 #ifndef DBH_F_AHEAD_EARLY
 #define DBH_F_AHEAD_EARLY 0
 #endif
@@ -1764,6 +1770,7 @@ __device__ __forceinline__ void stage_b_chain(float* lds, const float* __restric
         U3[k] = Z[0][k] - row_from_right(hr[k], Z[0][k]);
     }
     // conv7's last third follows conv4's out of slot 2, once every wave has left its tile 2
+    // (asked for in front of the layer's first MFMAs instead: no difference, profiles/r06_steps)
     chain_check(lds, 2, pk_b, tiles0 + 24);
     dma_weights<kWinoHalf>(packed + weight_offset(6) + 2 * kWinoHalf, lds + kSlot2, lane, wave);
 #pragma unroll
@@ -2313,37 +2320,57 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
 #if !DBH_F_AHEAD_EARLY
         ahead();
 #endif
-    #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const f4 b = tab4[(bias_offset(15) - TB) / 4 + 4 * t];
+        // The fragments of a third of the contraction at a time (four 16-byte reads: twelve
+        // registers' worth less to hold beside this lane's 48 outputs), asked for ONE THIRD AHEAD
+        // from inline asm and waited for by count: as plain loads hipcc put each read and an
+        // lgkmcnt(0) right in front of the two to six MFMAs that use it - 36 exposed LDS round
+        // trips per wave (profiles/r06_steps).
+        const unsigned w16_addr = lds_addr(lds + kEW16 + lane * 4);
+        f4 wbuf[2][2][2];      // [parity][s2][pr]
+        auto ask = [&](auto it_tag) {
+            constexpr int IT = decltype(it_tag)::value;      // t * 3 + third_k
+            constexpr int T16 = IT / 3, TK = IT % 3;
+            wbuf[IT & 1][0][0] = ds_read_f4<(((T16 * 6 + 2 * TK + 0) * 2 + 0) * 256) * 4>(w16_addr);
+            wbuf[IT & 1][0][1] = ds_read_f4<(((T16 * 6 + 2 * TK + 0) * 2 + 1) * 256) * 4>(w16_addr);
+            wbuf[IT & 1][1][0] = ds_read_f4<(((T16 * 6 + 2 * TK + 1) * 2 + 0) * 256) * 4>(w16_addr);
+            wbuf[IT & 1][1][1] = ds_read_f4<(((T16 * 6 + 2 * TK + 1) * 2 + 1) * 256) * 4>(w16_addr);
+        };
+        f4 M0, M1, M2, M3;
+        f4 b16 = tab4[(bias_offset(15) - TB) / 4];
+        auto third_of = [&](auto it_tag, auto&& self) -> void {
+            constexpr int IT = decltype(it_tag)::value;
+            constexpr int T16 = IT / 3, TK = IT % 3;
+            if constexpr (IT + 1 < 9) {
+                ask(IntC<IT + 1>{});
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            f4(&wf)[2][2] = wbuf[IT & 1];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(wf[s2][0]), "+v"(wf[s2][1]));
             const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-            f4 M0, M1, M2, M3;
-            // (the fragments of a third of the contraction at a time: twelve registers' worth less
-            // to hold beside this lane's 48 outputs)
 #pragma unroll
-            for (int third_k = 0; third_k < 3; ++third_k) {
-                f4 wf[2][2];
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr)
-                        wf[s2][pr] = *reinterpret_cast<const f4*>(
-                            lds + kEW16 + ((t * 6 + 2 * third_k + s2) * 2 + pr) * 256 + lane * 4);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        // k-step 2 sp + e <-> channels 16 tc + 4q + r, sp = 2 third_k + s2
-                        const int tc = third_k, r = 2 * s2 + e;
-                        const bool first = third_k == 0 && s2 == 0 && e == 0;
-                        M0 = mfma4(wf[s2][0][e], U0[tc][r], first ? b : M0);
-                        M1 = mfma4(wf[s2][0][2 + e], U1[tc][r], first ? zero4 : M1);
-                        M2 = mfma4(wf[s2][1][e], U2[tc][r], first ? zero4 : M2);
-                        M3 = mfma4(wf[s2][1][2 + e], U3[tc][r], first ? -b : M3);
-                    }
+                for (int e = 0; e < 2; ++e) {
+                    // k-step 2 sp + e <-> channels 16 tc + 4q + r, sp = 2 third_k + s2
+                    constexpr int tc = TK;
+                    const int r = 2 * s2 + e;
+                    const bool first = TK == 0 && s2 == 0 && e == 0;
+                    M0 = mfma4(wf[s2][0][e], U0[tc][r], first ? b16 : M0);
+                    M1 = mfma4(wf[s2][0][2 + e], U1[tc][r], first ? zero4 : M1);
+                    M2 = mfma4(wf[s2][1][e], U2[tc][r], first ? zero4 : M2);
+                    M3 = mfma4(wf[s2][1][2 + e], U3[tc][r], first ? -b16 : M3);
                 }
-            pooled_out(OUT[3][t], 144 + 16 * t, relu4(M0 + M1 + M2), relu4(M1 - M2 - M3));
-        }
+            if constexpr (TK == 2) {
+                pooled_out(OUT[3][T16], 144 + 16 * T16, relu4(M0 + M1 + M2), relu4(M1 - M2 - M3));
+                if constexpr (T16 + 1 < 3) b16 = tab4[(bias_offset(15) - TB) / 4 + 4 * (T16 + 1)];
+            }
+            if constexpr (IT + 1 < 9) self(IntC<IT + 1>{}, self);
+        };
+        ask(IntC<0>{});
+        third_of(IntC<0>{}, third_of);
     }
     __builtin_amdgcn_sched_barrier(0);
     mark(ts, 40);
@@ -3414,7 +3441,20 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 window_mean_inv(lds, in_cnt, &mean, &inv);
             } else {
                 int cnt, pad;
-                if (k == 0) {
+                if (k == 0 && DBH_STATS0_IN_F) {
+                    // the group's first window was staged like the others (its statistics by wave 4
+                    // under the group before's stage F); the barrier publishes slot 0's weights
+                    // (asked for in that stage F) and keeps this group off the LDS that group's last
+                    // reads still use
+                    full_barrier();
+                    mark(ts, 51);
+                    thirds_mode = thirds_ahead ? 0 : 2;
+                    const float* st = lds + kStageStats;
+                    mean = reinterpret_cast<const double*>(st)[0];
+                    inv = reinterpret_cast<const double*>(st)[1];
+                    cnt = reinterpret_cast<const int*>(st)[4];
+                    pad = reinterpret_cast<const int*>(st)[5];
+                } else if (k == 0) {
                     // the group's first window came in registers (fetched under the last stage F of
                     // the group before): its samples go to the staging and its exact sums ride on
                     // the barrier that also publishes slot 0's weights (asked for in that stage F)
@@ -3841,7 +3881,7 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     mark(ts, 43);
     // the next group's windows 1 .. 3: samples to the staging, exact sums for the barrier below
 #pragma unroll
-    for (int w = 1; w < kGroup; ++w) {
+    for (int w = DBH_STATS0_IN_F ? 0 : 1; w < kGroup; ++w) {
         asm volatile("" : "+v"(nv0[w]), "+v"(nv1[w]));
         if (seam_b2 && w < next_n) {
             window_partial_sums(lds, ncnt[w], nv0[w], nv1[w], tid, lane, wave, w);
@@ -3862,29 +3902,36 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
         dma_weights<conv_weight_floats(18)>(packed + weight_offset(18), lds + kTW19, lane, wave);
         dma_weights<conv_weight_floats(19)>(packed + weight_offset(19), lds + kTW20, lane, wave);
     }
-    if (wave >= 5) {
+    if (wave >= (DBH_STATS0_IN_F ? 4 : 5)) {
         const int w = wave - 4;
         if (seam_b2 && w < next_n) {
             double mean, inv;
-            window_mean_inv(lds, ncnt[1], &mean, &inv, 1);
-            if (w == 2) window_mean_inv(lds, ncnt[2], &mean, &inv, 2);
-            if (w == 3) window_mean_inv(lds, ncnt[3], &mean, &inv, 3);
+            if (DBH_STATS0_IN_F) {
+                const int c = w == 0 ? ncnt[0] : w == 1 ? ncnt[1] : w == 2 ? ncnt[2] : ncnt[3];
+                window_mean_inv(lds, c, &mean, &inv, w);
+            } else {
+                window_mean_inv(lds, ncnt[1], &mean, &inv, 1);
+                if (w == 2) window_mean_inv(lds, ncnt[2], &mean, &inv, 2);
+                if (w == 3) window_mean_inv(lds, ncnt[3], &mean, &inv, 3);
+            }
             float* st = lds + kStageStats + w * 8;
             if (lane == 0) {
                 reinterpret_cast<double*>(st)[0] = mean;
                 reinterpret_cast<double*>(st)[1] = inv;
-                reinterpret_cast<int*>(st)[4] = w == 1 ? ncnt[1] : w == 2 ? ncnt[2] : ncnt[3];
-                reinterpret_cast<int*>(st)[5] = w == 1 ? npad[1] : w == 2 ? npad[2] : npad[3];
+                reinterpret_cast<int*>(st)[4] = w == 0 ? ncnt[0] : w == 1 ? ncnt[1] : w == 2 ? ncnt[2] : ncnt[3];
+                reinterpret_cast<int*>(st)[5] = w == 0 ? npad[0] : w == 1 ? npad[1] : w == 2 ? npad[2] : npad[3];
             }
         }
     }
     phase_add(8, f_since);
     mark_realtime(ts, 63);
     phase_stamp(3);
-    carry_cnt = ncnt[0];
-    carry_pad = npad[0];
-    carry_v0 = nv0[0];
-    carry_v1 = nv1[0];
+    if (!DBH_STATS0_IN_F) {
+        carry_cnt = ncnt[0];
+        carry_pad = npad[0];
+        carry_v0 = nv0[0];
+        carry_v1 = nv1[0];
+    }
 
     // ---------------- stages G + H for the batch: conv18, conv19 (+ MaxPool + BN7), conv20 (1x1 ->
     // classes) + ReLU + GlobalAveragePool + Softmax (+ renormalise + call), one wave per window ---
