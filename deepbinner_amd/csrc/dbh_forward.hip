@@ -2121,12 +2121,12 @@ __device__ __forceinline__ void stage_d_chain(float* lds, const float* __restric
     f4 Z3[2], Z4[2];
     {
         f2 w12[6], w14[6];
+        const f4 b12 = tab4[(bias_offset(11) - TB) / 4], b14 = tab4[(bias_offset(13) - TB) / 4];
 #pragma unroll
         for (int sp = 0; sp < 6; ++sp) {
             w12[sp] = *reinterpret_cast<const f2*>(lds + kEW12 + sp * 128 + lane * 2);
             w14[sp] = *reinterpret_cast<const f2*>(lds + kEW14 + sp * 128 + lane * 2);
         }
-        const f4 b12 = tab4[(bias_offset(11) - TB) / 4], b14 = tab4[(bias_offset(13) - TB) / 4];
 #pragma unroll
         for (int sp = 0; sp < 6; ++sp)
 #pragma unroll
@@ -3807,27 +3807,41 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
     {
         // stride-2 'same' pads on the right only: output position n reads rows 2n, 2n + 1, 2n + 2 of
         // the image's rows 1 .. 32 (+ the zero row 33)
-        const float* a_lane[kGroup];
+        unsigned a_addr[kGroup];
 #pragma unroll
         for (int w4 = 0; w4 < kGroup; ++w4)
-            a_lane[w4] = lds + cat_offset(w4 < group_n ? w4 : 0, group_n) + (1 + 2 * n) * kS192 + 2 * q + wave * 24;
+            a_addr[w4] = lds_addr(lds + cat_offset(w4 < group_n ? w4 : 0, group_n) + (1 + 2 * n) * kS192 + 2 * q + wave * 24);
         f4 acc[kGroup][3];
 #pragma unroll
         for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[w4][t] = f4{0.f, 0.f, 0.f, 0.f};
-        // (all 36 operand pairs asked for at once: 72 registers the wave has to spare here, and no
-        // LDS round trip between the taps)
-        f2 a[3][kGroup][3];
+        // the twelve operand pairs of a tap (four windows x three channel groups of eight) are asked
+        // for ONE TAP AHEAD from inline asm and waited for by count (as plain loads hipcc put sixteen
+        // reads with an lgkmcnt(0) each in front of their first MFMAs)
+        f2 a[2][kGroup][3];
+        auto ask_tap = [&](auto tap_tag) {
+            constexpr int TAP = decltype(tap_tag)::value;
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+            for (int w4 = 0; w4 < kGroup; ++w4) {
+                a[TAP & 1][w4][0] = ds_read_f2<(TAP * kS192 + 0) * 4>(a_addr[w4]);
+                a[TAP & 1][w4][1] = ds_read_f2<(TAP * kS192 + 8) * 4>(a_addr[w4]);
+                a[TAP & 1][w4][2] = ds_read_f2<(TAP * kS192 + 16) * 4>(a_addr[w4]);
+            }
+        };
+        auto run_tap = [&](auto tap_tag) {
+            constexpr int TAP = decltype(tap_tag)::value;
+            if constexpr (TAP + 1 < 3) {
+                ask_tap(IntC<TAP + 1>{});
+                asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            f2(&at)[kGroup][3] = a[TAP & 1];
 #pragma unroll
             for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    a[tap][w4][sp] = *reinterpret_cast<const f2*>(a_lane[w4] + tap * kS192 + sp * 8);
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
+                for (int sp = 0; sp < 3; ++sp) asm volatile("" : "+v"(at[w4][sp]));
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
@@ -3836,8 +3850,12 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                     for (int w4 = 0; w4 < kGroup; ++w4)
 #pragma unroll
                         for (int t = 0; t < 3; ++t)
-                            acc[w4][t] = mfma4(a[tap][w4][sp][e], w17[(tap * 3 + sp) * 3 + t][e], acc[w4][t]);
-        }
+                            acc[w4][t] = mfma4(at[w4][sp][e], w17[(TAP * 3 + sp) * 3 + t][e], acc[w4][t]);
+        };
+        ask_tap(IntC<0>{});
+        run_tap(IntC<0>{});
+        run_tap(IntC<1>{});
+        run_tap(IntC<2>{});
         phase_add(5, f_since);
         mark(ts, 41);
         lds_barrier();         // every wave has read the images: the partial tiles go over them
