@@ -3096,6 +3096,11 @@ int f5_stream_open(const char* const* paths, int64_t n_paths, int64_t keep, int 
 int f5_stream_open_raw(const char* const* paths, int64_t n_paths, int n_threads, int depth,
                        int64_t host_inflate_above, f5_stream** out) {
     f5_stream* s = nullptr;
+    // A raw container is little work per read (no inflating) behind a serial start (one thread
+    // opens and parses it: 5-6 ms of the ~30 ms of CPU a container of 4,000 reads costs): a window
+    // of three starves a team of sixteen - 1.2 M reads/s where eight in flight give 1.7 M and
+    // sixteen 1.9 M (profiles/r06_loader).  Default: half the team, between 3 and 8.
+    if (depth <= 0) depth = std::max(3, std::min(8, thread_count(n_threads) / 2));
     // (opened without a team first, so that the mode is set before any thread looks at it)
     const int st = f5_stream_open(paths, 0, 0, 1, depth, &s);
     if (st != F5_OK) return st;

@@ -5,7 +5,8 @@ containers of 4,000 deflated reads written on the spot (bench.py's configs[4] co
 few team sizes, with the byte buffers in malloc'd and - where a GPU is there - in pinned memory.
 DEEPBINNER_FAST5_LIB=<another build> measures that build instead (an A/B of the loader alone);
 DEEPBINNER_FAST5_TIMING=1 makes the library print its own parse / resolve / fetch split;
-LOADER_COST_SAMPLES=lo,hi sets the reads' lengths (default 2000,9000: bench.py's containers).
+LOADER_COST_SAMPLES=lo,hi sets the reads' lengths (default 2000,9000: bench.py's containers),
+LOADER_COST_DEPTH the containers in flight (default 4).
 Usage: python tools/loader_cost.py [containers] [directory]  -> gpurun_out/loader_cost.json"""
 import json
 import os
@@ -55,7 +56,7 @@ def measure(paths, threads, repeats=5):
     best = None
     for _ in range(repeats):
         t0, c0, reads, comp_bytes = time.perf_counter(), time.process_time(), 0, 0
-        for item in fast5_native.stream_raw(paths, threads=threads, depth=4):
+        for item in fast5_native.stream_raw(paths, threads=threads, depth=int(os.environ.get('LOADER_COST_DEPTH', '4'))):
             reads += len(item[1])
             comp_bytes += len(item[4])
         cpu, wall = time.process_time() - c0, time.perf_counter() - t0
