@@ -83,6 +83,11 @@
 #ifndef DBH_STATS0_IN_F
 #define DBH_STATS0_IN_F 1
 #endif
+// stage D's operands of the earlier windows asked for behind conv7's mid-layer barrier (1: +0.13 %,
+// the group's last conv7 12.9 k -> 12.0 k cycles) or behind its last MFMAs (0)
+#ifndef DBH_Y_EARLY
+#define DBH_Y_EARLY 1
+#endif
 #ifndef DBH_F_AHEAD_EARLY
 #define DBH_F_AHEAD_EARLY 0
 #endif
@@ -3648,8 +3653,16 @@ __global__ __launch_bounds__(kThreads, 2) void dbh_forward_kernel(ForwardArgs by
                 constexpr int G = decltype(tag)::value;
                 if constexpr (G < 3) third_step(packed + weight_offset(7), lds + kDS0, G);
                 else if constexpr (G < 6) third_step(packed + weight_offset(7) + kWinoHalf, lds + kDS1, G - 3);
+#if DBH_Y_EARLY
+                if constexpr (G == 6)
+                    d_load_y(Y, (const float*)(wg_scratch + kWgPark7Off + (wave >> 1) * kPark7Floats +
+                                               (wave & 1) * 3072 + lane * 4));
+#endif
             },
             [&]() -> bool {
+#if DBH_Y_EARLY
+                return true;
+#endif
                 // (every wave: the two that own the last window load what their park holds - stale -
                 // and overwrite it below.  Loaded under a condition the registers would count as
                 // live around the whole persistent loop - on the path that takes neither branch -
