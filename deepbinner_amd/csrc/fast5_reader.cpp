@@ -2714,6 +2714,7 @@ struct f5_stream {
     bool raw = false;                // hand out the Signal pieces as stored (f5_stream_open_raw)
     int64_t zlib_above = 0;          // ... except deflate streams longer than this: host-inflated
     int host_share = 0;              // ... and the longest ones holding this share (%) of the bytes
+    static constexpr int64_t kLongStreamBytes = 64 * 1024;
     std::mutex m;
     std::condition_variable work_cv, done_cv;
     std::deque<std::unique_ptr<Container>> inflight;      // in path order
@@ -2852,8 +2853,14 @@ struct f5_stream {
                             }
                 std::sort(sizes.begin(), sizes.end(), std::greater<int64_t>());
                 int64_t cut = INT64_MAX, taken = 0;
+                // ... of a container of ORDINARY reads.  Where the streams are long throughout
+                // (mean above kLongStreamBytes: reads of ~50 k samples and more) the host keeps
+                // none: a 200 KB stream is 0.6 ms of a core, and with a wavefront per stream the GPU
+                // decodes such containers alone at 134 k reads/s where a fifth of the bytes on the
+                // host's sixteen threads made it 54 k (profiles/r06_loader).
+                const bool long_streams = !sizes.empty() && all / (int64_t)sizes.size() > kLongStreamBytes;
                 for (int64_t v : sizes) {
-                    if (taken * 100 >= all * host_share) break;
+                    if (long_streams || taken * 100 >= all * host_share) break;
                     taken += v;
                     cut = v;
                 }

@@ -45,6 +45,28 @@ PER_PASS = {'single': 20000, 'multi': 5}       # reference realtime.py:86-94
 # one that finds its CU taken simply takes fewer (while they walked fixed shares, 32 were).
 INFLATE_QUEUES = 3
 INFLATE_CUS = 0
+# ... unless the streams are LONG (a stream is one wave's sequential work in the inflate kernels: a
+# container of 1,000 reads of ~100 k samples keeps a quarter of the wave slots 4,000 ordinary reads do,
+# each for four times as long, and the forward kernel on every CU starves them): a container whose
+# zlib streams average more than LONG_STREAM_BYTES leaves LONG_STREAM_CUS CUs out of its forward
+# launches for the inflate kernels of the containers behind it - 139 k reads/s instead of 115 k on such
+# containers, the host inflating nothing; ordinary containers (34 KB streams) are best at 0 (209 k
+# against 199 k at 32: profiles/r06_loader/long_reads_cu_sweep.txt).  DEEPBINNER_INFLATE_CUS overrides.
+LONG_STREAM_BYTES = 64 * 1024
+LONG_STREAM_CUS = 64
+
+
+def inflate_cus_for(comp_bytes, modes):
+    """CUs a container with these raw records (their ``comp_bytes`` and ``mode``) leaves to the
+    inflate kernels, or None where DEEPBINNER_INFLATE_CUS has said it already."""
+    if os.environ.get('DEEPBINNER_INFLATE_CUS') is not None:
+        return None
+    total = count = 0
+    for size, mode in zip(comp_bytes, modes):
+        if mode == 0:                   # fast5_native.RAW_ZLIB
+            total += int(size)
+            count += 1
+    return LONG_STREAM_CUS if count and total / count > LONG_STREAM_BYTES else INFLATE_CUS
 
 
 def host_inflate_share(n_gpus):
@@ -368,6 +390,11 @@ class Session:
         import numpy as np
         from . import fast5_native, hip_backend
         number, path, ids, offsets, comp, records = item
+        cus = inflate_cus_for(records['comp_bytes'].tolist(), records['mode'].tolist())
+        if cus is not None:
+            for model in (start_replica, end_replica):
+                if model is not None:
+                    model.reserve_cus(cus)
         result = hip_backend.classify_pair_deflated(
             start_replica, end_replica, comp, records, offsets, int(self.args.scan_size),
             self.args.score_diff, classify.combine_mode(self.args) if start_replica is not None and

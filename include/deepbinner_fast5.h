@@ -111,7 +111,8 @@ void f5_stream_close(f5_stream* stream);
  *     filters beyond deflate / fletcher32 - inflated and unshuffled by the host after all - and
  *     the deflate streams the host is to keep: those longer than host_inflate_above bytes, or,
  *     with host_inflate_above = -p (1..100), the longest ones of each container holding p per
- *     cent of its compressed bytes; 0: none).  `reserved` = the
+ *     cent of its compressed bytes - none in a container whose deflate streams average more than
+ *     64 KiB: long reads throughout are the GPU's alone; 0: none).  `reserved` = the
  *     index of the read the piece belongs to.  Layout identical to dbh_inflate_stream.
  * depth <= 0: half the team, between 3 and 8 (a raw container is ~30 ms of CPU behind a serial
  * 5-6 ms of parsing: three in flight starve sixteen threads). */

@@ -389,6 +389,40 @@ def test_raw_stream_of_containers(tmp_path):
     assert list(fast5_native.stream_raw([])) == []
 
 
+def test_the_host_keeps_no_share_of_a_container_of_long_streams(tmp_path):
+    """host_inflate_above = -p: the host inflates the longest streams holding p per cent of an
+    ordinary container's bytes - and none of a container whose streams average more than 64 KiB
+    (long reads throughout are left to the GPU's decoder: profiles/r06_loader)."""
+    import uuid
+    import zlib
+    from deepbinner_amd import hdf5_write
+    rng = np.random.default_rng(11)
+
+    def container(path, n_reads, samples):
+        reads = []
+        for k in range(n_reads):
+            n = samples + 100 * k
+            levels = np.repeat(rng.normal(450, 80, n // 8 + 1), 8)[:n]
+            sig = np.clip(np.rint(levels + rng.normal(0, 8, n)), 0, 2047).astype(np.int16)
+            reads.append((str(uuid.UUID(int=k + 1)), sig, None, zlib.compress(sig.tobytes(), 1)))
+        with open(path, 'wb') as f:
+            f.write(hdf5_write.multi_read_fast5_bytes(reads))
+
+    short, long_ = str(tmp_path / 'short.fast5'), str(tmp_path / 'long.fast5')
+    container(short, 12, 9000)
+    container(long_, 6, 70000)
+    kept = {}
+    for index, ids, offsets, status, comp, records in fast5_native.stream_raw(
+            [short, long_], threads=2, host_inflate_above=-50):
+        assert (np.asarray(status) == 0).all()
+        kept[index] = int((records['mode'] == fast5_native.RAW_STORED).sum())
+        want = fast5_native.load_reads([short, long_][index], threads=1)
+        assert np.array_equal(decode_raw_batch(offsets, comp, records), want[1])
+        z = records[records['mode'] == fast5_native.RAW_ZLIB]['comp_bytes']
+        assert index == 0 or z.mean() > 64 * 1024
+    assert kept[0] > 0 and kept[1] == 0
+
+
 def test_sample_buffers_are_recycled_and_can_come_from_the_caller():
     """The packed samples of a batch come from a pool of recycled buffers, or from an allocator
     the caller installs (pinned host memory on a GPU box; here: counted malloc)."""

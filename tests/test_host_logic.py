@@ -560,3 +560,17 @@ def test_queue_clones_hold_no_cycle_and_follow_their_partner():
     finally:
         gc.enable()
     assert Fake.live == 1       # `end` itself
+
+
+def test_long_streams_leave_cus_to_the_inflate_kernels(monkeypatch):
+    """realtime.inflate_cus_for: a container of long zlib streams takes CUs out of its forward
+    launches, an ordinary one none; stored pieces do not count; the environment has the last word."""
+    from deepbinner_amd import realtime
+    monkeypatch.delenv('DEEPBINNER_INFLATE_CUS', raising=False)
+    assert realtime.inflate_cus_for([34000] * 10, [0] * 10) == realtime.INFLATE_CUS
+    assert realtime.inflate_cus_for([124000] * 10, [0] * 10) == realtime.LONG_STREAM_CUS
+    assert realtime.inflate_cus_for([124000] * 10 + [10 ** 7], [0] * 10 + [1]) == realtime.LONG_STREAM_CUS
+    assert realtime.inflate_cus_for([10 ** 7], [1]) == realtime.INFLATE_CUS
+    assert realtime.inflate_cus_for([], []) == realtime.INFLATE_CUS
+    monkeypatch.setenv('DEEPBINNER_INFLATE_CUS', '16')
+    assert realtime.inflate_cus_for([124000] * 10, [0] * 10) is None
