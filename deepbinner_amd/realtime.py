@@ -52,6 +52,7 @@ INFLATE_CUS = 0
 # launches for the inflate kernels of the containers behind it - 139 k reads/s instead of 115 k on such
 # containers, the host inflating nothing; ordinary containers (34 KB streams) are best at 0 (209 k
 # against 199 k at 32: profiles/r06_loader/long_reads_cu_sweep.txt).  DEEPBINNER_INFLATE_CUS overrides.
+HOST_ONLY_CORES_PER_GPU = 30
 LONG_STREAM_BYTES = 64 * 1024
 LONG_STREAM_CUS = 64
 
@@ -75,16 +76,14 @@ def host_inflate_share(n_gpus):
     loader path), 0 = everything on the GPUs.  DEEPBINNER_GPU_INFLATE=0 / =1 force either end,
     DEEPBINNER_HOST_INFLATE_SHARE=<per cent> any split.
 
-    Left alone: what the host's cores can do beside their other work while a GPU classifies at
-    the rate it reaches with the inflate kernels running beside the forward kernel.  Measured
-    (profiles/r05_k2/forward_stream_sweep_64_containers.txt; 27 k-sample reads, gzip 1, 16 loader
-    threads, three containers in flight, one forward launch at a time): the host spends ~18 us per
-    read on everything but inflating and ~1.0 us more per per cent of the bytes it inflates; a GPU
-    settles at 203-207 k reads/s for any share between 20 and 50, and at 195 k with no help at all
-    - so the host takes what four fifths of its cores manage at 200 k reads/s (16 cores, one GPU:
-    46 %; 30 cores per GPU and more: everything, and the inflate kernels are not used at all; a
-    16-core host in front of eight GPUs - BASELINE.json configs[4] - nothing: there the GPUs
-    inflate every stream)."""
+    Left alone: all or nothing.  Measured with round 6's kernels (profiles/r06_loader/
+    long_reads_cu_sweep.txt and host_share_ordinary.txt; 27 k-sample reads, gzip 1, 16 loader
+    threads, three containers in flight): a GPU alone settles at 209-210 k reads/s for 17 us of host
+    CPU per read; with the host's threads taking 20 % of the bytes 205 k for 39 us, with 46 % (what
+    round 5's rule gave this box, when the help was worth +5 %) 199-202 k for 66 us.  So the GPUs
+    inflate every stream - unless the host has cores to spare (30 per GPU and more: the CPU-only
+    loader path is as fast and the inflate kernels are not used at all).  A 16-core host in front
+    of eight GPUs - BASELINE.json configs[4] - nothing either way."""
     flag = os.environ.get('DEEPBINNER_GPU_INFLATE')
     if flag == '0':
         return 100
@@ -94,8 +93,7 @@ def host_inflate_share(n_gpus):
     if explicit:
         return max(0, min(100, int(explicit)))
     cores, gpus = float(usable_cpus()), float(max(n_gpus, 1))
-    budget_us = 0.8 * cores / gpus / 200e3 * 1e6           # host time per read at the GPU's rate
-    return int(round(max(0.0, min(100.0, (budget_us - 18.0) / 1.0))))
+    return 100 if cores / gpus >= HOST_ONLY_CORES_PER_GPU else 0
 
 
 def queue_clones(pair, n_more):

@@ -487,8 +487,8 @@ def test_usable_cpus_is_a_sane_number():
 
 def test_host_inflate_share_follows_the_cores_per_gpu(monkeypatch):
     """How much of the inflating the host keeps (realtime.host_inflate_share): everything when it
-    has cores to spare, nothing when eight GPUs hang off sixteen cores, in between in between;
-    the environment overrides either way."""
+    has cores to spare (30 per GPU), nothing otherwise - a split has not paid since round 6's
+    kernels; the environment overrides either way."""
     import deepbinner_amd.realtime as realtime
     for name in ('DEEPBINNER_GPU_INFLATE', 'DEEPBINNER_HOST_INFLATE_SHARE'):
         monkeypatch.delenv(name, raising=False)
@@ -498,7 +498,8 @@ def test_host_inflate_share_follows_the_cores_per_gpu(monkeypatch):
         shares.append(realtime.host_inflate_share(1))
         assert realtime.host_inflate_share(8) <= shares[-1]
     assert shares == sorted(shares) and shares[0] == 0 and shares[-1] == 100
-    assert 40 <= shares[3] <= 70                     # 16 cores, one GPU: the box it was measured on
+    assert set(shares) == {0, 100} and shares[3] == 0     # 16 cores, one GPU: the box it was measured on
+    assert shares[5] == 100                               # 32 cores for one GPU: the host alone
     monkeypatch.setattr(realtime, 'usable_cpus', lambda: 16)
     assert realtime.host_inflate_share(8) == 0       # BASELINE.json configs[4]: one host, eight GPUs
     monkeypatch.setenv('DEEPBINNER_HOST_INFLATE_SHARE', '37')
