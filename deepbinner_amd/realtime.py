@@ -53,6 +53,7 @@ INFLATE_CUS = 0
 # containers, the host inflating nothing; ordinary containers (34 KB streams) are best at 0 (209 k
 # against 199 k at 32: profiles/r06_loader/long_reads_cu_sweep.txt).  DEEPBINNER_INFLATE_CUS overrides.
 HOST_ONLY_CORES_PER_GPU = 30
+RAW_LOADER_THREADS_PER_GPU = 4
 LONG_STREAM_BYTES = 64 * 1024
 LONG_STREAM_CUS = 64
 
@@ -373,9 +374,15 @@ class Session:
     # host has few cores per GPU - and dbh_classify_pair_deflated does the
     # rest.  The host's threads keep the longest streams of every container (a lane of the GPU
     # decoder walks ONE stream, however long): `host_inflate_share` of the bytes.
-    def _raw_containers(self, fast5s, host_share):
+    def _raw_containers(self, fast5s, host_share, n_gpus=1):
         from . import fast5_native
         threads = int(getattr(self.args, 'loader_procs', 0) or 0)
+        if threads <= 0 and host_share == 0:
+            # nothing to inflate: a read costs a loader thread ~5 us, and a GPU takes ~210 k a second -
+            # two threads feed it, sixteen cost the process 19 us of CPU per read instead of 13
+            # (woken sixteen times per container for a fifth of what they can deliver:
+            # profiles/r06_loader/loader_team_size.txt)
+            threads = min(usable_cpus(), RAW_LOADER_THREADS_PER_GPU * max(1, n_gpus))
         stream = fast5_native.stream_raw(fast5s, threads=threads, host_inflate_above=-host_share,
                                          depth=int(os.environ.get('DEEPBINNER_LOADER_DEPTH', 0)))
         for index, ids, offsets, status, comp, records in stream:
@@ -477,7 +484,8 @@ class Session:
         host_share = host_inflate_share(len({getattr(r[0] or r[1], 'device', 0) for r in replicas}))
         queues = []
         if packed and host_share < 100 and all(hasattr(m, 'handle') for m in models):
-            items = self._raw_containers(fast5s, host_share)
+            items = self._raw_containers(
+                fast5s, host_share, len({getattr(r[0] or r[1], 'device', 0) for r in replicas}))
             work = self._classify_raw_container
             replicas, queues = inflate_queues(replicas, host_share)
         elif packed:
